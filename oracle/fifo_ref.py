@@ -1,0 +1,128 @@
+"""Oracle: FIFO diagonal-denoising queue (host algorithm) — TEST INFRASTRUCTURE ONLY.
+
+Restates longvgen/fifo_sampling/cogvideo_sampling_mp_fifo.py:27-395 (driver) and :408-579 (worker
+body) as single-process functions with the denoiser and the noise source injected.
+"""
+import numpy as np
+import torch
+
+from . import scheduler_ref as S
+
+
+def window_plan(queue_start, nf=13, num_partitions=4):
+    """Window geometry for one FIFO iteration, cogvideo_sampling_mp_fifo.py:235-253.
+
+    Returns list of dicts(rank,start,mid,end,real_end) for the windows that run."""
+    r = nf // 2
+    l = nf - r
+    out = []
+    for rank in range(2 * num_partitions):
+        start = nf * (rank // 2) + r * (rank % 2)
+        nxt = nf * ((rank + 1) // 2) + r * ((rank + 1) % 2)
+        if nxt <= queue_start:
+            continue
+        mid = start + (l if rank % 2 == 1 else r)
+        real_end = start + nf
+        start = max(start, queue_start)
+        out.append(dict(rank=rank, start=start, mid=mid, end=start + nf, real_end=real_end))
+    return out
+
+
+def keep_slice(w, queue_start, nf=13):
+    """Which queue positions a finished window writes back, :322-329. Returns (q_lo, q_hi, local_lo)."""
+    r = nf // 2
+    if w["start"] > queue_start:
+        return w["mid"], w["end"], w["mid"] - w["start"]
+    lo = max(r, w["start"])
+    return lo, w["real_end"], max(r - w["start"], 0)
+
+
+def timestep_tables(timesteps, nf=13):
+    """Per-queue-position (t, prev_t, next_t), already flipped to ascending-noise order, :182-185,255-257."""
+    r = nf // 2
+    ts = np.asarray(timesteps, dtype=np.int64)
+    t = np.concatenate([ts, np.full(r, ts[-1])])[::-1].copy()
+    prev_t = np.concatenate([ts[1:], np.full(r + 1, -1)])[::-1].copy()
+    next_t = np.concatenate([[-1], ts[:-1], np.full(r, ts[-2])])[::-1].copy()
+    return t, prev_t, next_t
+
+
+def grid_t_tables(grid_t, cond_t, T, nf=13, vip_nf=4):
+    """vip RoPE time bookkeeping, :84-99. Returns (queue_grid_t[T+r], grid_t_feed, cond_t_extended)."""
+    r = nf // 2
+    grid_t = np.asarray(grid_t, dtype=np.float32)
+    init = np.concatenate([grid_t[[0]]] * (r + T - nf) + [grid_t[:nf]])
+    feed = np.concatenate([grid_t[nf:], np.linspace(grid_t[-1] + 1, grid_t[-1] + 1 + T, T, endpoint=False,
+                                                   dtype=np.float32)])
+    cond = [np.asarray(cond_t)]
+    for i in range(T // nf + 1):
+        cond.append(np.asarray(cond_t)[-vip_nf:] + (i + 1) * nf)
+    return init, feed, np.concatenate(cond)
+
+
+def find_embed_index(cond_t, pos, start_frame_idx):
+    """:110-115."""
+    return int(np.searchsorted(cond_t, pos + start_frame_idx, side="right") - 1)
+
+
+def window_step(denoise, ac, guidance_scale, latents, old_x0, t, prev_t, next_t, draw, out_dtype):
+    """Worker body :491-550: CFG-batched denoiser call, CFG combine, 13 per-frame DPM steps.
+
+    denoise(latent_in [2,nf,C,H,W], timesteps [2,nf]) -> [2,nf,C,H,W];
+    draw() -> next gaussian [1,1,C,H,W] (see scheduler_ref.dpm_step).  Returns (latents_out, x0 list)."""
+    nf = latents.shape[1]
+    inp = torch.cat([latents] * 2)
+    tt = torch.as_tensor(t)[None].expand(2, -1)
+    pred = S.cfg_combine(denoise(inp, tt), guidance_scale)
+    out = latents.clone()
+    x0s = []
+    for j in range(nf):
+        nxt = int(next_t[j]) if next_t[j] > 0 else None
+        x, x0 = S.dpm_step(ac, pred[:, [j]], old_x0[j], int(t[j]), int(prev_t[j]), nxt, latents[:, [j]], draw)
+        out[:, [j]] = x.to(out_dtype)
+        x0s.append(x0.to(out_dtype))
+    return out, x0s
+
+
+def run_fifo(denoise_window, betas, ac, fifo_latents, fifo_old_x0, timesteps, num_frames, guidance_scale,
+             grid_t, cond_t, start_frame_idx, step_noise, tail_noise, nf=13, vip_nf=4, num_partitions=4,
+             trace=None):
+    """Driver :27-367 (latent output).  denoise_window(latents[2,nf,...], timesteps[2,nf], grid_t_window,
+    cond_t_window, vip_start) -> [2,nf,...]; step_noise() -> next worker-side gaussian [1,1,C,H,W];
+    tail_noise() -> next driver-side gaussian [1,C,H,W].  Returns latents [1, num_frames, C,H,W] (first T-nf outputs discarded, :367)."""
+    T = len(timesteps)
+    r = nf // 2
+    l = nf - r
+    latents = torch.cat([fifo_latents[:, [0]]] * r + [fifo_latents], dim=1)
+    old_x0 = [fifo_old_x0[0]] * r + list(fifo_old_x0)
+    q_grid_t, feed, cond_ext = grid_t_tables(grid_t, cond_t, T, nf, vip_nf)
+    t_tab, p_tab, n_tab = timestep_tables(timesteps, nf)
+    queue_start = T - l
+    outs = []
+    for i in range(num_frames + T - nf):
+        new_lat = latents.clone()
+        new_x0 = list(old_x0)
+        for w in window_plan(queue_start, nf, num_partitions):
+            s, e = w["start"], w["end"]
+            vs = find_embed_index(cond_ext, q_grid_t[s], start_frame_idx)
+            n_c = min(vip_nf + 1, nf)
+            dn = lambda x, tt, _s=s, _e=e, _vs=vs: denoise_window(x, tt, q_grid_t[_s:_e].copy(),
+                                                                   cond_ext[_vs:_vs + n_c].copy(), _vs)
+            o_lat, o_x0 = window_step(dn, ac, guidance_scale, latents[:, s:e].clone(), old_x0[s:e],
+                                      t_tab[s:e], p_tab[s:e], n_tab[s:e], step_noise,
+                                      latents.dtype)
+            lo, hi, loc = keep_slice(w, queue_start, nf)
+            new_lat[:, lo:hi] = o_lat[:, loc:loc + (hi - lo)]
+            new_x0[lo:hi] = o_x0[loc:loc + (hi - lo)]
+            if trace is not None:
+                trace.append((i, w["rank"], s, w["mid"], e, w["real_end"], vs, lo, hi, loc))
+        latents, old_x0 = new_lat, new_x0
+        outs.append(latents[:, [r]].clone())
+        latents[:, :-1] = latents[:, 1:].clone()
+        old_x0 = old_x0[1:] + [None]
+        latents[:, -1] = S.add_noise_to_xt(betas, latents[:, -1], tail_noise()).to(latents.dtype)
+        q_grid_t[:-1] = q_grid_t[1:].copy()
+        q_grid_t[-1] = feed[0]
+        feed = feed[1:]
+        queue_start = max(0, queue_start - 1)
+    return torch.cat(outs[T - nf:], dim=1)

@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.pt by running the REFERENCE (/root/reference, imported through
+tools/ref_shim) on CPU with seeded inputs.  Run in the build container only:
+
+    python tools/make_golden.py [--full-block]
+
+Fixtures hold inputs/outputs (data), never reference source.  Weights are regenerated from seeds
+by oracle.dit_ref.make_state_dict (same torch build here and on the GPU box); a checksum of the
+weights is stored to detect RNG drift.
+"""
+import argparse
+import os
+import queue
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, ROOT)
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+from longvgen.models.cogvideox_transformer_3d import CogVideoXBlock, CogVideoXTransformer3DModel  # noqa: E402
+from longvgen.models.embeddings import get_3d_rotary_pos_embed, get_3d_rotary_pos_embed_v2  # noqa: E402
+from longvgen.schedulers.scheduling_dpm_cogvideox import CogVideoXDPMScheduler  # noqa: E402
+import importlib.util  # noqa: E402
+
+from oracle import dit_ref as O  # noqa: E402  (only for make_state_dict: seeded weights + names)
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+TINY = dict(num_attention_heads=2, attention_head_dim=64, num_layers=2, patch_size=2, time_embed_dim=64,
+            text_embed_dim=32, in_channels=16, out_channels=16)
+TINY_VIP = dict(length=5 * 2 * 3, func_type="1", scale=[0.6],
+                resampler_params=dict(output_dim=128, num_height_queries=2, num_width_queries=3,
+                                      num_temporal_queries=4))
+
+
+def load_ref_module(rel, name):
+    """Import one reference file without triggering its package __init__ (which needs more deps)."""
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ref_shim.REFERENCE_ROOT, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def sd_checksum(sd):
+    return float(sum(v.double().abs().sum() for v in sd.values()))
+
+
+def tiny_model(seed, vip=True, H=4, W=6):
+    m = CogVideoXTransformer3DModel(num_attention_heads=2, attention_head_dim=64, num_layers=2, in_channels=16,
+                                    out_channels=16, text_embed_dim=32, time_embed_dim=64, sample_width=W,
+                                    sample_height=H, sample_frames=49, use_rotary_positional_embeddings=True,
+                                    max_text_seq_length=8)
+    if vip:
+        m.set_vip_layers(None, **TINY_VIP)
+    sd = O.make_state_dict(TINY, n_vip_dim=128 if vip else None, seed=seed)
+    m.load_state_dict(sd, strict=True)
+    return m.eval(), sd
+
+
+def tiny_inputs(seed, B=2, H=4, W=6):
+    g = torch.Generator().manual_seed(seed)
+    return dict(hs=torch.randn(B, 13, 16, H, W, generator=g), enc=torch.randn(B, 8, 32, generator=g),
+                vip=torch.randn(B, 5, 128, 2, 3, generator=g), ts=torch.randint(0, 1000, (B, 13), generator=g))
+
+
+def tiny_ropes(H=4, W=6, t0=0.0):
+    f32 = np.float32
+    rope = get_3d_rotary_pos_embed(64, ((0, 0, 0), (13, H // 2, W // 2)), (13, H // 2, W // 2))
+    vrope = get_3d_rotary_pos_embed_v2(64, np.arange(13, dtype=f32) + f32(t0), np.arange(H // 2, dtype=f32),
+                                       np.arange(W // 2, dtype=f32))
+    crope = get_3d_rotary_pos_embed_v2(64, np.linspace(1000, 1016.25, 5, dtype=f32),
+                                       np.linspace(0, H // 2, 2, endpoint=False, dtype=f32),
+                                       np.linspace(0, W // 2, 3, endpoint=False, dtype=f32))
+    return rope, vrope, crope
+
+
+@torch.no_grad()
+def gen_dit_tiny():
+    out = {"cfg": TINY, "vip": TINY_VIP, "cases": []}
+    for seed in (0, 1):
+        m, sd = tiny_model(100 + seed)
+        inp = tiny_inputs(200 + seed)
+        rope, vrope, crope = tiny_ropes(t0=3.0 * seed)
+        for dt in (torch.float32, torch.bfloat16):
+            mm, _ = tiny_model(100 + seed)
+            mm = mm.to(dt)
+            for ts in (inp["ts"], inp["ts"][:, 0].clone()):
+                taps = {}
+                hooks = [blk.register_forward_hook(lambda mod, a, o, i=i: taps.__setitem__(f"block{i}.hidden", o[0].clone()))
+                         for i, blk in enumerate(mm.transformer_blocks) if i == 0]
+                y = mm(inp["hs"].to(dt), inp["enc"].to(dt), ts, vip_encoder_hidden_states=inp["vip"].to(dt),
+                       image_rotary_emb=rope, vip_image_rotary_emb=vrope, vip_condition_rotary_emb=crope,
+                       return_dict=False)[0]
+                for h in hooks:
+                    h.remove()
+                out["cases"].append(dict(weight_seed=100 + seed, input_seed=200 + seed, t0=3.0 * seed, dtype=str(dt),
+                                         ts=ts, out=y.clone(), taps={k: v.clone() for k, v in taps.items()},
+                                         sd_checksum=sd_checksum(sd)))
+        if seed == 0:
+            out["inputs0"] = inp
+            out["ropes0"] = dict(rope=rope, vrope=vrope, crope=crope)
+    # plain (no-vip) model: the T2To / base-model processor
+    m, sd = tiny_model(300, vip=False)
+    inp = tiny_inputs(301)
+    rope, _, _ = tiny_ropes()
+    y = m(inp["hs"], inp["enc"], inp["ts"][:, 0], image_rotary_emb=rope, return_dict=False)[0]
+    out["plain"] = dict(weight_seed=300, input_seed=301, out=y, sd_checksum=sd_checksum(sd))
+    torch.save(out, os.path.join(GOLD, "dit_tiny.pt"))
+    print("dit_tiny.pt", len(out["cases"]), "cases")
+
+
+@torch.no_grad()
+def gen_vip_processor():
+    """VIP attention processor alone (head_dim 64, 2 heads), with intermediate q/k/v and the three SDPAs."""
+    ap = sys.modules["longvgen.models.attention_processor"]
+    torch.manual_seed(7)
+    D, heads = 128, 2
+    attn = ap.Attention(query_dim=D, dim_head=64, heads=heads, qk_norm="layer_norm", eps=1e-6, bias=True,
+                        out_bias=True, processor=ap.CogVideoXAttnProcessor2_0())
+    proc = ap.VideoIPAdapterCogVideoXAttnProcessor2_0(heads=heads, cross_attention_dim=D, dim_head=64, eps=1e-6,
+                                                      scale=[0.6], qk_norm="layer_norm", bias=True, num_tokens=30)
+    attn.set_processor(proc)
+    for p in attn.parameters():
+        p.data = torch.randn_like(p) * (0.3 if p.ndim == 1 else 0.08)
+    Nt, Nv, Np = 8, 13 * 2 * 3, 30
+    hid = torch.randn(1, Nv, D)
+    enc = torch.randn(1, Nt + Np, D)
+    rope, vrope, crope = tiny_ropes()
+    captured = []
+    orig = ap.F.scaled_dot_product_attention
+
+    def spy(q, k, v, **kw):
+        o = orig(q, k, v, **kw)
+        captured.append(dict(q=q.clone(), k=k.clone(), v=v.clone(), o=o.clone()))
+        return o
+    ap.F.scaled_dot_product_attention = spy
+    try:
+        oh, oe = attn(hid, encoder_hidden_states=enc, image_rotary_emb=rope, vip_image_rotary_emb=vrope,
+                      vip_condition_rotary_emb=crope)
+    finally:
+        ap.F.scaled_dot_product_attention = orig
+    sd = {("attn1." + k): v.clone() for k, v in attn.state_dict().items()}
+    torch.save(dict(sd=sd, hid=hid, enc=enc, rope=rope, vrope=vrope, crope=crope, sdpa=captured, out_hidden=oh,
+                    out_enc=oe, scale=[0.6], heads=heads, n_vip=Np), os.path.join(GOLD, "vip_processor.pt"))
+    print("vip_processor.pt sdpa calls:", len(captured))
+
+
+def make_sched():
+    s = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0,
+                              timestep_spacing="trailing")
+    s.set_timesteps(52)
+    return s
+
+
+@torch.no_grad()
+def gen_scheduler():
+    s = make_sched()
+    ts = s.timesteps.clone()
+    out = dict(alphas_cumprod=s.alphas_cumprod.clone(), betas=s.betas.clone(), timesteps=ts, steps=[])
+    g = torch.Generator().manual_seed(5)
+    shape = (1, 1, 2, 2, 3)
+    triples = [(999, 980, None, False), (980, 961, 999, True), (500 - 1, 480, 518, True), (37, 18, 57, True),
+               (18, -1, 37, True), (18, -1, 37, False), (961, 941, 980, True), (999, 980, None, True)]
+    # every (t, prev_t, t_back) the FIFO uses is a consecutive triple of the 52 trailing steps (+ the edges above)
+    for i in range(1, 51):
+        triples.append((int(ts[i]), int(ts[i + 1]), int(ts[i - 1]), True))
+    for (t, pt, tb, has_old) in triples:
+        if t not in ts.tolist():
+            t = int(ts[(ts - t).abs().argmin()])
+        for dt in (torch.float32, torch.bfloat16):
+            mo = torch.randn(shape, generator=g).to(dt)
+            x = torch.randn(shape, generator=g).to(dt)
+            old = torch.randn(shape, generator=g).to(dt) if (has_old and tb is not None) else None
+            torch.manual_seed(1000 + t)
+            prev, x0 = s.step(mo, old, torch.tensor(t), torch.tensor(pt), None if tb is None else torch.tensor(tb), x,
+                              return_dict=False)
+            out["steps"].append(dict(t=t, prev_t=pt, t_back=tb, dtype=str(dt), model_output=mo, sample=x, old=old,
+                                     noise_seed=1000 + t, prev_sample=prev.clone(), x0=x0.clone()))
+    x = torch.randn(1, 2, 2, 3, generator=g)
+    n = torch.randn(1, 2, 2, 3, generator=g)
+    out["add_noise_to_xt"] = dict(x=x, noise=n, out=s.add_noise_to_xt(x, n, torch.Tensor([999]).long()))
+    torch.save(out, os.path.join(GOLD, "scheduler.pt"))
+    print("scheduler.pt", len(out["steps"]), "steps")
+
+
+@torch.no_grad()
+def gen_fifo(num_chunks=2, dtype=torch.float32, tag="fifo_tiny"):
+    """Run the reference driver cogvideo_fifo_mp_v2 end-to-end on CPU (1 forked worker) with the tiny DiT."""
+    fifo = load_ref_module("longvgen/fifo_sampling/cogvideo_sampling_mp_fifo.py", "ref_fifo")
+    import threading
+
+    class _ThreadProcess(threading.Thread):
+        """mp.Process stand-in: a forked torch worker deadlocks on CPU (OpenMP after fork), and the driver
+        blocks on the output queue while the worker runs, so a thread gives the same serial order — worker
+        and driver then share ONE global RNG stream, which the oracle test replays with one generator."""
+        def __init__(self, target, args):
+            super().__init__(target=target, args=args, daemon=True)
+
+        def close(self):
+            pass
+
+    fifo.mp = types.SimpleNamespace(Queue=queue.Queue, Process=_ThreadProcess)
+    H, W, nf, T = 4, 6, 13, 52
+    m, sd = tiny_model(400)
+    m = m.to(dtype)
+    sched = make_sched()
+    pipe = types.SimpleNamespace(
+        device=torch.device("cpu"), transformer=m, scheduler=sched, guidance_scale=6.0,
+        _prepare_vip_rotary_positional_embeddings=lambda grid_t, grid_h, grid_w, device:
+            get_3d_rotary_pos_embed_v2(64, grid_t, grid_h, grid_w))
+    g = torch.Generator().manual_seed(401)
+    fifo_latents = torch.randn(1, T, 16, H, W, generator=g).to(dtype)
+    # base stage pushes to the FRONT each step (pipeline_cogvideox_mp_fifo.py:1190-1194): entry 51 (noisiest) has no x0 yet
+    fifo_old = [torch.randn(1, 1, 16, H, W, generator=g).to(dtype) for _ in range(T - 1)] + [None]
+    prompt = torch.randn(2, 8, 32, generator=g).to(dtype)
+    n_groups = 4 * (num_chunks + 1)
+    image_embeddings = torch.randn(1, n_groups, 128, 2, 3, generator=g).to(dtype).repeat(2, 1, 1, 1, 1)
+    f32 = np.float32
+    grid_t = np.linspace(0, num_chunks * nf, num_chunks * nf, endpoint=False, dtype=f32)
+    grid_h = np.linspace(0, H // 2, H // 2, endpoint=False, dtype=f32)
+    grid_w = np.linspace(0, W // 2, W // 2, endpoint=False, dtype=f32)
+    cond_t = np.concatenate([np.linspace(1000 + i * nf, 1000 + (i + 1) * nf, 4, endpoint=False, dtype=f32)
+                             for i in range(num_chunks + 1)])
+    cond_h = np.linspace(0, H // 2, 2, endpoint=False, dtype=f32)
+    cond_w = np.linspace(0, W // 2, 3, endpoint=False, dtype=f32)
+    rope = get_3d_rotary_pos_embed(64, ((0, 0, 0), (nf, H // 2, W // 2)), (nf, H // 2, W // 2))
+    base = types.SimpleNamespace(
+        sampling_params=dict(use_adaptive_padding=True, num_partitions=4), fifo_latents=fifo_latents.clone(),
+        fifo_old_pred_original_sample=list(fifo_old), nf_per_chunk=nf, vip_nf_per_chunk=4, num_frames=num_chunks * nf,
+        image_embeddings=image_embeddings, timesteps=sched.timesteps, num_inference_steps=T,
+        do_classifier_free_guidance=True, use_separate_guidance=False, use_dynamic_cfg=False, prompt_embeds=prompt,
+        image_rotary_emb=rope, vip_image_rotary_grid=[grid_t.copy(), grid_h, grid_w],
+        vip_condition_rotary_grid=[cond_t.copy(), cond_h, cond_w], attention_kwargs=None, guidance_scale=6.0,
+        guidance_scale_img=None, extra_step_kwargs={}, cache_idx=[], condition_frames=None,
+        video_ipadapter_start_frame_idx=1000, output_type="latent", return_dict=False,
+        orig_latents=fifo_latents[:, :nf].clone())
+    torch.manual_seed(4242)          # worker thread and driver both draw from this global stream, serially
+    orig, video, cache = fifo.cogvideo_fifo_mp_v2([pipe], base)
+    torch.save(dict(weight_seed=400, input_seed=401, rng_seed=4242, num_chunks=num_chunks, dtype=str(dtype), H=H, W=W,
+                    fifo_latents=fifo_latents, fifo_old=fifo_old, prompt=prompt, image_embeddings=image_embeddings,
+                    grid_t=grid_t, grid_h=grid_h, grid_w=grid_w, cond_t=cond_t, cond_h=cond_h, cond_w=cond_w,
+                    video=video.clone(), sd_checksum=sd_checksum(sd)), os.path.join(GOLD, tag + ".pt"))
+    print(tag + ".pt", tuple(video.shape))
+
+
+@torch.no_grad()
+def gen_full_block():
+    """Full-width CogVideoX-5B block with VIP (BASELINE config 1), B=1: sampled outputs + statistics."""
+    D, heads = 3072, 48
+    cfg = dict(num_attention_heads=heads, attention_head_dim=64, num_layers=1, time_embed_dim=512)
+    sd = O.make_state_dict(cfg, n_vip_dim=3072, seed=500)
+    bsd = {k[len("transformer_blocks.0."):]: v for k, v in sd.items() if k.startswith("transformer_blocks.0.")}
+    blk = CogVideoXBlock(dim=D, num_attention_heads=heads, attention_head_dim=64, time_embed_dim=512,
+                         attention_bias=True)
+    blk.set_vip_layers(length=480, func_type="1", scale=[0.6])
+    blk.load_state_dict(bsd, strict=True)
+    blk.eval()
+    g = torch.Generator().manual_seed(501)
+    hid = torch.randn(1, 17550, D, generator=g)
+    enc = torch.randn(1, 706, D, generator=g)
+    temb = torch.randn(1, 13, 512, generator=g)
+    f32 = np.float32
+    rope = get_3d_rotary_pos_embed_v2(64, np.arange(13, dtype=f32), np.arange(30, dtype=f32), np.arange(45, dtype=f32))
+    crope = get_3d_rotary_pos_embed_v2(64, np.linspace(1000, 1016.25, 5, dtype=f32),
+                                       np.linspace(0, 30, 8, endpoint=False, dtype=f32),
+                                       np.linspace(0, 45, 12, endpoint=False, dtype=f32))
+    idx_h = torch.randint(0, 17550 * D, (4096,), generator=g)
+    idx_e = torch.randint(0, 706 * D, (2048,), generator=g)
+    res = dict(weight_seed=500, input_seed=501, idx_h=idx_h, idx_e=idx_e, sd_checksum=sd_checksum(bsd))
+    for dt in (torch.bfloat16, torch.float32):
+        b = blk.to(dt)
+        oh, oe = b(hid.to(dt), enc.to(dt), temb.to(dt), image_rotary_emb=rope, vip_image_rotary_emb=rope,
+                   vip_condition_rotary_emb=crope)
+        res[str(dt)] = dict(h_samples=oh.flatten()[idx_h].clone(), e_samples=oe.flatten()[idx_e].clone(),
+                            h_mean=oh.float().mean().item(), h_std=oh.float().std().item(),
+                            h_absmax=oh.float().abs().max().item(), e_mean=oe.float().mean().item(),
+                            e_std=oe.float().std().item(), e_absmax=oe.float().abs().max().item())
+        print("full block", dt, res[str(dt)]["h_std"], res[str(dt)]["e_std"])
+    torch.save(res, os.path.join(GOLD, "block_full.pt"))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full-block", action="store_true")
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    jobs = dict(dit=gen_dit_tiny, vip=gen_vip_processor, sched=gen_scheduler, fifo=gen_fifo)
+    if a.only:
+        jobs = {a.only: jobs.get(a.only, gen_full_block)}
+    for k, fn in jobs.items():
+        fn()
+    if a.full_block and not a.only:
+        gen_full_block()
