@@ -1,0 +1,129 @@
+/* libtokensgen_hip.so — C ABI of the MI355X (gfx950) kernels behind the TokensGen denoising hot path.
+ *
+ * The reference (Vicky0522/TokensGen) is pure Python/PyTorch: it has no native FFI.  Each entry point
+ * below replaces a *sequence of PyTorch ops* at the reference's own operator seams; the reference
+ * file:line each one stands in for is cited per function.  INTEGRATION.md shows the ctypes binding a
+ * maintainer adds on the reference side.
+ *
+ * Conventions:
+ *   - plain pointers + sizes only; all tensors are bf16 (raw uint16 bits) unless stated, fp32 accumulate;
+ *   - the caller owns every buffer (outputs and workspace are caller-allocated); nothing is retained;
+ *   - every call is asynchronous on the given hipStream_t, never synchronises, never selects a device;
+ *   - returns 0 on success; <0 on error (-1 argument, -2 shape, -3 alignment, <=-100 HIP error);
+ *     tg_last_error_string() gives the message for the calling thread.  No exceptions cross the ABI.
+ */
+#ifndef TOKENSGEN_HIP_H
+#define TOKENSGEN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;   /* same declaration as <hip/hip_runtime_api.h>; opaque to C callers */
+
+#define TG_MAX_GROUPS 16
+
+/* Token -> modulation-row lookup shared by the AdaLN kernels and the gated-residual GEMM epilogue.
+ * A DiT window has G = frames + 2 token groups: video frame f (per-frame modulation), text and
+ * condensed ("vip") tokens (frame-0 modulation) — normalization.py:441-460,477-488.
+ * `mod` is the output of the modulation linears, [batch][mod_rows][mod_ld] bf16; for a token of group
+ * g in batch b the shift/scale/gate vectors start at
+ *     mod + b*mod_batch_stride + row[g]*mod_ld + {shift,scale,gate}_col[g]. */
+typedef struct tg_group_table {
+    const void*    mod;               /* bf16 */
+    long           mod_ld;
+    long           mod_batch_stride;
+    const uint8_t* tok_group;         /* [tokens] group id of each token (same for every batch item) */
+    int32_t        row[TG_MAX_GROUPS];
+    int32_t        shift_col[TG_MAX_GROUPS];
+    int32_t        scale_col[TG_MAX_GROUPS];
+    int32_t        gate_col[TG_MAX_GROUPS];
+} tg_group_table;
+
+enum {
+    TG_EPI_BIAS = 0,          /* C = A W^T + bias                                   (nn.Linear)            */
+    TG_EPI_BIAS_GELU = 1,     /* C = gelu_tanh(bf16(A W^T + bias))                  (FeedForward net.0)    */
+    TG_EPI_BIAS_SILU = 2,     /* C = silu(bf16(A W^T + bias))                       (TimestepEmbedding act)*/
+    TG_EPI_BIAS_GATE_RES = 3  /* C = R + gate[group(m)] * (A W^T + bias)            (gated residual)       */
+};
+
+const char* tg_version(void);
+const char* tg_last_error_string(void);
+
+/* C[b,m,:] = epilogue(A[b,m,:] @ W^T + bias), W is an nn.Linear weight [N,K].  Batched by element strides.
+ * Replaces: attention_processor.py:2009-2018 (to_q/k/v, vip_to_q/k/v), :2143 (to_out[0]) fused with the
+ * gated residual cogvideox_transformer_3d.py:290-293,318-324; diffusers FeedForward (call sites
+ * cogvideox_transformer_3d.py:316,322); the modulation linears normalization.py:447,483,79;
+ * embeddings.py:516-536 (patch/text/vip projections), :953-965 (TimestepEmbedding); proj_out dit:748.
+ * Requires N%128==0, K%64==0 (pad weights once at load time), any M. */
+int tg_gemm_bf16(const void* A, long lda, long strideA, const void* W, long ldw, const void* bias,
+                 void* C, long ldc, long strideC, int M, int N, int K, int batch, int epilogue,
+                 const void* R, long ldr, long strideR, const tg_group_table* gate, hipStream_t stream);
+
+/* y = LayerNorm(x; w, b, eps) * (1 + scale[g]) + shift[g], g = group of the token.  One pass, fp32 stats.
+ * modulate == 0: plain affine LayerNorm (norm_final, cogvideox_transformer_3d.py:741).
+ * Replaces normalization.py:441-460 (CogVideoXLayerNormZero), :477-488 (VIP), :70-92 (AdaLayerNorm).
+ * x, y: [batch][tokens][dim] with row strides ldx/ldy and batch strides; dim % 8 == 0, dim <= 8192. */
+int tg_adaln_modulate(const void* x, long ldx, long strideX, void* y, long ldy, long strideY,
+                      const void* ln_weight, const void* ln_bias, float eps, int tokens, int dim, int batch,
+                      int modulate, const tg_group_table* g, hipStream_t stream);
+
+/* In-place per-head LayerNorm(64, eps, affine) followed by interleaved-pair RoPE on the rows of up to two
+ * token ranges.  x points at the q (or k) columns of a fused QKV buffer: element (b, t, h, d) at
+ * x[b*strideB + t*ld + h*64 + d].  seg i rotates tokens [start_i, start_i+len_i) with fp32 tables
+ * cos_i/sin_i [len_i][64]; other tokens are normalised only (text rows).
+ * Replaces attention_processor.py:2031-2056 + embeddings.py:840-885 (apply_rotary_emb). */
+int tg_qk_layernorm_rope(void* x, long ld, long strideB, int tokens, int heads, int batch,
+                         const void* ln_weight, const void* ln_bias, float eps,
+                         int start0, int len0, const float* cos0, const float* sin0,
+                         int start1, int len1, const float* cos1, const float* sin1, hipStream_t stream);
+
+/* vt[b][h][d][j] = v[b*strideB + (key_start + j)*ld + h*64 + d] for j < n_keys, zero for n_keys <= j < ldvt.
+ * Lays V out key-contiguous so the PV MFMA operands are plain 16-byte LDS reads (the "transpose" that
+ * F.scaled_dot_product_attention does internally).  ldvt % 64 == 0, ldvt >= n_keys. */
+int tg_transpose_v(const void* v, long ld, long strideB, int key_start, int n_keys, int heads, int batch,
+                   void* vt, long ldvt, hipStream_t stream);
+
+/* Flash attention forward, head_dim 64, no mask, softmax scale `scale`, up to two independently
+ * normalised key/value segments:   out = softmax(q1 k1^T) v1  +  seg2_scale * softmax(q2 k2^T) v2.
+ * q1,q2,k1,k2: element (b, t, h, d) at ptr[b*strideB + t*ld + h*64 + d];  vt1,vt2: from tg_transpose_v
+ * ([b][h][64][ldvt]);  out: (b, t, h, d) at out[b*out_strideB + t*out_ld + h*64 + d] (merged heads).
+ * Segment 2 is skipped when q2 == NULL.
+ * Replaces the three F.scaled_dot_product_attention calls + `hs + scale*tv_hs` + head merge,
+ * attention_processor.py:2066-2069,2117-2135,2141 (and :1937-1941 for the plain processor). */
+int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
+                     const void* k1, long k1_ld, long k1_strideB, const void* vt1, long vt1_ld, int nk1,
+                     const void* q2, long q2_ld, long q2_strideB,
+                     const void* k2, long k2_ld, long k2_strideB, const void* vt2, long vt2_ld, int nk2,
+                     float seg2_scale, void* out, long out_ld, long out_strideB,
+                     int nq, int heads, int batch, float scale, hipStream_t stream);
+
+/* emb[i][:] = bf16( [cos(t_i w_k) | sin(t_i w_k)] ), w_k = exp(-ln(1e4) k / (dim/2)), k < dim/2
+ * (flip_sin_to_cos=True, freq_shift=0).  Replaces embeddings.py:28-79 + dit:678.  t: int64[n]. */
+int tg_timestep_sinusoid(const int64_t* t, int n, int dim, void* emb, hipStream_t stream);
+
+/* Gather 2x2 patches: out[(b f) (h/2 w/2)][c*4 + dy*2 + dx] = lat[b][f][c][2y+dy][2x+dx]  (the im2col of
+ * Conv2d(k=2,s=2), embeddings.py:516-523) so that patch embedding is one GEMM with K = 4*C. */
+int tg_patchify(const void* lat, void* out, int bf, int C, int H, int W, hipStream_t stream);
+
+/* Inverse for the output head: lat[b][f][c][2y+dy][2x+dx] = x[(b f)(y x)][ld][c*4 + dy*2 + dx]
+ * (cogvideox_transformer_3d.py:754-759). */
+int tg_unpatchify(const void* x, long ldx, void* lat, int bf, int C, int H, int W, hipStream_t stream);
+
+/* Fused classifier-free guidance + per-frame SDE-DPM-solver++(2M) update for one FIFO window:
+ *   v   = uncond + g*(cond - uncond)                                    (cogvideo_sampling_mp_fifo.py:531-533)
+ *   x0  = sa_f*x - sb_f*v ;  d = has_old_f ? m3_f*x0 - m4_f*old_x0 : x0
+ *   x'  = m1_f*x - m2_f*d + mn_f*noise[f][has_old_f]                    (scheduling_dpm_cogvideox.py:424-463)
+ * for every frame f of the window with its own fp32 coefficient row coef[f] = {sa,sb,m1,m2,m3,m4,mn,has_old}.
+ * model_out: [2][frames][frame_elems] bf16 (uncond, cond); x, old_x0, x_out, x0_out: [frames][frame_elems];
+ * noise: [frames][2][frame_elems] bf16 (the reference's two randn draws per step). */
+int tg_cfg_dpm_step(const void* model_out, const void* x, const void* old_x0, const void* noise,
+                    const float* coef, float guidance, void* x_out, void* x0_out,
+                    int frames, long frame_elems, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOKENSGEN_HIP_H */

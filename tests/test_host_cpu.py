@@ -1,0 +1,140 @@
+"""CPU: host logic of the product (no kernels run): RoPE tables, scheduler tables, packing of the fused weight
+storages, and that the C-ABI library exports every symbol include/tokensgen_hip.h declares."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dit_ref as O
+from oracle import scheduler_ref as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rope_tables_bit_exact_vs_oracle():
+    from tokensgen_amd import rope as R
+    f32 = np.float32
+    for gt, gh, gw in [(np.arange(13, dtype=f32), np.arange(30, dtype=f32), np.arange(45, dtype=f32)),
+                       (np.linspace(1000, 1016.25, 5, dtype=f32), np.linspace(0, 30, 8, endpoint=False, dtype=f32),
+                        np.linspace(0, 45, 12, endpoint=False, dtype=f32)),
+                       (np.arange(13, dtype=f32) + f32(137.0), np.arange(4, dtype=f32), np.arange(6, dtype=f32))]:
+        a, b = R.rope_3d(64, gt, gh, gw), O.rope_3d(64, gt, gh, gw)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    a, b = R.rope_3d_crop(64, (0, 0, 0), (13, 30, 45), (13, 30, 45)), O.rope_3d_crop(64, (0, 0, 0), (13, 30, 45), (13, 30, 45))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # T2To split 52/6/6 (pipeline_cogvideox_t2to.py:557-559)
+    a = R.rope_3d(64, np.arange(4, dtype=f32), np.arange(8, dtype=f32), np.arange(12, dtype=f32), 52, 6, 6)
+    b = O.rope_3d(64, np.arange(4, dtype=f32), np.arange(8, dtype=f32), np.arange(12, dtype=f32), 52, 6, 6)
+    assert torch.equal(a[0], b[0]) and a[0].shape == (384, 64)
+
+
+def test_scheduler_tables_vs_oracle(golden_dir):
+    from tokensgen_amd.scheduler import CogVideoXDPMScheduler, dpm_coef_row
+    s = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0,
+                              timestep_spacing="trailing")
+    s.set_timesteps(52)
+    g = torch.load(os.path.join(golden_dir, "scheduler.pt"), weights_only=False)
+    assert torch.equal(s.timesteps, g["timesteps"])
+    assert (s.alphas_cumprod - g["alphas_cumprod"]).abs().max() < 1e-15 and s.alphas_cumprod[-1] == 0
+    assert torch.equal(s.betas, g["betas"])
+    _, ac = S.alphas_cumprod()
+    ts = s.timesteps.tolist()
+    for i in range(1, 51):
+        row = dpm_coef_row(s.alphas_cumprod.numpy(), ts[i], ts[i + 1], ts[i - 1], True)
+        c = S.step_coefficients(ac, ts[i], ts[i + 1], ts[i - 1])
+        ref = [float(c[k]) for k in ("sa", "sb", "m1", "m2", "m3", "m4", "mn")]
+        assert np.allclose(row[:7], ref, rtol=1e-12, atol=1e-14) and row[7] == 1.0
+    # edges: t=999 first step (no x0 yet), prev_t=-1 final step
+    assert dpm_coef_row(s.alphas_cumprod.numpy(), 999, 980, None, False)[2] == 0.0
+    last = dpm_coef_row(s.alphas_cumprod.numpy(), 18, -1, 37, True)
+    assert last[2] == 0.0 and last[3] == -1.0 and last[6] == 0.0 and last[7] == 0.0
+    with pytest.raises(NotImplementedError):
+        CogVideoXDPMScheduler(beta_schedule="vip_1")
+    for sp, n in (("leading", 50), ("linspace", 7)):
+        CogVideoXDPMScheduler(prediction_type="v_prediction", timestep_spacing=sp).set_timesteps(n)
+
+
+def test_transformer_state_dict_contract():
+    """Reference key names, fused storages shared with the named parameters, vip layers added later."""
+    from tokensgen_amd.transformer import CogVideoXTransformer3DModel, VideoIPAdapterCogVideoXAttnProcessor2_0
+    cfg = dict(num_attention_heads=2, attention_head_dim=64, num_layers=2, patch_size=2, time_embed_dim=128,
+               text_embed_dim=64, in_channels=16, out_channels=16)
+    m = CogVideoXTransformer3DModel(num_attention_heads=2, attention_head_dim=64, num_layers=2, time_embed_dim=128,
+                                    text_embed_dim=64, use_rotary_positional_embeddings=True, device="cpu")
+    assert sorted(m.state_dict()) == sorted(O.make_state_dict(cfg, None, seed=1))
+    base = {k: v.to(torch.bfloat16) for k, v in O.make_state_dict(cfg, None, seed=1).items()}
+    m.load_state_dict(base, strict=True)
+    vipcfg = dict(length=30, func_type="1", scale=[0.6],
+                  resampler_params=dict(output_dim=128, num_height_queries=2, num_width_queries=3, num_temporal_queries=4))
+    m.set_vip_layers(None, **vipcfg)
+    sd = {k: v.to(torch.bfloat16) for k, v in O.make_state_dict(cfg, 128, seed=1).items()}
+    assert sorted(m.state_dict()) == sorted(sd)
+    # set_vip_layers initialises the vip projections from the base ones (cogvideox_transformer_3d.py:207-218)
+    assert torch.equal(m.state_dict()["transformer_blocks.1.attn1.processor.vip_to_k.weight"], base["transformer_blocks.1.attn1.to_k.weight"])
+    # ... and keeps the already-loaded modulation weights when the fused matrix is re-laid-out
+    assert torch.equal(m.state_dict()["transformer_blocks.1.norm2.linear.weight"], base["transformer_blocks.1.norm2.linear.weight"])
+    m.load_state_dict(sd, strict=True)
+    D = 128
+    per, out_base, total = m._mod_cols()
+    assert (per, out_base, total) == (18 * D, 36 * D, 38 * D)
+    assert torch.equal(m._fused["mod.w"][per + 9 * D: per + 15 * D], sd["transformer_blocks.1.norm2.linear.weight"])
+    assert torch.equal(m._fused["mod.w"][per + 6 * D: per + 9 * D], sd["transformer_blocks.1.vip_norm1.linear.weight"])
+    assert torch.equal(m._fused["l0.vqkv.w"][2 * D:], sd["transformer_blocks.0.attn1.processor.vip_to_v.weight"])
+    assert torch.equal(m._fused["patch.w"], sd["patch_embed.proj.weight"].reshape(D, 64))
+    assert m._fused["proj_out.w"].shape == (128, D) and (m._fused["proj_out.w"][64:] == 0).all()
+    procs = [mod for mod in m.modules() if mod.__class__.__name__ == "VideoIPAdapterCogVideoXAttnProcessor2_0"]
+    assert len(procs) == 2 and isinstance(procs[0], VideoIPAdapterCogVideoXAttnProcessor2_0) and procs[0].scale == [0.6]
+    # vip.pt round trip (save_vip_layers / set_vip_layers(vip_ckpt_dir), cogvideox_transformer_3d.py:603-634)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        m.save_vip_layers(d)
+        saved = torch.load(os.path.join(d, "vip.pt"), weights_only=True)
+        assert all("vip_" in k for k in saved) and len(saved) == 2 * 18 + 2
+        m2 = CogVideoXTransformer3DModel(num_attention_heads=2, attention_head_dim=64, num_layers=2, time_embed_dim=128,
+                                         text_embed_dim=64, use_rotary_positional_embeddings=True, device="cpu")
+        m2.load_state_dict(base, strict=True)
+        m2.set_vip_layers(d, **vipcfg)
+        sd2 = m2.state_dict()
+        assert all(torch.equal(sd2[k].float(), v) for k, v in saved.items())
+        assert torch.equal(m2._fused["l1.vqkv.w"], m._fused["l1.vqkv.w"])
+        assert torch.equal(sd2["transformer_blocks.0.norm1.linear.weight"], base["transformer_blocks.0.norm1.linear.weight"])
+        with pytest.raises(IOError):
+            m2.set_vip_layers(os.path.join(d, "missing"), **vipcfg) if os.makedirs(os.path.join(d, "missing")) is None else None
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly without a GPU — never route through torch/CPU."""
+    from tokensgen_amd.transformer import CogVideoXTransformer3DModel
+    m = CogVideoXTransformer3DModel(num_attention_heads=2, attention_head_dim=64, num_layers=1, time_embed_dim=128,
+                                    text_embed_dim=64, use_rotary_positional_embeddings=True, device="cpu")
+    z = torch.zeros
+    with pytest.raises(RuntimeError, match="GPU"):
+        m(z(1, 13, 16, 4, 6, dtype=torch.bfloat16), z(1, 8, 64, dtype=torch.bfloat16), z(1, dtype=torch.long),
+          image_rotary_emb=(z(78, 64), z(78, 64)))
+    with pytest.raises(NotImplementedError):
+        CogVideoXTransformer3DModel(num_attention_heads=2, attention_head_dim=32, use_rotary_positional_embeddings=True, device="cpu")
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from tokensgen_amd import lib as L
+    hdr = open(os.path.join(ROOT, "include", "tokensgen_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(tg_[a-z0-9_]+)\s*\(", hdr))
+    assert {"tg_gemm_bf16", "tg_attention_fwd", "tg_adaln_modulate", "tg_qk_layernorm_rope", "tg_cfg_dpm_step"} <= declared
+    assert os.path.exists(L.LIB_PATH), "build the library first: python -c 'import __graft_entry__ as g; g.build()'"
+    so = ctypes.CDLL(L.LIB_PATH)
+    for name in declared:
+        assert hasattr(so, name), f"{name} declared in include/tokensgen_hip.h but not exported"
+    lib = L.load()
+    assert set(L.PROTOTYPES) | {"tg_version", "tg_last_error_string"} == declared
+    assert b"gfx950" in lib.tg_version()
+    # argument validation happens before any launch, so it is testable without a GPU
+    assert lib.tg_gemm_bf16(None, 0, 0, None, 0, None, None, 0, 0, 1, 128, 64, 1, 0, None, 0, 0, None, None) == -1
+    assert b"null pointer" in lib.tg_last_error_string()
+    buf = ctypes.create_string_buffer(4096)
+    p = ctypes.addressof(buf) + (16 - ctypes.addressof(buf) % 16)
+    assert lib.tg_gemm_bf16(p, 64, 0, p, 64, None, p, 100, 0, 4, 100, 64, 1, 0, None, 0, 0, None, None) == -2
+    assert b"N%128" in lib.tg_last_error_string()

@@ -1,0 +1,225 @@
+"""GPU: each HIP kernel (called through the C ABI) against a plain fp32 torch restatement / the oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _rel(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def K():
+    from tokensgen_amd import kernels
+    return kernels
+
+
+def _table(K, B, rows, D, ngroups, tokens, seed):
+    from tokensgen_amd import kernels
+    mod = _rand(B, rows, 3 * D * ngroups, seed=seed, scale=0.5)
+    g = torch.Generator().manual_seed(seed + 1)
+    tok_group = torch.randint(0, ngroups, (tokens,), generator=g, dtype=torch.uint8).to(DEV)
+    r = [int(x) for x in torch.randint(0, rows, (ngroups,), generator=g)]
+    sh = [3 * D * i for i in range(ngroups)]
+    sc = [3 * D * i + D for i in range(ngroups)]
+    ga = [3 * D * i + 2 * D for i in range(ngroups)]
+    return kernels.GroupTable(mod, tok_group, r, sh, sc, ga), mod, tok_group, r, sh, sc, ga
+
+
+def _gather(mod, tok_group, rows, cols, D):
+    """[B, tokens, D] rows of the modulation table selected per token."""
+    tg = tok_group.long()
+    r = torch.tensor(rows, device=DEV)[tg]
+    c = torch.tensor(cols, device=DEV)[tg]
+    idx = c[:, None] + torch.arange(D, device=DEV)[None]
+    return mod.float()[:, r[:, None], idx]
+
+
+@pytest.mark.parametrize("M,N,K_,B", [(300, 256, 192, 2), (128, 128, 64, 1), (26, 384, 128, 1), (1031, 512, 320, 3)])
+def test_gemm_bias(K, M, N, K_, B):
+    from tokensgen_amd import lib as L
+    a_full = _rand(B, M + 5, K_ + 8, seed=1)            # strided views: row stride and batch stride differ from M,K
+    a = a_full[:, 2:2 + M, :K_]
+    w = _rand(N, K_, seed=2, scale=0.1)
+    bias = _rand(N, seed=3)
+    out_full = torch.zeros(B, M, N + 16, dtype=torch.bfloat16, device=DEV)
+    out = out_full[:, :, 8:8 + N]
+    K.gemm(a, w, bias, out, L.EPI_BIAS)
+    ref = a.float() @ w.float().T + bias.float()
+    assert _rel(out, ref) < 4e-3
+    assert (out_full[:, :, :8] == 0).all() and (out_full[:, :, 8 + N:] == 0).all()
+
+
+def test_gemm_transpose_detecting(K):
+    """A = I (asymmetric W): C must equal W^T exactly (catches row/col swaps in the MFMA C layout)."""
+    from tokensgen_amd import lib as L
+    n = 128
+    a = torch.eye(n, dtype=torch.bfloat16, device=DEV)
+    w = _rand(n, n, seed=5)
+    out = torch.empty(n, n, dtype=torch.bfloat16, device=DEV)
+    K.gemm(a, w, None, out, L.EPI_BIAS)
+    assert torch.equal(out, w.T.contiguous())
+
+
+def test_gemm_gelu_silu(K):
+    from tokensgen_amd import lib as L
+    a, w, bias = _rand(200, 256, seed=1), _rand(384, 256, seed=2, scale=0.1), _rand(384, seed=3)
+    pre = (a.float() @ w.float().T + bias.float()).to(torch.bfloat16).float()
+    out = torch.empty(200, 384, dtype=torch.bfloat16, device=DEV)
+    K.gemm(a, w, bias, out, L.EPI_BIAS_GELU)
+    assert _rel(out, torch.nn.functional.gelu(pre, approximate="tanh")) < 6e-3
+    K.gemm(a, w, bias, out, L.EPI_BIAS_SILU)
+    assert _rel(out, torch.nn.functional.silu(pre)) < 6e-3
+
+
+def test_gemm_gate_residual_inplace(K):
+    from tokensgen_amd import lib as L
+    B, M, N, K_ = 2, 333, 256, 128
+    a, w, bias = _rand(B, M, K_, seed=1), _rand(N, K_, seed=2, scale=0.1), _rand(N, seed=3)
+    x = _rand(B, M, N, seed=4)
+    tab, mod, tg, r, sh, sc, ga = _table(K, B, 7, N, 5, M, seed=9)
+    ref = x.float() + _gather(mod, tg, r, ga, N) * (a.float() @ w.float().T + bias.float())
+    K.gemm(a, w, bias, x, L.EPI_BIAS_GATE_RES, residual=x, gate=tab)
+    assert _rel(x, ref) < 4e-3
+
+
+@pytest.mark.parametrize("D", [128, 3072])
+def test_adaln_modulate(K, D):
+    B, T = 2, 77
+    x = _rand(B, T + 3, D, seed=1, scale=2.0)[:, 1:1 + T]
+    w, b = _rand(D, seed=2, scale=0.1) + 1, _rand(D, seed=3, scale=0.1)
+    tab, mod, tg, r, sh, sc, ga = _table(K, B, 13, D, 4, T, seed=5)
+    out = torch.empty(B, T, D, dtype=torch.bfloat16, device=DEV)
+    K.adaln_modulate(x, out, w, b, 1e-5, tab)
+    ln = torch.nn.functional.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-5)
+    ref = ln * (1 + _gather(mod, tg, r, sc, D)) + _gather(mod, tg, r, sh, D)
+    assert _rel(out, ref) < 4e-3
+    K.adaln_modulate(x, out, w, b, 1e-5, None)
+    assert _rel(out, ln) < 4e-3
+
+
+def test_qk_layernorm_rope(K):
+    from oracle import dit_ref as O
+    B, T, H = 2, 50, 3
+    buf = _rand(B, T, 3 * H * 64, seed=1)
+    orig = buf.clone()
+    w, b = _rand(64, seed=2, scale=0.1) + 1, _rand(64, seed=3, scale=0.1)
+    f32 = np.float32
+    c0 = O.rope_3d(64, np.arange(2, dtype=f32), np.arange(3, dtype=f32), np.arange(4, dtype=f32))     # 24 tokens
+    c1 = O.rope_3d(64, np.linspace(1000, 1003, 2, dtype=f32), np.arange(2, dtype=f32), np.arange(3, dtype=f32))  # 12
+    c0d = tuple(t.to(DEV).contiguous() for t in c0)
+    c1d = tuple(t.to(DEV).contiguous() for t in c1)
+    q = buf[:, :, H * 64:2 * H * 64]                       # the "k" columns of a fused buffer
+    K.qk_layernorm_rope(q, H, w, b, 1e-6, (8, c0d), (34, c1d))
+    x = orig[:, :, H * 64:2 * H * 64].float().cpu().view(B, T, H, 64).transpose(1, 2)
+    ln = torch.nn.functional.layer_norm(x, (64,), w.float().cpu(), b.float().cpu(), 1e-6).to(torch.bfloat16)
+    ln[:, :, 8:32] = O.apply_rope(ln[:, :, 8:32], c0)
+    ln[:, :, 34:46] = O.apply_rope(ln[:, :, 34:46], c1)
+    got = q.cpu().view(B, T, H, 64).transpose(1, 2)
+    assert _rel(got, ln) < 3e-3
+    assert torch.equal(buf[:, :, :H * 64], orig[:, :, :H * 64]) and torch.equal(buf[:, :, 2 * H * 64:], orig[:, :, 2 * H * 64:])
+
+
+def test_transpose_v(K):
+    B, T, H = 2, 150, 3
+    buf = _rand(B, T, 3 * H * 64, seed=1)
+    v = buf[:, :, 2 * H * 64:]
+    vt = torch.full((B, H, 64, 128), 7.0, dtype=torch.bfloat16, device=DEV)
+    K.transpose_v(v, H, 30, 100, vt)
+    ref = v[:, 30:130].reshape(B, 100, H, 64).permute(0, 2, 3, 1)
+    assert torch.equal(vt[..., :100], ref) and (vt[..., 100:] == 0).all()
+
+
+def _sdpa_ref(q, k, v, H, scale):
+    B = q.shape[0]
+    qh, kh, vh = (t.float().reshape(B, t.shape[1], H, 64).transpose(1, 2) for t in (q, k, v))
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(B, q.shape[1], H * 64)
+
+
+@pytest.mark.parametrize("nq,nk1,nk2", [(200, 333, 100), (128, 64, 0), (77, 1000, 30), (513, 4097, 480)])
+def test_attention_two_segments(K, nq, nk1, nk2):
+    B, H = 2, 4
+    qkv1 = _rand(B, max(nq, nk1), 3 * H * 64, seed=1)
+    qkv2 = _rand(B, max(nq, nk2, 1), 3 * H * 64, seed=2)
+    q1, k1, v1 = qkv1[:, :nq, :H * 64], qkv1[:, :nk1, H * 64:2 * H * 64], qkv1[:, :nk1, 2 * H * 64:]
+    pad = lambda n: (n + 63) // 64 * 64
+    vt1 = torch.empty(B, H, 64, pad(nk1), dtype=torch.bfloat16, device=DEV)
+    K.transpose_v(v1, H, 0, nk1, vt1)
+    out = torch.empty(B, nq, H * 64, dtype=torch.bfloat16, device=DEV)
+    ref = _sdpa_ref(q1, k1, v1, H, 0.125)
+    if nk2:
+        q2, k2, v2 = qkv2[:, :nq, :H * 64], qkv2[:, :nk2, H * 64:2 * H * 64], qkv2[:, :nk2, 2 * H * 64:]
+        vt2 = torch.empty(B, H, 64, pad(nk2), dtype=torch.bfloat16, device=DEV)
+        K.transpose_v(v2, H, 0, nk2, vt2)
+        K.attention(q1, k1, vt1, nk1, out, H, 0.125, q2, k2, vt2, nk2, 0.6)
+        ref = ref + 0.6 * _sdpa_ref(q2, k2, v2, H, 0.125)
+    else:
+        K.attention(q1, k1, vt1, nk1, out, H, 0.125)
+    assert _rel(out, ref) < 6e-3
+
+
+def test_attention_forced_rescale(K):
+    """Spike one key late in the sequence so the running max jumps mid-stream (online-softmax rescale path)."""
+    B, H, nq, nk = 1, 1, 128, 512
+    q, k, v = _rand(B, nq, 64, seed=1), _rand(B, nk, 64, seed=2), _rand(B, nk, 64, seed=3)
+    k[:, 300] = q[:, 5] * 4.0
+    k[:, 3] = q[:, 70] * 3.0
+    vt = torch.empty(B, H, 64, nk, dtype=torch.bfloat16, device=DEV)
+    K.transpose_v(v, H, 0, nk, vt)
+    out = torch.empty(B, nq, 64, dtype=torch.bfloat16, device=DEV)
+    K.attention(q, k, vt, nk, out, H, 0.125)
+    ref = _sdpa_ref(q, k, v, H, 0.125)
+    assert (out.float() - ref).abs().max().item() < 3e-2
+    assert _rel(out, ref) < 6e-3
+
+
+def test_timestep_sinusoid(K):
+    from oracle import dit_ref as O
+    t = torch.tensor([0, 1, 18, 500, 999, 37], dtype=torch.int64)
+    out = torch.empty(6, 256, dtype=torch.bfloat16, device=DEV)
+    K.timestep_sinusoid(t.to(DEV), 256, out)
+    ref = O.timestep_sinusoid(t, 256).to(torch.bfloat16)
+    assert (out.cpu().float() - ref.float()).abs().max().item() <= 2 ** -7
+
+
+def test_patchify_roundtrip(K):
+    lat = _rand(6, 16, 8, 12, seed=1)
+    cols = torch.empty(6 * 4 * 6, 64, dtype=torch.bfloat16, device=DEV)
+    K.patchify(lat, cols)
+    ref = lat.reshape(6, 16, 4, 2, 6, 2).permute(0, 2, 4, 1, 3, 5).reshape(6 * 24, 64)
+    assert torch.equal(cols, ref)
+    back = torch.empty_like(lat)
+    K.unpatchify(cols, back)
+    assert torch.equal(back, lat)
+
+
+def test_cfg_dpm_step_matches_oracle(K):
+    from oracle import scheduler_ref as S
+    _, ac = S.alphas_cumprod()
+    ts = S.trailing_timesteps(52)
+    frames, E = 5, 16 * 4 * 6
+    mo, x, old, noise = _rand(2, frames, E, seed=1), _rand(frames, E, seed=2), _rand(frames, E, seed=3), _rand(frames, 2, E, seed=4)
+    cases = [(999, 980, None, False), (980, 961, 999, True), (499, 480, 518, True), (18, -1, 37, True), (37, 18, 57, False)]
+    from tokensgen_amd.scheduler import dpm_coef_row
+    coef = torch.tensor([dpm_coef_row(ac, t, p, tb, ho) for (t, p, tb, ho) in cases], dtype=torch.float32, device=DEV)
+    xo, x0o = torch.empty_like(x), torch.empty_like(x)
+    K.cfg_dpm_step(mo, x, old, noise, coef, 6.0, xo, x0o)
+    for f, (t, p, tb, ho) in enumerate(cases):
+        v = S.cfg_combine(mo[:, f].cpu(), 6.0).float()
+        it = iter([noise[f, 0].cpu().float(), noise[f, 1].cpu().float()])
+        prev, x0 = S.dpm_step(ac, v, old[f].cpu().float() if ho else None, t, p, tb, x[f].cpu().float(), lambda: next(it))
+        assert (x0o[f].cpu().float() - x0).abs().max().item() <= 2e-2 * x0.abs().max().item() + 1e-3, (t, p)
+        assert (xo[f].cpu().float() - prev).abs().max().item() <= 2e-2 * prev.abs().max().item() + 1e-3, (t, p)

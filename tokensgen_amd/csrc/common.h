@@ -1,0 +1,61 @@
+// Shared device helpers for the tokensgen gfx950 kernels (bf16 storage, fp32 math).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define TG_OK 0
+#define TG_ERR_ARG (-1)
+#define TG_ERR_SHAPE (-2)
+#define TG_ERR_ALIGN (-3)
+#define TG_ERR_HIP (-100)
+
+// set the thread-local last-error string (api.cpp) and return `code`
+extern "C" int tg_set_error(int code, const char* fmt, ...);
+
+#define TG_REQUIRE(cond, code, ...)              \
+    do {                                         \
+        if (!(cond)) return tg_set_error((code), __VA_ARGS__); \
+    } while (0)
+
+#define TG_LAUNCH_CHECK(name)                                                              \
+    do {                                                                                   \
+        hipError_t e__ = hipGetLastError();                                                \
+        if (e__ != hipSuccess)                                                             \
+            return tg_set_error(TG_ERR_HIP - (int)e__, "%s: launch failed: %s", (name), hipGetErrorString(e__)); \
+    } while (0)
+
+static inline bool tg_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ float bf16lo_to_f32(uint32_t packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
+
+// round-to-nearest-even pack of two floats into (lo | hi<<16)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float v) { return (bf16_t)(pack_bf16x2(v, 0.f) & 0xffffu); }
+// value of v after a round trip through bf16 (mimics the reference's per-op bf16 rounding)
+__device__ __forceinline__ float round_bf16(float v) { return bf16lo_to_f32(pack_bf16x2(v, 0.f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// XCD-aware block remap (8 XCDs, block b lands on XCD b%8): give each XCD a contiguous chunk.
+// Bijective for any nwg (cdna guide T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}

@@ -1,0 +1,228 @@
+// bf16 GEMM for the DiT linear layers:  C[b, m, n] = epilogue( sum_k A[b, m, k] * W[n, k] + bias[n] )
+//
+// Replaces the reference's nn.Linear calls on the hot path (attention_processor.py:2009-2018 QKV +
+// vip QKV, :2143 to_out; diffusers FeedForward at cogvideox_transformer_3d.py:316,322; the modulation
+// linears normalization.py:447,483; embeddings.py:516-536,953-965).  nn.Linear weights are [N, K]
+// row-major, i.e. both operands are K-contiguous, which is exactly what MFMA fragments want.
+//
+// gfx950 design (v1 structure: 128x128x64 tile, 4 waves as 2x2, each 64x64 = 4x4 MFMA 16x16x32):
+//   * global -> LDS by `global_load_lds_dwordx4` (LDS-DMA, 1 KiB per wave instruction, no VGPR trip);
+//     the LDS image is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE
+//     address and again on the ds_read side (same involution: 16-B slot ^= (row>>1)&7).
+//   * double-buffered LDS, tile t+1 in flight while tile t is multiplied.
+//   * operands are fed swapped (W rows as the MFMA "A", activations as "B") so each lane ends up with
+//     4 consecutive output columns of one row -> 8-byte bf16 stores and vector bias/gate loads.
+//   * block ids are remapped XCD-aware and grouped 8 m-tiles x n so the tiles resident on one XCD share
+//     A/W panels in that XCD's L2.
+//   * M edge: rows >= M are clamped on load and predicated on store.  N % 128 == 0, K % 64 == 0.
+#include "common.h"
+#include "tokensgen_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + W
+constexpr int GROUP_M = 8;
+
+struct GemmParams {
+    const bf16_t* A; long lda; long sAb;
+    const bf16_t* W; long ldw;
+    const bf16_t* bias;
+    bf16_t* C; long ldc; long sCb;
+    const bf16_t* R; long ldr; long sRb;          // residual (EPI_GATE_RES)
+    int M, N, K, batch;
+    tg_group_table g;                             // gate lookup (EPI_GATE_RES)
+};
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+    // F.gelu(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float e = __expf(2.f * u);
+    const float t = 1.f - 2.f / (e + 1.f);        // tanh(u), saturates cleanly at +-1
+    return 0.5f * x * (1.f + t);
+}
+__device__ __forceinline__ float silu(float x) { return x / (1.f + __expf(-x)); }
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- tile assignment: XCD-aware remap, then grouped (GROUP_M m-tiles per n sweep) ----
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
+    const int per_batch = tiles_m * tiles_n;
+    const int nwg = per_batch * p.batch;
+    int t = xcd_remap(blockIdx.x, nwg);
+    const int b = t / per_batch;
+    t -= b * per_batch;
+    const int per_group = GROUP_M * tiles_n;
+    const int grp = t / per_group;
+    const int first_m = grp * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int in_g = t - grp * per_group;
+    const int tm = first_m + in_g % gsz, tn = in_g / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const bf16_t* Ab = p.A + (long)b * p.sAb;
+
+    // ---- per-lane LDS-DMA source pointers (4 pieces of A, 4 of W per k-tile) ----
+    // wave-instruction i covers tile rows [wave*32 + i*8, +8): lane -> row += lane>>3, physical slot lane&7
+    const char* srcA[4];
+    const char* srcW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave * 32 + i * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((r >> 1) & 7);          // logical 16-B slot stored at this physical one
+        const int ma = min(m0 + r, p.M - 1);
+        srcA[i] = (const char*)(Ab + (long)ma * p.lda + slot * 8);
+        srcW[i] = (const char*)(p.W + (long)(n0 + r) * p.ldw + slot * 8);
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE_BYTES + wave * (32 * 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + (long)kt * (BK * 2)),
+                                             (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + (long)kt * (BK * 2)),
+                                             (__attribute__((address_space(3))) void*)(base + TILE_BYTES + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside a tile) ----
+    // row = w?*64 + f*16 + (lane&15); logical slot = ks*4 + (lane>>4); physical = slot ^ ((row>>1)&7)
+    int offA[4][2], offW[4][2];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ra = wm * 64 + f * 16 + (lane & 15);
+            const int rw = wn * 64 + f * 16 + (lane & 15);
+            const int sl = ks * 4 + (lane >> 4);
+            offA[f][ks] = ra * 128 + ((sl ^ ((ra >> 1) & 7)) << 4);
+            offW[f][ks] = rw * 128 + ((sl ^ ((rw >> 1) & 7)) << 4);
+        }
+    }
+
+    f32x4 acc[4][4];   // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* tA = smem + cur * STAGE_BYTES;
+        const char* tW = tA + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fw[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                fa[f] = *(const bf16x8*)(tA + offA[f][ks]);
+                fw[f] = *(const bf16x8*)(tW + offW[f][ks]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds D[n = (lane>>4)*4 + r][m = lane&15] per fragment ----
+    bf16_t* Cb = p.C + (long)b * p.sCb;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 64 + mi * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const bf16_t* gate_row = nullptr;
+        if (EPI == TG_EPI_BIAS_GATE_RES) {
+            const int g = p.g.tok_group[m];
+            gate_row = (const bf16_t*)p.g.mod + (long)b * p.g.mod_batch_stride + (long)p.g.row[g] * p.g.mod_ld + p.g.gate_col[g];
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+            float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+            if (p.bias) {
+                const uint2 bb = *(const uint2*)(p.bias + n);
+                v[0] += bf16lo_to_f32(bb.x); v[1] += bf16hi_to_f32(bb.x);
+                v[2] += bf16lo_to_f32(bb.y); v[3] += bf16hi_to_f32(bb.y);
+            }
+            if (EPI == TG_EPI_BIAS_GELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = gelu_tanh(round_bf16(v[i]));
+            } else if (EPI == TG_EPI_BIAS_SILU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = silu(round_bf16(v[i]));
+            } else if (EPI == TG_EPI_BIAS_GATE_RES) {
+                const uint2 gg = *(const uint2*)(gate_row + n);
+                const uint2 rr = *(const uint2*)(p.R + (long)b * p.sRb + (long)m * p.ldr + n);
+                v[0] = bf16lo_to_f32(rr.x) + bf16lo_to_f32(gg.x) * v[0];
+                v[1] = bf16hi_to_f32(rr.x) + bf16hi_to_f32(gg.x) * v[1];
+                v[2] = bf16lo_to_f32(rr.y) + bf16lo_to_f32(gg.y) * v[2];
+                v[3] = bf16hi_to_f32(rr.y) + bf16hi_to_f32(gg.y) * v[3];
+            }
+            uint2 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            *(uint2*)(Cb + (long)m * p.ldc + n) = o;
+        }
+    }
+}
+
+template <int EPI>
+int launch(const GemmParams& p, hipStream_t stream) {
+    const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN) * p.batch;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(tiles), dim3(256), 2 * STAGE_BYTES, stream, p);
+    TG_LAUNCH_CHECK("tg_gemm_bf16");
+    return TG_OK;
+}
+
+}  // namespace
+
+extern "C" int tg_gemm_bf16(const void* A, long lda, long strideA, const void* W, long ldw, const void* bias,
+                            void* C, long ldc, long strideC, int M, int N, int K, int batch, int epilogue,
+                            const void* R, long ldr, long strideR, const tg_group_table* gate, hipStream_t stream) {
+    TG_REQUIRE(A && W && C, TG_ERR_ARG, "tg_gemm_bf16: null pointer");
+    TG_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, TG_ERR_SHAPE, "tg_gemm_bf16: bad dims M=%d N=%d K=%d batch=%d", M, N, K, batch);
+    TG_REQUIRE(N % BN == 0 && K % BK == 0, TG_ERR_SHAPE, "tg_gemm_bf16: need N%%128==0 and K%%64==0 (N=%d K=%d)", N, K);
+    TG_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && strideA % 8 == 0 && strideC % 4 == 0, TG_ERR_ALIGN,
+               "tg_gemm_bf16: leading dimensions must keep 16-byte (A, W) / 8-byte (C) alignment");
+    TG_REQUIRE(tg_aligned16(A) && tg_aligned16(W) && (((uintptr_t)C) & 7) == 0, TG_ERR_ALIGN, "tg_gemm_bf16: unaligned base pointer");
+    GemmParams p{};
+    p.A = (const bf16_t*)A; p.lda = lda; p.sAb = strideA;
+    p.W = (const bf16_t*)W; p.ldw = ldw;
+    p.bias = (const bf16_t*)bias;
+    p.C = (bf16_t*)C; p.ldc = ldc; p.sCb = strideC;
+    p.R = (const bf16_t*)R; p.ldr = ldr; p.sRb = strideR;
+    p.M = M; p.N = N; p.K = K; p.batch = batch;
+    switch (epilogue) {
+        case TG_EPI_BIAS: return launch<TG_EPI_BIAS>(p, stream);
+        case TG_EPI_BIAS_GELU: return launch<TG_EPI_BIAS_GELU>(p, stream);
+        case TG_EPI_BIAS_SILU: return launch<TG_EPI_BIAS_SILU>(p, stream);
+        case TG_EPI_BIAS_GATE_RES:
+            TG_REQUIRE(R && gate && gate->mod && gate->tok_group, TG_ERR_ARG, "tg_gemm_bf16: gate/residual epilogue needs R and a group table");
+            TG_REQUIRE(ldr % 4 == 0 && strideR % 4 == 0 && (((uintptr_t)R) & 7) == 0, TG_ERR_ALIGN, "tg_gemm_bf16: residual alignment");
+            p.g = *gate;
+            return launch<TG_EPI_BIAS_GATE_RES>(p, stream);
+        default: return tg_set_error(TG_ERR_ARG, "tg_gemm_bf16: unknown epilogue %d", epilogue);
+    }
+}

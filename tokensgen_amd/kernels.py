@@ -1,0 +1,202 @@
+"""torch-tensor front end of the C ABI (include/tokensgen_hip.h).  Plumbing only: device memory comes from
+torch, launches go on torch's current HIP stream.  Every function requires bf16 CUDA(HIP) tensors; there is
+no CPU path."""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, dtype=BF16):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (tokensgen_amd has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost dimension must be contiguous")
+    return t
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+# Optional per-launch timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+PROFILE_ON = [False]
+PROFILE = {}
+
+
+def _launch(name, fn, *args):
+    if not PROFILE_ON[0]:
+        return fn(*args)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    code = fn(*args)
+    e.record()
+    PROFILE.setdefault(name, []).append((s, e))
+    return code
+
+
+def profile_summary():
+    """{kernel name: {"ms": mean launch duration, "n": launches, "total_ms": sum}} from the recorded events."""
+    torch.cuda.synchronize()
+    out = {}
+    for name, evs in PROFILE.items():
+        ms = [s.elapsed_time(e) for s, e in evs]
+        out[name] = {"ms": sum(ms) / len(ms), "n": len(ms), "total_ms": sum(ms)}
+    return out
+
+
+class GroupTable:
+    """Host mirror of tg_group_table: token -> (modulation row, shift/scale/gate column)."""
+
+    def __init__(self, mod, tok_group, rows, shift_cols, scale_cols, gate_cols, tok_offset=0):
+        _chk(mod, "mod")
+        assert mod.dim() == 3, "mod must be [batch, rows, cols]"
+        _chk(tok_group, "tok_group", torch.uint8)
+        self.mod, self.tok_group = mod, tok_group
+        self.c = L.GroupTable()
+        self.c.mod = mod.data_ptr()
+        self.c.mod_ld = mod.stride(1)
+        self.c.mod_batch_stride = mod.stride(0)
+        self.c.tok_group = tok_group.data_ptr() + tok_offset
+        n = len(rows)
+        assert n <= L.TG_MAX_GROUPS
+        for i in range(n):
+            self.c.row[i], self.c.shift_col[i], self.c.scale_col[i], self.c.gate_col[i] = (
+                int(rows[i]), int(shift_cols[i]), int(scale_cols[i]), int(gate_cols[i]))
+        self.rows, self.shift_cols, self.scale_cols, self.gate_cols = list(rows), list(shift_cols), list(scale_cols), list(gate_cols)
+
+    def offset(self, tok_offset):
+        """Same table, token indices shifted (for launches that start at a later token)."""
+        return GroupTable(self.mod, self.tok_group, self.rows, self.shift_cols, self.scale_cols, self.gate_cols, tok_offset)
+
+    def ref(self):
+        return C.byref(self.c)
+
+
+def _bmk(t):
+    """View a [M,K] or [B,M,K] tensor as (batch, M, K, ld, batch_stride)."""
+    if t.dim() == 2:
+        return 1, t.shape[0], t.shape[1], t.stride(0), 0
+    if t.dim() == 3:
+        return t.shape[0], t.shape[1], t.shape[2], t.stride(1), t.stride(0)
+    raise ValueError("expected a 2-D or 3-D tensor")
+
+
+def gemm(a, w, bias, out, epilogue=L.EPI_BIAS, residual=None, gate=None):
+    """out = epilogue(a @ w.T + bias); a [..,M,K], w [N,K] (nn.Linear layout), out [..,M,N] (views allowed)."""
+    _chk(a, "a"); _chk(w, "w"); _chk(out, "out")
+    B, M, K, lda, sa = _bmk(a)
+    Bo, Mo, N, ldc, sc = _bmk(out)
+    if (B, M) != (Bo, Mo) or w.shape != (N, K):
+        raise ValueError(f"gemm: shape mismatch a{tuple(a.shape)} w{tuple(w.shape)} out{tuple(out.shape)}")
+    if bias is not None:
+        _chk(bias, "bias")
+    ldr = sr = 0
+    if residual is not None:
+        _chk(residual, "residual")
+        _, _, _, ldr, sr = _bmk(residual)
+    L.check(_launch(f"gemm_M{M}_N{N}_K{K}_epi{epilogue}", L.load().tg_gemm_bf16, _p(a), lda, sa, _p(w), w.stride(0), _p(bias), _p(out), ldc, sc, M, N, K, B, epilogue,
+                                  _p(residual), ldr, sr, gate.ref() if gate is not None else None, _stream()), "tg_gemm_bf16")
+    return out
+
+
+def adaln_modulate(x, out, ln_weight, ln_bias, eps, table=None):
+    """out = LN(x)*(1+scale[g])+shift[g] (table given) or plain affine LN (table None). x/out [B,T,D] views."""
+    _chk(x, "x"); _chk(out, "out")
+    B, T, D, ldx, sx = _bmk(x)
+    _, _, _, ldy, sy = _bmk(out)
+    L.check(_launch("adaln_modulate", L.load().tg_adaln_modulate, _p(x), ldx, sx, _p(out), ldy, sy, _p(ln_weight), _p(ln_bias), float(eps), T, D, B,
+                                       1 if table is not None else 0, table.ref() if table is not None else None,
+                                       _stream()), "tg_adaln_modulate")
+    return out
+
+
+def qk_layernorm_rope(x, heads, ln_weight, ln_bias, eps, seg0=None, seg1=None):
+    """In place on x [B,T,heads*64] (a column slice of the fused QKV buffer). seg = (start, (cos, sin))."""
+    _chk(x, "x")
+    B, T, HD, ld, sb = _bmk(x)
+    assert HD == heads * 64
+
+    def unpack(seg):
+        if seg is None:
+            return 0, 0, None, None
+        start, (cos, sin) = seg
+        _chk(cos, "cos", torch.float32); _chk(sin, "sin", torch.float32)
+        assert cos.is_contiguous() and sin.is_contiguous() and cos.shape[-1] == 64
+        return int(start), int(cos.shape[0]), cos, sin
+    s0, l0, c0, n0 = unpack(seg0)
+    s1, l1, c1, n1 = unpack(seg1)
+    L.check(_launch("qk_layernorm_rope", L.load().tg_qk_layernorm_rope, _p(x), ld, sb, T, heads, B, _p(ln_weight), _p(ln_bias), float(eps), s0, l0, _p(c0),
+                                          _p(n0), s1, l1, _p(c1), _p(n1), _stream()), "tg_qk_layernorm_rope")
+    return x
+
+
+def transpose_v(v, heads, key_start, n_keys, vt):
+    """vt [B,heads,64,ldvt] <- v[:, key_start:key_start+n_keys] (v is a [B,T,heads*64] column slice)."""
+    _chk(v, "v"); _chk(vt, "vt")
+    B, T, HD, ld, sb = _bmk(v)
+    assert vt.is_contiguous() and vt.shape[:3] == (B, heads, 64)
+    L.check(_launch("transpose_v", L.load().tg_transpose_v, _p(v), ld, sb, key_start, n_keys, heads, B, _p(vt), vt.shape[3], _stream()), "tg_transpose_v")
+    return vt
+
+
+def attention(q1, k1, vt1, nk1, out, heads, scale, q2=None, k2=None, vt2=None, nk2=0, seg2_scale=0.0):
+    """out[B,nq,heads*64] = softmax(q1 k1^T) v1 + seg2_scale*softmax(q2 k2^T) v2 (segment 2 optional)."""
+    _chk(q1, "q1"); _chk(k1, "k1"); _chk(vt1, "vt1"); _chk(out, "out")
+    B, nq, _, qld, qsb = _bmk(q1)
+    _, _, _, kld, ksb = _bmk(k1)
+    _, _, _, old, osb = _bmk(out)
+    a2 = (0, 0, 0, 0, 0, 0, 0, 0, 0)
+    if q2 is not None:
+        _chk(q2, "q2"); _chk(k2, "k2"); _chk(vt2, "vt2")
+        _, _, _, q2ld, q2sb = _bmk(q2)
+        _, _, _, k2ld, k2sb = _bmk(k2)
+        a2 = (_p(q2), q2ld, q2sb, _p(k2), k2ld, k2sb, _p(vt2), vt2.shape[3], nk2)
+    L.check(_launch("attention_2seg" if q2 is not None else f"attention_1seg_nq{nq}", L.load().tg_attention_fwd, _p(q1), qld, qsb, _p(k1), kld, ksb, _p(vt1), vt1.shape[3], nk1, *a2, float(seg2_scale),
+                                      _p(out), old, osb, nq, heads, B, float(scale), _stream()), "tg_attention_fwd")
+    return out
+
+
+def timestep_sinusoid(t, dim, out):
+    _chk(t, "t", torch.int64); _chk(out, "out")
+    L.check(L.load().tg_timestep_sinusoid(_p(t), t.numel(), dim, _p(out), _stream()), "tg_timestep_sinusoid")
+    return out
+
+
+def patchify(lat, out):
+    """lat [BF,C,H,W] contiguous -> out [BF*(H/2)*(W/2), 4C]"""
+    _chk(lat, "lat"); _chk(out, "out")
+    assert lat.is_contiguous() and out.is_contiguous()
+    BF, Cc, H, W = lat.shape
+    L.check(L.load().tg_patchify(_p(lat), _p(out), BF, Cc, H, W, _stream()), "tg_patchify")
+    return out
+
+
+def unpatchify(x, lat):
+    """x [BF*(H/2)*(W/2), ld>=4C] rows -> lat [BF,C,H,W] contiguous"""
+    _chk(x, "x"); _chk(lat, "lat")
+    assert lat.is_contiguous()
+    BF, Cc, H, W = lat.shape
+    L.check(L.load().tg_unpatchify(_p(x), x.stride(0), _p(lat), BF, Cc, H, W, _stream()), "tg_unpatchify")
+    return lat
+
+
+def cfg_dpm_step(model_out, x, old_x0, noise, coef, guidance, x_out, x0_out):
+    """model_out [2,F,E]; x/old_x0/x_out/x0_out [F,E]; noise [F,2,E]; coef fp32 [F,8] (device)."""
+    for n, t in (("model_out", model_out), ("x", x), ("old_x0", old_x0), ("noise", noise), ("x_out", x_out), ("x0_out", x0_out)):
+        _chk(t, n)
+        assert t.is_contiguous()
+    _chk(coef, "coef", torch.float32)
+    F_, E = x.shape[0], x[0].numel()
+    L.check(L.load().tg_cfg_dpm_step(_p(model_out), _p(x), _p(old_x0), _p(noise), _p(coef), float(guidance), _p(x_out),
+                                     _p(x0_out), F_, E, _stream()), "tg_cfg_dpm_step")
+    return x_out, x0_out

@@ -1,0 +1,59 @@
+"""ctypes binding of libtokensgen_hip.so (include/tokensgen_hip.h).  Fails loudly if the library is missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtokensgen_hip.so")
+TG_MAX_GROUPS = 16
+
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SILU, EPI_BIAS_GATE_RES = 0, 1, 2, 3
+
+
+class GroupTable(C.Structure):
+    """struct tg_group_table"""
+    _fields_ = [("mod", C.c_void_p), ("mod_ld", C.c_long), ("mod_batch_stride", C.c_long),
+                ("tok_group", C.c_void_p), ("row", C.c_int32 * TG_MAX_GROUPS),
+                ("shift_col", C.c_int32 * TG_MAX_GROUPS), ("scale_col", C.c_int32 * TG_MAX_GROUPS),
+                ("gate_col", C.c_int32 * TG_MAX_GROUPS)]
+
+
+_vp, _l, _i, _f = C.c_void_p, C.c_long, C.c_int, C.c_float
+# name -> argtypes, exactly the prototypes of include/tokensgen_hip.h
+PROTOTYPES = {
+    "tg_gemm_bf16": [_vp, _l, _l, _vp, _l, _vp, _vp, _l, _l, _i, _i, _i, _i, _i, _vp, _l, _l, C.POINTER(GroupTable), _vp],
+    "tg_adaln_modulate": [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _f, _i, _i, _i, _i, C.POINTER(GroupTable), _vp],
+    "tg_qk_layernorm_rope": [_vp, _l, _l, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    "tg_transpose_v": [_vp, _l, _l, _i, _i, _i, _i, _vp, _l, _vp],
+    "tg_attention_fwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _f, _vp, _l, _l,
+                         _i, _i, _i, _f, _vp],
+    "tg_timestep_sinusoid": [_vp, _i, _i, _vp, _vp],
+    "tg_patchify": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "tg_unpatchify": [_vp, _l, _vp, _i, _i, _i, _i, _vp],
+    "tg_cfg_dpm_step": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _l, _vp],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise (never fall back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(make -C tokensgen_amd/csrc). tokensgen_amd has no CPU/PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.tg_version.restype = C.c_char_p
+    lib.tg_last_error_string.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError(f"{what} failed ({code}): {load().tg_last_error_string().decode()}")

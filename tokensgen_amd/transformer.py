@@ -1,0 +1,509 @@
+"""CogVideoXTransformer3DModel — host mirror of longvgen/models/cogvideox_transformer_3d.py for the To2V
+("vip", func_type "1") and plain (T2To / base) processors, driving the HIP kernels of libtokensgen_hip.so.
+
+Same constructor keywords, `forward` signature, `set_vip_layers`, `config` and state-dict key names as the
+reference, so `infer_cogvideo_mp_fifo.py` can build it and load the same checkpoints.
+
+MI355X-first layout decisions:
+  * one residual stream buffer X [B, Nt+Nv+Np, D] ordered text | video | vip — the reference's
+    cat/split/slice traffic (cogvideox_transformer_3d.py:232-235, 267-288, 315-324) disappears: the three
+    token kinds are row ranges of the same buffer;
+  * parameters that feed one GEMM share ONE storage: to_q|to_k|to_v -> [3D, D]; vip_to_q|k|v -> [3D, D];
+    every AdaLN modulation linear of every layer (+ norm_out.linear) -> one [L*18D + 2D, 512] matrix that is
+    multiplied ONCE per forward (temb is layer independent).  The nn.Parameters registered under the
+    reference's names are views into those storages, so state_dict()/load_state_dict() keep the reference
+    key names with zero copies;
+  * gated residuals, GELU, SiLU, bias are GEMM epilogues; LayerNorm+modulate, QK-LayerNorm+RoPE are single
+    passes; the three SDPAs of the To2V processor are two launches of one flash kernel.
+"""
+import json
+import math
+import os
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from . import kernels as K
+from . import lib as L
+
+BF16 = torch.bfloat16
+
+
+class Transformer2DModelOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+class VideoIPAdapterCogVideoXAttnProcessor2_0(nn.Module):
+    """Holder of the To2V branch weights under the reference's names (attention_processor.py:1955-1980).
+    The class name is load-bearing: the pipeline sets `.scale` on modules named exactly like this
+    (pipeline_cogvideox_mp_fifo.py:981-983).  Arithmetic happens in CogVideoXTransformer3DModel.forward."""
+
+    def __init__(self, scale=1.0, num_tokens=None):
+        super().__init__()
+        self.scale = scale
+        self.num_tokens = num_tokens
+        self.vip_to_q, self.vip_to_k, self.vip_to_v = _Lin(), _Lin(), _Lin()
+        self.vip_norm_q, self.vip_norm_k = _Lin(), _Lin()
+
+
+class CogVideoXAttnProcessor2_0:
+    """Plain joint-attention processor marker (attention_processor.py:1885-1953)."""
+
+
+class _Lin(nn.Module):
+    """Parameter holder (`weight`, `bias`) — parameters are attached later as views of fused storages."""
+
+
+class _Attention(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.to_q, self.to_k, self.to_v = _Lin(), _Lin(), _Lin()
+        self.norm_q, self.norm_k = _Lin(), _Lin()
+        self.to_out = nn.ModuleList([_Lin()])
+        object.__setattr__(self, "processor", CogVideoXAttnProcessor2_0())
+
+    def set_processor(self, processor):
+        """attention_processor.py:423-441: processors that own weights are registered sub-modules."""
+        self.__dict__.pop("processor", None)
+        self._modules.pop("processor", None)
+        if isinstance(processor, nn.Module):
+            self._modules["processor"] = processor
+        else:
+            object.__setattr__(self, "processor", processor)
+
+    def get_processor(self):
+        return self.processor
+
+
+class _Norm(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.linear, self.norm = _Lin(), _Lin()
+
+
+class _FF(nn.Module):
+    """diffusers FeedForward key layout: net.0.proj / net.2"""
+
+    def __init__(self):
+        super().__init__()
+        g = nn.Module()
+        g.proj = _Lin()
+        self.net = nn.ModuleList([g, nn.Identity(), _Lin()])
+
+
+class CogVideoXBlock(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.norm1, self.norm2 = _Norm(), _Norm()
+        self.attn1 = _Attention()
+        self.ff = _FF()
+        self.use_vip = False
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.proj, self.text_proj = _Lin(), _Lin()
+
+
+def _pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+class CogVideoXTransformer3DModel(nn.Module):
+    """See module docstring.  Construct directly on the GPU: CogVideoXTransformer3DModel(**config, device="cuda")."""
+
+    def __init__(self, num_attention_heads=30, attention_head_dim=64, in_channels=16, out_channels=16,
+                 flip_sin_to_cos=True, freq_shift=0, time_embed_dim=512, text_embed_dim=4096, num_layers=30,
+                 dropout=0.0, attention_bias=True, sample_width=90, sample_height=60, sample_frames=49, patch_size=2,
+                 temporal_compression_ratio=4, max_text_seq_length=226, activation_fn="gelu-approximate",
+                 timestep_activation_fn="silu", norm_elementwise_affine=True, norm_eps=1e-5,
+                 spatial_interpolation_scale=1.875, temporal_interpolation_scale=1.0,
+                 use_rotary_positional_embeddings=False, use_learned_positional_embeddings=False,
+                 use_output_projection=True, device="cuda", dtype=BF16):
+        super().__init__()
+        cfg = {k: v for k, v in locals().items() if k not in ("self", "__class__", "device", "dtype")}
+        self.config = SimpleNamespace(**cfg)
+        if attention_head_dim != 64:
+            raise NotImplementedError("the gfx950 attention kernel is specialised for head_dim 64 (CogVideoX)")
+        if not use_rotary_positional_embeddings:
+            raise NotImplementedError("only the rotary (CogVideoX-5B) model is on the hot path; the 2B sin-cos variant is out of scope")
+        if activation_fn != "gelu-approximate" or timestep_activation_fn != "silu" or not attention_bias \
+                or not norm_elementwise_affine or patch_size != 2 or not flip_sin_to_cos or freq_shift != 0 \
+                or not use_output_projection or dtype != BF16:
+            raise NotImplementedError("configuration differs from CogVideoX-5b in a way the fused kernels do not cover")
+        self.use_vip = False
+        self.vip_length = 0
+        self.vip_func_type = None
+        self._device = torch.device(device)
+        self._fused = {}          # name -> storage tensor
+        self._views = []          # (holder module, attr, fused name, row slice, shape)
+        self._ws = {}
+        D = num_attention_heads * attention_head_dim
+        self.inner_dim = D
+        self.patch_embed = _PatchEmbed()
+        self.time_embedding = nn.Module()
+        self.time_embedding.linear_1, self.time_embedding.linear_2 = _Lin(), _Lin()
+        self.transformer_blocks = nn.ModuleList([CogVideoXBlock() for _ in range(num_layers)])
+        self.norm_final = _Lin()
+        self.norm_out = _Norm()
+        self.proj_out = _Lin()
+        self._build_storage()
+
+    # ------------------------------------------------------------------------------------------ storage
+    def _alloc(self, name, *shape):
+        t = torch.zeros(*shape, dtype=BF16, device=self._device)
+        self._fused[name] = t
+        return t
+
+    def _bind(self, holder, attr, fused, rows, shape=None):
+        """Register holder.<attr> as an nn.Parameter that is a view of self._fused[fused][rows]."""
+        self._views.append((holder, attr, fused, rows, shape))
+        v = self._fused[fused][rows]
+        if shape is not None:
+            v = v.view(*shape)
+        holder._parameters[attr] = nn.Parameter(v, requires_grad=False)
+
+    def _mod_cols(self):
+        """Column (= output feature) layout of the fused modulation matrix."""
+        D, Lyr = self.inner_dim, self.config.num_layers
+        per = 18 * D if self.use_vip else 12 * D
+        return per, Lyr * per, Lyr * per + 2 * D
+
+    def _build_storage(self):
+        c, D = self.config, self.inner_dim
+        te, Lyr = c.time_embed_dim, c.num_layers
+        kin = c.in_channels * 4
+        self._alloc("patch.w", D, kin); self._alloc("patch.b", D)
+        self._bind(self.patch_embed.proj, "weight", "patch.w", slice(None), (D, c.in_channels, 2, 2))
+        self._bind(self.patch_embed.proj, "bias", "patch.b", slice(None))
+        self._alloc("text.w", D, c.text_embed_dim); self._alloc("text.b", D)
+        self._bind(self.patch_embed.text_proj, "weight", "text.w", slice(None))
+        self._bind(self.patch_embed.text_proj, "bias", "text.b", slice(None))
+        self._alloc("t1.w", te, D); self._alloc("t1.b", te); self._alloc("t2.w", te, te); self._alloc("t2.b", te)
+        self._bind(self.time_embedding.linear_1, "weight", "t1.w", slice(None)); self._bind(self.time_embedding.linear_1, "bias", "t1.b", slice(None))
+        self._bind(self.time_embedding.linear_2, "weight", "t2.w", slice(None)); self._bind(self.time_embedding.linear_2, "bias", "t2.b", slice(None))
+        for i, blk in enumerate(self.transformer_blocks):
+            p = f"l{i}."
+            self._alloc(p + "qkv.w", 3 * D, D); self._alloc(p + "qkv.b", 3 * D)
+            for j, n in enumerate(("to_q", "to_k", "to_v")):
+                self._bind(getattr(blk.attn1, n), "weight", p + "qkv.w", slice(j * D, (j + 1) * D))
+                self._bind(getattr(blk.attn1, n), "bias", p + "qkv.b", slice(j * D, (j + 1) * D))
+            self._alloc(p + "qknorm", 4, 64)   # norm_q.w, norm_q.b, norm_k.w, norm_k.b
+            self._bind(blk.attn1.norm_q, "weight", p + "qknorm", 0); self._bind(blk.attn1.norm_q, "bias", p + "qknorm", 1)
+            self._bind(blk.attn1.norm_k, "weight", p + "qknorm", 2); self._bind(blk.attn1.norm_k, "bias", p + "qknorm", 3)
+            self._alloc(p + "out.w", D, D); self._alloc(p + "out.b", D)
+            self._bind(blk.attn1.to_out[0], "weight", p + "out.w", slice(None)); self._bind(blk.attn1.to_out[0], "bias", p + "out.b", slice(None))
+            self._alloc(p + "ff1.w", 4 * D, D); self._alloc(p + "ff1.b", 4 * D)
+            self._alloc(p + "ff2.w", D, 4 * D); self._alloc(p + "ff2.b", D)
+            self._bind(blk.ff.net[0].proj, "weight", p + "ff1.w", slice(None)); self._bind(blk.ff.net[0].proj, "bias", p + "ff1.b", slice(None))
+            self._bind(blk.ff.net[2], "weight", p + "ff2.w", slice(None)); self._bind(blk.ff.net[2], "bias", p + "ff2.b", slice(None))
+            self._alloc(p + "ln", 4, D)        # norm1.norm.w/b, norm2.norm.w/b
+            self._bind(blk.norm1.norm, "weight", p + "ln", 0); self._bind(blk.norm1.norm, "bias", p + "ln", 1)
+            self._bind(blk.norm2.norm, "weight", p + "ln", 2); self._bind(blk.norm2.norm, "bias", p + "ln", 3)
+        self._alloc("final.ln", 4, D)          # norm_final.w/b, norm_out.norm.w/b
+        self._bind(self.norm_final, "weight", "final.ln", 0); self._bind(self.norm_final, "bias", "final.ln", 1)
+        self._bind(self.norm_out.norm, "weight", "final.ln", 2); self._bind(self.norm_out.norm, "bias", "final.ln", 3)
+        npo = 4 * c.out_channels
+        self._alloc("proj_out.w", _pad_to(npo, 128), D); self._alloc("proj_out.b", _pad_to(npo, 128))   # N padded to the GEMM tile
+        self._bind(self.proj_out, "weight", "proj_out.w", slice(0, npo)); self._bind(self.proj_out, "bias", "proj_out.b", slice(0, npo))
+        self._build_mod_storage()
+
+    def _build_mod_storage(self):
+        """(Re)build the fused modulation matrix; called again by set_vip_layers (layout gains the vip rows)."""
+        c, D, te = self.config, self.inner_dim, self.config.time_embed_dim
+        old = {}
+        for (holder, attr, fused, rows, shape) in self._views:
+            if fused in ("mod.w", "mod.b"):
+                old[(id(holder), attr)] = holder._parameters[attr].detach().clone()
+        self._views = [v for v in self._views if v[2] not in ("mod.w", "mod.b")]
+        per, out_base, total = self._mod_cols()
+        self._alloc("mod.w", _pad_to(total, 128), te); self._alloc("mod.b", _pad_to(total, 128))
+        for i, blk in enumerate(self.transformer_blocks):
+            base = i * per
+            order = [(blk.norm1.linear, 6 * D)]
+            if self.use_vip:
+                order.append((blk.vip_norm1.linear, 3 * D))
+            order.append((blk.norm2.linear, 6 * D))
+            if self.use_vip:
+                order.append((blk.vip_norm2.linear, 3 * D))
+            for holder, n in order:
+                self._bind(holder, "weight", "mod.w", slice(base, base + n)); self._bind(holder, "bias", "mod.b", slice(base, base + n))
+                base += n
+        self._bind(self.norm_out.linear, "weight", "mod.w", slice(out_base, out_base + 2 * D))
+        self._bind(self.norm_out.linear, "bias", "mod.b", slice(out_base, out_base + 2 * D))
+        for (holder, attr, fused, rows, shape) in self._views:
+            if fused in ("mod.w", "mod.b") and (id(holder), attr) in old:
+                holder._parameters[attr].data.copy_(old[(id(holder), attr)])
+
+    def _apply(self, fn, recurse=True):
+        """Keep the shared storages shared across .to()/.cuda(): move storages, then re-create the views."""
+        for name in list(self._fused):
+            self._fused[name] = fn(self._fused[name])
+        for (holder, attr, fused, rows, shape) in self._views:
+            v = self._fused[fused][rows]
+            if shape is not None:
+                v = v.view(*shape)
+            holder._parameters[attr] = nn.Parameter(v, requires_grad=False)
+        any_t = next(iter(self._fused.values()))
+        if any_t.dtype != BF16:
+            raise NotImplementedError("tokensgen_amd kernels are bf16-only")
+        self._device = any_t.device
+        self._ws = {}
+        return self
+
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def dtype(self):
+        return BF16
+
+    # ------------------------------------------------------------------------------------------ vip layers
+    def set_vip_layers(self, vip_ckpt_dir=None, **kwargs):
+        """cogvideox_transformer_3d.py:591-622 (+ block :145-218, patch_embed embeddings.py:423-431)."""
+        func_type = kwargs["func_type"]
+        if func_type != "1":
+            raise NotImplementedError(f"vip func_type {func_type!r}: only \"1\" (the shipped To2V configs) is on the hot path")
+        self.use_vip = True
+        self.vip_length = kwargs["length"]
+        self.vip_func_type = func_type
+        D = self.inner_dim
+        rp = kwargs["resampler_params"]
+        pe = self.patch_embed
+        pe.vip_proj = _Lin()
+        pe.vip_num_height_queries, pe.vip_num_width_queries = rp["num_height_queries"], rp["num_width_queries"]
+        pe.vip_num_temporal_queries = rp["num_temporal_queries"]
+        self._alloc("vipproj.w", D, rp["output_dim"]); self._alloc("vipproj.b", D)
+        self._bind(pe.vip_proj, "weight", "vipproj.w", slice(None)); self._bind(pe.vip_proj, "bias", "vipproj.b", slice(None))
+        for i, blk in enumerate(self.transformer_blocks):
+            p = f"l{i}."
+            blk.use_vip = True
+            blk.vip_length = kwargs["length"]
+            blk.vip_norm1, blk.vip_norm2 = _Norm(), _Norm()
+            proc = VideoIPAdapterCogVideoXAttnProcessor2_0(scale=kwargs["scale"], num_tokens=kwargs["length"])
+            blk.attn1.set_processor(proc)
+            self._alloc(p + "vqkv.w", 3 * D, D); self._alloc(p + "vqkv.b", 3 * D)
+            for j, n in enumerate(("vip_to_q", "vip_to_k", "vip_to_v")):
+                self._bind(getattr(proc, n), "weight", p + "vqkv.w", slice(j * D, (j + 1) * D))
+                self._bind(getattr(proc, n), "bias", p + "vqkv.b", slice(j * D, (j + 1) * D))
+            self._alloc(p + "vqknorm", 4, 64)
+            self._bind(proc.vip_norm_q, "weight", p + "vqknorm", 0); self._bind(proc.vip_norm_q, "bias", p + "vqknorm", 1)
+            self._bind(proc.vip_norm_k, "weight", p + "vqknorm", 2); self._bind(proc.vip_norm_k, "bias", p + "vqknorm", 3)
+            self._alloc(p + "vln", 4, D)
+            self._bind(blk.vip_norm1.norm, "weight", p + "vln", 0); self._bind(blk.vip_norm1.norm, "bias", p + "vln", 1)
+            self._bind(blk.vip_norm2.norm, "weight", p + "vln", 2); self._bind(blk.vip_norm2.norm, "bias", p + "vln", 3)
+            # the reference initialises the vip projections / norms as copies of the base ones (:207-218)
+            self._fused[p + "vqkv.w"].copy_(self._fused[p + "qkv.w"]); self._fused[p + "vqkv.b"].copy_(self._fused[p + "qkv.b"])
+            self._fused[p + "vqknorm"].copy_(self._fused[p + "qknorm"])
+            self._fused[p + "vln"][0].fill_(1.0); self._fused[p + "vln"][2].fill_(1.0)
+        self._build_mod_storage()
+        self._ws = {}
+        if vip_ckpt_dir is not None:
+            path = os.path.join(vip_ckpt_dir, "vip.pt")
+            if not os.path.exists(path):
+                raise IOError(f"no vip weights found in {vip_ckpt_dir}")
+            sd = torch.load(path, weights_only=True)
+            own = self.state_dict().keys()
+            for k in sd:
+                assert k in own, k
+            self.load_state_dict(sd, strict=False)
+
+    def save_vip_layers(self, vip_ckpt_dir=None):
+        """cogvideox_transformer_3d.py:624-634"""
+        assert self.use_vip
+        sd = {n: p.detach().to("cpu").to(torch.float32) for n, p in self.named_parameters() if "vip_" in n}
+        os.makedirs(vip_ckpt_dir, exist_ok=True)
+        torch.save(sd, os.path.join(vip_ckpt_dir, "vip.pt"))
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=BF16, device="cuda", **kw):
+        """from_pretrained-lite: <dir>/config.json + diffusion_pytorch_model*.safetensors."""
+        from safetensors.torch import load_file
+        d = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(d, "config.json")) as f:
+            cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        m = cls(**cfg, device=device, dtype=torch_dtype)
+        idx = os.path.join(d, "diffusion_pytorch_model.safetensors.index.json")
+        files = sorted(set(json.load(open(idx))["weight_map"].values())) if os.path.exists(idx) else ["diffusion_pytorch_model.safetensors"]
+        for fn in files:
+            m.load_state_dict(load_file(os.path.join(d, fn)), strict=False)
+        return m
+
+    # ------------------------------------------------------------------------------------------ workspace
+    def _workspace(self, B, Nt, Nv, Np, Fm):
+        key = (B, Nt, Nv, Np, Fm)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        D, H = self.inner_dim, self.config.num_attention_heads
+        N1, N = Nt + Nv, Nt + Nv + Np
+        dev = self._device
+        e = lambda *s: torch.empty(*s, dtype=BF16, device=dev)
+        ws = SimpleNamespace()
+        ws.X, ws.Xn, ws.AO = e(B, N, D), e(B, N, D), e(B, N, D)
+        ws.QKV = e(B, N1, 3 * D)
+        ws.FF = e(B, N, 4 * D)
+        ws.Vt1 = e(B, H, 64, _pad_to(N1, 64))
+        if Np:
+            ws.QKVv = e(B, N, 3 * D)
+            ws.Vt2 = e(B, H, 64, _pad_to(Np, 64))
+            ws.Vt3 = e(B, H, 64, _pad_to(N, 64))
+        per, out_base, total = self._mod_cols()
+        ws.mod = e(B, Fm, _pad_to(total, 128))
+        ws.sin = e(B * Fm, D)
+        ws.t1 = e(B * Fm, self.config.time_embed_dim)
+        ws.semb = e(B * Fm, self.config.time_embed_dim)
+        ws.patches = e(B, Nv, self.config.in_channels * 4)
+        ws.po = e(B, Nv, self._fused["proj_out.w"].shape[0])
+        hw = Nv // Fm if Fm > 1 else Nv
+        tg = torch.empty(N, dtype=torch.uint8)
+        tg[:Nt] = Fm
+        tg[Nt:N1] = (torch.arange(Nv) // hw).to(torch.uint8) if Fm > 1 else 0
+        tg[N1:] = Fm + 1
+        ws.tok_group = tg.to(dev)
+        self._ws = {key: ws}          # keep one shape resident
+        return ws
+
+    def _tables(self, ws, layer, Fm, which):
+        """Group table for norm{which} of `layer`: groups 0..Fm-1 video frames, Fm text, Fm+1 vip."""
+        D = self.inner_dim
+        per, _, _ = self._mod_cols()
+        base = layer * per
+        if self.use_vip:
+            main = base + (0 if which == 1 else 9 * D)
+            vip = main + 6 * D
+        else:
+            main = base + (0 if which == 1 else 6 * D)
+            vip = main
+        rows = list(range(Fm)) + [0, 0]
+        sh = [main] * Fm + [main + 3 * D, vip]
+        sc = [main + D] * Fm + [main + 4 * D, vip + D]
+        ga = [main + 2 * D] * Fm + [main + 5 * D, vip + 2 * D]
+        return K.GroupTable(ws.mod, ws.tok_group, rows, sh, sc, ga)
+
+    def _run_block(self, i, ws, B, Nt, Nv, Np, Fm, rope, vrope, crope):
+        """One CogVideoXBlock (cogvideox_transformer_3d.py:221-332 + attention_processor.py:1982-2155) on the
+        residual stream ws.X = text | video | vip, in place."""
+        c, D, H = self.config, self.inner_dim, self.config.num_attention_heads
+        F = self._fused
+        X = ws.X
+        N1, N = Nt + Nv, Nt + Nv + Np
+        use_vip = Np > 0
+        sm_scale = 1.0 / math.sqrt(64)
+        blk = self.transformer_blocks[i]
+        p = f"l{i}."
+        ln = F[p + "ln"]
+        t1 = self._tables(ws, i, Fm, 1)
+        K.adaln_modulate(X[:, :N1], ws.Xn[:, :N1], ln[0], ln[1], c.norm_eps, t1)
+        if use_vip:
+            vln = F[p + "vln"]
+            K.adaln_modulate(X[:, N1:], ws.Xn[:, N1:], vln[0], vln[1], c.norm_eps, t1.offset(N1))
+        # QKV projections (+ vip-weight projections over ALL tokens: x rows and vip rows share vip_to_*)
+        K.gemm(ws.Xn[:, :N1], F[p + "qkv.w"], F[p + "qkv.b"], ws.QKV, L.EPI_BIAS)
+        qn = F[p + "qknorm"]
+        K.qk_layernorm_rope(ws.QKV[:, :, :D], H, qn[0], qn[1], 1e-6, (Nt, rope))
+        K.qk_layernorm_rope(ws.QKV[:, :, D:2 * D], H, qn[2], qn[3], 1e-6, (Nt, rope))
+        K.transpose_v(ws.QKV[:, :, 2 * D:], H, 0, N1, ws.Vt1)
+        if use_vip:
+            K.gemm(ws.Xn, F[p + "vqkv.w"], F[p + "vqkv.b"], ws.QKVv, L.EPI_BIAS)
+            vqn = F[p + "vqknorm"]
+            K.qk_layernorm_rope(ws.QKVv[:, :, :D], H, vqn[0], vqn[1], 1e-6, (Nt, vrope), (N1, crope))
+            K.qk_layernorm_rope(ws.QKVv[:, :, D:2 * D], H, vqn[2], vqn[3], 1e-6, (Nt, vrope), (N1, crope))
+            K.transpose_v(ws.QKVv[:, :, 2 * D:], H, N1, Np, ws.Vt2)
+            K.transpose_v(ws.QKVv[:, :, 2 * D:], H, 0, N, ws.Vt3)
+            s = blk.attn1.processor.scale
+            s = float(s[0] if isinstance(s, (list, tuple)) else s)
+            # text+video rows: softmax(q k^T) v  +  s * softmax(qx kv^T) vv   (attention_processor.py:2066-2069,2117-2134)
+            K.attention(ws.QKV[:, :, :D], ws.QKV[:, :, D:2 * D], ws.Vt1, N1, ws.AO[:, :N1], H, sm_scale,
+                        ws.QKVv[:, :N1, :D], ws.QKVv[:, N1:, D:2 * D], ws.Vt2, Np, s)
+            # vip rows: qv against cat(kx, kv) / cat(vx, vv)                  (:2120-2125)
+            K.attention(ws.QKVv[:, N1:, :D], ws.QKVv[:, :, D:2 * D], ws.Vt3, N, ws.AO[:, N1:], H, sm_scale)
+        else:
+            K.attention(ws.QKV[:, :, :D], ws.QKV[:, :, D:2 * D], ws.Vt1, N1, ws.AO[:, :N1], H, sm_scale)
+        # out projection with the gated residual as epilogue (cogvideox_transformer_3d.py:290-293)
+        K.gemm(ws.AO, F[p + "out.w"], F[p + "out.b"], X, L.EPI_BIAS_GATE_RES, residual=X, gate=t1)
+        t2 = self._tables(ws, i, Fm, 2)
+        K.adaln_modulate(X[:, :N1], ws.Xn[:, :N1], ln[2], ln[3], c.norm_eps, t2)
+        if use_vip:
+            K.adaln_modulate(X[:, N1:], ws.Xn[:, N1:], vln[2], vln[3], c.norm_eps, t2.offset(N1))
+        # feed-forward over all tokens (same ff weights for the vip rows, :315-324)
+        K.gemm(ws.Xn, F[p + "ff1.w"], F[p + "ff1.b"], ws.FF, L.EPI_BIAS_GELU)
+        K.gemm(ws.FF, F[p + "ff2.w"], F[p + "ff2.b"], X, L.EPI_BIAS_GATE_RES, residual=X, gate=t2)
+
+
+    # ------------------------------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, hidden_states, encoder_hidden_states, timestep, vip_encoder_hidden_states=None,
+                timestep_cond=None, image_rotary_emb=None, vip_image_rotary_emb=None, vip_condition_rotary_emb=None,
+                vip_grid_t=None, attention_kwargs=None, return_dict=True):
+        """cogvideox_transformer_3d.py:636-770.  hidden_states [B,F,C,H,W] bf16 on the GPU."""
+        if timestep_cond is not None:
+            raise NotImplementedError("timestep_cond is unused by CogVideoX")
+        if attention_kwargs and attention_kwargs.get("attention_masks") is not None:
+            raise NotImplementedError("attention masks are not used on the TokensGen hot path")
+        if image_rotary_emb is None:
+            raise ValueError("image_rotary_emb is required (CogVideoX-5B uses rotary embeddings)")
+        c, D, H = self.config, self.inner_dim, self.config.num_attention_heads
+        F = self._fused
+        B, Fr, C, Hh, Ww = hidden_states.shape
+        hw = (Hh // 2) * (Ww // 2)
+        Nt, Nv = encoder_hidden_states.shape[1], Fr * hw
+        use_vip = self.use_vip
+        if use_vip:
+            if vip_encoder_hidden_states is None or vip_image_rotary_emb is None or vip_condition_rotary_emb is None:
+                raise ValueError("vip layers are set: vip_encoder_hidden_states and both vip rotary tables are required")
+            vb, vf, vc, vh, vw = vip_encoder_hidden_states.shape
+            Np = vf * vh * vw
+            if Np != self.vip_length:
+                raise ValueError(f"vip token count {Np} != configured length {self.vip_length}")
+        else:
+            Np = 0
+        N1, N = Nt + Nv, Nt + Nv + Np
+        timestep = torch.as_tensor(timestep, device=self._device)
+        if timestep.ndim == 0:
+            timestep = timestep.expand(B)
+        Fm = timestep.shape[1] if timestep.ndim == 2 else 1
+        if Fm not in (1, Fr):
+            raise ValueError("timestep must be [B] or [B, num_frames]")
+        ws = self._workspace(B, Nt, Nv, Np, Fm)
+        dev = lambda t: t.to(self._device, torch.float32).contiguous()
+        rope = tuple(dev(t) for t in image_rotary_emb)
+
+        # 1. timestep embedding -> silu(emb) -> every modulation vector of every layer in one GEMM
+        K.timestep_sinusoid(timestep.reshape(-1).to(torch.int64).contiguous(), D, ws.sin)
+        K.gemm(ws.sin, F["t1.w"], F["t1.b"], ws.t1, L.EPI_BIAS_SILU)
+        K.gemm(ws.t1, F["t2.w"], F["t2.b"], ws.semb, L.EPI_BIAS_SILU)     # block/out norms all consume silu(emb)
+        K.gemm(ws.semb.view(B, Fm, -1), F["mod.w"], F["mod.b"], ws.mod, L.EPI_BIAS)
+
+        # 2. patch / text / vip embeddings straight into the residual stream X = text | video | vip
+        X = ws.X
+        K.patchify(hidden_states.to(BF16).reshape(B * Fr, C, Hh, Ww).contiguous(), ws.patches.view(B * Nv, -1))
+        K.gemm(ws.patches, F["patch.w"], F["patch.b"], X[:, Nt:N1], L.EPI_BIAS)
+        K.gemm(encoder_hidden_states.to(BF16).contiguous(), F["text.w"], F["text.b"], X[:, :Nt], L.EPI_BIAS)
+        if use_vip:
+            vtok = vip_encoder_hidden_states.to(BF16).permute(0, 1, 3, 4, 2).reshape(B, Np, vc).contiguous()
+            K.gemm(vtok, F["vipproj.w"], F["vipproj.b"], X[:, N1:], L.EPI_BIAS)
+            vrope = tuple(dev(t) for t in vip_image_rotary_emb)
+            crope = tuple(dev(t) for t in vip_condition_rotary_emb)
+        # 3. blocks
+        for i in range(len(self.transformer_blocks)):
+            self._run_block(i, ws, B, Nt, Nv, Np, Fm, rope, vrope if use_vip else None, crope if use_vip else None)
+
+        # 4. final norm (per-token, so only the video rows matter), AdaLayerNorm(shift, scale), proj_out, unpatchify
+        fl = F["final.ln"]
+        vid, vidn, vid2 = X[:, Nt:N1], ws.Xn[:, Nt:N1], ws.AO[:, Nt:N1]
+        K.adaln_modulate(vid, vidn, fl[0], fl[1], c.norm_eps, None)
+        _, out_base, _ = self._mod_cols()
+        tout = K.GroupTable(ws.mod, ws.tok_group, list(range(Fm)) + [0, 0], [out_base] * (Fm + 2), [out_base + D] * (Fm + 2),
+                            [out_base] * (Fm + 2)).offset(Nt)
+        K.adaln_modulate(vidn, vid2, fl[2], fl[3], c.norm_eps, tout)
+        K.gemm(vid2, F["proj_out.w"], F["proj_out.b"], ws.po, L.EPI_BIAS)
+        out = torch.empty(B, Fr, c.out_channels, Hh, Ww, dtype=BF16, device=self._device)
+        K.unpatchify(ws.po.view(B * Nv, -1), out.view(B * Fr, c.out_channels, Hh, Ww))
+        if not return_dict:
+            return (out,)
+        return Transformer2DModelOutput(sample=out)

@@ -31,8 +31,9 @@ import importlib.util  # noqa: E402
 from oracle import dit_ref as O  # noqa: E402  (only for make_state_dict: seeded weights + names)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-TINY = dict(num_attention_heads=2, attention_head_dim=64, num_layers=2, patch_size=2, time_embed_dim=64,
-            text_embed_dim=32, in_channels=16, out_channels=16)
+# GEMM-tile friendly tiny config (every N % 128 == 0, K % 64 == 0 except proj_out, which the product pads)
+TINY = dict(num_attention_heads=2, attention_head_dim=64, num_layers=2, patch_size=2, time_embed_dim=128,
+            text_embed_dim=64, in_channels=16, out_channels=16)
 TINY_VIP = dict(length=5 * 2 * 3, func_type="1", scale=[0.6],
                 resampler_params=dict(output_dim=128, num_height_queries=2, num_width_queries=3,
                                       num_temporal_queries=4))
@@ -52,7 +53,8 @@ def sd_checksum(sd):
 
 def tiny_model(seed, vip=True, H=4, W=6):
     m = CogVideoXTransformer3DModel(num_attention_heads=2, attention_head_dim=64, num_layers=2, in_channels=16,
-                                    out_channels=16, text_embed_dim=32, time_embed_dim=64, sample_width=W,
+                                    out_channels=16, text_embed_dim=TINY["text_embed_dim"],
+                                    time_embed_dim=TINY["time_embed_dim"], sample_width=W,
                                     sample_height=H, sample_frames=49, use_rotary_positional_embeddings=True,
                                     max_text_seq_length=8)
     if vip:
@@ -64,7 +66,7 @@ def tiny_model(seed, vip=True, H=4, W=6):
 
 def tiny_inputs(seed, B=2, H=4, W=6):
     g = torch.Generator().manual_seed(seed)
-    return dict(hs=torch.randn(B, 13, 16, H, W, generator=g), enc=torch.randn(B, 8, 32, generator=g),
+    return dict(hs=torch.randn(B, 13, 16, H, W, generator=g), enc=torch.randn(B, 8, TINY["text_embed_dim"], generator=g),
                 vip=torch.randn(B, 5, 128, 2, 3, generator=g), ts=torch.randint(0, 1000, (B, 13), generator=g))
 
 
@@ -217,7 +219,7 @@ def gen_fifo(num_chunks=2, dtype=torch.float32, tag="fifo_tiny"):
     fifo_latents = torch.randn(1, T, 16, H, W, generator=g).to(dtype)
     # base stage pushes to the FRONT each step (pipeline_cogvideox_mp_fifo.py:1190-1194): entry 51 (noisiest) has no x0 yet
     fifo_old = [torch.randn(1, 1, 16, H, W, generator=g).to(dtype) for _ in range(T - 1)] + [None]
-    prompt = torch.randn(2, 8, 32, generator=g).to(dtype)
+    prompt = torch.randn(2, 8, TINY["text_embed_dim"], generator=g).to(dtype)
     n_groups = 4 * (num_chunks + 1)
     image_embeddings = torch.randn(1, n_groups, 128, 2, 3, generator=g).to(dtype).repeat(2, 1, 1, 1, 1)
     f32 = np.float32
