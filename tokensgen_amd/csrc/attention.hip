@@ -24,7 +24,7 @@
 
 namespace {
 
-constexpr int QTILE = 128, KVBLK = 64;
+constexpr int KVBLK = 64;
 constexpr int TILE_B = 64 * 128;   // one 64x64 bf16 tile
 
 struct Seg {
@@ -47,14 +47,19 @@ __device__ __forceinline__ int pi_row(int i) {   // swap bits 2 and 3
 }
 __device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
+// QB = 32-row query blocks per wave (1 or 2).  QB=2 shares every K / V^T fragment read between two query
+// blocks (half the LDS and L2 traffic per MFMA); QB=1 gives 2x the workgroups for short query ranges.
+template <int QB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // K[2], Vt[2]
+    constexpr int QT = 128 * QB;
+    constexpr float RESCALE_THR = 8.0f;   // log2 units: skip the O rescale while the row max grows < 2^8
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int hi = lane >> 5, j = lane & 31;
 
-    const int nqt = (p.nq + QTILE - 1) / QTILE;
+    const int nqt = (p.nq + QT - 1) / QT;
     const int nhb = p.heads * p.batch;
     int hb, qt;
     if ((nhb & 7) == 0) {
@@ -66,8 +71,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         qt = blockIdx.x % nqt;
     }
     const int h = hb % p.heads, b = hb / p.heads;
-    const int q0 = qt * QTILE + wave * 32;
-    const int qrow = min(q0 + j, p.nq - 1);
+    const int q0 = qt * QT + wave * (32 * QB);
 
     // staging map: chunk c in [0,512): row = c>>3, slot = c&7 ; this thread owns chunks tid and tid+256
     const int r0 = tid >> 3, sl = tid & 7;
@@ -84,18 +88,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) offV[db][ks] = swz(db * 32 + j, ks * 2 + hi);
 
-    float res[2][16];
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) res[db][r] = 0.f;
-
     for (int sg = 0; sg < p.nseg; ++sg) {
         const Seg& S = p.s[sg];
-        const bf16_t* qp = S.q + (long)b * S.q_sb + (long)qrow * S.q_ld + h * 64 + hi * 8;
-        bf16x8 qf[4];
+        bf16x8 qf[QB][4];
 #pragma unroll
-        for (int kd = 0; kd < 4; ++kd) qf[kd] = *(const bf16x8*)(qp + kd * 16);
+        for (int qb = 0; qb < QB; ++qb) {
+            const int qrow = min(q0 + qb * 32 + j, p.nq - 1);
+            const bf16_t* qp = S.q + (long)b * S.q_sb + (long)qrow * S.q_ld + h * 64 + hi * 8;
+#pragma unroll
+            for (int kd = 0; kd < 4; ++kd) qf[qb][kd] = *(const bf16x8*)(qp + kd * 16);
+        }
 
         const bf16_t* kbase = S.k + (long)b * S.k_sb + h * 64 + sl * 8;
         const bf16_t* vbase = S.vt + ((long)(b * p.heads + h) * 64) * S.vt_ld + sl * 8;
@@ -116,12 +118,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
             *(uint4*)(vb_ + ldsoff0) = vr0; *(uint4*)(vb_ + ldsoff1) = vr1;
         };
 
-        f32x16 acc_o[2];
+        f32x16 acc_o[QB][2];
+        float m[QB], l[QB];
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int qb = 0; qb < QB; ++qb) {
+            m[qb] = -1e30f; l[qb] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
-        float m = -1e30f, l = 0.f;
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[qb][db][r] = 0.f;
+        }
 
         gload(0);
         lwrite(0);
@@ -133,89 +139,118 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
             const char* tK = smem + cur * TILE_B;
             const char* tV = smem + (2 + cur) * TILE_B;
 
-            // ---- S^T = K Q^T : 2 key blocks x 4 d-steps ----
-            f32x16 sc[2];
+            // ---- S^T = K Q^T : 2 key blocks x 4 d-steps, every K fragment feeds all QB query blocks ----
+            f32x16 sc[QB][2];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int kd = 0; kd < 4; ++kd) {
+                    for (int r = 0; r < 16; ++r) sc[qb][kb][r] = 0.f;
+#pragma unroll
+            for (int kd = 0; kd < 4; ++kd) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
                     const bf16x8 kf = *(const bf16x8*)(tK + offK[kb][kd]);
-                    sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kd], sc[kb], 0, 0, 0);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb)
+                        sc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][kd], sc[qb][kb], 0, 0, 0);
                 }
             }
             // ---- mask the ragged last tile: reg r of block kb is key t*64 + kb*32 + 16*(r>>3) + 8*hi + (r&7)
             if ((t + 1) * KVBLK > S.nk) {
 #pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = t * KVBLK + kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                            if (key >= S.nk) sc[qb][kb][r] = -1e30f;
+                        }
+            }
+            // ---- online softmax (log2 domain), lane-local row; P packed to bf16 MFMA operands in place ----
+            bf16x8 pf[QB][4];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float mx = sc[qb][0][0];
+#pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = t * KVBLK + kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
-                        if (key >= S.nk) sc[kb][r] = -1e30f;
-                    }
-            }
-            // ---- online softmax (log2 domain), lane-local row ----
-            float mx = sc[0][0];
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[qb][kb][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;
+                // defer the rescale while the running max grows by less than 2^THR (wave-uniform decision)
+                if (__any(mx > m[qb] + RESCALE_THR)) {
+                    const float m_new = fmaxf(m[qb], mx);
+                    const float alpha = __builtin_amdgcn_exp2f(m[qb] - m_new);
+                    m[qb] = m_new;
+                    l[qb] *= alpha;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                    for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m, mx * p.scale_log2);
-            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-            m = m_new;
-            float ls = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(sc[kb][r] * p.scale_log2 - m_new);
-                    sc[kb][r] = e;
-                    ls += e;
+                        for (int r = 0; r < 16; ++r) acc_o[qb][db][r] *= alpha;
                 }
-            l = l * alpha + ls;
+                const float mq = m[qb];
+                float ls = 0.f;
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int kb = ks >> 1, rb = (ks & 1) * 8;
+                    float e[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
-
-            // ---- O^T += V^T P^T : P straight from the score registers ----
+                    for (int i = 0; i < 8; ++i) {
+                        e[i] = __builtin_amdgcn_exp2f(sc[qb][kb][rb + i] * p.scale_log2 - mq);
+                        ls += e[i];
+                    }
+                    union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pk.u[i] = pack_bf16x2(e[2 * i], e[2 * i + 1]);
+                    pf[qb][ks] = pk.v;
+                }
+                l[qb] += ls;
+            }
+            // ---- O^T += V^T P^T : every V^T fragment feeds all QB query blocks ----
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int kb = ks >> 1, rb = (ks & 1) * 8;
-                union { bf16x8 v; uint32_t u[4]; } pf;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pf.u[i] = pack_bf16x2(sc[kb][rb + 2 * i], sc[kb][rb + 2 * i + 1]);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const bf16x8 vf = *(const bf16x8*)(tV + offV[db][ks]);
-                    acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, acc_o[db], 0, 0, 0);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb)
+                        acc_o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][ks], acc_o[qb][db], 0, 0, 0);
                 }
             }
             if (t + 1 < ntiles) lwrite(cur ^ 1);
             __syncthreads();
         }
-        const float lt = l + __shfl_xor(l, 32, 64);
-        const float w = (sg == 0 ? 1.f : p.seg2_scale) / lt;
+        // ---- segment epilogue: normalise and write (segment 2 accumulates onto segment 1's bf16 result, like the
+        //      reference's `hidden_states + scale * text_video_hidden_states` on bf16 tensors) ----
+        //      lane holds O[q0 + qb*32 + j][d = db*32 + 8*(r>>2) + 4*hi + (r&3)]
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int qb = 0; qb < QB; ++qb) {
+            const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
+            const float w = (sg == 0 ? 1.f : p.seg2_scale) / lt;
+            const int q = q0 + qb * 32 + j;
+            if (q < p.nq) {
+                bf16_t* op = p.out + (long)b * p.o_sb + (long)q * p.o_ld + h * 64;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) res[db][r] += acc_o[db][r] * w;
-    }
-
-    // ---- store: lane holds O[q0+j][d = db*32 + 8*(r>>2) + 4*hi + (r&3)] ----
-    if (q0 + j < p.nq) {
-        bf16_t* op = p.out + (long)b * p.o_sb + (long)(q0 + j) * p.o_ld + h * 64;
+                for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                uint2 o;
-                o.x = pack_bf16x2(res[db][g4 * 4 + 0], res[db][g4 * 4 + 1]);
-                o.y = pack_bf16x2(res[db][g4 * 4 + 2], res[db][g4 * 4 + 3]);
-                *(uint2*)(op + db * 32 + g4 * 8 + hi * 4) = o;
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        uint2* dst = (uint2*)(op + db * 32 + g4 * 8 + hi * 4);
+                        float v0 = acc_o[qb][db][g4 * 4 + 0] * w, v1 = acc_o[qb][db][g4 * 4 + 1] * w;
+                        float v2 = acc_o[qb][db][g4 * 4 + 2] * w, v3 = acc_o[qb][db][g4 * 4 + 3] * w;
+                        if (sg > 0) {
+                            const uint2 prev = *dst;
+                            v0 = bf16lo_to_f32(prev.x) + round_bf16(v0); v1 = bf16hi_to_f32(prev.x) + round_bf16(v1);
+                            v2 = bf16lo_to_f32(prev.y) + round_bf16(v2); v3 = bf16hi_to_f32(prev.y) + round_bf16(v3);
+                        }
+                        uint2 o;
+                        o.x = pack_bf16x2(v0, v1);
+                        o.y = pack_bf16x2(v2, v3);
+                        *dst = o;
+                    }
             }
+        }
     }
 }
 
@@ -248,8 +283,14 @@ extern "C" int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
     p.out = (bf16_t*)out; p.o_ld = out_ld; p.o_sb = out_strideB;
     p.nq = nq; p.heads = heads; p.batch = batch;
     p.scale_log2 = scale * 1.4426950408889634f;
-    const int nqt = (nq + QTILE - 1) / QTILE;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(nqt * heads * batch)), dim3(256), 0, stream, p);
+    // 256-row query tiles (2 query blocks per wave) once they still give >= 4 workgroups per CU, else 128-row tiles
+    const long wg256 = (long)((nq + 255) / 256) * heads * batch;
+    if (wg256 >= 1024) {
+        hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)wg256), dim3(256), 0, stream, p);
+    } else {
+        const int nqt = (nq + 127) / 128;
+        hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3((unsigned)(nqt * heads * batch)), dim3(256), 0, stream, p);
+    }
     TG_LAUNCH_CHECK("tg_attention_fwd");
     return TG_OK;
 }

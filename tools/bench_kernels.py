@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks at the CogVideoX-5B To2V shapes (GPU box only): TFLOP/s per hot kernel.
+Usage: python tools/bench_kernels.py [attn] [gemm] [norm]"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tokensgen_amd import kernels as K  # noqa: E402
+from tokensgen_amd import lib as L  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+B, H, D, NT, NV, NP = 2, 48, 3072, 226, 17550, 480
+N1, N = NT + NV, NT + NV + NP
+
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(iters):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record()
+        evs.append((s, e))
+    torch.cuda.synchronize()
+    ms = sorted(s.elapsed_time(e) for s, e in evs)
+    return ms[len(ms) // 2]
+
+
+def rnd(*shape, scale=1.0):
+    return (torch.randn(*shape, device=DEV, dtype=torch.float32) * scale).to(BF)
+
+
+def bench_attn():
+    qkv = rnd(B, N1, 3 * D)
+    qkvv = rnd(B, N, 3 * D)
+    pad = lambda n: (n + 63) // 64 * 64
+    vt1 = torch.empty(B, H, 64, pad(N1), dtype=BF, device=DEV)
+    vt2 = torch.empty(B, H, 64, pad(NP), dtype=BF, device=DEV)
+    vt3 = torch.empty(B, H, 64, pad(N), dtype=BF, device=DEV)
+    K.transpose_v(qkv[:, :, 2 * D:], H, 0, N1, vt1)
+    K.transpose_v(qkvv[:, :, 2 * D:], H, N1, NP, vt2)
+    K.transpose_v(qkvv[:, :, 2 * D:], H, 0, N, vt3)
+    ao = torch.empty(B, N, D, dtype=BF, device=DEV)
+    f_main = lambda: K.attention(qkv[:, :, :D], qkv[:, :, D:2 * D], vt1, N1, ao[:, :N1], H, 0.125,
+                                 qkvv[:, :N1, :D], qkvv[:, N1:, D:2 * D], vt2, NP, 0.6)
+    f_vip = lambda: K.attention(qkvv[:, N1:, :D], qkvv[:, :, D:2 * D], vt3, N, ao[:, N1:], H, 0.125)
+    ms = timeit(f_main)
+    fl = B * (4.0 * N1 * N1 * D + 4.0 * N1 * NP * D)
+    print(json.dumps({"kernel": "attention_main_2seg", "ms": ms, "tflops": fl / ms / 1e9}))
+    ms = timeit(f_vip)
+    print(json.dumps({"kernel": "attention_vip", "ms": ms, "tflops": B * 4.0 * NP * N * D / ms / 1e9}))
+
+
+def bench_gemm():
+    for (M, Nn, Kk, epi, name) in [(N1, 3 * D, D, L.EPI_BIAS, "qkv"), (N, D, D, L.EPI_BIAS, "out(bias)"),
+                                   (N, 4 * D, D, L.EPI_BIAS_GELU, "ff1"), (N, D, 4 * D, L.EPI_BIAS, "ff2(bias)")]:
+        a, w, bias = rnd(B, M, Kk), rnd(Nn, Kk, scale=0.02), rnd(Nn)
+        out = torch.empty(B, M, Nn, dtype=BF, device=DEV)
+        ms = timeit(lambda: K.gemm(a, w, bias, out, epi))
+        print(json.dumps({"kernel": f"gemm_{name}_M{M}_N{Nn}_K{Kk}", "ms": ms, "tflops": 2.0 * B * M * Nn * Kk / ms / 1e9}))
+
+
+def bench_norm():
+    x, y = rnd(B, N, D), torch.empty(B, N, D, dtype=BF, device=DEV)
+    w, b = rnd(D), rnd(D)
+    ms = timeit(lambda: K.adaln_modulate(x, y, w, b, 1e-5, None))
+    print(json.dumps({"kernel": "adaln(plain)", "ms": ms, "GBps": 2 * x.numel() * 2 / ms / 1e6}))
+    qkv = rnd(B, N, 3 * D)
+    ms = timeit(lambda: K.qk_layernorm_rope(qkv[:, :, :D], H, w[:64], b[:64], 1e-6))
+    print(json.dumps({"kernel": "qk_layernorm_rope", "ms": ms, "GBps": 2 * B * N * D * 2 / ms / 1e6}))
+    vt = torch.empty(B, H, 64, (N + 63) // 64 * 64, dtype=BF, device=DEV)
+    ms = timeit(lambda: K.transpose_v(qkv[:, :, 2 * D:], H, 0, N, vt))
+    print(json.dumps({"kernel": "transpose_v", "ms": ms, "GBps": 2 * B * N * D * 2 / ms / 1e6}))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["attn", "gemm", "norm"]
+    if "attn" in what:
+        bench_attn()
+    if "gemm" in what:
+        bench_gemm()
+    if "norm" in what:
+        bench_norm()
