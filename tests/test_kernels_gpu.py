@@ -47,7 +47,8 @@ def _gather(mod, tok_group, rows, cols, D):
     return mod.float()[:, r[:, None], idx]
 
 
-@pytest.mark.parametrize("M,N,K_,B", [(300, 256, 192, 2), (128, 128, 64, 1), (26, 384, 128, 1), (1031, 512, 320, 3)])
+@pytest.mark.parametrize("M,N,K_,B", [(300, 256, 192, 2), (128, 128, 64, 1), (26, 384, 128, 1), (1031, 512, 320, 3),
+                                      (2050, 768, 1024, 2), (1024, 256, 64, 1), (1500, 384, 128, 1)])
 def test_gemm_bias(K, M, N, K_, B):
     from tokensgen_amd import lib as L
     a_full = _rand(B, M + 5, K_ + 8, seed=1)            # strided views: row stride and batch stride differ from M,K
@@ -84,9 +85,10 @@ def test_gemm_gelu_silu(K):
     assert _rel(out, torch.nn.functional.silu(pre)) < 6e-3
 
 
-def test_gemm_gate_residual_inplace(K):
+@pytest.mark.parametrize("M", [333, 1111])     # 128^2 kernel / 256^2 ping-pong kernel
+def test_gemm_gate_residual_inplace(K, M):
     from tokensgen_amd import lib as L
-    B, M, N, K_ = 2, 333, 256, 128
+    B, N, K_ = 2, 256, 128
     a, w, bias = _rand(B, M, K_, seed=1), _rand(N, K_, seed=2, scale=0.1), _rand(N, seed=3)
     x = _rand(B, M, N, seed=4)
     tab, mod, tg, r, sh, sc, ga = _table(K, B, 7, N, 5, M, seed=9)

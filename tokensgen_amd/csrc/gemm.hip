@@ -15,6 +15,8 @@
 //   * block ids are remapped XCD-aware and grouped 8 m-tiles x n so the tiles resident on one XCD share
 //     A/W panels in that XCD's L2.
 //   * M edge: rows >= M are clamped on load and predicated on store.  N % 128 == 0, K % 64 == 0.
+#include <stdlib.h>
+
 #include "common.h"
 #include "tokensgen_hip.h"
 
@@ -24,6 +26,7 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + W
 constexpr int GROUP_M = 8;
+bool g_force_128 = false;   // debugging knob (TG_GEMM_FORCE_128=1): route everything through the 128^2 kernel
 
 struct GemmParams {
     const bf16_t* A; long lda; long sAb;
@@ -183,8 +186,213 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     }
 }
 
+// ================================================================================================
+// 256x256x64 tile, 8 waves (2 M-groups x 4 N-columns, 128x64 per wave), "ping-pong" schedule.
+//
+// Why: a 128x128 tile needs ~39 TB/s of L2->LDS fill at full MFMA rate (more than the chip has) and every
+// wave stalls together at the per-k-tile barrier.  Here the tile traffic per MFMA is halved and the two waves
+// that share a SIMD (wave w of group 0 and wave w+4 of group 1) alternate roles every phase: while one
+// issues its 16 MFMAs (one 64x32 quadrant of its output, K=64), the other does its ds_read_b128 fragment
+// loads and issues its share of the next k-tile's LDS-DMA.  Group 1 simply runs one barrier behind group 0.
+//   per wave per k-tile: 4 phases = {LOAD (ds_read + glds) | s_barrier | 16 MFMA | s_barrier}
+//   LDS: 2 buffers x (A 256x64 + W 256x64) bf16 = 128 KiB, same 16-B-slot swizzle as the 128^2 kernel.
+//   glds for tile t+1 are issued in phases 0/1 of tile t and retired (vmcnt(0)) in phase 3, one barrier
+//   before their first reader; buffer reuse is fenced by lgkmcnt(0)+barrier after the last reader.
+// ================================================================================================
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int TILE2_BYTES = BM2 * BK * 2;        // 32 KiB per operand tile
+constexpr int STAGE2_BYTES = 2 * TILE2_BYTES;    // 64 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+
+    const int tiles_m = (p.M + BM2 - 1) / BM2, tiles_n = p.N / BN2;
+    const int per_batch = tiles_m * tiles_n;
+    const int nwg = per_batch * p.batch;
+    int t = xcd_remap(blockIdx.x, nwg);
+    const int b = t / per_batch;
+    t -= b * per_batch;
+    const int per_group = GROUP_M * tiles_n;
+    const int gi = t / per_group;
+    const int first_m = gi * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int in_g = t - gi * per_group;
+    const int tm = first_m + in_g % gsz, tn = in_g / gsz;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+    const bf16_t* Ab = p.A + (long)b * p.sAb;
+
+    // LDS-DMA sources: wave-instruction i covers tile rows [wave*32 + i*8, +8)
+    const char* srcA[4];
+    const char* srcW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave * 32 + i * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((r >> 1) & 7);
+        srcA[i] = (const char*)(Ab + (long)min(m0 + r, p.M - 1) * p.lda + slot * 8);
+        srcW[i] = (const char*)(p.W + (long)(n0 + r) * p.ldw + slot * 8);
+    }
+    auto stageA = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE2_BYTES + wave * (32 * 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + (long)kt * (BK * 2)),
+                                             (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+    };
+    auto stageW = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE2_BYTES + TILE2_BYTES + wave * (32 * 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + (long)kt * (BK * 2)),
+                                             (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+    };
+
+    // fragment offsets: row = base + f*16 (same swizzle term for every f); ks toggles slot bit 2 (byte ^ 64)
+    const int rA = grp * 128 + (lane & 15), rW = wn * 64 + (lane & 15);
+    const int offA0 = rA * 128 + (((lane >> 4) ^ ((rA >> 1) & 7)) << 4);
+    const int offW0 = rW * 128 + (((lane >> 4) ^ ((rW >> 1) & 7)) << 4);
+
+    f32x4 acc[8][4];   // [m frag][n frag]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[4][2], fw[2][2];   // current A half (4 m-frags x 2 k-steps), current W half (2 n-frags x 2 k-steps)
+
+    auto loadA = [&](const char* tA, int qm) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                fa[f][ks] = *(const bf16x8*)(tA + ((offA0 + (qm * 64 + f * 16) * 128) ^ (ks * 64)));
+    };
+    auto loadW = [&](const char* tW, int qn) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                fw[f][ks] = *(const bf16x8*)(tW + ((offW0 + (qn * 32 + f * 16) * 128) ^ (ks * 64)));
+    };
+#define TG_BAR()                                         \
+    do {                                                 \
+        __builtin_amdgcn_sched_barrier(0);               \
+        __builtin_amdgcn_s_barrier();                    \
+        __builtin_amdgcn_sched_barrier(0);               \
+    } while (0)
+#define TG_COMPUTE(QM, QN)                                                                                  \
+    do {                                                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                      \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
+            _Pragma("unroll") for (int f = 0; f < 4; ++f)                                                   \
+                _Pragma("unroll") for (int n = 0; n < 2; ++n)                                               \
+                    acc[(QM) * 4 + f][(QN) * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(              \
+                        fw[n][ks], fa[f][ks], acc[(QM) * 4 + f][(QN) * 2 + n], 0, 0, 0);                    \
+        __builtin_amdgcn_s_setprio(0);                                                                      \
+    } while (0)
+
+    const int nk = p.K / BK;
+    stageA(0, 0);
+    stageW(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TG_BAR();
+    if (grp == 1) TG_BAR();   // group 1 runs one barrier (= one phase half) behind group 0
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const char* tA = smem + cur * STAGE2_BYTES;
+        const char* tW = tA + TILE2_BYTES;
+        const bool more = kt + 1 < nk;
+        // phase 0: quadrant (0,0)
+        loadW(tW, 0);
+        loadA(tA, 0);
+        if (more) stageA(cur ^ 1, kt + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TG_BAR();
+        TG_COMPUTE(0, 0);
+        TG_BAR();
+        // phase 1: quadrant (0,1)
+        loadW(tW, 1);
+        if (more) stageW(cur ^ 1, kt + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TG_BAR();
+        TG_COMPUTE(0, 1);
+        TG_BAR();
+        // phase 2: quadrant (1,1)
+        loadA(tA, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TG_BAR();
+        TG_COMPUTE(1, 1);
+        TG_BAR();
+        // phase 3: quadrant (1,0); retire this wave's LDS-DMA for tile kt+1 one barrier before its first reader
+        loadW(tW, 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        TG_BAR();
+        TG_COMPUTE(1, 0);
+        TG_BAR();
+    }
+    if (grp == 0) TG_BAR();
+#undef TG_BAR
+#undef TG_COMPUTE
+
+    // ---- epilogue: lane holds D[n = (lane>>4)*4 + r][m = lane&15] per fragment ----
+    bf16_t* Cb = p.C + (long)b * p.sCb;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = m0 + grp * 128 + mi * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const bf16_t* gate_row = nullptr;
+        if (EPI == TG_EPI_BIAS_GATE_RES) {
+            const int g = p.g.tok_group[m];
+            gate_row = (const bf16_t*)p.g.mod + (long)b * p.g.mod_batch_stride + (long)p.g.row[g] * p.g.mod_ld + p.g.gate_col[g];
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+            float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+            if (p.bias) {
+                const uint2 bb = *(const uint2*)(p.bias + n);
+                v[0] += bf16lo_to_f32(bb.x); v[1] += bf16hi_to_f32(bb.x);
+                v[2] += bf16lo_to_f32(bb.y); v[3] += bf16hi_to_f32(bb.y);
+            }
+            if (EPI == TG_EPI_BIAS_GELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = gelu_tanh(round_bf16(v[i]));
+            } else if (EPI == TG_EPI_BIAS_SILU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = silu(round_bf16(v[i]));
+            } else if (EPI == TG_EPI_BIAS_GATE_RES) {
+                const uint2 gg = *(const uint2*)(gate_row + n);
+                const uint2 rr = *(const uint2*)(p.R + (long)b * p.sRb + (long)m * p.ldr + n);
+                v[0] = bf16lo_to_f32(rr.x) + bf16lo_to_f32(gg.x) * v[0];
+                v[1] = bf16hi_to_f32(rr.x) + bf16hi_to_f32(gg.x) * v[1];
+                v[2] = bf16lo_to_f32(rr.y) + bf16lo_to_f32(gg.y) * v[2];
+                v[3] = bf16hi_to_f32(rr.y) + bf16hi_to_f32(gg.y) * v[3];
+            }
+            uint2 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            *(uint2*)(Cb + (long)m * p.ldc + n) = o;
+        }
+    }
+}
+
 template <int EPI>
 int launch(const GemmParams& p, hipStream_t stream) {
+    if (p.M >= 1024 && p.N % BN2 == 0 && !g_force_128) {   // large-M shapes: 256^2 ping-pong kernel
+        const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2) * p.batch;
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES);
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(tiles2), dim3(512), 2 * STAGE2_BYTES, stream, p);
+        TG_LAUNCH_CHECK("tg_gemm_bf16(256)");
+        return TG_OK;
+    }
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN) * p.batch;
     static bool attr_set = false;
     if (!attr_set) {
@@ -207,6 +415,8 @@ extern "C" int tg_gemm_bf16(const void* A, long lda, long strideA, const void* W
     TG_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && strideA % 8 == 0 && strideC % 4 == 0, TG_ERR_ALIGN,
                "tg_gemm_bf16: leading dimensions must keep 16-byte (A, W) / 8-byte (C) alignment");
     TG_REQUIRE(tg_aligned16(A) && tg_aligned16(W) && (((uintptr_t)C) & 7) == 0, TG_ERR_ALIGN, "tg_gemm_bf16: unaligned base pointer");
+    static const bool env_init = [] { const char* e = getenv("TG_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; return true; }();
+    (void)env_init;
     GemmParams p{};
     p.A = (const bf16_t*)A; p.lda = lda; p.sAb = strideA;
     p.W = (const bf16_t*)W; p.ldw = ldw;
