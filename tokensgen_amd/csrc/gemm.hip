@@ -192,12 +192,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 // Why: a 128x128 tile needs ~39 TB/s of L2->LDS fill at full MFMA rate (more than the chip has) and every
 // wave stalls together at the per-k-tile barrier.  Here the tile traffic per MFMA is halved and the two waves
 // that share a SIMD (wave w of group 0 and wave w+4 of group 1) alternate roles every phase: while one
-// issues its 16 MFMAs (one 64x32 quadrant of its output, K=64), the other does its ds_read_b128 fragment
-// loads and issues its share of the next k-tile's LDS-DMA.  Group 1 simply runs one barrier behind group 0.
-//   per wave per k-tile: 4 phases = {LOAD (ds_read + glds) | s_barrier | 16 MFMA | s_barrier}
+// issues its 8 MFMAs (v_mfma_f32_32x32x16_bf16: one 64x32 quadrant of its output, K=64), the other does its
+// ds_read_b128 fragment loads and issues its share (2 pieces) of the next k-tile's LDS-DMA.  Group 1 simply
+// runs one barrier behind group 0, so per SIMD one wave is always in its MFMA phase.
+//   per wave per k-tile: 4 phases = {LOAD (ds_read + 2 glds + counted vmcnt) | s_barrier | 8 MFMA | s_barrier}
 //   LDS: 2 buffers x (A 256x64 + W 256x64) bf16 = 128 KiB, same 16-B-slot swizzle as the 128^2 kernel.
-//   glds for tile t+1 are issued in phases 0/1 of tile t and retired (vmcnt(0)) in phase 3, one barrier
-//   before their first reader; buffer reuse is fenced by lgkmcnt(0)+barrier after the last reader.
+// LDS-DMA ordering.  Call "interval" the time between two consecutive barriers; tile t occupies intervals
+// 8t..8t+7 for group 0 (LOAD p at 8t+2p, MFMA at 8t+2p+1) and one later for group 1.  The 64 pieces of tile
+// t+1 are issued region by region in the order they will be needed:
+//     8t+0 g0: A(0,0)   8t+1 g1: A(1,0)   8t+2 g0: W(*,0)a   8t+3 g1: W(*,0)b
+//     8t+4 g0: W(*,1)a  8t+5 g1: W(*,1)b  8t+6 g0: A(0,1)    8t+7 g1: A(1,1)
+// (A(g,h) = 64 A rows of group g, half h; W(*,h) = the 32-row half h of every wave column).  Every LOAD phase
+// ends with `s_waitcnt vmcnt(4)`: the pieces a wave issued two phases ago have landed, and the barrier that
+// follows publishes them one interval before their first reader (worked through in DESIGN.md).  A buffer is
+// only rewritten after the lgkmcnt(0)+barrier that follows its last reader.  Never vmcnt(0) in the loop.
 // ================================================================================================
 constexpr int BM2 = 256, BN2 = 256;
 constexpr int TILE2_BYTES = BM2 * BK * 2;        // 32 KiB per operand tile
@@ -226,56 +234,61 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     const int m0 = tm * BM2, n0 = tn * BN2;
     const bf16_t* Ab = p.A + (long)b * p.sAb;
 
-    // LDS-DMA sources: wave-instruction i covers tile rows [wave*32 + i*8, +8)
-    const char* srcA[4];
-    const char* srcW[4];
+    // ---- LDS-DMA pieces of this wave: phase ph -> 2 pieces (8 rows each) of one region (see header) ----
+    //   ph:   0        1         2         3
+    //   g0:  A(0,0)   W(*,0)a   W(*,1)a   A(0,1)        W(*,h)a = wave columns 0,1 ; W(*,h)b = wave columns 2,3
+    //   g1:  A(1,0)   W(*,0)b   W(*,1)b   A(1,1)
+    const char* src[4][2];
+    int dst[4][2];       // byte offset inside a stage (A tile at 0, W tile at TILE2_BYTES), wave-uniform
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wave * 32 + i * 8 + (lane >> 3);
-        const int slot = (lane & 7) ^ ((r >> 1) & 7);
-        srcA[i] = (const char*)(Ab + (long)min(m0 + r, p.M - 1) * p.lda + slot * 8);
-        srcW[i] = (const char*)(p.W + (long)(n0 + r) * p.ldw + slot * 8);
+    for (int ph = 0; ph < 4; ++ph) {
+        const bool isA = (ph == 0 || ph == 3);
+        const int half = (ph >= 2 && !isA) || ph == 3 ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int row0;   // first row of the 8-row piece (wave-uniform)
+            if (isA) row0 = grp * 128 + half * 64 + (2 * wn + i) * 8;
+            else row0 = (2 * grp + (wn >> 1)) * 64 + half * 32 + (wn & 1) * 16 + i * 8;
+            const int r = row0 + (lane >> 3);
+            const int slot = (lane & 7) ^ ((r >> 1) & 7);
+            src[ph][i] = isA ? (const char*)(Ab + (long)min(m0 + r, p.M - 1) * p.lda + slot * 8)
+                             : (const char*)(p.W + (long)(n0 + r) * p.ldw + slot * 8);
+            dst[ph][i] = (isA ? 0 : TILE2_BYTES) + row0 * 128;
+        }
     }
-    auto stageA = [&](int buf, int kt) {
-        char* base = smem + buf * STAGE2_BYTES + wave * (32 * 128);
+    auto stage = [&](int buf, int kt, int ph) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + (long)kt * (BK * 2)),
-                                             (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
-    };
-    auto stageW = [&](int buf, int kt) {
-        char* base = smem + buf * STAGE2_BYTES + TILE2_BYTES + wave * (32 * 128);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + (long)kt * (BK * 2)),
-                                             (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[ph][i] + (long)kt * (BK * 2)),
+                                             (__attribute__((address_space(3))) void*)(smem + buf * STAGE2_BYTES + dst[ph][i]), 16, 0, 0);
     };
 
-    // fragment offsets: row = base + f*16 (same swizzle term for every f); ks toggles slot bit 2 (byte ^ 64)
-    const int rA = grp * 128 + (lane & 15), rW = wn * 64 + (lane & 15);
-    const int offA0 = rA * 128 + (((lane >> 4) ^ ((rA >> 1) & 7)) << 4);
-    const int offW0 = rW * 128 + (((lane >> 4) ^ ((rW >> 1) & 7)) << 4);
+    // ---- fragment offsets (32x32x16 operands: lane -> row lane&31, 16-B slot ks*2 + (lane>>5)) ----
+    // row = base(multiple of 32) + (lane&31): one swizzle term per lane; ks advances the slot by 2 (byte ^ ks*32)
+    const int j31 = lane & 31, hi = lane >> 5;
+    const int sw = (j31 >> 1) & 7;
+    const int offA0 = (grp * 128 + j31) * 128 + ((hi ^ sw) << 4);
+    const int offW0 = (wn * 64 + j31) * 128 + ((hi ^ sw) << 4);
 
-    f32x4 acc[8][4];   // [m frag][n frag]
+    f32x16 acc[4][2];   // [32-row m block][32-col n block]
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 fa[4][2], fw[2][2];   // current A half (4 m-frags x 2 k-steps), current W half (2 n-frags x 2 k-steps)
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+    bf16x8 fa[2][4], fw[4];   // current A half (2 m-blocks x 4 k-steps), current W half (4 k-steps)
 
     auto loadA = [&](const char* tA, int qm) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                fa[f][ks] = *(const bf16x8*)(tA + ((offA0 + (qm * 64 + f * 16) * 128) ^ (ks * 64)));
+            for (int ks = 0; ks < 4; ++ks)
+                fa[mb][ks] = *(const bf16x8*)(tA + ((offA0 + (qm * 64 + mb * 32) * 128) ^ (ks * 32)));
     };
     auto loadW = [&](const char* tW, int qn) {
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                fw[f][ks] = *(const bf16x8*)(tW + ((offW0 + (qn * 32 + f * 16) * 128) ^ (ks * 64)));
+        for (int ks = 0; ks < 4; ++ks) fw[ks] = *(const bf16x8*)(tW + ((offW0 + (qn * 32) * 128) ^ (ks * 32)));
     };
 #define TG_BAR()                                         \
     do {                                                 \
@@ -286,20 +299,25 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 #define TG_COMPUTE(QM, QN)                                                                                  \
     do {                                                                                                    \
         __builtin_amdgcn_s_setprio(1);                                                                      \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
-            _Pragma("unroll") for (int f = 0; f < 4; ++f)                                                   \
-                _Pragma("unroll") for (int n = 0; n < 2; ++n)                                               \
-                    acc[(QM) * 4 + f][(QN) * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(              \
-                        fw[n][ks], fa[f][ks], acc[(QM) * 4 + f][(QN) * 2 + n], 0, 0, 0);                    \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                    \
+            _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                \
+                acc[(QM) * 2 + mb][(QN)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                          \
+                    fw[ks], fa[mb][ks], acc[(QM) * 2 + mb][(QN)], 0, 0, 0);                                 \
         __builtin_amdgcn_s_setprio(0);                                                                      \
+    } while (0)
+#define TG_LOAD_END(MORE)                                                              \
+    do {                                                                               \
+        if (MORE) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");          \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");               \
+        TG_BAR();                                                                      \
     } while (0)
 
     const int nk = p.K / BK;
-    stageA(0, 0);
-    stageW(0, 0);
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) stage(0, 0, ph);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TG_BAR();
-    if (grp == 1) TG_BAR();   // group 1 runs one barrier (= one phase half) behind group 0
+    if (grp == 1) TG_BAR();   // group 1 runs one barrier (= half a phase) behind group 0
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
@@ -309,40 +327,39 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         // phase 0: quadrant (0,0)
         loadW(tW, 0);
         loadA(tA, 0);
-        if (more) stageA(cur ^ 1, kt + 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        TG_BAR();
+        if (more) stage(cur ^ 1, kt + 1, 0);
+        TG_LOAD_END(more);
         TG_COMPUTE(0, 0);
         TG_BAR();
         // phase 1: quadrant (0,1)
         loadW(tW, 1);
-        if (more) stageW(cur ^ 1, kt + 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        TG_BAR();
+        if (more) stage(cur ^ 1, kt + 1, 1);
+        TG_LOAD_END(more);
         TG_COMPUTE(0, 1);
         TG_BAR();
         // phase 2: quadrant (1,1)
         loadA(tA, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        TG_BAR();
+        if (more) stage(cur ^ 1, kt + 1, 2);
+        TG_LOAD_END(more);
         TG_COMPUTE(1, 1);
         TG_BAR();
-        // phase 3: quadrant (1,0); retire this wave's LDS-DMA for tile kt+1 one barrier before its first reader
+        // phase 3: quadrant (1,0)
         loadW(tW, 0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        TG_BAR();
+        if (more) stage(cur ^ 1, kt + 1, 3);
+        TG_LOAD_END(more);
         TG_COMPUTE(1, 0);
         TG_BAR();
     }
     if (grp == 0) TG_BAR();
 #undef TG_BAR
 #undef TG_COMPUTE
+#undef TG_LOAD_END
 
-    // ---- epilogue: lane holds D[n = (lane>>4)*4 + r][m = lane&15] per fragment ----
+    // ---- epilogue: per 32x32 block lane holds D[n = 8*(r>>2) + 4*hi + (r&3)][m = lane&31] ----
     bf16_t* Cb = p.C + (long)b * p.sCb;
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-        const int m = m0 + grp * 128 + mi * 16 + (lane & 15);
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + grp * 128 + mt * 32 + j31;
         if (m >= p.M) continue;
         const bf16_t* gate_row = nullptr;
         if (EPI == TG_EPI_BIAS_GATE_RES) {
@@ -350,32 +367,35 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             gate_row = (const bf16_t*)p.g.mod + (long)b * p.g.mod_batch_stride + (long)p.g.row[g] * p.g.mod_ld + p.g.gate_col[g];
         }
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
-            float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-            if (p.bias) {
-                const uint2 bb = *(const uint2*)(p.bias + n);
-                v[0] += bf16lo_to_f32(bb.x); v[1] += bf16hi_to_f32(bb.x);
-                v[2] += bf16lo_to_f32(bb.y); v[3] += bf16hi_to_f32(bb.y);
-            }
-            if (EPI == TG_EPI_BIAS_GELU) {
+        for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = gelu_tanh(round_bf16(v[i]));
-            } else if (EPI == TG_EPI_BIAS_SILU) {
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int n = n0 + wn * 64 + nt * 32 + r4 * 8 + hi * 4;
+                float v[4] = {acc[mt][nt][r4 * 4 + 0], acc[mt][nt][r4 * 4 + 1], acc[mt][nt][r4 * 4 + 2], acc[mt][nt][r4 * 4 + 3]};
+                if (p.bias) {
+                    const uint2 bb = *(const uint2*)(p.bias + n);
+                    v[0] += bf16lo_to_f32(bb.x); v[1] += bf16hi_to_f32(bb.x);
+                    v[2] += bf16lo_to_f32(bb.y); v[3] += bf16hi_to_f32(bb.y);
+                }
+                if (EPI == TG_EPI_BIAS_GELU) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = silu(round_bf16(v[i]));
-            } else if (EPI == TG_EPI_BIAS_GATE_RES) {
-                const uint2 gg = *(const uint2*)(gate_row + n);
-                const uint2 rr = *(const uint2*)(p.R + (long)b * p.sRb + (long)m * p.ldr + n);
-                v[0] = bf16lo_to_f32(rr.x) + bf16lo_to_f32(gg.x) * v[0];
-                v[1] = bf16hi_to_f32(rr.x) + bf16hi_to_f32(gg.x) * v[1];
-                v[2] = bf16lo_to_f32(rr.y) + bf16lo_to_f32(gg.y) * v[2];
-                v[3] = bf16hi_to_f32(rr.y) + bf16hi_to_f32(gg.y) * v[3];
+                    for (int i = 0; i < 4; ++i) v[i] = gelu_tanh(round_bf16(v[i]));
+                } else if (EPI == TG_EPI_BIAS_SILU) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = silu(round_bf16(v[i]));
+                } else if (EPI == TG_EPI_BIAS_GATE_RES) {
+                    const uint2 gg = *(const uint2*)(gate_row + n);
+                    const uint2 rr = *(const uint2*)(p.R + (long)b * p.sRb + (long)m * p.ldr + n);
+                    v[0] = bf16lo_to_f32(rr.x) + bf16lo_to_f32(gg.x) * v[0];
+                    v[1] = bf16hi_to_f32(rr.x) + bf16hi_to_f32(gg.x) * v[1];
+                    v[2] = bf16lo_to_f32(rr.y) + bf16lo_to_f32(gg.y) * v[2];
+                    v[3] = bf16hi_to_f32(rr.y) + bf16hi_to_f32(gg.y) * v[3];
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *(uint2*)(Cb + (long)m * p.ldc + n) = o;
             }
-            uint2 o;
-            o.x = pack_bf16x2(v[0], v[1]);
-            o.y = pack_bf16x2(v[2], v[3]);
-            *(uint2*)(Cb + (long)m * p.ldc + n) = o;
         }
     }
 }
