@@ -126,3 +126,53 @@ def run_fifo(denoise_window, betas, ac, fifo_latents, fifo_old_x0, timesteps, nu
         feed = feed[1:]
         queue_start = max(0, queue_start - 1)
     return torch.cat(outs[T - nf:], dim=1)
+
+
+def run_fifo_prenoise(denoise_window, betas, ac, fifo_latents, fifo_old_x0, timesteps, num_frames, guidance_scale,
+                      grid_t, cond_t, start_frame_idx, noise_fn, nf=13, vip_nf=4, num_partitions=4, trace=None):
+    """Same algorithm as run_fifo, with the gaussian noise PRE-DRAWN per window: noise_fn(i, rank, (nf,2,C,H,W)) gives both
+    candidate draws of every frame (index 1 is used on the 2M branch, exactly the draw the reference keeps, :460-461) and
+    noise_fn(i, 97, (1,C,H,W)) the tail noise.  This is the keyed-noise form the product uses, so both can share noise."""
+    T = len(timesteps)
+    r, l = nf // 2, nf - nf // 2
+    dt = fifo_latents.dtype
+    latents = torch.cat([fifo_latents[:, [0]]] * r + [fifo_latents], dim=1)
+    old = [fifo_old_x0[0]] * r + list(fifo_old_x0)
+    q_grid_t, feed, cond_ext = grid_t_tables(grid_t, cond_t, T, nf, vip_nf)
+    t_tab, p_tab, n_tab = timestep_tables(timesteps, nf)
+    C, H, W = latents.shape[2:]
+    qs = T - l
+    outs = []
+    for i in range(num_frames + T - nf):
+        nl, no = latents.clone(), list(old)
+        for w in window_plan(qs, nf, num_partitions):
+            s, e = w["start"], w["end"]
+            vs = find_embed_index(cond_ext, q_grid_t[s], start_frame_idx)
+            nz = noise_fn(i, w["rank"], (nf, 2, C, H, W))
+            x_in = latents[:, s:e].clone()
+            tt = torch.as_tensor(t_tab[s:e])[None].expand(2, -1)
+            pred = S.cfg_combine(denoise_window(torch.cat([x_in] * 2), tt, q_grid_t[s:e].copy(),
+                                                cond_ext[vs:vs + min(vip_nf + 1, nf)].copy(), vs), guidance_scale)
+            o_lat, o_x0 = x_in.clone(), []
+            for j in range(nf):
+                nxt = int(n_tab[s + j]) if n_tab[s + j] > 0 else None
+                seq = iter([nz[j, 0][None, None], nz[j, 1][None, None]])
+                x, x0 = S.dpm_step(ac, pred[:, [j]].float(), None if old[s + j] is None else old[s + j].float(),
+                                   int(t_tab[s + j]), int(p_tab[s + j]), nxt, x_in[:, [j]].float(), lambda: next(seq).float())
+                o_lat[:, [j]] = x.to(dt)
+                o_x0.append(x0.to(dt))
+            lo, hi, loc = keep_slice(w, qs, nf)
+            nl[:, lo:hi] = o_lat[:, loc:loc + (hi - lo)]
+            no[lo:hi] = o_x0[loc:loc + (hi - lo)]
+            if trace is not None:
+                trace.append((i, w["rank"], s, w["mid"], e, w["real_end"], vs))
+        latents, old = nl, no
+        outs.append(latents[:, [r]].clone())
+        latents[:, :-1] = latents[:, 1:].clone()
+        old = old[1:] + [None]
+        latents[:, -1] = S.add_noise_to_xt(betas, latents[:, -1], noise_fn(i, 97, (1, C, H, W))).to(dt)
+        q_grid_t[:-1] = q_grid_t[1:].copy()
+        q_grid_t[-1] = feed[0]
+        feed = feed[1:]
+        qs = max(0, qs - 1)
+    return torch.cat(outs[T - nf:], dim=1)

@@ -1,0 +1,71 @@
+"""GPU: whole FIFO queue evolution on the HIP path (tiny DiT, 1 clip = 52 iterations / 274 window steps, keyed noise)
+against the oracle driving the oracle DiT with the SAME noise.  bf16 on both sides; the tolerance covers the drift of
+52 stochastic denoising steps per frame (end-to-end 3e-2 per step)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from types import SimpleNamespace
+
+from oracle import dit_ref as O
+from oracle import fifo_ref as Fq
+from oracle import scheduler_ref as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _noise(i, tag, shape):
+    g = torch.Generator().manual_seed(1000 * i + tag)
+    return torch.randn(shape, generator=g).to(BF)
+
+
+@pytest.mark.timeout(900)
+def test_fifo_queue_evolution_vs_oracle(golden_dir):
+    from tokensgen_amd import fifo
+    from tokensgen_amd.scheduler import CogVideoXDPMScheduler
+    from tokensgen_amd.transformer import CogVideoXTransformer3DModel
+    gt = torch.load(os.path.join(golden_dir, "dit_tiny.pt"), weights_only=False)
+    g = torch.load(os.path.join(golden_dir, "fifo_tiny.pt"), weights_only=False)
+    cfg, vipcfg = gt["cfg"], gt["vip"]
+    sd = {k: v.to(BF) for k, v in O.make_state_dict(cfg, 128, seed=g["weight_seed"]).items()}
+    H, W, nf, T = g["H"], g["W"], 13, 52
+    num_frames = 13
+    lat = g["fifo_latents"].to(BF)
+    old = [None if t is None else t.to(BF) for t in g["fifo_old"]]
+    prompt, emb = g["prompt"].to(BF), g["image_embeddings"].to(BF)[:, :8]
+    grid_t = g["grid_t"][:13].copy()
+    cond_t = g["cond_t"][:8].copy()
+    rope = O.rope_3d_crop(64, (0, 0, 0), (nf, H // 2, W // 2), (nf, H // 2, W // 2))
+    betas, ac = S.alphas_cumprod()
+    ts = S.trailing_timesteps(T)
+    emb_ext = torch.cat([emb] + [emb[:, -4:]] * (T // nf + 1), dim=1)
+
+    def denoise(x, tt, gt_, ct_, vs):
+        return O.dit_forward(sd, cfg, x, prompt, tt, emb_ext[:, vs:vs + 5], rope, O.rope_3d(64, gt_, g["grid_h"], g["grid_w"]),
+                             O.rope_3d(64, ct_, g["cond_h"], g["cond_w"]), vip_scale=[0.6])
+    ref_trace = []
+    ref = Fq.run_fifo_prenoise(denoise, betas, ac, lat, old, ts, num_frames, 6.0, grid_t, cond_t, 1000, _noise, trace=ref_trace)
+
+    m = CogVideoXTransformer3DModel(num_attention_heads=2, attention_head_dim=64, num_layers=2, time_embed_dim=cfg["time_embed_dim"],
+                                    text_embed_dim=cfg["text_embed_dim"], use_rotary_positional_embeddings=True, device=DEV)
+    m.set_vip_layers(None, **vipcfg)
+    m.load_state_dict(sd, strict=True)
+    sched = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
+    sched.set_timesteps(T)
+    pipe = SimpleNamespace(device=torch.device(DEV), scheduler=sched, transformer=m, guidance_scale=6.0)
+    bo = SimpleNamespace(sampling_params=dict(use_adaptive_padding=True, num_partitions=4), fifo_latents=lat, fifo_old_pred_original_sample=old,
+                         nf_per_chunk=nf, vip_nf_per_chunk=4, num_frames=num_frames, image_embeddings=emb, timesteps=sched.timesteps,
+                         num_inference_steps=T, do_classifier_free_guidance=True, use_separate_guidance=False, use_dynamic_cfg=False,
+                         prompt_embeds=prompt, image_rotary_emb=rope, vip_image_rotary_grid=[grid_t, g["grid_h"], g["grid_w"]],
+                         vip_condition_rotary_grid=[cond_t, g["cond_h"], g["cond_w"]], guidance_scale=6.0, cache_idx=[],
+                         video_ipadapter_start_frame_idx=1000, output_type="latent", return_dict=False, orig_latents=lat[:, :nf])
+    trace = []
+    out = fifo.cogvideo_fifo_mp_v2([pipe], bo, step_noise_fn=lambda i, r, s: _noise(i, r, s).to(DEV),
+                                   tail_noise_fn=lambda i, s: _noise(i, 97, s).to(DEV), trace=trace)[1]
+    assert trace == ref_trace and len(trace) == 274
+    assert out.shape == ref.shape == (1, num_frames, 16, H, W) and torch.isfinite(out).all()
+    rel = ((out.float().cpu() - ref.float()).norm() / ref.float().norm()).item()
+    assert rel < 0.1, rel

@@ -66,3 +66,180 @@ class FifoWorker:
                                                list(map(int, t)), list(map(int, prev_t)), t_back, list(has_old),
                                                self.guidance_scale)
         return x_out[None], x0
+
+
+# --------------------------------------------------------------------------------------------------
+# driver
+# --------------------------------------------------------------------------------------------------
+def window_plan(queue_start, nf=13, num_partitions=4):
+    """Windows of one iteration (cogvideo_sampling_mp_fifo.py:235-253): list of dict(rank,start,mid,end,real_end)."""
+    r, l = nf // 2, nf - nf // 2
+    plan = []
+    for rank in range(2 * num_partitions):
+        start = nf * (rank // 2) + r * (rank % 2)
+        following = nf * ((rank + 1) // 2) + r * ((rank + 1) % 2)
+        if following <= queue_start:        # adaptive padding: window still entirely inside the padding
+            continue
+        mid = start + (l if rank % 2 == 1 else r)
+        real_end = start + nf
+        start = max(start, queue_start)
+        plan.append(dict(rank=rank, start=start, mid=mid, end=start + nf, real_end=real_end))
+    return plan
+
+
+def keep_slice(w, queue_start, nf=13):
+    """(queue_lo, queue_hi, local_lo) of the frames a window writes back (:322-329)."""
+    r = nf // 2
+    if w["start"] > queue_start:
+        return w["mid"], w["end"], w["mid"] - w["start"]
+    if w["start"] == queue_start:
+        lo = max(r, w["start"])
+        return lo, w["real_end"], max(r - w["start"], 0)
+    raise NotImplementedError
+
+
+def _seed_for(seed, i, tag):
+    return (int(seed) * 1000003 + int(i) * 8191 + int(tag) * 131 + 12345) % (2 ** 63 - 1)
+
+
+class _SeededNoise:
+    """Noise keyed by (seed, iteration, window) — identical on every rank and for every GPU count, unlike the
+    reference's per-process global RNG (:452,460 of the scheduler; SURVEY §7 'stochastic scheduler')."""
+
+    def __init__(self, seed, device):
+        self.seed, self.device = seed, device
+
+    def step(self, i, rank, shape):
+        g = torch.Generator(device=self.device).manual_seed(_seed_for(self.seed, i, rank))
+        return torch.randn(shape, generator=g, device=self.device, dtype=torch.float32).to(BF16)
+
+    def tail(self, i, shape):
+        g = torch.Generator(device=self.device).manual_seed(_seed_for(self.seed, i, 97))
+        return torch.randn(shape, generator=g, device=self.device, dtype=torch.float32).to(BF16)
+
+
+@torch.no_grad()
+def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None, tail_noise_fn=None, trace=None,
+                        window_fn=None, **kwargs):
+    """Mirror of cogvideo_sampling_mp_fifo.py:27-395.
+
+    `pipe_list` holds this process's pipeline(s); with torch.distributed initialised (one process per GPU) the
+    windows of every iteration are split rank-round-robin and the results all_gathered; the queue, the index
+    bookkeeping and the tail noise are replicated.  Returns (orig_video, video, cache_video) like the reference
+    (latents when output_type == "latent").  `window_fn(worker, **window_inputs)` lets tests substitute the
+    denoiser (CPU/gloo tests of the exchange logic); the default is FifoWorker.window_step (HIP)."""
+    import torch.distributed as dist
+    bo = base_output
+    sp = bo.sampling_params
+    if sp.get("use_sliding_window_embedding"):
+        raise NotImplementedError("use_sliding_window_embedding is not used by the shipped configs")
+    if getattr(bo, "use_separate_guidance", False) or getattr(bo, "use_dynamic_cfg", False) or not bo.do_classifier_free_guidance:
+        raise NotImplementedError("only static 2-way classifier-free guidance (the CLI's setting, infer:310) is on the hot path")
+    if len(getattr(bo, "cache_idx", []) or []):
+        raise NotImplementedError("cache_idx capture is a debugging feature of the reference and is not mirrored")
+    num_partitions = sp.get("num_partitions", 4)
+    adaptive = sp.get("use_adaptive_padding", True)
+    pipe = pipe_list[0]
+    dev = pipe.device
+    nf, vnf, T = bo.nf_per_chunk, bo.vip_nf_per_chunk, bo.num_inference_steps
+    r, l = nf // 2, nf - nf // 2
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    me = dist.get_rank() if world > 1 else 0
+    use_vip = bo.image_embeddings is not None
+
+    lat = bo.fifo_latents.to(dev, BF16)
+    latents = torch.cat([lat[:, [0]]] * r + [lat], dim=1).contiguous()          # :72-82
+    Q = latents.shape[1]
+    C, H, W = latents.shape[2:]
+    x0q = torch.zeros(Q, C, H, W, dtype=BF16, device=dev)
+    has_old = [False] * Q
+    fo = [bo.fifo_old_pred_original_sample[0]] * r + list(bo.fifo_old_pred_original_sample)   # :145-146
+    for q, t_ in enumerate(fo):
+        if t_ is not None:
+            x0q[q] = t_.to(dev, BF16).reshape(C, H, W)
+            has_old[q] = True
+
+    timesteps = np.asarray(bo.timesteps.cpu() if torch.is_tensor(bo.timesteps) else bo.timesteps, dtype=np.int64)
+    t_tab = np.concatenate([timesteps, np.full(r, timesteps[-1])])[::-1].copy()                       # :182-185, flipped
+    p_tab = np.concatenate([timesteps[1:], np.full(r + 1, -1)])[::-1].copy()
+    n_tab = np.concatenate([[-1], timesteps[:-1], np.full(r, timesteps[-2])])[::-1].copy()
+
+    worker = None
+    if use_vip:
+        g_t, g_h, g_w = bo.vip_image_rotary_grid
+        c_t, c_h, c_w = bo.vip_condition_rotary_grid
+        g_t = np.asarray(g_t, dtype=np.float32)
+        q_grid_t = np.concatenate([g_t[[0]]] * (r + T - nf) + [g_t[:nf]])                           # :84-93
+        feed = np.concatenate([g_t[nf:], np.linspace(g_t[-1] + 1, g_t[-1] + 1 + T, T, endpoint=False, dtype=np.float32)])
+        cond = [np.asarray(c_t)] + [np.asarray(c_t)[-vnf:] + (k + 1) * nf for k in range(T // nf + 1)]   # :95-99
+        cond_t = np.concatenate(cond)
+        emb = bo.image_embeddings.to(dev, BF16)
+        emb = torch.cat([emb] + [emb[:, -vnf:]] * (T // nf + 1), dim=1)                            # :101-108
+        n_c = min(vnf + 1, nf)
+    if window_fn is None:
+        worker = FifoWorker(pipe.transformer, pipe.scheduler, bo.prompt_embeds, bo.image_rotary_emb, bo.guidance_scale,
+                            *( (g_h, g_w, c_h, c_w) if use_vip else (None,) * 4))
+        window_fn = lambda **kw: worker.window_step(**kw)
+    noise = _SeededNoise(noise_seed, dev)
+    step_noise_fn = step_noise_fn or noise.step
+    tail_noise_fn = tail_noise_fn or noise.tail
+
+    queue_start = T - l if adaptive else 0
+    outs = []
+    n_iter = bo.num_frames + T - nf
+    for i in range(n_iter):
+        plan = window_plan(queue_start, nf, num_partitions)
+        mine = [(k, w) for k, w in enumerate(plan) if k % world == me]
+        per_rank = (len(plan) + world - 1) // world
+        buf = torch.zeros(per_rank, 2, nf, C, H, W, dtype=BF16, device=dev)
+        for slot, (k, w) in enumerate(mine):
+            s, e = w["start"], w["end"]
+            kw = dict(latents=latents[:, s:e].clone(), old_x0=x0q[s:e].clone(), has_old=has_old[s:e], t=t_tab[s:e],
+                      prev_t=p_tab[s:e], next_t=n_tab[s:e], noise=step_noise_fn(i, w["rank"], (nf, 2, C, H, W)))
+            if use_vip:
+                vs = int(np.searchsorted(cond_t, q_grid_t[s] + bo.video_ipadapter_start_frame_idx, side="right") - 1)   # :110-115
+                kw.update(grid_t=q_grid_t[s:e].copy(), cond_grid_t=cond_t[vs:vs + n_c].copy(), image_embeddings=emb[:, vs:vs + n_c].contiguous())
+                if trace is not None:
+                    trace.append((i, w["rank"], s, w["mid"], e, w["real_end"], vs))
+            x_out, x0_out = window_fn(**kw)
+            buf[slot, 0], buf[slot, 1] = x_out[0], x0_out
+        if world > 1:                                   # the path's one exchange: kept windows of every rank
+            allbuf = torch.empty(world * per_rank, *buf.shape[1:], dtype=BF16, device=dev)   # rank-major concat
+            dist.all_gather_into_tensor(allbuf, buf)
+        else:
+            allbuf = buf
+        new_lat, new_x0, new_has = latents.clone(), x0q.clone(), list(has_old)
+        for k, w in enumerate(plan):                    # identical write-back on every rank (:308-334)
+            src = allbuf[(k % world) * per_rank + k // world]
+            lo, hi, loc = keep_slice(w, queue_start, nf)
+            new_lat[0, lo:hi] = src[0, loc:loc + (hi - lo)]
+            new_x0[lo:hi] = src[1, loc:loc + (hi - lo)]
+            for q in range(lo, hi):
+                new_has[q] = True
+        latents, x0q, has_old = new_lat, new_x0, new_has
+        outs.append(latents[:, [r]].clone())                                                      # :336-342
+        latents[:, :-1] = latents[:, 1:].clone()
+        x0q[:-1] = x0q[1:].clone()
+        has_old = has_old[1:] + [False]
+        latents[:, -1] = pipe.scheduler.add_noise_to_xt(latents[:, -1], tail_noise_fn(i, (1, C, H, W)), torch.tensor([999]))
+        if use_vip:
+            q_grid_t[:-1] = q_grid_t[1:].copy()
+            q_grid_t[-1] = feed[0]
+            feed = feed[1:]
+        queue_start = max(0, queue_start - 1)
+
+    video_latents = torch.cat(outs[T - nf:], dim=1)                                              # :367
+    if getattr(bo, "output_type", "latent") == "latent":
+        result = (bo.orig_latents, video_latents, [])
+    else:
+        video = pipe.decode_latents(video_latents)
+        orig = pipe.decode_latents(bo.orig_latents)
+        vp = getattr(pipe, "video_processor", None)
+        if vp is not None:
+            video = vp.postprocess_video(video=video, output_type=bo.output_type)
+            orig = vp.postprocess_video(video=orig, output_type=bo.output_type)
+        result = (orig, video, [])
+    if getattr(bo, "return_dict", False):
+        from types import SimpleNamespace
+        return SimpleNamespace(frames=result[1], orig_frames=result[0], cache_frames=result[2])
+    return result
