@@ -286,13 +286,52 @@ def gen_full_block():
     torch.save(res, os.path.join(GOLD, "block_full.pt"))
 
 
+VAE_TINY = dict(block_out_channels=(64, 128, 128, 128), layers_per_block=1, latent_channels=16, sample_height=64, sample_width=96)
+
+
+@torch.no_grad()
+def gen_vae():
+    """Vendored VAE twin (longvgen/models/autoencoder_kl_cogvideox.py) on a tiny config: plain + tiled encode/decode.
+    CogVideoXDownsample3D / Upsample3D / DiagonalGaussianDistribution come from the shim (restated, unpinned)."""
+    from oracle import vae_ref as V
+    rv = load_ref_module("longvgen/models/autoencoder_kl_cogvideox.py", "ref_vae")
+    cfg = VAE_TINY
+    vae = rv.AutoencoderKLCogVideoX(in_channels=3, out_channels=3, block_out_channels=cfg["block_out_channels"], latent_channels=16,
+                                    layers_per_block=1, sample_height=64, sample_width=96, temporal_compression_ratio=4)
+    sd = V.make_state_dict(cfg, seed=600)
+    vae.load_state_dict(sd, strict=True)
+    vae.eval()
+    g = torch.Generator().manual_seed(601)
+    x = torch.rand(1, 3, 17, 64, 96, generator=g) * 2 - 1
+    z5 = torch.randn(1, 16, 5, 8, 12, generator=g)
+    z13 = torch.randn(1, 16, 13, 8, 12, generator=g)
+    idx = torch.randint(0, 3 * 17 * 64 * 96, (4096,), generator=g)
+
+    def samp(t):
+        f = t.flatten()
+        return dict(shape=tuple(t.shape), samples=f[idx % f.numel()].clone(), mean=t.mean().item(), std=t.std().item(), absmax=t.abs().max().item())
+    out = dict(cfg=cfg, weight_seed=600, input_seed=601, idx=idx, sd_checksum=sd_checksum(sd))
+    out["encode_plain"] = vae._encode(x).clone()
+    out["decode_plain"] = samp(vae._decode(z5).sample)
+    vae.enable_tiling()
+    out["encode_tiled"] = vae._encode(x).clone()
+    out["decode_tiled"] = samp(vae.tiled_decode(z13).sample)
+    # building blocks for kernel-level parity: causal conv across two calls (cache), spatial norm, resnet
+    conv = rv.CogVideoXCausalConv3d(64, 128, 3)
+    xs = torch.randn(1, 64, 5, 6, 10, generator=g)
+    y1 = conv(xs[:, :, :3]); y2 = conv(xs[:, :, 3:])
+    out["causal_conv"] = dict(w=conv.conv.weight.detach().clone(), b=conv.conv.bias.detach().clone(), x=xs, y=torch.cat([y1, y2], 2))
+    torch.save(out, os.path.join(GOLD, "vae_tiny.pt"))
+    print("vae_tiny.pt", out["encode_tiled"].shape, out["decode_tiled"]["shape"])
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full-block", action="store_true")
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    jobs = dict(dit=gen_dit_tiny, vip=gen_vip_processor, sched=gen_scheduler, fifo=gen_fifo)
+    jobs = dict(dit=gen_dit_tiny, vip=gen_vip_processor, sched=gen_scheduler, fifo=gen_fifo, vae=gen_vae)
     if a.only:
         jobs = {a.only: jobs.get(a.only, gen_full_block)}
     for k, fn in jobs.items():
