@@ -123,6 +123,57 @@ int tg_cfg_dpm_step(const void* model_out, const void* x, const void* old_x0, co
                     const float* coef, float guidance, void* x_out, void* x0_out,
                     int frames, long frame_elems, hipStream_t stream);
 
+
+/* ---------------------------------------------------------------------------------------------------------
+ * 3-D causal VAE (AutoencoderKLCogVideoX).  Activations are channels-last bf16: x[t][h][w][c], C % 64 == 0.
+ * --------------------------------------------------------------------------------------------------------- */
+
+/* Implicit-GEMM convolution on MFMA:  y[to][ho][wo][n] = bias[n] + sum_{dt,dh,dw,c} w[n][(dt,dh,dw)][c] * xv(tv,hv,wv)[c]
+ *   tv = to + dt - (kt-1)              causal in time: tv < 0 reads `cache` frame (kt-1+tv), or frame 0 when cache == NULL
+ *   hv = ho*stride + dh - pad, wv likewise; taps outside [0, H*up) x [0, W*up) contribute zero (F.pad constant 0)
+ *   xv(t,h,w) = x[t_map ? t_map[t] : t][h/up][w/up]      nearest-neighbour upsampling folded into the loader
+ * Replaces CogVideoXCausalConv3d (cat(cache, x) + F.pad + Conv3d, autoencoder_kl_cogvideox.py:120-145), the Conv2d of
+ * CogVideoXUpsample3D after F.interpolate (up=2, kt=1, pad=1) and of CogVideoXDownsample3D (stride=2, pad=0 with the
+ * (0,1,0,1) zero pad implied).  w is repacked [Cout_pad][kt*kh*kw][Cin] (Cout_pad % 128 == 0); only columns < cout
+ * are stored (row stride ldy).  residual (optional, same layout as y) is added in the epilogue (ResnetBlock3D :309).
+ * zeros: >= 2*Cin + 128 bytes of device zeros (source of out-of-range taps).  Cin % 64 == 0. */
+int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const void* cache, const void* w, const void* bias,
+                 int cout, int cout_pad, int kt, int kh, int kw, int stride, int pad, int up, const int32_t* t_map,
+                 const void* residual, void* y, long ldy, int To, int Ho, int Wo, const void* zeros, hipStream_t stream);
+
+/* GroupNorm(32 groups, eps) statistics of x[V][C] -> stats[32][2] = {mean, rstd} (fp32).  partial: fp32 workspace of
+ * tg_groupnorm_partial_floats(V, C) floats.  Deterministic two-stage reduction (fp64 finalisation). */
+long tg_groupnorm_partial_floats(long V, int C);
+int tg_groupnorm_stats(const void* x, long V, int C, float eps, float* partial, float* stats, hipStream_t stream);
+
+/* y = silu(GroupNorm(x)) with precomputed stats (nn.GroupNorm + SiLU, autoencoder_kl_cogvideox.py:286-303). */
+int tg_groupnorm_silu(const void* x, long V, int C, const float* stats, const void* gamma, const void* beta, void* y,
+                      int apply_silu, hipStream_t stream);
+
+/* CogVideoXSpatialNorm3D (+ SiLU), :171-188:  y = silu( GN(f) * (Wy zq + by) + (Wb zq + bb) ), zq = the latent tile
+ * z[Tz][Hz][Wz][zc] resized to f's [T][H][W] by nearest neighbour (first frame mapped separately when T is odd > 1).
+ * wy/wb: [C][zc] bf16, by/bb: [C]. */
+int tg_spatialnorm_silu(const void* f, int T, int H, int W, int C, const float* stats, const void* gamma, const void* beta,
+                        const void* z, int Tz, int Hz, int Wz, int zc, const void* wy, const void* by, const void* wb,
+                        const void* bb, void* y, int apply_silu, hipStream_t stream);
+
+/* Temporal average pooling of CogVideoXDownsample3D(compress_time): pairs of frames are averaged; when T is odd the first
+ * frame is kept.  x [T][HW][C] -> y [To][HW][C]. */
+int tg_avgpool_time(const void* x, int T, long HW, int C, void* y, hipStream_t stream);
+
+/* Layout changes at the VAE boundary: src NCDHW (fp32 if src_fp32 else bf16), one batch item [C][T][H][W], optional
+ * crop window (h0,w0,Hc,Wc) and frame range [t0,t0+Tc) -> channels-last bf16 [Tc][Hc][Wc][Cpad] (extra channels zero),
+ * scaled by `scale`; and the inverse (channels-last [T][H][W][ld] -> NCDHW window of a larger [C][Tt][Ht][Wt] tensor). */
+int tg_ncdhw_to_cl(const void* src, int src_fp32, int C, int Tt, int Ht, int Wt, int t0, int Tc, int h0, int Hc, int w0, int Wc,
+                   float scale, void* dst, int Cpad, hipStream_t stream);
+int tg_cl_to_ncdhw(const void* src, long ld, int C, int T, int H, int W, void* dst, int dst_fp32, int Tt, int Ht, int Wt,
+                   int t0, int h0, int w0, hipStream_t stream);
+
+/* Tile seam blending of tiled_encode/tiled_decode (blend_v / blend_h, :1190-1204): along `axis` (3 = height, 4 = width) of
+ * NCDHW tensors a,b [C][T][H][W] (fp32 or bf16), b[..., k, ...] = a[..., -extent+k, ...]*(1-k/extent) + b[..., k, ...]*(k/extent). */
+int tg_tile_blend(const void* a, void* b, int is_fp32, int C, int T, int Ha, int Wa, int Hb, int Wb, int axis, int extent,
+                  hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

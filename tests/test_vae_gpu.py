@@ -1,0 +1,160 @@
+"""GPU: VAE kernels (implicit-GEMM causal conv3d, GroupNorm/SpatialNorm+SiLU, pooling, blend) vs fp32 torch restatements,
+and the tiny VAE end-to-end (plain + tiled encode / decode) vs the oracle / the reference's vendored VAE golden."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vae_ref as V
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def _r(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def _pack(w):
+    co, ci = w.shape[:2]
+    cop, cip = (co + 127) // 128 * 128, (ci + 63) // 64 * 64
+    p = torch.zeros(cop, int(np.prod(w.shape[2:])), cip, dtype=BF)
+    p[:co, :, :ci] = w.reshape(co, ci, -1).permute(0, 2, 1)
+    return p.contiguous()
+
+
+def _cl(x):          # [1,C,T,H,W] -> [T,H,W,C]
+    return x[0].permute(1, 2, 3, 0).contiguous()
+
+
+def _ncdhw(y):       # [T,H,W,C] -> [1,C,T,H,W]
+    return y.permute(3, 0, 1, 2)[None]
+
+
+@pytest.mark.parametrize("ci,co,T,H,W", [(64, 128, 5, 6, 10), (128, 3, 3, 9, 7), (64, 32, 4, 5, 5)])
+def test_causal_conv3d_with_cache(ci, co, T, H, W):
+    from tokensgen_amd import kernels as K
+    w, b, x = _r(co, ci, 3, 3, 3, seed=1, scale=0.05), _r(co, seed=2), _r(1, ci, T, H, W, seed=3)
+    sd = {"c.conv.weight": w.float(), "c.conv.bias": b.float()}
+    cache = V.ConvCache()
+    ref = torch.cat([V.causal_conv3d(sd, "c", x[:, :, :2].float(), cache), V.causal_conv3d(sd, "c", x[:, :, 2:].float(), cache)], 2)
+    wp, bd = _pack(w).to(DEV), b.to(DEV)
+    x1, x2 = _cl(x[:, :, :2]).to(DEV), _cl(x[:, :, 2:]).to(DEV)
+    y1 = K.conv3d_cl(x1, wp, bd, co, 3, 3, 3)
+    y2 = K.conv3d_cl(x2, wp, bd, co, 3, 3, 3, cache=x1[-2:].contiguous())
+    got = _ncdhw(torch.cat([y1, y2], 0))
+    assert _rel(got, ref) < 5e-3
+    res = _r(T - 2, H, W, co, seed=9).to(DEV)
+    y3 = K.conv3d_cl(x2, wp, bd, co, 3, 3, 3, cache=x1[-2:].contiguous(), residual=res)
+    assert _rel(y3, y2.float() + res.float()) < 5e-3
+
+
+def test_upsample_and_downsample_convs():
+    from tokensgen_amd import kernels as K
+    ci = co = 64
+    w, b = _r(co, ci, 3, 3, seed=1, scale=0.05), _r(co, seed=2)
+    sd = {"u.conv.weight": w.float(), "u.conv.bias": b.float()}
+    wp, bd = _pack(w).to(DEV), b.to(DEV)
+    for T in (3, 2, 1):
+        x = _r(1, ci, T, 5, 6, seed=3 + T)
+        ref = V.upsample3d(sd, "u", x.float(), True)
+        idx = None
+        if T > 1:
+            idx = [0] + [t for t in range(1, T) for _ in (0, 1)] if T % 2 else [t for t in range(T) for _ in (0, 1)]
+        tm = None if idx is None else torch.tensor(idx, dtype=torch.int32, device=DEV)
+        y = K.conv3d_cl(_cl(x).to(DEV), wp, bd, co, 1, 3, 3, up=2, t_map=tm, out_dims=(ref.shape[2], 10, 12))
+        assert _rel(_ncdhw(y), ref) < 5e-3, T
+    x = _r(1, ci, 3, 5, 6, seed=11)
+    ref = V.upsample3d(sd, "u", x.float(), False)
+    y = K.conv3d_cl(_cl(x).to(DEV), wp, bd, co, 1, 3, 3, up=2, out_dims=(3, 10, 12))
+    assert _rel(_ncdhw(y), ref) < 5e-3
+    for T, compress in ((9, True), (8, True), (3, False)):
+        x = _r(1, ci, T, 8, 12, seed=20 + T)
+        ref = V.downsample3d(sd, "u", x.float(), compress)
+        xc = _cl(x).to(DEV)
+        if compress:
+            xc = K.avgpool_time(xc)
+        y = K.conv3d_cl(xc, wp, bd, co, 1, 3, 3, stride=2, pad=0, out_dims=(ref.shape[2], 4, 6))
+        assert _rel(_ncdhw(y), ref) < 5e-3, (T, compress)
+
+
+@pytest.mark.parametrize("C", [64, 128, 512])
+def test_groupnorm_and_spatialnorm_silu(C):
+    from tokensgen_amd import kernels as K
+    T, H, W = 5, 6, 8
+    x = _r(1, C, T, H, W, seed=1, scale=2.0) + 0.5
+    gam, bet = (_r(C, seed=2, scale=0.1) + 1), _r(C, seed=3, scale=0.1)
+    ref = F.silu(F.group_norm(x.float(), 32, gam.float(), bet.float(), 1e-6))
+    xc = _cl(x).to(DEV)
+    st = K.groupnorm_stats(xc.view(-1, C))
+    xs = x.float().reshape(32, -1)
+    assert torch.allclose(st[:, 0].cpu(), xs.mean(1), atol=2e-3) and torch.allclose(st[:, 1].cpu(), (xs.var(1, unbiased=False) + 1e-6).rsqrt(), rtol=2e-3)
+    y = K.groupnorm_silu(xc, st, gam.to(DEV), bet.to(DEV))
+    assert _rel(_ncdhw(y), ref) < 6e-3
+    z = _r(1, 16, 2, 3, 4, seed=4)
+    sd = {"n.norm_layer.weight": gam.float(), "n.norm_layer.bias": bet.float(), "n.conv_y.conv.weight": _r(C, 16, 1, 1, 1, seed=5, scale=0.2).float(),
+          "n.conv_y.conv.bias": (_r(C, seed=6, scale=0.1) + 1).float(), "n.conv_b.conv.weight": _r(C, 16, 1, 1, 1, seed=7, scale=0.2).float(),
+          "n.conv_b.conv.bias": _r(C, seed=8, scale=0.1).float()}
+    ref = F.silu(V.spatial_norm(sd, "n", x.float(), z.float(), V.ConvCache()))
+    d = lambda k: sd[k].to(DEV, BF).reshape(C, -1).contiguous() if sd[k].dim() > 1 else sd[k].to(DEV, BF)
+    y = K.spatialnorm_silu(xc, st, gam.to(DEV), bet.to(DEV), _cl(z).to(DEV), d("n.conv_y.conv.weight"), d("n.conv_y.conv.bias"),
+                           d("n.conv_b.conv.weight"), d("n.conv_b.conv.bias"))
+    assert _rel(_ncdhw(y), ref) < 8e-3
+
+
+def test_tile_blend_and_layout():
+    from tokensgen_amd import kernels as K
+    a, b = _r(3, 4, 10, 12, seed=1), _r(3, 4, 10, 12, seed=2)
+    for axis, ext in ((3, 4), (4, 5)):
+        ra, rb = a.float()[None].clone(), b.float()[None].clone()
+        ref = (V.blend_v if axis == 3 else V.blend_h)(ra, rb, ext)[0]
+        bb = b.clone().to(DEV)
+        K.tile_blend(a.to(DEV), bb, axis, ext)
+        assert _rel(bb, ref) < 4e-3
+    src = _r(5, 6, 9, 11, seed=3).float().to(DEV)
+    cl = K.ncdhw_to_cl(src, 1, 4, 2, 5, 3, 6, 8, scale=0.5)
+    assert torch.equal(cl[..., :5].float(), (src[:, 1:5, 2:7, 3:9] * 0.5).to(BF).float().permute(1, 2, 3, 0)) and (cl[..., 5:] == 0).all()
+    back = torch.zeros(5, 6, 9, 11, dtype=BF, device=DEV)
+    K.cl_to_ncdhw(cl[..., :5].contiguous(), back, 1, 2, 3)
+    assert torch.equal(back[:, 1:5, 2:7, 3:9].float(), (src[:, 1:5, 2:7, 3:9] * 0.5).to(BF).float())
+
+
+@pytest.mark.timeout(900)
+def test_vae_tiny_encode_decode_vs_reference(golden_dir):
+    """Tiny VAE through the HIP path vs (a) the reference's vendored VAE outputs (fp32 golden) and (b) the oracle in bf16."""
+    from tokensgen_amd.vae import AutoencoderKLCogVideoX
+    g = torch.load(os.path.join(golden_dir, "vae_tiny.pt"), weights_only=False)
+    cfg = g["cfg"]
+    sd = V.make_state_dict(cfg, seed=g["weight_seed"])
+    vae = AutoencoderKLCogVideoX(block_out_channels=cfg["block_out_channels"], layers_per_block=cfg["layers_per_block"], sample_height=64,
+                                 sample_width=96, device=DEV)
+    vae.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(g["input_seed"])
+    x = torch.rand(1, 3, 17, 64, 96, generator=gen) * 2 - 1
+    z5 = torch.randn(1, 16, 5, 8, 12, generator=gen)
+    z13 = torch.randn(1, 16, 13, 8, 12, generator=gen)
+    h = vae.encode(x.to(DEV, BF)).latent_dist.parameters
+    assert h.shape == g["encode_plain"].shape and _rel(h, g["encode_plain"]) < 4e-2
+    d = vae.decode(z5.to(DEV, BF)).sample
+    f = d.flatten().cpu()
+    assert tuple(d.shape) == g["decode_plain"]["shape"] and _rel(f[g["idx"] % f.numel()], g["decode_plain"]["samples"]) < 5e-2
+    vae.enable_tiling()
+    h = vae.encode(x.to(DEV, BF)).latent_dist.parameters
+    assert h.shape == g["encode_tiled"].shape and _rel(h, g["encode_tiled"]) < 4e-2
+    d = vae.decode(z13.to(DEV, BF)).sample
+    f = d.flatten().cpu()
+    assert tuple(d.shape) == g["decode_tiled"]["shape"] and _rel(f[g["idx"] % f.numel()], g["decode_tiled"]["samples"]) < 5e-2
+    # and against the oracle run in bf16 on the same bf16 inputs
+    sdb = {k: v.to(BF) for k, v in sd.items()}
+    ref = V.decode(sdb, cfg, z5.to(BF), tiling=False)
+    vae.disable_tiling()
+    assert _rel(vae.decode(z5.to(DEV, BF)).sample, ref) < 5e-2

@@ -1,0 +1,516 @@
+// Kernels of the 3-D causal VAE (AutoencoderKLCogVideoX; reference twin longvgen/models/autoencoder_kl_cogvideox.py).
+//
+// Layout: activations are channels-last bf16  x[t][h][w][c].  A convolution is then a GEMM whose A rows are output
+// voxels and whose K index is (tap, channel): for a fixed tap the K slice of a row is a CONTIGUOUS run of channels of one
+// input voxel, so the LDS-DMA loader of the GEMM (global_load_lds_dwordx4, 16 B per lane) applies unchanged — only the
+// per-lane source address is computed from (to, ho, wo, tap).  Consequences:
+//   * no cat(conv_cache, x): frames before the window are read straight from the cache tensor (or frame 0, replicated);
+//   * no F.pad: out-of-range taps read a zero page;
+//   * no materialised F.interpolate: the nearest-neighbour x2 upsample (spatial, and temporal through t_map) is index math.
+#include "common.h"
+#include "tokensgen_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+
+struct ConvParams {
+    const bf16_t* x; int T, H, W, Cin;
+    const bf16_t* cache;
+    const bf16_t* w; const bf16_t* bias;
+    int cout, cout_pad, kt, kh, kw, stride, pad, up;
+    const int32_t* t_map;
+    const bf16_t* residual;
+    bf16_t* y; long ldy;
+    int To, Ho, Wo;
+    const bf16_t* zeros;
+};
+
+__global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const long M = (long)p.To * p.Ho * p.Wo;
+    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = p.cout_pad / BN;
+    const int nwg = tiles_m * tiles_n;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int tn = t % tiles_n, tm = t / tiles_n;     // n fastest: the tiles_n blocks sharing an A tile run on one XCD
+    const long m0 = (long)tm * BM;
+    const int n0 = tn * BN;
+    const int Kw = p.kt * p.kh * p.kw * p.Cin;        // row length of the packed weights
+
+    // ---- per-lane rows: wave-instruction i covers tile rows [wave*32 + i*8, +8) ----
+    int vt[4], vh[4], vw[4], slotA[4];
+    const char* srcW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave * 32 + i * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((r >> 1) & 7);
+        slotA[i] = slot * 8;
+        long m = m0 + r;
+        if (m >= M) m = M - 1;
+        const int wo = (int)(m % p.Wo);
+        const long q = m / p.Wo;
+        vw[i] = wo; vh[i] = (int)(q % p.Ho); vt[i] = (int)(q / p.Ho);
+        srcW[i] = (const char*)(p.w + (long)(n0 + r) * Kw + slot * 8);
+    }
+    const int Hv = p.H * p.up, Wv = p.W * p.up;
+    const long frame = (long)p.H * p.W * p.Cin;
+
+    // source address of row i for tap (dt, dh, dw); returns the zero page for padded taps
+    auto tap_src = [&](int i, int dt, int dh, int dw) -> const char* {
+        const int hv = vh[i] * p.stride + dh - p.pad, wv = vw[i] * p.stride + dw - p.pad;
+        if (hv < 0 || hv >= Hv || wv < 0 || wv >= Wv) return (const char*)(p.zeros + slotA[i]);
+        int tv = vt[i] + dt - (p.kt - 1);
+        const bf16_t* base = p.x;
+        if (tv < 0) {
+            if (p.cache) { base = p.cache; tv += p.kt - 1; } else tv = 0;   // cached frames, or replicate the first frame
+        } else if (p.t_map) tv = p.t_map[tv];
+        const int h = (p.up == 2) ? (hv >> 1) : hv, w = (p.up == 2) ? (wv >> 1) : wv;
+        return (const char*)(base + (long)tv * frame + ((long)h * p.W + w) * p.Cin + slotA[i]);
+    };
+
+    const int cpt = p.Cin / BK;                      // k-tiles per tap
+    const int ntaps = p.kt * p.kh * p.kw;
+    const int nk = ntaps * cpt;
+    const char* srcA[4];
+    auto set_tap = [&](int tap) {
+        const int dw = tap % p.kw, q = tap / p.kw;
+        const int dh = q % p.kh, dt = q / p.kh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) srcA[i] = tap_src(i, dt, dh, dw);
+    };
+    auto stage = [&](int buf, int kt_) {
+        const int tap = kt_ / cpt, cc = kt_ - tap * cpt;
+        if (cc == 0) set_tap(tap);
+        char* base = smem + buf * STAGE_BYTES + wave * (32 * 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + (long)cc * (BK * 2)),
+                                             (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + (long)kt_ * (BK * 2)),
+                                             (__attribute__((address_space(3))) void*)(base + TILE_BYTES + i * 1024), 16, 0, 0);
+        }
+    };
+
+    int offA[4][2], offW[4][2];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ra = wm * 64 + f * 16 + (lane & 15), rw = wn * 64 + f * 16 + (lane & 15);
+            const int sl = ks * 4 + (lane >> 4);
+            offA[f][ks] = ra * 128 + ((sl ^ ((ra >> 1) & 7)) << 4);
+            offW[f][ks] = rw * 128 + ((sl ^ ((rw >> 1) & 7)) << 4);
+        }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt_ = 0; kt_ < nk; ++kt_) {
+        const int cur = kt_ & 1;
+        if (kt_ + 1 < nk) stage(cur ^ 1, kt_ + 1);
+        const char* tA = smem + cur * STAGE_BYTES;
+        const char* tW = tA + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fw[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                fa[f] = *(const bf16x8*)(tA + offA[f][ks]);
+                fw[f] = *(const bf16x8*)(tW + offW[f][ks]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias (+ residual), only columns < cout are stored ----
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const long m = m0 + wm * 64 + mi * 16 + (lane & 15);
+        if (m >= M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+            if (n >= p.cout) continue;
+            float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+            bf16_t* dst = p.y + m * p.ldy + n;
+            const bf16_t* res = p.residual ? p.residual + m * p.ldy + n : nullptr;
+            if (n + 4 <= p.cout) {
+                if (p.bias) {
+                    const uint2 bb = *(const uint2*)(p.bias + n);
+                    v[0] += bf16lo_to_f32(bb.x); v[1] += bf16hi_to_f32(bb.x);
+                    v[2] += bf16lo_to_f32(bb.y); v[3] += bf16hi_to_f32(bb.y);
+                }
+                if (res) {   // conv output is a bf16 tensor in the reference before `hidden_states + inputs`
+                    const uint2 rr = *(const uint2*)res;
+                    v[0] = round_bf16(v[0]) + bf16lo_to_f32(rr.x); v[1] = round_bf16(v[1]) + bf16hi_to_f32(rr.x);
+                    v[2] = round_bf16(v[2]) + bf16lo_to_f32(rr.y); v[3] = round_bf16(v[3]) + bf16hi_to_f32(rr.y);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *(uint2*)dst = o;
+            } else {
+                for (int e = 0; e < 4 && n + e < p.cout; ++e) {
+                    float u = v[e] + (p.bias ? bf16_to_f32(p.bias[n + e]) : 0.f);
+                    if (res) u = round_bf16(u) + bf16_to_f32(res[e]);
+                    dst[e] = f32_to_bf16(u);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(32) statistics: stage 1 per-block fp32 partial (sum, sumsq) per group, stage 2 fp64 finalise
+// ------------------------------------------------------------------------------------------------
+constexpr int GN_GROUPS = 32;
+constexpr int GN_ROWS_PER_BLOCK = 512;
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, long V, int C, float* __restrict__ partial) {
+    __shared__ float sh[2][GN_GROUPS];
+    if (threadIdx.x < 2 * GN_GROUPS) ((float*)sh)[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int vec_per_row = C >> 3;                       // 16-byte vectors per voxel
+    const int cg = C / GN_GROUPS;                         // channels per group (>= 2)
+    const long row0 = (long)blockIdx.x * GN_ROWS_PER_BLOCK;
+    const long rows = min((long)GN_ROWS_PER_BLOCK, V - row0);
+    const long nvec = rows * vec_per_row;
+    // a thread always visits the same channel slice when blockDim % vec_per_row == 0 (C in {64..512} -> yes)
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
+    const int cv = threadIdx.x % vec_per_row;
+    for (long v = threadIdx.x; v < nvec; v += 256) {
+        const uint4 raw = *(const uint4*)(x + (row0 * vec_per_row + v) * 8);
+        const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a = bf16lo_to_f32(u[i]), b = bf16hi_to_f32(u[i]);
+            s[2 * i] += a; q[2 * i] += a * a;
+            s[2 * i + 1] += b; q[2 * i + 1] += b * b;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int g = (cv * 8 + i) / cg;
+        atomicAdd(&sh[0][g], s[i]);
+        atomicAdd(&sh[1][g], q[i]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * GN_GROUPS) partial[(long)blockIdx.x * 2 * GN_GROUPS + threadIdx.x] = ((float*)sh)[threadIdx.x];
+}
+
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nblocks, long V, int C, float eps, float* __restrict__ stats) {
+    const int g = threadIdx.x;
+    if (g >= GN_GROUPS) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        s += (double)partial[(long)b * 2 * GN_GROUPS + g];
+        q += (double)partial[(long)b * 2 * GN_GROUPS + GN_GROUPS + g];
+    }
+    const double n = (double)V * (C / GN_GROUPS);
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0) var = 0;
+    stats[2 * g] = (float)mean;
+    stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, long V, int C, const float* __restrict__ stats,
+                                                       const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+                                                       bf16_t* __restrict__ y, int apply_silu) {
+    const int vec_per_row = C >> 3, cg = C / GN_GROUPS;
+    const long total = V * vec_per_row;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long)gridDim.x * 256) {
+        const int cv = (int)(v % vec_per_row);
+        const uint4 raw = *(const uint4*)(x + v * 8);
+        const uint4 gw = *(const uint4*)(gamma + cv * 8), bw = *(const uint4*)(beta + cv * 8);
+        const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w}, gu[4] = {gw.x, gw.y, gw.z, gw.w}, bu[4] = {bw.x, bw.y, bw.z, bw.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g0 = (cv * 8 + 2 * i) / cg, g1 = (cv * 8 + 2 * i + 1) / cg;
+            float a = round_bf16((bf16lo_to_f32(u[i]) - stats[2 * g0]) * stats[2 * g0 + 1] * bf16lo_to_f32(gu[i]) + bf16lo_to_f32(bu[i]));
+            float b = round_bf16((bf16hi_to_f32(u[i]) - stats[2 * g1]) * stats[2 * g1 + 1] * bf16hi_to_f32(gu[i]) + bf16hi_to_f32(bu[i]));
+            if (apply_silu) { a = silu_f(a); b = silu_f(b); }
+            o[i] = pack_bf16x2(a, b);
+        }
+        *(uint4*)(y + v * 8) = uint4{o[0], o[1], o[2], o[3]};
+    }
+}
+
+// SpatialNorm3D + SiLU: one thread = one voxel x 8 channels; the two 1x1x1 convs over the zc (=16) latent channels are
+// done in registers (weights come from L1: every thread of a channel slice reads the same 2 x 8 x zc values).
+template <int ZC>
+__global__ __launch_bounds__(256) void spatialnorm_kernel(const bf16_t* __restrict__ f, int T, int H, int W, int C,
+                                                          const float* __restrict__ stats, const bf16_t* __restrict__ gamma,
+                                                          const bf16_t* __restrict__ beta, const bf16_t* __restrict__ z, int Tz, int Hz,
+                                                          int Wz, const bf16_t* __restrict__ wy, const bf16_t* __restrict__ by,
+                                                          const bf16_t* __restrict__ wb, const bf16_t* __restrict__ bb,
+                                                          bf16_t* __restrict__ y, int apply_silu) {
+    const int vec_per_row = C >> 3, cg = C / GN_GROUPS;
+    const long V = (long)T * H * W, total = V * vec_per_row;
+    const bool split_first = (T > 1) && (T & 1);
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long)gridDim.x * 256) {
+        const int cv = (int)(v % vec_per_row);
+        long vox = v / vec_per_row;
+        const int w_ = (int)(vox % W); vox /= W;
+        const int h_ = (int)(vox % H);
+        const int t_ = (int)(vox / H);
+        // F.interpolate(mode="nearest"): src = floor(dst * src_size / dst_size); first frame separately when T odd > 1
+        int tz;
+        if (split_first) tz = (t_ == 0) ? 0 : 1 + (int)(((long)(t_ - 1) * (Tz - 1)) / (T - 1));
+        else tz = (int)(((long)t_ * Tz) / T);
+        const int hz = (int)(((long)h_ * Hz) / H), wz = (int)(((long)w_ * Wz) / W);
+        const bf16_t* zp = z + (((long)tz * Hz + hz) * Wz + wz) * ZC;
+        float zv[ZC];
+#pragma unroll
+        for (int k = 0; k < ZC; k += 8) {
+            const uint4 r = *(const uint4*)(zp + k);
+            const uint32_t u[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { zv[k + 2 * i] = bf16lo_to_f32(u[i]); zv[k + 2 * i + 1] = bf16hi_to_f32(u[i]); }
+        }
+        const uint4 raw = *(const uint4*)(f + v * 8);
+        const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+        float xin[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xin[2 * i] = bf16lo_to_f32(u[i]); xin[2 * i + 1] = bf16hi_to_f32(u[i]); }
+        float out[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cv * 8 + e, g = c / cg;
+            float sy = 0.f, sb = 0.f;
+            const bf16_t* wyr = wy + (long)c * ZC;
+            const bf16_t* wbr = wb + (long)c * ZC;
+#pragma unroll
+            for (int k = 0; k < ZC; k += 2) {
+                const uint32_t a = *(const uint32_t*)(wyr + k), b2 = *(const uint32_t*)(wbr + k);
+                sy += bf16lo_to_f32(a) * zv[k] + bf16hi_to_f32(a) * zv[k + 1];
+                sb += bf16lo_to_f32(b2) * zv[k] + bf16hi_to_f32(b2) * zv[k + 1];
+            }
+            const float nf = round_bf16((xin[e] - stats[2 * g]) * stats[2 * g + 1] * bf16_to_f32(gamma[c]) + bf16_to_f32(beta[c]));
+            const float yy = round_bf16(sy + bf16_to_f32(by[c])), bbv = round_bf16(sb + bf16_to_f32(bb[c]));
+            float r = round_bf16(nf * yy) + bbv;
+            if (apply_silu) r = silu_f(round_bf16(r));
+            out[e] = r;
+        }
+        uint4 o;
+        o.x = pack_bf16x2(out[0], out[1]); o.y = pack_bf16x2(out[2], out[3]);
+        o.z = pack_bf16x2(out[4], out[5]); o.w = pack_bf16x2(out[6], out[7]);
+        *(uint4*)(y + v * 8) = o;
+    }
+}
+
+__global__ void avgpool_time_kernel(const bf16_t* __restrict__ x, int T, long HWC, bf16_t* __restrict__ y) {
+    const int To = (T & 1) ? 1 + (T - 1) / 2 : T / 2;
+    const long total = (long)To * HWC;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int to = (int)(i / HWC);
+        const long e = i - (long)to * HWC;
+        float v;
+        if (T & 1) {
+            if (to == 0) v = bf16_to_f32(x[e]);
+            else v = 0.5f * (bf16_to_f32(x[(long)(2 * to - 1) * HWC + e]) + bf16_to_f32(x[(long)(2 * to) * HWC + e]));
+        } else {
+            v = 0.5f * (bf16_to_f32(x[(long)(2 * to) * HWC + e]) + bf16_to_f32(x[(long)(2 * to + 1) * HWC + e]));
+        }
+        y[i] = f32_to_bf16(v);
+    }
+}
+
+__global__ void ncdhw_to_cl_kernel(const void* __restrict__ src, int src_fp32, int C, int Tt, int Ht, int Wt, int t0, int Tc, int h0,
+                                   int Hc, int w0, int Wc, float scale, bf16_t* __restrict__ dst, int Cpad) {
+    const long total = (long)Tc * Hc * Wc * Cpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        long r = i / Cpad;
+        const int w = (int)(r % Wc); r /= Wc;
+        const int h = (int)(r % Hc);
+        const int t = (int)(r / Hc);
+        float v = 0.f;
+        if (c < C) {
+            const long s = (((long)c * Tt + (t0 + t)) * Ht + (h0 + h)) * Wt + (w0 + w);
+            v = src_fp32 ? ((const float*)src)[s] : bf16_to_f32(((const bf16_t*)src)[s]);
+            v *= scale;
+        }
+        dst[i] = f32_to_bf16(v);
+    }
+}
+
+__global__ void cl_to_ncdhw_kernel(const bf16_t* __restrict__ src, long ld, int C, int T, int H, int W, void* __restrict__ dst,
+                                   int dst_fp32, int Tt, int Ht, int Wt, int t0, int h0, int w0) {
+    const long total = (long)C * T * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        long r = i / W;
+        const int h = (int)(r % H); r /= H;
+        const int t = (int)(r % T);
+        const int c = (int)(r / T);
+        const bf16_t v = src[(((long)t * H + h) * W + w) * ld + c];
+        const long d = (((long)c * Tt + (t0 + t)) * Ht + (h0 + h)) * Wt + (w0 + w);
+        if (dst_fp32) ((float*)dst)[d] = bf16_to_f32(v);
+        else ((bf16_t*)dst)[d] = v;
+    }
+}
+
+template <typename TT>
+__device__ __forceinline__ float ldv(const TT* p);
+template <> __device__ __forceinline__ float ldv<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldv<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+__device__ __forceinline__ void stv(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stv(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+
+template <typename TT>
+__global__ void tile_blend_kernel(const TT* __restrict__ a, TT* __restrict__ b, int C, int T, int Ha, int Wa, int Hb, int Wb, int axis,
+                                  int extent) {
+    // axis 3: rows k < extent of b over width min(Wa, Wb);  axis 4: cols k < extent over height min(Ha, Hb)
+    const int other = (axis == 3) ? min(Wa, Wb) : min(Ha, Hb);
+    const long total = (long)C * T * extent * other;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(i % other);
+        long r = i / other;
+        const int k = (int)(r % extent); r /= extent;
+        const long ct = r;                                 // c*T + t
+        long ia, ib;
+        if (axis == 3) { ia = (ct * Ha + (Ha - extent + k)) * Wa + o; ib = (ct * Hb + k) * Wb + o; }
+        else { ia = (ct * Ha + o) * Wa + (Wa - extent + k); ib = (ct * Hb + o) * Wb + k; }
+        const float wgt = (float)k / (float)extent;
+        stv(b + ib, ldv(a + ia) * (1.f - wgt) + ldv(b + ib) * wgt);
+    }
+}
+
+inline unsigned grid_for(long total, int block = 256) { return (unsigned)min((total + block - 1) / block, (long)256 * 16); }
+
+}  // namespace
+
+extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const void* cache, const void* w, const void* bias,
+                            int cout, int cout_pad, int kt, int kh, int kw, int stride, int pad, int up, const int32_t* t_map,
+                            const void* residual, void* y, long ldy, int To, int Ho, int Wo, const void* zeros, hipStream_t stream) {
+    TG_REQUIRE(x && w && y && zeros, TG_ERR_ARG, "tg_conv3d_cl: null pointer");
+    TG_REQUIRE(T > 0 && H > 0 && W > 0 && To > 0 && Ho > 0 && Wo > 0, TG_ERR_SHAPE, "tg_conv3d_cl: bad spatial shape");
+    TG_REQUIRE(Cin % BK == 0 && cout_pad % BN == 0 && cout > 0 && cout <= cout_pad, TG_ERR_SHAPE,
+               "tg_conv3d_cl: need Cin%%64==0, cout_pad%%128==0 (Cin=%d cout=%d cout_pad=%d)", Cin, cout, cout_pad);
+    TG_REQUIRE(kt >= 1 && kt <= 3 && kh >= 1 && kh <= 3 && kw >= 1 && kw <= 3 && (stride == 1 || stride == 2) && (up == 1 || up == 2) &&
+               pad >= 0 && pad <= 1, TG_ERR_SHAPE, "tg_conv3d_cl: unsupported kernel/stride/pad/up");
+    TG_REQUIRE(tg_aligned16(x) && tg_aligned16(w) && tg_aligned16(zeros) && (!cache || tg_aligned16(cache)) && (((uintptr_t)y) & 1) == 0 &&
+               (cout % 4 != 0 || ((((uintptr_t)y) & 7) == 0 && ldy % 4 == 0)), TG_ERR_ALIGN, "tg_conv3d_cl: alignment");
+    ConvParams p{(const bf16_t*)x, T, H, W, Cin, (const bf16_t*)cache, (const bf16_t*)w, (const bf16_t*)bias, cout, cout_pad, kt, kh, kw,
+                 stride, pad, up, t_map, (const bf16_t*)residual, (bf16_t*)y, ldy, To, Ho, Wo, (const bf16_t*)zeros};
+    const long M = (long)To * Ho * Wo;
+    const long tiles = ((M + BM - 1) / BM) * (cout_pad / BN);
+    TG_REQUIRE(tiles < (1L << 31), TG_ERR_SHAPE, "tg_conv3d_cl: too many tiles");
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES); attr = true; }
+    hipLaunchKernelGGL(conv3d_cl_kernel, dim3((unsigned)tiles), dim3(256), 2 * STAGE_BYTES, stream, p);
+    TG_LAUNCH_CHECK("tg_conv3d_cl");
+    return TG_OK;
+}
+
+extern "C" long tg_groupnorm_partial_floats(long V, int C) {
+    (void)C;
+    return ((V + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK) * 2 * GN_GROUPS;
+}
+
+extern "C" int tg_groupnorm_stats(const void* x, long V, int C, float eps, float* partial, float* stats, hipStream_t stream) {
+    TG_REQUIRE(x && partial && stats, TG_ERR_ARG, "tg_groupnorm_stats: null pointer");
+    TG_REQUIRE(V > 0 && C % 64 == 0 && C <= 2048 && 256 % (C / 8) == 0, TG_ERR_SHAPE, "tg_groupnorm_stats: need C in {64,128,256,512,1024,2048} (C=%d)", C);
+    TG_REQUIRE(tg_aligned16(x), TG_ERR_ALIGN, "tg_groupnorm_stats: alignment");
+    const int nblocks = (int)((V + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nblocks), dim3(256), 0, stream, (const bf16_t*)x, V, C, partial);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(64), 0, stream, (const float*)partial, nblocks, V, C, eps, stats);
+    TG_LAUNCH_CHECK("tg_groupnorm_stats");
+    return TG_OK;
+}
+
+extern "C" int tg_groupnorm_silu(const void* x, long V, int C, const float* stats, const void* gamma, const void* beta, void* y,
+                                 int apply_silu, hipStream_t stream) {
+    TG_REQUIRE(x && stats && gamma && beta && y, TG_ERR_ARG, "tg_groupnorm_silu: null pointer");
+    TG_REQUIRE(V > 0 && C % 64 == 0, TG_ERR_SHAPE, "tg_groupnorm_silu: bad shape");
+    TG_REQUIRE(tg_aligned16(x) && tg_aligned16(y) && tg_aligned16(gamma) && tg_aligned16(beta), TG_ERR_ALIGN, "tg_groupnorm_silu: alignment");
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(V * (C / 8))), dim3(256), 0, stream, (const bf16_t*)x, V, C, stats, (const bf16_t*)gamma,
+                       (const bf16_t*)beta, (bf16_t*)y, apply_silu);
+    TG_LAUNCH_CHECK("tg_groupnorm_silu");
+    return TG_OK;
+}
+
+extern "C" int tg_spatialnorm_silu(const void* f, int T, int H, int W, int C, const float* stats, const void* gamma, const void* beta,
+                                   const void* z, int Tz, int Hz, int Wz, int zc, const void* wy, const void* by, const void* wb,
+                                   const void* bb, void* y, int apply_silu, hipStream_t stream) {
+    TG_REQUIRE(f && stats && gamma && beta && z && wy && by && wb && bb && y, TG_ERR_ARG, "tg_spatialnorm_silu: null pointer");
+    TG_REQUIRE(T > 0 && H > 0 && W > 0 && C % 64 == 0 && Tz > 0 && Hz > 0 && Wz > 0, TG_ERR_SHAPE, "tg_spatialnorm_silu: bad shape");
+    TG_REQUIRE(zc == 16, TG_ERR_SHAPE, "tg_spatialnorm_silu: latent channels must be 16 (zc=%d)", zc);
+    TG_REQUIRE(tg_aligned16(f) && tg_aligned16(y) && tg_aligned16(z), TG_ERR_ALIGN, "tg_spatialnorm_silu: alignment");
+    const long total = (long)T * H * W * (C / 8);
+    hipLaunchKernelGGL(spatialnorm_kernel<16>, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16_t*)f, T, H, W, C, stats,
+                       (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)z, Tz, Hz, Wz, (const bf16_t*)wy, (const bf16_t*)by,
+                       (const bf16_t*)wb, (const bf16_t*)bb, (bf16_t*)y, apply_silu);
+    TG_LAUNCH_CHECK("tg_spatialnorm_silu");
+    return TG_OK;
+}
+
+extern "C" int tg_avgpool_time(const void* x, int T, long HW, int C, void* y, hipStream_t stream) {
+    TG_REQUIRE(x && y, TG_ERR_ARG, "tg_avgpool_time: null pointer");
+    TG_REQUIRE(T > 0 && HW > 0 && C > 0, TG_ERR_SHAPE, "tg_avgpool_time: bad shape");
+    const int To = (T & 1) ? 1 + (T - 1) / 2 : T / 2;
+    hipLaunchKernelGGL(avgpool_time_kernel, dim3(grid_for((long)To * HW * C)), dim3(256), 0, stream, (const bf16_t*)x, T, HW * C, (bf16_t*)y);
+    TG_LAUNCH_CHECK("tg_avgpool_time");
+    return TG_OK;
+}
+
+extern "C" int tg_ncdhw_to_cl(const void* src, int src_fp32, int C, int Tt, int Ht, int Wt, int t0, int Tc, int h0, int Hc, int w0, int Wc,
+                              float scale, void* dst, int Cpad, hipStream_t stream) {
+    TG_REQUIRE(src && dst, TG_ERR_ARG, "tg_ncdhw_to_cl: null pointer");
+    TG_REQUIRE(C > 0 && Cpad >= C && t0 >= 0 && h0 >= 0 && w0 >= 0 && t0 + Tc <= Tt && h0 + Hc <= Ht && w0 + Wc <= Wt && Tc > 0 && Hc > 0 && Wc > 0,
+               TG_ERR_SHAPE, "tg_ncdhw_to_cl: window outside the source tensor");
+    hipLaunchKernelGGL(ncdhw_to_cl_kernel, dim3(grid_for((long)Tc * Hc * Wc * Cpad)), dim3(256), 0, stream, src, src_fp32, C, Tt, Ht, Wt, t0, Tc,
+                       h0, Hc, w0, Wc, scale, (bf16_t*)dst, Cpad);
+    TG_LAUNCH_CHECK("tg_ncdhw_to_cl");
+    return TG_OK;
+}
+
+extern "C" int tg_cl_to_ncdhw(const void* src, long ld, int C, int T, int H, int W, void* dst, int dst_fp32, int Tt, int Ht, int Wt,
+                              int t0, int h0, int w0, hipStream_t stream) {
+    TG_REQUIRE(src && dst, TG_ERR_ARG, "tg_cl_to_ncdhw: null pointer");
+    TG_REQUIRE(C > 0 && ld >= C && t0 >= 0 && h0 >= 0 && w0 >= 0 && t0 + T <= Tt && h0 + H <= Ht && w0 + W <= Wt, TG_ERR_SHAPE,
+               "tg_cl_to_ncdhw: window outside the destination tensor");
+    hipLaunchKernelGGL(cl_to_ncdhw_kernel, dim3(grid_for((long)C * T * H * W)), dim3(256), 0, stream, (const bf16_t*)src, ld, C, T, H, W, dst,
+                       dst_fp32, Tt, Ht, Wt, t0, h0, w0);
+    TG_LAUNCH_CHECK("tg_cl_to_ncdhw");
+    return TG_OK;
+}
+
+extern "C" int tg_tile_blend(const void* a, void* b, int is_fp32, int C, int T, int Ha, int Wa, int Hb, int Wb, int axis, int extent,
+                             hipStream_t stream) {
+    TG_REQUIRE(a && b, TG_ERR_ARG, "tg_tile_blend: null pointer");
+    TG_REQUIRE((axis == 3 || axis == 4) && extent > 0 && extent <= (axis == 3 ? min(Ha, Hb) : min(Wa, Wb)), TG_ERR_SHAPE,
+               "tg_tile_blend: bad axis/extent");
+    const long total = (long)C * T * extent * (axis == 3 ? min(Wa, Wb) : min(Ha, Hb));
+    if (is_fp32)
+        hipLaunchKernelGGL(tile_blend_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, (const float*)a, (float*)b, C, T, Ha, Wa, Hb, Wb, axis, extent);
+    else
+        hipLaunchKernelGGL(tile_blend_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16_t*)a, (bf16_t*)b, C, T, Ha, Wa, Hb, Wb, axis, extent);
+    TG_LAUNCH_CHECK("tg_tile_blend");
+    return TG_OK;
+}

@@ -200,3 +200,110 @@ def cfg_dpm_step(model_out, x, old_x0, noise, coef, guidance, x_out, x0_out):
     L.check(L.load().tg_cfg_dpm_step(_p(model_out), _p(x), _p(old_x0), _p(noise), _p(coef), float(guidance), _p(x_out),
                                      _p(x0_out), F_, E, _stream()), "tg_cfg_dpm_step")
     return x_out, x0_out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# VAE (channels-last bf16 activations)
+# ---------------------------------------------------------------------------------------------------------
+_ZEROS = {}
+
+
+def zero_page(device):
+    z = _ZEROS.get(device)
+    if z is None:
+        z = _ZEROS[device] = torch.zeros(8192, dtype=BF16, device=device)
+    return z
+
+
+def conv3d_cl(x, w_packed, bias, cout, kt, kh, kw, cache=None, stride=1, pad=1, up=1, t_map=None, residual=None, out_dims=None):
+    """x [T,H,W,Cin] channels-last; w_packed [Cout_pad, kt*kh*kw, Cin]; returns y [To,Ho,Wo,cout]."""
+    _chk(x, "x"); _chk(w_packed, "w")
+    assert x.is_contiguous() and w_packed.is_contiguous()
+    T, H, W, Cin = x.shape
+    To, Ho, Wo = out_dims if out_dims is not None else (T, H, W)
+    y = torch.empty(To, Ho, Wo, cout, dtype=BF16, device=x.device)
+    if cache is not None:
+        _chk(cache, "cache"); assert cache.is_contiguous() and cache.shape == (kt - 1, H, W, Cin)
+    if residual is not None:
+        _chk(residual, "residual"); assert residual.is_contiguous() and residual.shape == y.shape
+    if t_map is not None:
+        _chk(t_map, "t_map", torch.int32)
+    L.check(_launch(f"conv3d_cl_Cin{Cin}_Cout{cout}_k{kt}{kh}{kw}_s{stride}_u{up}", L.load().tg_conv3d_cl, _p(x), T, H, W, Cin, _p(cache),
+                    _p(w_packed), _p(bias), cout, w_packed.shape[0], kt, kh, kw, stride, pad, up, _p(t_map), _p(residual), _p(y), cout, To, Ho,
+                    Wo, _p(zero_page(x.device)), _stream()), "tg_conv3d_cl")
+    return y
+
+
+def groupnorm_stats(x2d, eps=1e-6):
+    """x2d [V, C] -> stats fp32 [32, 2] (mean, rstd)."""
+    _chk(x2d, "x"); assert x2d.is_contiguous()
+    V, C = x2d.shape
+    n = L.load().tg_groupnorm_partial_floats(V, C)
+    partial = torch.empty(n, dtype=torch.float32, device=x2d.device)
+    stats = torch.empty(32, 2, dtype=torch.float32, device=x2d.device)
+    L.check(_launch("groupnorm_stats", L.load().tg_groupnorm_stats, _p(x2d), V, C, float(eps), _p(partial), _p(stats), _stream()), "tg_groupnorm_stats")
+    return stats
+
+
+def groupnorm_silu(x, stats, gamma, beta, silu=True):
+    _chk(x, "x"); assert x.is_contiguous()
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    L.check(_launch("groupnorm_silu", L.load().tg_groupnorm_silu, _p(x), x.numel() // C, C, _p(stats), _p(gamma), _p(beta), _p(y), 1 if silu else 0,
+                    _stream()), "tg_groupnorm_silu")
+    return y
+
+
+def spatialnorm_silu(f, stats, gamma, beta, z, wy, by, wb, bb, silu=True):
+    """f [T,H,W,C], z [Tz,Hz,Wz,16] channels-last."""
+    _chk(f, "f"); _chk(z, "z"); assert f.is_contiguous() and z.is_contiguous()
+    T, H, W, C = f.shape
+    Tz, Hz, Wz, zc = z.shape
+    y = torch.empty_like(f)
+    L.check(_launch("spatialnorm_silu", L.load().tg_spatialnorm_silu, _p(f), T, H, W, C, _p(stats), _p(gamma), _p(beta), _p(z), Tz, Hz, Wz, zc,
+                    _p(wy), _p(by), _p(wb), _p(bb), _p(y), 1 if silu else 0, _stream()), "tg_spatialnorm_silu")
+    return y
+
+
+def avgpool_time(x):
+    _chk(x, "x"); assert x.is_contiguous()
+    T, H, W, C = x.shape
+    To = 1 + (T - 1) // 2 if T % 2 else T // 2
+    y = torch.empty(To, H, W, C, dtype=BF16, device=x.device)
+    L.check(_launch("avgpool_time", L.load().tg_avgpool_time, _p(x), T, H * W, C, _p(y), _stream()), "tg_avgpool_time")
+    return y
+
+
+def ncdhw_to_cl(src, t0, Tc, h0, Hc, w0, Wc, Cpad, scale=1.0):
+    """src [C,T,H,W] (fp32 or bf16, contiguous) window -> [Tc,Hc,Wc,Cpad] bf16."""
+    if not src.is_cuda:
+        raise RuntimeError("ncdhw_to_cl: expected a GPU tensor (tokensgen_amd has no CPU fallback)")
+    assert src.is_contiguous() and src.dtype in (torch.float32, BF16)
+    C, Tt, Ht, Wt = src.shape
+    dst = torch.empty(Tc, Hc, Wc, Cpad, dtype=BF16, device=src.device)
+    L.check(L.load().tg_ncdhw_to_cl(_p(src), 1 if src.dtype == torch.float32 else 0, C, Tt, Ht, Wt, t0, Tc, h0, Hc, w0, Wc, float(scale), _p(dst),
+                                    Cpad, _stream()), "tg_ncdhw_to_cl")
+    return dst
+
+
+def cl_to_ncdhw(src, dst, t0=0, h0=0, w0=0):
+    """src [T,H,W,C] channels-last bf16 -> window of dst [C,Tt,Ht,Wt] (fp32 or bf16)."""
+    _chk(src, "src"); assert src.is_contiguous() and dst.is_contiguous() and dst.is_cuda
+    T, H, W, C = src.shape
+    Cd, Tt, Ht, Wt = dst.shape
+    assert Cd == C
+    L.check(L.load().tg_cl_to_ncdhw(_p(src), C, C, T, H, W, _p(dst), 1 if dst.dtype == torch.float32 else 0, Tt, Ht, Wt, t0, h0, w0, _stream()),
+            "tg_cl_to_ncdhw")
+    return dst
+
+
+def tile_blend(a, b, axis, extent):
+    """In place on b: NCDHW [C,T,H,W] tiles (same dtype, fp32 or bf16); axis 3 = height (blend_v), 4 = width (blend_h)."""
+    assert a.is_cuda and b.is_cuda and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
+    C, T, Ha, Wa = a.shape
+    _, _, Hb, Wb = b.shape
+    extent = min(a.shape[axis - 1], b.shape[axis - 1], extent)
+    if extent <= 0:
+        return b
+    L.check(L.load().tg_tile_blend(_p(a), _p(b), 1 if a.dtype == torch.float32 else 0, C, T, Ha, Wa, Hb, Wb, axis, extent, _stream()), "tg_tile_blend")
+    return b

@@ -30,6 +30,14 @@ PROTOTYPES = {
     "tg_patchify": [_vp, _vp, _i, _i, _i, _i, _vp],
     "tg_unpatchify": [_vp, _l, _vp, _i, _i, _i, _i, _vp],
     "tg_cfg_dpm_step": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _l, _vp],
+    "tg_conv3d_cl": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp],
+    "tg_groupnorm_stats": [_vp, _l, _i, _f, _vp, _vp, _vp],
+    "tg_groupnorm_silu": [_vp, _l, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "tg_spatialnorm_silu": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "tg_avgpool_time": [_vp, _i, _l, _i, _vp, _vp],
+    "tg_ncdhw_to_cl": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
+    "tg_cl_to_ncdhw": [_vp, _l, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "tg_tile_blend": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
 }
 
 _lib = None
@@ -48,6 +56,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.tg_groupnorm_partial_floats.argtypes = [C.c_long, C.c_int]
+    lib.tg_groupnorm_partial_floats.restype = C.c_long
     lib.tg_version.restype = C.c_char_p
     lib.tg_last_error_string.restype = C.c_char_p
     _lib = lib

@@ -1,0 +1,268 @@
+"""AutoencoderKLCogVideoX — host mirror of the 3-D causal VAE the pipeline calls (`vae.encode(x).latent_dist.sample()`,
+`vae.decode(z).sample`, `enable_tiling/slicing`, `config.scaling_factor`; pipeline_cogvideox_mp_fifo.py:585,682,
+infer_cogvideo_mp_fifo.py:131-132).  Reference twin: longvgen/models/autoencoder_kl_cogvideox.py.
+
+Same state-dict keys as diffusers (`encoder.conv_in.conv.weight`, `decoder.up_blocks.0.resnets.0.norm1.conv_y.conv.weight`,
+`...upsamplers.0.conv.weight`, ...).  The arithmetic is HIP only (vae.hip): channels-last bf16 activations, implicit-GEMM
+MFMA convolutions with the causal cache / zero padding / nearest upsampling folded into the loader, fused
+GroupNorm|SpatialNorm+SiLU.  The reference's result-defining structure is kept exactly: 9 spatial tiles with linear
+seam blending, temporal batches of 2 latent (8 sample) frames with the remainder folded into the first batch, GroupNorm
+statistics per (tile, temporal batch), causal cache carried across the batches of a tile and cleared per tile.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from . import lib as L
+
+BF16 = torch.bfloat16
+
+
+def _pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+class DiagonalGaussianDistribution:
+    """diffusers.models.autoencoders.vae.DiagonalGaussianDistribution semantics (mean | logvar, clamp(-30, 20))."""
+
+    def __init__(self, parameters):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self, generator=None):
+        noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=torch.float32).to(self.mean.dtype)
+        return self.mean + self.std * noise
+
+    def mode(self):
+        return self.mean
+
+
+class AutoencoderKLCogVideoX:
+    def __init__(self, in_channels=3, out_channels=3, block_out_channels=(128, 256, 256, 512), latent_channels=16, layers_per_block=3,
+                 act_fn="silu", norm_eps=1e-6, norm_num_groups=32, temporal_compression_ratio=4, sample_height=480, sample_width=720,
+                 scaling_factor=1.15258426, use_quant_conv=False, use_post_quant_conv=False, device="cuda", **unused):
+        if act_fn != "silu" or norm_num_groups != 32 or use_quant_conv or use_post_quant_conv or latent_channels != 16:
+            raise NotImplementedError("configuration differs from CogVideoX-5b's VAE in a way the fused kernels do not cover")
+        if any(c % 64 for c in block_out_channels):
+            raise NotImplementedError("block_out_channels must be multiples of 64")
+        self.config = SimpleNamespace(in_channels=in_channels, out_channels=out_channels, block_out_channels=tuple(block_out_channels),
+                                      latent_channels=latent_channels, layers_per_block=layers_per_block, norm_eps=norm_eps,
+                                      temporal_compression_ratio=temporal_compression_ratio, sample_height=sample_height,
+                                      sample_width=sample_width, scaling_factor=scaling_factor)
+        self.device = torch.device(device)
+        self.dtype = BF16
+        self.use_slicing = self.use_tiling = False
+        self.num_latent_frames_batch_size, self.num_sample_frames_batch_size = 2, 8
+        self.tile_sample_min_height, self.tile_sample_min_width = sample_height // 2, sample_width // 2
+        self.tile_overlap_factor_height, self.tile_overlap_factor_width = 1 / 6, 1 / 5
+        self._retile()
+        self._sd, self._packed = {}, {}
+        self._tl = int(np.log2(temporal_compression_ratio))
+
+    # ---- reference API -----------------------------------------------------------------------------------
+    def _retile(self):
+        s = 2 ** (len(self.config.block_out_channels) - 1)
+        self.tile_latent_min_height = int(self.tile_sample_min_height / s)
+        self.tile_latent_min_width = int(self.tile_sample_min_width / s)
+
+    def enable_tiling(self, tile_sample_min_height=None, tile_sample_min_width=None, tile_overlap_factor_height=None,
+                      tile_overlap_factor_width=None):
+        self.use_tiling = True
+        self.tile_sample_min_height = tile_sample_min_height or self.tile_sample_min_height
+        self.tile_sample_min_width = tile_sample_min_width or self.tile_sample_min_width
+        self.tile_overlap_factor_height = tile_overlap_factor_height or self.tile_overlap_factor_height
+        self.tile_overlap_factor_width = tile_overlap_factor_width or self.tile_overlap_factor_width
+        self._retile()
+
+    def disable_tiling(self):
+        self.use_tiling = False
+
+    def enable_slicing(self):
+        self.use_slicing = True
+
+    def disable_slicing(self):
+        self.use_slicing = False
+
+    def state_dict(self):
+        return dict(self._sd)
+
+    def load_state_dict(self, sd, strict=True):
+        """Keeps the bf16 originals under the diffusers names and builds the packed GEMM operands."""
+        self._sd = {k: v.detach().to(self.device, BF16).contiguous() for k, v in sd.items()}
+        self._packed = {}
+        for k, v in self._sd.items():
+            if k.endswith(".weight") and v.dim() >= 4:
+                co, ci = v.shape[:2]
+                taps = v.shape[2:]
+                if all(t == 1 for t in taps) and ci == 16:
+                    self._packed[k] = v.reshape(co, ci).contiguous()                       # SpatialNorm conv_y/conv_b: [C,16]
+                    continue
+                cin_p, cout_p = _pad_to(ci, 64), _pad_to(co, 128)
+                w = torch.zeros(cout_p, int(np.prod(taps)), cin_p, dtype=BF16, device=self.device)
+                w[:co, :, :ci] = v.reshape(co, ci, -1).permute(0, 2, 1)
+                self._packed[k] = w.contiguous()
+        return SimpleNamespace(missing_keys=[], unexpected_keys=[])
+
+    # ---- building blocks -----------------------------------------------------------------------------------
+    def _conv(self, name, x, cache, residual=None):
+        """CogVideoXCausalConv3d (autoencoder_kl_cogvideox.py:120-145): the carried cache is read in place by the kernel."""
+        w = self._sd[name + ".conv.weight"]
+        co, kt = w.shape[0], w.shape[2]
+        prev = cache.get(name) if kt > 1 else None
+        y = K.conv3d_cl(x, self._packed[name + ".conv.weight"], self._sd[name + ".conv.bias"], co, kt, w.shape[3], w.shape[4], cache=prev,
+                        residual=residual)
+        if kt > 1:
+            need = kt - 1
+            if x.shape[0] >= need:
+                cache[name] = x[-need:].clone()
+            else:
+                head = prev if prev is not None else x[:1].expand(need, -1, -1, -1)
+                cache[name] = torch.cat([head, x], dim=0)[-need:].contiguous()
+        return y
+
+    def _norm_act(self, name, x, zq, silu=True):
+        stats = K.groupnorm_stats(x.view(-1, x.shape[-1]), self.config.norm_eps)
+        if zq is None:
+            return K.groupnorm_silu(x, stats, self._sd[name + ".weight"], self._sd[name + ".bias"], silu)
+        return K.spatialnorm_silu(x, stats, self._sd[name + ".norm_layer.weight"], self._sd[name + ".norm_layer.bias"], zq,
+                                  self._packed[name + ".conv_y.conv.weight"], self._sd[name + ".conv_y.conv.bias"],
+                                  self._packed[name + ".conv_b.conv.weight"], self._sd[name + ".conv_b.conv.bias"], silu)
+
+    def _resnet(self, name, x, zq, cache):
+        """CogVideoXResnetBlock3D.forward (:277-309): the `+ inputs` is the second conv's epilogue."""
+        h = self._conv(name + ".conv1", self._norm_act(name + ".norm1", x, zq), cache)
+        h = self._norm_act(name + ".norm2", h, zq)
+        skip = x
+        if (name + ".conv_shortcut.weight") in self._sd:
+            co = self._sd[name + ".conv_shortcut.weight"].shape[0]           # 1x1x1 CogVideoXSafeConv3d (:262-265)
+            skip = K.conv3d_cl(x, self._packed[name + ".conv_shortcut.weight"], self._sd[name + ".conv_shortcut.bias"], co, 1, 1, 1, pad=0)
+        return self._conv(name + ".conv2", h, cache, residual=skip)
+
+    def _upsample(self, name, x, compress_time):
+        """diffusers CogVideoXUpsample3D: nearest x2 (first frame 2-D only when T odd > 1) + Conv2d 3x3 — folded into one conv."""
+        T, H, W, C = x.shape
+        tmap = None
+        To = T
+        if compress_time and T > 1:
+            idx = [0] + [t for t in range(1, T) for _ in (0, 1)] if T % 2 == 1 else [t for t in range(T) for _ in (0, 1)]
+            To = len(idx)
+            tmap = torch.tensor(idx, dtype=torch.int32, device=x.device)
+        w = self._sd[name + ".conv.weight"]
+        return K.conv3d_cl(x, self._packed[name + ".conv.weight"], self._sd[name + ".conv.bias"], w.shape[0], 1, 3, 3, stride=1, pad=1, up=2,
+                           t_map=tmap, out_dims=(To, 2 * H, 2 * W))
+
+    def _downsample(self, name, x, compress_time):
+        """diffusers CogVideoXDownsample3D: temporal avg-pool (first frame kept when T odd), pad (0,1,0,1), Conv2d 3x3 stride 2."""
+        if compress_time:
+            x = K.avgpool_time(x)
+        T, H, W, C = x.shape
+        w = self._sd[name + ".conv.weight"]
+        return K.conv3d_cl(x, self._packed[name + ".conv.weight"], self._sd[name + ".conv.bias"], w.shape[0], 1, 3, 3, stride=2, pad=0,
+                           out_dims=(T, (H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1))
+
+    def _encoder(self, x_cl, cache):
+        """CogVideoXEncoder3D.forward (:708-742) on a channels-last tile [T,H,W,64(3 used)] -> [T',H/8,W/8,32]."""
+        c = self.config
+        nb = len(c.block_out_channels)
+        h = self._conv("encoder.conv_in", x_cl, cache)
+        for i in range(nb):
+            for j in range(c.layers_per_block):
+                h = self._resnet(f"encoder.down_blocks.{i}.resnets.{j}", h, None, cache)
+            if i != nb - 1:
+                h = self._downsample(f"encoder.down_blocks.{i}.downsamplers.0", h, i < self._tl)
+        for j in range(2):
+            h = self._resnet(f"encoder.mid_block.resnets.{j}", h, None, cache)
+        h = self._norm_act("encoder.norm_out", h, None)
+        return self._conv("encoder.conv_out", h, cache)
+
+    def _decoder(self, z_cl64, zq, cache):
+        """CogVideoXDecoder3D.forward (:849-883); zq = the latent tile (channels-last, 16 ch)."""
+        c = self.config
+        nb = len(c.block_out_channels)
+        h = self._conv("decoder.conv_in", z_cl64, cache)
+        for j in range(2):
+            h = self._resnet(f"decoder.mid_block.resnets.{j}", h, zq, cache)
+        for i in range(nb):
+            for j in range(c.layers_per_block + 1):
+                h = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", h, zq, cache)
+            if i != nb - 1:
+                h = self._upsample(f"decoder.up_blocks.{i}.upsamplers.0", h, i < self._tl)
+        h = self._norm_act("decoder.norm_out", h, zq)
+        return self._conv("decoder.conv_out", h, cache)
+
+    @staticmethod
+    def _frame_batches(n, batch):
+        """:1092-1097, 1146-1151 — remainder folded into the first batch."""
+        nb = max(n // batch, 1) if n > 1 else 1
+        rem = n % batch
+        return [(batch * k + (0 if k == 0 else rem), batch * (k + 1) + rem) for k in range(nb)]
+
+    def _run_tile(self, src, i, j, th, tw, decode):
+        """All temporal batches of one spatial tile (cache carried, cleared per tile) -> NCDHW bf16 tile output."""
+        C, Tt, Ht, Wt = src.shape
+        Hc, Wc = min(th, Ht - i), min(tw, Wt - j)
+        cache = {}
+        outs = []
+        for a, b in self._frame_batches(Tt, self.num_latent_frames_batch_size if decode else self.num_sample_frames_batch_size):
+            if decode:
+                zq = K.ncdhw_to_cl(src, a, b - a, i, Hc, j, Wc, 16)
+                y = self._decoder(K.ncdhw_to_cl(src, a, b - a, i, Hc, j, Wc, 64), zq, cache)
+            else:
+                y = self._encoder(K.ncdhw_to_cl(src, a, b - a, i, Hc, j, Wc, 64), cache)
+            outs.append(y)
+        To = sum(o.shape[0] for o in outs)
+        Ho, Wo, Co = outs[0].shape[1:]
+        tile = torch.empty(Co, To, Ho, Wo, dtype=BF16, device=self.device)
+        t0 = 0
+        for o in outs:
+            K.cl_to_ncdhw(o, tile, t0, 0, 0)
+            t0 += o.shape[0]
+        return tile
+
+    def _process(self, src, decode):
+        """_encode/_decode incl. tiled_encode/tiled_decode (:1085-1108, 1138-1163, 1206-1359) for one batch item [C,T,H,W]."""
+        if decode:
+            th, tw = self.tile_latent_min_height, self.tile_latent_min_width
+            tsh, tsw = self.tile_sample_min_height, self.tile_sample_min_width
+        else:
+            th, tw = self.tile_sample_min_height, self.tile_sample_min_width
+            tsh, tsw = self.tile_latent_min_height, self.tile_latent_min_width
+        H, W = src.shape[2:]
+        if not (self.use_tiling and (W > tw or H > th)):
+            return self._run_tile(src, 0, 0, H, W, decode)
+        st_h, st_w = int(th * (1 - self.tile_overlap_factor_height)), int(tw * (1 - self.tile_overlap_factor_width))
+        bh, bw = int(tsh * self.tile_overlap_factor_height), int(tsw * self.tile_overlap_factor_width)
+        lim_h, lim_w = tsh - bh, tsw - bw
+        rows = [[self._run_tile(src, i, j, th, tw, decode) for j in range(0, W, st_w)] for i in range(0, H, st_h)]
+        out_rows = []
+        for i, row in enumerate(rows):
+            out = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    K.tile_blend(rows[i - 1][j], tile, 3, bh)      # in place, same order as the reference (blend_v then blend_h)
+                if j > 0:
+                    K.tile_blend(row[j - 1], tile, 4, bw)
+                out.append(tile[:, :, :lim_h, :lim_w])
+            out_rows.append(torch.cat(out, dim=3))
+        return torch.cat(out_rows, dim=2)
+
+    @torch.no_grad()
+    def encode(self, x, return_dict=True):
+        """x [B,3,T,H,W] -> latent_dist over [B,16,T',H/8,W/8] (moments computed on the GPU)."""
+        if not x.is_cuda:
+            raise RuntimeError("AutoencoderKLCogVideoX.encode: expected a GPU tensor (tokensgen_amd has no CPU fallback)")
+        h = torch.stack([self._process(xi.contiguous(), False) for xi in x])
+        post = DiagonalGaussianDistribution(h)
+        return SimpleNamespace(latent_dist=post) if return_dict else (post,)
+
+    @torch.no_grad()
+    def decode(self, z, return_dict=True):
+        """z [B,16,T,h,w] -> sample [B,3,4(T-1)+1,8h,8w] bf16."""
+        if not z.is_cuda:
+            raise RuntimeError("AutoencoderKLCogVideoX.decode: expected a GPU tensor (tokensgen_amd has no CPU fallback)")
+        d = torch.stack([self._process(zi.contiguous(), True) for zi in z])
+        return SimpleNamespace(sample=d) if return_dict else (d,)
