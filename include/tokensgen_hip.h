@@ -150,12 +150,13 @@ int tg_groupnorm_stats(const void* x, long V, int C, float eps, float* partial, 
 int tg_groupnorm_silu(const void* x, long V, int C, const float* stats, const void* gamma, const void* beta, void* y,
                       int apply_silu, hipStream_t stream);
 
-/* CogVideoXSpatialNorm3D (+ SiLU), :171-188:  y = silu( GN(f) * (Wy zq + by) + (Wb zq + bb) ), zq = the latent tile
- * z[Tz][Hz][Wz][zc] resized to f's [T][H][W] by nearest neighbour (first frame mapped separately when T is odd > 1).
- * wy/wb: [C][zc] bf16, by/bb: [C]. */
+/* CogVideoXSpatialNorm3D (+ SiLU), :171-188:  y = silu( GN(f) * conv_y(zq) + conv_b(zq) ), zq = the latent tile resized to
+ * f's [T][H][W] by nearest neighbour (first frame mapped separately when T is odd > 1).  The two 1x1x1 convs commute with
+ * the nearest resize, so the caller evaluates them once per LATENT voxel (one small tg_gemm_bf16 over the latent tile):
+ * yz, bz: [Tz*Hz*Wz][ldz] bf16 = conv_y(z), conv_b(z); this kernel gathers them per output voxel. */
 int tg_spatialnorm_silu(const void* f, int T, int H, int W, int C, const float* stats, const void* gamma, const void* beta,
-                        const void* z, int Tz, int Hz, int Wz, int zc, const void* wy, const void* by, const void* wb,
-                        const void* bb, void* y, int apply_silu, hipStream_t stream);
+                        const void* yz, const void* bz, long ldz, int Tz, int Hz, int Wz, void* y, int apply_silu,
+                        hipStream_t stream);
 
 /* Temporal average pooling of CogVideoXDownsample3D(compress_time): pairs of frames are averaged; when T is odd the first
  * frame is kept.  x [T][HW][C] -> y [To][HW][C]. */

@@ -105,9 +105,11 @@ def test_groupnorm_and_spatialnorm_silu(C):
           "n.conv_y.conv.bias": (_r(C, seed=6, scale=0.1) + 1).float(), "n.conv_b.conv.weight": _r(C, 16, 1, 1, 1, seed=7, scale=0.2).float(),
           "n.conv_b.conv.bias": _r(C, seed=8, scale=0.1).float()}
     ref = F.silu(V.spatial_norm(sd, "n", x.float(), z.float(), V.ConvCache()))
-    d = lambda k: sd[k].to(DEV, BF).reshape(C, -1).contiguous() if sd[k].dim() > 1 else sd[k].to(DEV, BF)
-    y = K.spatialnorm_silu(xc, st, gam.to(DEV), bet.to(DEV), _cl(z).to(DEV), d("n.conv_y.conv.weight"), d("n.conv_y.conv.bias"),
-                           d("n.conv_b.conv.weight"), d("n.conv_b.conv.bias"))
+    zc = _cl(z).to(DEV)                                                       # [2,3,4,16]
+    wy, wb = sd["n.conv_y.conv.weight"].reshape(C, 16), sd["n.conv_b.conv.weight"].reshape(C, 16)
+    yz = (zc.float().reshape(-1, 16) @ wy.to(DEV).T + sd["n.conv_y.conv.bias"].to(DEV)).to(BF)
+    bz = (zc.float().reshape(-1, 16) @ wb.to(DEV).T + sd["n.conv_b.conv.bias"].to(DEV)).to(BF)
+    y = K.spatialnorm_silu(xc, st, gam.to(DEV), bet.to(DEV), yz.contiguous(), bz.contiguous(), (2, 3, 4))
     assert _rel(_ncdhw(y), ref) < 8e-3
 
 

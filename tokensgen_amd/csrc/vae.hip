@@ -219,20 +219,27 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
     if (threadIdx.x < 2 * GN_GROUPS) partial[(long)blockIdx.x * 2 * GN_GROUPS + threadIdx.x] = ((float*)sh)[threadIdx.x];
 }
 
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nblocks, long V, int C, float eps, float* __restrict__ stats) {
-    const int g = threadIdx.x;
-    if (g >= GN_GROUPS) return;
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ partial, int nblocks, long V, int C, float eps, float* __restrict__ stats) {
+    // 32 groups x 32 lanes: lane k of group g sums partial blocks k, k+32, ... in fp64, then a 32-lane shuffle tree
+    const int g = threadIdx.x >> 5, k = threadIdx.x & 31;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
+    for (int b = k; b < nblocks; b += 32) {
         s += (double)partial[(long)b * 2 * GN_GROUPS + g];
         q += (double)partial[(long)b * 2 * GN_GROUPS + GN_GROUPS + g];
     }
-    const double n = (double)V * (C / GN_GROUPS);
-    const double mean = s / n;
-    double var = q / n - mean * mean;
-    if (var < 0) var = 0;
-    stats[2 * g] = (float)mean;
-    stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off, 64);
+        q += __shfl_xor(q, off, 64);
+    }
+    if (k == 0) {
+        const double n = (double)V * (C / GN_GROUPS);
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0) var = 0;
+        stats[2 * g] = (float)mean;
+        stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
@@ -260,14 +267,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     }
 }
 
-// SpatialNorm3D + SiLU: one thread = one voxel x 8 channels; the two 1x1x1 convs over the zc (=16) latent channels are
-// done in registers (weights come from L1: every thread of a channel slice reads the same 2 x 8 x zc values).
-template <int ZC>
+// SpatialNorm3D + SiLU.  conv_y / conv_b are 1x1x1 convolutions of the nearest-resized latent, and a 1x1x1 conv commutes
+// with nearest-neighbour resizing, so they are evaluated once per LATENT voxel (yz, bz: [Tz*Hz*Wz][C] bf16, a tiny GEMM) and
+// this kernel is a pure streaming pass: y = silu( GN(f) * yz[map(voxel)] + bz[map(voxel)] ).
 __global__ __launch_bounds__(256) void spatialnorm_kernel(const bf16_t* __restrict__ f, int T, int H, int W, int C,
                                                           const float* __restrict__ stats, const bf16_t* __restrict__ gamma,
-                                                          const bf16_t* __restrict__ beta, const bf16_t* __restrict__ z, int Tz, int Hz,
-                                                          int Wz, const bf16_t* __restrict__ wy, const bf16_t* __restrict__ by,
-                                                          const bf16_t* __restrict__ wb, const bf16_t* __restrict__ bb,
+                                                          const bf16_t* __restrict__ beta, const bf16_t* __restrict__ yz,
+                                                          const bf16_t* __restrict__ bz, long ldz, int Tz, int Hz, int Wz,
                                                           bf16_t* __restrict__ y, int apply_silu) {
     const int vec_per_row = C >> 3, cg = C / GN_GROUPS;
     const long V = (long)T * H * W, total = V * vec_per_row;
@@ -283,43 +289,24 @@ __global__ __launch_bounds__(256) void spatialnorm_kernel(const bf16_t* __restri
         if (split_first) tz = (t_ == 0) ? 0 : 1 + (int)(((long)(t_ - 1) * (Tz - 1)) / (T - 1));
         else tz = (int)(((long)t_ * Tz) / T);
         const int hz = (int)(((long)h_ * Hz) / H), wz = (int)(((long)w_ * Wz) / W);
-        const bf16_t* zp = z + (((long)tz * Hz + hz) * Wz + wz) * ZC;
-        float zv[ZC];
-#pragma unroll
-        for (int k = 0; k < ZC; k += 8) {
-            const uint4 r = *(const uint4*)(zp + k);
-            const uint32_t u[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { zv[k + 2 * i] = bf16lo_to_f32(u[i]); zv[k + 2 * i + 1] = bf16hi_to_f32(u[i]); }
-        }
+        const long zrow = (((long)tz * Hz + hz) * Wz + wz) * ldz + cv * 8;
         const uint4 raw = *(const uint4*)(f + v * 8);
-        const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
-        float xin[8];
+        const uint4 yr = *(const uint4*)(yz + zrow), br = *(const uint4*)(bz + zrow);
+        const uint4 gw = *(const uint4*)(gamma + cv * 8), bw = *(const uint4*)(beta + cv * 8);
+        const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w}, yu[4] = {yr.x, yr.y, yr.z, yr.w}, zu[4] = {br.x, br.y, br.z, br.w};
+        const uint32_t gu[4] = {gw.x, gw.y, gw.z, gw.w}, bu[4] = {bw.x, bw.y, bw.z, bw.w};
+        uint32_t o[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { xin[2 * i] = bf16lo_to_f32(u[i]); xin[2 * i + 1] = bf16hi_to_f32(u[i]); }
-        float out[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = cv * 8 + e, g = c / cg;
-            float sy = 0.f, sb = 0.f;
-            const bf16_t* wyr = wy + (long)c * ZC;
-            const bf16_t* wbr = wb + (long)c * ZC;
-#pragma unroll
-            for (int k = 0; k < ZC; k += 2) {
-                const uint32_t a = *(const uint32_t*)(wyr + k), b2 = *(const uint32_t*)(wbr + k);
-                sy += bf16lo_to_f32(a) * zv[k] + bf16hi_to_f32(a) * zv[k + 1];
-                sb += bf16lo_to_f32(b2) * zv[k] + bf16hi_to_f32(b2) * zv[k + 1];
-            }
-            const float nf = round_bf16((xin[e] - stats[2 * g]) * stats[2 * g + 1] * bf16_to_f32(gamma[c]) + bf16_to_f32(beta[c]));
-            const float yy = round_bf16(sy + bf16_to_f32(by[c])), bbv = round_bf16(sb + bf16_to_f32(bb[c]));
-            float r = round_bf16(nf * yy) + bbv;
-            if (apply_silu) r = silu_f(round_bf16(r));
-            out[e] = r;
+        for (int i = 0; i < 4; ++i) {
+            const int g0 = (cv * 8 + 2 * i) / cg, g1 = (cv * 8 + 2 * i + 1) / cg;
+            const float n0 = round_bf16((bf16lo_to_f32(u[i]) - stats[2 * g0]) * stats[2 * g0 + 1] * bf16lo_to_f32(gu[i]) + bf16lo_to_f32(bu[i]));
+            const float n1 = round_bf16((bf16hi_to_f32(u[i]) - stats[2 * g1]) * stats[2 * g1 + 1] * bf16hi_to_f32(gu[i]) + bf16hi_to_f32(bu[i]));
+            float a = round_bf16(n0 * bf16lo_to_f32(yu[i])) + bf16lo_to_f32(zu[i]);
+            float b = round_bf16(n1 * bf16hi_to_f32(yu[i])) + bf16hi_to_f32(zu[i]);
+            if (apply_silu) { a = silu_f(round_bf16(a)); b = silu_f(round_bf16(b)); }
+            o[i] = pack_bf16x2(a, b);
         }
-        uint4 o;
-        o.x = pack_bf16x2(out[0], out[1]); o.y = pack_bf16x2(out[2], out[3]);
-        o.z = pack_bf16x2(out[4], out[5]); o.w = pack_bf16x2(out[6], out[7]);
-        *(uint4*)(y + v * 8) = o;
+        *(uint4*)(y + v * 8) = uint4{o[0], o[1], o[2], o[3]};
     }
 }
 
@@ -439,7 +426,7 @@ extern "C" int tg_groupnorm_stats(const void* x, long V, int C, float eps, float
     TG_REQUIRE(tg_aligned16(x), TG_ERR_ALIGN, "tg_groupnorm_stats: alignment");
     const int nblocks = (int)((V + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nblocks), dim3(256), 0, stream, (const bf16_t*)x, V, C, partial);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(64), 0, stream, (const float*)partial, nblocks, V, C, eps, stats);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(1024), 0, stream, (const float*)partial, nblocks, V, C, eps, stats);
     TG_LAUNCH_CHECK("tg_groupnorm_stats");
     return TG_OK;
 }
@@ -456,16 +443,15 @@ extern "C" int tg_groupnorm_silu(const void* x, long V, int C, const float* stat
 }
 
 extern "C" int tg_spatialnorm_silu(const void* f, int T, int H, int W, int C, const float* stats, const void* gamma, const void* beta,
-                                   const void* z, int Tz, int Hz, int Wz, int zc, const void* wy, const void* by, const void* wb,
-                                   const void* bb, void* y, int apply_silu, hipStream_t stream) {
-    TG_REQUIRE(f && stats && gamma && beta && z && wy && by && wb && bb && y, TG_ERR_ARG, "tg_spatialnorm_silu: null pointer");
-    TG_REQUIRE(T > 0 && H > 0 && W > 0 && C % 64 == 0 && Tz > 0 && Hz > 0 && Wz > 0, TG_ERR_SHAPE, "tg_spatialnorm_silu: bad shape");
-    TG_REQUIRE(zc == 16, TG_ERR_SHAPE, "tg_spatialnorm_silu: latent channels must be 16 (zc=%d)", zc);
-    TG_REQUIRE(tg_aligned16(f) && tg_aligned16(y) && tg_aligned16(z), TG_ERR_ALIGN, "tg_spatialnorm_silu: alignment");
+                                   const void* yz, const void* bz, long ldz, int Tz, int Hz, int Wz, void* y, int apply_silu,
+                                   hipStream_t stream) {
+    TG_REQUIRE(f && stats && gamma && beta && yz && bz && y, TG_ERR_ARG, "tg_spatialnorm_silu: null pointer");
+    TG_REQUIRE(T > 0 && H > 0 && W > 0 && C % 64 == 0 && Tz > 0 && Hz > 0 && Wz > 0 && ldz >= C && ldz % 8 == 0, TG_ERR_SHAPE,
+               "tg_spatialnorm_silu: bad shape");
+    TG_REQUIRE(tg_aligned16(f) && tg_aligned16(y) && tg_aligned16(yz) && tg_aligned16(bz), TG_ERR_ALIGN, "tg_spatialnorm_silu: alignment");
     const long total = (long)T * H * W * (C / 8);
-    hipLaunchKernelGGL(spatialnorm_kernel<16>, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16_t*)f, T, H, W, C, stats,
-                       (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)z, Tz, Hz, Wz, (const bf16_t*)wy, (const bf16_t*)by,
-                       (const bf16_t*)wb, (const bf16_t*)bb, (bf16_t*)y, apply_silu);
+    hipLaunchKernelGGL(spatialnorm_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16_t*)f, T, H, W, C, stats,
+                       (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)yz, (const bf16_t*)bz, ldz, Tz, Hz, Wz, (bf16_t*)y, apply_silu);
     TG_LAUNCH_CHECK("tg_spatialnorm_silu");
     return TG_OK;
 }

@@ -254,14 +254,15 @@ def groupnorm_silu(x, stats, gamma, beta, silu=True):
     return y
 
 
-def spatialnorm_silu(f, stats, gamma, beta, z, wy, by, wb, bb, silu=True):
-    """f [T,H,W,C], z [Tz,Hz,Wz,16] channels-last."""
-    _chk(f, "f"); _chk(z, "z"); assert f.is_contiguous() and z.is_contiguous()
+def spatialnorm_silu(f, stats, gamma, beta, yz, bz, zdims, silu=True):
+    """f [T,H,W,C]; yz/bz [Tz*Hz*Wz, >=C] = conv_y(z)/conv_b(z) per latent voxel (row stride may exceed C); zdims=(Tz,Hz,Wz)."""
+    _chk(f, "f"); _chk(yz, "yz"); _chk(bz, "bz"); assert f.is_contiguous()
     T, H, W, C = f.shape
-    Tz, Hz, Wz, zc = z.shape
+    Tz, Hz, Wz = zdims
+    assert yz.shape[0] == Tz * Hz * Wz and yz.stride(0) == bz.stride(0)
     y = torch.empty_like(f)
-    L.check(_launch("spatialnorm_silu", L.load().tg_spatialnorm_silu, _p(f), T, H, W, C, _p(stats), _p(gamma), _p(beta), _p(z), Tz, Hz, Wz, zc,
-                    _p(wy), _p(by), _p(wb), _p(bb), _p(y), 1 if silu else 0, _stream()), "tg_spatialnorm_silu")
+    L.check(_launch("spatialnorm_silu", L.load().tg_spatialnorm_silu, _p(f), T, H, W, C, _p(stats), _p(gamma), _p(beta), _p(yz), _p(bz),
+                    yz.stride(0), Tz, Hz, Wz, _p(y), 1 if silu else 0, _stream()), "tg_spatialnorm_silu")
     return y
 
 

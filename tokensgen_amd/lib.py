@@ -33,7 +33,7 @@ PROTOTYPES = {
     "tg_conv3d_cl": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp],
     "tg_groupnorm_stats": [_vp, _l, _i, _f, _vp, _vp, _vp],
     "tg_groupnorm_silu": [_vp, _l, _i, _vp, _vp, _vp, _vp, _i, _vp],
-    "tg_spatialnorm_silu": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "tg_spatialnorm_silu": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _i, _vp],
     "tg_avgpool_time": [_vp, _i, _l, _i, _vp, _vp],
     "tg_ncdhw_to_cl": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
     "tg_cl_to_ncdhw": [_vp, _l, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],

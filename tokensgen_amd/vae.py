@@ -98,13 +98,24 @@ class AutoencoderKLCogVideoX:
             if k.endswith(".weight") and v.dim() >= 4:
                 co, ci = v.shape[:2]
                 taps = v.shape[2:]
-                if all(t == 1 for t in taps) and ci == 16:
-                    self._packed[k] = v.reshape(co, ci).contiguous()                       # SpatialNorm conv_y/conv_b: [C,16]
-                    continue
+                if all(t == 1 for t in taps) and ci == 16 and (k.endswith("conv_y.conv.weight") or k.endswith("conv_b.conv.weight")):
+                    continue                                                               # SpatialNorm convs: fused below
                 cin_p, cout_p = _pad_to(ci, 64), _pad_to(co, 128)
                 w = torch.zeros(cout_p, int(np.prod(taps)), cin_p, dtype=BF16, device=self.device)
                 w[:co, :, :ci] = v.reshape(co, ci, -1).permute(0, 2, 1)
                 self._packed[k] = w.contiguous()
+        # SpatialNorm: conv_y | conv_b of one norm layer -> ONE [2*Cpad, 64] GEMM weight over the (zero-padded) latent channels
+        for k in list(self._sd):
+            if k.endswith(".conv_y.conv.weight"):
+                base = k[: -len(".conv_y.conv.weight")]
+                wy, wb = self._sd[k], self._sd[base + ".conv_b.conv.weight"]
+                C = wy.shape[0]
+                Cp = _pad_to(C, 128)
+                w = torch.zeros(2 * Cp, 64, dtype=BF16, device=self.device)
+                w[:C, :16], w[Cp:Cp + C, :16] = wy.reshape(C, 16), wb.reshape(C, 16)
+                b = torch.zeros(2 * Cp, dtype=BF16, device=self.device)
+                b[:C], b[Cp:Cp + C] = self._sd[base + ".conv_y.conv.bias"], self._sd[base + ".conv_b.conv.bias"]
+                self._packed[base + ".yb.weight"], self._packed[base + ".yb.bias"] = w, b
         return SimpleNamespace(missing_keys=[], unexpected_keys=[])
 
     # ---- building blocks -----------------------------------------------------------------------------------
@@ -128,9 +139,13 @@ class AutoencoderKLCogVideoX:
         stats = K.groupnorm_stats(x.view(-1, x.shape[-1]), self.config.norm_eps)
         if zq is None:
             return K.groupnorm_silu(x, stats, self._sd[name + ".weight"], self._sd[name + ".bias"], silu)
-        return K.spatialnorm_silu(x, stats, self._sd[name + ".norm_layer.weight"], self._sd[name + ".norm_layer.bias"], zq,
-                                  self._packed[name + ".conv_y.conv.weight"], self._sd[name + ".conv_y.conv.bias"],
-                                  self._packed[name + ".conv_b.conv.weight"], self._sd[name + ".conv_b.conv.bias"], silu)
+        z64, zdims = zq                                    # latent tile, channels-last padded to 64: [Vz, 64]
+        w, b = self._packed[name + ".yb.weight"], self._packed[name + ".yb.bias"]
+        yb = torch.empty(z64.shape[0], w.shape[0], dtype=BF16, device=x.device)
+        K.gemm(z64, w, b, yb, L.EPI_BIAS)                 # conv_y(z) | conv_b(z) per latent voxel (1x1x1 conv commutes with nearest resize)
+        Cp = w.shape[0] // 2
+        return K.spatialnorm_silu(x, stats, self._sd[name + ".norm_layer.weight"], self._sd[name + ".norm_layer.bias"], yb[:, :Cp], yb[:, Cp:],
+                                  zdims, silu)
 
     def _resnet(self, name, x, zq, cache):
         """CogVideoXResnetBlock3D.forward (:277-309): the `+ inputs` is the second conv's epilogue."""
@@ -209,8 +224,8 @@ class AutoencoderKLCogVideoX:
         outs = []
         for a, b in self._frame_batches(Tt, self.num_latent_frames_batch_size if decode else self.num_sample_frames_batch_size):
             if decode:
-                zq = K.ncdhw_to_cl(src, a, b - a, i, Hc, j, Wc, 16)
-                y = self._decoder(K.ncdhw_to_cl(src, a, b - a, i, Hc, j, Wc, 64), zq, cache)
+                z64 = K.ncdhw_to_cl(src, a, b - a, i, Hc, j, Wc, 64)
+                y = self._decoder(z64, (z64.view(-1, 64), (b - a, Hc, Wc)), cache)
             else:
                 y = self._encoder(K.ncdhw_to_cl(src, a, b - a, i, Hc, j, Wc, 64), cache)
             outs.append(y)

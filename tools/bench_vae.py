@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""BASELINE config 4: 3-D causal VAE encode/decode only, 720x480x49 frames, 1 GPU (tiling + slicing on, like the pipeline)."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import vae_ref as V  # noqa: E402  (seeded weight initialiser with the diffusers key names only)
+from tokensgen_amd import kernels as K  # noqa: E402
+from tokensgen_amd.vae import AutoencoderKLCogVideoX  # noqa: E402
+
+DEV = "cuda"
+cfg = dict(block_out_channels=(128, 256, 256, 512), layers_per_block=3, latent_channels=16, sample_height=480, sample_width=720)
+vae = AutoencoderKLCogVideoX(device=DEV)
+vae.load_state_dict(V.make_state_dict(cfg, seed=1, dtype=torch.bfloat16))
+vae.enable_tiling(); vae.enable_slicing()
+g = torch.Generator(device=DEV).manual_seed(0)
+z = (torch.randn(1, 16, 13, 60, 90, generator=g, device=DEV) / 1.15258426).to(torch.bfloat16)
+x = (torch.rand(1, 3, 49, 480, 720, generator=g, device=DEV) * 2 - 1).to(torch.bfloat16)
+what = sys.argv[1:] or ["decode", "encode"]
+for name in what:
+    fn = (lambda: vae.decode(z).sample) if name == "decode" else (lambda: vae.encode(x).latent_dist.mode())
+    out = fn(); torch.cuda.synchronize()
+    K.PROFILE.clear(); K.PROFILE_ON[0] = True
+    t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    K.PROFILE_ON[0] = False
+    prof = K.profile_summary()
+    flop = {"decode": 3.1e14, "encode": 1.5e14}[name]      # untiled algorithmic count; executed = x1.40
+    top = sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:8]
+    print(json.dumps({"op": f"vae_{name}", "out_shape": list(out.shape), "seconds": dt, "clips_per_s": 1 / dt,
+                      "algorithmic_TFLOPs": flop / dt / 1e12, "executed_TFLOPs": 1.4 * flop / dt / 1e12, "finite": bool(torch.isfinite(out).all()),
+                      "kernel_total_ms": {k: round(v["total_ms"], 1) for k, v in top}, "launches": sum(v["n"] for v in prof.values())}))
