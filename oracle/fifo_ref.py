@@ -176,3 +176,29 @@ def run_fifo_prenoise(denoise_window, betas, ac, fifo_latents, fifo_old_x0, time
         feed = feed[1:]
         qs = max(0, qs - 1)
     return torch.cat(outs[T - nf:], dim=1)
+
+
+def base_stage(denoise, ac, latents, timesteps, guidance_scale, noise_fn, nf=13):
+    """Base stage of the pipeline, pipeline_cogvideox_mp_fifo.py:1186-1307 (chunk 0, scalar timestep, CFG in fp32,
+    whole-chunk scheduler step, latents cast back to the model dtype).  denoise(x[2,nf,...], t[2]) -> [2,nf,...];
+    noise_fn(i) -> [nf,2,C,H,W] (draw 1 of every frame is the one the 2M branch keeps).  Returns
+    (fifo_latents [1,T,C,H,W], fifo_old list, final latents)."""
+    dt = latents.dtype
+    fifo_lat, fifo_old, old = [], [], None
+    ts = [int(t) for t in timesteps]
+    for i, t in enumerate(ts):
+        k = max(0, nf - 1 - i)
+        fifo_lat.insert(0, latents[:, [k]])
+        fifo_old.insert(0, None if old is None else old[:, [k]])
+        pred = denoise(torch.cat([latents] * 2), torch.tensor([t, t])).float()
+        u, c = pred.chunk(2)
+        pred = u + guidance_scale * (c - u)
+        prev_t = ts[i + 1] if i + 1 < len(ts) else -1
+        t_back = ts[i - 1] if i > 0 else None
+        nz = noise_fn(i)
+        second = old is not None and prev_t >= 0
+        n = nz[:, 1 if second else 0].float()[None]           # [1,nf,C,H,W]
+        seq = iter([n, n])
+        latents_f, old = S.dpm_step(ac, pred, old, t, prev_t, t_back, latents, lambda: next(seq))
+        latents = latents_f.to(dt)
+    return torch.cat(fifo_lat, dim=1), fifo_old, latents

@@ -69,3 +69,43 @@ def test_fifo_queue_evolution_vs_oracle(golden_dir):
     assert out.shape == ref.shape == (1, num_frames, 16, H, W) and torch.isfinite(out).all()
     rel = ((out.float().cpu() - ref.float()).norm() / ref.float().norm()).item()
     assert rel < 0.1, rel
+
+
+@pytest.mark.timeout(900)
+def test_base_stage_seeds_fifo_like_reference(golden_dir):
+    """Pipeline base stage (52 scalar-timestep CFG steps on chunk 0) on the HIP path vs the oracle restatement of
+    pipeline_cogvideox_mp_fifo.py:1186-1307 with the same keyed noise; then decode the result with the HIP VAE."""
+    from tokensgen_amd.pipeline import MPFIFOVideoIPAdapterCogVideoXPipeline
+    from tokensgen_amd.scheduler import CogVideoXDPMScheduler
+    from tokensgen_amd.transformer import CogVideoXTransformer3DModel
+    gt = torch.load(os.path.join(golden_dir, "dit_tiny.pt"), weights_only=False)
+    g = torch.load(os.path.join(golden_dir, "fifo_tiny.pt"), weights_only=False)
+    cfg, vipcfg = gt["cfg"], gt["vip"]
+    sd = {k: v.to(BF) for k, v in O.make_state_dict(cfg, 128, seed=g["weight_seed"]).items()}
+    H, W, nf, T = g["H"], g["W"], 13, 52
+    gen = torch.Generator().manual_seed(77)
+    lat0 = torch.randn(1, nf, 16, H, W, generator=gen).to(BF)
+    prompt, emb = g["prompt"].to(BF), g["image_embeddings"].to(BF)[:, :8]
+    rope = O.rope_3d_crop(64, (0, 0, 0), (nf, H // 2, W // 2), (nf, H // 2, W // 2))
+    _, ac = S.alphas_cumprod()
+    ts = S.trailing_timesteps(T)
+    vr = O.rope_3d(64, g["grid_t"][:13], g["grid_h"], g["grid_w"])
+    cr = O.rope_3d(64, g["cond_t"][:5], g["cond_h"], g["cond_w"])
+    den = lambda x, t: O.dit_forward(sd, cfg, x, prompt, t, emb[:, :5], rope, vr, cr, vip_scale=[0.6])
+    ref_lat, ref_old, ref_final = Fq.base_stage(den, ac, lat0, ts, 6.0, lambda i: _noise(i, 5, (nf, 2, 16, H, W)))
+
+    m = CogVideoXTransformer3DModel(num_attention_heads=2, attention_head_dim=64, num_layers=2, time_embed_dim=cfg["time_embed_dim"],
+                                    text_embed_dim=cfg["text_embed_dim"], use_rotary_positional_embeddings=True, device=DEV)
+    m.set_vip_layers(None, **vipcfg)
+    m.load_state_dict(sd, strict=True)
+    sched = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
+    pipe = MPFIFOVideoIPAdapterCogVideoXPipeline(m, sched, resampler_config=dict(num_temporal_queries=4, num_height_queries=2, num_width_queries=3))
+    out = pipe(prompt_embeds=prompt[1:], negative_prompt_embeds=prompt[:1], image_embeddings=emb, height=H * 8, width=W * 8,
+               latents=lat0, step_noise=lambda i: _noise(i, 5, (nf, 2, 16, H, W)))
+    assert out.fifo_latents.shape == ref_lat.shape == (1, T, 16, H, W)
+    rel = lambda a, b: ((a.float().cpu() - b.float()).norm() / b.float().norm()).item()
+    assert rel(out.fifo_latents, ref_lat) < 0.1 and rel(out.orig_latents, ref_final) < 0.1
+    assert [o is None for o in out.fifo_old_pred_original_sample] == [o is None for o in ref_old]
+    assert np.array_equal(out.vip_condition_rotary_grid[0], g["cond_t"][:8]) and np.array_equal(out.vip_image_rotary_grid[0], g["grid_t"][:13])
+    with pytest.raises(NotImplementedError):
+        pipe(prompt="a cat")

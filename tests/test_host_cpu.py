@@ -138,3 +138,38 @@ def test_c_abi_exports_every_declared_symbol():
     p = ctypes.addressof(buf) + (16 - ctypes.addressof(buf) % 16)
     assert lib.tg_gemm_bf16(p, 64, 0, p, 64, None, p, 100, 0, 4, 100, 64, 1, 0, None, 0, 0, None, None) == -2
     assert b"N%128" in lib.tg_last_error_string()
+
+
+def test_longvgen_alias_and_vae_host_contract():
+    import sys
+    from tokensgen_amd import compat
+    from tokensgen_amd.vae import AutoencoderKLCogVideoX
+    from oracle import vae_ref as V
+    assert "longvgen" not in sys.modules
+    compat.install_longvgen_alias()
+    try:
+        from longvgen.models import CogVideoXTransformer3DModel, AutoencoderKLCogVideoX as A2
+        from longvgen.schedulers import CogVideoXDPMScheduler
+        from longvgen.fifo_sampling import cogvideo_fifo_mp_v2
+        from longvgen.pipeline import MPFIFOVideoIPAdapterCogVideoXPipeline
+        assert A2 is AutoencoderKLCogVideoX and callable(cogvideo_fifo_mp_v2)
+        with pytest.raises(ImportError):
+            import longvgen.data  # noqa: F401  (out of scope: never silently stubbed)
+    finally:
+        for k in [k for k in sys.modules if k == "longvgen" or k.startswith("longvgen.")]:
+            del sys.modules[k]
+    vae = AutoencoderKLCogVideoX(device="cpu")
+    assert (vae.tile_sample_min_height, vae.tile_sample_min_width, vae.tile_latent_min_height, vae.tile_latent_min_width) == (240, 360, 30, 45)
+    assert vae.config.scaling_factor == 1.15258426 and vae._frame_batches(13, 2) == V.frame_batches(13, 2) and vae._frame_batches(49, 8) == V.frame_batches(49, 8)
+    cfg = dict(block_out_channels=(64, 128, 128, 128), layers_per_block=1, latent_channels=16, sample_height=64, sample_width=96)
+    v2 = AutoencoderKLCogVideoX(block_out_channels=cfg["block_out_channels"], layers_per_block=1, sample_height=64, sample_width=96, device="cpu")
+    sd = V.make_state_dict(cfg, seed=1)
+    v2.load_state_dict(sd)
+    assert sorted(v2.state_dict()) == sorted(sd)
+    w = v2._packed["decoder.conv_in.conv.weight"]                 # [Cout_pad, taps, Cin_pad], taps ordered (dt, dh, dw)
+    assert w.shape == (128, 27, 64) and torch.equal(w[:128, 5, :16].float(), sd["decoder.conv_in.conv.weight"][:, :, 0, 1, 2].to(torch.bfloat16).float())
+    assert (w[:, :, 16:] == 0).all()
+    with pytest.raises(RuntimeError, match="GPU"):
+        v2.decode(torch.zeros(1, 16, 3, 4, 6))
+    with pytest.raises(NotImplementedError):
+        AutoencoderKLCogVideoX(latent_channels=8, device="cpu")

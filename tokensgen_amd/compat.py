@@ -1,0 +1,35 @@
+"""`longvgen`-compatible import aliases, so the reference's entry script keeps its import lines
+(infer_cogvideo_mp_fifo.py:63-71):
+
+    import tokensgen_amd.compat; tokensgen_amd.compat.install_longvgen_alias()
+    from longvgen.models import CogVideoXTransformer3DModel            # -> tokensgen_amd.transformer
+    from longvgen.schedulers import CogVideoXDPMScheduler              # -> tokensgen_amd.scheduler
+    from longvgen.fifo_sampling import cogvideo_fifo_mp_v2             # -> tokensgen_amd.fifo
+    from longvgen.pipeline import MPFIFOVideoIPAdapterCogVideoXPipeline
+
+Only the hot-path names exist; anything else of the reference package (data loading, Resampler, T2To pipeline, training
+utilities) is deliberately absent and raises ImportError."""
+import sys
+import types
+
+
+def install_longvgen_alias(force=False):
+    if "longvgen" in sys.modules and not force:
+        raise RuntimeError("a `longvgen` package is already imported; refusing to shadow it (pass force=True to override)")
+    from . import fifo, pipeline, scheduler, transformer, vae
+    root = types.ModuleType("longvgen")
+    root.__path__ = []
+    subs = {
+        "models": dict(CogVideoXTransformer3DModel=transformer.CogVideoXTransformer3DModel, AutoencoderKLCogVideoX=vae.AutoencoderKLCogVideoX),
+        "schedulers": dict(CogVideoXDPMScheduler=scheduler.CogVideoXDPMScheduler),
+        "fifo_sampling": dict(cogvideo_fifo_mp_v2=fifo.cogvideo_fifo_mp_v2),
+        "pipeline": dict(MPFIFOVideoIPAdapterCogVideoXPipeline=pipeline.MPFIFOVideoIPAdapterCogVideoXPipeline),
+    }
+    sys.modules["longvgen"] = root
+    for name, attrs in subs.items():
+        m = types.ModuleType(f"longvgen.{name}")
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        setattr(root, name, m)
+        sys.modules[f"longvgen.{name}"] = m
+    return root

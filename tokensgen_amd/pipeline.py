@@ -1,0 +1,145 @@
+"""MPFIFOVideoIPAdapterCogVideoXPipeline — host mirror of the parts of longvgen/pipeline/pipeline_cogvideox_mp_fifo.py that
+are on the hot path: the 52-step base stage on chunk 0 that seeds the FIFO queue (:1186-1307),
+`prepare_latents` (:650-674), the RoPE helpers (:769-813), `preprare_for_fifo` (sic, :1491-1514) and `decode_latents`
+(:676-684).  Prompt encoding (T5) and the condensed-token encoder (Resampler) are upstream of the path: pass
+`prompt_embeds` / `negative_prompt_embeds` / `image_embeddings` tensors (as the reference's own `image_embeddings is not
+None` branch does, :611-616); passing raw prompts or frames raises NotImplementedError.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import rope as R
+from .fifo import BF16
+
+
+class MPFIFOVideoIPAdapterCogVideoXPipeline:
+    def __init__(self, transformer, scheduler, vae=None, resampler_config=None, device=None):
+        self.transformer, self.scheduler, self.vae = transformer, scheduler, vae
+        self.device = torch.device(device) if device is not None else transformer.device
+        self.vae_scale_factor_spatial = 2 ** (len(vae.config.block_out_channels) - 1) if vae is not None else 8
+        self.vae_scale_factor_temporal = vae.config.temporal_compression_ratio if vae is not None else 4
+        self.vae_scaling_factor_image = vae.config.scaling_factor if vae is not None else 1.15258426
+        self.resampler = SimpleNamespace(config=SimpleNamespace(**(resampler_config or dict(
+            num_temporal_queries=4, num_height_queries=8, num_width_queries=12))))
+        self._guidance_scale = 6.0
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    # ---- helpers -------------------------------------------------------------------------------------------
+    def prepare_latents(self, batch_size, num_channels_latents, num_frames, height, width, generator=None, latents=None):
+        """:650-674 — [B, (F-1)/4+1, C, H/8, W/8] * init_noise_sigma."""
+        shape = (batch_size, (num_frames - 1) // self.vae_scale_factor_temporal + 1, num_channels_latents,
+                 height // self.vae_scale_factor_spatial, width // self.vae_scale_factor_spatial)
+        if latents is None:
+            latents = torch.randn(shape, generator=generator, device=self.device, dtype=torch.float32).to(BF16)
+        return latents.to(self.device, BF16) * self.scheduler.init_noise_sigma
+
+    def _prepare_rotary_positional_embeddings(self, height, width, num_frames, device=None):
+        """:769-795 (720x480 base size: the crop region is the full grid)."""
+        p = self.transformer.config.patch_size
+        gh, gw = height // (self.vae_scale_factor_spatial * p), width // (self.vae_scale_factor_spatial * p)
+        return R.rope_3d_crop(self.transformer.config.attention_head_dim, (0, 0, 0), (num_frames, gh, gw), (num_frames, gh, gw))
+
+    def _prepare_vip_rotary_positional_embeddings(self, grid_t, grid_h, grid_w, device=None):
+        """:797-813"""
+        return R.rope_3d(self.transformer.config.attention_head_dim, grid_t, grid_h, grid_w)
+
+    def decode_latents(self, latents, nf_per_chunk=13):
+        """:676-684 — [B,F,C,h,w] -> frames [B,3,T,H,W], one vae.decode per 13-latent-frame chunk."""
+        z = (latents.permute(0, 2, 1, 3, 4).float() / self.vae_scaling_factor_image).to(BF16).contiguous()
+        frames = [self.vae.decode(z[:, :, c * nf_per_chunk:(c + 1) * nf_per_chunk].contiguous()).sample
+                  for c in range(z.shape[2] // nf_per_chunk)]
+        return torch.cat(frames, dim=2)
+
+    def preprare_for_fifo(self, num_inference_steps=52, guidance_scale=6.0, video_ipadapter_scale=None, **unused):
+        """:1491-1514 — what the non-zero ranks run instead of the base stage: set vip scale + timesteps."""
+        self._guidance_scale = guidance_scale
+        self._set_vip_scale(video_ipadapter_scale)
+        self.scheduler.set_timesteps(num_inference_steps, device=None)
+
+    def _set_vip_scale(self, scale):
+        if scale is None:
+            return
+        for m in self.transformer.modules():          # :981-983 — matched by class NAME in the reference
+            if m.__class__.__name__ == "VideoIPAdapterCogVideoXAttnProcessor2_0":
+                m.scale = scale
+
+    # ---- base stage --------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, prompt=None, frames=None, prompt_embeds=None, negative_prompt_embeds=None, image_embeddings=None,
+                 height=480, width=720, num_frames_per_chunk=49, num_chunks=1, num_inference_steps=52, guidance_scale=6.0,
+                 video_ipadapter_scale=None, video_ipadapter_start_frame_idx=1000, latents=None, generator=None, step_noise=None,
+                 sampling_params=None, output_type="latent", return_dict=False, **unused):
+        """Base stage (:837-1344): `num_inference_steps` scalar-timestep CFG steps on chunk 0, harvesting
+        `latents[:, max(0, 12-i)]` (and the matching x0) into the FIFO seed lists before every step (:1190-1194).
+        step_noise: optional callable i -> [nf,2,C,h,w] bf16 (default: seeded device generator)."""
+        if prompt is not None or frames is not None:
+            raise NotImplementedError("T5 prompt encoding and the Resampler are upstream of the hot path: pass prompt_embeds / image_embeddings")
+        if prompt_embeds is None or negative_prompt_embeds is None:
+            raise ValueError("prompt_embeds and negative_prompt_embeds are required")
+        dev = self.device
+        self._guidance_scale = guidance_scale
+        self._set_vip_scale(video_ipadapter_scale)
+        use_vip = image_embeddings is not None
+        embeds = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0).to(dev, BF16)            # :1028 (uncond, cond)
+        self.scheduler.set_timesteps(num_inference_steps, device=None)
+        ts = self.scheduler.timesteps.tolist()
+        nf = (num_frames_per_chunk - 1) // self.vae_scale_factor_temporal + 1
+        C = self.transformer.config.in_channels
+        latents = self.prepare_latents(1, C, num_frames_per_chunk, height, width, generator, latents)
+        h, w = latents.shape[-2:]
+        p = self.transformer.config.patch_size
+        rope = self._prepare_rotary_positional_embeddings(height, width, nf)
+        f32 = np.float32
+        vr = cr = emb0 = None
+        grids = None
+        if use_vip:
+            rq = self.resampler.config
+            gh, gw = np.linspace(0, h // p, h // p, endpoint=False, dtype=f32), np.linspace(0, w // p, w // p, endpoint=False, dtype=f32)
+            gt = np.linspace(0, num_chunks * nf, num_chunks * nf, endpoint=False, dtype=f32)
+            vnf = rq.num_temporal_queries
+            ch = np.linspace(0, h // p, rq.num_height_queries, endpoint=False, dtype=f32)
+            cw = np.linspace(0, w // p, rq.num_width_queries, endpoint=False, dtype=f32)
+            ct = np.concatenate([np.linspace(video_ipadapter_start_frame_idx + i * nf, video_ipadapter_start_frame_idx + (i + 1) * nf, vnf,
+                                             endpoint=False, dtype=f32) for i in range(num_chunks + 1)])
+            grids = ([gt, gh, gw], [ct, ch, cw])
+            n_c = min(vnf + 1, nf)
+            vr = R.rope_3d(64, gt[:nf], gh, gw, device=dev)
+            cr = R.rope_3d(64, ct[:n_c], ch, cw, device=dev)
+            image_embeddings = image_embeddings.to(dev, BF16)
+            emb0 = image_embeddings[:, :n_c].contiguous()
+        rope_d = tuple(t.to(dev) for t in rope)
+        gen = generator if generator is not None else torch.Generator(device=dev).manual_seed(0)
+        fifo_latents, fifo_old = [], []
+        old_x0 = None
+        for i, t in enumerate(ts):
+            k = max(0, nf - 1 - i)
+            fifo_latents.insert(0, latents[:, [k]].clone())
+            fifo_old.insert(0, None if old_x0 is None else old_x0[[k]].clone()[None])
+            inp = torch.cat([latents, latents], dim=0)
+            tt = torch.full((2,), t, dtype=torch.int64, device=dev)
+            pred = self.transformer(hidden_states=inp, encoder_hidden_states=embeds, timestep=tt, image_rotary_emb=rope_d,
+                                    vip_image_rotary_emb=vr, vip_condition_rotary_emb=cr, vip_encoder_hidden_states=emb0,
+                                    return_dict=False)[0]
+            prev_t = ts[i + 1] if i + 1 < len(ts) else -1
+            t_back = ts[i - 1] if i > 0 else None
+            nz = step_noise(i) if step_noise is not None else torch.randn((nf, 2) + tuple(latents.shape[2:]), generator=gen, device=dev,
+                                                                          dtype=torch.float32).to(BF16)
+            has = old_x0 is not None
+            x, x0 = self.scheduler.window_step(pred, latents[0].contiguous(), old_x0 if has else torch.zeros_like(latents[0]), nz.to(dev),
+                                               [t] * nf, [prev_t] * nf, [t_back] * nf, [has] * nf, guidance_scale)
+            latents, old_x0 = x[None], x0
+        return SimpleNamespace(
+            fifo_latents=torch.cat(fifo_latents, dim=1), fifo_old_pred_original_sample=fifo_old, orig_latents=latents.clone(),
+            nf_per_chunk=nf, vip_nf_per_chunk=self.resampler.config.num_temporal_queries if use_vip else None,
+            num_frames=num_chunks * nf, image_embeddings=image_embeddings, timesteps=self.scheduler.timesteps,
+            num_inference_steps=num_inference_steps, do_classifier_free_guidance=True, use_separate_guidance=False, use_dynamic_cfg=False,
+            prompt_embeds=embeds, image_rotary_emb=rope, vip_image_rotary_grid=grids[0] if use_vip else None,
+            vip_condition_rotary_grid=grids[1] if use_vip else None, attention_kwargs=None, guidance_scale=guidance_scale,
+            guidance_scale_img=None, extra_step_kwargs={}, cache_idx=[], condition_frames=None,
+            video_ipadapter_start_frame_idx=video_ipadapter_start_frame_idx, sampling_params=sampling_params or dict(use_adaptive_padding=True, num_partitions=4),
+            output_type=output_type, return_dict=return_dict)
