@@ -202,8 +202,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 // t+1 are issued region by region in the order they will be needed:
 //     8t+0 g0: A(0,0)   8t+1 g1: A(1,0)   8t+2 g0: W(*,0)a   8t+3 g1: W(*,0)b
 //     8t+4 g0: W(*,1)a  8t+5 g1: W(*,1)b  8t+6 g0: A(0,1)    8t+7 g1: A(1,1)
-// (A(g,h) = 64 A rows of group g, half h; W(*,h) = the 32-row half h of every wave column).  Every LOAD phase
-// ends with `s_waitcnt vmcnt(4)`: the pieces a wave issued two phases ago have landed, and the barrier that
+// (A(g,h) = 64 A rows of group g, half h; W(*,h) = the 32-row half h of every wave column; the pieces are issued from
+// inside the MFMA phase that follows the listed LOAD phase).  Every LOAD phase ends with `s_waitcnt vmcnt(2)`: the
+// pieces a wave issued two MFMA phases ago have landed, and the barrier that
 // follows publishes them one interval before their first reader (worked through in DESIGN.md).  A buffer is
 // only rewritten after the lgkmcnt(0)+barrier that follows its last reader.  Never vmcnt(0) in the loop.
 // ================================================================================================
@@ -213,6 +214,9 @@ constexpr int STAGE2_BYTES = 2 * TILE2_BYTES;    // 64 KiB
 
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
+    // PERSISTENT: one workgroup per CU walks the tile list (tile += gridDim.x).  The first k-tile of the NEXT output tile
+    // is put in flight (LDS buffer 0) before the epilogue of the current one, and the epilogue goes through LDS (buffer 1)
+    // so that every global access of the C tile is a full 128-byte row segment (16 B per lane, 8 lanes per row).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -222,17 +226,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     const int tiles_m = (p.M + BM2 - 1) / BM2, tiles_n = p.N / BN2;
     const int per_batch = tiles_m * tiles_n;
     const int nwg = per_batch * p.batch;
-    int t = xcd_remap(blockIdx.x, nwg);
-    const int b = t / per_batch;
-    t -= b * per_batch;
-    const int per_group = GROUP_M * tiles_n;
-    const int gi = t / per_group;
-    const int first_m = gi * GROUP_M;
-    const int gsz = min(tiles_m - first_m, GROUP_M);
-    const int in_g = t - gi * per_group;
-    const int tm = first_m + in_g % gsz, tn = in_g / gsz;
-    const int m0 = tm * BM2, n0 = tn * BN2;
-    const bf16_t* Ab = p.A + (long)b * p.sAb;
 
     // ---- LDS-DMA pieces of this wave: phase ph -> 2 pieces (8 rows each) of one region (see header) ----
     //   ph:   0        1         2         3
@@ -240,27 +233,43 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     //   g1:  A(1,0)   W(*,0)b   W(*,1)b   A(1,1)
     const char* src[4][2];
     int dst[4][2];       // byte offset inside a stage (A tile at 0, W tile at TILE2_BYTES), wave-uniform
+    int cb = 0, cm0 = 0, cn0 = 0;   // batch index and origin of the tile `src` points at
+    auto set_tile = [&](int id) {
+        int t = xcd_remap(id, nwg);
+        cb = t / per_batch;
+        t -= cb * per_batch;
+        const int per_group = GROUP_M * tiles_n;
+        const int gi = t / per_group;
+        const int first_m = gi * GROUP_M;
+        const int gsz = min(tiles_m - first_m, GROUP_M);
+        const int in_g = t - gi * per_group;
+        cm0 = (first_m + in_g % gsz) * BM2;
+        cn0 = (in_g / gsz) * BN2;
+        const bf16_t* Ab = p.A + (long)cb * p.sAb;
 #pragma unroll
-    for (int ph = 0; ph < 4; ++ph) {
-        const bool isA = (ph == 0 || ph == 3);
-        const int half = (ph >= 2 && !isA) || ph == 3 ? 1 : 0;
+        for (int ph = 0; ph < 4; ++ph) {
+            const bool isA = (ph == 0 || ph == 3);
+            const int half = (ph >= 2 && !isA) || ph == 3 ? 1 : 0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int row0;   // first row of the 8-row piece (wave-uniform)
-            if (isA) row0 = grp * 128 + half * 64 + (2 * wn + i) * 8;
-            else row0 = (2 * grp + (wn >> 1)) * 64 + half * 32 + (wn & 1) * 16 + i * 8;
-            const int r = row0 + (lane >> 3);
-            const int slot = (lane & 7) ^ ((r >> 1) & 7);
-            src[ph][i] = isA ? (const char*)(Ab + (long)min(m0 + r, p.M - 1) * p.lda + slot * 8)
-                             : (const char*)(p.W + (long)(n0 + r) * p.ldw + slot * 8);
-            dst[ph][i] = (isA ? 0 : TILE2_BYTES) + row0 * 128;
+            for (int i = 0; i < 2; ++i) {
+                int row0;   // first row of the 8-row piece (wave-uniform)
+                if (isA) row0 = grp * 128 + half * 64 + (2 * wn + i) * 8;
+                else row0 = (2 * grp + (wn >> 1)) * 64 + half * 32 + (wn & 1) * 16 + i * 8;
+                const int r = row0 + (lane >> 3);
+                const int slot = (lane & 7) ^ ((r >> 1) & 7);
+                src[ph][i] = isA ? (const char*)(Ab + (long)min(cm0 + r, p.M - 1) * p.lda + slot * 8)
+                                 : (const char*)(p.W + (long)(cn0 + r) * p.ldw + slot * 8);
+                dst[ph][i] = (isA ? 0 : TILE2_BYTES) + row0 * 128;
+            }
         }
-    }
+    };
+    auto stage1 = [&](int buf, int kt, int ph, int i) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[ph][i] + (long)kt * (BK * 2)),
+                                         (__attribute__((address_space(3))) void*)(smem + buf * STAGE2_BYTES + dst[ph][i]), 16, 0, 0);
+    };
     auto stage = [&](int buf, int kt, int ph) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[ph][i] + (long)kt * (BK * 2)),
-                                             (__attribute__((address_space(3))) void*)(smem + buf * STAGE2_BYTES + dst[ph][i]), 16, 0, 0);
+        stage1(buf, kt, ph, 0);
+        stage1(buf, kt, ph, 1);
     };
 
     // ---- fragment offsets (32x32x16 operands: lane -> row lane&31, 16-B slot ks*2 + (lane>>5)) ----
@@ -271,12 +280,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     const int offW0 = (wn * 64 + j31) * 128 + ((hi ^ sw) << 4);
 
     f32x16 acc[4][2];   // [32-row m block][32-col n block]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
     bf16x8 fa[2][4], fw[4];   // current A half (2 m-blocks x 4 k-steps), current W half (4 k-steps)
 
     auto loadA = [&](const char* tA, int qm) {
@@ -296,108 +299,148 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();                    \
         __builtin_amdgcn_sched_barrier(0);               \
     } while (0)
-#define TG_COMPUTE(QM, QN)                                                                                  \
+#define TG_MFMA(QM, QN, KS, MB) \
+    acc[(QM) * 2 + (MB)][(QN)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[KS], fa[MB][KS], acc[(QM) * 2 + (MB)][(QN)], 0, 0, 0)
+// 8 MFMAs of one quadrant; the wave's 2 LDS-DMA pieces of phase PH for the next k-tile are issued from INSIDE the MFMA
+// stream (the issuing wave idles ~24 of every 32 cycles there), not from the LOAD phase whose length gates the partner
+#define TG_COMPUTE(QM, QN, PH, MORE)                                                                        \
     do {                                                                                                    \
         __builtin_amdgcn_s_setprio(1);                                                                      \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                    \
-            _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                \
-                acc[(QM) * 2 + mb][(QN)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                          \
-                    fw[ks], fa[mb][ks], acc[(QM) * 2 + mb][(QN)], 0, 0, 0);                                 \
+        TG_MFMA(QM, QN, 0, 0); TG_MFMA(QM, QN, 0, 1);                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if (MORE) stage1(cur ^ 1, kt + 1, PH, 0);                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        TG_MFMA(QM, QN, 1, 0); TG_MFMA(QM, QN, 1, 1); TG_MFMA(QM, QN, 2, 0);                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if (MORE) stage1(cur ^ 1, kt + 1, PH, 1);                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        TG_MFMA(QM, QN, 2, 1); TG_MFMA(QM, QN, 3, 0); TG_MFMA(QM, QN, 3, 1);                                \
         __builtin_amdgcn_s_setprio(0);                                                                      \
     } while (0)
 #define TG_LOAD_END(MORE)                                                              \
     do {                                                                               \
-        if (MORE) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");          \
+        if (MORE) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");          \
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");               \
         TG_BAR();                                                                      \
     } while (0)
 
     const int nk = p.K / BK;
+    int tile = blockIdx.x;
+    set_tile(tile);
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph) stage(0, 0, ph);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TG_BAR();
-    if (grp == 1) TG_BAR();   // group 1 runs one barrier (= half a phase) behind group 0
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const char* tA = smem + cur * STAGE2_BYTES;
-        const char* tW = tA + TILE2_BYTES;
-        const bool more = kt + 1 < nk;
-        // phase 0: quadrant (0,0)
-        loadW(tW, 0);
-        loadA(tA, 0);
-        if (more) stage(cur ^ 1, kt + 1, 0);
-        TG_LOAD_END(more);
-        TG_COMPUTE(0, 0);
+    for (; tile < nwg; tile += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // k-tile 0 landed (and the previous epilogue's stores/reads retired)
         TG_BAR();
-        // phase 1: quadrant (0,1)
-        loadW(tW, 1);
-        if (more) stage(cur ^ 1, kt + 1, 1);
-        TG_LOAD_END(more);
-        TG_COMPUTE(0, 1);
-        TG_BAR();
-        // phase 2: quadrant (1,1)
-        loadA(tA, 1);
-        if (more) stage(cur ^ 1, kt + 1, 2);
-        TG_LOAD_END(more);
-        TG_COMPUTE(1, 1);
-        TG_BAR();
-        // phase 3: quadrant (1,0)
-        loadW(tW, 0);
-        if (more) stage(cur ^ 1, kt + 1, 3);
-        TG_LOAD_END(more);
-        TG_COMPUTE(1, 0);
-        TG_BAR();
+        if (grp == 1) TG_BAR();   // group 1 runs one barrier (= half a phase) behind group 0
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const char* tA = smem + cur * STAGE2_BYTES;
+            const char* tW = tA + TILE2_BYTES;
+            const bool more = kt + 1 < nk;
+            // phase 0: quadrant (0,0)
+            loadW(tW, 0);
+            loadA(tA, 0);
+            TG_LOAD_END(more);
+            TG_COMPUTE(0, 0, 0, more);
+            TG_BAR();
+            // phase 1: quadrant (0,1)
+            loadW(tW, 1);
+            TG_LOAD_END(more);
+            TG_COMPUTE(0, 1, 1, more);
+            TG_BAR();
+            // phase 2: quadrant (1,1)
+            loadA(tA, 1);
+            TG_LOAD_END(more);
+            TG_COMPUTE(1, 1, 2, more);
+            TG_BAR();
+            // phase 3: quadrant (1,0)
+            loadW(tW, 0);
+            TG_LOAD_END(more);
+            TG_COMPUTE(1, 0, 3, more);
+            TG_BAR();
+        }
+        if (grp == 0) TG_BAR();   // every wave is now past its last LDS read of this tile
+
+        // ---- next tile's first k-tile goes in flight (buffer 0) under the epilogue ----
+        const int eb = cb, em0 = cm0, en0 = cn0;
+        if (tile + (int)gridDim.x < nwg) {
+            set_tile(tile + gridDim.x);
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) stage(0, 0, ph);
+        }
+
+        // ---- epilogue through LDS (buffer 1, 4608 B per wave): MFMA layout -> full-row 16-byte accesses ----
+        // per 32x32 block a lane holds D[n = 8*(r>>2) + 4*hi + (r&3)][m = lane&31]
+        char* stg = smem + STAGE2_BYTES + wave * 4608;
+        bf16_t* Cb = p.C + (long)eb * p.sCb;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int nl = nt * 32 + r4 * 8 + hi * 4;
+                    float v[4] = {acc[mt][nt][r4 * 4 + 0], acc[mt][nt][r4 * 4 + 1], acc[mt][nt][r4 * 4 + 2], acc[mt][nt][r4 * 4 + 3]};
+                    if (p.bias) {
+                        const uint2 bb = *(const uint2*)(p.bias + en0 + wn * 64 + nl);
+                        v[0] += bf16lo_to_f32(bb.x); v[1] += bf16hi_to_f32(bb.x);
+                        v[2] += bf16lo_to_f32(bb.y); v[3] += bf16hi_to_f32(bb.y);
+                    }
+                    if (EPI == TG_EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = gelu_tanh(round_bf16(v[i]));
+                    } else if (EPI == TG_EPI_BIAS_SILU) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = silu(round_bf16(v[i]));
+                    }
+                    uint2 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    *(uint2*)(stg + j31 * 144 + nl * 2) = o;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                const uint4 val = *(const uint4*)(stg + row * 144 + ch * 16);
+                const int m = em0 + grp * 128 + mt * 32 + row;
+                const int n = en0 + wn * 64 + ch * 8;
+                if (m < p.M) {
+                    uint4 o = val;
+                    if (EPI == TG_EPI_BIAS_GATE_RES) {   // y = residual + gate[group(m)] * bf16(linear)
+                        const int g = p.g.tok_group[m];
+                        const bf16_t* gate_row = (const bf16_t*)p.g.mod + (long)eb * p.g.mod_batch_stride + (long)p.g.row[g] * p.g.mod_ld + p.g.gate_col[g];
+                        const uint4 gg = *(const uint4*)(gate_row + n);
+                        const uint4 rr = *(const uint4*)(p.R + (long)eb * p.sRb + (long)m * p.ldr + n);
+                        const uint32_t vu[4] = {val.x, val.y, val.z, val.w}, gu[4] = {gg.x, gg.y, gg.z, gg.w}, ru[4] = {rr.x, rr.y, rr.z, rr.w};
+                        uint32_t ou[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            ou[i] = pack_bf16x2(bf16lo_to_f32(ru[i]) + bf16lo_to_f32(gu[i]) * bf16lo_to_f32(vu[i]),
+                                                bf16hi_to_f32(ru[i]) + bf16hi_to_f32(gu[i]) * bf16hi_to_f32(vu[i]));
+                        o = uint4{ou[0], ou[1], ou[2], ou[3]};
+                    }
+                    *(uint4*)(Cb + (long)m * p.ldc + n) = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads done before the next block overwrites it
+            __builtin_amdgcn_wave_barrier();
+        }
     }
-    if (grp == 0) TG_BAR();
 #undef TG_BAR
 #undef TG_COMPUTE
+#undef TG_MFMA
 #undef TG_LOAD_END
-
-    // ---- epilogue: per 32x32 block lane holds D[n = 8*(r>>2) + 4*hi + (r&3)][m = lane&31] ----
-    bf16_t* Cb = p.C + (long)b * p.sCb;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + grp * 128 + mt * 32 + j31;
-        if (m >= p.M) continue;
-        const bf16_t* gate_row = nullptr;
-        if (EPI == TG_EPI_BIAS_GATE_RES) {
-            const int g = p.g.tok_group[m];
-            gate_row = (const bf16_t*)p.g.mod + (long)b * p.g.mod_batch_stride + (long)p.g.row[g] * p.g.mod_ld + p.g.gate_col[g];
-        }
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int n = n0 + wn * 64 + nt * 32 + r4 * 8 + hi * 4;
-                float v[4] = {acc[mt][nt][r4 * 4 + 0], acc[mt][nt][r4 * 4 + 1], acc[mt][nt][r4 * 4 + 2], acc[mt][nt][r4 * 4 + 3]};
-                if (p.bias) {
-                    const uint2 bb = *(const uint2*)(p.bias + n);
-                    v[0] += bf16lo_to_f32(bb.x); v[1] += bf16hi_to_f32(bb.x);
-                    v[2] += bf16lo_to_f32(bb.y); v[3] += bf16hi_to_f32(bb.y);
-                }
-                if (EPI == TG_EPI_BIAS_GELU) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = gelu_tanh(round_bf16(v[i]));
-                } else if (EPI == TG_EPI_BIAS_SILU) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = silu(round_bf16(v[i]));
-                } else if (EPI == TG_EPI_BIAS_GATE_RES) {
-                    const uint2 gg = *(const uint2*)(gate_row + n);
-                    const uint2 rr = *(const uint2*)(p.R + (long)b * p.sRb + (long)m * p.ldr + n);
-                    v[0] = bf16lo_to_f32(rr.x) + bf16lo_to_f32(gg.x) * v[0];
-                    v[1] = bf16hi_to_f32(rr.x) + bf16hi_to_f32(gg.x) * v[1];
-                    v[2] = bf16lo_to_f32(rr.y) + bf16lo_to_f32(gg.y) * v[2];
-                    v[3] = bf16hi_to_f32(rr.y) + bf16hi_to_f32(gg.y) * v[3];
-                }
-                uint2 o;
-                o.x = pack_bf16x2(v[0], v[1]);
-                o.y = pack_bf16x2(v[2], v[3]);
-                *(uint2*)(Cb + (long)m * p.ldc + n) = o;
-            }
-        }
-    }
 }
 
 template <int EPI>
@@ -409,7 +452,13 @@ int launch(const GemmParams& p, hipStream_t stream) {
             (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES);
             attr2 = true;
         }
-        hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(tiles2), dim3(512), 2 * STAGE2_BYTES, stream, p);
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+        }
+        hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(tiles2 < n_cu ? tiles2 : n_cu), dim3(512), 2 * STAGE2_BYTES, stream, p);
         TG_LAUNCH_CHECK("tg_gemm_bf16(256)");
         return TG_OK;
     }
@@ -432,9 +481,9 @@ extern "C" int tg_gemm_bf16(const void* A, long lda, long strideA, const void* W
     TG_REQUIRE(A && W && C, TG_ERR_ARG, "tg_gemm_bf16: null pointer");
     TG_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, TG_ERR_SHAPE, "tg_gemm_bf16: bad dims M=%d N=%d K=%d batch=%d", M, N, K, batch);
     TG_REQUIRE(N % BN == 0 && K % BK == 0, TG_ERR_SHAPE, "tg_gemm_bf16: need N%%128==0 and K%%64==0 (N=%d K=%d)", N, K);
-    TG_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && strideA % 8 == 0 && strideC % 4 == 0, TG_ERR_ALIGN,
+    TG_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && strideA % 8 == 0 && strideC % 8 == 0, TG_ERR_ALIGN,
                "tg_gemm_bf16: leading dimensions must keep 16-byte (A, W) / 8-byte (C) alignment");
-    TG_REQUIRE(tg_aligned16(A) && tg_aligned16(W) && (((uintptr_t)C) & 7) == 0, TG_ERR_ALIGN, "tg_gemm_bf16: unaligned base pointer");
+    TG_REQUIRE(tg_aligned16(A) && tg_aligned16(W) && tg_aligned16(C), TG_ERR_ALIGN, "tg_gemm_bf16: unaligned base pointer");
     static const bool env_init = [] { const char* e = getenv("TG_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; return true; }();
     (void)env_init;
     GemmParams p{};
@@ -450,7 +499,8 @@ extern "C" int tg_gemm_bf16(const void* A, long lda, long strideA, const void* W
         case TG_EPI_BIAS_SILU: return launch<TG_EPI_BIAS_SILU>(p, stream);
         case TG_EPI_BIAS_GATE_RES:
             TG_REQUIRE(R && gate && gate->mod && gate->tok_group, TG_ERR_ARG, "tg_gemm_bf16: gate/residual epilogue needs R and a group table");
-            TG_REQUIRE(ldr % 4 == 0 && strideR % 4 == 0 && (((uintptr_t)R) & 7) == 0, TG_ERR_ALIGN, "tg_gemm_bf16: residual alignment");
+            TG_REQUIRE(ldr % 8 == 0 && strideR % 8 == 0 && tg_aligned16(R) && gate->mod_ld % 8 == 0 && gate->mod_batch_stride % 8 == 0 &&
+                       tg_aligned16(gate->mod), TG_ERR_ALIGN, "tg_gemm_bf16: residual / gate table must be 16-byte aligned");
             p.g = *gate;
             return launch<TG_EPI_BIAS_GATE_RES>(p, stream);
         default: return tg_set_error(TG_ERR_ARG, "tg_gemm_bf16: unknown epilogue %d", epilogue);
