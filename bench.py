@@ -92,9 +92,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    use_dist = "RANK" in os.environ            # launched by torch.distributed.run (also exercised with 1 rank)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from tokensgen_amd import kernels as K
@@ -132,19 +134,19 @@ def main():
     grid_t = np.arange(nf, dtype=f32) + f32(start)
     cond_t = np.linspace(1000, 1016.25, 5, dtype=f32)
     keep = torch.empty(2, 7, C, H, W, device=device, dtype=bf)
-    gathered = torch.empty(world, 2, 7, C, H, W, device=device, dtype=bf) if world > 1 else None
+    gathered = torch.empty(world * 2, 7, C, H, W, device=device, dtype=bf) if use_dist else None   # rank-major concat
 
     def step():
         noise = torch.randn(nf, 2, C, H, W, generator=g, device=device, dtype=torch.float32).to(bf)
         x, x0 = worker.window_step(latents, old_x0, has_old, t, prev_t, next_t, noise, grid_t, cond_t, emb)
-        if world > 1:
+        if use_dist:
             keep[0].copy_(x[0, 6:]); keep[1].copy_(x0[6:])
             dist.all_gather_into_tensor(gathered, keep)
         return x
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -158,7 +160,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     K.PROFILE_ON[0] = False
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -174,7 +176,7 @@ def main():
             "dtype": "bf16", "data": "synthetic latents/embeddings, random-init weights at CogVideoX-5B shapes",
             "config": {"workload": "To2V FIFO window step, CogVideoX-5B (42 layers, D=3072, 48x64 heads), 13x60x90 latent "
                                    "window = 226 text + 17550 video + 480 condensed tokens, CFG batch 2, DPM-solver++ (52 trailing steps)",
-                       "layers": a.layers, "exchange": "all_gather of kept half-windows per step" if world > 1 else "none"},
+                       "layers": a.layers, "exchange": "RCCL all_gather of kept half-windows per step" if use_dist else "none"},
             "step_mfma_frac": FLOP_PER_STEP * (a.layers / 42.0) * (a.steps / dt) / PEAK_BF16,
             "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel (main: SDPA#1+#2 fused)", "achieved": achieved,
                          "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16 / 1e12), "traffic": None,
@@ -184,7 +186,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

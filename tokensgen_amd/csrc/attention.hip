@@ -19,8 +19,6 @@
 //     ds_read_b128 group touches 16 distinct bank groups (conflict-free), for K and V^T alike.
 //   * blocks are ordered so that the 8 XCDs work on different (batch, head) pairs: one head's K/V
 //     (4.5 MB at N=17776) stays resident in that XCD's 4 MiB L2 while its query tiles stream by.
-#include <stdlib.h>
-
 #include "common.h"
 #include "tokensgen_hip.h"
 
@@ -51,7 +49,7 @@ __device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slo
 
 // QB = 32-row query blocks per wave (1 or 2).  QB=2 shares every K / V^T fragment read between two query
 // blocks (half the LDS and L2 traffic per MFMA); QB=1 gives 2x the workgroups for short query ranges.
-template <int QB, int PRIO>
+template <int QB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // K[2], Vt[2]
     constexpr int QT = 128 * QB;
@@ -149,7 +147,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sc[qb][kb][r] = 0.f;
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kd = 0; kd < 4; ++kd) {
 #pragma unroll
@@ -160,7 +157,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
                         sc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][kd], sc[qb][kb], 0, 0, 0);
                 }
             }
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
             // ---- mask the ragged last tile: reg r of block kb is key t*64 + kb*32 + 16*(r>>3) + 8*hi + (r&7)
             if ((t + 1) * KVBLK > S.nk) {
 #pragma unroll
@@ -213,7 +209,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
                 l[qb] += ls;
             }
             // ---- O^T += V^T P^T : every V^T fragment feeds all QB query blocks ----
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -224,7 +219,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
                         acc_o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][ks], acc_o[qb][db], 0, 0, 0);
                 }
             }
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
             if (t + 1 < ntiles) lwrite(cur ^ 1);
             __syncthreads();
         }
@@ -291,16 +285,13 @@ extern "C" int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
     p.scale_log2 = scale * 1.4426950408889634f;
     // 256-row query tiles (2 query blocks per wave) once they still give >= 4 workgroups per CU, else 128-row tiles
     const long wg256 = (long)((nq + 255) / 256) * heads * batch;
-    static const int force_qb = [] { const char* e = getenv("TG_ATTN_QB"); return e ? atoi(e) : 0; }();       // tuning knobs
-    static const int prio = [] { const char* e = getenv("TG_ATTN_PRIO"); return e ? atoi(e) : 0; }();
-    const bool big = force_qb ? force_qb == 2 : wg256 >= 1024;
-    if (big) {
-        if (prio) hipLaunchKernelGGL((attn_fwd_kernel<2, 1>), dim3((unsigned)wg256), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((attn_fwd_kernel<2, 0>), dim3((unsigned)wg256), dim3(256), 0, stream, p);
+    // measured on MI355X at N=17776: 256-row tiles 900 TFLOP/s vs 128-row tiles 845; s_setprio around the MFMA clusters and an
+    // intra-wave S(t+1)/softmax(t) software pipeline both measured slower (885 / 781) and were dropped
+    if (wg256 >= 1024) {
+        hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)wg256), dim3(256), 0, stream, p);
     } else {
         const int nqt = (nq + 127) / 128;
-        if (prio) hipLaunchKernelGGL((attn_fwd_kernel<1, 1>), dim3((unsigned)(nqt * heads * batch)), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((attn_fwd_kernel<1, 0>), dim3((unsigned)(nqt * heads * batch)), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3((unsigned)(nqt * heads * batch)), dim3(256), 0, stream, p);
     }
     TG_LAUNCH_CHECK("tg_attention_fwd");
     return TG_OK;
