@@ -169,6 +169,12 @@ def main():
         attn = prof.get("attention_2seg", {"ms": float("nan"), "n": 0})
         attn_s = attn["ms"] * 1e-3
         achieved = ATTN_FLOP_PER_LAUNCH / attn_s / 1e12 if attn["n"] else float("nan")
+        traffic = None          # HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as f:
+                traffic = json.load(f)["_derived"]["attention_main_traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "DiT denoising steps/sec (CFG-batched 13-frame window: DiT fwd + CFG + 13 DPM updates), CogVideoX-5B To2V 720x480",
             "value": world * a.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -179,7 +185,7 @@ def main():
                        "layers": a.layers, "exchange": "RCCL all_gather of kept half-windows per step" if use_dist else "none"},
             "step_mfma_frac": FLOP_PER_STEP * (a.layers / 42.0) * (a.steps / dt) / PEAK_BF16,
             "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel (main: SDPA#1+#2 fused)", "achieved": achieved,
-                         "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16 / 1e12), "traffic": None,
+                         "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16 / 1e12), "traffic": traffic,
                          "launch_ms": attn["ms"], "launches_timed": attn["n"]},
             "kernel_ms": {k: round(v["ms"], 4) for k, v in prof.items()},
         }
