@@ -120,3 +120,28 @@ def test_full_width_block_vs_reference_samples(golden_dir):
         assert _rel(hs, r["h_samples"]) < tol, (key, _rel(hs, r["h_samples"]))
         assert _rel(es, r["e_samples"]) < tol, (key, _rel(es, r["e_samples"]))
         assert abs(oh.float().std().item() - r["h_std"]) < 2e-2 * r["h_std"]
+
+
+def test_resampler_vs_reference_golden(golden_dir):
+    """Condensed-token encoder on the HIP kernels vs the reference Resampler's outputs."""
+    from oracle import resampler_ref as RR
+    from tokensgen_amd.resampler import Resampler
+    g = torch.load(os.path.join(golden_dir, "resampler_tiny.pt"), weights_only=False)
+    cfg = g["cfg"]
+    sd = RR.make_state_dict(cfg, seed=g["weight_seed"])
+    m = Resampler(**cfg, device=DEV)
+    m.load_state_dict(sd)
+    assert sorted(m.state_dict()) == sorted(sd)
+    gen = torch.Generator().manual_seed(g["input_seed"])
+    x = torch.randn(1, 13, 24, 128, generator=gen)
+    f32 = np.float32
+    img = O.rope_3d(64, np.arange(13, dtype=f32), np.arange(4, dtype=f32), np.arange(6, dtype=f32))
+    smp = O.rope_3d(64, np.linspace(1000, 1013, 4, endpoint=False, dtype=f32), np.linspace(0, 4, 2, endpoint=False, dtype=f32),
+                    np.linspace(0, 6, 3, endpoint=False, dtype=f32))
+    y = m(x.to(DEV, torch.bfloat16), image_rotary_emb=img, sampling_rotary_emb=smp)
+    assert y.shape == g["bf16"].shape
+    assert _rel(y, g["bf16"]) < 2e-2 and _rel(y, g["fp32"]) < 2e-2
+    y2 = m(x.to(DEV, torch.bfloat16), image_rotary_emb=img, sampling_rotary_emb=smp)      # the learned queries must not be updated in place
+    assert torch.equal(y, y2) and torch.equal(m.state_dict()["latents"].cpu(), sd["latents"].to(torch.bfloat16))
+    with pytest.raises(NotImplementedError):
+        m.set_pca("pca.pt")

@@ -160,3 +160,52 @@ def test_vae_tiny_encode_decode_vs_reference(golden_dir):
     ref = V.decode(sdb, cfg, z5.to(BF), tiling=False)
     vae.disable_tiling()
     assert _rel(vae.decode(z5.to(DEV, BF)).sample, ref) < 5e-2
+
+
+@pytest.mark.timeout(900)
+def test_condensed_token_front_end_vs_oracle(golden_dir):
+    """frames -> VAE encode -> x scaling -> patch_embed.proj -> Resampler (pipeline vae_encode_image, :562-648)
+    on the HIP path vs the same composition of the oracles (posterior mode, so the map is deterministic)."""
+    from oracle import dit_ref as O
+    from oracle import resampler_ref as RR
+    from tokensgen_amd.pipeline import MPFIFOVideoIPAdapterCogVideoXPipeline
+    from tokensgen_amd.resampler import Resampler
+    from tokensgen_amd.scheduler import CogVideoXDPMScheduler
+    from tokensgen_amd.transformer import CogVideoXTransformer3DModel
+    from tokensgen_amd.vae import AutoencoderKLCogVideoX
+    gv = torch.load(os.path.join(golden_dir, "vae_tiny.pt"), weights_only=False)
+    vcfg = gv["cfg"]
+    vsd = V.make_state_dict(vcfg, seed=gv["weight_seed"])
+    dcfg = dict(num_attention_heads=2, attention_head_dim=64, num_layers=1, patch_size=2, time_embed_dim=128, text_embed_dim=64, in_channels=16, out_channels=16)
+    dsd = O.make_state_dict(dcfg, None, seed=21)
+    rcfg = dict(dim=128, depth=2, dim_head=64, heads=2, num_height_queries=2, num_width_queries=3, num_temporal_queries=4, embedding_dim=128,
+                output_dim=128, ff_mult=4, max_height_seq_len=4, max_width_seq_len=6, max_temporal_seq_len=5)
+    rsd = RR.make_state_dict(rcfg, seed=22)
+    gen = torch.Generator().manual_seed(23)
+    frames = torch.rand(1, 17, 3, 64, 96, generator=gen) * 2 - 1                  # one 17-frame "chunk" -> 5 latent frames of 8x12
+    # ---- oracle composition (bf16) ----
+    b16 = lambda d: {k: v.to(BF) for k, v in d.items()}
+    video = frames.to(BF).permute(0, 2, 1, 3, 4)
+    video = torch.cat([video] + [video[:, :, [-1]]] * 17, dim=2)
+    lat = torch.cat([V.gaussian_sample(V.encode(b16(vsd), vcfg, video[:, :, c * 17:(c + 1) * 17], tiling=False)) * 1.15258426 for c in range(2)], dim=2)
+    lat = lat.to(BF).permute(0, 2, 1, 3, 4)
+    tok = torch.nn.functional.conv2d(lat.reshape(-1, 16, *lat.shape[-2:]), b16(dsd)["patch_embed.proj.weight"], b16(dsd)["patch_embed.proj.bias"], stride=2)
+    tok = tok.view(1, lat.shape[1], 128, -1).transpose(2, 3)
+    f32 = np.float32
+    img = O.rope_3d(64, np.arange(5, dtype=f32), np.arange(4, dtype=f32), np.arange(6, dtype=f32))
+    smp = O.rope_3d(64, np.linspace(1000, 1005, 4, endpoint=False, dtype=f32), np.linspace(0, 4, 2, endpoint=False, dtype=f32),
+                    np.linspace(0, 6, 3, endpoint=False, dtype=f32))
+    nfc = lat.shape[1] // 2
+    ref = torch.cat([RR.resampler_forward(b16(rsd), rcfg, tok[:, c * nfc:(c + 1) * nfc], img, smp) for c in range(2)], dim=1)
+    # ---- HIP path ----
+    vae = AutoencoderKLCogVideoX(block_out_channels=vcfg["block_out_channels"], layers_per_block=1, sample_height=64, sample_width=96, device=DEV)
+    vae.load_state_dict(vsd)      # tiling off: at this toy size the reference's tile geometry yields an odd (9-row) latent
+    m = CogVideoXTransformer3DModel(num_attention_heads=2, attention_head_dim=64, num_layers=1, time_embed_dim=128, text_embed_dim=64,
+                                    use_rotary_positional_embeddings=True, device=DEV)
+    m.load_state_dict(b16(dsd), strict=True)
+    rs = Resampler(**rcfg, device=DEV); rs.load_state_dict(rsd)
+    sched = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
+    pipe = MPFIFOVideoIPAdapterCogVideoXPipeline(m, sched, vae=vae, resampler=rs)
+    emb = pipe.vae_encode_image(frames.to(DEV), nf_per_chunk=17, compressed_nf_per_chunk=nfc, sample_posterior=False)
+    assert emb.shape == (2, 8, 128, 2, 3) and torch.equal(emb[0], emb[1])
+    assert _rel(emb[:1], ref) < 6e-2

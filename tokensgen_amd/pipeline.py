@@ -15,13 +15,14 @@ from .fifo import BF16
 
 
 class MPFIFOVideoIPAdapterCogVideoXPipeline:
-    def __init__(self, transformer, scheduler, vae=None, resampler_config=None, device=None):
+    def __init__(self, transformer, scheduler, vae=None, resampler_config=None, device=None, resampler=None):
         self.transformer, self.scheduler, self.vae = transformer, scheduler, vae
+        self._resampler = resampler
         self.device = torch.device(device) if device is not None else transformer.device
         self.vae_scale_factor_spatial = 2 ** (len(vae.config.block_out_channels) - 1) if vae is not None else 8
         self.vae_scale_factor_temporal = vae.config.temporal_compression_ratio if vae is not None else 4
         self.vae_scaling_factor_image = vae.config.scaling_factor if vae is not None else 1.15258426
-        self.resampler = SimpleNamespace(config=SimpleNamespace(**(resampler_config or dict(
+        self.resampler = resampler if resampler is not None else SimpleNamespace(config=SimpleNamespace(**(resampler_config or dict(
             num_temporal_queries=4, num_height_queries=8, num_width_queries=12))))
         self._guidance_scale = 6.0
 
@@ -54,6 +55,39 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
         frames = [self.vae.decode(z[:, :, c * nf_per_chunk:(c + 1) * nf_per_chunk].contiguous()).sample
                   for c in range(z.shape[2] // nf_per_chunk)]
         return torch.cat(frames, dim=2)
+
+    @torch.no_grad()
+    def vae_encode_image(self, frames, nf_per_chunk=49, compressed_nf_per_chunk=13, video_ipadapter_start_frame_idx=1000, generator=None,
+                         sample_posterior=True, do_classifier_free_guidance=True):
+        """Condensed-token encoding of the source video (pipeline_cogvideox_mp_fifo.py:562-648, `use_vae_as_encoder`):
+        frames [b, F, 3, H, W] in [-1, 1] -> pad one chunk with the last frame -> per 49-frame chunk: vae.encode, sample, x scaling
+        -> `transformer.patch_embed.proj` -> per chunk Resampler -> [2b, 4*(chunks+1), D, 8, 12] (the same tokens in both CFG halves,
+        :646; the zero-video "uncond" branch of the reference is computed but unused when use_separate_guidance is off and is skipped)."""
+        if self._resampler is None or self.vae is None:
+            raise RuntimeError("vae_encode_image needs a VAE and a Resampler")
+        rq = self.resampler.config
+        dev = self.device
+        video = frames.to(dev, BF16).permute(0, 2, 1, 3, 4)
+        video = torch.cat([video] + [video[:, :, [-1]]] * nf_per_chunk, dim=2)                      # :581 pad one chunk
+        lat = []
+        for c in range(video.shape[2] // nf_per_chunk):
+            post = self.vae.encode(video[:, :, c * nf_per_chunk:(c + 1) * nf_per_chunk].contiguous()).latent_dist
+            z = post.sample(generator=generator) if sample_posterior else post.mode()
+            lat.append((z.float() * self.vae.config.scaling_factor).to(BF16))
+        lat = torch.cat(lat, dim=2).permute(0, 2, 1, 3, 4).contiguous()                             # b f c h w
+        tokens = self.transformer.patch_embed_proj(lat)                                              # b f (h w) D
+        f32 = np.float32
+        img = R.rope_3d(rq.dim_head, np.linspace(0, rq.max_temporal_seq_len, rq.max_temporal_seq_len, endpoint=False, dtype=f32),
+                        np.linspace(0, rq.max_height_seq_len, rq.max_height_seq_len, endpoint=False, dtype=f32),
+                        np.linspace(0, rq.max_width_seq_len, rq.max_width_seq_len, endpoint=False, dtype=f32))             # :1103-1126
+        smp = R.rope_3d(rq.dim_head, np.linspace(video_ipadapter_start_frame_idx, video_ipadapter_start_frame_idx + rq.max_temporal_seq_len,
+                                                 rq.num_temporal_queries, endpoint=False, dtype=f32),
+                        np.linspace(0, rq.max_height_seq_len, rq.num_height_queries, endpoint=False, dtype=f32),
+                        np.linspace(0, rq.max_width_seq_len, rq.num_width_queries, endpoint=False, dtype=f32))             # :1127-1149
+        out = [self._resampler(tokens[:, c * compressed_nf_per_chunk:(c + 1) * compressed_nf_per_chunk].contiguous(), image_rotary_emb=img,
+                               sampling_rotary_emb=smp) for c in range(tokens.shape[1] // compressed_nf_per_chunk)]
+        emb = torch.cat(out, dim=1)
+        return torch.cat([emb, emb], dim=0) if do_classifier_free_guidance else emb
 
     def preprare_for_fifo(self, num_inference_steps=52, guidance_scale=6.0, video_ipadapter_scale=None, **unused):
         """:1491-1514 — what the non-zero ranks run instead of the base stage: set vip scale + timesteps."""

@@ -435,6 +435,18 @@ class CogVideoXTransformer3DModel(nn.Module):
         K.gemm(ws.FF, F[p + "ff2.w"], F[p + "ff2.b"], X, L.EPI_BIAS_GATE_RES, residual=X, gate=t2)
 
 
+    @torch.no_grad()
+    def patch_embed_proj(self, latents):
+        """`transformer.patch_embed.proj` as the pipeline calls it directly (pipeline_cogvideox_mp_fifo.py:596): Conv2d(k=2, s=2) on
+        latents [b, f, C, h, w] -> patch tokens [b, f, (h/2)(w/2), D], as one patch gather + GEMM (embeddings.py:516-523)."""
+        b, f, C, h, w = latents.shape
+        F = self._fused
+        cols = torch.empty(b * f * (h // 2) * (w // 2), C * 4, dtype=BF16, device=self._device)
+        K.patchify(latents.to(self._device, BF16).reshape(b * f, C, h, w).contiguous(), cols)
+        out = torch.empty(cols.shape[0], self.inner_dim, dtype=BF16, device=self._device)
+        K.gemm(cols, F["patch.w"], F["patch.b"], out, L.EPI_BIAS)
+        return out.view(b, f, (h // 2) * (w // 2), self.inner_dim)
+
     # ------------------------------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward(self, hidden_states, encoder_hidden_states, timestep, vip_encoder_hidden_states=None,

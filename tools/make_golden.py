@@ -325,13 +325,40 @@ def gen_vae():
     print("vae_tiny.pt", out["encode_tiled"].shape, out["decode_tiled"]["shape"])
 
 
+RESAMPLER_TINY = dict(dim=128, depth=2, dim_head=64, heads=2, num_height_queries=2, num_width_queries=3, num_temporal_queries=4,
+                      embedding_dim=128, output_dim=128, ff_mult=4, max_height_seq_len=4, max_width_seq_len=6, max_temporal_seq_len=13)
+
+
+@torch.no_grad()
+def gen_resampler():
+    """Reference Resampler (longvgen/video_ipadapter/resampler.py) on a tiny config, fp32 and bf16, with both RoPE tables."""
+    from oracle import resampler_ref as RR
+    rs = load_ref_module("longvgen/video_ipadapter/resampler.py", "ref_resampler")
+    cfg = RESAMPLER_TINY
+    m = rs.Resampler(**cfg)
+    sd = RR.make_state_dict(cfg, seed=700)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    g = torch.Generator().manual_seed(701)
+    x = torch.randn(1, 13, 24, 128, generator=g)
+    f32 = np.float32
+    img = get_3d_rotary_pos_embed_v2(64, np.arange(13, dtype=f32), np.arange(4, dtype=f32), np.arange(6, dtype=f32))
+    smp = get_3d_rotary_pos_embed_v2(64, np.linspace(1000, 1013, 4, endpoint=False, dtype=f32), np.linspace(0, 4, 2, endpoint=False, dtype=f32),
+                                     np.linspace(0, 6, 3, endpoint=False, dtype=f32))
+    out = dict(cfg=cfg, weight_seed=700, input_seed=701, sd_checksum=sd_checksum(sd))
+    out["fp32"] = m(x, image_rotary_emb=img, sampling_rotary_emb=smp).clone()
+    out["bf16"] = m.to(torch.bfloat16)(x.bfloat16(), image_rotary_emb=img, sampling_rotary_emb=smp).clone()
+    torch.save(out, os.path.join(GOLD, "resampler_tiny.pt"))
+    print("resampler_tiny.pt", tuple(out["fp32"].shape))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full-block", action="store_true")
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    jobs = dict(dit=gen_dit_tiny, vip=gen_vip_processor, sched=gen_scheduler, fifo=gen_fifo, vae=gen_vae)
+    jobs = dict(dit=gen_dit_tiny, vip=gen_vip_processor, sched=gen_scheduler, fifo=gen_fifo, vae=gen_vae, resampler=gen_resampler)
     if a.only:
         jobs = {a.only: jobs.get(a.only, gen_full_block)}
     for k, fn in jobs.items():
