@@ -212,7 +212,7 @@ constexpr int BM2 = 256, BN2 = 256;
 constexpr int TILE2_BYTES = BM2 * BK * 2;        // 32 KiB per operand tile
 constexpr int STAGE2_BYTES = 2 * TILE2_BYTES;    // 64 KiB
 
-template <int EPI>
+template <int EPI, int ABL = 0>   // ABL: profiling ablations (1 = no fragment ds_reads, 2 = no MFMA, 3 = no LDS-DMA); 0 ships
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     // PERSISTENT: one workgroup per CU walks the tile list (tile += gridDim.x).  The first k-tile of the NEXT output tile
     // is put in flight (LDS buffer 0) before the epilogue of the current one, and the epilogue goes through LDS (buffer 1)
@@ -264,6 +264,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         }
     };
     auto stage1 = [&](int buf, int kt, int ph, int i) {
+        if (ABL == 3) return;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[ph][i] + (long)kt * (BK * 2)),
                                          (__attribute__((address_space(3))) void*)(smem + buf * STAGE2_BYTES + dst[ph][i]), 16, 0, 0);
     };
@@ -281,8 +282,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 
     f32x16 acc[4][2];   // [32-row m block][32-col n block]
     bf16x8 fa[2][4], fw[4];   // current A half (2 m-blocks x 4 k-steps), current W half (4 k-steps)
+    if (ABL == 1) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { fw[ks] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; fa[0][ks] = fw[ks]; fa[1][ks] = fw[ks]; }
+    }
 
     auto loadA = [&](const char* tA, int qm) {
+        if (ABL == 1) return;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -290,6 +296,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                 fa[mb][ks] = *(const bf16x8*)(tA + ((offA0 + (qm * 64 + mb * 32) * 128) ^ (ks * 32)));
     };
     auto loadW = [&](const char* tW, int qn) {
+        if (ABL == 1) return;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fw[ks] = *(const bf16x8*)(tW + ((offW0 + (qn * 32) * 128) ^ (ks * 32)));
     };
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);               \
     } while (0)
 #define TG_MFMA(QM, QN, KS, MB) \
-    acc[(QM) * 2 + (MB)][(QN)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[KS], fa[MB][KS], acc[(QM) * 2 + (MB)][(QN)], 0, 0, 0)
+    if (ABL != 2) acc[(QM) * 2 + (MB)][(QN)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[KS], fa[MB][KS], acc[(QM) * 2 + (MB)][(QN)], 0, 0, 0)
 // 8 MFMAs of one quadrant; the wave's 2 LDS-DMA pieces of phase PH for the next k-tile are issued from INSIDE the MFMA
 // stream (the issuing wave idles ~24 of every 32 cycles there), not from the LOAD phase whose length gates the partner
 #define TG_COMPUTE(QM, QN, PH, MORE)                                                                        \
@@ -458,7 +465,15 @@ int launch(const GemmParams& p, hipStream_t stream) {
             (void)hipGetDevice(&dev);
             if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
         }
-        hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(tiles2 < n_cu ? tiles2 : n_cu), dim3(512), 2 * STAGE2_BYTES, stream, p);
+        static const int abl = [] { const char* e = getenv("TG_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+        const dim3 grid2(tiles2 < n_cu ? tiles2 : n_cu);
+        if (abl == 1) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES);
+                        hipLaunchKernelGGL((gemm256_kernel<EPI, 1>), grid2, dim3(512), 2 * STAGE2_BYTES, stream, p); }
+        else if (abl == 2) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES);
+                             hipLaunchKernelGGL((gemm256_kernel<EPI, 2>), grid2, dim3(512), 2 * STAGE2_BYTES, stream, p); }
+        else if (abl == 3) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES);
+                             hipLaunchKernelGGL((gemm256_kernel<EPI, 3>), grid2, dim3(512), 2 * STAGE2_BYTES, stream, p); }
+        else hipLaunchKernelGGL(gemm256_kernel<EPI>, grid2, dim3(512), 2 * STAGE2_BYTES, stream, p);
         TG_LAUNCH_CHECK("tg_gemm_bf16(256)");
         return TG_OK;
     }
