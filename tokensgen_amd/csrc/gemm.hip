@@ -187,36 +187,40 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 }
 
 // ================================================================================================
-// 256x256x64 tile, 8 waves (2 M-groups x 4 N-columns, 128x64 per wave), "ping-pong" schedule.
+// 256x256 tile, 8 waves (2 M-groups x 4 N-columns, 128x64 per wave), "ping-pong" schedule over a 4-deep LDS ring.
 //
-// Why: a 128x128 tile needs ~39 TB/s of L2->LDS fill at full MFMA rate (more than the chip has) and every
-// wave stalls together at the per-k-tile barrier.  Here the tile traffic per MFMA is halved and the two waves
-// that share a SIMD (wave w of group 0 and wave w+4 of group 1) alternate roles every phase: while one
-// issues its 8 MFMAs (v_mfma_f32_32x32x16_bf16: one 64x32 quadrant of its output, K=64), the other does its
-// ds_read_b128 fragment loads and issues its share (2 pieces) of the next k-tile's LDS-DMA.  Group 1 simply
+// Why this shape: a 128x128 tile needs ~39 TB/s of L2->LDS fill at full MFMA rate (more than the chip has) and every
+// wave stalls together at the per-k-tile barrier.  Here the traffic per MFMA is halved and the two waves that share a
+// SIMD (wave w of group 0 and wave w+4 of group 1) alternate roles every phase: while one issues its 8 MFMAs
+// (v_mfma_f32_32x32x16_bf16, 4 independent accumulators), the other does its ds_read_b128 fragment loads.  Group 1 simply
 // runs one barrier behind group 0, so per SIMD one wave is always in its MFMA phase.
-//   per wave per k-tile: 4 phases = {LOAD (ds_read + 2 glds + counted vmcnt) | s_barrier | 8 MFMA | s_barrier}
-//   LDS: 2 buffers x (A 256x64 + W 256x64) bf16 = 128 KiB, same 16-B-slot swizzle as the 128^2 kernel.
-// LDS-DMA ordering.  Call "interval" the time between two consecutive barriers; tile t occupies intervals
-// 8t..8t+7 for group 0 (LOAD p at 8t+2p, MFMA at 8t+2p+1) and one later for group 1.  The 64 pieces of tile
-// t+1 are issued region by region in the order they will be needed:
-//     8t+0 g0: A(0,0)   8t+1 g1: A(1,0)   8t+2 g0: W(*,0)a   8t+3 g1: W(*,0)b
-//     8t+4 g0: W(*,1)a  8t+5 g1: W(*,1)b  8t+6 g0: A(0,1)    8t+7 g1: A(1,1)
-// (A(g,h) = 64 A rows of group g, half h; W(*,h) = the 32-row half h of every wave column; the pieces are issued from
-// inside the MFMA phase that follows the listed LOAD phase).  Every LOAD phase ends with `s_waitcnt vmcnt(2)`: the
-// pieces a wave issued two MFMA phases ago have landed, and the barrier that
-// follows publishes them one interval before their first reader (worked through in DESIGN.md).  A buffer is
-// only rewritten after the lgkmcnt(0)+barrier that follows its last reader.  Never vmcnt(0) in the loop.
+//
+// Why a 4-deep ring of K=32 stages (and not 2 x K=64): ablation on MI355X (TG_GEMM_ABLATE) showed the schedule without
+// its LDS-DMA runs at 1.87 PFLOP/s-equivalent while the DMA path alone takes 72 % of the full kernel's time at only 40 % of
+// L2 bandwidth — the fill is bound by bytes in flight x miss latency (19 % of the pieces are compulsory L2 misses served
+// by MALL/HBM, and vmcnt retires in order).  Four 32-KiB stages keep THREE stages (up to 12 KiB per wave, 96 KiB per CU)
+// in flight for ~10 barrier intervals before their first reader instead of one stage for ~4.
+//
+//   per wave per stage (K=32): 2 phases = {LOAD ds_reads | s_barrier | 8 MFMA + 2 LDS-DMA pieces | s_barrier}
+//     phase 0: reads W frags (2 n-blocks x 2 k-steps) + A frags of rows [0,64) of its half   -> 8 ds_read_b128
+//     phase 1: reads A frags of rows [64,128)                                                 -> 4 ds_read_b128
+//   LDS stage = A[256 rows][64 B] | W[256 rows][64 B]; 16-B slot XOR-swizzled by (row>>2)&3 (conflict-free b128 reads,
+//   applied on the DMA source address since LDS-DMA writes lane-linear).  DMA piece = 16 rows x 64 B.
+//   During stage s every wave issues its 4 pieces of stage s+3 (2 per MFMA phase, from inside the MFMA stream); every LOAD
+//   phase ends with `s_waitcnt vmcnt(6)`: everything older than the last three issue phases has landed, i.e. a stage is
+//   complete one full phase before its first reader, and the barrier that follows publishes it.  The ring slot of stage
+//   s+3 is that of stage s-1, whose last reader (group 1, LOAD phase 1) finished two intervals before the first overwrite.
 // ================================================================================================
-constexpr int BM2 = 256, BN2 = 256;
-constexpr int TILE2_BYTES = BM2 * BK * 2;        // 32 KiB per operand tile
-constexpr int STAGE2_BYTES = 2 * TILE2_BYTES;    // 64 KiB
+constexpr int BM2 = 256, BN2 = 256, BK2 = 32, NS2 = 4;
+constexpr int OPER2_BYTES = BM2 * BK2 * 2;       // 16 KiB per operand per stage
+constexpr int STAGE2_BYTES = 2 * OPER2_BYTES;    // 32 KiB
+constexpr int RING2_BYTES = NS2 * STAGE2_BYTES;  // 128 KiB
 
 template <int EPI, int ABL = 0>   // ABL: profiling ablations (1 = no fragment ds_reads, 2 = no MFMA, 3 = no LDS-DMA); 0 ships
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
-    // PERSISTENT: one workgroup per CU walks the tile list (tile += gridDim.x).  The first k-tile of the NEXT output tile
-    // is put in flight (LDS buffer 0) before the epilogue of the current one, and the epilogue goes through LDS (buffer 1)
-    // so that every global access of the C tile is a full 128-byte row segment (16 B per lane, 8 lanes per row).
+    // PERSISTENT: one workgroup per CU walks the tile list (tile += gridDim.x).  The first three stages of the NEXT output
+    // tile are put in flight before the epilogue of the current one, and the epilogue goes through LDS (ring slot 3) so that
+    // every global access of the C tile is a full 128-byte row segment (16 B per lane, 8 lanes per row).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -227,13 +231,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     const int per_batch = tiles_m * tiles_n;
     const int nwg = per_batch * p.batch;
 
-    // ---- LDS-DMA pieces of this wave: phase ph -> 2 pieces (8 rows each) of one region (see header) ----
-    //   ph:   0        1         2         3
-    //   g0:  A(0,0)   W(*,0)a   W(*,1)a   A(0,1)        W(*,h)a = wave columns 0,1 ; W(*,h)b = wave columns 2,3
-    //   g1:  A(1,0)   W(*,0)b   W(*,1)b   A(1,1)
-    const char* src[4][2];
-    int dst[4][2];       // byte offset inside a stage (A tile at 0, W tile at TILE2_BYTES), wave-uniform
+    // ---- LDS-DMA pieces of this wave: issue phase 0 -> A pieces 2*wave, 2*wave+1 ; phase 1 -> W pieces 2*wave, 2*wave+1 ----
+    const char* src[2][2];
     int cb = 0, cm0 = 0, cn0 = 0;   // batch index and origin of the tile `src` points at
+    const int prow = wave * 32 + (lane >> 2);                 // + i*16 : tile row of this lane's 16-B chunk
     auto set_tile = [&](int id) {
         int t = xcd_remap(id, nwg);
         cb = t / per_batch;
@@ -247,58 +248,51 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         cn0 = (in_g / gsz) * BN2;
         const bf16_t* Ab = p.A + (long)cb * p.sAb;
 #pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
-            const bool isA = (ph == 0 || ph == 3);
-            const int half = (ph >= 2 && !isA) || ph == 3 ? 1 : 0;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int row0;   // first row of the 8-row piece (wave-uniform)
-                if (isA) row0 = grp * 128 + half * 64 + (2 * wn + i) * 8;
-                else row0 = (2 * grp + (wn >> 1)) * 64 + half * 32 + (wn & 1) * 16 + i * 8;
-                const int r = row0 + (lane >> 3);
-                const int slot = (lane & 7) ^ ((r >> 1) & 7);
-                src[ph][i] = isA ? (const char*)(Ab + (long)min(cm0 + r, p.M - 1) * p.lda + slot * 8)
-                                 : (const char*)(p.W + (long)(cn0 + r) * p.ldw + slot * 8);
-                dst[ph][i] = (isA ? 0 : TILE2_BYTES) + row0 * 128;
-            }
+        for (int i = 0; i < 2; ++i) {
+            const int r = prow + i * 16;
+            const int slot = (lane & 3) ^ ((r >> 2) & 3);     // logical 16-B slot stored at physical slot lane&3
+            src[0][i] = (const char*)(Ab + (long)min(cm0 + r, p.M - 1) * p.lda + slot * 8);
+            src[1][i] = (const char*)(p.W + (long)(cn0 + r) * p.ldw + slot * 8);
         }
     };
-    auto stage1 = [&](int buf, int kt, int ph, int i) {
+    auto stage1 = [&](int st, int ph, int i) {               // piece i of issue phase ph for stage st
         if (ABL == 3) return;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[ph][i] + (long)kt * (BK * 2)),
-                                         (__attribute__((address_space(3))) void*)(smem + buf * STAGE2_BYTES + dst[ph][i]), 16, 0, 0);
+        char* dstp = smem + (st & (NS2 - 1)) * STAGE2_BYTES + ph * OPER2_BYTES + (wave * 32 + i * 16) * 64;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[ph][i] + (long)st * (BK2 * 2)),
+                                         (__attribute__((address_space(3))) void*)dstp, 16, 0, 0);
     };
-    auto stage = [&](int buf, int kt, int ph) {
-        stage1(buf, kt, ph, 0);
-        stage1(buf, kt, ph, 1);
+    auto stage_all = [&](int st) {
+        stage1(st, 0, 0); stage1(st, 0, 1); stage1(st, 1, 0); stage1(st, 1, 1);
     };
 
     // ---- fragment offsets (32x32x16 operands: lane -> row lane&31, 16-B slot ks*2 + (lane>>5)) ----
-    // row = base(multiple of 32) + (lane&31): one swizzle term per lane; ks advances the slot by 2 (byte ^ ks*32)
+    // row = base(multiple of 32) + (lane&31): one swizzle term per lane; ks advances the slot by 2 (byte ^ 32)
     const int j31 = lane & 31, hi = lane >> 5;
-    const int sw = (j31 >> 1) & 7;
-    const int offA0 = (grp * 128 + j31) * 128 + ((hi ^ sw) << 4);
-    const int offW0 = (wn * 64 + j31) * 128 + ((hi ^ sw) << 4);
+    const int sw = (j31 >> 2) & 3;
+    const int offA0 = (grp * 128 + j31) * 64 + ((hi ^ sw) << 4);
+    const int offW0 = (wn * 64 + j31) * 64 + ((hi ^ sw) << 4);
 
     f32x16 acc[4][2];   // [32-row m block][32-col n block]
-    bf16x8 fa[2][4], fw[4];   // current A half (2 m-blocks x 4 k-steps), current W half (4 k-steps)
+    bf16x8 fa[2][2], fw[2][2];   // A: 2 m-blocks x 2 k-steps of the current 64-row half; W: 2 n-blocks x 2 k-steps
     if (ABL == 1) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { fw[ks] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; fa[0][ks] = fw[ks]; fa[1][ks] = fw[ks]; }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { fw[i][ks] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; fa[i][ks] = fw[i][ks]; }
     }
-
     auto loadA = [&](const char* tA, int qm) {
         if (ABL == 1) return;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                fa[mb][ks] = *(const bf16x8*)(tA + ((offA0 + (qm * 64 + mb * 32) * 128) ^ (ks * 32)));
+            for (int ks = 0; ks < 2; ++ks) fa[mb][ks] = *(const bf16x8*)(tA + ((offA0 + (qm * 64 + mb * 32) * 64) ^ (ks * 32)));
     };
-    auto loadW = [&](const char* tW, int qn) {
+    auto loadW = [&](const char* tW) {
         if (ABL == 1) return;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fw[ks] = *(const bf16x8*)(tW + ((offW0 + (qn * 32) * 128) ^ (ks * 32)));
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fw[nb][ks] = *(const bf16x8*)(tW + ((offW0 + (nb * 32) * 64) ^ (ks * 32)));
     };
 #define TG_BAR()                                         \
     do {                                                 \
@@ -306,36 +300,37 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();                    \
         __builtin_amdgcn_sched_barrier(0);               \
     } while (0)
-#define TG_MFMA(QM, QN, KS, MB) \
-    if (ABL != 2) acc[(QM) * 2 + (MB)][(QN)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[KS], fa[MB][KS], acc[(QM) * 2 + (MB)][(QN)], 0, 0, 0)
-// 8 MFMAs of one quadrant; the wave's 2 LDS-DMA pieces of phase PH for the next k-tile are issued from INSIDE the MFMA
-// stream (the issuing wave idles ~24 of every 32 cycles there), not from the LOAD phase whose length gates the partner
-#define TG_COMPUTE(QM, QN, PH, MORE)                                                                        \
+#define TG_MFMA(QM, KS, MB, NB) \
+    if (ABL != 2) acc[(QM) * 2 + (MB)][NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[NB][KS], fa[MB][KS], acc[(QM) * 2 + (MB)][NB], 0, 0, 0)
+// 8 MFMAs of one 64x64 half-tile step (4 independent accumulators, each used twice 4 issues apart); the wave's 2 LDS-DMA
+// pieces of issue phase PH for stage st+3 are issued from INSIDE the MFMA stream (the wave idles ~24 of every 32 cycles there)
+#define TG_COMPUTE(QM, PH, MORE)                                                                            \
     do {                                                                                                    \
         __builtin_amdgcn_s_setprio(1);                                                                      \
-        TG_MFMA(QM, QN, 0, 0); TG_MFMA(QM, QN, 0, 1);                                                       \
+        TG_MFMA(QM, 0, 0, 0); TG_MFMA(QM, 0, 1, 0);                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
-        if (MORE) stage1(cur ^ 1, kt + 1, PH, 0);                                                           \
+        if (MORE) stage1(st + 3, PH, 0);                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
-        TG_MFMA(QM, QN, 1, 0); TG_MFMA(QM, QN, 1, 1); TG_MFMA(QM, QN, 2, 0);                                \
+        TG_MFMA(QM, 0, 0, 1); TG_MFMA(QM, 0, 1, 1); TG_MFMA(QM, 1, 0, 0);                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
-        if (MORE) stage1(cur ^ 1, kt + 1, PH, 1);                                                           \
+        if (MORE) stage1(st + 3, PH, 1);                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
-        TG_MFMA(QM, QN, 2, 1); TG_MFMA(QM, QN, 3, 0); TG_MFMA(QM, QN, 3, 1);                                \
+        TG_MFMA(QM, 1, 1, 0); TG_MFMA(QM, 1, 0, 1); TG_MFMA(QM, 1, 1, 1);                                   \
         __builtin_amdgcn_s_setprio(0);                                                                      \
     } while (0)
 #define TG_LOAD_END(MORE)                                                              \
     do {                                                                               \
-        if (MORE) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");          \
+        if (MORE) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");          \
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");               \
         TG_BAR();                                                                      \
     } while (0)
 
-    const int nk = p.K / BK;
+    const int nst = p.K / BK2;
     int tile = blockIdx.x;
     set_tile(tile);
 #pragma unroll
-    for (int ph = 0; ph < 4; ++ph) stage(0, 0, ph);
+    for (int st = 0; st < 3; ++st)
+        if (st < nst) stage_all(st);
 
     for (; tile < nwg; tile += gridDim.x) {
 #pragma unroll
@@ -344,50 +339,40 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // k-tile 0 landed (and the previous epilogue's stores/reads retired)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // stages 0..2 landed (and the previous epilogue retired)
         TG_BAR();
         if (grp == 1) TG_BAR();   // group 1 runs one barrier (= half a phase) behind group 0
 
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            const char* tA = smem + cur * STAGE2_BYTES;
-            const char* tW = tA + TILE2_BYTES;
-            const bool more = kt + 1 < nk;
-            // phase 0: quadrant (0,0)
-            loadW(tW, 0);
+        for (int st = 0; st < nst; ++st) {
+            const char* tA = smem + (st & (NS2 - 1)) * STAGE2_BYTES;
+            const char* tW = tA + OPER2_BYTES;
+            const bool more = st + 3 < nst;
+            // phase 0: rows [0,64) of this wave's half x all 64 columns
+            loadW(tW);
             loadA(tA, 0);
             TG_LOAD_END(more);
-            TG_COMPUTE(0, 0, 0, more);
+            TG_COMPUTE(0, 0, more);
             TG_BAR();
-            // phase 1: quadrant (0,1)
-            loadW(tW, 1);
-            TG_LOAD_END(more);
-            TG_COMPUTE(0, 1, 1, more);
-            TG_BAR();
-            // phase 2: quadrant (1,1)
+            // phase 1: rows [64,128)
             loadA(tA, 1);
             TG_LOAD_END(more);
-            TG_COMPUTE(1, 1, 2, more);
-            TG_BAR();
-            // phase 3: quadrant (1,0)
-            loadW(tW, 0);
-            TG_LOAD_END(more);
-            TG_COMPUTE(1, 0, 3, more);
+            TG_COMPUTE(1, 1, more);
             TG_BAR();
         }
         if (grp == 0) TG_BAR();   // every wave is now past its last LDS read of this tile
 
-        // ---- next tile's first k-tile goes in flight (buffer 0) under the epilogue ----
+        // ---- next tile's first three stages go in flight (ring slots 0..2) under the epilogue ----
         const int eb = cb, em0 = cm0, en0 = cn0;
         if (tile + (int)gridDim.x < nwg) {
             set_tile(tile + gridDim.x);
 #pragma unroll
-            for (int ph = 0; ph < 4; ++ph) stage(0, 0, ph);
+            for (int st = 0; st < 3; ++st)
+                if (st < nst) stage_all(st);
         }
 
-        // ---- epilogue through LDS (buffer 1, 4608 B per wave): MFMA layout -> full-row 16-byte accesses ----
+        // ---- epilogue through LDS (ring slot 3, 4 KiB per wave, 16-B slots XOR-swizzled by row&7): MFMA layout -> full rows ----
         // per 32x32 block a lane holds D[n = 8*(r>>2) + 4*hi + (r&3)][m = lane&31]
-        char* stg = smem + STAGE2_BYTES + wave * 4608;
+        char* stg = smem + 3 * STAGE2_BYTES + wave * 4096;
         bf16_t* Cb = p.C + (long)eb * p.sCb;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -412,14 +397,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     uint2 o;
                     o.x = pack_bf16x2(v[0], v[1]);
                     o.y = pack_bf16x2(v[2], v[3]);
-                    *(uint2*)(stg + j31 * 144 + nl * 2) = o;
+                    *(uint2*)(stg + j31 * 128 + ((((nl >> 3) ^ (j31 & 7)) << 4) | ((nl & 4) << 1))) = o;
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 8 + (lane >> 3), ch = lane & 7;
-                const uint4 val = *(const uint4*)(stg + row * 144 + ch * 16);
+                const uint4 val = *(const uint4*)(stg + row * 128 + ((ch ^ (row & 7)) << 4));
                 const int m = em0 + grp * 128 + mt * 32 + row;
                 const int n = en0 + wn * 64 + ch * 8;
                 if (m < p.M) {
@@ -456,7 +441,7 @@ int launch(const GemmParams& p, hipStream_t stream) {
         const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2) * p.batch;
         static bool attr2 = false;
         if (!attr2) {
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2_BYTES);
             attr2 = true;
         }
         static int n_cu = 0;
@@ -467,13 +452,13 @@ int launch(const GemmParams& p, hipStream_t stream) {
         }
         static const int abl = [] { const char* e = getenv("TG_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
         const dim3 grid2(tiles2 < n_cu ? tiles2 : n_cu);
-        if (abl == 1) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES);
-                        hipLaunchKernelGGL((gemm256_kernel<EPI, 1>), grid2, dim3(512), 2 * STAGE2_BYTES, stream, p); }
-        else if (abl == 2) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES);
-                             hipLaunchKernelGGL((gemm256_kernel<EPI, 2>), grid2, dim3(512), 2 * STAGE2_BYTES, stream, p); }
-        else if (abl == 3) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES);
-                             hipLaunchKernelGGL((gemm256_kernel<EPI, 3>), grid2, dim3(512), 2 * STAGE2_BYTES, stream, p); }
-        else hipLaunchKernelGGL(gemm256_kernel<EPI>, grid2, dim3(512), 2 * STAGE2_BYTES, stream, p);
+        if (abl == 1) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2_BYTES);
+                        hipLaunchKernelGGL((gemm256_kernel<EPI, 1>), grid2, dim3(512), RING2_BYTES, stream, p); }
+        else if (abl == 2) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2_BYTES);
+                             hipLaunchKernelGGL((gemm256_kernel<EPI, 2>), grid2, dim3(512), RING2_BYTES, stream, p); }
+        else if (abl == 3) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2_BYTES);
+                             hipLaunchKernelGGL((gemm256_kernel<EPI, 3>), grid2, dim3(512), RING2_BYTES, stream, p); }
+        else hipLaunchKernelGGL(gemm256_kernel<EPI>, grid2, dim3(512), RING2_BYTES, stream, p);
         TG_LAUNCH_CHECK("tg_gemm_bf16(256)");
         return TG_OK;
     }
