@@ -73,12 +73,13 @@ int tg_adaln_modulate(const void* x, long ldx, long strideX, void* y, long ldy, 
 /* In-place per-head LayerNorm(64, eps, affine) followed by interleaved-pair RoPE on the rows of up to two
  * token ranges.  x points at the q (or k) columns of a fused QKV buffer: element (b, t, h, d) at
  * x[b*strideB + t*ld + h*64 + d].  seg i rotates tokens [start_i, start_i+len_i) with fp32 tables
- * cos_i/sin_i [len_i][64]; other tokens are normalised only (text rows).
+ * cos_i/sin_i [len_i][64]; other tokens are normalised only (text rows).  The result is multiplied by out_scale before its
+ * single bf16 rounding (1.0, or softmax_scale*log2(e) for K so that tg_attention_fwd can run with k_prescaled=1).
  * Replaces attention_processor.py:2031-2056 + embeddings.py:840-885 (apply_rotary_emb). */
 int tg_qk_layernorm_rope(void* x, long ld, long strideB, int tokens, int heads, int batch,
                          const void* ln_weight, const void* ln_bias, float eps,
                          int start0, int len0, const float* cos0, const float* sin0,
-                         int start1, int len1, const float* cos1, const float* sin1, hipStream_t stream);
+                         int start1, int len1, const float* cos1, const float* sin1, float out_scale, hipStream_t stream);
 
 /* vt[b][h][d][j] = v[b*strideB + (key_start + j)*ld + h*64 + d] for j < n_keys, zero for n_keys <= j < ldvt.
  * Lays V out key-contiguous so the PV MFMA operands are plain 16-byte LDS reads (the "transpose" that
@@ -90,7 +91,8 @@ int tg_transpose_v(const void* v, long ld, long strideB, int key_start, int n_ke
  * normalised key/value segments:   out = softmax(q1 k1^T) v1  +  seg2_scale * softmax(q2 k2^T) v2.
  * q1,q2,k1,k2: element (b, t, h, d) at ptr[b*strideB + t*ld + h*64 + d];  vt1,vt2: from tg_transpose_v
  * ([b][h][64][ldvt]);  out: (b, t, h, d) at out[b*out_strideB + t*out_ld + h*64 + d] (merged heads).
- * Segment 2 is skipped when q2 == NULL.
+ * Segment 2 is skipped when q2 == NULL.  k_prescaled=1: k1/k2 already carry scale*log2(e) (scale is ignored): the kernel
+ * then seeds the score accumulator with -max and needs no per-element scale/subtract in its softmax.
  * Replaces the three F.scaled_dot_product_attention calls + `hs + scale*tv_hs` + head merge,
  * attention_processor.py:2066-2069,2117-2135,2141 (and :1937-1941 for the plain processor). */
 int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
@@ -98,7 +100,7 @@ int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
                      const void* q2, long q2_ld, long q2_strideB,
                      const void* k2, long k2_ld, long k2_strideB, const void* vt2, long vt2_ld, int nk2,
                      float seg2_scale, void* out, long out_ld, long out_strideB,
-                     int nq, int heads, int batch, float scale, hipStream_t stream);
+                     int nq, int heads, int batch, float scale, int k_prescaled, hipStream_t stream);
 
 /* emb[i][:] = bf16( [cos(t_i w_k) | sin(t_i w_k)] ), w_k = exp(-ln(1e4) k / (dim/2)), k < dim/2
  * (flip_sin_to_cos=True, freq_shift=0).  Replaces embeddings.py:28-79 + dit:678.  t: int64[n]. */

@@ -173,6 +173,34 @@ def test_attention_two_segments(K, nq, nk1, nk2):
     assert _rel(out, ref) < 6e-3
 
 
+@pytest.mark.parametrize("nq,nk1,nk2", [(200, 333, 100), (513, 1500, 480)])
+def test_attention_prescaled_keys(K, nq, nk1, nk2):
+    """K carries softmax_scale*log2(e) (tg_qk_layernorm_rope out_scale) and the kernel runs in the log2 domain directly."""
+    B, H = 2, 4
+    c = 0.125 * 1.4426950408889634
+    qkv1, qkv2 = _rand(B, max(nq, nk1), 3 * H * 64, seed=1), _rand(B, max(nq, nk2), 3 * H * 64, seed=2)
+    q1, k1, v1 = qkv1[:, :nq, :H * 64], qkv1[:, :nk1, H * 64:2 * H * 64], qkv1[:, :nk1, 2 * H * 64:]
+    q2, k2, v2 = qkv2[:, :nq, :H * 64], qkv2[:, :nk2, H * 64:2 * H * 64], qkv2[:, :nk2, 2 * H * 64:]
+    ref = _sdpa_ref(q1, k1, v1, H, 0.125) + 0.6 * _sdpa_ref(q2, k2, v2, H, 0.125)
+    pad = lambda n: (n + 63) // 64 * 64
+    vt1 = torch.empty(B, H, 64, pad(nk1), dtype=torch.bfloat16, device=DEV)
+    vt2 = torch.empty(B, H, 64, pad(nk2), dtype=torch.bfloat16, device=DEV)
+    K.transpose_v(v1, H, 0, nk1, vt1); K.transpose_v(v2, H, 0, nk2, vt2)
+    k1s, k2s = (k1.float() * c).to(torch.bfloat16), (k2.float() * c).to(torch.bfloat16)
+    out = torch.empty(B, nq, H * 64, dtype=torch.bfloat16, device=DEV)
+    K.attention(q1, k1s, vt1, nk1, out, H, 0.125, q2, k2s, vt2, nk2, 0.6, k_prescaled=True)
+    assert _rel(out, ref) < 8e-3
+
+
+def test_qk_layernorm_out_scale(K):
+    x = _rand(1, 40, 2 * 64, seed=1)
+    w, b = _rand(64, seed=2, scale=0.1) + 1, _rand(64, seed=3, scale=0.1)
+    a, bb = x.clone(), x.clone()
+    K.qk_layernorm_rope(a, 2, w, b, 1e-6)
+    K.qk_layernorm_rope(bb, 2, w, b, 1e-6, out_scale=0.18033688)
+    assert _rel(bb, a.float() * 0.18033688) < 4e-3
+
+
 def test_attention_forced_rescale(K):
     """Spike one key late in the sequence so the running max jumps mid-stream (online-softmax rescale path)."""
     B, H, nq, nk = 1, 1, 128, 512

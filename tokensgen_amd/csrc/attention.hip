@@ -19,6 +19,8 @@
 //     ds_read_b128 group touches 16 distinct bank groups (conflict-free), for K and V^T alike.
 //   * blocks are ordered so that the 8 XCDs work on different (batch, head) pairs: one head's K/V
 //     (4.5 MB at N=17776) stays resident in that XCD's 4 MiB L2 while its query tiles stream by.
+#include <stdlib.h>
+
 #include "common.h"
 #include "tokensgen_hip.h"
 
@@ -40,6 +42,7 @@ struct AttnParams {
     bf16_t* out; long o_ld, o_sb;
     int nq, heads, batch;
     float scale_log2;   // softmax scale * log2(e)
+    int prescaled;      // 1: K already carries scale*log2(e) (tg_qk_layernorm_rope out_scale): scores are log2-domain as produced
 };
 
 __device__ __forceinline__ int pi_row(int i) {   // swap bits 2 and 3
@@ -49,7 +52,7 @@ __device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slo
 
 // QB = 32-row query blocks per wave (1 or 2).  QB=2 shares every K / V^T fragment read between two query
 // blocks (half the LDS and L2 traffic per MFMA); QB=1 gives 2x the workgroups for short query ranges.
-template <int QB>
+template <int QB, int ABL = 0>   // ABL: profiling ablations (1 = no K/V staging after tile 0, 2 = no softmax math, 3 = no MFMA); 0 ships
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // K[2], Vt[2]
     constexpr int QT = 128 * QB;
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 
         for (int t = 0; t < ntiles; ++t) {
             const int cur = t & 1;
-            if (t + 1 < ntiles) gload(t + 1);
+            if (ABL != 1 && t + 1 < ntiles) gload(t + 1);
             const char* tK = smem + cur * TILE_B;
             const char* tV = smem + (2 + cur) * TILE_B;
 
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
                     const bf16x8 kf = *(const bf16x8*)(tK + offK[kb][kd]);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb)
-                        sc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][kd], sc[qb][kb], 0, 0, 0);
+                        if (ABL != 3) sc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][kd], sc[qb][kb], 0, 0, 0);
                 }
             }
             // ---- mask the ragged last tile: reg r of block kb is key t*64 + kb*32 + 16*(r>>3) + 8*hi + (r&7)
@@ -171,6 +174,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
             }
             // ---- online softmax (log2 domain), lane-local row; P packed to bf16 MFMA operands in place ----
             bf16x8 pf[QB][4];
+            if (ABL == 2) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        union { bf16x8 v; float f[4]; } pk;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pk.f[i] = sc[qb][ks >> 1][(ks & 1) * 8 + i] + sc[qb][ks >> 1][(ks & 1) * 8 + 4 + i];
+                        pf[qb][ks] = pk.v;
+                    }
+            } else
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 float mx = sc[qb][0][0];
@@ -216,10 +230,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
                     const bf16x8 vf = *(const bf16x8*)(tV + offV[db][ks]);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb)
-                        acc_o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][ks], acc_o[qb][db], 0, 0, 0);
+                        if (ABL != 3) acc_o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][ks], acc_o[qb][db], 0, 0, 0);
                 }
             }
-            if (t + 1 < ntiles) lwrite(cur ^ 1);
+            if (ABL != 1 && t + 1 < ntiles) lwrite(cur ^ 1);
             __syncthreads();
         }
         // ---- segment epilogue: normalise and write (segment 2 accumulates onto segment 1's bf16 result, like the
@@ -254,6 +268,264 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 8-wave "ping-pong" kernel for long query ranges (512 query rows per workgroup, 64 per wave).
+//
+// Ablation of the 4-wave kernel on MI355X (TG_ATTN_ABLATE): full 9.15 ms = no-MFMA 4.3 ms + MFMA-only ~4 ms — the two
+// co-resident waves of a SIMD run the same instruction stream in phase, so their MFMA segments collide and their softmax
+// (VALU) segments collide: matrix and vector pipes are used one after the other, not together.  Here the two waves that
+// share a SIMD (wave w of group 0, wave w+4 of group 1) are put in ANTI-PHASE by construction: group 1 runs one barrier
+// behind group 0, and every wave alternates
+//     X(t) = { P(t-1).V(t-1) ; S(t) = K(t).Q^T }   32 MFMAs + 16 ds_read_b128        (matrix segment)
+//     Y(t) = { online softmax of S(t) -> P(t), lazy rescale of O }                   (vector segment)
+// with one s_barrier after each segment, so while one wave of a SIMD is in X its partner is in Y.
+// K/V tiles are staged by LDS-DMA (1 K piece + 1 V^T piece per wave per tile, swizzle on the source address), shared by
+// all 512 query rows (half the L2 traffic of the 256-row kernel), double-buffered:
+//     pair u = (K(u+1), V(u)) is issued in interval 2u (group 0: start of X(u); group 1: start of Y(u-1)), retired by every
+//     wave before the barrier that ends interval 2u+1, first read in interval 2u+2; the buffers it overwrites were last read
+//     in interval 2u-1.
+// ------------------------------------------------------------------------------------------------
+template <bool PRESCALED>
+__global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // K[2], Vt[2]
+    constexpr float RESCALE_THR = 8.0f;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int hi = lane >> 5, j = lane & 31;
+
+    const int nqt = (p.nq + 511) / 512;
+    const int nhb = p.heads * p.batch;
+    int hb, qt;
+    if ((nhb & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        hb = xcd + 8 * (slot / nqt);
+        qt = slot % nqt;
+    } else {
+        hb = blockIdx.x / nqt;
+        qt = blockIdx.x % nqt;
+    }
+    const int h = hb % p.heads, b = hb / p.heads;
+    const int q0 = qt * 512 + wave * 64;
+
+    // fragment offsets: one base per operand, k-step advances the 16-B slot by 2 (byte ^ (k << 5)), blocks add 4096 B
+    const int pr = pi_row(j);
+    const int offK0 = pr * 128 + ((hi ^ ((pr >> 1) & 7)) << 4);
+    const int offV0 = j * 128 + ((hi ^ ((j >> 1) & 7)) << 4);
+    // LDS-DMA piece of this wave: tile rows [wave*8, +8), lane -> row wave*8 + (lane>>3), physical slot lane&7
+    const int drow = wave * 8 + (lane >> 3);
+    const int dslot = ((lane & 7) ^ ((drow >> 1) & 7)) * 8;     // logical slot (elements) stored at this lane's position
+
+#define PP_BAR()                                         \
+    do {                                                 \
+        __builtin_amdgcn_sched_barrier(0);               \
+        __builtin_amdgcn_s_barrier();                    \
+        __builtin_amdgcn_sched_barrier(0);               \
+    } while (0)
+
+    for (int sg = 0; sg < p.nseg; ++sg) {
+        const Seg& S = p.s[sg];
+        bf16x8 qf[2][4];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qrow = min(q0 + qb * 32 + j, p.nq - 1);
+            const bf16_t* qp = S.q + (long)b * S.q_sb + (long)qrow * S.q_ld + h * 64 + hi * 8;
+#pragma unroll
+            for (int kd = 0; kd < 4; ++kd) qf[qb][kd] = *(const bf16x8*)(qp + kd * 16);
+        }
+        const bf16_t* kbase = S.k + (long)b * S.k_sb + h * 64 + dslot;
+        const bf16_t* vsrc = S.vt + ((long)(b * p.heads + h) * 64 + drow) * S.vt_ld + dslot;
+        const int ntiles = (S.nk + KVBLK - 1) / KVBLK;
+        auto dmaK = [&](int t) {      // K(t) -> K buffer t&1
+            const int key = min(t * KVBLK + drow, S.nk - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (long)key * S.k_ld),
+                                             (__attribute__((address_space(3))) void*)(smem + (t & 1) * TILE_B + wave * 1024), 16, 0, 0);
+        };
+        auto dmaV = [&](int t) {      // V^T(t) -> V buffer t&1
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + (long)t * KVBLK),
+                                             (__attribute__((address_space(3))) void*)(smem + (2 + (t & 1)) * TILE_B + wave * 1024), 16, 0, 0);
+        };
+        auto dma_pair = [&](int u) {  // (K(u+1), V(u))
+            if (u + 1 < ntiles) dmaK(u + 1);
+            if (u < ntiles) dmaV(u);
+        };
+
+        f32x16 acc_o[2][2], sc[2][2];
+        bf16x8 pf[2][4];
+        float m[2], l[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            m[qb] = PRESCALED ? 0.f : -1e30f;   // PRESCALED seeds the accumulator with -m, so m must stay finite and small
+            l[qb] = 0.f;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[qb][db][r] = 0.f;
+        }
+        // P(t-1).V(t-1): every V^T fragment feeds both query blocks
+        auto pv = [&](int tprev) {
+            const char* tV = smem + (2 + (tprev & 1)) * TILE_B;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x8 vf = *(const bf16x8*)(tV + ((offV0 + db * 4096) ^ (ks << 5)));
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb)
+                        acc_o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][ks], acc_o[qb][db], 0, 0, 0);
+                }
+        };
+        // S(t) = K(t).Q^T (+ ragged-tile mask)
+        auto scores = [&](int t) {
+            const char* tK = smem + (t & 1) * TILE_B;
+            // PRESCALED: the accumulator starts at -m (a lane owns ONE query row, so all 16 registers of a block take the same
+            // value) and the MFMA output is already s - m in log2 units: no per-element scale/subtract in the vector segment
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[qb][kb][r] = PRESCALED ? -m[qb] : 0.f;
+#pragma unroll
+            for (int kd = 0; kd < 4; ++kd)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const bf16x8 kf = *(const bf16x8*)(tK + ((offK0 + kb * 4096) ^ (kd << 5)));
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb)
+                        sc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][kd], sc[qb][kb], 0, 0, 0);
+                }
+            if ((t + 1) * KVBLK > S.nk) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = t * KVBLK + kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                            if (key >= S.nk) sc[qb][kb][r] = -1e30f;
+                        }
+            }
+        };
+        // online softmax (log2 domain), lane-local row; P packed to bf16 MFMA operands.
+        // PRESCALED: sc holds a = s - m (m = running max when the scores were issued); otherwise sc holds raw q.k
+        auto softmax = [&]() {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                float mx = sc[qb][0][0];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[qb][kb][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                if (PRESCALED) {
+                    if (__any(mx > RESCALE_THR)) {                       // rare: the row max grew by more than 2^THR
+                        const float delta = fmaxf(mx, 0.f);
+                        const float alpha = __builtin_amdgcn_exp2f(-delta);
+                        m[qb] += delta;
+                        l[qb] *= alpha;
+#pragma unroll
+                        for (int db = 0; db < 2; ++db)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc_o[qb][db][r] *= alpha;
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) sc[qb][kb][r] -= delta;
+                    }
+                } else {
+                    mx *= p.scale_log2;
+                    if (__any(mx > m[qb] + RESCALE_THR)) {
+                        const float m_new = fmaxf(m[qb], mx);
+                        const float alpha = __builtin_amdgcn_exp2f(m[qb] - m_new);
+                        m[qb] = m_new;
+                        l[qb] *= alpha;
+#pragma unroll
+                        for (int db = 0; db < 2; ++db)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc_o[qb][db][r] *= alpha;
+                    }
+                }
+                const float mq = m[qb];
+                f32x2 ls2 = {0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int kb = ks >> 1, rb = (ks & 1) * 8;
+                    float e[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        e[i] = PRESCALED ? __builtin_amdgcn_exp2f(sc[qb][kb][rb + i]) : __builtin_amdgcn_exp2f(sc[qb][kb][rb + i] * p.scale_log2 - mq);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ls2 += f32x2{e[2 * i], e[2 * i + 1]};
+                    union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pk.u[i] = pack_bf16x2(e[2 * i], e[2 * i + 1]);
+                    pf[qb][ks] = pk.v;
+                }
+                l[qb] += ls2[0] + ls2[1];
+            }
+        };
+
+        // ---- prologue: K(0) resident for everybody; group 1 issues pair 0 and falls one barrier behind ----
+        dmaK(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_BAR();
+        if (grp == 1) {
+            dma_pair(0);
+            PP_BAR();
+        }
+        for (int t = 0; t < ntiles; ++t) {
+            // X(t): matrix segment
+            if (grp == 0) dma_pair(t);
+            if (t > 0) pv(t - 1);
+            scores(t);
+            if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t (issued one segment ago) has landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_BAR();
+            // Y(t): vector segment
+            if (grp == 1) dma_pair(t + 1);
+            softmax();
+            if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t has landed
+            PP_BAR();
+        }
+        pv(ntiles - 1);                                                            // X(nt): last P.V
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (grp == 0) PP_BAR();                                                    // barrier counts of the two groups meet again
+        PP_BAR();                                                                  // all LDS reads of this segment done
+
+        // ---- segment epilogue (same as the 4-wave kernel) ----
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
+            const float w = (sg == 0 ? 1.f : p.seg2_scale) / lt;
+            const int q = q0 + qb * 32 + j;
+            if (q < p.nq) {
+                bf16_t* op = p.out + (long)b * p.o_sb + (long)q * p.o_ld + h * 64;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        uint2* dst = (uint2*)(op + db * 32 + g4 * 8 + hi * 4);
+                        float v0 = acc_o[qb][db][g4 * 4 + 0] * w, v1 = acc_o[qb][db][g4 * 4 + 1] * w;
+                        float v2 = acc_o[qb][db][g4 * 4 + 2] * w, v3 = acc_o[qb][db][g4 * 4 + 3] * w;
+                        if (sg > 0) {
+                            const uint2 prev = *dst;
+                            v0 = bf16lo_to_f32(prev.x) + round_bf16(v0); v1 = bf16hi_to_f32(prev.x) + round_bf16(v1);
+                            v2 = bf16lo_to_f32(prev.y) + round_bf16(v2); v3 = bf16hi_to_f32(prev.y) + round_bf16(v3);
+                        }
+                        uint2 o;
+                        o.x = pack_bf16x2(v0, v1);
+                        o.y = pack_bf16x2(v2, v3);
+                        *dst = o;
+                    }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // segment-1 stores retired before segment 2's DMA accounting starts
+    }
+#undef PP_BAR
+}
+
 }  // namespace
 
 extern "C" int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
@@ -261,7 +533,7 @@ extern "C" int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
                                 const void* q2, long q2_ld, long q2_strideB,
                                 const void* k2, long k2_ld, long k2_strideB, const void* vt2, long vt2_ld, int nk2,
                                 float seg2_scale, void* out, long out_ld, long out_strideB,
-                                int nq, int heads, int batch, float scale, hipStream_t stream) {
+                                int nq, int heads, int batch, float scale, int k_prescaled, hipStream_t stream) {
     TG_REQUIRE(q1 && k1 && vt1 && out, TG_ERR_ARG, "tg_attention_fwd: null pointer");
     TG_REQUIRE(nq > 0 && nk1 > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_attention_fwd: bad shape nq=%d nk1=%d", nq, nk1);
     TG_REQUIRE(q1_ld % 8 == 0 && k1_ld % 8 == 0 && vt1_ld % 64 == 0 && out_ld % 4 == 0 && q1_strideB % 8 == 0 &&
@@ -282,12 +554,25 @@ extern "C" int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
     p.seg2_scale = seg2_scale;
     p.out = (bf16_t*)out; p.o_ld = out_ld; p.o_sb = out_strideB;
     p.nq = nq; p.heads = heads; p.batch = batch;
-    p.scale_log2 = scale * 1.4426950408889634f;
+    // k_prescaled: K rows already carry scale*log2(e) (written by tg_qk_layernorm_rope with out_scale), `scale` is then ignored
+    p.prescaled = k_prescaled ? 1 : 0;
+    p.scale_log2 = k_prescaled ? 1.0f : scale * 1.4426950408889634f;
     // 256-row query tiles (2 query blocks per wave) once they still give >= 4 workgroups per CU, else 128-row tiles
     const long wg256 = (long)((nq + 255) / 256) * heads * batch;
     // measured on MI355X at N=17776: 256-row tiles 900 TFLOP/s vs 128-row tiles 845; s_setprio around the MFMA clusters and an
     // intra-wave S(t+1)/softmax(t) software pipeline both measured slower (885 / 781) and were dropped
-    if (wg256 >= 1024) {
+    static const int abl = [] { const char* e = getenv("TG_ATTN_ABLATE"); return e ? atoi(e) : 0; }();
+    static const int no_pp = [] { const char* e = getenv("TG_ATTN_NO_PP"); return e ? atoi(e) : 0; }();
+    static const long pp_min = [] { const char* e = getenv("TG_ATTN_PP_MIN_WG"); return e ? atol(e) : 1024L; }();   // tests lower it
+    const long wg512 = (long)((nq + 511) / 512) * heads * batch;
+    if (wg512 >= pp_min && !abl && !no_pp) {
+        if (p.prescaled) hipLaunchKernelGGL(attn_fwd_pp_kernel<true>, dim3((unsigned)wg512), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL(attn_fwd_pp_kernel<false>, dim3((unsigned)wg512), dim3(512), 0, stream, p);
+    } else if (wg256 >= 1024 && abl) {
+        if (abl == 1) hipLaunchKernelGGL((attn_fwd_kernel<2, 1>), dim3((unsigned)wg256), dim3(256), 0, stream, p);
+        else if (abl == 2) hipLaunchKernelGGL((attn_fwd_kernel<2, 2>), dim3((unsigned)wg256), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((attn_fwd_kernel<2, 3>), dim3((unsigned)wg256), dim3(256), 0, stream, p);
+    } else if (wg256 >= 1024) {
         hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)wg256), dim3(256), 0, stream, p);
     } else {
         const int nqt = (nq + 127) / 128;

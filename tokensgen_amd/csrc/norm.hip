@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
                                                            int start0, int len0, const float* __restrict__ cos0,
                                                            const float* __restrict__ sin0, int start1, int len1,
                                                            const float* __restrict__ cos1,
-                                                           const float* __restrict__ sin1) {
+                                                           const float* __restrict__ sin1, float out_scale) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const int part = (int)(gid & 7);
     const long rowid = gid >> 3;                       // (b, t, h)
@@ -154,6 +154,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
         }
     }
     if (live) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= out_scale;    // 1, or softmax_scale*log2(e) folded into K before its single bf16 rounding
         uint4 o;
         o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
         o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
@@ -228,7 +230,8 @@ extern "C" int tg_adaln_modulate(const void* x, long ldx, long strideX, void* y,
 extern "C" int tg_qk_layernorm_rope(void* x, long ld, long strideB, int tokens, int heads, int batch,
                                     const void* ln_weight, const void* ln_bias, float eps,
                                     int start0, int len0, const float* cos0, const float* sin0,
-                                    int start1, int len1, const float* cos1, const float* sin1, hipStream_t stream) {
+                                    int start1, int len1, const float* cos1, const float* sin1, float out_scale,
+                                    hipStream_t stream) {
     TG_REQUIRE(x && ln_weight && ln_bias, TG_ERR_ARG, "tg_qk_layernorm_rope: null pointer");
     TG_REQUIRE(tokens > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_qk_layernorm_rope: bad shape");
     TG_REQUIRE(ld % 8 == 0 && strideB % 8 == 0 && tg_aligned16(x), TG_ERR_ALIGN, "tg_qk_layernorm_rope: rows must be 16-byte aligned");
@@ -240,7 +243,7 @@ extern "C" int tg_qk_layernorm_rope(void* x, long ld, long strideB, int tokens, 
     const long threads = (long)batch * tokens * heads * 8;
     hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (bf16_t*)x, ld,
                        strideB, tokens, heads, batch, (const bf16_t*)ln_weight, (const bf16_t*)ln_bias, eps, start0, len0,
-                       cos0, sin0, start1, len1, cos1, sin1);
+                       cos0, sin0, start1, len1, cos1, sin1, out_scale);
     TG_LAUNCH_CHECK("tg_qk_layernorm_rope");
     return TG_OK;
 }

@@ -120,7 +120,7 @@ def adaln_modulate(x, out, ln_weight, ln_bias, eps, table=None):
     return out
 
 
-def qk_layernorm_rope(x, heads, ln_weight, ln_bias, eps, seg0=None, seg1=None):
+def qk_layernorm_rope(x, heads, ln_weight, ln_bias, eps, seg0=None, seg1=None, out_scale=1.0):
     """In place on x [B,T,heads*64] (a column slice of the fused QKV buffer). seg = (start, (cos, sin))."""
     _chk(x, "x")
     B, T, HD, ld, sb = _bmk(x)
@@ -136,7 +136,7 @@ def qk_layernorm_rope(x, heads, ln_weight, ln_bias, eps, seg0=None, seg1=None):
     s0, l0, c0, n0 = unpack(seg0)
     s1, l1, c1, n1 = unpack(seg1)
     L.check(_launch("qk_layernorm_rope", L.load().tg_qk_layernorm_rope, _p(x), ld, sb, T, heads, B, _p(ln_weight), _p(ln_bias), float(eps), s0, l0, _p(c0),
-                                          _p(n0), s1, l1, _p(c1), _p(n1), _stream()), "tg_qk_layernorm_rope")
+                                          _p(n0), s1, l1, _p(c1), _p(n1), float(out_scale), _stream()), "tg_qk_layernorm_rope")
     return x
 
 
@@ -149,7 +149,7 @@ def transpose_v(v, heads, key_start, n_keys, vt):
     return vt
 
 
-def attention(q1, k1, vt1, nk1, out, heads, scale, q2=None, k2=None, vt2=None, nk2=0, seg2_scale=0.0):
+def attention(q1, k1, vt1, nk1, out, heads, scale, q2=None, k2=None, vt2=None, nk2=0, seg2_scale=0.0, k_prescaled=False):
     """out[B,nq,heads*64] = softmax(q1 k1^T) v1 + seg2_scale*softmax(q2 k2^T) v2 (segment 2 optional)."""
     _chk(q1, "q1"); _chk(k1, "k1"); _chk(vt1, "vt1"); _chk(out, "out")
     B, nq, _, qld, qsb = _bmk(q1)
@@ -162,7 +162,7 @@ def attention(q1, k1, vt1, nk1, out, heads, scale, q2=None, k2=None, vt2=None, n
         _, _, _, k2ld, k2sb = _bmk(k2)
         a2 = (_p(q2), q2ld, q2sb, _p(k2), k2ld, k2sb, _p(vt2), vt2.shape[3], nk2)
     L.check(_launch("attention_2seg" if q2 is not None else f"attention_1seg_nq{nq}", L.load().tg_attention_fwd, _p(q1), qld, qsb, _p(k1), kld, ksb, _p(vt1), vt1.shape[3], nk1, *a2, float(seg2_scale),
-                                      _p(out), old, osb, nq, heads, B, float(scale), _stream()), "tg_attention_fwd")
+                                      _p(out), old, osb, nq, heads, B, float(scale), 1 if k_prescaled else 0, _stream()), "tg_attention_fwd")
     return out
 
 

@@ -406,24 +406,25 @@ class CogVideoXTransformer3DModel(nn.Module):
         K.gemm(ws.Xn[:, :N1], F[p + "qkv.w"], F[p + "qkv.b"], ws.QKV, L.EPI_BIAS)
         qn = F[p + "qknorm"]
         K.qk_layernorm_rope(ws.QKV[:, :, :D], H, qn[0], qn[1], 1e-6, (Nt, rope))
-        K.qk_layernorm_rope(ws.QKV[:, :, D:2 * D], H, qn[2], qn[3], 1e-6, (Nt, rope))
+        kscale = sm_scale * 1.4426950408889634       # softmax scale * log2(e) folded into K before its single bf16 rounding
+        K.qk_layernorm_rope(ws.QKV[:, :, D:2 * D], H, qn[2], qn[3], 1e-6, (Nt, rope), out_scale=kscale)
         K.transpose_v(ws.QKV[:, :, 2 * D:], H, 0, N1, ws.Vt1)
         if use_vip:
             K.gemm(ws.Xn, F[p + "vqkv.w"], F[p + "vqkv.b"], ws.QKVv, L.EPI_BIAS)
             vqn = F[p + "vqknorm"]
             K.qk_layernorm_rope(ws.QKVv[:, :, :D], H, vqn[0], vqn[1], 1e-6, (Nt, vrope), (N1, crope))
-            K.qk_layernorm_rope(ws.QKVv[:, :, D:2 * D], H, vqn[2], vqn[3], 1e-6, (Nt, vrope), (N1, crope))
+            K.qk_layernorm_rope(ws.QKVv[:, :, D:2 * D], H, vqn[2], vqn[3], 1e-6, (Nt, vrope), (N1, crope), out_scale=kscale)
             K.transpose_v(ws.QKVv[:, :, 2 * D:], H, N1, Np, ws.Vt2)
             K.transpose_v(ws.QKVv[:, :, 2 * D:], H, 0, N, ws.Vt3)
             s = blk.attn1.processor.scale
             s = float(s[0] if isinstance(s, (list, tuple)) else s)
             # text+video rows: softmax(q k^T) v  +  s * softmax(qx kv^T) vv   (attention_processor.py:2066-2069,2117-2134)
             K.attention(ws.QKV[:, :, :D], ws.QKV[:, :, D:2 * D], ws.Vt1, N1, ws.AO[:, :N1], H, sm_scale,
-                        ws.QKVv[:, :N1, :D], ws.QKVv[:, N1:, D:2 * D], ws.Vt2, Np, s)
+                        ws.QKVv[:, :N1, :D], ws.QKVv[:, N1:, D:2 * D], ws.Vt2, Np, s, k_prescaled=True)
             # vip rows: qv against cat(kx, kv) / cat(vx, vv)                  (:2120-2125)
-            K.attention(ws.QKVv[:, N1:, :D], ws.QKVv[:, :, D:2 * D], ws.Vt3, N, ws.AO[:, N1:], H, sm_scale)
+            K.attention(ws.QKVv[:, N1:, :D], ws.QKVv[:, :, D:2 * D], ws.Vt3, N, ws.AO[:, N1:], H, sm_scale, k_prescaled=True)
         else:
-            K.attention(ws.QKV[:, :, :D], ws.QKV[:, :, D:2 * D], ws.Vt1, N1, ws.AO[:, :N1], H, sm_scale)
+            K.attention(ws.QKV[:, :, :D], ws.QKV[:, :, D:2 * D], ws.Vt1, N1, ws.AO[:, :N1], H, sm_scale, k_prescaled=True)
         # out projection with the gated residual as epilogue (cogvideox_transformer_3d.py:290-293)
         K.gemm(ws.AO, F[p + "out.w"], F[p + "out.b"], X, L.EPI_BIAS_GATE_RES, residual=X, gate=t1)
         t2 = self._tables(ws, i, Fm, 2)

@@ -37,8 +37,9 @@ def rnd(*shape, scale=1.0):
 
 
 def bench_attn():
-    qkv = rnd(B, N1, 3 * D)
-    qkvv = rnd(B, N, 3 * D)
+    PRE = os.environ.get("TG_BENCH_PRESCALED", "1") == "1"      # the model folds scale*log2(e) into K
+    qkv = rnd(B, N1, 3 * D, scale=0.4 if PRE else 1.0)
+    qkvv = rnd(B, N, 3 * D, scale=0.4 if PRE else 1.0)
     pad = lambda n: (n + 63) // 64 * 64
     vt1 = torch.empty(B, H, 64, pad(N1), dtype=BF, device=DEV)
     vt2 = torch.empty(B, H, 64, pad(NP), dtype=BF, device=DEV)
@@ -48,7 +49,7 @@ def bench_attn():
     K.transpose_v(qkvv[:, :, 2 * D:], H, 0, N, vt3)
     ao = torch.empty(B, N, D, dtype=BF, device=DEV)
     f_main = lambda: K.attention(qkv[:, :, :D], qkv[:, :, D:2 * D], vt1, N1, ao[:, :N1], H, 0.125,
-                                 qkvv[:, :N1, :D], qkvv[:, N1:, D:2 * D], vt2, NP, 0.6)
+                                 qkvv[:, :N1, :D], qkvv[:, N1:, D:2 * D], vt2, NP, 0.6, k_prescaled=PRE)
     f_vip = lambda: K.attention(qkvv[:, N1:, :D], qkvv[:, :, D:2 * D], vt3, N, ao[:, N1:], H, 0.125)
     ms = timeit(f_main)
     fl = B * (4.0 * N1 * N1 * D + 4.0 * N1 * NP * D)
