@@ -43,8 +43,19 @@ struct AttnParams {
     int nq, heads, batch;
     float scale_log2;   // softmax scale * log2(e)
     int prescaled;      // 1: K already carries scale*log2(e) (tg_qk_layernorm_rope out_scale): scores are log2-domain as produced
+    int knob;           // TG_ATTN_KNOB experiment bits (bit 0: static s_setprio 1 for the second-dispatched wave group)
 };
 
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ int pi_row(int i) {   // swap bits 2 and 3
     return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
 }
@@ -285,7 +296,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 //     wave before the barrier that ends interval 2u+1, first read in interval 2u+2; the buffers it overwrites were last read
 //     in interval 2u-1.
 // ------------------------------------------------------------------------------------------------
-template <bool PRESCALED>
+__device__ long long tg_attn_dbg[16];   // TG_ATTN_TIMING: cycles {X work, X barrier wait, Y work, Y barrier wait} of block 0, waves 0 and 4
+
+template <bool PRESCALED, bool TIMING = false>
 __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // K[2], Vt[2]
     constexpr float RESCALE_THR = 8.0f;
@@ -354,6 +367,10 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         f32x16 acc_o[2][2], sc[2][2];
         bf16x8 pf[2][4];
         float m[2], l[2];
+        // PRESCALED seed operands: ones = 1.0 in k-slot 0 of every key row (lanes 0-31, element 0), negm[qb] = -m of the
+        // lane's query row in k-slot 0; m is kept bf16-representable so the seed is exactly -m
+        bf16x8 ones = {0, 0, 0, 0, 0, 0, 0, 0}, negm[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+        if (hi == 0) ones[0] = (bf16_t)0x3F80;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             m[qb] = PRESCALED ? 0.f : -1e30f;   // PRESCALED seeds the accumulator with -m, so m must stay finite and small
@@ -408,22 +425,90 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
                         }
             }
         };
+        // X(t) for t > 0: the 8 fragment groups {V^T(t-1) ks=0..3, K(t) kd=0..3} software-pipelined one group ahead, so the
+        // ds_read_b128 latency of group g+1 runs under the 4 MFMAs (128 cycles) of group g instead of after them
+        auto xseg = [&](int t) {
+            const char* tV = smem + (2 + ((t - 1) & 1)) * TILE_B;
+            const char* tK = smem + (t & 1) * TILE_B;
+            // fragment i = 2g + xb (g: k-step group, xb: 32-row block of V^T / K); two 4-register buffers, fragment i+2 is
+            // fetched into the buffer fragment i just left, so every ds_read_b128 has two MFMAs (64 cycles) of cover
+            bf16x8 fr[2];
+            auto ld = [&](int i) {
+                const int g = i >> 1, xb = i & 1;
+                if (g < 4) fr[i & 1] = *(const bf16x8*)(tV + ((offV0 + xb * 4096) ^ (g << 5)));
+                else fr[i & 1] = *(const bf16x8*)(tK + ((offK0 + xb * 4096) ^ ((g - 4) << 5)));
+            };
+            ld(0);
+            ld(1);
+            if (PRESCALED) {
+                // seed S with -m through the matrix pipe: ones[key][k=0] x negm[k=0][query] = -m[query] in every register of
+                // the lane's row, 4 MFMAs that run under the first fragments' ds_read latency (no 64 v_mov per tile)
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) sc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, negm[qb], z, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int g = i >> 1, xb = i & 1;
+                if (i == 8 && !PRESCALED) {
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) sc[qb][kb][r] = 0.f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    if (g < 4) acc_o[qb][xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1], pf[qb][g], acc_o[qb][xb], 0, 0, 0);
+                    else sc[qb][xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1], qf[qb][g - 4], sc[qb][xb], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + 2 < 16) ld(i + 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if ((t + 1) * KVBLK > S.nk) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = t * KVBLK + kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                            if (key >= S.nk) sc[qb][kb][r] = -1e30f;
+                        }
+            }
+        };
         // online softmax (log2 domain), lane-local row; P packed to bf16 MFMA operands.
         // PRESCALED: sc holds a = s - m (m = running max when the scores were issued); otherwise sc holds raw q.k
         auto softmax = [&]() {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
-                float mx = sc[qb][0][0];
+                // row max: two independent v_max3 chains (one per key block), halves joined by v_permlane32_swap (no LDS trip);
+                // asm keeps the compiler from canonicalising every MFMA output with an extra v_max first
+                float ma = vmax3(sc[qb][0][0], sc[qb][0][1], sc[qb][0][2]);
+                float mb = vmax3(sc[qb][1][0], sc[qb][1][1], sc[qb][1][2]);
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[qb][kb][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                for (int r = 3; r < 15; r += 2) {
+                    ma = vmax3(ma, sc[qb][0][r], sc[qb][0][r + 1]);
+                    mb = vmax3(mb, sc[qb][1][r], sc[qb][1][r + 1]);
+                }
+                ma = vmax3(ma, mb, sc[qb][0][15]);
+                float mx = vmax2(ma, sc[qb][1][15]);
+                {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                    mx = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+                }
                 if (PRESCALED) {
                     if (__any(mx > RESCALE_THR)) {                       // rare: the row max grew by more than 2^THR
-                        const float delta = fmaxf(mx, 0.f);
+                        const float m_new = round_bf16(m[qb] + fmaxf(mx, 0.f));
+                        const float delta = m_new - m[qb];
                         const float alpha = __builtin_amdgcn_exp2f(-delta);
-                        m[qb] += delta;
+                        m[qb] = m_new;
+                        if (hi == 0) negm[qb][0] = f32_to_bf16(-m_new);
                         l[qb] *= alpha;
 #pragma unroll
                         for (int db = 0; db < 2; ++db)
@@ -448,47 +533,79 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
                     }
                 }
                 const float mq = m[qb];
-                f32x2 ls2 = {0.f, 0.f};
+                // row sums as packed f32 adds: plain v_add_f32 on two chains measured slower here (8.94 vs 8.63 ms)
+                f32x2 ls2[4];          // one row-sum chain per k-step: no dependent packed adds back to back
+                float e[4][8];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int kb = ks >> 1, rb = (ks & 1) * 8;
-                    float e[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        e[i] = PRESCALED ? __builtin_amdgcn_exp2f(sc[qb][kb][rb + i]) : __builtin_amdgcn_exp2f(sc[qb][kb][rb + i] * p.scale_log2 - mq);
+                        e[ks][i] = PRESCALED ? __builtin_amdgcn_exp2f(sc[qb][kb][rb + i]) : __builtin_amdgcn_exp2f(sc[qb][kb][rb + i] * p.scale_log2 - mq);
+                }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) ls2 += f32x2{e[2 * i], e[2 * i + 1]};
+                for (int ks = 0; ks < 4; ++ks) {
                     union { bf16x8 v; uint32_t u[4]; } pk;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) pk.u[i] = pack_bf16x2(e[2 * i], e[2 * i + 1]);
+                    for (int i = 0; i < 4; ++i) pk.u[i] = pack_bf16x2(e[ks][2 * i], e[ks][2 * i + 1]);
                     pf[qb][ks] = pk.v;
                 }
-                l[qb] += ls2[0] + ls2[1];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) ls2[ks] = f32x2{e[ks][0], e[ks][1]};
+#pragma unroll
+                for (int i = 1; i < 4; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) ls2[ks] += f32x2{e[ks][2 * i], e[ks][2 * i + 1]};
+                const f32x2 lsum = (ls2[0] + ls2[1]) + (ls2[2] + ls2[3]);
+                l[qb] += lsum[0] + lsum[1];
             }
         };
 
         // ---- prologue: K(0) resident for everybody; group 1 issues pair 0 and falls one barrier behind ----
+        // X(0) runs the P.V half too, on P = 0 against V buffer 1: zero both so that 0 x stale-LDS cannot make a NaN
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) pf[qb][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        *(uint4*)(smem + 3 * TILE_B + tid * 16) = uint4{0, 0, 0, 0};
         dmaK(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         PP_BAR();
         if (grp == 1) {
             dma_pair(0);
             PP_BAR();
+            if (p.knob & 1) __builtin_amdgcn_s_setprio(1);
         }
+        long long tc[4] = {0, 0, 0, 0}, c0 = 0, c1;
+#define PP_TICK(i)                                                    \
+    if (TIMING) {                                                     \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        c1 = __builtin_amdgcn_s_memtime();                            \
+        tc[i] += c1 - c0;                                             \
+        c0 = c1;                                                      \
+        __builtin_amdgcn_sched_barrier(0);                            \
+    }
+        if (TIMING) c0 = __builtin_amdgcn_s_memtime();
         for (int t = 0; t < ntiles; ++t) {
             // X(t): matrix segment
+            PP_TICK(3);
             if (grp == 0) dma_pair(t);
-            if (t > 0) pv(t - 1);
-            scores(t);
+            xseg(t);
             if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t (issued one segment ago) has landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_TICK(0);
             PP_BAR();
+            PP_TICK(1);
             // Y(t): vector segment
             if (grp == 1) dma_pair(t + 1);
             softmax();
             if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t has landed
+            PP_TICK(2);
             PP_BAR();
         }
+        if (TIMING && blockIdx.x == 0 && sg == 0 && (wave & 3) == 0 && lane == 0)
+            for (int i = 0; i < 4; ++i) tg_attn_dbg[grp * 4 + i] = tc[i];
+#undef PP_TICK
         pv(ntiles - 1);                                                            // X(nt): last P.V
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (grp == 0) PP_BAR();                                                    // barrier counts of the two groups meet again
@@ -557,6 +674,8 @@ extern "C" int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
     // k_prescaled: K rows already carry scale*log2(e) (written by tg_qk_layernorm_rope with out_scale), `scale` is then ignored
     p.prescaled = k_prescaled ? 1 : 0;
     p.scale_log2 = k_prescaled ? 1.0f : scale * 1.4426950408889634f;
+    static const int knob = [] { const char* e = getenv("TG_ATTN_KNOB"); return e ? atoi(e) : 0; }();
+    p.knob = knob;
     // 256-row query tiles (2 query blocks per wave) once they still give >= 4 workgroups per CU, else 128-row tiles
     const long wg256 = (long)((nq + 255) / 256) * heads * batch;
     // measured on MI355X at N=17776: 256-row tiles 900 TFLOP/s vs 128-row tiles 845; s_setprio around the MFMA clusters and an
@@ -565,7 +684,14 @@ extern "C" int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
     static const int no_pp = [] { const char* e = getenv("TG_ATTN_NO_PP"); return e ? atoi(e) : 0; }();
     static const long pp_min = [] { const char* e = getenv("TG_ATTN_PP_MIN_WG"); return e ? atol(e) : 1024L; }();   // tests lower it
     const long wg512 = (long)((nq + 511) / 512) * heads * batch;
-    if (wg512 >= pp_min && !abl && !no_pp) {
+    static const int timing = [] { const char* e = getenv("TG_ATTN_TIMING"); return e ? atoi(e) : 0; }();
+    if (timing && p.prescaled && wg512 >= pp_min) {
+        hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true>), dim3((unsigned)wg512), dim3(512), 0, stream, p);
+        long long h[8];
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(tg_attn_dbg), sizeof(h));
+        fprintf(stderr, "[tg_attention timing] g0: X %lld Xwait %lld Y %lld Ywait %lld | g1: X %lld Xwait %lld Y %lld Ywait %lld (s_memtime ticks, seg 0)\n",
+                h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    } else if (wg512 >= pp_min && !abl && !no_pp) {
         if (p.prescaled) hipLaunchKernelGGL(attn_fwd_pp_kernel<true>, dim3((unsigned)wg512), dim3(512), 0, stream, p);
         else hipLaunchKernelGGL(attn_fwd_pp_kernel<false>, dim3((unsigned)wg512), dim3(512), 0, stream, p);
     } else if (wg256 >= 1024 && abl) {
