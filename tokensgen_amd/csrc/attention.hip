@@ -46,16 +46,10 @@ struct AttnParams {
     int knob;           // TG_ATTN_KNOB experiment bits (bit 0: static s_setprio 1 for the second-dispatched wave group)
 };
 
-__device__ __forceinline__ float vmax3(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ float vmax2(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
+// plain fmaxf nests: clang fuses them to v_max3_f32 (built with -fno-honor-nans so MFMA outputs are not canonicalised by an
+// extra v_max first); inline-asm versions get an s_nop after every dependent op and measured ~1.5 % slower
+__device__ __forceinline__ float vmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float vmax2(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ int pi_row(int i) {   // swap bits 2 and 3
     return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
 }
@@ -295,6 +289,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 //     pair u = (K(u+1), V(u)) is issued in interval 2u (group 0: start of X(u); group 1: start of Y(u-1)), retired by every
 //     wave before the barrier that ends interval 2u+1, first read in interval 2u+2; the buffers it overwrites were last read
 //     in interval 2u-1.
+//
+// Measured on MI355X, N = 17776 (same-box A/B, tools/ab_run.sh; box-to-box spread is ~4 %):
+//   in-kernel s_memtime per tile: X ~1600 cycles (1152 of MFMA), Y ~2000 cycles for ~190 VALU — a lone wave issues one VALU
+//   per ~6.6 cycles (tools/ubench/valu_rate.hip: 6.64 plain / 10.6 v_exp_f32 with 1 wave per SIMD, half that per SIMD with 2).
+//   Helped: fragment-granular ds_read pipelining in X, -m seeding through the matrix pipe, two v_max3 chains +
+//   v_permlane32_swap, four row-sum chains (8.63 -> 7.8 ms).  Did not help: plain v_add_f32 row sums; s_setprio 1 for the
+//   second-dispatched half; exponentiating the last 1 or 2 k-steps of P(t) inside X(t+1) as MFMA fillers (9.1 / 11.4 ms:
+//   VALU between the MFMAs of the matrix segment costs more than it frees in the vector segment).
 // ------------------------------------------------------------------------------------------------
 __device__ long long tg_attn_dbg[16];   // TG_ATTN_TIMING: cycles {X work, X barrier wait, Y work, Y barrier wait} of block 0, waves 0 and 4
 
@@ -488,7 +490,6 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 // row max: two independent v_max3 chains (one per key block), halves joined by v_permlane32_swap (no LDS trip);
-                // asm keeps the compiler from canonicalising every MFMA output with an extra v_max first
                 float ma = vmax3(sc[qb][0][0], sc[qb][0][1], sc[qb][0][2]);
                 float mb = vmax3(sc[qb][1][0], sc[qb][1][1], sc[qb][1][2]);
 #pragma unroll

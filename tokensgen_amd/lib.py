@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtokensgen_hip.so")
+LIB_PATH = os.environ.get("TG_LIB_PATH") or os.path.join(_HERE, "libtokensgen_hip.so")   # override: A/B builds in tools/
 TG_MAX_GROUPS = 16
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SILU, EPI_BIAS_GATE_RES = 0, 1, 2, 3
