@@ -171,7 +171,7 @@ def main():
         achieved = ATTN_FLOP_PER_LAUNCH / attn_s / 1e12 if attn["n"] else float("nan")
         traffic = None          # HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
         try:
-            with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r1b_pmc_summary.json")) as f:
                 traffic = json.load(f)["_derived"]["attention_main_traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
@@ -184,7 +184,7 @@ def main():
                                    "window = 226 text + 17550 video + 480 condensed tokens, CFG batch 2, DPM-solver++ (52 trailing steps)",
                        "layers": a.layers, "exchange": "RCCL all_gather of kept half-windows per step" if use_dist else "none"},
             "step_mfma_frac": FLOP_PER_STEP * (a.layers / 42.0) * (a.steps / dt) / PEAK_BF16,
-            "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel (main: SDPA#1+#2 fused)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "attn_fwd_pp_kernel (main attention: SDPA#1+#2 fused)", "achieved": achieved,
                          "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16 / 1e12), "traffic": traffic,
                          "launch_ms": attn["ms"], "launches_timed": attn["n"]},
             "kernel_ms": {k: round(v["ms"], 4) for k, v in prof.items()},
