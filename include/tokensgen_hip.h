@@ -106,13 +106,15 @@ int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
  * (flip_sin_to_cos=True, freq_shift=0).  Replaces embeddings.py:28-79 + dit:678.  t: int64[n]. */
 int tg_timestep_sinusoid(const int64_t* t, int n, int dim, void* emb, hipStream_t stream);
 
-/* Gather 2x2 patches: out[(b f) (h/2 w/2)][c*4 + dy*2 + dx] = lat[b][f][c][2y+dy][2x+dx]  (the im2col of
- * Conv2d(k=2,s=2), embeddings.py:516-523) so that patch embedding is one GEMM with K = 4*C. */
-int tg_patchify(const void* lat, void* out, int bf, int C, int H, int W, hipStream_t stream);
+/* Gather p x p patches (p = 2: To2V model; p = 1: the T2To model, train_cogvideo_t2to.py:1277):
+ *   out[(b f)(h/p w/p)][ldo][c*p*p + dy*p + dx] = lat[b][f][c][p*y+dy][p*x+dx]
+ * (the im2col of Conv2d(k=p,s=p), embeddings.py:516-523) so that patch embedding is one GEMM with K = p*p*C;
+ * ldo >= p*p*C lets the caller keep zero pad columns up to the GEMM's K granule. */
+int tg_patchify(const void* lat, void* out, long ldo, int bf, int C, int H, int W, int p, hipStream_t stream);
 
-/* Inverse for the output head: lat[b][f][c][2y+dy][2x+dx] = x[(b f)(y x)][ld][c*4 + dy*2 + dx]
+/* Inverse for the output head: lat[b][f][c][p*y+dy][p*x+dx] = x[(b f)(y x)][ldx][c*p*p + dy*p + dx]
  * (cogvideox_transformer_3d.py:754-759). */
-int tg_unpatchify(const void* x, long ldx, void* lat, int bf, int C, int H, int W, hipStream_t stream);
+int tg_unpatchify(const void* x, long ldx, void* lat, int bf, int C, int H, int W, int p, hipStream_t stream);
 
 /* Fused classifier-free guidance + per-frame SDE-DPM-solver++(2M) update for one FIFO window:
  *   v   = uncond + g*(cond - uncond)                                    (cogvideo_sampling_mp_fifo.py:531-533)
@@ -124,6 +126,22 @@ int tg_unpatchify(const void* x, long ldx, void* lat, int bf, int C, int H, int 
 int tg_cfg_dpm_step(const void* model_out, const void* x, const void* old_x0, const void* noise,
                     const float* coef, float guidance, void* x_out, void* x0_out,
                     int frames, long frame_elems, hipStream_t stream);
+
+/* The same update as the pipelines' own denoising loops run it (pipeline_cogvideox_t2to.py:845-870 and the To2V base stage,
+ * pipeline_cogvideox_mp_fifo.py:1236-1276): `noise_pred.float()` precedes guidance, so CFG is NOT rounded to bf16 and the solver
+ * history old_x0 / x0_out is fp32; sample and noise are bf16 tensors there, so `sa*x`, `m1*x`, `mn*noise` are bf16 products with
+ * the coefficient itself cast to bf16 first (torch's 0-dim promotion rule); the new sample is cast to bf16.  noise: bf16 [frames][2][E]. */
+int tg_cfg_dpm_step_f32(const void* model_out, const void* x, const float* old_x0, const void* noise,
+                        const float* coef, float guidance, void* x_out, float* x0_out,
+                        int frames, long frame_elems, hipStream_t stream);
+
+/* T2To tail (pipeline_cogvideox_t2to.py:890-899 with pca.py:64-66): the sampled latents hold `ncoef` (= 16) normalised PCA
+ * coefficients per token; de-normalise and project back to the condensed-token width in fp32:
+ *   out[f][c][s] = bf16( pmean[c] + sum_j (lat[f][j][s] * std[j] + mean[j]) * comp[j][c] )      f < frames, s < hw, c < cout
+ * lat bf16 [frames][ncoef][hw]; std/mean fp32 [ncoef]; comp fp32 [ncoef][cout] (the first ncoef PCA components);
+ * pmean fp32 [cout]; out bf16 [frames][cout][hw] (= image_embeddings [b f c h w]). */
+int tg_pca_inverse(const void* lat, const float* std16, const float* mean16, const float* comp, const float* pmean,
+                   void* out, int frames, int ncoef, int hw, int cout, hipStream_t stream);
 
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -197,7 +197,7 @@ def base_stage(denoise, ac, latents, timesteps, guidance_scale, noise_fn, nf=13)
         t_back = ts[i - 1] if i > 0 else None
         nz = noise_fn(i)
         second = old is not None and prev_t >= 0
-        n = nz[:, 1 if second else 0].float()[None]           # [1,nf,C,H,W]
+        n = nz[:, 1 if second else 0].to(dt)[None]            # [1,nf,C,H,W]; randn_tensor(dtype=sample.dtype), scheduling_dpm:452,460
         seq = iter([n, n])
         latents_f, old = S.dpm_step(ac, pred, old, t, prev_t, t_back, latents, lambda: next(seq))
         latents = latents_f.to(dt)

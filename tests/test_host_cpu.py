@@ -151,12 +151,13 @@ def test_longvgen_alias_and_vae_host_contract():
         from longvgen.models import CogVideoXTransformer3DModel, AutoencoderKLCogVideoX as A2
         from longvgen.schedulers import CogVideoXDPMScheduler
         from longvgen.fifo_sampling import cogvideo_fifo_mp_v2
-        from longvgen.pipeline import MPFIFOVideoIPAdapterCogVideoXPipeline
-        assert A2 is AutoencoderKLCogVideoX and callable(cogvideo_fifo_mp_v2)
+        from longvgen.pipeline import MPFIFOVideoIPAdapterCogVideoXPipeline, LongVGenCogVideoXPipeline
+        from longvgen.video_ipadapter import Resampler
+        assert A2 is AutoencoderKLCogVideoX and callable(cogvideo_fifo_mp_v2) and callable(LongVGenCogVideoXPipeline) and callable(Resampler)
         with pytest.raises(ImportError):
             import longvgen.data  # noqa: F401  (out of scope: never silently stubbed)
     finally:
-        for k in [k for k in sys.modules if k == "longvgen" or k.startswith("longvgen.")]:
+        for k in [k for k in sys.modules if k == "longvgen" or k.startswith("longvgen.") or k == "pca"]:
             del sys.modules[k]
     vae = AutoencoderKLCogVideoX(device="cpu")
     assert (vae.tile_sample_min_height, vae.tile_sample_min_width, vae.tile_latent_min_height, vae.tile_latent_min_width) == (240, 360, 30, 45)
@@ -173,3 +174,37 @@ def test_longvgen_alias_and_vae_host_contract():
         v2.decode(torch.zeros(1, 16, 3, 4, 6))
     with pytest.raises(NotImplementedError):
         AutoencoderKLCogVideoX(latent_channels=8, device="cpu")
+
+
+def test_pca_holder_matches_reference_fit_and_unpickles_under_the_reference_module_name(golden_dir, tmp_path):
+    """tokensgen_amd.pca.PCA: the fit/inverse algebra (pca.py:11-66), and a pickle written under the module name `pca` (what the
+    reference's torch.save of its own object produces) loads through the alias — the T2To pipeline torch.load()s such a file."""
+    import sys
+    from tokensgen_amd import compat
+    from tokensgen_amd.pca import PCA
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(200, 12, generator=g) * torch.linspace(3, 0.2, 12)
+    p = PCA(n_components=5).fit(X)
+    assert p.components_.shape == (5, 12) and p.mean_.shape == (1, 12)
+    assert torch.allclose(p.components_ @ p.components_.t(), torch.eye(5), atol=1e-5)
+    U, Sv, Vt = torch.linalg.svd(X - X.mean(0, keepdim=True), full_matrices=False)
+    assert torch.allclose(p.components_.abs(), Vt[:5].abs(), atol=1e-5)
+    full = PCA().fit(X)
+    assert torch.allclose(full.inverse_transform(full.transform(X)), X, atol=1e-4)
+    # the fixture's 16 rows came from the reference class fitted on seeded data: same sign convention (largest |u| positive)
+    t = torch.load(os.path.join(golden_dir, "t2to_tiny.pt"), weights_only=False)
+    assert t["pca_components16"].shape == (16, 3072) and torch.allclose(t["pca_components16"] @ t["pca_components16"].t(), torch.eye(16), atol=1e-4)
+    compat.install_longvgen_alias()
+    try:
+        assert sys.modules["pca"].PCA is PCA
+        PCA.__module__ = "pca"                      # what a pickle of the reference's own class records
+        try:
+            torch.save(p, tmp_path / "pca.pt")
+        finally:
+            PCA.__module__ = "tokensgen_amd.pca"
+        assert b"tokensgen_amd" not in (tmp_path / "pca.pt").read_bytes()
+        q = torch.load(tmp_path / "pca.pt", weights_only=False)
+        assert type(q) is PCA and torch.equal(q.components_, p.components_)
+    finally:
+        for k in [k for k in sys.modules if k == "longvgen" or k.startswith("longvgen.") or k == "pca"]:
+            del sys.modules[k]

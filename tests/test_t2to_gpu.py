@@ -1,0 +1,144 @@
+"""GPU: the T2To stage (tokensgen_amd.pipeline_t2to, through the C ABI) against the reference run stored in
+tests/golden/t2to_tiny.pt and the CPU oracle (oracle/t2to_ref.py).  Tolerances: elementwise kernels exact up to one bf16
+rounding of an fp32 result; DiT-in-the-loop rel-L2 per SURVEY §8c (3e-2 single forward; 6 sampling steps compound it)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dit_ref as O
+from oracle import scheduler_ref as S
+from oracle import t2to_ref as T
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def _gold(golden_dir):
+    return torch.load(os.path.join(golden_dir, "t2to_tiny.pt"), weights_only=False)
+
+
+def _model(g):
+    from tokensgen_amd.transformer import CogVideoXTransformer3DModel
+    cfg = g["cfg"]
+    m = CogVideoXTransformer3DModel(num_attention_heads=cfg["num_attention_heads"], attention_head_dim=64, num_layers=cfg["num_layers"],
+                                    time_embed_dim=cfg["time_embed_dim"], text_embed_dim=cfg["text_embed_dim"], patch_size=1,
+                                    use_rotary_positional_embeddings=True, device=DEV)
+    sd = O.make_state_dict(cfg, seed=g["weight_seed"])
+    m.load_state_dict({k: v.to(BF) for k, v in sd.items()}, strict=True)
+    return m, sd
+
+
+def test_pca_inverse_matches_oracle_tail(golden_dir):
+    from tokensgen_amd import kernels as K
+    g = _gold(golden_dir)
+    c = g["cases"]["torch.bfloat16"]
+    lat = c["sampled"]                                            # [1, F, 16, h, w] bf16
+    width = g["pca_mean"].shape[1]
+    comp = torch.zeros(width, width); comp[:16] = g["pca_components16"]
+    want = T.pca_inverse_tail(lat, g["mean"], g["std"], comp, g["pca_mean"], width)[0]
+    out = torch.empty(lat.shape[1], width, lat.shape[3], lat.shape[4], dtype=BF, device=DEV)
+    K.pca_inverse(lat[0].to(DEV).contiguous(), g["std"].reshape(-1)[:16].to(DEV).contiguous(), g["mean"].reshape(-1)[:16].to(DEV).contiguous(),
+                  g["pca_components16"].to(DEV).contiguous(), g["pca_mean"].reshape(-1).to(DEV).contiguous(), out)
+    # fp32 sums in a different order, then one bf16 rounding: at most one bf16 ulp apart, and only rarely
+    d = (out.cpu().float() - want.float()).abs()
+    assert (d <= want.float().abs() * 2 ** -7 + 1e-6).all()
+    assert (out.cpu() != want).float().mean() < 0.02
+    assert torch.equal(out.cpu(), c["frames"][0]) or (out.cpu() != c["frames"][0]).float().mean() < 0.02
+
+
+def test_cfg_dpm_step_f32_matches_oracle():
+    from tokensgen_amd import kernels as K
+    from tokensgen_amd.scheduler import CogVideoXDPMScheduler
+    sched = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
+    sched.set_timesteps(52)
+    _, ac = S.alphas_cumprod(snr_shift_scale=1.0)
+    gen = torch.Generator().manual_seed(5)
+    F_, shp = 12, (16, 2, 3)
+    for (t, prev_t, t_back, has) in ((999, 980, None, False), (500, 481, 519, True), (18, -1, 37, True)):
+        mo = torch.randn(2, F_, *shp, generator=gen).to(BF)
+        x = torch.randn(F_, *shp, generator=gen).to(BF)
+        old = torch.randn(F_, *shp, generator=gen)
+        nz = torch.randn(F_, 2, *shp, generator=gen).to(BF)
+        gsc = 4.37
+        pred = mo[0].float() + gsc * (mo[1].float() - mo[0].float())
+        second = has and prev_t >= 0
+        n = nz[:, 1 if second else 0]
+        seq = iter([n, n])
+        want_x, want_x0 = S.dpm_step(ac, pred, old if has else None, t, prev_t, t_back, x, lambda: next(seq))
+        coef = sched.coef_table([t] * F_, [prev_t] * F_, [t_back] * F_, [second] * F_, DEV)
+        xo = torch.empty(F_, *shp, dtype=BF, device=DEV)
+        x0o = torch.empty(F_, *shp, dtype=torch.float32, device=DEV)
+        K.cfg_dpm_step_f32(mo.to(DEV).reshape(2, F_, -1), x.to(DEV).reshape(F_, -1), old.to(DEV).reshape(F_, -1), nz.to(DEV).reshape(F_, 2, -1),
+                           coef, gsc, xo.view(F_, -1), x0o.view(F_, -1))
+        torch.testing.assert_close(x0o.cpu(), want_x0.float(), rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(xo.cpu().float(), want_x.to(BF).float(), rtol=2 ** -7, atol=1e-5)
+
+
+def test_patch1_dit_forward_vs_oracle(golden_dir):
+    g = _gold(golden_dir)
+    m, sd = _model(g)
+    c = g["cases"]["torch.bfloat16"]
+    F_, H, W = g["nfc"] * g["chunks"], g["H"], g["W"]
+    x = torch.cat([c["init_latents"]] * 2)
+    emb = torch.cat([c["negative"], c["prompt"]])
+    t = torch.tensor([999, 999])
+    rope = T.rope_tables(64, F_, H, W)
+    want = O.dit_forward({k: v.to(BF) for k, v in sd.items()}, g["cfg"], x, emb, t, image_rotary_emb=rope)
+    got = m(x.to(DEV), emb.to(DEV), t.to(DEV), image_rotary_emb=rope, return_dict=False)[0]
+    assert got.shape == want.shape and torch.isfinite(got).all()
+    assert _rel(got, want) < 3e-2
+
+
+def test_t2to_pipeline_vs_reference_fixture(golden_dir):
+    """The whole stage with the reference's initial latents and gaussian draws replayed: sampled latents and condensed tokens
+    against the reference's bf16 run."""
+    from tokensgen_amd.pipeline_t2to import LongVGenCogVideoXPipeline
+    from tokensgen_amd.scheduler import CogVideoXDPMScheduler
+    from tokensgen_amd.pca import PCA
+    g = _gold(golden_dir)
+    m, _ = _model(g)
+    c = g["cases"]["torch.bfloat16"]
+    sched = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
+    pipe = LongVGenCogVideoXPipeline(m, sched)
+    pca = PCA()
+    pca.register_buffer("mean_", g["pca_mean"]); pca.register_buffer("components_", g["pca_components16"])
+    draws = list(c["step_draws"])
+    order = []
+
+    def step_noise(i, k):
+        order.append((i, k))
+        return draws[len(order) - 1]
+
+    out = pipe(prompt_embeds=c["prompt"], negative_prompt_embeds=c["negative"], height=g["H"], width=g["W"], num_frames_per_chunk=g["nfc"],
+               num_chunks=g["chunks"], num_inference_steps=g["steps"], use_dynamic_cfg=True, guidance_scale=g["guidance_scale"],
+               latents=c["init_latents"], longvgen_mean=g["mean"], longvgen_std=g["std"], longvgen_pca=pca, step_noise=step_noise).frames
+    assert order == [(0, 0)] + [(i, k) for i in range(1, g["steps"] - 1) for k in (0, 1)] + [(g["steps"] - 1, 0)]
+    assert out.shape == c["frames"].shape and out.dtype == BF
+    assert _rel(out, c["frames"]) < 6e-2
+    # same seed through a CPU generator reproduces the reference's start and draw order without the replay hooks
+    out2 = pipe(prompt_embeds=c["prompt"], negative_prompt_embeds=c["negative"], height=g["H"], width=g["W"], num_frames_per_chunk=g["nfc"],
+                num_chunks=g["chunks"], num_inference_steps=g["steps"], use_dynamic_cfg=True, guidance_scale=g["guidance_scale"],
+                generator=torch.Generator().manual_seed(g["gen_seed"]), longvgen_mean=g["mean"], longvgen_std=g["std"], longvgen_pca=pca).frames
+    assert _rel(out2, c["frames"]) < 6e-2
+
+
+def test_t2to_argument_errors(golden_dir):
+    from tokensgen_amd.pipeline_t2to import LongVGenCogVideoXPipeline
+    from tokensgen_amd.scheduler import CogVideoXDPMScheduler
+    g = _gold(golden_dir)
+    m, _ = _model(g)
+    pipe = LongVGenCogVideoXPipeline(m, CogVideoXDPMScheduler(prediction_type="v_prediction", timestep_spacing="trailing"))
+    c = g["cases"]["torch.bfloat16"]
+    with pytest.raises(ValueError, match="must equal 4"):
+        pipe(prompt_embeds=c["prompt"], negative_prompt_embeds=c["negative"], num_frames_per_chunk=5, longvgen_mean=g["mean"],
+             longvgen_std=g["std"], longvgen_pca=object())
+    with pytest.raises(ValueError, match="prompt_embeds"):
+        pipe(longvgen_mean=g["mean"], longvgen_std=g["std"], longvgen_pca=object())

@@ -17,24 +17,25 @@ __global__ void timestep_sinusoid_kernel(const int64_t* __restrict__ t, int n, i
     emb[(long)i * dim + half + k] = f32_to_bf16(sinf(a));
 }
 
-// out[(bf, y, x)][c*4 + dy*2 + dx] = lat[bf][c][2y+dy][2x+dx]
-__global__ void patchify_kernel(const bf16_t* __restrict__ lat, bf16_t* __restrict__ out, int bf, int C, int H, int W) {
-    const int hp = H >> 1, wp = W >> 1, K = C * 4;
+// out[(bf, y, x)][ldo][c*p*p + dy*p + dx] = lat[bf][c][p*y+dy][p*x+dx]   (p = patch size: 2 for To2V, 1 for the T2To model)
+__global__ void patchify_kernel(const bf16_t* __restrict__ lat, bf16_t* __restrict__ out, long ldo, int bf, int C, int H, int W, int p) {
+    const int hp = H / p, wp = W / p, pp = p * p, K = C * pp;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)bf * hp * wp * K;
     if (idx >= total) return;
     const int kk = (int)(idx % K);
     long tok = idx / K;
+    const long row = tok;
     const int x = (int)(tok % wp); tok /= wp;
     const int y = (int)(tok % hp);
     const int f = (int)(tok / hp);
-    const int c = kk >> 2, dy = (kk >> 1) & 1, dx = kk & 1;
-    out[idx] = lat[(((long)f * C + c) * H + 2 * y + dy) * W + 2 * x + dx];
+    const int c = kk / pp, dy = (kk / p) % p, dx = kk % p;
+    out[row * ldo + kk] = lat[(((long)f * C + c) * H + p * y + dy) * W + p * x + dx];
 }
 
-// lat[bf][c][2y+dy][2x+dx] = x[(bf, y, x)][c*4 + dy*2 + dx]
-__global__ void unpatchify_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ lat, int bf, int C, int H, int W) {
-    const int hp = H >> 1, wp = W >> 1;
+// lat[bf][c][p*y+dy][p*x+dx] = x[(bf, y, x)][ldx][c*p*p + dy*p + dx]
+__global__ void unpatchify_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ lat, int bf, int C, int H, int W, int p) {
+    const int hp = H / p, wp = W / p;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)bf * C * H * W;
     if (idx >= total) return;
@@ -43,8 +44,8 @@ __global__ void unpatchify_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t
     const int yy = (int)(r % H); r /= H;
     const int c = (int)(r % C);
     const int f = (int)(r / C);
-    const long tok = ((long)f * hp + (yy >> 1)) * wp + (xx >> 1);
-    lat[idx] = x[tok * ldx + c * 4 + (yy & 1) * 2 + (xx & 1)];
+    const long tok = ((long)f * hp + (yy / p)) * wp + (xx / p);
+    lat[idx] = x[tok * ldx + c * p * p + (yy % p) * p + (xx % p)];
 }
 
 // coef row: {sa, sb, m1, m2, m3, m4, mn, has_old}
@@ -71,6 +72,60 @@ __global__ void cfg_dpm_step_kernel(const bf16_t* __restrict__ mo, const bf16_t*
     x0_out[idx] = f32_to_bf16(x0);
 }
 
+
+// Pipeline-loop variant (pipeline_cogvideox_t2to.py:845-870, pipeline_cogvideox_mp_fifo.py:1236-1276): the pipelines take
+// `noise_pred.float()` before guidance, so CFG, x0 and the solver history stay fp32; the gaussian draws take the SAMPLE's
+// dtype (bf16, scheduling_dpm_cogvideox.py:452,460) and the new sample is cast back to the model dtype after the step.
+__global__ void cfg_dpm_step_f32_kernel(const bf16_t* __restrict__ mo, const bf16_t* __restrict__ x,
+                                        const float* __restrict__ old_x0, const bf16_t* __restrict__ noise,
+                                        const float* __restrict__ coef, float guidance, bf16_t* __restrict__ x_out,
+                                        float* __restrict__ x0_out, int frames, long fe) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)frames * fe;
+    if (idx >= total) return;
+    const int f = (int)(idx / fe);
+    const long e = idx - (long)f * fe;
+    const float* c = coef + f * 8;
+    const float u = bf16_to_f32(mo[idx]), cd = bf16_to_f32(mo[total + idx]);
+    const float v = u + guidance * (cd - u);
+    const float xs = bf16_to_f32(x[idx]);
+    // the sample and the noise are bf16 tensors and the coefficients are 0-dim fp64 tensors, which do not widen them: in
+    // `sa * sample`, `m1 * sample` and `mn * noise` torch first casts the coefficient to bf16, then rounds the product to bf16
+    // (scheduling_dpm_cogvideox.py:437,457-463); everything after is fp32
+    const float x0 = round_bf16(round_bf16(c[0]) * xs) - c[1] * v;
+    const bool has_old = c[7] != 0.f;
+    float d = x0;
+    if (has_old) d = c[4] * x0 - c[5] * old_x0[idx];
+    const float nz = bf16_to_f32(noise[((long)f * 2 + (has_old ? 1 : 0)) * fe + e]);
+    x_out[idx] = f32_to_bf16(round_bf16(round_bf16(c[2]) * xs) - c[3] * d + round_bf16(round_bf16(c[6]) * nz));
+    x0_out[idx] = x0;
+}
+
+// T2To tail (pipeline_cogvideox_t2to.py:890-899, pca.py:64-66): de-normalise the 16 sampled coefficients and take them back
+// through the PCA basis to the condensed-token width, fp32 like the reference's CPU tail, written in the [b f c h w] order
+// the To2V stage consumes:  out[bf][c][s] = pmean[c] + sum_j (lat[bf][j][s] * std[j] + mean[j]) * comp[j][c]
+template <int NC>
+__global__ void pca_inverse_kernel(const bf16_t* __restrict__ lat, const float* __restrict__ std_, const float* __restrict__ mean_,
+                                   const float* __restrict__ comp, const float* __restrict__ pmean, bf16_t* __restrict__ out,
+                                   int hw, int cout) {
+    // block = one frame x 64 output channels; the frame's NC x hw coefficients are de-normalised once into LDS
+    extern __shared__ float sl[];                       // [NC][hw]
+    const int f = blockIdx.x, c0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < NC * hw; i += blockDim.x) {
+        const int j = i / hw;
+        sl[i] = bf16_to_f32(lat[(long)f * NC * hw + i]) * std_[j] + mean_[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * hw; i += blockDim.x) {
+        const int cl = i / hw, s = i - cl * hw, c = c0 + cl;
+        if (c >= cout) break;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) acc = fmaf(sl[j * hw + s], comp[(long)j * cout + c], acc);
+        out[((long)f * cout + c) * hw + s] = f32_to_bf16(acc + pmean[c]);
+    }
+}
+
 }  // namespace
 
 extern "C" int tg_timestep_sinusoid(const int64_t* t, int n, int dim, void* emb, hipStream_t stream) {
@@ -82,20 +137,22 @@ extern "C" int tg_timestep_sinusoid(const int64_t* t, int n, int dim, void* emb,
     return TG_OK;
 }
 
-extern "C" int tg_patchify(const void* lat, void* out, int bf, int C, int H, int W, hipStream_t stream) {
+extern "C" int tg_patchify(const void* lat, void* out, long ldo, int bf, int C, int H, int W, int p, hipStream_t stream) {
     TG_REQUIRE(lat && out, TG_ERR_ARG, "tg_patchify: null pointer");
-    TG_REQUIRE(bf > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, TG_ERR_SHAPE, "tg_patchify: bad shape");
-    const long total = (long)bf * (H / 2) * (W / 2) * C * 4;
-    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)lat, (bf16_t*)out, bf, C, H, W);
+    TG_REQUIRE(bf > 0 && C > 0 && H > 0 && W > 0 && (p == 1 || p == 2) && H % p == 0 && W % p == 0 && ldo >= (long)C * p * p, TG_ERR_SHAPE,
+               "tg_patchify: bad shape (p=%d)", p);
+    const long total = (long)bf * (H / p) * (W / p) * C * p * p;
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)lat, (bf16_t*)out, ldo, bf, C, H, W, p);
     TG_LAUNCH_CHECK("tg_patchify");
     return TG_OK;
 }
 
-extern "C" int tg_unpatchify(const void* x, long ldx, void* lat, int bf, int C, int H, int W, hipStream_t stream) {
+extern "C" int tg_unpatchify(const void* x, long ldx, void* lat, int bf, int C, int H, int W, int p, hipStream_t stream) {
     TG_REQUIRE(x && lat, TG_ERR_ARG, "tg_unpatchify: null pointer");
-    TG_REQUIRE(bf > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && ldx >= 4L * C, TG_ERR_SHAPE, "tg_unpatchify: bad shape");
+    TG_REQUIRE(bf > 0 && C > 0 && H > 0 && W > 0 && (p == 1 || p == 2) && H % p == 0 && W % p == 0 && ldx >= (long)C * p * p, TG_ERR_SHAPE,
+               "tg_unpatchify: bad shape (p=%d)", p);
     const long total = (long)bf * C * H * W;
-    hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (bf16_t*)lat, bf, C, H, W);
+    hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (bf16_t*)lat, bf, C, H, W, p);
     TG_LAUNCH_CHECK("tg_unpatchify");
     return TG_OK;
 }
@@ -110,5 +167,29 @@ extern "C" int tg_cfg_dpm_step(const void* model_out, const void* x, const void*
                        (const bf16_t*)x, (const bf16_t*)old_x0, (const bf16_t*)noise, coef, guidance, (bf16_t*)x_out, (bf16_t*)x0_out,
                        frames, frame_elems);
     TG_LAUNCH_CHECK("tg_cfg_dpm_step");
+    return TG_OK;
+}
+
+extern "C" int tg_cfg_dpm_step_f32(const void* model_out, const void* x, const float* old_x0, const void* noise,
+                                   const float* coef, float guidance, void* x_out, float* x0_out, int frames,
+                                   long frame_elems, hipStream_t stream) {
+    TG_REQUIRE(model_out && x && old_x0 && noise && coef && x_out && x0_out, TG_ERR_ARG, "tg_cfg_dpm_step_f32: null pointer");
+    TG_REQUIRE(frames > 0 && frame_elems > 0, TG_ERR_SHAPE, "tg_cfg_dpm_step_f32: bad shape");
+    const long total = (long)frames * frame_elems;
+    hipLaunchKernelGGL(cfg_dpm_step_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)model_out,
+                       (const bf16_t*)x, old_x0, (const bf16_t*)noise, coef, guidance, (bf16_t*)x_out, x0_out, frames, frame_elems);
+    TG_LAUNCH_CHECK("tg_cfg_dpm_step_f32");
+    return TG_OK;
+}
+
+extern "C" int tg_pca_inverse(const void* lat, const float* std16, const float* mean16, const float* comp, const float* pmean,
+                              void* out, int frames, int ncoef, int hw, int cout, hipStream_t stream) {
+    TG_REQUIRE(lat && std16 && mean16 && comp && pmean && out, TG_ERR_ARG, "tg_pca_inverse: null pointer");
+    TG_REQUIRE(frames > 0 && hw > 0 && cout > 0, TG_ERR_SHAPE, "tg_pca_inverse: bad shape");
+    TG_REQUIRE(ncoef == 16, TG_ERR_SHAPE, "tg_pca_inverse: the T2To model samples 16 PCA coefficients (got %d)", ncoef);
+    TG_REQUIRE((long)16 * hw * 4 <= 64 * 1024, TG_ERR_SHAPE, "tg_pca_inverse: hw=%d too large for the LDS stage", hw);
+    hipLaunchKernelGGL(pca_inverse_kernel<16>, dim3((unsigned)frames, (unsigned)((cout + 63) / 64)), dim3(256), (size_t)16 * hw * 4, stream,
+                       (const bf16_t*)lat, std16, mean16, comp, pmean, (bf16_t*)out, hw, cout);
+    TG_LAUNCH_CHECK("tg_pca_inverse");
     return TG_OK;
 }

@@ -172,21 +172,21 @@ def timestep_sinusoid(t, dim, out):
     return out
 
 
-def patchify(lat, out):
-    """lat [BF,C,H,W] contiguous -> out [BF*(H/2)*(W/2), 4C]"""
+def patchify(lat, out, p=2):
+    """lat [BF,C,H,W] contiguous -> out [BF*(H/p)*(W/p), ld >= p*p*C] (pad columns are left untouched)"""
     _chk(lat, "lat"); _chk(out, "out")
-    assert lat.is_contiguous() and out.is_contiguous()
+    assert lat.is_contiguous() and out.stride(1) == 1
     BF, Cc, H, W = lat.shape
-    L.check(L.load().tg_patchify(_p(lat), _p(out), BF, Cc, H, W, _stream()), "tg_patchify")
+    L.check(L.load().tg_patchify(_p(lat), _p(out), out.stride(0), BF, Cc, H, W, p, _stream()), "tg_patchify")
     return out
 
 
-def unpatchify(x, lat):
-    """x [BF*(H/2)*(W/2), ld>=4C] rows -> lat [BF,C,H,W] contiguous"""
+def unpatchify(x, lat, p=2):
+    """x [BF*(H/p)*(W/p), ld >= p*p*C] rows -> lat [BF,C,H,W] contiguous"""
     _chk(x, "x"); _chk(lat, "lat")
     assert lat.is_contiguous()
     BF, Cc, H, W = lat.shape
-    L.check(L.load().tg_unpatchify(_p(x), x.stride(0), _p(lat), BF, Cc, H, W, _stream()), "tg_unpatchify")
+    L.check(L.load().tg_unpatchify(_p(x), x.stride(0), _p(lat), BF, Cc, H, W, p, _stream()), "tg_unpatchify")
     return lat
 
 
@@ -200,6 +200,34 @@ def cfg_dpm_step(model_out, x, old_x0, noise, coef, guidance, x_out, x0_out):
     L.check(L.load().tg_cfg_dpm_step(_p(model_out), _p(x), _p(old_x0), _p(noise), _p(coef), float(guidance), _p(x_out),
                                      _p(x0_out), F_, E, _stream()), "tg_cfg_dpm_step")
     return x_out, x0_out
+
+
+def cfg_dpm_step_f32(model_out, x, old_x0, noise, coef, guidance, x_out, x0_out):
+    """Pipeline-loop variant: model_out [2,F,E] / x / x_out / noise [F,2,E] bf16; old_x0, x0_out [F,E] fp32."""
+    for n, t in (("model_out", model_out), ("x", x), ("x_out", x_out), ("noise", noise)):
+        _chk(t, n)
+        assert t.is_contiguous()
+    for n, t in (("old_x0", old_x0), ("x0_out", x0_out), ("coef", coef)):
+        _chk(t, n, torch.float32)
+        assert t.is_contiguous()
+    F_, E = x.shape[0], x[0].numel()
+    L.check(L.load().tg_cfg_dpm_step_f32(_p(model_out), _p(x), _p(old_x0), _p(noise), _p(coef), float(guidance), _p(x_out),
+                                         _p(x0_out), F_, E, _stream()), "tg_cfg_dpm_step_f32")
+    return x_out, x0_out
+
+
+def pca_inverse(lat, std, mean, comp, pmean, out):
+    """lat bf16 [F,16,h,w]; std/mean fp32 [16]; comp fp32 [16,C]; pmean fp32 [C] -> out bf16 [F,C,h,w]."""
+    _chk(lat, "lat"); _chk(out, "out")
+    for n, t in (("std", std), ("mean", mean), ("comp", comp), ("pmean", pmean)):
+        _chk(t, n, torch.float32)
+        assert t.is_contiguous()
+    assert lat.is_contiguous() and out.is_contiguous()
+    F_, nc, h, w = lat.shape
+    Cc = out.shape[1]
+    assert comp.shape == (nc, Cc) and pmean.numel() == Cc and std.numel() == nc and mean.numel() == nc and out.shape == (F_, Cc, h, w)
+    L.check(L.load().tg_pca_inverse(_p(lat), _p(std), _p(mean), _p(comp), _p(pmean), _p(out), F_, nc, h * w, Cc, _stream()), "tg_pca_inverse")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -27,9 +27,11 @@ PROTOTYPES = {
     "tg_attention_fwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _f, _vp, _l, _l,
                          _i, _i, _i, _f, _i, _vp],
     "tg_timestep_sinusoid": [_vp, _i, _i, _vp, _vp],
-    "tg_patchify": [_vp, _vp, _i, _i, _i, _i, _vp],
-    "tg_unpatchify": [_vp, _l, _vp, _i, _i, _i, _i, _vp],
+    "tg_patchify": [_vp, _vp, _l, _i, _i, _i, _i, _i, _vp],
+    "tg_unpatchify": [_vp, _l, _vp, _i, _i, _i, _i, _i, _vp],
     "tg_cfg_dpm_step": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _l, _vp],
+    "tg_cfg_dpm_step_f32": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _l, _vp],
+    "tg_pca_inverse": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "tg_conv3d_cl": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp],
     "tg_groupnorm_stats": [_vp, _l, _i, _f, _vp, _vp, _vp],
     "tg_groupnorm_silu": [_vp, _l, _i, _vp, _vp, _vp, _vp, _i, _vp],

@@ -10,6 +10,7 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
+from . import kernels as K
 from . import rope as R
 from .fifo import BF16
 
@@ -153,7 +154,7 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
         for i, t in enumerate(ts):
             k = max(0, nf - 1 - i)
             fifo_latents.insert(0, latents[:, [k]].clone())
-            fifo_old.insert(0, None if old_x0 is None else old_x0[[k]].clone()[None])
+            fifo_old.insert(0, None if old_x0 is None else old_x0[[k]].to(BF16)[None])    # the queue holds model-dtype x0
             inp = torch.cat([latents, latents], dim=0)
             tt = torch.full((2,), t, dtype=torch.int64, device=dev)
             pred = self.transformer(hidden_states=inp, encoder_hidden_states=embeds, timestep=tt, image_rotary_emb=rope_d,
@@ -162,10 +163,16 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
             prev_t = ts[i + 1] if i + 1 < len(ts) else -1
             t_back = ts[i - 1] if i > 0 else None
             nz = step_noise(i) if step_noise is not None else torch.randn((nf, 2) + tuple(latents.shape[2:]), generator=gen, device=dev,
-                                                                          dtype=torch.float32).to(BF16)
+                                                                          dtype=torch.float32)
             has = old_x0 is not None
-            x, x0 = self.scheduler.window_step(pred, latents[0].contiguous(), old_x0 if has else torch.zeros_like(latents[0]), nz.to(dev),
-                                               [t] * nf, [prev_t] * nf, [t_back] * nf, [has] * nf, guidance_scale)
+            second = has and prev_t >= 0
+            # the pipeline loop keeps the solver state in fp32 (`noise_pred.float()`, :1236-1276): f32 variant of the fused step
+            coef = self.scheduler.coef_table([t] * nf, [prev_t] * nf, [t_back] * nf, [second] * nf, dev)
+            x = torch.empty_like(latents[0])
+            x0 = torch.empty(latents.shape[1:], dtype=torch.float32, device=dev)
+            K.cfg_dpm_step_f32(pred.reshape(2, nf, -1), latents[0].reshape(nf, -1),
+                               (old_x0 if has else torch.zeros_like(x0)).reshape(nf, -1), nz.to(dev, BF16).contiguous().reshape(nf, 2, -1),
+                               coef, guidance_scale, x.view(nf, -1), x0.view(nf, -1))
             latents, old_x0 = x[None], x0
         return SimpleNamespace(
             fifo_latents=torch.cat(fifo_latents, dim=1), fifo_old_pred_original_sample=fifo_old, orig_latents=latents.clone(),

@@ -131,7 +131,7 @@ class CogVideoXTransformer3DModel(nn.Module):
         if not use_rotary_positional_embeddings:
             raise NotImplementedError("only the rotary (CogVideoX-5B) model is on the hot path; the 2B sin-cos variant is out of scope")
         if activation_fn != "gelu-approximate" or timestep_activation_fn != "silu" or not attention_bias \
-                or not norm_elementwise_affine or patch_size != 2 or not flip_sin_to_cos or freq_shift != 0 \
+                or not norm_elementwise_affine or patch_size not in (1, 2) or not flip_sin_to_cos or freq_shift != 0 \
                 or not use_output_projection or dtype != BF16:
             raise NotImplementedError("configuration differs from CogVideoX-5b in a way the fused kernels do not cover")
         self.use_vip = False
@@ -175,9 +175,10 @@ class CogVideoXTransformer3DModel(nn.Module):
     def _build_storage(self):
         c, D = self.config, self.inner_dim
         te, Lyr = c.time_embed_dim, c.num_layers
-        kin = c.in_channels * 4
-        self._alloc("patch.w", D, kin); self._alloc("patch.b", D)
-        self._bind(self.patch_embed.proj, "weight", "patch.w", slice(None), (D, c.in_channels, 2, 2))
+        ps = c.patch_size                   # 2: To2V / base model; 1: the T2To token model (train_cogvideo_t2to.py:1277)
+        kin = c.in_channels * ps * ps
+        self._alloc("patch.w", D, _pad_to(kin, 64)); self._alloc("patch.b", D)       # K padded to the GEMM granule (zeros)
+        self._bind(self.patch_embed.proj, "weight", "patch.w", (slice(None), slice(0, kin)), (D, c.in_channels, ps, ps))
         self._bind(self.patch_embed.proj, "bias", "patch.b", slice(None))
         self._alloc("text.w", D, c.text_embed_dim); self._alloc("text.b", D)
         self._bind(self.patch_embed.text_proj, "weight", "text.w", slice(None))
@@ -206,7 +207,7 @@ class CogVideoXTransformer3DModel(nn.Module):
         self._alloc("final.ln", 4, D)          # norm_final.w/b, norm_out.norm.w/b
         self._bind(self.norm_final, "weight", "final.ln", 0); self._bind(self.norm_final, "bias", "final.ln", 1)
         self._bind(self.norm_out.norm, "weight", "final.ln", 2); self._bind(self.norm_out.norm, "bias", "final.ln", 3)
-        npo = 4 * c.out_channels
+        npo = ps * ps * c.out_channels
         self._alloc("proj_out.w", _pad_to(npo, 128), D); self._alloc("proj_out.b", _pad_to(npo, 128))   # N padded to the GEMM tile
         self._bind(self.proj_out, "weight", "proj_out.w", slice(0, npo)); self._bind(self.proj_out, "bias", "proj_out.b", slice(0, npo))
         self._build_mod_storage()
@@ -357,7 +358,7 @@ class CogVideoXTransformer3DModel(nn.Module):
         ws.sin = e(B * Fm, D)
         ws.t1 = e(B * Fm, self.config.time_embed_dim)
         ws.semb = e(B * Fm, self.config.time_embed_dim)
-        ws.patches = e(B, Nv, self.config.in_channels * 4)
+        ws.patches = torch.zeros(B, Nv, self._fused["patch.w"].shape[1], dtype=BF16, device=dev)   # pad columns stay zero
         ws.po = e(B, Nv, self._fused["proj_out.w"].shape[0])
         hw = Nv // Fm if Fm > 1 else Nv
         tg = torch.empty(N, dtype=torch.uint8)
@@ -442,11 +443,13 @@ class CogVideoXTransformer3DModel(nn.Module):
         latents [b, f, C, h, w] -> patch tokens [b, f, (h/2)(w/2), D], as one patch gather + GEMM (embeddings.py:516-523)."""
         b, f, C, h, w = latents.shape
         F = self._fused
-        cols = torch.empty(b * f * (h // 2) * (w // 2), C * 4, dtype=BF16, device=self._device)
-        K.patchify(latents.to(self._device, BF16).reshape(b * f, C, h, w).contiguous(), cols)
-        out = torch.empty(cols.shape[0], self.inner_dim, dtype=BF16, device=self._device)
+        ps = self.config.patch_size
+        ntok = b * f * (h // ps) * (w // ps)
+        cols = torch.zeros(ntok, F["patch.w"].shape[1], dtype=BF16, device=self._device)
+        K.patchify(latents.to(self._device, BF16).reshape(b * f, C, h, w).contiguous(), cols, ps)
+        out = torch.empty(ntok, self.inner_dim, dtype=BF16, device=self._device)
         K.gemm(cols, F["patch.w"], F["patch.b"], out, L.EPI_BIAS)
-        return out.view(b, f, (h // 2) * (w // 2), self.inner_dim)
+        return out.view(b, f, (h // ps) * (w // ps), self.inner_dim)
 
     # ------------------------------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -463,7 +466,8 @@ class CogVideoXTransformer3DModel(nn.Module):
         c, D, H = self.config, self.inner_dim, self.config.num_attention_heads
         F = self._fused
         B, Fr, C, Hh, Ww = hidden_states.shape
-        hw = (Hh // 2) * (Ww // 2)
+        ps = c.patch_size
+        hw = (Hh // ps) * (Ww // ps)
         Nt, Nv = encoder_hidden_states.shape[1], Fr * hw
         use_vip = self.use_vip
         if use_vip:
@@ -494,7 +498,7 @@ class CogVideoXTransformer3DModel(nn.Module):
 
         # 2. patch / text / vip embeddings straight into the residual stream X = text | video | vip
         X = ws.X
-        K.patchify(hidden_states.to(BF16).reshape(B * Fr, C, Hh, Ww).contiguous(), ws.patches.view(B * Nv, -1))
+        K.patchify(hidden_states.to(BF16).reshape(B * Fr, C, Hh, Ww).contiguous(), ws.patches.view(B * Nv, -1), ps)
         K.gemm(ws.patches, F["patch.w"], F["patch.b"], X[:, Nt:N1], L.EPI_BIAS)
         K.gemm(encoder_hidden_states.to(BF16).contiguous(), F["text.w"], F["text.b"], X[:, :Nt], L.EPI_BIAS)
         if use_vip:
@@ -516,7 +520,7 @@ class CogVideoXTransformer3DModel(nn.Module):
         K.adaln_modulate(vidn, vid2, fl[2], fl[3], c.norm_eps, tout)
         K.gemm(vid2, F["proj_out.w"], F["proj_out.b"], ws.po, L.EPI_BIAS)
         out = torch.empty(B, Fr, c.out_channels, Hh, Ww, dtype=BF16, device=self._device)
-        K.unpatchify(ws.po.view(B * Nv, -1), out.view(B * Fr, c.out_channels, Hh, Ww))
+        K.unpatchify(ws.po.view(B * Nv, -1), out.view(B * Fr, c.out_channels, Hh, Ww), ps)
         if not return_dict:
             return (out,)
         return Transformer2DModelOutput(sample=out)

@@ -352,13 +352,94 @@ def gen_resampler():
     print("resampler_tiny.pt", tuple(out["fp32"].shape))
 
 
+
+@torch.no_grad()
+def gen_t2to():
+    """Run the reference LongVGenCogVideoXPipeline.__call__ (pipeline_cogvideox_t2to.py:566-912) on CPU with a tiny plain
+    patch-1 DiT: 6 DPM steps, dynamic CFG, CPU generator (initial latents + every SDE draw), real PCA fitted with the
+    reference's pca.PCA on seeded data.  Stored: inputs, the initial latents, every gaussian in draw order, the sampled
+    latents before the tail, the final condensed tokens, and the 16 PCA rows / mean the tail actually uses."""
+    import contextlib
+    import tempfile
+    ref = load_ref_module("longvgen/pipeline/pipeline_cogvideox_t2to.py", "ref_t2to")
+    refpca = load_ref_module("pca.py", "pca")
+    sys.modules["pca"] = refpca                       # the pipeline torch.load()s a pickled pca.PCA
+    torch.serialization.add_safe_globals([refpca.PCA])   # torch >= 2.6 defaults weights_only=True; the reference predates it
+    cfg = dict(TINY, patch_size=1)
+    H, W, nfc, chunks, steps = 2, 3, 4, 3, 6
+
+    class Pipe(ref.LongVGenCogVideoXPipeline):
+        def __init__(self, transformer, scheduler):      # skip DiffusionPipeline.register_modules / T5 / VAE
+            self.transformer, self.scheduler = transformer, scheduler
+        _execution_device = property(lambda self: torch.device("cpu"))
+
+        @contextlib.contextmanager
+        def progress_bar(self, total=None):
+            yield types.SimpleNamespace(update=lambda *a: None)
+
+        def maybe_free_model_hooks(self):
+            pass
+
+    results = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = CogVideoXTransformer3DModel(num_attention_heads=2, attention_head_dim=64, num_layers=2, in_channels=16, out_channels=16,
+                                        text_embed_dim=TINY["text_embed_dim"], time_embed_dim=TINY["time_embed_dim"], sample_width=W,
+                                        sample_height=H, sample_frames=49, use_rotary_positional_embeddings=True, max_text_seq_length=8,
+                                        patch_size=1, use_output_projection=True)
+        sd = O.make_state_dict(cfg, seed=800)
+        m.load_state_dict(sd, strict=True)
+        m = m.eval().to(dt)
+        sched = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0,
+                                      timestep_spacing="trailing")
+        g = torch.Generator().manual_seed(801)
+        prompt = torch.randn(1, 8, TINY["text_embed_dim"], generator=g).to(dt)
+        negative = torch.randn(1, 8, TINY["text_embed_dim"], generator=g).to(dt)
+        mean = torch.randn(1, 32, generator=g) * 0.5
+        std = torch.rand(1, 32, generator=g) + 0.5
+        pca = refpca.PCA(n_components=None).fit(torch.randn(3200, 3072, generator=g) * torch.linspace(2.0, 0.1, 3072))
+        draws = []
+        real_randn = ref.randn_tensor
+
+        def spy(shape, generator=None, device=None, dtype=None, layout=None):
+            t = real_randn(shape, generator=generator, device=device, dtype=dtype)
+            draws.append(t.clone())
+            return t
+        ref.randn_tensor = spy
+        sched_mod = sys.modules[CogVideoXDPMScheduler.__module__]
+        sched_randn = sched_mod.randn_tensor
+        sched_mod.randn_tensor = spy
+        taps = {}
+        pipe = Pipe(m, sched)
+        with tempfile.TemporaryDirectory() as td:
+            torch.save(mean, os.path.join(td, "mean.pt")); torch.save(std, os.path.join(td, "std.pt")); torch.save(pca, os.path.join(td, "pca.pt"))
+            # the tail overwrites `latents`; keep the sampled ones through the (reference-supported) step-end callback
+            def cb(pp, i, t, kw):
+                taps["latents"] = kw["latents"].clone()
+                return {}
+            out = pipe(prompt_embeds=prompt, negative_prompt_embeds=negative, height=H, width=W, num_frames_per_chunk=nfc,
+                       num_chunks=chunks, num_inference_steps=steps, use_dynamic_cfg=True, guidance_scale=6.0,
+                       generator=torch.Generator().manual_seed(802), longvgen_mean=os.path.join(td, "mean.pt"),
+                       longvgen_std=os.path.join(td, "std.pt"), longvgen_pca=os.path.join(td, "pca.pt"),
+                       callback_on_step_end=cb, callback_on_step_end_tensor_inputs=["latents"]).frames
+        ref.randn_tensor = real_randn
+        sched_mod.randn_tensor = sched_randn
+        results[str(dt)] = dict(prompt=prompt, negative=negative, init_latents=draws[0], step_draws=draws[1:], sampled=taps["latents"],
+                                frames=out.clone(), timesteps=sched.timesteps.clone())
+        if dt == torch.float32:
+            common = dict(mean=mean, std=std, pca_mean=pca.mean_.clone(), pca_components16=pca.components_[:16].clone(),
+                          sd_checksum=sd_checksum(sd))
+    torch.save(dict(cfg=cfg, weight_seed=800, input_seed=801, gen_seed=802, H=H, W=W, nfc=nfc, chunks=chunks, steps=steps,
+                    guidance_scale=6.0, **common, cases=results), os.path.join(GOLD, "t2to_tiny.pt"))
+    print("t2to_tiny.pt", tuple(results[str(torch.float32)]["frames"].shape), len(results[str(torch.float32)]["step_draws"]), "draws")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full-block", action="store_true")
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    jobs = dict(dit=gen_dit_tiny, vip=gen_vip_processor, sched=gen_scheduler, fifo=gen_fifo, vae=gen_vae, resampler=gen_resampler)
+    jobs = dict(dit=gen_dit_tiny, vip=gen_vip_processor, sched=gen_scheduler, fifo=gen_fifo, vae=gen_vae, resampler=gen_resampler, t2to=gen_t2to)
     if a.only:
         jobs = {a.only: jobs.get(a.only, gen_full_block)}
     for k, fn in jobs.items():

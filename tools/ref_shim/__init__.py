@@ -266,6 +266,7 @@ _EXPLICIT = {
     "deprecate": lambda *a, **k: None, "is_torch_npu_available": lambda: False,
     "is_xformers_available": lambda: False, "check_min_version": lambda *a, **k: None,
     "__version__": "0.0.28",
+    "replace_example_docstring": lambda doc: (lambda fn: fn),          # decorator factory on the pipelines' __call__
 }
 
 
