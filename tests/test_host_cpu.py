@@ -208,3 +208,19 @@ def test_pca_holder_matches_reference_fit_and_unpickles_under_the_reference_modu
     finally:
         for k in [k for k in sys.modules if k == "longvgen" or k.startswith("longvgen.") or k == "pca"]:
             del sys.modules[k]
+
+
+def test_scheduler_from_config_like_the_entry_script(tmp_path):
+    """infer_cogvideo_mp_fifo.py:129,232 — from_config(existing.config, timestep_spacing="trailing"), also from a json file."""
+    import json
+    from tokensgen_amd.scheduler import CogVideoXDPMScheduler
+    a = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0)
+    b = CogVideoXDPMScheduler.from_config(a.config, timestep_spacing="trailing")
+    assert b.config.timestep_spacing == "trailing" and b.config.snr_shift_scale == 1.0 and torch.equal(a.alphas_cumprod, b.alphas_cumprod)
+    b.set_timesteps(52)
+    assert b.timesteps[0] == 999 and len(b.timesteps) == 52
+    f = tmp_path / "scheduler_config.json"
+    f.write_text(json.dumps(dict(_class_name="CogVideoXDPMScheduler", _diffusers_version="0.31.0", prediction_type="v_prediction",
+                                 rescale_betas_zero_snr=True, snr_shift_scale=3.0, beta_schedule="scaled_linear")))
+    c = CogVideoXDPMScheduler.from_config(str(f), timestep_spacing="trailing")
+    assert c.config.snr_shift_scale == 3.0 and c.alphas_cumprod[-1] == 0.0
