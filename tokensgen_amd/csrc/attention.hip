@@ -296,8 +296,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 //   Helped: fragment-granular ds_read pipelining in X, -m seeding through the matrix pipe, two v_max3 chains +
 //   v_permlane32_swap, four row-sum chains (8.63 -> 7.8 ms).  Did not help: plain v_add_f32 row sums; s_setprio 1 for the
 //   second-dispatched half; exponentiating the last 1 or 2 k-steps of P(t) inside X(t+1) as MFMA fillers (9.1 / 11.4 ms:
-//   VALU between the MFMAs of the matrix segment costs more than it frees in the vector segment).
+//   VALU between the MFMAs of the matrix segment costs more than it frees in the vector segment); rescale triggered by the
+//   tile's row SUM instead of a row max (30 fewer VALU per tile, yet 8.3 vs 7.9 ms); ONE barrier per tile with 3-deep K/V rings
+//   (group 0: X|B|Y, group 1: B|X|Y — nobody waits for the partner's longer segment): 8.54 vs 8.12 ms, the per-wave X+Y issue
+//   time (~3600 cycles per tile) did not change, only where the waiting happens; fragment prefetch depth 2/3/4: 7.95/7.89/7.92.
 // ------------------------------------------------------------------------------------------------
+#ifndef TG_ATTN_NFR
+#define TG_ATTN_NFR 3
+#endif
 __device__ long long tg_attn_dbg[16];   // TG_ATTN_TIMING: cycles {X work, X barrier wait, Y work, Y barrier wait} of block 0, waves 0 and 4
 
 template <bool PRESCALED, bool TIMING = false>
@@ -432,16 +438,17 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         auto xseg = [&](int t) {
             const char* tV = smem + (2 + ((t - 1) & 1)) * TILE_B;
             const char* tK = smem + (t & 1) * TILE_B;
-            // fragment i = 2g + xb (g: k-step group, xb: 32-row block of V^T / K); two 4-register buffers, fragment i+2 is
-            // fetched into the buffer fragment i just left, so every ds_read_b128 has two MFMAs (64 cycles) of cover
-            bf16x8 fr[2];
+            // fragment i = 2g + xb (g: k-step group, xb: 32-row block of V^T / K); NFR 4-register buffers, fragment i+NFR is
+            // fetched into the buffer fragment i just left, so every ds_read_b128 has NFR-1 MFMA pairs (64 cycles each) of cover
+            constexpr int NFR = TG_ATTN_NFR;
+            bf16x8 fr[NFR];
             auto ld = [&](int i) {
                 const int g = i >> 1, xb = i & 1;
-                if (g < 4) fr[i & 1] = *(const bf16x8*)(tV + ((offV0 + xb * 4096) ^ (g << 5)));
-                else fr[i & 1] = *(const bf16x8*)(tK + ((offK0 + xb * 4096) ^ ((g - 4) << 5)));
+                if (g < 4) fr[i % NFR] = *(const bf16x8*)(tV + ((offV0 + xb * 4096) ^ (g << 5)));
+                else fr[i % NFR] = *(const bf16x8*)(tK + ((offK0 + xb * 4096) ^ ((g - 4) << 5)));
             };
-            ld(0);
-            ld(1);
+#pragma unroll
+            for (int i = 0; i < NFR; ++i) ld(i);
             if (PRESCALED) {
                 // seed S with -m through the matrix pipe: ones[key][k=0] x negm[k=0][query] = -m[query] in every register of
                 // the lane's row, 4 MFMAs that run under the first fragments' ds_read latency (no 64 v_mov per tile)
@@ -465,11 +472,11 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
-                    if (g < 4) acc_o[qb][xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1], pf[qb][g], acc_o[qb][xb], 0, 0, 0);
-                    else sc[qb][xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1], qf[qb][g - 4], sc[qb][xb], 0, 0, 0);
+                    if (g < 4) acc_o[qb][xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % NFR], pf[qb][g], acc_o[qb][xb], 0, 0, 0);
+                    else sc[qb][xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % NFR], qf[qb][g - 4], sc[qb][xb], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (i + 2 < 16) ld(i + 2);
+                if (i + NFR < 16) ld(i + NFR);
             }
             __builtin_amdgcn_sched_barrier(0);
             if ((t + 1) * KVBLK > S.nk) {
