@@ -142,3 +142,52 @@ def test_t2to_argument_errors(golden_dir):
              longvgen_std=g["std"], longvgen_pca=object())
     with pytest.raises(ValueError, match="prompt_embeds"):
         pipe(longvgen_mean=g["mean"], longvgen_std=g["std"], longvgen_pca=object())
+
+
+@pytest.mark.timeout(900)
+def test_gen_flow_t2to_into_to2v_end_to_end(golden_dir):
+    """gen.yaml's flow on tiny models (infer_cogvideo_mp_fifo.py:262-330): T2To tokens [1, 4*chunks, C, h, w] -> To2V base stage
+    (which pads one chunk of tokens and repeats them for CFG, pipeline_cogvideox_mp_fifo.py:611-646) -> FIFO driver.  Checks that the
+    stages compose through the reference's own hand-over tensors, shapes/finite, and that the run is reproducible."""
+    from tokensgen_amd import fifo
+    from tokensgen_amd.pca import PCA
+    from tokensgen_amd.pipeline import MPFIFOVideoIPAdapterCogVideoXPipeline
+    from tokensgen_amd.pipeline_t2to import LongVGenCogVideoXPipeline
+    from tokensgen_amd.scheduler import CogVideoXDPMScheduler
+    from tokensgen_amd.transformer import CogVideoXTransformer3DModel
+    g = _gold(golden_dir)
+    gt = torch.load(os.path.join(golden_dir, "dit_tiny.pt"), weights_only=False)
+    cfg, vipcfg = gt["cfg"], gt["vip"]
+    chunks, H, W = 2, 4, 6                                      # To2V latent 4x6 -> token grid 2x3, vip tokens 4 x 2 x 3 per chunk
+
+    def sched():
+        return CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
+
+    def run():
+        m1, _ = _model(g)
+        pca = PCA()
+        gen = torch.Generator().manual_seed(31)
+        q, _ = torch.linalg.qr(torch.randn(128, 16, generator=gen))
+        pca.register_buffer("mean_", torch.randn(1, 128, generator=gen) * 0.1); pca.register_buffer("components_", q.t().contiguous())
+        c = g["cases"]["torch.bfloat16"]
+        tokens = LongVGenCogVideoXPipeline(m1, sched())(
+            prompt_embeds=c["prompt"], negative_prompt_embeds=c["negative"], height=2, width=3, num_frames_per_chunk=4, num_chunks=chunks,
+            num_inference_steps=4, use_dynamic_cfg=True, guidance_scale=6.0, generator=torch.Generator().manual_seed(32),
+            longvgen_mean=g["mean"], longvgen_std=g["std"], longvgen_pca=pca).frames
+        assert tokens.shape == (1, 4 * chunks, 128, 2, 3)
+        m2 = CogVideoXTransformer3DModel(num_attention_heads=2, attention_head_dim=64, num_layers=2, time_embed_dim=cfg["time_embed_dim"],
+                                         text_embed_dim=cfg["text_embed_dim"], use_rotary_positional_embeddings=True, device=DEV)
+        m2.set_vip_layers(None, **vipcfg)
+        m2.load_state_dict({k: v.to(BF) for k, v in O.make_state_dict(cfg, 128, seed=400).items()}, strict=True)
+        pipe = MPFIFOVideoIPAdapterCogVideoXPipeline(m2, sched(), resampler_config=dict(num_temporal_queries=4, num_height_queries=2, num_width_queries=3))
+        base = pipe(prompt_embeds=c["prompt"], negative_prompt_embeds=c["negative"], image_embeddings=tokens, height=H * 8, width=W * 8,
+                    num_chunks=chunks, generator=torch.Generator(device=DEV).manual_seed(33))
+        assert base.image_embeddings.shape == (2, 4 * (chunks + 1), 128, 2, 3)
+        assert torch.equal(base.image_embeddings[0], base.image_embeddings[1]) and torch.equal(base.image_embeddings[0, -4:], tokens[0, -1:].expand(4, -1, -1, -1).to(DEV))
+        video = fifo.cogvideo_fifo_mp_v2([pipe], base, noise_seed=7)[1]
+        assert video.shape == (1, chunks * 13, 16, H, W) and torch.isfinite(video).all()
+        return tokens.cpu(), video.cpu()
+
+    t1, v1 = run()
+    t2, v2 = run()
+    assert torch.equal(t1, t2) and torch.equal(v1, v2)

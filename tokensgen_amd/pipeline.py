@@ -146,6 +146,16 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
             vr = R.rope_3d(64, gt[:nf], gh, gw, device=dev)
             cr = R.rope_3d(64, ct[:n_c], ch, cw, device=dev)
             image_embeddings = image_embeddings.to(dev, BF16)
+            if image_embeddings.shape[0] == 1:
+                # tokens straight from the T2To stage / vae_encode_image(do_classifier_free_guidance=False), as gen.yaml passes
+                # them (infer:262-300): pad one chunk's worth of tokens with the last group and repeat for the two CFG halves
+                # (pipeline_cogvideox_mp_fifo.py:611-646; the zero-video "uncond" tokens are computed there but not used)
+                per_chunk = image_embeddings.shape[1] // num_chunks
+                image_embeddings = torch.cat([image_embeddings] + [image_embeddings[:, [-1]]] * per_chunk, dim=1)
+                image_embeddings = torch.cat([image_embeddings, image_embeddings], dim=0)
+            if image_embeddings.shape[0] != 2 or image_embeddings.shape[1] < n_c:
+                raise ValueError(f"image_embeddings must be [1, 4*num_chunks, C, h, w] (reference input) or the prepared [2, 4*(num_chunks+1), "
+                                 f"C, h, w]; got {tuple(image_embeddings.shape)}")
             emb0 = image_embeddings[:, :n_c].contiguous()
         rope_d = tuple(t.to(dev) for t in rope)
         gen = generator if generator is not None else torch.Generator(device=dev).manual_seed(0)
