@@ -1,5 +1,6 @@
 """GPU: each HIP kernel (called through the C ABI) against a plain fp32 torch restatement / the oracle."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -253,3 +254,18 @@ def test_cfg_dpm_step_matches_oracle(K):
         prev, x0 = S.dpm_step(ac, v, old[f].cpu().float() if ho else None, t, p, tb, x[f].cpu().float(), lambda: next(it))
         assert (x0o[f].cpu().float() - x0).abs().max().item() <= 2e-2 * x0.abs().max().item() + 1e-3, (t, p)
         assert (xo[f].cpu().float() - prev).abs().max().item() <= 2e-2 * prev.abs().max().item() + 1e-3, (t, p)
+
+
+def test_attention_cases_again_on_the_pingpong_kernel():
+    """tg_attention_fwd picks the 8-wave ping-pong kernel only for long query ranges (>= 1024 workgroups of 512 rows); the cases above
+    are too small for it.  TG_ATTN_PP_MIN_WG is read once per process, so re-run them in a child process with the threshold at 1:
+    every shape (ragged tiles, nq not a multiple of 512, second segment, prescaled keys) then goes through attn_fwd_pp_kernel."""
+    import subprocess
+    import sys
+    if os.environ.get("TG_ATTN_PP_MIN_WG") == "1":
+        pytest.skip("already inside the forced run")
+    env = dict(os.environ, TG_ATTN_PP_MIN_WG="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "attention and not pingpong", "-x"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
