@@ -68,7 +68,14 @@ def _oracle_run(d):
     return out, trace
 
 
-def _product_run(d, trace=None):
+def _fake_decode(z):
+    """Stand-in for vae.decode on one chunk (the sharding logic is what the CPU test checks): [1,nf,C,h,w] -> [1,3,4(nf-1)+1,2h,2w]."""
+    x = z.float().permute(0, 2, 1, 3, 4)[:, :3]
+    x = torch.nn.functional.interpolate(x, size=(4 * (z.shape[1] - 1) + 1, 2 * z.shape[3], 2 * z.shape[4]), mode="nearest")
+    return (x * 0.5 + z.float().mean()).to(BF)
+
+
+def _product_run(d, trace=None, output_type="latent"):
     from tokensgen_amd import fifo
     from tokensgen_amd.scheduler import CogVideoXDPMScheduler
     sched = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
@@ -82,7 +89,7 @@ def _product_run(d, trace=None):
                          use_separate_guidance=False, use_dynamic_cfg=False, prompt_embeds=None, image_rotary_emb=None,
                          vip_image_rotary_grid=[d["grid_t"].copy(), np.arange(1, dtype=f32), np.arange(1, dtype=f32)],
                          vip_condition_rotary_grid=[d["cond_t"].copy(), np.arange(1, dtype=f32), np.arange(1, dtype=f32)],
-                         guidance_scale=6.0, cache_idx=[], video_ipadapter_start_frame_idx=1000, output_type="latent", return_dict=False,
+                         guidance_scale=6.0, cache_idx=[], video_ipadapter_start_frame_idx=1000, output_type=output_type, return_dict=False,
                          orig_latents=d["fifo_latents"][:, :NF])
 
     def window_fn(latents, old_x0, has_old, t, prev_t, next_t, noise, grid_t, cond_grid_t, image_embeddings):
@@ -101,8 +108,9 @@ def _product_run(d, trace=None):
             o_x0[j] = x0.to(BF)[0, 0]
         return o_lat, o_x0
 
-    return fifo.cogvideo_fifo_mp_v2([pipe], bo, step_noise_fn=_noise, tail_noise_fn=lambda i, shape: _noise(i, 97, shape),
-                                    window_fn=window_fn, trace=trace)[1]
+    res = fifo.cogvideo_fifo_mp_v2([pipe], bo, step_noise_fn=_noise, tail_noise_fn=lambda i, shape: _noise(i, 97, shape),
+                                   window_fn=window_fn, trace=trace, decode_chunk_fn=_fake_decode)
+    return res[1] if output_type == "latent" else torch.cat([res[0], res[1]], dim=2)
 
 
 def test_driver_single_process_matches_oracle():
@@ -123,7 +131,8 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         out = _product_run(_inputs())
-        q.put((rank, out.float()))
+        dec = _product_run(_inputs(2), output_type="pt")
+        q.put((rank, out.float(), dec.float()))
     finally:
         dist.destroy_process_group()
 
@@ -138,10 +147,13 @@ def test_driver_two_ranks_gloo_matches_single():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=240) for _ in range(2))
+    ref_dec = _product_run(_inputs(2), output_type="pt")      # 2 chunks: one per rank in the sharded decode, + the 1-chunk orig video
+    assert ref_dec.shape == (1, 3, 3 * 49, 2 * H, 2 * W)
+    got = {r: (o, dcd) for r, o, dcd in (q.get(timeout=280) for _ in range(2))}
     for p in procs:
         p.join(timeout=60)
-    assert torch.equal(got[0], ref.float()) and torch.equal(got[1], ref.float())
+    assert torch.equal(got[0][0], ref.float()) and torch.equal(got[1][0], ref.float())
+    assert torch.equal(got[0][1], ref_dec.float()) and torch.equal(got[1][1], ref_dec.float())
 
 
 def test_unsupported_modes_raise():

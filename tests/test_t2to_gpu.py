@@ -191,3 +191,37 @@ def test_gen_flow_t2to_into_to2v_end_to_end(golden_dir):
     t1, v1 = run()
     t2, v2 = run()
     assert torch.equal(t1, t2) and torch.equal(v1, v2)
+
+
+def test_cfg_parallel_halves_equal_the_batched_forward_bitwise(golden_dir):
+    """cfg_parallel="emulate" runs the unconditional and the conditional forward as two batch-1 calls (what ranks 0 and 1 do under
+    torch.distributed) — per-sample kernels do not depend on the batch, so the stage output must be bitwise the batched one."""
+    from tokensgen_amd.pca import PCA
+    from tokensgen_amd.pipeline import MPFIFOVideoIPAdapterCogVideoXPipeline
+    from tokensgen_amd.pipeline_t2to import LongVGenCogVideoXPipeline
+    from tokensgen_amd.scheduler import CogVideoXDPMScheduler
+    from tokensgen_amd.transformer import CogVideoXTransformer3DModel
+    g = _gold(golden_dir)
+    c = g["cases"]["torch.bfloat16"]
+    sch = lambda: CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
+    m, _ = _model(g)
+    pca = PCA()
+    pca.register_buffer("mean_", g["pca_mean"]); pca.register_buffer("components_", g["pca_components16"])
+    kw = dict(prompt_embeds=c["prompt"], negative_prompt_embeds=c["negative"], height=g["H"], width=g["W"], num_frames_per_chunk=g["nfc"],
+              num_chunks=g["chunks"], num_inference_steps=4, use_dynamic_cfg=True, guidance_scale=6.0, longvgen_mean=g["mean"],
+              longvgen_std=g["std"], longvgen_pca=pca)
+    a = LongVGenCogVideoXPipeline(m, sch())(generator=torch.Generator().manual_seed(5), cfg_parallel=False, **kw).frames
+    b = LongVGenCogVideoXPipeline(m, sch())(generator=torch.Generator().manual_seed(5), cfg_parallel="emulate", **kw).frames
+    assert torch.equal(a, b)
+    gt = torch.load(os.path.join(golden_dir, "dit_tiny.pt"), weights_only=False)
+    cfg, vipcfg = gt["cfg"], gt["vip"]
+    m2 = CogVideoXTransformer3DModel(num_attention_heads=2, attention_head_dim=64, num_layers=2, time_embed_dim=cfg["time_embed_dim"],
+                                     text_embed_dim=cfg["text_embed_dim"], use_rotary_positional_embeddings=True, device=DEV)
+    m2.set_vip_layers(None, **vipcfg)
+    m2.load_state_dict({k: v.to(BF) for k, v in O.make_state_dict(cfg, 128, seed=400).items()}, strict=True)
+    pipe = MPFIFOVideoIPAdapterCogVideoXPipeline(m2, sch(), resampler_config=dict(num_temporal_queries=4, num_height_queries=2, num_width_queries=3))
+    emb = torch.randn(1, 4, 128, 2, 3, generator=torch.Generator().manual_seed(6)).to(BF)
+    outs = [pipe(prompt_embeds=c["prompt"], negative_prompt_embeds=c["negative"], image_embeddings=emb, height=32, width=48, num_inference_steps=6,
+                 generator=torch.Generator(device=DEV).manual_seed(8), latents=torch.randn(1, 13, 16, 4, 6, generator=torch.Generator().manual_seed(9)).to(BF),
+                 cfg_parallel=mode) for mode in (False, "emulate")]
+    assert torch.equal(outs[0].fifo_latents, outs[1].fifo_latents) and torch.equal(outs[0].orig_latents, outs[1].orig_latents)

@@ -1,0 +1,45 @@
+"""Classifier-free-guidance parallelism for the stages the reference runs on ONE GPU while the others idle (the 52-step
+base stage on GPU 0, infer_cogvideo_mp_fifo.py:300, and the T2To stage, :262): the unconditional and the conditional forward of a
+step are independent, so with >= 2 ranks rank r runs half r % 2 (batch 1) and ONE all_gather per step (2.8 MB at the To2V shape)
+gives every rank both halves; every rank then applies the identical fused CFG + solver step with identically seeded noise, so all
+ranks leave the stage holding the same state — which the FIFO stage needs anyway (the reference pickles it to its workers)."""
+import torch
+
+
+def world_and_rank():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def resolve(mode):
+    """mode: None/"auto" (parallel iff >= 2 ranks), False (batched forward on every rank), True (require >= 2 ranks),
+    "emulate" (one process runs both batch-1 halves in turn: the numerics of the parallel path without a second GPU)."""
+    world, _ = world_and_rank()
+    if mode in (None, "auto"):
+        return "parallel" if world >= 2 else "batched"
+    if mode is False:
+        return "batched"
+    if mode == "emulate":
+        return "emulate"
+    if mode is True:
+        if world < 2:
+            raise RuntimeError("cfg_parallel=True needs torch.distributed with at least 2 ranks")
+        return "parallel"
+    raise ValueError(f"cfg_parallel={mode!r}")
+
+
+def predict(mode, forward_half, forward_both):
+    """forward_half(h) -> prediction [1, ...] of CFG half h (0 = unconditional, 1 = conditional); forward_both() -> [2, ...].
+    Returns the [2, ...] prediction tensor on every rank."""
+    if mode == "batched":
+        return forward_both()
+    if mode == "emulate":
+        return torch.cat([forward_half(0), forward_half(1)], dim=0)
+    import torch.distributed as dist
+    world, me = world_and_rank()
+    mine = forward_half(me % 2).contiguous()
+    allp = torch.empty((world,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(allp, mine)
+    return allp[:2].contiguous()          # rank 0 holds half 0, rank 1 holds half 1

@@ -119,15 +119,43 @@ class _SeededNoise:
 
 
 @torch.no_grad()
+def decode_chunks_sharded(pipe, latents, nf, decode_chunk_fn=None):
+    """VAE decode of a [1, chunks*nf, C, h, w] latent video, one `vae.decode` per nf-frame chunk like the reference's
+    `decode_latents` (pipeline_cogvideox_mp_fifo.py:676-684) — but the chunks, which are independent, are dealt round-robin to the
+    ranks and ONE all_gather brings every chunk's frames to every rank (the reference decodes the whole video on GPU 0 while the
+    others idle, cogvideo_sampling_mp_fifo.py:373-376).  decode_chunk_fn(z [1,nf,C,h,w]) -> frames [1,3,F,H,W]; default: the
+    pipeline's own decode_latents."""
+    import torch.distributed as dist
+    fn = decode_chunk_fn or (lambda z: pipe.decode_latents(z, nf_per_chunk=nf))
+    chunks = latents.shape[1] // nf
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    me = dist.get_rank() if world > 1 else 0
+    mine = [c for c in range(chunks) if c % world == me]
+    dec = [fn(latents[:, c * nf:(c + 1) * nf].contiguous()) for c in mine]
+    if world == 1:
+        return torch.cat(dec, dim=2)
+    meta = [None] * world
+    dist.all_gather_object(meta, (tuple(dec[0].shape), dec[0].dtype) if dec else None)      # a rank may hold no chunk
+    shape, dtype = next(m for m in meta if m is not None)
+    per = (chunks + world - 1) // world
+    buf = torch.zeros((per,) + shape, dtype=dtype, device=latents.device)
+    for slot, d in enumerate(dec):
+        buf[slot] = d
+    allbuf = torch.empty((world * per,) + shape, dtype=dtype, device=latents.device)       # rank-major concat
+    dist.all_gather_into_tensor(allbuf, buf)
+    return torch.cat([allbuf[(c % world) * per + c // world] for c in range(chunks)], dim=2)
+
+
 def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None, tail_noise_fn=None, trace=None,
-                        window_fn=None, **kwargs):
+                        window_fn=None, decode_chunk_fn=None, **kwargs):
     """Mirror of cogvideo_sampling_mp_fifo.py:27-395.
 
     `pipe_list` holds this process's pipeline(s); with torch.distributed initialised (one process per GPU) the
     windows of every iteration are split rank-round-robin and the results all_gathered; the queue, the index
     bookkeeping and the tail noise are replicated.  Returns (orig_video, video, cache_video) like the reference
     (latents when output_type == "latent").  `window_fn(worker, **window_inputs)` lets tests substitute the
-    denoiser (CPU/gloo tests of the exchange logic); the default is FifoWorker.window_step (HIP)."""
+    denoiser (CPU/gloo tests of the exchange logic); the default is FifoWorker.window_step (HIP).  With an output_type other
+    than "latent" the final VAE decode is sharded by chunk over the ranks (decode_chunks_sharded)."""
     import torch.distributed as dist
     bo = base_output
     sp = bo.sampling_params
@@ -232,8 +260,8 @@ def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None
     if getattr(bo, "output_type", "latent") == "latent":
         result = (bo.orig_latents, video_latents, [])
     else:
-        video = pipe.decode_latents(video_latents)
-        orig = pipe.decode_latents(bo.orig_latents)
+        video = decode_chunks_sharded(pipe, video_latents, nf, decode_chunk_fn)           # chunk-sharded over the ranks
+        orig = decode_chunks_sharded(pipe, bo.orig_latents, nf, decode_chunk_fn)
         vp = getattr(pipe, "video_processor", None)
         if vp is not None:
             video = vp.postprocess_video(video=video, output_type=bo.output_type)

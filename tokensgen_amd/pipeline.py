@@ -10,6 +10,7 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
+from . import cfg_parallel as CP
 from . import kernels as K
 from . import rope as R
 from .fifo import BF16
@@ -108,10 +109,11 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
     def __call__(self, prompt=None, frames=None, prompt_embeds=None, negative_prompt_embeds=None, image_embeddings=None,
                  height=480, width=720, num_frames_per_chunk=49, num_chunks=1, num_inference_steps=52, guidance_scale=6.0,
                  video_ipadapter_scale=None, video_ipadapter_start_frame_idx=1000, latents=None, generator=None, step_noise=None,
-                 sampling_params=None, output_type="latent", return_dict=False, **unused):
+                 sampling_params=None, output_type="latent", return_dict=False, cfg_parallel=None, **unused):
         """Base stage (:837-1344): `num_inference_steps` scalar-timestep CFG steps on chunk 0, harvesting
         `latents[:, max(0, 12-i)]` (and the matching x0) into the FIFO seed lists before every step (:1190-1194).
-        step_noise: optional callable i -> [nf,2,C,h,w] bf16 (default: seeded device generator)."""
+        step_noise: optional callable i -> [nf,2,C,h,w] bf16 (default: seeded device generator).
+        cfg_parallel: see tokensgen_amd/cfg_parallel.py (default: split the two CFG halves over ranks 0/1 when >= 2 ranks run)."""
         if prompt is not None or frames is not None:
             raise NotImplementedError("T5 prompt encoding and the Resampler are upstream of the hot path: pass prompt_embeds / image_embeddings")
         if prompt_embeds is None or negative_prompt_embeds is None:
@@ -161,15 +163,18 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
         gen = generator if generator is not None else torch.Generator(device=dev).manual_seed(0)
         fifo_latents, fifo_old = [], []
         old_x0 = None
+        cfg_mode = CP.resolve(cfg_parallel)
         for i, t in enumerate(ts):
             k = max(0, nf - 1 - i)
             fifo_latents.insert(0, latents[:, [k]].clone())
             fifo_old.insert(0, None if old_x0 is None else old_x0[[k]].to(BF16)[None])    # the queue holds model-dtype x0
-            inp = torch.cat([latents, latents], dim=0)
-            tt = torch.full((2,), t, dtype=torch.int64, device=dev)
-            pred = self.transformer(hidden_states=inp, encoder_hidden_states=embeds, timestep=tt, image_rotary_emb=rope_d,
-                                    vip_image_rotary_emb=vr, vip_condition_rotary_emb=cr, vip_encoder_hidden_states=emb0,
-                                    return_dict=False)[0]
+            def fwd(lo, hi):
+                n = hi - lo
+                return self.transformer(hidden_states=torch.cat([latents] * n, dim=0), encoder_hidden_states=embeds[lo:hi],
+                                        timestep=torch.full((n,), t, dtype=torch.int64, device=dev), image_rotary_emb=rope_d,
+                                        vip_image_rotary_emb=vr, vip_condition_rotary_emb=cr,
+                                        vip_encoder_hidden_states=None if emb0 is None else emb0[lo:hi].contiguous(), return_dict=False)[0]
+            pred = CP.predict(cfg_mode, lambda h: fwd(h, h + 1), lambda: fwd(0, 2))
             prev_t = ts[i + 1] if i + 1 < len(ts) else -1
             t_back = ts[i - 1] if i > 0 else None
             nz = step_noise(i) if step_noise is not None else torch.randn((nf, 2) + tuple(latents.shape[2:]), generator=gen, device=dev,

@@ -12,6 +12,7 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
+from . import cfg_parallel as CP
 from . import kernels as K
 from . import rope as R
 
@@ -65,10 +66,11 @@ class LongVGenCogVideoXPipeline:
                  num_inference_steps=50, timesteps=None, guidance_scale=6, use_dynamic_cfg=False, num_videos_per_prompt=1, eta=0.0,
                  generator=None, latents=None, prompt_embeds=None, negative_prompt_embeds=None, output_type="pil", return_dict=True,
                  attention_kwargs=None, max_sequence_length=226, longvgen_mean=None, longvgen_std=None, longvgen_pca=None,
-                 step_noise=None, **unused):
+                 step_noise=None, cfg_parallel=None, **unused):
         """:566-912.  height/width/num_frames_per_chunk are the condensed-token grid (8, 12, 4 in the shipped configs).
         step_noise: optional callable (i, k) -> bf16 gaussian shaped like the latents (k = 0: first draw of step i, 1: the 2M
-        branch's draw); default: `generator`, drawn in the reference's order and dtype (the sample's, scheduling_dpm:452,460)."""
+        branch's draw); default: `generator`, drawn in the reference's order and dtype (the sample's, scheduling_dpm:452,460).
+        cfg_parallel: see tokensgen_amd/cfg_parallel.py (default: split the two CFG halves over ranks 0/1 when >= 2 ranks run)."""
         if prompt is not None or negative_prompt is not None:
             raise NotImplementedError("T5 prompt encoding is upstream of the hot path: pass prompt_embeds and negative_prompt_embeds")
         if prompt_embeds is None:
@@ -116,12 +118,15 @@ class LongVGenCogVideoXPipeline:
             return torch.randn((1,) + shape, generator=generator, device=gdev, dtype=BF16).to(dev)[0]
 
         old_x0 = None
+        cfg_mode = CP.resolve(cfg_parallel)
         zeros = torch.zeros(shape, dtype=torch.float32, device=dev)
         noise = torch.zeros((nfr, 2) + shape[1:], dtype=BF16, device=dev)
         for i, t in enumerate(ts):
-            inp = torch.cat([latents, latents], dim=0)
-            tt = torch.full((2,), t, dtype=torch.int64, device=dev)
-            pred = self.transformer(hidden_states=inp, encoder_hidden_states=embeds, timestep=tt, image_rotary_emb=rope, return_dict=False)[0]
+            def fwd(lo, hi):
+                n = hi - lo
+                return self.transformer(hidden_states=torch.cat([latents] * n, dim=0), encoder_hidden_states=embeds[lo:hi],
+                                        timestep=torch.full((n,), t, dtype=torch.int64, device=dev), image_rotary_emb=rope, return_dict=False)[0]
+            pred = CP.predict(cfg_mode, lambda h: fwd(h, h + 1), lambda: fwd(0, 2))
             if use_dynamic_cfg:                              # :852-855, Python floats like the reference
                 self._guidance_scale = 1 + guidance_scale * (
                     (1 - math.cos(math.pi * ((num_inference_steps - t) / num_inference_steps) ** 5.0)) / 2)
