@@ -145,3 +145,27 @@ def test_resampler_vs_reference_golden(golden_dir):
     assert torch.equal(y, y2) and torch.equal(m.state_dict()["latents"].cpu(), sd["latents"].to(torch.bfloat16))
     with pytest.raises(NotImplementedError):
         m.set_pca("pca.pt")
+
+
+def test_processor_operator_seam_vs_reference_processor(golden_dir):
+    """The reference's own plugin seam: `blk.attn1(hidden_states, encoder_hidden_states=..., rotary tables)` -> Attention.forward ->
+    VideoIPAdapterCogVideoXAttnProcessor2_0.__call__ (attention_processor.py:457-501, 1982-2155).  Here the same call on the HIP
+    kernels, against the output of the reference processor itself (fp32 run, tests/golden/vip_processor.pt)."""
+    from tokensgen_amd.transformer import CogVideoXTransformer3DModel, VideoIPAdapterCogVideoXAttnProcessor2_0
+    g = torch.load(os.path.join(golden_dir, "vip_processor.pt"), weights_only=False)
+    m = CogVideoXTransformer3DModel(num_attention_heads=g["heads"], attention_head_dim=64, num_layers=1, time_embed_dim=128, text_embed_dim=64,
+                                    use_rotary_positional_embeddings=True, device=DEV)
+    m.set_vip_layers(None, length=g["n_vip"], func_type="1", scale=g["scale"],
+                     resampler_params=dict(output_dim=128, num_height_queries=2, num_width_queries=3, num_temporal_queries=4))
+    missing = m.load_state_dict({"transformer_blocks.0." + k: v.to(torch.bfloat16) for k, v in g["sd"].items()}, strict=False)
+    assert not missing.unexpected_keys and all(".attn1." not in k for k in missing.missing_keys)
+    attn = m.transformer_blocks[0].attn1
+    assert isinstance(attn.processor, VideoIPAdapterCogVideoXAttnProcessor2_0)
+    bf = lambda t: t.to(DEV, torch.bfloat16)
+    oh, oe = attn(bf(g["hid"]), encoder_hidden_states=bf(g["enc"]), image_rotary_emb=g["rope"], vip_image_rotary_emb=g["vrope"],
+                  vip_condition_rotary_emb=g["crope"], some_unrelated_kwarg=1)
+    assert oh.shape == g["out_hidden"].shape and oe.shape == g["out_enc"].shape
+    assert _rel(oh, g["out_hidden"]) < 2e-2 and _rel(oe, g["out_enc"]) < 2e-2
+    with pytest.raises(NotImplementedError):
+        attn(bf(g["hid"]), encoder_hidden_states=bf(g["enc"]), attention_mask=torch.ones(1), image_rotary_emb=g["rope"],
+             vip_image_rotary_emb=g["vrope"], vip_condition_rotary_emb=g["crope"])

@@ -38,7 +38,8 @@ class Transformer2DModelOutput:
 class VideoIPAdapterCogVideoXAttnProcessor2_0(nn.Module):
     """Holder of the To2V branch weights under the reference's names (attention_processor.py:1955-1980).
     The class name is load-bearing: the pipeline sets `.scale` on modules named exactly like this
-    (pipeline_cogvideox_mp_fifo.py:981-983).  Arithmetic happens in CogVideoXTransformer3DModel.forward."""
+    (pipeline_cogvideox_mp_fifo.py:981-983).  Inside the model the arithmetic is fused into CogVideoXTransformer3DModel.forward;
+    called on its own (`__call__`, the reference's processor signature :1982-1991) it runs the same kernels as a standalone op."""
 
     def __init__(self, scale=1.0, num_tokens=None):
         super().__init__()
@@ -47,9 +48,27 @@ class VideoIPAdapterCogVideoXAttnProcessor2_0(nn.Module):
         self.vip_to_q, self.vip_to_k, self.vip_to_v = _Lin(), _Lin(), _Lin()
         self.vip_norm_q, self.vip_norm_k = _Lin(), _Lin()
 
+    def __call__(self, attn, hidden_states, encoder_hidden_states, attention_mask=None, image_rotary_emb=None,
+                 vip_image_rotary_emb=None, vip_condition_rotary_emb=None):
+        return _processor_call(attn, hidden_states, encoder_hidden_states, attention_mask, image_rotary_emb, vip_image_rotary_emb,
+                               vip_condition_rotary_emb)
+
+
+def _processor_call(attn, hidden_states, encoder_hidden_states, attention_mask, image_rotary_emb, vip_image_rotary_emb=None,
+                    vip_condition_rotary_emb=None):
+    if attention_mask is not None:
+        raise NotImplementedError("attention masks are not used on the TokensGen hot path")
+    model = attn._owner() if getattr(attn, "_owner", None) is not None else None
+    if model is None:
+        raise RuntimeError("this Attention module is not attached to a CogVideoXTransformer3DModel (its weights live in the model's fused storages)")
+    return model.attention_op(attn._layer, hidden_states, encoder_hidden_states, image_rotary_emb, vip_image_rotary_emb, vip_condition_rotary_emb)
+
 
 class CogVideoXAttnProcessor2_0:
-    """Plain joint-attention processor marker (attention_processor.py:1885-1953)."""
+    """Plain joint-attention processor (attention_processor.py:1885-1953): same call signature, runs on the HIP kernels."""
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states, attention_mask=None, image_rotary_emb=None, **unused):
+        return _processor_call(attn, hidden_states, encoder_hidden_states, attention_mask, image_rotary_emb)
 
 
 class _Lin(nn.Module):
@@ -75,6 +94,13 @@ class _Attention(nn.Module):
 
     def get_processor(self):
         return self.processor
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **cross_attention_kwargs):
+        """attention_processor.py:457-501: hand over to the processor with the keyword arguments its signature accepts."""
+        import inspect
+        ok = set(inspect.signature(self.processor.__call__).parameters)
+        kw = {k: v for k, v in cross_attention_kwargs.items() if k in ok}
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask, **kw)
 
 
 class _Norm(nn.Module):
@@ -147,6 +173,10 @@ class CogVideoXTransformer3DModel(nn.Module):
         self.time_embedding = nn.Module()
         self.time_embedding.linear_1, self.time_embedding.linear_2 = _Lin(), _Lin()
         self.transformer_blocks = nn.ModuleList([CogVideoXBlock() for _ in range(num_layers)])
+        import weakref
+        for li, blk in enumerate(self.transformer_blocks):      # operator-level seam: blk.attn1(...) finds its fused weights
+            object.__setattr__(blk.attn1, "_owner", weakref.ref(self))
+            blk.attn1._layer = li
         self.norm_final = _Lin()
         self.norm_out = _Norm()
         self.proj_out = _Lin()
@@ -403,6 +433,29 @@ class CogVideoXTransformer3DModel(nn.Module):
         if use_vip:
             vln = F[p + "vln"]
             K.adaln_modulate(X[:, N1:], ws.Xn[:, N1:], vln[0], vln[1], c.norm_eps, t1.offset(N1))
+        self._attn_core(i, ws, B, Nt, Nv, Np, rope, vrope, crope)
+        # out projection with the gated residual as epilogue (cogvideox_transformer_3d.py:290-293)
+        K.gemm(ws.AO, F[p + "out.w"], F[p + "out.b"], X, L.EPI_BIAS_GATE_RES, residual=X, gate=t1)
+        t2 = self._tables(ws, i, Fm, 2)
+        K.adaln_modulate(X[:, :N1], ws.Xn[:, :N1], ln[2], ln[3], c.norm_eps, t2)
+        if use_vip:
+            K.adaln_modulate(X[:, N1:], ws.Xn[:, N1:], vln[2], vln[3], c.norm_eps, t2.offset(N1))
+        # feed-forward over all tokens (same ff weights for the vip rows, :315-324)
+        K.gemm(ws.Xn, F[p + "ff1.w"], F[p + "ff1.b"], ws.FF, L.EPI_BIAS_GELU)
+        K.gemm(ws.FF, F[p + "ff2.w"], F[p + "ff2.b"], X, L.EPI_BIAS_GATE_RES, residual=X, gate=t2)
+
+
+    def _attn_core(self, i, ws, B, Nt, Nv, Np, rope, vrope, crope):
+        """Attention of block i between the input norm and `to_out` (attention_processor.py:1982-2135 / 1895-1945): reads ws.Xn
+        (text | video | vip rows), leaves the pre-projection attention output in ws.AO.  ws needs Xn, QKV, Vt1, AO and, with vip
+        tokens, QKVv, Vt2, Vt3."""
+        D, H = self.inner_dim, self.config.num_attention_heads
+        F = self._fused
+        N1, N = Nt + Nv, Nt + Nv + Np
+        use_vip = Np > 0
+        sm_scale = 1.0 / math.sqrt(64)
+        blk = self.transformer_blocks[i]
+        p = f"l{i}."
         # QKV projections (+ vip-weight projections over ALL tokens: x rows and vip rows share vip_to_*)
         K.gemm(ws.Xn[:, :N1], F[p + "qkv.w"], F[p + "qkv.b"], ws.QKV, L.EPI_BIAS)
         qn = F[p + "qknorm"]
@@ -426,16 +479,36 @@ class CogVideoXTransformer3DModel(nn.Module):
             K.attention(ws.QKVv[:, N1:, :D], ws.QKVv[:, :, D:2 * D], ws.Vt3, N, ws.AO[:, N1:], H, sm_scale, k_prescaled=True)
         else:
             K.attention(ws.QKV[:, :, :D], ws.QKV[:, :, D:2 * D], ws.Vt1, N1, ws.AO[:, :N1], H, sm_scale, k_prescaled=True)
-        # out projection with the gated residual as epilogue (cogvideox_transformer_3d.py:290-293)
-        K.gemm(ws.AO, F[p + "out.w"], F[p + "out.b"], X, L.EPI_BIAS_GATE_RES, residual=X, gate=t1)
-        t2 = self._tables(ws, i, Fm, 2)
-        K.adaln_modulate(X[:, :N1], ws.Xn[:, :N1], ln[2], ln[3], c.norm_eps, t2)
-        if use_vip:
-            K.adaln_modulate(X[:, N1:], ws.Xn[:, N1:], vln[2], vln[3], c.norm_eps, t2.offset(N1))
-        # feed-forward over all tokens (same ff weights for the vip rows, :315-324)
-        K.gemm(ws.Xn, F[p + "ff1.w"], F[p + "ff1.b"], ws.FF, L.EPI_BIAS_GELU)
-        K.gemm(ws.FF, F[p + "ff2.w"], F[p + "ff2.b"], X, L.EPI_BIAS_GATE_RES, residual=X, gate=t2)
 
+    @torch.no_grad()
+    def attention_op(self, i, hidden_states, encoder_hidden_states, image_rotary_emb=None, vip_image_rotary_emb=None,
+                     vip_condition_rotary_emb=None):
+        """The reference's operator-level seam for block i: what `blk.attn1(hidden_states, encoder_hidden_states=..., rotary tables)`
+        returns there (Attention.forward -> processor.__call__, attention_processor.py:457-501, 1982-2155 / 1895-1953):
+        (video rows [B,Nv,D], cat(text, vip) rows [B,Nt+Np,D]) AFTER `to_out`, from already normalised + modulated inputs."""
+        dev = self._device
+        B, Nv, D = hidden_states.shape
+        Np = self.vip_length if self.transformer_blocks[i].use_vip else 0
+        Nt = encoder_hidden_states.shape[1] - Np
+        N1, N = Nt + Nv, Nt + Nv + Np
+        H = self.config.num_attention_heads
+        if image_rotary_emb is None or (Np and (vip_image_rotary_emb is None or vip_condition_rotary_emb is None)):
+            raise ValueError("rotary tables are required (CogVideoX-5B attention)")
+        e = lambda *sh: torch.empty(*sh, dtype=BF16, device=dev)
+        ws = SimpleNamespace(Xn=e(B, N, D), QKV=e(B, N1, 3 * D), Vt1=e(B, H, 64, _pad_to(N1, 64)), AO=e(B, N, D))
+        ws.Xn[:, :Nt] = encoder_hidden_states[:, :Nt].to(dev, BF16)
+        ws.Xn[:, Nt:N1] = hidden_states.to(dev, BF16)
+        f32 = lambda t: tuple(x.to(dev, torch.float32).contiguous() for x in t)
+        vr = cr = None
+        if Np:
+            ws.Xn[:, N1:] = encoder_hidden_states[:, Nt:].to(dev, BF16)
+            ws.QKVv, ws.Vt2, ws.Vt3 = e(B, N, 3 * D), e(B, H, 64, _pad_to(Np, 64)), e(B, H, 64, _pad_to(N, 64))
+            vr, cr = f32(vip_image_rotary_emb), f32(vip_condition_rotary_emb)
+        self._attn_core(i, ws, B, Nt, Nv, Np, f32(image_rotary_emb), vr, cr)
+        out = e(B, N, D)
+        F = self._fused
+        K.gemm(ws.AO, F[f"l{i}.out.w"], F[f"l{i}.out.b"], out, L.EPI_BIAS)
+        return out[:, Nt:N1], torch.cat([out[:, :Nt], out[:, N1:]], dim=1)
 
     @torch.no_grad()
     def patch_embed_proj(self, latents):
