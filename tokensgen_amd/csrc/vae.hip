@@ -186,19 +186,16 @@ constexpr int GN_GROUPS = 32;
 constexpr int GN_ROWS_PER_BLOCK = 512;
 
 __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, long V, int C, float* __restrict__ partial) {
-    __shared__ float sh[2][GN_GROUPS];
-    if (threadIdx.x < 2 * GN_GROUPS) ((float*)sh)[threadIdx.x] = 0.f;
-    __syncthreads();
+    __shared__ float sh[256][17];                         // per-thread (sum, sumsq) of its 8 channels; +1 pad against bank conflicts
     const int vec_per_row = C >> 3;                       // 16-byte vectors per voxel
     const int cg = C / GN_GROUPS;                         // channels per group (>= 2)
     const long row0 = (long)blockIdx.x * GN_ROWS_PER_BLOCK;
     const long rows = min((long)GN_ROWS_PER_BLOCK, V - row0);
     const long nvec = rows * vec_per_row;
-    // a thread always visits the same channel slice when blockDim % vec_per_row == 0 (C in {64..512} -> yes)
+    // a thread always visits the same channel slice when blockDim % vec_per_row == 0 (C in {64..2048} -> yes)
     float s[8], q[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
-    const int cv = threadIdx.x % vec_per_row;
     for (long v = threadIdx.x; v < nvec; v += 256) {
         const uint4 raw = *(const uint4*)(x + (row0 * vec_per_row + v) * 8);
         const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -210,13 +207,18 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
         }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int g = (cv * 8 + i) / cg;
-        atomicAdd(&sh[0][g], s[i]);
-        atomicAdd(&sh[1][g], q[i]);
-    }
+    for (int i = 0; i < 8; ++i) { sh[threadIdx.x][i] = s[i]; sh[threadIdx.x][8 + i] = q[i]; }
     __syncthreads();
-    if (threadIdx.x < 2 * GN_GROUPS) partial[(long)blockIdx.x * 2 * GN_GROUPS + threadIdx.x] = ((float*)sh)[threadIdx.x];
+    // fixed summation order (no atomics): thread (stat, g) walks the group's channels and, per channel, the threads that own it
+    if (threadIdx.x < 2 * GN_GROUPS) {
+        const int st = threadIdx.x / GN_GROUPS, g = threadIdx.x % GN_GROUPS;
+        float acc = 0.f;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) {
+            const int cv = c >> 3, i = c & 7;
+            for (int t = cv; t < 256; t += vec_per_row) acc += sh[t][st * 8 + i];
+        }
+        partial[(long)blockIdx.x * 2 * GN_GROUPS + threadIdx.x] = acc;
+    }
 }
 
 __global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ partial, int nblocks, long V, int C, float eps, float* __restrict__ stats) {
