@@ -43,7 +43,8 @@ struct AttnParams {
     int nq, heads, batch;
     float scale_log2;   // softmax scale * log2(e)
     int prescaled;      // 1: K already carries scale*log2(e) (tg_qk_layernorm_rope out_scale): scores are log2-domain as produced
-    int knob;           // TG_ATTN_KNOB experiment bits (bit 0: static s_setprio 1 for the second-dispatched wave group)
+    int knob;           // TG_ATTN_KNOB experiment bits (1: static s_setprio 1 for the second-dispatched wave group; 4: no raised
+                        // priority for the matrix segment)
 };
 
 // plain fmaxf nests: clang fuses them to v_max3_f32 (built with -fno-honor-nans so MFMA outputs are not canonicalised by an
@@ -294,7 +295,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 //   in-kernel s_memtime per tile: X ~1600 cycles (1152 of MFMA), Y ~2000 cycles for ~190 VALU — a lone wave issues one VALU
 //   per ~6.6 cycles (tools/ubench/valu_rate.hip: 6.64 plain / 10.6 v_exp_f32 with 1 wave per SIMD, half that per SIMD with 2).
 //   Helped: fragment-granular ds_read pipelining in X, -m seeding through the matrix pipe, two v_max3 chains +
-//   v_permlane32_swap, four row-sum chains (8.63 -> 7.8 ms).  Did not help: plain v_add_f32 row sums; s_setprio 1 for the
+//   v_permlane32_swap, four row-sum chains (8.63 -> 7.8 ms), s_setprio 2 around the matrix segment (-> 7.5 ms; raising
+//   the VECTOR segment instead: +6 %).  Did not help: plain v_add_f32 row sums; s_setprio 1 for the
 //   second-dispatched half; exponentiating the last 1 or 2 k-steps of P(t) inside X(t+1) as MFMA fillers (9.1 / 11.4 ms:
 //   VALU between the MFMAs of the matrix segment costs more than it frees in the vector segment); rescale triggered by the
 //   tile's row SUM instead of a row max (30 fewer VALU per tile, yet 8.3 vs 7.9 ms); ONE barrier per tile with 3-deep K/V rings
@@ -598,7 +600,11 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             // X(t): matrix segment
             PP_TICK(3);
             if (grp == 0) dma_pair(t);
+            // the matrix segment runs at raised priority: its MFMA / ds_read issue slots are few (one per ~32 cycles) but each one the
+            // partner's VALU stream delays idles the matrix pipe; measured -4..6 % (7.52 vs 7.94 ms same box); prio 1: -2 %, prio 3 = 2
+            if (!(p.knob & 4)) __builtin_amdgcn_s_setprio(2);
             xseg(t);
+            if (!(p.knob & 4)) __builtin_amdgcn_s_setprio(0);
             if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t (issued one segment ago) has landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PP_TICK(0);
