@@ -102,6 +102,27 @@ int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
                      float seg2_scale, void* out, long out_ld, long out_strideB,
                      int nq, int heads, int batch, float scale, int k_prescaled, hipStream_t stream);
 
+/* The same operator with its arguments in structs, and room for a second problem in the same launch.
+ * problems[0]: as tg_attention_fwd (nseg = 1 or 2).  problems[1] (optional, nseg = 1, same heads/batch/scale): its workgroups are
+ * appended to problem 0's in one launch when problem 0 is long enough for the 512-row kernel; otherwise the two run one after the
+ * other.  Built for the To2V block: the main attention (text+video queries) leaves most of its last round of CUs idle and the
+ * vip-query attention (attention_processor.py:2120-2125), of the same length per workgroup, fits in there. */
+typedef struct tg_attn_segment {
+    const void* q; long q_ld, q_strideB;
+    const void* k; long k_ld, k_strideB;
+    const void* vt; long vt_ld;
+    int nk;
+} tg_attn_segment;
+typedef struct tg_attn_problem {
+    tg_attn_segment seg[2];
+    int nseg;
+    float seg2_scale;
+    void* out; long out_ld, out_strideB;
+    int nq;
+} tg_attn_problem;
+int tg_attention_fwd_multi(const tg_attn_problem* problems, int nproblems, int heads, int batch, float scale, int k_prescaled,
+                           hipStream_t stream);
+
 /* emb[i][:] = bf16( [cos(t_i w_k) | sin(t_i w_k)] ), w_k = exp(-ln(1e4) k / (dim/2)), k < dim/2
  * (flip_sin_to_cos=True, freq_shift=0).  Replaces embeddings.py:28-79 + dit:678.  t: int64[n]. */
 int tg_timestep_sinusoid(const int64_t* t, int n, int dim, void* emb, hipStream_t stream);

@@ -269,3 +269,26 @@ def test_attention_cases_again_on_the_pingpong_kernel():
                        env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_attention_multi_rider_matches_separate_launches(K):
+    BF = torch.bfloat16
+    """tg_attention_fwd_multi: the second problem's workgroups ride in the first problem's launch (ping-pong kernel) or run as a launch
+    of their own (short query ranges) — either way bitwise what two tg_attention_fwd calls give."""
+    torch.manual_seed(3)
+    B, H, N1, NP = 2, 2, 700, 70
+    D, N = H * 64, N1 + NP
+    qkv = (torch.randn(B, N1, 3 * D, device=DEV) * 0.5).to(BF)
+    qkvv = (torch.randn(B, N, 3 * D, device=DEV) * 0.5).to(BF)
+    pad = lambda n: (n + 63) // 64 * 64
+    vt1 = torch.zeros(B, H, 64, pad(N1), dtype=BF, device=DEV); K.transpose_v(qkv[:, :, 2 * D:], H, 0, N1, vt1)
+    vt2 = torch.zeros(B, H, 64, pad(NP), dtype=BF, device=DEV); K.transpose_v(qkvv[:, :, 2 * D:], H, N1, NP, vt2)
+    vt3 = torch.zeros(B, H, 64, pad(N), dtype=BF, device=DEV); K.transpose_v(qkvv[:, :, 2 * D:], H, 0, N, vt3)
+    for pre in (False, True):
+        a = torch.zeros(B, N, D, dtype=BF, device=DEV); b = torch.zeros(B, N, D, dtype=BF, device=DEV)
+        K.attention(qkv[:, :, :D], qkv[:, :, D:2 * D], vt1, N1, a[:, :N1], H, 0.125, qkvv[:, :N1, :D], qkvv[:, N1:, D:2 * D], vt2, NP, 0.6, k_prescaled=pre)
+        K.attention(qkvv[:, N1:, :D], qkvv[:, :, D:2 * D], vt3, N, a[:, N1:], H, 0.125, k_prescaled=pre)
+        K.attention_multi(dict(q1=qkv[:, :, :D], k1=qkv[:, :, D:2 * D], vt1=vt1, nk1=N1, out=b[:, :N1], q2=qkvv[:, :N1, :D],
+                               k2=qkvv[:, N1:, D:2 * D], vt2=vt2, nk2=NP, seg2_scale=0.6),
+                          dict(q1=qkvv[:, N1:, :D], k1=qkvv[:, :, D:2 * D], vt1=vt3, nk1=N, out=b[:, N1:]), H, 0.125, k_prescaled=pre)
+        assert torch.isfinite(b).all() and torch.equal(a, b)

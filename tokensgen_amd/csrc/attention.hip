@@ -45,6 +45,13 @@ struct AttnParams {
     int prescaled;      // 1: K already carries scale*log2(e) (tg_qk_layernorm_rope out_scale): scores are log2-domain as produced
     int knob;           // TG_ATTN_KNOB experiment bits (1: static s_setprio 1 for the second-dispatched wave group; 4: no raised
                         // priority for the matrix segment)
+    // "rider": a second, single-segment problem of the same heads/batch whose workgroups are appended to the launch (ping-pong
+    // kernel only).  The main attention leaves 3360 - 13*256 = 32 workgroups for its last round of 256 CUs; the To2V block's
+    // vip-query attention (96 workgroups of the same length) rides in that round instead of costing a launch of its own.
+    Seg r_s;
+    bf16_t* r_out; long r_o_ld, r_o_sb;
+    int r_nq;
+    int main_wgs;       // workgroups of the main problem (rider workgroups follow); 0 rider workgroups when r_nq == 0
 };
 
 // plain fmaxf nests: clang fuses them to v_max3_f32 (built with -fno-honor-nans so MFMA outputs are not canonicalised by an
@@ -318,16 +325,22 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
     const int grp = wave >> 2;
     const int hi = lane >> 5, j = lane & 31;
 
-    const int nqt = (p.nq + 511) / 512;
+    const bool rider = p.r_nq > 0 && (int)blockIdx.x >= p.main_wgs;      // workgroup-uniform
+    const int bid = rider ? (int)blockIdx.x - p.main_wgs : (int)blockIdx.x;
+    const int nq_ = rider ? p.r_nq : p.nq;
+    const int nseg_ = rider ? 1 : p.nseg;
+    bf16_t* const out_ = rider ? p.r_out : p.out;
+    const long o_ld_ = rider ? p.r_o_ld : p.o_ld, o_sb_ = rider ? p.r_o_sb : p.o_sb;
+    const int nqt = (nq_ + 511) / 512;
     const int nhb = p.heads * p.batch;
     int hb, qt;
     if ((nhb & 7) == 0) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int xcd = bid & 7, slot = bid >> 3;
         hb = xcd + 8 * (slot / nqt);
         qt = slot % nqt;
     } else {
-        hb = blockIdx.x / nqt;
-        qt = blockIdx.x % nqt;
+        hb = bid / nqt;
+        qt = bid % nqt;
     }
     const int h = hb % p.heads, b = hb / p.heads;
     const int q0 = qt * 512 + wave * 64;
@@ -347,12 +360,12 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         __builtin_amdgcn_sched_barrier(0);               \
     } while (0)
 
-    for (int sg = 0; sg < p.nseg; ++sg) {
-        const Seg& S = p.s[sg];
+    for (int sg = 0; sg < nseg_; ++sg) {
+        const Seg& S = rider ? p.r_s : p.s[sg];
         bf16x8 qf[2][4];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            const int qrow = min(q0 + qb * 32 + j, p.nq - 1);
+            const int qrow = min(q0 + qb * 32 + j, nq_ - 1);
             const bf16_t* qp = S.q + (long)b * S.q_sb + (long)qrow * S.q_ld + h * 64 + hi * 8;
 #pragma unroll
             for (int kd = 0; kd < 4; ++kd) qf[qb][kd] = *(const bf16x8*)(qp + kd * 16);
@@ -631,8 +644,8 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
             const float w = (sg == 0 ? 1.f : p.seg2_scale) / lt;
             const int q = q0 + qb * 32 + j;
-            if (q < p.nq) {
-                bf16_t* op = p.out + (long)b * p.o_sb + (long)q * p.o_ld + h * 64;
+            if (q < nq_) {
+                bf16_t* op = out_ + (long)b * o_sb_ + (long)q * o_ld_ + h * 64;
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -659,32 +672,8 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
 
 }  // namespace
 
-extern "C" int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
-                                const void* k1, long k1_ld, long k1_strideB, const void* vt1, long vt1_ld, int nk1,
-                                const void* q2, long q2_ld, long q2_strideB,
-                                const void* k2, long k2_ld, long k2_strideB, const void* vt2, long vt2_ld, int nk2,
-                                float seg2_scale, void* out, long out_ld, long out_strideB,
-                                int nq, int heads, int batch, float scale, int k_prescaled, hipStream_t stream) {
-    TG_REQUIRE(q1 && k1 && vt1 && out, TG_ERR_ARG, "tg_attention_fwd: null pointer");
-    TG_REQUIRE(nq > 0 && nk1 > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_attention_fwd: bad shape nq=%d nk1=%d", nq, nk1);
-    TG_REQUIRE(q1_ld % 8 == 0 && k1_ld % 8 == 0 && vt1_ld % 64 == 0 && out_ld % 4 == 0 && q1_strideB % 8 == 0 &&
-               k1_strideB % 8 == 0 && out_strideB % 4 == 0 && tg_aligned16(q1) && tg_aligned16(k1) && tg_aligned16(vt1) &&
-               (((uintptr_t)out) & 7) == 0, TG_ERR_ALIGN, "tg_attention_fwd: segment 1 alignment");
-    TG_REQUIRE(vt1_ld >= ((nk1 + 63) / 64) * 64, TG_ERR_SHAPE, "tg_attention_fwd: vt1_ld must cover nk1 rounded up to 64");
-    AttnParams p{};
-    p.s[0] = Seg{(const bf16_t*)q1, q1_ld, q1_strideB, (const bf16_t*)k1, k1_ld, k1_strideB, (const bf16_t*)vt1, vt1_ld, nk1};
-    p.nseg = 1;
-    if (q2) {
-        TG_REQUIRE(k2 && vt2 && nk2 > 0, TG_ERR_ARG, "tg_attention_fwd: segment 2 incomplete");
-        TG_REQUIRE(q2_ld % 8 == 0 && k2_ld % 8 == 0 && vt2_ld % 64 == 0 && q2_strideB % 8 == 0 && k2_strideB % 8 == 0 &&
-                   tg_aligned16(q2) && tg_aligned16(k2) && tg_aligned16(vt2), TG_ERR_ALIGN, "tg_attention_fwd: segment 2 alignment");
-        TG_REQUIRE(vt2_ld >= ((nk2 + 63) / 64) * 64, TG_ERR_SHAPE, "tg_attention_fwd: vt2_ld must cover nk2 rounded up to 64");
-        p.s[1] = Seg{(const bf16_t*)q2, q2_ld, q2_strideB, (const bf16_t*)k2, k2_ld, k2_strideB, (const bf16_t*)vt2, vt2_ld, nk2};
-        p.nseg = 2;
-    }
-    p.seg2_scale = seg2_scale;
-    p.out = (bf16_t*)out; p.o_ld = out_ld; p.o_sb = out_strideB;
-    p.nq = nq; p.heads = heads; p.batch = batch;
+static int attention_launch(AttnParams& p, float scale, int k_prescaled, const char* who, hipStream_t stream) {
+    const int nq = p.nq, heads = p.heads, batch = p.batch;
     // k_prescaled: K rows already carry scale*log2(e) (written by tg_qk_layernorm_rope with out_scale), `scale` is then ignored
     p.prescaled = k_prescaled ? 1 : 0;
     p.scale_log2 = k_prescaled ? 1.0f : scale * 1.4426950408889634f;
@@ -699,15 +688,28 @@ extern "C" int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
     static const long pp_min = [] { const char* e = getenv("TG_ATTN_PP_MIN_WG"); return e ? atol(e) : 1024L; }();   // tests lower it
     const long wg512 = (long)((nq + 511) / 512) * heads * batch;
     static const int timing = [] { const char* e = getenv("TG_ATTN_TIMING"); return e ? atoi(e) : 0; }();
+    const bool pp = wg512 >= pp_min && !abl && !no_pp;
+    if (p.r_nq > 0 && !pp) {
+        // the rider needs the ping-pong kernel: run it as a launch of its own through the ordinary dispatch
+        AttnParams r{};
+        r.s[0] = p.r_s; r.nseg = 1; r.seg2_scale = 0.f;
+        r.out = p.r_out; r.o_ld = p.r_o_ld; r.o_sb = p.r_o_sb;
+        r.nq = p.r_nq; r.heads = heads; r.batch = batch;
+        p.r_nq = 0;
+        const int rc = attention_launch(p, scale, k_prescaled, who, stream);
+        return rc ? rc : attention_launch(r, scale, k_prescaled, who, stream);
+    }
+    p.main_wgs = (int)wg512;
+    const long grid512 = wg512 + (p.r_nq > 0 ? (long)((p.r_nq + 511) / 512) * heads * batch : 0);
     if (timing && p.prescaled && wg512 >= pp_min) {
-        hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true>), dim3((unsigned)wg512), dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true>), dim3((unsigned)grid512), dim3(512), 0, stream, p);
         long long h[8];
-        hipMemcpyFromSymbol(h, HIP_SYMBOL(tg_attn_dbg), sizeof(h));
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(tg_attn_dbg), sizeof(h));
         fprintf(stderr, "[tg_attention timing] g0: X %lld Xwait %lld Y %lld Ywait %lld | g1: X %lld Xwait %lld Y %lld Ywait %lld (s_memtime ticks, seg 0)\n",
                 h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
-    } else if (wg512 >= pp_min && !abl && !no_pp) {
-        if (p.prescaled) hipLaunchKernelGGL(attn_fwd_pp_kernel<true>, dim3((unsigned)wg512), dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL(attn_fwd_pp_kernel<false>, dim3((unsigned)wg512), dim3(512), 0, stream, p);
+    } else if (pp) {
+        if (p.prescaled) hipLaunchKernelGGL(attn_fwd_pp_kernel<true>, dim3((unsigned)grid512), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL(attn_fwd_pp_kernel<false>, dim3((unsigned)grid512), dim3(512), 0, stream, p);
     } else if (wg256 >= 1024 && abl) {
         if (abl == 1) hipLaunchKernelGGL((attn_fwd_kernel<2, 1>), dim3((unsigned)wg256), dim3(256), 0, stream, p);
         else if (abl == 2) hipLaunchKernelGGL((attn_fwd_kernel<2, 2>), dim3((unsigned)wg256), dim3(256), 0, stream, p);
@@ -718,6 +720,62 @@ extern "C" int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
         const int nqt = (nq + 127) / 128;
         hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3((unsigned)(nqt * heads * batch)), dim3(256), 0, stream, p);
     }
-    TG_LAUNCH_CHECK("tg_attention_fwd");
+    TG_LAUNCH_CHECK(who);
     return TG_OK;
+}
+
+static int fill_segment(Seg& S, const tg_attn_segment& g, const char* what) {
+    TG_REQUIRE(g.q && g.k && g.vt, TG_ERR_ARG, "tg_attention: %s: null pointer", what);
+    TG_REQUIRE(g.nk > 0, TG_ERR_SHAPE, "tg_attention: %s: nk=%d", what, g.nk);
+    TG_REQUIRE(g.q_ld % 8 == 0 && g.k_ld % 8 == 0 && g.vt_ld % 64 == 0 && g.q_strideB % 8 == 0 && g.k_strideB % 8 == 0 && tg_aligned16(g.q) &&
+               tg_aligned16(g.k) && tg_aligned16(g.vt), TG_ERR_ALIGN, "tg_attention: %s alignment", what);
+    TG_REQUIRE(g.vt_ld >= ((g.nk + 63) / 64) * 64, TG_ERR_SHAPE, "tg_attention: %s: vt_ld must cover nk rounded up to 64", what);
+    S = Seg{(const bf16_t*)g.q, g.q_ld, g.q_strideB, (const bf16_t*)g.k, g.k_ld, g.k_strideB, (const bf16_t*)g.vt, g.vt_ld, g.nk};
+    return TG_OK;
+}
+
+extern "C" int tg_attention_fwd_multi(const tg_attn_problem* problems, int nproblems, int heads, int batch, float scale, int k_prescaled,
+                                      hipStream_t stream) {
+    TG_REQUIRE(problems && (nproblems == 1 || nproblems == 2), TG_ERR_ARG, "tg_attention_fwd_multi: 1 or 2 problems");
+    TG_REQUIRE(heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_attention_fwd_multi: bad shape");
+    const tg_attn_problem& A = problems[0];
+    TG_REQUIRE(A.out && A.nq > 0 && (A.nseg == 1 || A.nseg == 2), TG_ERR_ARG, "tg_attention_fwd_multi: problem 0");
+    TG_REQUIRE(A.out_ld % 4 == 0 && A.out_strideB % 4 == 0 && (((uintptr_t)A.out) & 7) == 0, TG_ERR_ALIGN, "tg_attention_fwd_multi: output alignment");
+    AttnParams p{};
+    int rc = fill_segment(p.s[0], A.seg[0], "problem 0 segment 1");
+    if (rc) return rc;
+    p.nseg = A.nseg;
+    if (A.nseg == 2 && (rc = fill_segment(p.s[1], A.seg[1], "problem 0 segment 2"))) return rc;
+    p.seg2_scale = A.seg2_scale;
+    p.out = (bf16_t*)A.out; p.o_ld = A.out_ld; p.o_sb = A.out_strideB;
+    p.nq = A.nq; p.heads = heads; p.batch = batch;
+    if (nproblems == 2) {
+        const tg_attn_problem& B = problems[1];
+        TG_REQUIRE(B.out && B.nq > 0 && B.nseg == 1, TG_ERR_ARG, "tg_attention_fwd_multi: problem 1 must have one key segment");
+        TG_REQUIRE(B.out_ld % 4 == 0 && B.out_strideB % 4 == 0 && (((uintptr_t)B.out) & 7) == 0, TG_ERR_ALIGN, "tg_attention_fwd_multi: output alignment");
+        if ((rc = fill_segment(p.r_s, B.seg[0], "problem 1"))) return rc;
+        p.r_out = (bf16_t*)B.out; p.r_o_ld = B.out_ld; p.r_o_sb = B.out_strideB; p.r_nq = B.nq;
+    }
+    return attention_launch(p, scale, k_prescaled, "tg_attention_fwd_multi", stream);
+}
+
+extern "C" int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
+                                const void* k1, long k1_ld, long k1_strideB, const void* vt1, long vt1_ld, int nk1,
+                                const void* q2, long q2_ld, long q2_strideB,
+                                const void* k2, long k2_ld, long k2_strideB, const void* vt2, long vt2_ld, int nk2,
+                                float seg2_scale, void* out, long out_ld, long out_strideB,
+                                int nq, int heads, int batch, float scale, int k_prescaled, hipStream_t stream) {
+    TG_REQUIRE(q1 && k1 && vt1 && out, TG_ERR_ARG, "tg_attention_fwd: null pointer");
+    TG_REQUIRE(nq > 0 && nk1 > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_attention_fwd: bad shape nq=%d nk1=%d", nq, nk1);
+    tg_attn_problem A{};
+    A.seg[0] = tg_attn_segment{q1, q1_ld, q1_strideB, k1, k1_ld, k1_strideB, vt1, vt1_ld, nk1};
+    A.nseg = 1;
+    if (q2) {
+        TG_REQUIRE(k2 && vt2 && nk2 > 0, TG_ERR_ARG, "tg_attention_fwd: segment 2 incomplete");
+        A.seg[1] = tg_attn_segment{q2, q2_ld, q2_strideB, k2, k2_ld, k2_strideB, vt2, vt2_ld, nk2};
+        A.nseg = 2;
+    }
+    A.seg2_scale = seg2_scale;
+    A.out = out; A.out_ld = out_ld; A.out_strideB = out_strideB; A.nq = nq;
+    return tg_attention_fwd_multi(&A, 1, heads, batch, scale, k_prescaled, stream);
 }

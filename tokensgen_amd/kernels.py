@@ -166,6 +166,40 @@ def attention(q1, k1, vt1, nk1, out, heads, scale, q2=None, k2=None, vt2=None, n
     return out
 
 
+def _attn_problem(q1, k1, vt1, nk1, out, q2=None, k2=None, vt2=None, nk2=0, seg2_scale=0.0):
+    import ctypes
+    for n, t in (("q1", q1), ("k1", k1), ("vt1", vt1), ("out", out)):
+        _chk(t, n)
+    pr = L.AttnProblem()
+    B, nq, _, qld, qsb = _bmk(q1)
+    _, _, _, kld, ksb = _bmk(k1)
+    _, _, _, old, osb = _bmk(out)
+    pr.seg[0] = L.AttnSegment(_p(q1), qld, qsb, _p(k1), kld, ksb, _p(vt1), vt1.shape[3], nk1)
+    pr.nseg = 1
+    if q2 is not None:
+        _chk(q2, "q2"); _chk(k2, "k2"); _chk(vt2, "vt2")
+        _, _, _, q2ld, q2sb = _bmk(q2)
+        _, _, _, k2ld, k2sb = _bmk(k2)
+        pr.seg[1] = L.AttnSegment(_p(q2), q2ld, q2sb, _p(k2), k2ld, k2sb, _p(vt2), vt2.shape[3], nk2)
+        pr.nseg = 2
+    pr.seg2_scale = float(seg2_scale)
+    pr.out, pr.out_ld, pr.out_strideB, pr.nq = _p(out), old, osb, nq
+    return pr, B
+
+
+def attention_multi(main, rider, heads, scale, k_prescaled=False):
+    """One launch for two attention problems of the same heads/batch (tg_attention_fwd_multi).  main / rider: dicts of the
+    keyword arguments of `attention` (q1, k1, vt1, nk1, out [, q2, k2, vt2, nk2, seg2_scale]); the rider has one key segment."""
+    import ctypes
+    pa, B = _attn_problem(**main)
+    pb, B2 = _attn_problem(**rider)
+    assert B == B2
+    arr = (L.AttnProblem * 2)(pa, pb)
+    L.check(_launch("attention_2seg+rider", L.load().tg_attention_fwd_multi, ctypes.addressof(arr), 2, heads, B, float(scale),
+                    1 if k_prescaled else 0, _stream()), "tg_attention_fwd_multi")
+    return main["out"], rider["out"]
+
+
 def timestep_sinusoid(t, dim, out):
     _chk(t, "t", torch.int64); _chk(out, "out")
     L.check(L.load().tg_timestep_sinusoid(_p(t), t.numel(), dim, _p(out), _stream()), "tg_timestep_sinusoid")

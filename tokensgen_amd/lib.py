@@ -26,6 +26,7 @@ PROTOTYPES = {
     "tg_transpose_v": [_vp, _l, _l, _i, _i, _i, _i, _vp, _l, _vp],
     "tg_attention_fwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _f, _vp, _l, _l,
                          _i, _i, _i, _f, _i, _vp],
+    "tg_attention_fwd_multi": [_vp, _i, _i, _i, _f, _i, _vp],
     "tg_timestep_sinusoid": [_vp, _i, _i, _vp, _vp],
     "tg_patchify": [_vp, _vp, _l, _i, _i, _i, _i, _i, _vp],
     "tg_unpatchify": [_vp, _l, _vp, _i, _i, _i, _i, _i, _vp],
@@ -69,3 +70,16 @@ def load():
 def check(code, what):
     if code != 0:
         raise RuntimeError(f"{what} failed ({code}): {load().tg_last_error_string().decode()}")
+
+
+class AttnSegment(C.Structure):
+    """tg_attn_segment (include/tokensgen_hip.h)"""
+    _fields_ = [("q", C.c_void_p), ("q_ld", C.c_long), ("q_strideB", C.c_long),
+                ("k", C.c_void_p), ("k_ld", C.c_long), ("k_strideB", C.c_long),
+                ("vt", C.c_void_p), ("vt_ld", C.c_long), ("nk", C.c_int)]
+
+
+class AttnProblem(C.Structure):
+    """tg_attn_problem (include/tokensgen_hip.h)"""
+    _fields_ = [("seg", AttnSegment * 2), ("nseg", C.c_int), ("seg2_scale", C.c_float),
+                ("out", C.c_void_p), ("out_ld", C.c_long), ("out_strideB", C.c_long), ("nq", C.c_int)]

@@ -473,10 +473,11 @@ class CogVideoXTransformer3DModel(nn.Module):
             s = blk.attn1.processor.scale
             s = float(s[0] if isinstance(s, (list, tuple)) else s)
             # text+video rows: softmax(q k^T) v  +  s * softmax(qx kv^T) vv   (attention_processor.py:2066-2069,2117-2134)
-            K.attention(ws.QKV[:, :, :D], ws.QKV[:, :, D:2 * D], ws.Vt1, N1, ws.AO[:, :N1], H, sm_scale,
-                        ws.QKVv[:, :N1, :D], ws.QKVv[:, N1:, D:2 * D], ws.Vt2, Np, s, k_prescaled=True)
-            # vip rows: qv against cat(kx, kv) / cat(vx, vv)                  (:2120-2125)
-            K.attention(ws.QKVv[:, N1:, :D], ws.QKVv[:, :, D:2 * D], ws.Vt3, N, ws.AO[:, N1:], H, sm_scale, k_prescaled=True)
+            # vip rows: qv against cat(kx, kv) / cat(vx, vv)                  (:2120-2125) — rides in the main launch's last round
+            K.attention_multi(dict(q1=ws.QKV[:, :, :D], k1=ws.QKV[:, :, D:2 * D], vt1=ws.Vt1, nk1=N1, out=ws.AO[:, :N1],
+                                   q2=ws.QKVv[:, :N1, :D], k2=ws.QKVv[:, N1:, D:2 * D], vt2=ws.Vt2, nk2=Np, seg2_scale=s),
+                              dict(q1=ws.QKVv[:, N1:, :D], k1=ws.QKVv[:, :, D:2 * D], vt1=ws.Vt3, nk1=N, out=ws.AO[:, N1:]),
+                              H, sm_scale, k_prescaled=True)
         else:
             K.attention(ws.QKV[:, :, :D], ws.QKV[:, :, D:2 * D], ws.Vt1, N1, ws.AO[:, :N1], H, sm_scale, k_prescaled=True)
 
