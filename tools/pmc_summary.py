@@ -40,7 +40,8 @@ def main(src, dst):
             "attention_main_kernel": main_attn[0],
             "attention_main_traffic_bytes_per_launch": (2 * a["FETCH_SIZE"]["mean"] + a["WRITE_SIZE"]["mean"]) * 1024,
             # B=2, bf16: q1,k1,v1,q2 read + out written by segment 1, read and re-written by segment 2 (counted once each way) + k2,v2
-            "attention_main_algorithmic_bytes_per_launch": 2 * 2 * (6 * n1 * d + 2 * nv * d),
+            # + the rider (vip queries, SDPA#3): q 480 rows, k and v of all N rows, out 480 rows
+            "attention_main_algorithmic_bytes_per_launch": 2 * 2 * (6 * n1 * d + 2 * nv * d) + 2 * 2 * (2 * nv * d + 2 * (n1 + nv) * d),
             "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024  [gfx950: FETCH_SIZE reports half of a wide coalesced read]",
             # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs (so /8 = the
             # kernel's wall in shader cycles: 16.3 M cycles for 8.2 ms = 1.99 GHz under this load)
