@@ -457,10 +457,24 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             // fetched into the buffer fragment i just left, so every ds_read_b128 has NFR-1 MFMA pairs (64 cycles each) of cover
             constexpr int NFR = TG_ATTN_NFR;
             bf16x8 fr[NFR];
+            // The fragment reads are inline asm with hand-counted lgkmcnt waits: for a C++ LDS load the compiler (a) waits vmcnt(0)
+            // first whenever an LDS-DMA piece is in flight (it cannot prove the DMA target is another buffer) — group 0 issues its
+            // pair at the start of this very segment, so the wait landed in the middle of the MFMA stream — and (b) falls back to
+            // lgkmcnt(0) in the first half.  The low 32 bits of a flat LDS address are the LDS offset.
+            const uint32_t ldsV = (uint32_t)(uintptr_t)tV, ldsK = (uint32_t)(uintptr_t)tK;
             auto ld = [&](int i) {
                 const int g = i >> 1, xb = i & 1;
-                if (g < 4) fr[i % NFR] = *(const bf16x8*)(tV + ((offV0 + xb * 4096) ^ (g << 5)));
-                else fr[i % NFR] = *(const bf16x8*)(tK + ((offK0 + xb * 4096) ^ ((g - 4) << 5)));
+                const uint32_t a = (g < 4) ? ldsV + (uint32_t)((offV0 + xb * 4096) ^ (g << 5)) : ldsK + (uint32_t)((offK0 + xb * 4096) ^ ((g - 4) << 5));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fr[i % NFR]) : "v"(a));
+            };
+            // before fragment i is consumed, min(15 - i, NFR - 1) younger reads may still be in flight (LDS returns in order; the
+            // "+v" operand ties the MFMAs that read the fragment to this wait)
+            auto wait_frag = [&](int i) {
+                const int younger = (15 - i) < (NFR - 1) ? (15 - i) : (NFR - 1);
+                if (younger >= 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fr[i % NFR]));
+                else if (younger == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fr[i % NFR]));
+                else if (younger == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fr[i % NFR]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[i % NFR]));
             };
 #pragma unroll
             for (int i = 0; i < NFR; ++i) ld(i);
@@ -485,6 +499,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
                             for (int r = 0; r < 16; ++r) sc[qb][kb][r] = 0.f;
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                wait_frag(i);
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
                     if (g < 4) acc_o[qb][xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % NFR], pf[qb][g], acc_o[qb][xb], 0, 0, 0);
@@ -616,8 +631,8 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             // the matrix segment runs at raised priority: its MFMA / ds_read issue slots are few (one per ~32 cycles) but each one the
             // partner's VALU stream delays idles the matrix pipe; measured -4..6 % (7.52 vs 7.94 ms same box); prio 1: -2 %, prio 3 = 2
             if (!(p.knob & 4)) __builtin_amdgcn_s_setprio(2);
-            xseg(t);
-            if (!(p.knob & 4)) __builtin_amdgcn_s_setprio(0);
+            if (!(TIMING && (p.knob & 32))) xseg(t);          // timing ablations (wrong results): 32 = no matrix segment, 16 = no softmax
+            if (!(p.knob & 4)) __builtin_amdgcn_s_setprio(0);       // (fencing this with sched_barrier(0) measured 2.5 % slower)
             if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t (issued one segment ago) has landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PP_TICK(0);
@@ -625,7 +640,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             PP_TICK(1);
             // Y(t): vector segment
             if (grp == 1) dma_pair(t + 1);
-            softmax();
+            if (!(TIMING && (p.knob & 16))) softmax();
             if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t has landed
             PP_TICK(2);
             PP_BAR();
