@@ -309,6 +309,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 //   tile's row SUM instead of a row max (30 fewer VALU per tile, yet 8.3 vs 7.9 ms); ONE barrier per tile with 3-deep K/V rings
 //   (group 0: X|B|Y, group 1: B|X|Y — nobody waits for the partner's longer segment): 8.54 vs 8.12 ms, the per-wave X+Y issue
 //   time (~3600 cycles per tile) did not change, only where the waiting happens; fragment prefetch depth 2/3/4: 7.95/7.89/7.92.
+//   Code generation is fragile here: a workgroup-uniform `if (knob) xseg(t)` around the matrix segment (for an ablation) made the
+//   whole kernel 60 % slower, fencing the closing s_setprio with sched_barrier(0) 2.5 % — so the TG_ATTN_TIMING build (which adds
+//   s_memtime reads and fences) is good for the RATIO of the segments, not for absolute cycles.
 // ------------------------------------------------------------------------------------------------
 #ifndef TG_ATTN_NFR
 #define TG_ATTN_NFR 3
@@ -631,7 +634,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             // the matrix segment runs at raised priority: its MFMA / ds_read issue slots are few (one per ~32 cycles) but each one the
             // partner's VALU stream delays idles the matrix pipe; measured -4..6 % (7.52 vs 7.94 ms same box); prio 1: -2 %, prio 3 = 2
             if (!(p.knob & 4)) __builtin_amdgcn_s_setprio(2);
-            if (!(TIMING && (p.knob & 32))) xseg(t);          // timing ablations (wrong results): 32 = no matrix segment, 16 = no softmax
+            xseg(t);
             if (!(p.knob & 4)) __builtin_amdgcn_s_setprio(0);       // (fencing this with sched_barrier(0) measured 2.5 % slower)
             if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t (issued one segment ago) has landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             PP_TICK(1);
             // Y(t): vector segment
             if (grp == 1) dma_pair(t + 1);
-            if (!(TIMING && (p.knob & 16))) softmax();
+            softmax();
             if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t has landed
             PP_TICK(2);
             PP_BAR();
