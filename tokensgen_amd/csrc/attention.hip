@@ -43,8 +43,7 @@ struct AttnParams {
     int nq, heads, batch;
     float scale_log2;   // softmax scale * log2(e)
     int prescaled;      // 1: K already carries scale*log2(e) (tg_qk_layernorm_rope out_scale): scores are log2-domain as produced
-    int knob;           // TG_ATTN_KNOB experiment bits (1: static s_setprio 1 for the second-dispatched wave group; 4: no raised
-                        // priority for the matrix segment)
+    int knob;           // TG_ATTN_KNOB experiment bits (1: static s_setprio 1 for the second-dispatched wave group)
     // "rider": a second, single-segment problem of the same heads/batch whose workgroups are appended to the launch (ping-pong
     // kernel only).  The main attention leaves 3360 - 13*256 = 32 workgroups for its last round of 256 CUs; the To2V block's
     // vip-query attention (96 workgroups of the same length) rides in that round instead of costing a launch of its own.
@@ -311,7 +310,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 //   time (~3600 cycles per tile) did not change, only where the waiting happens; fragment prefetch depth 2/3/4: 7.95/7.89/7.92.
 //   Code generation is fragile here: a workgroup-uniform `if (knob) xseg(t)` around the matrix segment (for an ablation) made the
 //   whole kernel 60 % slower, fencing the closing s_setprio with sched_barrier(0) 2.5 % — so the TG_ATTN_TIMING build (which adds
-//   s_memtime reads and fences) is good for the RATIO of the segments, not for absolute cycles.
+//   s_memtime reads and fences) is good for the RATIO of the segments, not for absolute cycles; one copy of the tile loop per wave
+//   group (no `if (grp == ..)` inside the loop) measured 6 % slower.
 // ------------------------------------------------------------------------------------------------
 #ifndef TG_ATTN_NFR
 #define TG_ATTN_NFR 3
@@ -633,9 +633,9 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             if (grp == 0) dma_pair(t);
             // the matrix segment runs at raised priority: its MFMA / ds_read issue slots are few (one per ~32 cycles) but each one the
             // partner's VALU stream delays idles the matrix pipe; measured -4..6 % (7.52 vs 7.94 ms same box); prio 1: -2 %, prio 3 = 2
-            if (!(p.knob & 4)) __builtin_amdgcn_s_setprio(2);
+            __builtin_amdgcn_s_setprio(2);
             xseg(t);
-            if (!(p.knob & 4)) __builtin_amdgcn_s_setprio(0);       // (fencing this with sched_barrier(0) measured 2.5 % slower)
+            __builtin_amdgcn_s_setprio(0);                         // (fencing this with sched_barrier(0) measured 2.5 % slower)
             if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t (issued one segment ago) has landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PP_TICK(0);
