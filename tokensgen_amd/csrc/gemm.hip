@@ -17,6 +17,7 @@
 //   * M edge: rows >= M are clamped on load and predicated on store.  N % 128 == 0, K % 64 == 0.
 #include <stdlib.h>
 
+#include <type_traits>
 #include "common.h"
 #include "tokensgen_hip.h"
 
@@ -343,10 +344,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         TG_BAR();
         if (grp == 1) TG_BAR();   // group 1 runs one barrier (= half a phase) behind group 0
 
-        for (int st = 0; st < nst; ++st) {
+        // steady part (st + 3 < nst: every `if (more)` is compile-time true -> a straight-line loop body without the eight
+        // wave-uniform branches per stage) + the last three stages through the generic body
+        auto kbody = [&](int st, auto steady_c) {
+            constexpr bool STEADY = decltype(steady_c)::value;
             const char* tA = smem + (st & (NS2 - 1)) * STAGE2_BYTES;
             const char* tW = tA + OPER2_BYTES;
-            const bool more = st + 3 < nst;
+            const bool more = STEADY || st + 3 < nst;
             // phase 0: rows [0,64) of this wave's half x all 64 columns
             loadW(tW);
             loadA(tA, 0);
@@ -358,6 +362,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
             TG_LOAD_END(more);
             TG_COMPUTE(1, 1, more);
             TG_BAR();
+        };
+        {
+            int st = 0;
+            for (; st + 3 < nst; ++st) kbody(st, std::true_type{});
+            for (; st < nst; ++st) kbody(st, std::false_type{});
         }
         if (grp == 0) TG_BAR();   // every wave is now past its last LDS read of this tile
 
