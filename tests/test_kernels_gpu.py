@@ -292,3 +292,28 @@ def test_attention_multi_rider_matches_separate_launches(K):
                                k2=qkvv[:, N1:, D:2 * D], vt2=vt2, nk2=NP, seg2_scale=0.6),
                           dict(q1=qkvv[:, N1:, :D], k1=qkvv[:, :, D:2 * D], vt1=vt3, nk1=N, out=b[:, N1:]), H, 0.125, k_prescaled=pre)
         assert torch.isfinite(b).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shift", [-400.0, -60.0, 90.0])
+def test_attention_prescaled_extreme_score_offsets(K, shift):
+    """Softmax is shift invariant: rows whose scores all sit far below (or above) zero in the log2 domain must come out like the
+    un-shifted rows.  -400 would underflow every weight if the running reference stayed at its initial 0; +90 overflows exp2 without
+    the max subtraction; a late spike exercises the upward rescale on top."""
+    B, H, nq, nk = 1, 8, 96, 640
+    torch.manual_seed(11)
+    q = torch.randn(B, nq, H * 64, device=DEV).to(torch.bfloat16)
+    k = (torch.randn(B, nk, H * 64, device=DEV) * 0.2).to(torch.bfloat16)
+    v = torch.randn(B, nk, H * 64, device=DEV).to(torch.bfloat16)
+    # add a component along a direction u that q carries with unit weight: every score of the row moves by `shift`
+    u = torch.zeros(64, device=DEV); u[7] = 1.0
+    qh = q.view(B, nq, H, 64).float(); qh[..., 7] = 1.0
+    kh = k.view(B, nk, H, 64).float(); kh[..., 7] = shift
+    kh[:, 500, :, :] += qh[:, 3, :, :] * 0.5                      # a late spike for one query
+    q, k = qh.view(B, nq, -1).to(torch.bfloat16), kh.view(B, nk, -1).to(torch.bfloat16)
+    ref = _sdpa_ref(q, k, v, H, 1.0 / 1.4426950408889634)         # scores are already in log2 units: softmax over s*ln2
+    vt = torch.empty(B, H, 64, nk, dtype=torch.bfloat16, device=DEV)
+    K.transpose_v(v, H, 0, nk, vt)
+    out = torch.empty(B, nq, H * 64, dtype=torch.bfloat16, device=DEV)
+    K.attention(q, k, vt, nk, out, H, 0.125, k_prescaled=True)
+    assert torch.isfinite(out).all()
+    assert _rel(out, ref) < 8e-3

@@ -396,10 +396,18 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         // PRESCALED seed operands: ones = 1.0 in k-slot 0 of every key row (lanes 0-31, element 0), negm[qb] = -m of the
         // lane's query row in k-slot 0; m is kept bf16-representable so the seed is exactly -m
         bf16x8 ones = {0, 0, 0, 0, 0, 0, 0, 0}, negm[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
-        if (hi == 0) ones[0] = (bf16_t)0x3F80;
+        if (hi == 0) {
+            ones[0] = (bf16_t)0x3F80;
+            if (PRESCALED) negm[0][0] = negm[1][0] = (bf16_t)0x4680;      // +2^14 = -m
+        }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            m[qb] = PRESCALED ? 0.f : -1e30f;   // PRESCALED seeds the accumulator with -m, so m must stay finite and small
+            // PRESCALED seeds the accumulator with -m, so m must stay finite and bf16-representable.  It starts at -2^14: the first
+            // tile then sees every score 2^14 above the reference and takes the ordinary (rare) rescale path, which sets m to the
+            // tile's true row max — upward OR downward, so rows whose scores all sit below -126 do not underflow to l = 0 — with no
+            // first-tile test in the hot loop (an explicit `t == 0` there cost 1.5-2 %).  Price: the first tile's 64 scores are
+            // formed as s + 2^14 in fp32, i.e. to 2^-9 absolute (0.14 % on their weights, below the bf16 rounding of P).
+            m[qb] = PRESCALED ? -16384.f : -1e30f;
             l[qb] = 0.f;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
