@@ -94,7 +94,9 @@ int tg_transpose_v(const void* v, long ld, long strideB, int key_start, int n_ke
  * Segment 2 is skipped when q2 == NULL.  k_prescaled=1: k1/k2 already carry scale*log2(e) (scale is ignored): the kernel
  * then seeds the score accumulator with -max and needs no per-element scale/subtract in its softmax.
  * Replaces the three F.scaled_dot_product_attention calls + `hs + scale*tv_hs` + head merge,
- * attention_processor.py:2066-2069,2117-2135,2141 (and :1937-1941 for the plain processor). */
+ * attention_processor.py:2066-2069,2117-2135,2141 (and :1937-1941 for the plain processor).  * Alignment: q/k/vt 16 B, their leading dimensions % 8 (vt_ld % 64); out 16 B with out_ld % 8 and out_strideB % 8 (whole 128-byte
+ * head rows are stored 16 B per lane).
+ */
 int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
                      const void* k1, long k1_ld, long k1_strideB, const void* vt1, long vt1_ld, int nk1,
                      const void* q2, long q2_ld, long q2_strideB,

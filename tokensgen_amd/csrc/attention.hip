@@ -320,7 +320,8 @@ __device__ long long tg_attn_dbg[16];   // TG_ATTN_TIMING: cycles {X work, X bar
 
 template <bool PRESCALED, bool TIMING = false>
 __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // K[2], Vt[2]
+    // K[2], Vt[2] tiles (32 KiB) + the output staging area: 8 waves x 64 query rows x 128 B (64 KiB)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr float RESCALE_THR = 8.0f;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -664,34 +665,46 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         if (grp == 0) PP_BAR();                                                    // barrier counts of the two groups meet again
         PP_BAR();                                                                  // all LDS reads of this segment done
 
-        // ---- segment epilogue (same as the 4-wave kernel) ----
+        // ---- segment epilogue: O through LDS so that every global access is a whole 128-byte row of this head.  A lane owns ONE query
+        // row in 8-byte pieces (4 d-values per accumulator group), which as direct stores touch 64 different lines per instruction;
+        // the wave's staging area [64 rows][128 B] (16-B slots XOR-swizzled by row&7) is written in that shape and read back as
+        // 8 lanes x 16 B per row.  With two key segments the normalised result of segment 1 simply WAITS there (no global write +
+        // read-modify-write as before): segment 2 adds its `seg2_scale * O2` on top (each lane re-reads exactly what it wrote).
+        char* stg = smem + 4 * TILE_B + wave * 8192;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
             const float w = (sg == 0 ? 1.f : p.seg2_scale) / lt;
-            const int q = q0 + qb * 32 + j;
-            if (q < nq_) {
-                bf16_t* op = out_ + (long)b * o_sb_ + (long)q * o_ld_ + h * 64;
+            const int row = qb * 32 + j;
 #pragma unroll
-                for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        uint2* dst = (uint2*)(op + db * 32 + g4 * 8 + hi * 4);
-                        float v0 = acc_o[qb][db][g4 * 4 + 0] * w, v1 = acc_o[qb][db][g4 * 4 + 1] * w;
-                        float v2 = acc_o[qb][db][g4 * 4 + 2] * w, v3 = acc_o[qb][db][g4 * 4 + 3] * w;
-                        if (sg > 0) {
-                            const uint2 prev = *dst;
-                            v0 = bf16lo_to_f32(prev.x) + round_bf16(v0); v1 = bf16hi_to_f32(prev.x) + round_bf16(v1);
-                            v2 = bf16lo_to_f32(prev.y) + round_bf16(v2); v3 = bf16hi_to_f32(prev.y) + round_bf16(v3);
-                        }
-                        uint2 o;
-                        o.x = pack_bf16x2(v0, v1);
-                        o.y = pack_bf16x2(v2, v3);
-                        *dst = o;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    uint2* dst = (uint2*)(stg + row * 128 + (((db * 4 + g4) ^ (row & 7)) << 4) + hi * 8);
+                    float v0 = acc_o[qb][db][g4 * 4 + 0] * w, v1 = acc_o[qb][db][g4 * 4 + 1] * w;
+                    float v2 = acc_o[qb][db][g4 * 4 + 2] * w, v3 = acc_o[qb][db][g4 * 4 + 3] * w;
+                    if (sg > 0) {     // `scale * O2` is a bf16 tensor before it is added to O1 (attention_processor.py:2117-2134)
+                        const uint2 prev = *dst;
+                        v0 = bf16lo_to_f32(prev.x) + round_bf16(v0); v1 = bf16hi_to_f32(prev.x) + round_bf16(v1);
+                        v2 = bf16lo_to_f32(prev.y) + round_bf16(v2); v3 = bf16hi_to_f32(prev.y) + round_bf16(v3);
                     }
+                    uint2 o;
+                    o.x = pack_bf16x2(v0, v1);
+                    o.y = pack_bf16x2(v2, v3);
+                    *dst = o;
+                }
+        }
+        if (sg + 1 == nseg_) {       // last segment: the staged rows go out, 8 rows (8 lanes x 16 B each) per instruction
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's own LDS writes (no other wave touches its area)
+            const int rl = lane >> 3, sl = lane & 7;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 8 + rl;
+                const int q = q0 + row;
+                const uint4 val = *(const uint4*)(stg + row * 128 + ((sl ^ (row & 7)) << 4));
+                if (q < nq_) *(uint4*)(out_ + (long)b * o_sb_ + (long)q * o_ld_ + h * 64 + sl * 8) = val;
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // segment-1 stores retired before segment 2's DMA accounting starts
     }
 #undef PP_BAR
 }
@@ -727,15 +740,23 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
     }
     p.main_wgs = (int)wg512;
     const long grid512 = wg512 + (p.r_nq > 0 ? (long)((p.r_nq + 511) / 512) * heads * batch : 0);
+    constexpr size_t PP_LDS = 4 * TILE_B + 8 * 8192;
+    static const bool pp_attr = [] {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        return true;
+    }();
+    (void)pp_attr;
     if (timing && p.prescaled && wg512 >= pp_min) {
-        hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true>), dim3((unsigned)grid512), dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true>), dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
         long long h[8];
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(tg_attn_dbg), sizeof(h));
         fprintf(stderr, "[tg_attention timing] g0: X %lld Xwait %lld Y %lld Ywait %lld | g1: X %lld Xwait %lld Y %lld Ywait %lld (s_memtime ticks, seg 0)\n",
                 h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     } else if (pp) {
-        if (p.prescaled) hipLaunchKernelGGL(attn_fwd_pp_kernel<true>, dim3((unsigned)grid512), dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL(attn_fwd_pp_kernel<false>, dim3((unsigned)grid512), dim3(512), 0, stream, p);
+        if (p.prescaled) hipLaunchKernelGGL(attn_fwd_pp_kernel<true>, dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
+        else hipLaunchKernelGGL(attn_fwd_pp_kernel<false>, dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
     } else if (wg256 >= 1024 && abl) {
         if (abl == 1) hipLaunchKernelGGL((attn_fwd_kernel<2, 1>), dim3((unsigned)wg256), dim3(256), 0, stream, p);
         else if (abl == 2) hipLaunchKernelGGL((attn_fwd_kernel<2, 2>), dim3((unsigned)wg256), dim3(256), 0, stream, p);
@@ -766,7 +787,7 @@ extern "C" int tg_attention_fwd_multi(const tg_attn_problem* problems, int nprob
     TG_REQUIRE(heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_attention_fwd_multi: bad shape");
     const tg_attn_problem& A = problems[0];
     TG_REQUIRE(A.out && A.nq > 0 && (A.nseg == 1 || A.nseg == 2), TG_ERR_ARG, "tg_attention_fwd_multi: problem 0");
-    TG_REQUIRE(A.out_ld % 4 == 0 && A.out_strideB % 4 == 0 && (((uintptr_t)A.out) & 7) == 0, TG_ERR_ALIGN, "tg_attention_fwd_multi: output alignment");
+    TG_REQUIRE(A.out_ld % 8 == 0 && A.out_strideB % 8 == 0 && tg_aligned16(A.out), TG_ERR_ALIGN, "tg_attention_fwd_multi: output alignment (16 B)");
     AttnParams p{};
     int rc = fill_segment(p.s[0], A.seg[0], "problem 0 segment 1");
     if (rc) return rc;
@@ -778,7 +799,7 @@ extern "C" int tg_attention_fwd_multi(const tg_attn_problem* problems, int nprob
     if (nproblems == 2) {
         const tg_attn_problem& B = problems[1];
         TG_REQUIRE(B.out && B.nq > 0 && B.nseg == 1, TG_ERR_ARG, "tg_attention_fwd_multi: problem 1 must have one key segment");
-        TG_REQUIRE(B.out_ld % 4 == 0 && B.out_strideB % 4 == 0 && (((uintptr_t)B.out) & 7) == 0, TG_ERR_ALIGN, "tg_attention_fwd_multi: output alignment");
+        TG_REQUIRE(B.out_ld % 8 == 0 && B.out_strideB % 8 == 0 && tg_aligned16(B.out), TG_ERR_ALIGN, "tg_attention_fwd_multi: output alignment (16 B)");
         if ((rc = fill_segment(p.r_s, B.seg[0], "problem 1"))) return rc;
         p.r_out = (bf16_t*)B.out; p.r_o_ld = B.out_ld; p.r_o_sb = B.out_strideB; p.r_nq = B.nq;
     }
