@@ -33,8 +33,11 @@ PROFILE_ON = [False]
 PROFILE = {}
 
 
+PROFILE_FILTER = [None]      # None: time every launch; a set of names: only those (fewer event markers in a timed region)
+
+
 def _launch(name, fn, *args):
-    if not PROFILE_ON[0]:
+    if not PROFILE_ON[0] or (PROFILE_FILTER[0] is not None and name not in PROFILE_FILTER[0]):
         return fn(*args)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
