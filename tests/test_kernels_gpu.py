@@ -340,3 +340,20 @@ def test_attention_repeatable_bitwise(K):
     assert all(torch.equal(outs[0], o) for o in outs[1:])
     ref = _sdpa_ref(q1, k1, v1, H, 0.125) + 0.6 * _sdpa_ref(q2, k2, v2, H, 0.125)
     assert _rel(outs[0], ref) < 8e-3
+
+
+def test_gemm256_repeatable_bitwise(K):
+    """Race screen for the 256x256 ping-pong GEMM (4-deep LDS-DMA ring, counted vmcnt): several tiles per CU, ragged last m-tile,
+    K long enough for the steady-state loop; 5 launches, bitwise identical, and right against fp32 torch."""
+    from tokensgen_amd import lib as L
+    B, M, N, Kd = 2, 2300, 512, 1536
+    a, w, bias = _rand(B, M, Kd, seed=21), _rand(N, Kd, seed=22, scale=0.05), _rand(N, seed=23)
+    outs = []
+    for _ in range(5):
+        out = torch.empty(B, M, N, dtype=torch.bfloat16, device=DEV)
+        K.gemm(a, w, bias, out, L.EPI_BIAS_GELU)
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    ref = torch.nn.functional.gelu((a.float() @ w.float().t() + bias.float()).to(torch.bfloat16).float(), approximate="tanh")
+    assert _rel(outs[0], ref) < 6e-3
