@@ -81,6 +81,15 @@ int tg_qk_layernorm_rope(void* x, long ld, long strideB, int tokens, int heads, 
                          int start0, int len0, const float* cos0, const float* sin0,
                          int start1, int len1, const float* cos1, const float* sin1, float out_scale, hipStream_t stream);
 
+/* The same for the q AND the k columns of the same rows in one launch (both in the same fused buffer: same ld / strideB), each with
+ * its own LayerNorm affine (norm_q / norm_k) and output scale: the rotary table slices, four times the size of the data they
+ * rotate, are fetched once for the pair. */
+int tg_qk_layernorm_rope_pair(void* xq, void* xk, long ld, long strideB, int tokens, int heads, int batch,
+                              const void* q_weight, const void* q_bias, const void* k_weight, const void* k_bias, float eps,
+                              int start0, int len0, const float* cos0, const float* sin0,
+                              int start1, int len1, const float* cos1, const float* sin1, float q_scale, float k_scale,
+                              hipStream_t stream);
+
 /* vt[b][h][d][j] = v[b*strideB + (key_start + j)*ld + h*64 + d] for j < n_keys, zero for n_keys <= j < ldvt.
  * Lays V out key-contiguous so the PV MFMA operands are plain 16-byte LDS reads (the "transpose" that
  * F.scaled_dot_product_attention does internally).  ldvt % 64 == 0, ldvt >= n_keys. */

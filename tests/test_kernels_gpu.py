@@ -357,3 +357,20 @@ def test_gemm256_repeatable_bitwise(K):
     assert all(torch.equal(outs[0], o) for o in outs[1:])
     ref = torch.nn.functional.gelu((a.float() @ w.float().t() + bias.float()).to(torch.bfloat16).float(), approximate="tanh")
     assert _rel(outs[0], ref) < 6e-3
+
+
+def test_qk_layernorm_rope_pair_equals_two_single_launches(K):
+    """tg_qk_layernorm_rope_pair (q and k columns of the fused buffer in one launch, tables read once) is bitwise the two single calls."""
+    from oracle import dit_ref as O
+    B, T, H = 2, 50, 3
+    buf = _rand(B, T, 3 * H * 64, seed=1)
+    wq, bq = _rand(64, seed=2, scale=0.1) + 1, _rand(64, seed=3, scale=0.1)
+    wk, bk = _rand(64, seed=4, scale=0.1) + 1, _rand(64, seed=5, scale=0.1)
+    f32 = np.float32
+    c0 = tuple(t.to(DEV).contiguous() for t in O.rope_3d(64, np.arange(2, dtype=f32), np.arange(3, dtype=f32), np.arange(4, dtype=f32)))
+    c1 = tuple(t.to(DEV).contiguous() for t in O.rope_3d(64, np.linspace(1000, 1003, 2, dtype=f32), np.arange(2, dtype=f32), np.arange(3, dtype=f32)))
+    a, b = buf.clone(), buf.clone()
+    K.qk_layernorm_rope(a[:, :, :H * 64], H, wq, bq, 1e-6, (8, c0), (34, c1))
+    K.qk_layernorm_rope(a[:, :, H * 64:2 * H * 64], H, wk, bk, 1e-6, (8, c0), (34, c1), out_scale=0.18033688)
+    K.qk_layernorm_rope_pair(b[:, :, :H * 64], b[:, :, H * 64:2 * H * 64], H, wq, bq, wk, bk, 1e-6, (8, c0), (34, c1), k_scale=0.18033688)
+    assert torch.equal(a, b) and not torch.equal(a[:, :, :2 * H * 64], buf[:, :, :2 * H * 64])

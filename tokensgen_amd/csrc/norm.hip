@@ -91,23 +91,9 @@ __global__ __launch_bounds__(256) void adaln_kernel(const bf16_t* __restrict__ x
 // per-head LayerNorm(64) + RoPE, in place  (attention_processor.py:2031-2056, embeddings.py:866-885)
 // 8 lanes per (token, head) row, 8 elements (16 B) per lane.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ x, long ld, long sb, int tokens,
-                                                           int heads, int batch, const bf16_t* __restrict__ w,
-                                                           const bf16_t* __restrict__ bvec, float eps,
-                                                           int start0, int len0, const float* __restrict__ cos0,
-                                                           const float* __restrict__ sin0, int start1, int len1,
-                                                           const float* __restrict__ cos1,
-                                                           const float* __restrict__ sin1, float out_scale) {
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const int part = (int)(gid & 7);
-    const long rowid = gid >> 3;                       // (b, t, h)
-    const long total = (long)batch * tokens * heads;
-    const bool live = rowid < total;
-    const long rid = live ? rowid : total - 1;
-    const int h = (int)(rid % heads);
-    const long bt = rid / heads;
-    const int t = (int)(bt % tokens), b = (int)(bt / tokens);
-    bf16_t* p = x + (long)b * sb + (long)t * ld + h * 64 + part * 8;
+// one (token, head) slice of 8 elements per lane: LayerNorm over the 8-lane group, affine, bf16 rounding, RoPE, scale, store
+__device__ __forceinline__ void qk_norm_rope_slice(bf16_t* p, const bf16_t* __restrict__ w, const bf16_t* __restrict__ bvec, int part,
+                                                   float eps, bool rope, const float (&c)[8], const float (&sv)[8], float out_scale, bool live) {
     const uint4 raw = *(const uint4*)p;
     const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
     float v[8];
@@ -132,20 +118,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
         v[2 * i] = round_bf16((v[2 * i] - mean) * rstd * bf16lo_to_f32(wu[i]) + bf16lo_to_f32(bu[i]));
         v[2 * i + 1] = round_bf16((v[2 * i + 1] - mean) * rstd * bf16hi_to_f32(wu[i]) + bf16hi_to_f32(bu[i]));
     }
-    const float* cs = nullptr;
-    const float* sn = nullptr;
-    if (t >= start0 && t < start0 + len0) {
-        cs = cos0 + (long)(t - start0) * 64 + part * 8;
-        sn = sin0 + (long)(t - start0) * 64 + part * 8;
-    } else if (t >= start1 && t < start1 + len1) {
-        cs = cos1 + (long)(t - start1) * 64 + part * 8;
-        sn = sin1 + (long)(t - start1) * 64 + part * 8;
-    }
-    if (cs) {
-        const float4 c0 = *(const float4*)cs, c1 = *(const float4*)(cs + 4);
-        const float4 s0 = *(const float4*)sn, s1 = *(const float4*)(sn + 4);
-        const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-        const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    if (rope) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {   // out = x*cos + rot(x)*sin, rot(x) = (-x1, x0) per pair
             const float a = v[2 * i], bb = v[2 * i + 1];
@@ -161,6 +134,46 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
         o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
         *(uint4*)p = o;
     }
+}
+
+// x2 != nullptr: the k columns of the same rows get the same treatment in the same launch (their own affine and scale): the
+// rotary table slice (64 B per lane, 4x the size of the data slice) is fetched once for q and k
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ x, bf16_t* __restrict__ x2, long ld, long sb, int tokens,
+                                                           int heads, int batch, const bf16_t* __restrict__ w,
+                                                           const bf16_t* __restrict__ bvec, const bf16_t* __restrict__ w2,
+                                                           const bf16_t* __restrict__ bvec2, float eps,
+                                                           int start0, int len0, const float* __restrict__ cos0,
+                                                           const float* __restrict__ sin0, int start1, int len1,
+                                                           const float* __restrict__ cos1,
+                                                           const float* __restrict__ sin1, float out_scale, float out_scale2) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int part = (int)(gid & 7);
+    const long rowid = gid >> 3;                       // (b, t, h)
+    const long total = (long)batch * tokens * heads;
+    const bool live = rowid < total;
+    const long rid = live ? rowid : total - 1;
+    const int h = (int)(rid % heads);
+    const long bt = rid / heads;
+    const int t = (int)(bt % tokens), b = (int)(bt / tokens);
+    const float* cs = nullptr;
+    const float* sn = nullptr;
+    if (t >= start0 && t < start0 + len0) {
+        cs = cos0 + (long)(t - start0) * 64 + part * 8;
+        sn = sin0 + (long)(t - start0) * 64 + part * 8;
+    } else if (t >= start1 && t < start1 + len1) {
+        cs = cos1 + (long)(t - start1) * 64 + part * 8;
+        sn = sin1 + (long)(t - start1) * 64 + part * 8;
+    }
+    float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (cs) {
+        const float4 c0 = *(const float4*)cs, c1 = *(const float4*)(cs + 4);
+        const float4 s0 = *(const float4*)sn, s1 = *(const float4*)(sn + 4);
+        c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+        sv[0] = s0.x; sv[1] = s0.y; sv[2] = s0.z; sv[3] = s0.w; sv[4] = s1.x; sv[5] = s1.y; sv[6] = s1.z; sv[7] = s1.w;
+    }
+    const long off = (long)b * sb + (long)t * ld + h * 64 + part * 8;
+    qk_norm_rope_slice(x + off, w, bvec, part, eps, cs != nullptr, c, sv, out_scale, live);
+    if (x2) qk_norm_rope_slice(x2 + off, w2, bvec2, part, eps, cs != nullptr, c, sv, out_scale2, live);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -227,25 +240,43 @@ extern "C" int tg_adaln_modulate(const void* x, long ldx, long strideX, void* y,
     return TG_OK;
 }
 
-extern "C" int tg_qk_layernorm_rope(void* x, long ld, long strideB, int tokens, int heads, int batch,
-                                    const void* ln_weight, const void* ln_bias, float eps,
-                                    int start0, int len0, const float* cos0, const float* sin0,
-                                    int start1, int len1, const float* cos1, const float* sin1, float out_scale,
-                                    hipStream_t stream) {
-    TG_REQUIRE(x && ln_weight && ln_bias, TG_ERR_ARG, "tg_qk_layernorm_rope: null pointer");
+static int qk_norm_rope_launch(void* xq, void* xk, long ld, long strideB, int tokens, int heads, int batch, const void* wq, const void* bq,
+                               const void* wk, const void* bk, float eps, int start0, int len0, const float* cos0, const float* sin0,
+                               int start1, int len1, const float* cos1, const float* sin1, float q_scale, float k_scale, hipStream_t stream) {
+    TG_REQUIRE(xq && wq && bq && (!xk || (wk && bk)), TG_ERR_ARG, "tg_qk_layernorm_rope: null pointer");
     TG_REQUIRE(tokens > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_qk_layernorm_rope: bad shape");
-    TG_REQUIRE(ld % 8 == 0 && strideB % 8 == 0 && tg_aligned16(x), TG_ERR_ALIGN, "tg_qk_layernorm_rope: rows must be 16-byte aligned");
+    TG_REQUIRE(ld % 8 == 0 && strideB % 8 == 0 && tg_aligned16(xq) && (!xk || tg_aligned16(xk)), TG_ERR_ALIGN,
+               "tg_qk_layernorm_rope: rows must be 16-byte aligned");
     TG_REQUIRE((len0 == 0 || (cos0 && sin0 && tg_aligned16(cos0) && tg_aligned16(sin0))) &&
                (len1 == 0 || (cos1 && sin1 && tg_aligned16(cos1) && tg_aligned16(sin1))), TG_ERR_ARG,
                "tg_qk_layernorm_rope: rope tables missing or unaligned");
     TG_REQUIRE(len0 >= 0 && len1 >= 0 && start0 >= 0 && start1 >= 0 && start0 + len0 <= tokens && start1 + len1 <= tokens,
                TG_ERR_SHAPE, "tg_qk_layernorm_rope: rope segment outside the token range");
     const long threads = (long)batch * tokens * heads * 8;
-    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (bf16_t*)x, ld,
-                       strideB, tokens, heads, batch, (const bf16_t*)ln_weight, (const bf16_t*)ln_bias, eps, start0, len0,
-                       cos0, sin0, start1, len1, cos1, sin1, out_scale);
+    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (bf16_t*)xq, (bf16_t*)xk, ld,
+                       strideB, tokens, heads, batch, (const bf16_t*)wq, (const bf16_t*)bq, (const bf16_t*)wk, (const bf16_t*)bk, eps,
+                       start0, len0, cos0, sin0, start1, len1, cos1, sin1, q_scale, k_scale);
     TG_LAUNCH_CHECK("tg_qk_layernorm_rope");
     return TG_OK;
+}
+
+extern "C" int tg_qk_layernorm_rope(void* x, long ld, long strideB, int tokens, int heads, int batch,
+                                    const void* ln_weight, const void* ln_bias, float eps,
+                                    int start0, int len0, const float* cos0, const float* sin0,
+                                    int start1, int len1, const float* cos1, const float* sin1, float out_scale,
+                                    hipStream_t stream) {
+    return qk_norm_rope_launch(x, nullptr, ld, strideB, tokens, heads, batch, ln_weight, ln_bias, nullptr, nullptr, eps, start0, len0, cos0, sin0,
+                               start1, len1, cos1, sin1, out_scale, 1.f, stream);
+}
+
+extern "C" int tg_qk_layernorm_rope_pair(void* xq, void* xk, long ld, long strideB, int tokens, int heads, int batch,
+                                         const void* q_weight, const void* q_bias, const void* k_weight, const void* k_bias, float eps,
+                                         int start0, int len0, const float* cos0, const float* sin0,
+                                         int start1, int len1, const float* cos1, const float* sin1, float q_scale, float k_scale,
+                                         hipStream_t stream) {
+    TG_REQUIRE(xk, TG_ERR_ARG, "tg_qk_layernorm_rope_pair: null pointer");
+    return qk_norm_rope_launch(xq, xk, ld, strideB, tokens, heads, batch, q_weight, q_bias, k_weight, k_bias, eps, start0, len0, cos0, sin0,
+                               start1, len1, cos1, sin1, q_scale, k_scale, stream);
 }
 
 extern "C" int tg_transpose_v(const void* v, long ld, long strideB, int key_start, int n_keys, int heads, int batch,

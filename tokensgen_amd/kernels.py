@@ -143,6 +143,27 @@ def qk_layernorm_rope(x, heads, ln_weight, ln_bias, eps, seg0=None, seg1=None, o
     return x
 
 
+def qk_layernorm_rope_pair(xq, xk, heads, q_weight, q_bias, k_weight, k_bias, eps, seg0=None, seg1=None, q_scale=1.0, k_scale=1.0):
+    """qk_layernorm_rope on the q and the k column slices of the same fused buffer in one launch (rotary tables read once)."""
+    _chk(xq, "xq"); _chk(xk, "xk")
+    B, T, HD, ld, sb = _bmk(xq)
+    assert HD == heads * 64 and _bmk(xk) == (B, T, HD, ld, sb)
+
+    def unpack(seg):
+        if seg is None:
+            return 0, 0, None, None
+        start, (cos, sin) = seg
+        _chk(cos, "cos", torch.float32); _chk(sin, "sin", torch.float32)
+        assert cos.is_contiguous() and sin.is_contiguous() and cos.shape[-1] == 64
+        return int(start), int(cos.shape[0]), cos, sin
+    s0, l0, c0, n0 = unpack(seg0)
+    s1, l1, c1, n1 = unpack(seg1)
+    L.check(_launch("qk_layernorm_rope_pair", L.load().tg_qk_layernorm_rope_pair, _p(xq), _p(xk), ld, sb, T, heads, B, _p(q_weight), _p(q_bias),
+                    _p(k_weight), _p(k_bias), float(eps), s0, l0, _p(c0), _p(n0), s1, l1, _p(c1), _p(n1), float(q_scale), float(k_scale),
+                    _stream()), "tg_qk_layernorm_rope_pair")
+    return xq, xk
+
+
 def transpose_v(v, heads, key_start, n_keys, vt):
     """vt [B,heads,64,ldvt] <- v[:, key_start:key_start+n_keys] (v is a [B,T,heads*64] column slice)."""
     _chk(v, "v"); _chk(vt, "vt")
