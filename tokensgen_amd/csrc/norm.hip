@@ -138,6 +138,7 @@ __device__ __forceinline__ void qk_norm_rope_slice(bf16_t* p, const bf16_t* __re
 
 // x2 != nullptr: the k columns of the same rows get the same treatment in the same launch (their own affine and scale): the
 // rotary table slice (64 B per lane, 4x the size of the data slice) is fetched once for q and k
+template <int HPG>   // heads per 8-lane group: the token's table slice stays in registers while the group walks HPG heads
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ x, bf16_t* __restrict__ x2, long ld, long sb, int tokens,
                                                            int heads, int batch, const bf16_t* __restrict__ w,
                                                            const bf16_t* __restrict__ bvec, const bf16_t* __restrict__ w2,
@@ -148,12 +149,13 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
                                                            const float* __restrict__ sin1, float out_scale, float out_scale2) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const int part = (int)(gid & 7);
-    const long rowid = gid >> 3;                       // (b, t, h)
-    const long total = (long)batch * tokens * heads;
+    const long rowid = gid >> 3;                       // (b, t, head group)
+    const int hgroups = heads / HPG;
+    const long total = (long)batch * tokens * hgroups;
     const bool live = rowid < total;
     const long rid = live ? rowid : total - 1;
-    const int h = (int)(rid % heads);
-    const long bt = rid / heads;
+    const int h0 = (int)(rid % hgroups) * HPG;
+    const long bt = rid / hgroups;
     const int t = (int)(bt % tokens), b = (int)(bt / tokens);
     const float* cs = nullptr;
     const float* sn = nullptr;
@@ -171,9 +173,12 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
         c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
         sv[0] = s0.x; sv[1] = s0.y; sv[2] = s0.z; sv[3] = s0.w; sv[4] = s1.x; sv[5] = s1.y; sv[6] = s1.z; sv[7] = s1.w;
     }
-    const long off = (long)b * sb + (long)t * ld + h * 64 + part * 8;
-    qk_norm_rope_slice(x + off, w, bvec, part, eps, cs != nullptr, c, sv, out_scale, live);
-    if (x2) qk_norm_rope_slice(x2 + off, w2, bvec2, part, eps, cs != nullptr, c, sv, out_scale2, live);
+#pragma unroll
+    for (int hh = 0; hh < HPG; ++hh) {
+        const long off = (long)b * sb + (long)t * ld + (h0 + hh) * 64 + part * 8;
+        qk_norm_rope_slice(x + off, w, bvec, part, eps, cs != nullptr, c, sv, out_scale, live);
+        if (x2) qk_norm_rope_slice(x2 + off, w2, bvec2, part, eps, cs != nullptr, c, sv, out_scale2, live);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -252,10 +257,14 @@ static int qk_norm_rope_launch(void* xq, void* xk, long ld, long strideB, int to
                "tg_qk_layernorm_rope: rope tables missing or unaligned");
     TG_REQUIRE(len0 >= 0 && len1 >= 0 && start0 >= 0 && start1 >= 0 && start0 + len0 <= tokens && start1 + len1 <= tokens,
                TG_ERR_SHAPE, "tg_qk_layernorm_rope: rope segment outside the token range");
-    const long threads = (long)batch * tokens * heads * 8;
-    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (bf16_t*)xq, (bf16_t*)xk, ld,
-                       strideB, tokens, heads, batch, (const bf16_t*)wq, (const bf16_t*)bq, (const bf16_t*)wk, (const bf16_t*)bk, eps,
-                       start0, len0, cos0, sin0, start1, len1, cos1, sin1, q_scale, k_scale);
+    const int hpg = heads % 4 == 0 ? 4 : heads % 2 == 0 ? 2 : 1;
+    const long threads = (long)batch * tokens * (heads / hpg) * 8;
+#define TG_QK_LAUNCH(H_)                                                                                                                 \
+    hipLaunchKernelGGL(qk_norm_rope_kernel<H_>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (bf16_t*)xq, (bf16_t*)xk, ld, \
+                       strideB, tokens, heads, batch, (const bf16_t*)wq, (const bf16_t*)bq, (const bf16_t*)wk, (const bf16_t*)bk, eps,     \
+                       start0, len0, cos0, sin0, start1, len1, cos1, sin1, q_scale, k_scale)
+    if (hpg == 4) TG_QK_LAUNCH(4); else if (hpg == 2) TG_QK_LAUNCH(2); else TG_QK_LAUNCH(1);
+#undef TG_QK_LAUNCH
     TG_LAUNCH_CHECK("tg_qk_layernorm_rope");
     return TG_OK;
 }
