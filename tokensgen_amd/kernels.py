@@ -184,8 +184,8 @@ def attention(q1, k1, vt1, nk1, out, heads, scale, q2=None, k2=None, vt2=None, n
         _chk(q2, "q2"); _chk(k2, "k2"); _chk(vt2, "vt2")
         _, _, _, q2ld, q2sb = _bmk(q2)
         _, _, _, k2ld, k2sb = _bmk(k2)
-        a2 = (_p(q2), q2ld, q2sb, _p(k2), k2ld, k2sb, _p(vt2), vt2.shape[3], nk2)
-    L.check(_launch("attention_2seg" if q2 is not None else f"attention_1seg_nq{nq}", L.load().tg_attention_fwd, _p(q1), qld, qsb, _p(k1), kld, ksb, _p(vt1), vt1.shape[3], nk1, *a2, float(seg2_scale),
+        a2 = (_p(q2), q2ld, q2sb, _p(k2), k2ld, k2sb, _p(vt2), vt2.stride(2), nk2)
+    L.check(_launch("attention_2seg" if q2 is not None else f"attention_1seg_nq{nq}", L.load().tg_attention_fwd, _p(q1), qld, qsb, _p(k1), kld, ksb, _p(vt1), vt1.stride(2), nk1, *a2, float(seg2_scale),
                                       _p(out), old, osb, nq, heads, B, float(scale), 1 if k_prescaled else 0, _stream()), "tg_attention_fwd")
     return out
 
@@ -198,13 +198,13 @@ def _attn_problem(q1, k1, vt1, nk1, out, q2=None, k2=None, vt2=None, nk2=0, seg2
     B, nq, _, qld, qsb = _bmk(q1)
     _, _, _, kld, ksb = _bmk(k1)
     _, _, _, old, osb = _bmk(out)
-    pr.seg[0] = L.AttnSegment(_p(q1), qld, qsb, _p(k1), kld, ksb, _p(vt1), vt1.shape[3], nk1)
+    pr.seg[0] = L.AttnSegment(_p(q1), qld, qsb, _p(k1), kld, ksb, _p(vt1), vt1.stride(2), nk1)
     pr.nseg = 1
     if q2 is not None:
         _chk(q2, "q2"); _chk(k2, "k2"); _chk(vt2, "vt2")
         _, _, _, q2ld, q2sb = _bmk(q2)
         _, _, _, k2ld, k2sb = _bmk(k2)
-        pr.seg[1] = L.AttnSegment(_p(q2), q2ld, q2sb, _p(k2), k2ld, k2sb, _p(vt2), vt2.shape[3], nk2)
+        pr.seg[1] = L.AttnSegment(_p(q2), q2ld, q2sb, _p(k2), k2ld, k2sb, _p(vt2), vt2.stride(2), nk2)
         pr.nseg = 2
     pr.seg2_scale = float(seg2_scale)
     pr.out, pr.out_ld, pr.out_strideB, pr.nq = _p(out), old, osb, nq

@@ -467,14 +467,17 @@ class CogVideoXTransformer3DModel(nn.Module):
             vqn = F[p + "vqknorm"]
             K.qk_layernorm_rope_pair(ws.QKVv[:, :, :D], ws.QKVv[:, :, D:2 * D], H, vqn[0], vqn[1], vqn[2], vqn[3], 1e-6, (Nt, vrope),
                                      (N1, crope), k_scale=kscale)
-            K.transpose_v(ws.QKVv[:, :, 2 * D:], H, N1, Np, ws.Vt2)
             K.transpose_v(ws.QKVv[:, :, 2 * D:], H, 0, N, ws.Vt3)
+            if N1 % 8 == 0:
+                vt2 = ws.Vt3[:, :, :, N1:]     # V^T of the vip keys = the tail columns of the all-keys image (16-B aligned start;
+            else:                              # its zero padding out to a multiple of 64 keys is the image's own)
+                vt2 = K.transpose_v(ws.QKVv[:, :, 2 * D:], H, N1, Np, ws.Vt2)
             s = blk.attn1.processor.scale
             s = float(s[0] if isinstance(s, (list, tuple)) else s)
             # text+video rows: softmax(q k^T) v  +  s * softmax(qx kv^T) vv   (attention_processor.py:2066-2069,2117-2134)
             # vip rows: qv against cat(kx, kv) / cat(vx, vv)                  (:2120-2125) — rides in the main launch's last round
             K.attention_multi(dict(q1=ws.QKV[:, :, :D], k1=ws.QKV[:, :, D:2 * D], vt1=ws.Vt1, nk1=N1, out=ws.AO[:, :N1],
-                                   q2=ws.QKVv[:, :N1, :D], k2=ws.QKVv[:, N1:, D:2 * D], vt2=ws.Vt2, nk2=Np, seg2_scale=s),
+                                   q2=ws.QKVv[:, :N1, :D], k2=ws.QKVv[:, N1:, D:2 * D], vt2=vt2, nk2=Np, seg2_scale=s),
                               dict(q1=ws.QKVv[:, N1:, :D], k1=ws.QKVv[:, :, D:2 * D], vt1=ws.Vt3, nk1=N, out=ws.AO[:, N1:]),
                               H, sm_scale, k_prescaled=True)
         else:
