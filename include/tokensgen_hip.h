@@ -138,6 +138,16 @@ int tg_attention_fwd_multi(const tg_attn_problem* problems, int nproblems, int h
  * (flip_sin_to_cos=True, freq_shift=0).  Replaces embeddings.py:28-79 + dit:678.  t: int64[n]. */
 int tg_timestep_sinusoid(const int64_t* t, int n, int dim, void* emb, hipStream_t stream);
 
+/* 3-D rotary position tables on the device: cos/sin [T*H*W][dim_t+dim_h+dim_w] fp32, tokens ordered (t,h,w), channels [t|h|w],
+ * every pair frequency repeated for its two channels (get_3d_rotary_pos_embed_v2 / get_1d_rotary_pos_embed, embeddings.py:641-707,
+ * 774-828, which the reference rebuilds on the CPU and uploads for every window, cogvideo_sampling_mp_fifo.py:478-489).
+ * pos_t/h/w: fp32 positions per axis (device); inv_t/h/w: the inverse frequencies theta^(-2i/dim) of each axis, dim/2 of them
+ * (device, computed once on the host with the reference's expression).  angle = pos * inv in fp32 like the host, so the tables equal the host ones up to
+ * the device cosf/sinf (<= 2 ulp). */
+int tg_rope_table_3d(const float* pos_t, int T, const float* pos_h, int H, const float* pos_w, int W,
+                     const float* inv_t, int dim_t, const float* inv_h, int dim_h, const float* inv_w, int dim_w,
+                     float* cos_out, float* sin_out, hipStream_t stream);
+
 /* Gather p x p patches (p = 2: To2V model; p = 1: the T2To model, train_cogvideo_t2to.py:1277):
  *   out[(b f)(h/p w/p)][ldo][c*p*p + dy*p + dx] = lat[b][f][c][p*y+dy][p*x+dx]
  * (the im2col of Conv2d(k=p,s=p), embeddings.py:516-523) so that patch embedding is one GEMM with K = p*p*C;

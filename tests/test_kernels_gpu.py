@@ -374,3 +374,19 @@ def test_qk_layernorm_rope_pair_equals_two_single_launches(K):
     K.qk_layernorm_rope(a[:, :, H * 64:2 * H * 64], H, wk, bk, 1e-6, (8, c0), (34, c1), out_scale=0.18033688)
     K.qk_layernorm_rope_pair(b[:, :, :H * 64], b[:, :, H * 64:2 * H * 64], H, wq, bq, wk, bk, 1e-6, (8, c0), (34, c1), k_scale=0.18033688)
     assert torch.equal(a, b) and not torch.equal(a[:, :, :2 * H * 64], buf[:, :, :2 * H * 64])
+
+
+def test_rope_tables_on_device_match_host():
+    """tg_rope_table_3d against the host tables (which are bit-exact to the reference's, tests/test_oracle_golden.py): FIFO-style grids
+    incl. the condensed-token positions around 1000 and the T2To 52/6/6 split; only the device cosf/sinf differ."""
+    from tokensgen_amd import rope as R
+    f32 = np.float32
+    cases = [(64, np.arange(13, dtype=f32) + 39, np.arange(30, dtype=f32), np.arange(45, dtype=f32), None),
+             (64, np.linspace(1000, 1016.25, 5, dtype=f32), np.linspace(0, 30, 8, endpoint=False, dtype=f32), np.linspace(0, 45, 12, endpoint=False, dtype=f32), None),
+             (64, np.arange(96, dtype=f32), np.arange(8, dtype=f32), np.arange(12, dtype=f32), (52, 6, 6))]
+    for hd, gt, gh, gw, dims in cases:
+        kw = {} if dims is None else dict(dim_t=dims[0], dim_h=dims[1], dim_w=dims[2])
+        hc, hs = R.rope_3d(hd, gt, gh, gw, **kw)
+        dc, ds = R.rope_3d(hd, gt, gh, gw, device=DEV, **kw)
+        assert dc.shape == hc.shape and dc.is_cuda
+        assert (dc.cpu() - hc).abs().max().item() < 2e-6 and (ds.cpu() - hs).abs().max().item() < 2e-6

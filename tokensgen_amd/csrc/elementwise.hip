@@ -48,6 +48,32 @@ __global__ void unpatchify_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t
     lat[idx] = x[tok * ldx + c * p * p + (yy % p) * p + (xx % p)];
 }
 
+// 3-D rotary tables on the device (embeddings.py:641-707 / 774-828): token (t,h,w), channel segments [t | h | w] of widths
+// 2*nt, 2*nh, 2*nw; pair i of a segment uses angle = pos * inv[i] (one fp32 product, as torch.outer on the host), cos/sin repeated
+// for the two channels of the pair.  inv_* come from the host (same torch expression as the reference), so only cosf/sinf differ
+// from the host tables, by <= 2 ulp.
+__global__ void rope_table_3d_kernel(const float* __restrict__ pos_t, int T, const float* __restrict__ pos_h, int H,
+                                     const float* __restrict__ pos_w, int W, const float* __restrict__ inv_t, int nt,
+                                     const float* __restrict__ inv_h, int nh, const float* __restrict__ inv_w, int nw,
+                                     float* __restrict__ cos_out, float* __restrict__ sin_out) {
+    const int pairs = nt + nh + nw;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)T * H * W * pairs;
+    if (idx >= total) return;
+    const int pi = (int)(idx % pairs);
+    long tok = idx / pairs;
+    const int w = (int)(tok % W); const long q = tok / W;
+    const int h = (int)(q % H), t = (int)(q / H);
+    float ang;
+    if (pi < nt) ang = pos_t[t] * inv_t[pi];
+    else if (pi < nt + nh) ang = pos_h[h] * inv_h[pi - nt];
+    else ang = pos_w[w] * inv_w[pi - nt - nh];
+    const float c = cosf(ang), sn = sinf(ang);
+    const long o = tok * (2L * pairs) + 2 * pi;
+    *(float2*)(cos_out + o) = float2{c, c};
+    *(float2*)(sin_out + o) = float2{sn, sn};
+}
+
 // coef row: {sa, sb, m1, m2, m3, m4, mn, has_old}
 __global__ void cfg_dpm_step_kernel(const bf16_t* __restrict__ mo, const bf16_t* __restrict__ x,
                                     const bf16_t* __restrict__ old_x0, const bf16_t* __restrict__ noise,
@@ -191,5 +217,19 @@ extern "C" int tg_pca_inverse(const void* lat, const float* std16, const float* 
     hipLaunchKernelGGL(pca_inverse_kernel<16>, dim3((unsigned)frames, (unsigned)((cout + 63) / 64)), dim3(256), (size_t)16 * hw * 4, stream,
                        (const bf16_t*)lat, std16, mean16, comp, pmean, (bf16_t*)out, hw, cout);
     TG_LAUNCH_CHECK("tg_pca_inverse");
+    return TG_OK;
+}
+
+extern "C" int tg_rope_table_3d(const float* pos_t, int T, const float* pos_h, int H, const float* pos_w, int W,
+                                const float* inv_t, int dim_t, const float* inv_h, int dim_h, const float* inv_w, int dim_w,
+                                float* cos_out, float* sin_out, hipStream_t stream) {
+    TG_REQUIRE(pos_t && pos_h && pos_w && inv_t && inv_h && inv_w && cos_out && sin_out, TG_ERR_ARG, "tg_rope_table_3d: null pointer");
+    TG_REQUIRE(T > 0 && H > 0 && W > 0 && dim_t > 0 && dim_h > 0 && dim_w > 0 && dim_t % 2 == 0 && dim_h % 2 == 0 && dim_w % 2 == 0,
+               TG_ERR_SHAPE, "tg_rope_table_3d: bad shape");
+    TG_REQUIRE((((uintptr_t)cos_out) & 7) == 0 && (((uintptr_t)sin_out) & 7) == 0, TG_ERR_ALIGN, "tg_rope_table_3d: alignment");
+    const long total = (long)T * H * W * ((dim_t + dim_h + dim_w) / 2);
+    hipLaunchKernelGGL(rope_table_3d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pos_t, T, pos_h, H, pos_w, W,
+                       inv_t, dim_t / 2, inv_h, dim_h / 2, inv_w, dim_w / 2, cos_out, sin_out);
+    TG_LAUNCH_CHECK("tg_rope_table_3d");
     return TG_OK;
 }

@@ -29,6 +29,7 @@ PROTOTYPES = {
                          _i, _i, _i, _f, _i, _vp],
     "tg_attention_fwd_multi": [_vp, _i, _i, _i, _f, _i, _vp],
     "tg_timestep_sinusoid": [_vp, _i, _i, _vp, _vp],
+    "tg_rope_table_3d": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "tg_patchify": [_vp, _vp, _l, _i, _i, _i, _i, _i, _vp],
     "tg_unpatchify": [_vp, _l, _vp, _i, _i, _i, _i, _i, _vp],
     "tg_cfg_dpm_step": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _l, _vp],
