@@ -198,10 +198,17 @@ int tg_pca_inverse(const void* lat, const float* std16, const float* mean16, con
  * CogVideoXUpsample3D after F.interpolate (up=2, kt=1, pad=1) and of CogVideoXDownsample3D (stride=2, pad=0 with the
  * (0,1,0,1) zero pad implied).  w is repacked [Cout_pad][kt*kh*kw][Cin] (Cout_pad % 128 == 0); only columns < cout
  * are stored (row stride ldy).  residual (optional, same layout as y) is added in the epilogue (ResnetBlock3D :309).
- * zeros: >= 2*Cin + 128 bytes of device zeros (source of out-of-range taps).  Cin % 64 == 0. */
+ * zeros: >= 2*Cin + 128 bytes of device zeros (source of out-of-range taps).  Cin % 64 == 0.
+ * gn_partial (optional, tg_conv3d_gn_partial_floats(To,Ho,Wo) floats; needs cout % 128 == 0): per 128-voxel tile row the sums and
+ * sums of squares, per GroupNorm(32) group, of the bf16 values this launch stores — summed in a fixed order — so that the
+ * GroupNorm / SpatialNorm that reads y next needs no statistics pass of its own: tg_groupnorm_finalize turns them into
+ * (mean, rstd) exactly like the second stage of tg_groupnorm_stats. */
 int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const void* cache, const void* w, const void* bias,
                  int cout, int cout_pad, int kt, int kh, int kw, int stride, int pad, int up, const int32_t* t_map,
-                 const void* residual, void* y, long ldy, int To, int Ho, int Wo, const void* zeros, hipStream_t stream);
+                 const void* residual, void* y, long ldy, int To, int Ho, int Wo, const void* zeros, float* gn_partial,
+                 hipStream_t stream);
+long tg_conv3d_gn_partial_floats(int To, int Ho, int Wo);
+int tg_groupnorm_finalize(const float* partial, long V, int C, float eps, float* stats, hipStream_t stream);
 
 /* GroupNorm(32 groups, eps) statistics of x[V][C] -> stats[32][2] = {mean, rstd} (fp32).  partial: fp32 workspace of
  * tg_groupnorm_partial_floats(V, C) floats.  Deterministic two-stage reduction (fp64 finalisation). */

@@ -209,3 +209,24 @@ def test_condensed_token_front_end_vs_oracle(golden_dir):
     emb = pipe.vae_encode_image(frames.to(DEV), nf_per_chunk=17, compressed_nf_per_chunk=nfc, sample_posterior=False)
     assert emb.shape == (2, 8, 128, 2, 3) and torch.equal(emb[0], emb[1])
     assert _rel(emb[:1], ref) < 6e-2
+
+
+@pytest.mark.parametrize("ci,co,T,H,W", [(64, 128, 3, 9, 11), (128, 256, 2, 16, 24), (64, 512, 1, 13, 10)])
+def test_conv_epilogue_groupnorm_sums(ci, co, T, H, W):
+    """tg_conv3d_cl with gn_partial: the (mean, rstd) that come out of the epilogue's per-tile sums equal the two-pass statistics of the
+    stored tensor (same fp32 partial / fp64 finalise scheme, different partition), with and without the residual add, on shapes with a
+    ragged last 128-voxel tile, 1-4 column tiles and 4 / 8 / 16 channels per group; the output tensor itself is unchanged."""
+    from tokensgen_amd import kernels as K
+    w, b, x = _r(co, ci, 3, 3, 3, seed=1, scale=0.05), _r(co, seed=2), _r(1, ci, T, H, W, seed=3)
+    wp, bd, xc = _pack(w).to(DEV), b.to(DEV), _cl(x).to(DEV)
+    res = _r(T, H, W, co, seed=9).to(DEV)
+    for r in (None, res):
+        y0 = K.conv3d_cl(xc, wp, bd, co, 3, 3, 3, residual=r)
+        y1 = K.conv3d_cl(xc, wp, bd, co, 3, 3, 3, residual=r, gn_stats_eps=1e-6)
+        assert torch.equal(y0, y1) and not hasattr(y0, "gn_stats")
+        want = K.groupnorm_stats(y1.view(-1, co), 1e-6)
+        got = y1.gn_stats
+        assert got.shape == (32, 2)
+        torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6)
+        y2 = K.conv3d_cl(xc, wp, bd, co, 3, 3, 3, residual=r, gn_stats_eps=1e-6)
+        assert torch.equal(y2.gn_stats, got)                      # fixed summation order: bitwise repeatable

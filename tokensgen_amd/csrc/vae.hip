@@ -13,6 +13,7 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int GN_GROUPS = 32;
 constexpr int TILE_BYTES = BM * BK * 2;
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;
 
@@ -26,6 +27,7 @@ struct ConvParams {
     bf16_t* y; long ldy;
     int To, Ho, Wo;
     const bf16_t* zeros;
+    float* gn_partial;    // optional [tiles_m][2][32]: per-tile GroupNorm(32) sums / sums of squares of the STORED bf16 values
 };
 
 __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
     }
 
     // ---- epilogue: bias (+ residual), only columns < cout are stored ----
+    float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};   // GroupNorm partials of this lane's channel quad per ni
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const long m = m0 + wm * 64 + mi * 16 + (lane & 15);
@@ -168,6 +171,11 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
                 o.x = pack_bf16x2(v[0], v[1]);
                 o.y = pack_bf16x2(v[2], v[3]);
                 *(uint2*)dst = o;
+                if (p.gn_partial) {      // statistics of what the next GroupNorm will read: the bf16 values just stored
+                    const float r0 = bf16lo_to_f32(o.x), r1 = bf16hi_to_f32(o.x), r2 = bf16lo_to_f32(o.y), r3 = bf16hi_to_f32(o.y);
+                    gs[ni] += (r0 + r1) + (r2 + r3);
+                    gq[ni] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+                }
             } else {
                 for (int e = 0; e < 4 && n + e < p.cout; ++e) {
                     float u = v[e] + (p.bias ? bf16_to_f32(p.bias[n + e]) : 0.f);
@@ -177,12 +185,43 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
             }
         }
     }
+    // ---- GroupNorm partial sums of this tile, summed in a fixed order (no atomics): lanes of a 16-lane row group -> per
+    // (wave, ni, channel quad) in LDS -> one thread per (statistic, group) walks the quads of its group and both row halves
+    if (p.gn_partial) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                gs[ni] += __shfl_xor(gs[ni], off, 64);
+                gq[ni] += __shfl_xor(gq[ni], off, 64);
+            }
+        }
+        float* red = (float*)smem;                          // the stage buffers are idle: the k loop ended with a __syncthreads
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                red[((wave * 4 + ni) * 4 + (lane >> 4)) * 2 + 0] = gs[ni];
+                red[((wave * 4 + ni) * 4 + (lane >> 4)) * 2 + 1] = gq[ni];
+            }
+        }
+        __syncthreads();
+        const int cg = p.cout / GN_GROUPS, qpg = cg >> 2, gpt = BN / cg;     // channels per group, quads per group, groups per tile
+        if (tid < 2 * gpt) {
+            const int stat = tid / gpt, gl = tid % gpt;
+            float a = 0.f;
+            for (int qd = 0; qd < qpg; ++qd) {
+                const int cq = gl * qpg + qd;                // tile-local channel quad 0..31 = wn*16 + ni*4 + (lane>>4)
+                const int wn_ = cq >> 4, ni_ = (cq >> 2) & 3, quad_ = cq & 3;
+                for (int wm_ = 0; wm_ < 2; ++wm_) a += red[(((wm_ * 2 + wn_) * 4 + ni_) * 4 + quad_) * 2 + stat];
+            }
+            p.gn_partial[(long)tm * 2 * GN_GROUPS + stat * GN_GROUPS + n0 / cg + gl] = a;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // GroupNorm(32) statistics: stage 1 per-block fp32 partial (sum, sumsq) per group, stage 2 fp64 finalise
 // ------------------------------------------------------------------------------------------------
-constexpr int GN_GROUPS = 32;
 constexpr int GN_ROWS_PER_BLOCK = 512;
 
 __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, long V, int C, float* __restrict__ partial) {
@@ -221,20 +260,26 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
     }
 }
 
-__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ partial, int nblocks, long V, int C, float eps, float* __restrict__ stats) {
-    // 32 groups x 32 lanes: lane k of group g sums partial blocks k, k+32, ... in fp64, then a 32-lane shuffle tree
-    const int g = threadIdx.x >> 5, k = threadIdx.x & 31;
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nblocks, long V, int C, float eps, float* __restrict__ stats) {
+    // one workgroup per group: thread k sums partial blocks k, k+256, ... in fp64, then a fixed-order tree (shuffles inside a wave,
+    // four wave results through LDS) — the summation order depends only on nblocks
+    __shared__ double sh[2][4];
+    const int g = blockIdx.x, k = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = k; b < nblocks; b += 32) {
+    for (int b = k; b < nblocks; b += 256) {
         s += (double)partial[(long)b * 2 * GN_GROUPS + g];
         q += (double)partial[(long)b * 2 * GN_GROUPS + GN_GROUPS + g];
     }
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) {
+    for (int off = 32; off > 0; off >>= 1) {
         s += __shfl_xor(s, off, 64);
         q += __shfl_xor(q, off, 64);
     }
+    if ((k & 63) == 0) { sh[0][k >> 6] = s; sh[1][k >> 6] = q; }
+    __syncthreads();
     if (k == 0) {
+        s = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        q = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
         const double n = (double)V * (C / GN_GROUPS);
         const double mean = s / n;
         double var = q / n - mean * mean;
@@ -396,7 +441,8 @@ inline unsigned grid_for(long total, int block = 256) { return (unsigned)min((to
 
 extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const void* cache, const void* w, const void* bias,
                             int cout, int cout_pad, int kt, int kh, int kw, int stride, int pad, int up, const int32_t* t_map,
-                            const void* residual, void* y, long ldy, int To, int Ho, int Wo, const void* zeros, hipStream_t stream) {
+                            const void* residual, void* y, long ldy, int To, int Ho, int Wo, const void* zeros, float* gn_partial,
+                            hipStream_t stream) {
     TG_REQUIRE(x && w && y && zeros, TG_ERR_ARG, "tg_conv3d_cl: null pointer");
     TG_REQUIRE(T > 0 && H > 0 && W > 0 && To > 0 && Ho > 0 && Wo > 0, TG_ERR_SHAPE, "tg_conv3d_cl: bad spatial shape");
     TG_REQUIRE(Cin % BK == 0 && cout_pad % BN == 0 && cout > 0 && cout <= cout_pad, TG_ERR_SHAPE,
@@ -406,7 +452,9 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
     TG_REQUIRE(tg_aligned16(x) && tg_aligned16(w) && tg_aligned16(zeros) && (!cache || tg_aligned16(cache)) && (((uintptr_t)y) & 1) == 0 &&
                (cout % 4 != 0 || ((((uintptr_t)y) & 7) == 0 && ldy % 4 == 0)), TG_ERR_ALIGN, "tg_conv3d_cl: alignment");
     ConvParams p{(const bf16_t*)x, T, H, W, Cin, (const bf16_t*)cache, (const bf16_t*)w, (const bf16_t*)bias, cout, cout_pad, kt, kh, kw,
-                 stride, pad, up, t_map, (const bf16_t*)residual, (bf16_t*)y, ldy, To, Ho, Wo, (const bf16_t*)zeros};
+                 stride, pad, up, t_map, (const bf16_t*)residual, (bf16_t*)y, ldy, To, Ho, Wo, (const bf16_t*)zeros, gn_partial};
+    TG_REQUIRE(!gn_partial || (cout == cout_pad && cout % BN == 0 && (cout / GN_GROUPS) % 4 == 0), TG_ERR_SHAPE,
+               "tg_conv3d_cl: fused GroupNorm sums need cout in {128, 256, 512, ...} (cout=%d)", cout);
     const long M = (long)To * Ho * Wo;
     const long tiles = ((M + BM - 1) / BM) * (cout_pad / BN);
     TG_REQUIRE(tiles < (1L << 31), TG_ERR_SHAPE, "tg_conv3d_cl: too many tiles");
@@ -428,8 +476,21 @@ extern "C" int tg_groupnorm_stats(const void* x, long V, int C, float eps, float
     TG_REQUIRE(tg_aligned16(x), TG_ERR_ALIGN, "tg_groupnorm_stats: alignment");
     const int nblocks = (int)((V + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nblocks), dim3(256), 0, stream, (const bf16_t*)x, V, C, partial);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(1024), 0, stream, (const float*)partial, nblocks, V, C, eps, stats);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(GN_GROUPS), dim3(256), 0, stream, (const float*)partial, nblocks, V, C, eps, stats);
     TG_LAUNCH_CHECK("tg_groupnorm_stats");
+    return TG_OK;
+}
+
+extern "C" long tg_conv3d_gn_partial_floats(int To, int Ho, int Wo) {
+    return (((long)To * Ho * Wo + BM - 1) / BM) * 2 * GN_GROUPS;
+}
+
+extern "C" int tg_groupnorm_finalize(const float* partial, long V, int C, float eps, float* stats, hipStream_t stream) {
+    TG_REQUIRE(partial && stats, TG_ERR_ARG, "tg_groupnorm_finalize: null pointer");
+    TG_REQUIRE(V > 0 && C % GN_GROUPS == 0, TG_ERR_SHAPE, "tg_groupnorm_finalize: bad shape");
+    const int nblocks = (int)((V + BM - 1) / BM);           // one block of sums per 128-voxel conv tile row
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(GN_GROUPS), dim3(256), 0, stream, partial, nblocks, V, C, eps, stats);
+    TG_LAUNCH_CHECK("tg_groupnorm_finalize");
     return TG_OK;
 }
 

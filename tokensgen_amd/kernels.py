@@ -301,8 +301,11 @@ def zero_page(device):
     return z
 
 
-def conv3d_cl(x, w_packed, bias, cout, kt, kh, kw, cache=None, stride=1, pad=1, up=1, t_map=None, residual=None, out_dims=None):
-    """x [T,H,W,Cin] channels-last; w_packed [Cout_pad, kt*kh*kw, Cin]; returns y [To,Ho,Wo,cout]."""
+def conv3d_cl(x, w_packed, bias, cout, kt, kh, kw, cache=None, stride=1, pad=1, up=1, t_map=None, residual=None, out_dims=None,
+              gn_stats_eps=None):
+    """x [T,H,W,Cin] channels-last; w_packed [Cout_pad, kt*kh*kw, Cin]; returns y [To,Ho,Wo,cout].
+    gn_stats_eps: also produce the GroupNorm(32) statistics of y from the epilogue's partial sums (cout % 128 == 0): they are
+    attached as y.gn_stats ([32,2] fp32: mean, rstd) for the norm that consumes y."""
     _chk(x, "x"); _chk(w_packed, "w")
     assert x.is_contiguous() and w_packed.is_contiguous()
     T, H, W, Cin = x.shape
@@ -314,9 +317,16 @@ def conv3d_cl(x, w_packed, bias, cout, kt, kh, kw, cache=None, stride=1, pad=1, 
         _chk(residual, "residual"); assert residual.is_contiguous() and residual.shape == y.shape
     if t_map is not None:
         _chk(t_map, "t_map", torch.int32)
+    fuse = gn_stats_eps is not None and cout % 128 == 0 and w_packed.shape[0] == cout
+    partial = torch.empty(L.load().tg_conv3d_gn_partial_floats(To, Ho, Wo), dtype=torch.float32, device=x.device) if fuse else None
     L.check(_launch(f"conv3d_cl_Cin{Cin}_Cout{cout}_k{kt}{kh}{kw}_s{stride}_u{up}", L.load().tg_conv3d_cl, _p(x), T, H, W, Cin, _p(cache),
                     _p(w_packed), _p(bias), cout, w_packed.shape[0], kt, kh, kw, stride, pad, up, _p(t_map), _p(residual), _p(y), cout, To, Ho,
-                    Wo, _p(zero_page(x.device)), _stream()), "tg_conv3d_cl")
+                    Wo, _p(zero_page(x.device)), _p(partial), _stream()), "tg_conv3d_cl")
+    if fuse:
+        stats = torch.empty(32, 2, dtype=torch.float32, device=x.device)
+        L.check(_launch("groupnorm_finalize", L.load().tg_groupnorm_finalize, _p(partial), To * Ho * Wo, cout, float(gn_stats_eps), _p(stats),
+                        _stream()), "tg_groupnorm_finalize")
+        y.gn_stats = stats
     return y
 
 

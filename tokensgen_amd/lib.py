@@ -35,7 +35,8 @@ PROTOTYPES = {
     "tg_cfg_dpm_step": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _l, _vp],
     "tg_cfg_dpm_step_f32": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _l, _vp],
     "tg_pca_inverse": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "tg_conv3d_cl": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp],
+    "tg_conv3d_cl": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp],
+    "tg_groupnorm_finalize": [_vp, _l, _i, _f, _vp, _vp],
     "tg_groupnorm_stats": [_vp, _l, _i, _f, _vp, _vp, _vp],
     "tg_groupnorm_silu": [_vp, _l, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "tg_spatialnorm_silu": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _i, _vp],
@@ -63,6 +64,8 @@ def load():
         fn.restype = C.c_int
     lib.tg_groupnorm_partial_floats.argtypes = [C.c_long, C.c_int]
     lib.tg_groupnorm_partial_floats.restype = C.c_long
+    lib.tg_conv3d_gn_partial_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.tg_conv3d_gn_partial_floats.restype = C.c_long
     lib.tg_version.restype = C.c_char_p
     lib.tg_last_error_string.restype = C.c_char_p
     _lib = lib

@@ -125,7 +125,7 @@ class AutoencoderKLCogVideoX:
         co, kt = w.shape[0], w.shape[2]
         prev = cache.get(name) if kt > 1 else None
         y = K.conv3d_cl(x, self._packed[name + ".conv.weight"], self._sd[name + ".conv.bias"], co, kt, w.shape[3], w.shape[4], cache=prev,
-                        residual=residual)
+                        residual=residual, gn_stats_eps=self.config.norm_eps)    # the next norm's statistics come with y
         if kt > 1:
             need = kt - 1
             if x.shape[0] >= need:
@@ -136,7 +136,9 @@ class AutoencoderKLCogVideoX:
         return y
 
     def _norm_act(self, name, x, zq, silu=True):
-        stats = K.groupnorm_stats(x.view(-1, x.shape[-1]), self.config.norm_eps)
+        stats = getattr(x, "gn_stats", None)                 # left by the convolution that produced x (its epilogue's partial sums)
+        if stats is None:
+            stats = K.groupnorm_stats(x.view(-1, x.shape[-1]), self.config.norm_eps)
         if zq is None:
             return K.groupnorm_silu(x, stats, self._sd[name + ".weight"], self._sd[name + ".bias"], silu)
         z64, zdims = zq                                    # latent tile, channels-last padded to 64: [Vz, 64]
@@ -168,7 +170,7 @@ class AutoencoderKLCogVideoX:
             tmap = torch.tensor(idx, dtype=torch.int32, device=x.device)
         w = self._sd[name + ".conv.weight"]
         return K.conv3d_cl(x, self._packed[name + ".conv.weight"], self._sd[name + ".conv.bias"], w.shape[0], 1, 3, 3, stride=1, pad=1, up=2,
-                           t_map=tmap, out_dims=(To, 2 * H, 2 * W))
+                           t_map=tmap, out_dims=(To, 2 * H, 2 * W), gn_stats_eps=self.config.norm_eps)
 
     def _downsample(self, name, x, compress_time):
         """diffusers CogVideoXDownsample3D: temporal avg-pool (first frame kept when T odd), pad (0,1,0,1), Conv2d 3x3 stride 2."""
@@ -177,7 +179,7 @@ class AutoencoderKLCogVideoX:
         T, H, W, C = x.shape
         w = self._sd[name + ".conv.weight"]
         return K.conv3d_cl(x, self._packed[name + ".conv.weight"], self._sd[name + ".conv.bias"], w.shape[0], 1, 3, 3, stride=2, pad=0,
-                           out_dims=(T, (H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1))
+                           out_dims=(T, (H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1), gn_stats_eps=self.config.norm_eps)
 
     def _encoder(self, x_cl, cache):
         """CogVideoXEncoder3D.forward (:708-742) on a channels-last tile [T,H,W,64(3 used)] -> [T',H/8,W/8,32]."""
