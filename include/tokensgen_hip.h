@@ -62,6 +62,14 @@ int tg_gemm_bf16(const void* A, long lda, long strideA, const void* W, long ldw,
                  void* C, long ldc, long strideC, int M, int N, int K, int batch, int epilogue,
                  const void* R, long ldr, long strideR, const tg_group_table* gate, hipStream_t stream);
 
+/* Two GEMMs of the same N, K, batch, leading dimensions and epilogue (bias / GELU / SiLU) in ONE launch of the persistent 256x256
+ * kernel (M1, M2 >= 1024, N % 256 == 0): the second problem's tiles are appended to the first one's, so together they leave one
+ * partial last round of CUs instead of one each.  Built for the To2V block: to_q|k|v over the text+video rows and vip_to_q|k|v over
+ * all rows read the same normalised activations and are independent (attention_processor.py:2009-2018). */
+int tg_gemm_bf16_pair(const void* A1, long strideA1, const void* W1, const void* bias1, void* C1, long strideC1, int M1,
+                      const void* A2, long strideA2, const void* W2, const void* bias2, void* C2, long strideC2, int M2,
+                      long lda, long ldw, long ldc, int N, int K, int batch, int epilogue, hipStream_t stream);
+
 /* y = LayerNorm(x; w, b, eps) * (1 + scale[g]) + shift[g], g = group of the token.  One pass, fp32 stats.
  * modulate == 0: plain affine LayerNorm (norm_final, cogvideox_transformer_3d.py:741).
  * Replaces normalization.py:441-460 (CogVideoXLayerNormZero), :477-488 (VIP), :70-92 (AdaLayerNorm).

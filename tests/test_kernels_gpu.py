@@ -390,3 +390,19 @@ def test_rope_tables_on_device_match_host():
         dc, ds = R.rope_3d(hd, gt, gh, gw, device=DEV, **kw)
         assert dc.shape == hc.shape and dc.is_cuda
         assert (dc.cpu() - hc).abs().max().item() < 2e-6 and (ds.cpu() - hs).abs().max().item() < 2e-6
+
+
+def test_gemm_pair_equals_two_launches(K):
+    """tg_gemm_bf16_pair: the second problem's tiles ride in the first one's persistent launch — bitwise the two separate launches, for
+    row counts that leave ragged last m-tiles and with the second problem's rows a superset of the first's (the To2V QKV case)."""
+    from tokensgen_amd import lib as L
+    B, M1, M2, N, Kd = 2, 1100, 1230, 768, 512
+    x = _rand(B, M2, Kd, seed=31)
+    w1, w2, b1, b2 = _rand(N, Kd, seed=32, scale=0.05), _rand(N, Kd, seed=33, scale=0.05), _rand(N, seed=34), _rand(N, seed=35)
+    for epi in (L.EPI_BIAS, L.EPI_BIAS_GELU):
+        a1, a2 = torch.zeros(B, M1, N, dtype=torch.bfloat16, device=DEV), torch.zeros(B, M2, N, dtype=torch.bfloat16, device=DEV)
+        c1, c2 = torch.zeros_like(a1), torch.zeros_like(a2)
+        K.gemm(x[:, :M1], w1, b1, a1, epi)
+        K.gemm(x, w2, b2, a2, epi)
+        K.gemm_pair(x[:, :M1], w1, b1, c1, x, w2, b2, c2, epi)
+        assert torch.equal(a1, c1) and torch.equal(a2, c2) and a1.abs().sum() > 0

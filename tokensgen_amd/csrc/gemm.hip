@@ -37,6 +37,10 @@ struct GemmParams {
     const bf16_t* R; long ldr; long sRb;          // residual (EPI_GATE_RES)
     int M, N, K, batch;
     tg_group_table g;                             // gate lookup (EPI_GATE_RES)
+    // optional second problem of the same N, K, batch, leading dimensions and epilogue (256^2 kernel only): its tiles are appended to
+    // the persistent tile list, so the two problems share ONE partial last round of CUs instead of paying one each
+    const bf16_t* A2; const bf16_t* W2; const bf16_t* bias2; bf16_t* C2; long sAb2, sCb2; int M2;
+    int tiles1;                                   // tiles of the first problem
 };
 
 __device__ __forceinline__ float gelu_tanh(float x) {
@@ -228,16 +232,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wn = wave & 3;
 
-    const int tiles_m = (p.M + BM2 - 1) / BM2, tiles_n = p.N / BN2;
-    const int per_batch = tiles_m * tiles_n;
-    const int nwg = per_batch * p.batch;
+    const int tiles_n = p.N / BN2;
+    const int tiles_m1 = (p.M + BM2 - 1) / BM2, tiles_m2 = p.A2 ? (p.M2 + BM2 - 1) / BM2 : 0;
+    const int nwg1 = tiles_m1 * tiles_n * p.batch;
+    const int nwg = nwg1 + tiles_m2 * tiles_n * p.batch;
 
     // ---- LDS-DMA pieces of this wave: issue phase 0 -> A pieces 2*wave, 2*wave+1 ; phase 1 -> W pieces 2*wave, 2*wave+1 ----
     const char* src[2][2];
-    int cb = 0, cm0 = 0, cn0 = 0;   // batch index and origin of the tile `src` points at
+    int cb = 0, cm0 = 0, cn0 = 0, csec = 0;   // batch index, origin and problem (0/1) of the tile `src` points at
     const int prow = wave * 32 + (lane >> 2);                 // + i*16 : tile row of this lane's 16-B chunk
     auto set_tile = [&](int id) {
-        int t = xcd_remap(id, nwg);
+        csec = id >= nwg1;
+        const int tiles_m = csec ? tiles_m2 : tiles_m1;
+        const int per_batch = tiles_m * tiles_n;
+        const int Mc = csec ? p.M2 : p.M;
+        int t = csec ? xcd_remap(id - nwg1, nwg - nwg1) : xcd_remap(id, nwg1);
         cb = t / per_batch;
         t -= cb * per_batch;
         const int per_group = GROUP_M * tiles_n;
@@ -247,13 +256,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         const int in_g = t - gi * per_group;
         cm0 = (first_m + in_g % gsz) * BM2;
         cn0 = (in_g / gsz) * BN2;
-        const bf16_t* Ab = p.A + (long)cb * p.sAb;
+        const bf16_t* Ab = csec ? p.A2 + (long)cb * p.sAb2 : p.A + (long)cb * p.sAb;
+        const bf16_t* Wb = csec ? p.W2 : p.W;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = prow + i * 16;
             const int slot = (lane & 3) ^ ((r >> 2) & 3);     // logical 16-B slot stored at physical slot lane&3
-            src[0][i] = (const char*)(Ab + (long)min(cm0 + r, p.M - 1) * p.lda + slot * 8);
-            src[1][i] = (const char*)(p.W + (long)(cn0 + r) * p.ldw + slot * 8);
+            src[0][i] = (const char*)(Ab + (long)min(cm0 + r, Mc - 1) * p.lda + slot * 8);
+            src[1][i] = (const char*)(Wb + (long)(cn0 + r) * p.ldw + slot * 8);
         }
     };
     auto stage1 = [&](int st, int ph, int i) {               // piece i of issue phase ph for stage st
@@ -371,7 +381,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         if (grp == 0) TG_BAR();   // every wave is now past its last LDS read of this tile
 
         // ---- next tile's first three stages go in flight (ring slots 0..2) under the epilogue ----
-        const int eb = cb, em0 = cm0, en0 = cn0;
+        const int eb = cb, em0 = cm0, en0 = cn0, esec = csec;
         if (tile + (int)gridDim.x < nwg) {
             set_tile(tile + gridDim.x);
 #pragma unroll
@@ -382,7 +392,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         // ---- epilogue through LDS (ring slot 3, 4 KiB per wave, 16-B slots XOR-swizzled by row&7): MFMA layout -> full rows ----
         // per 32x32 block a lane holds D[n = 8*(r>>2) + 4*hi + (r&3)][m = lane&31]
         char* stg = smem + 3 * STAGE2_BYTES + wave * 4096;
-        bf16_t* Cb = p.C + (long)eb * p.sCb;
+        bf16_t* Cb = esec ? p.C2 + (long)eb * p.sCb2 : p.C + (long)eb * p.sCb;
+        const bf16_t* ebias = esec ? p.bias2 : p.bias;
+        const int eM = esec ? p.M2 : p.M;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
@@ -391,8 +403,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int nl = nt * 32 + r4 * 8 + hi * 4;
                     float v[4] = {acc[mt][nt][r4 * 4 + 0], acc[mt][nt][r4 * 4 + 1], acc[mt][nt][r4 * 4 + 2], acc[mt][nt][r4 * 4 + 3]};
-                    if (p.bias) {
-                        const uint2 bb = *(const uint2*)(p.bias + en0 + wn * 64 + nl);
+                    if (ebias) {
+                        const uint2 bb = *(const uint2*)(ebias + en0 + wn * 64 + nl);
                         v[0] += bf16lo_to_f32(bb.x); v[1] += bf16hi_to_f32(bb.x);
                         v[2] += bf16lo_to_f32(bb.y); v[3] += bf16hi_to_f32(bb.y);
                     }
@@ -416,7 +428,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                 const uint4 val = *(const uint4*)(stg + row * 128 + ((ch ^ (row & 7)) << 4));
                 const int m = em0 + grp * 128 + mt * 32 + row;
                 const int n = en0 + wn * 64 + ch * 8;
-                if (m < p.M) {
+                if (m < eM) {
                     uint4 o = val;
                     if (EPI == TG_EPI_BIAS_GATE_RES) {   // y = residual + gate[group(m)] * bf16(linear)
                         const int g = p.g.tok_group[m];
@@ -447,7 +459,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 template <int EPI>
 int launch(const GemmParams& p, hipStream_t stream) {
     if (p.M >= 1024 && p.N % BN2 == 0 && !g_force_128) {   // large-M shapes: 256^2 ping-pong kernel
-        const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2) * p.batch;
+        const int tiles2 = (((p.M + BM2 - 1) / BM2) + (p.A2 ? (p.M2 + BM2 - 1) / BM2 : 0)) * (p.N / BN2) * p.batch;
         static bool attr2 = false;
         if (!attr2) {
             (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2_BYTES);
@@ -513,5 +525,44 @@ extern "C" int tg_gemm_bf16(const void* A, long lda, long strideA, const void* W
             p.g = *gate;
             return launch<TG_EPI_BIAS_GATE_RES>(p, stream);
         default: return tg_set_error(TG_ERR_ARG, "tg_gemm_bf16: unknown epilogue %d", epilogue);
+    }
+}
+
+extern "C" int tg_gemm_bf16_pair(const void* A1, long strideA1, const void* W1, const void* bias1, void* C1, long strideC1, int M1,
+                                 const void* A2, long strideA2, const void* W2, const void* bias2, void* C2, long strideC2, int M2,
+                                 long lda, long ldw, long ldc, int N, int K, int batch, int epilogue, hipStream_t stream) {
+    TG_REQUIRE(A1 && W1 && C1 && A2 && W2 && C2, TG_ERR_ARG, "tg_gemm_bf16_pair: null pointer");
+    TG_REQUIRE(M1 >= 1024 && M2 >= 1024 && N > 0 && K > 0 && batch > 0 && N % BN2 == 0 && K % BK == 0, TG_ERR_SHAPE,
+               "tg_gemm_bf16_pair: both problems must be 256^2-kernel shapes (M >= 1024, N%%256 == 0, K%%64 == 0)");
+    TG_REQUIRE(epilogue == TG_EPI_BIAS || epilogue == TG_EPI_BIAS_GELU || epilogue == TG_EPI_BIAS_SILU, TG_ERR_ARG,
+               "tg_gemm_bf16_pair: bias / GELU / SiLU epilogues only");
+    TG_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && strideA1 % 8 == 0 && strideC1 % 8 == 0 && strideA2 % 8 == 0 && strideC2 % 8 == 0 &&
+               tg_aligned16(A1) && tg_aligned16(W1) && tg_aligned16(C1) && tg_aligned16(A2) && tg_aligned16(W2) && tg_aligned16(C2), TG_ERR_ALIGN,
+               "tg_gemm_bf16_pair: alignment");
+    GemmParams p{};
+    p.A = (const bf16_t*)A1; p.lda = lda; p.sAb = strideA1;
+    p.W = (const bf16_t*)W1; p.ldw = ldw;
+    p.bias = (const bf16_t*)bias1;
+    p.C = (bf16_t*)C1; p.ldc = ldc; p.sCb = strideC1;
+    p.M = M1; p.N = N; p.K = K; p.batch = batch;
+    p.A2 = (const bf16_t*)A2; p.W2 = (const bf16_t*)W2; p.bias2 = (const bf16_t*)bias2; p.C2 = (bf16_t*)C2; p.sAb2 = strideA2; p.sCb2 = strideC2;
+    p.M2 = M2;
+    static const bool env_init = [] { const char* e = getenv("TG_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; return true; }();
+    (void)env_init;
+    if (g_force_128) {          // the 128^2 kernel has no second problem: run the two one after the other
+        GemmParams q = p;
+        q.A = p.A2; q.sAb = p.sAb2; q.W = p.W2; q.bias = p.bias2; q.C = p.C2; q.sCb = p.sCb2; q.M = p.M2;
+        p.A2 = q.A2 = nullptr;
+        int rc;
+        switch (epilogue) {
+            case TG_EPI_BIAS: rc = launch<TG_EPI_BIAS>(p, stream); return rc ? rc : launch<TG_EPI_BIAS>(q, stream);
+            case TG_EPI_BIAS_GELU: rc = launch<TG_EPI_BIAS_GELU>(p, stream); return rc ? rc : launch<TG_EPI_BIAS_GELU>(q, stream);
+            default: rc = launch<TG_EPI_BIAS_SILU>(p, stream); return rc ? rc : launch<TG_EPI_BIAS_SILU>(q, stream);
+        }
+    }
+    switch (epilogue) {
+        case TG_EPI_BIAS: return launch<TG_EPI_BIAS>(p, stream);
+        case TG_EPI_BIAS_GELU: return launch<TG_EPI_BIAS_GELU>(p, stream);
+        default: return launch<TG_EPI_BIAS_SILU>(p, stream);
     }
 }

@@ -112,6 +112,21 @@ def gemm(a, w, bias, out, epilogue=L.EPI_BIAS, residual=None, gate=None):
     return out
 
 
+def gemm_pair(a1, w1, bias1, out1, a2, w2, bias2, out2, epilogue=L.EPI_BIAS):
+    """out1 = epi(a1 @ w1^T + bias1) and out2 = epi(a2 @ w2^T + bias2) in one launch (tg_gemm_bf16_pair): same N, K, batch, leading
+    dimensions; [B, M, K] activations with M >= 1024."""
+    for n, t in (("a1", a1), ("w1", w1), ("out1", out1), ("a2", a2), ("w2", w2), ("out2", out2)):
+        _chk(t, n)
+    B, M1, Kd, lda, sa1 = _bmk(a1)
+    B2, M2, Kd2, lda2, sa2 = _bmk(a2)
+    _, _, N, ldc, sc1 = _bmk(out1)
+    _, _, N2, ldc2, sc2 = _bmk(out2)
+    assert (B, Kd, lda, N, ldc) == (B2, Kd2, lda2, N2, ldc2) and w1.shape == w2.shape == (N, Kd) and w1.stride(0) == w2.stride(0)
+    L.check(_launch(f"gemm_pair_M{M1}+{M2}_N{N}_K{Kd}_epi{epilogue}", L.load().tg_gemm_bf16_pair, _p(a1), sa1, _p(w1), _p(bias1), _p(out1), sc1, M1,
+                    _p(a2), sa2, _p(w2), _p(bias2), _p(out2), sc2, M2, lda, w1.stride(0), ldc, N, Kd, B, epilogue, _stream()), "tg_gemm_bf16_pair")
+    return out1, out2
+
+
 def adaln_modulate(x, out, ln_weight, ln_bias, eps, table=None):
     """out = LN(x)*(1+scale[g])+shift[g] (table given) or plain affine LN (table None). x/out [B,T,D] views."""
     _chk(x, "x"); _chk(out, "out")
