@@ -48,13 +48,14 @@ struct GemmParams {
 };
 
 __device__ __forceinline__ float gelu_tanh(float x) {
-    // F.gelu(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    const float e = __expf(2.f * u);
-    const float t = 1.f - 2.f / (e + 1.f);        // tanh(u), saturates cleanly at +-1
-    return 0.5f * x * (1.f + t);
+    // F.gelu(approximate="tanh"): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3)  ==  x / (1 + exp(-2u)).
+    // One v_exp + one v_rcp (1 ulp each; the result is rounded to bf16 right after) instead of a correctly rounded fp32 division:
+    // the GELU of the FF1 epilogue is 64 Ki elements per 256x256 tile on VALUs that have nothing to overlap with.
+    const float x2 = x * x;
+    const float t = x * (-2.f * 0.7978845608028654f * 1.4426950408889634f) * (1.f + 0.044715f * x2);   // -2u log2(e)
+    return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(t));   // t -> +inf: x * 0; t -> -inf: x
 }
-__device__ __forceinline__ float silu(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
@@ -460,6 +461,348 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 #undef TG_LOAD_END
 }
 
+// ================================================================================================
+// 256x256x64 tile, FOUR waves (one per SIMD), each 128x128 = 4x4 MFMA 32x32x16 with the 256 accumulators in AGPRs.
+//
+// Why: LDS bandwidth.  In the 8-wave kernel above a wave owns 128x64 of the tile and reads 6 KiB of fragments per 8 MFMAs: at
+// full MFMA rate that is 94 B/clk/CU of ds_read traffic plus 32 B/clk of LDS-DMA writes against the 128 B/clk the LDS has.
+// With 128x128 per wave the fragment traffic is 8 KiB per 16 MFMAs = 64 B/clk/CU (the same trade the vendor's hand-written
+// gfx950 kernel makes: MT256x256x64, 4 waves, 8x8 16x16x32 blocks per wave).  There is no second wave on the SIMD to hide
+// anything, so the wave software-pipelines itself: every MFMA is followed by at most one LDS-DMA piece or one ds_read_b128.
+//
+//   LDS: 2 stages x (A[256 rows][128 B] | W[256 rows][128 B]) = 128 KiB, + 4 x 4 KiB epilogue staging.  16-B slot of a row
+//   XOR-swizzled by row&7 (applied on the DMA source address; conflict-free b128 reads).  DMA piece = 8 rows x 128 B: every
+//   global access of the fill is a full 128-byte row segment; `buffer_load_dwordx4 ... lds` with a per-tile resource whose
+//   num_records ends at the last valid row, so M-edge rows read zeros (no clamping arithmetic).
+//   stage s (buffer b = s&1), k16-steps 0..3 with fragment sets 0..3:
+//     H0: 32 MFMAs of steps 0,1 | ds_reads of sets 2,3 of stage s            (buffer b)
+//     s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier      -> stage s+1 landed everywhere, buffer b has no reader left
+//     H1: 32 MFMAs of steps 2,3 | 16 DMA pieces of stage s+2 -> buffer b | ds_reads of sets 0,1 of stage s+1 (buffer b^1)
+//   The stage stream runs across output tiles (persistent): the last two stages of a tile fetch the first two of the next.
+// ================================================================================================
+#ifndef W4_ABL
+#define W4_ABL 0   // timing-only ablations (wrong results): 1 = no LDS-DMA in the steady stages, 2 = no fragment reads, 3 = no epilogue
+#endif
+constexpr int BK3 = 64;
+constexpr int OPER3_BYTES = 256 * BK3 * 2;       // 32 KiB per operand per stage
+constexpr int STAGE3_BYTES = 2 * OPER3_BYTES;    // 64 KiB
+constexpr int W4_STG_OFF = 2 * STAGE3_BYTES;     // epilogue staging behind the two stages
+constexpr int W4_BIAS_OFF = W4_STG_OFF + 4 * 4096;   // 256 B of bias per wave
+constexpr int W4_LDS_BYTES = W4_BIAS_OFF + 4 * 256;
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = p.N / BN2;
+    const int tiles_m1 = (p.M + BM2 - 1) / BM2, tiles_m2 = p.A2 ? (p.M2 + BM2 - 1) / BM2 : 0;
+    const int nwg1 = tiles_m1 * tiles_n * p.batch;
+    const int nwg = nwg1 + tiles_m2 * tiles_n * p.batch;
+    const int nst = p.K / BK3;
+
+    struct Coord { int sec, b, m0, n0; };
+    auto coords = [&](int id) {
+        Coord c;
+        c.sec = id >= nwg1;
+        const int tiles_m = c.sec ? tiles_m2 : tiles_m1;
+        const int per_batch = tiles_m * tiles_n;
+        int t = c.sec ? xcd_remap(id - nwg1, nwg - nwg1) : xcd_remap(id, nwg1);
+        c.b = t / per_batch;
+        t -= c.b * per_batch;
+        const int per_group = p.group_m * tiles_n;
+        const int gi = t / per_group;
+        const int first_m = gi * p.group_m;
+        const int gsz = min(tiles_m - first_m, p.group_m);
+        const int in_g = t - gi * per_group;
+        c.m0 = (first_m + in_g % gsz) * BM2;
+        c.n0 = (in_g / gsz) * BN2;
+        return c;
+    };
+
+    // ---- DMA side: a cursor (tile, k-stage) that runs two stages ahead of the MFMAs ----
+    // lane -> row lane>>3 of the piece, physical slot lane&7 holds logical slot (lane&7)^(row&7); row&7 == lane>>3
+    const int dslot = (lane & 7) ^ (lane >> 3);
+    const int voffA = (int)(((long)(wave * 64 + (lane >> 3)) * p.lda + dslot * 8) * 2);
+    const int voffW = (int)(((long)(wave * 64 + (lane >> 3)) * p.ldw + dslot * 8) * 2);
+    const int pieceA = (int)(p.lda * 16), pieceW = (int)(p.ldw * 16);      // 8 rows, bytes
+    __amdgpu_buffer_rsrc_t rA, rW;
+    Coord nc;                                      // coordinates of the tile the DMA cursor is in (= the next tile once it left this one)
+    int dtile = blockIdx.x, dk = 0, dbuf = 0;
+    auto set_dma_tile = [&](int id) {
+        const Coord c = coords(id);
+        nc = c;
+        const int Mc = c.sec ? p.M2 : p.M;
+        const bf16_t* Ab = (c.sec ? p.A2 + (long)c.b * p.sAb2 : p.A + (long)c.b * p.sAb) + (long)c.m0 * p.lda;
+        const bf16_t* Wb = (c.sec ? p.W2 : p.W) + (long)c.n0 * p.ldw;
+        rA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)(min(Mc - c.m0, BM2) * p.lda * 2), 0x00020000);
+        rW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, (int)(BN2 * p.ldw * 2), 0x00020000);
+    };
+    auto dma_piece = [&](int q) {                  // q = 0..7: A pieces, 8..15: W pieces of the cursor's stage
+        char* dst = smem + dbuf * STAGE3_BYTES + (q >> 3) * OPER3_BYTES + (wave * 64 + (q & 7) * 8) * 128;
+        if (q < 8)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)dst, 16, voffA + (q & 7) * pieceA, dk * (BK3 * 2), 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)dst, 16, voffW + (q & 7) * pieceW, dk * (BK3 * 2), 0, 0);
+    };
+    auto dma_advance = [&]() { dbuf ^= 1; ++dk; };
+    auto dma_next_tile = [&]() {                   // the cursor leaves the current tile (called once per tile, before its last two stages)
+        dk = 0;
+        dtile += gridDim.x;
+        if (dtile < nwg) set_dma_tile(dtile);
+    };
+
+    // ---- fragment addresses (32x32x16 operands: lane -> row lane&31, logical 16-B slot ks*2 + (lane>>5)) ----
+    const int j31 = lane & 31, hi = lane >> 5;
+    const int swz = (hi ^ (j31 & 7)) << 4;
+    int ra[4], rw[4];                              // byte address of k-step ks; + mb*4096 / nb*4096 as the immediate
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        ra[ks] = ((wm * 128 + j31) * 128 + swz) ^ (ks << 5);
+        rw[ks] = (OPER3_BYTES + (wn * 128 + j31) * 128 + swz) ^ (ks << 5);
+    }
+    bf16x8 fa[4][4], fw[4][4];                     // [k-step][32-row block]
+    f32x16 acc[4][4];                              // [m block][n block]
+    if (W4_ABL == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { fa[i][j] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; fw[i][j] = fa[i][j]; }
+    }
+
+#define W4_SB() __builtin_amdgcn_sched_barrier(0)
+#define W4_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+    // fragment read r (0..7) of k-step KS: 0..3 -> W blocks, 4..7 -> A blocks
+    auto frag_read = [&](auto ksc, auto rc) {
+        constexpr int KS = decltype(ksc)::value, R = decltype(rc)::value;
+        if constexpr (W4_ABL == 2) return;
+        if constexpr (R < 4) {
+            bf16x8& d = fw[KS][R];
+            const int ad = rw[KS];
+            W4_DSR(d, ad, R * 4096);
+        } else {
+            bf16x8& d = fa[KS][R - 4];
+            const int ad = ra[KS];
+            W4_DSR(d, ad, (R - 4) * 4096);
+        }
+    };
+    // one stage = 64 MFMA slots (k-steps 0..3 x 16 blocks); after MFMA I the slot may carry one ds_read / one DMA piece / a barrier:
+    //   slots [0, 16*R1S)      every R1S-th: fragment read r of sets 2,3 of THIS stage                     (buffer b)
+    //   slot  B1               lgkmcnt(0); s_barrier -> buffer b has no reader left; fragment addresses flip to buffer b^1
+    //   slots [D0, D0+16*DS)   every DS-th: DMA piece of stage s+2 -> buffer b
+    //   slot  B2               vmcnt(pieces issued so far in this stage); s_barrier -> stage s+1 landed everywhere
+    //   slots [R20, R20+16)    fragment read r of sets 0,1 of stage s+1                                    (buffer b^1)
+#ifndef W4_R1S
+#define W4_R1S 1
+#endif
+#ifndef W4_B1
+#define W4_B1 17
+#endif
+#ifndef W4_D0
+#define W4_D0 18
+#endif
+#ifndef W4_DS
+#define W4_DS 2
+#endif
+#ifndef W4_B2
+#define W4_B2 46
+#endif
+#ifndef W4_R20
+#define W4_R20 47
+#endif
+    static_assert(W4_B1 >= 16 * W4_R1S - W4_R1S && W4_B1 < 32 && W4_D0 > W4_B1 && W4_R20 > W4_B2 && W4_R20 + 16 <= 64 && W4_B2 >= 32, "schedule");
+    auto toggle = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { ra[ks] ^= STAGE3_BYTES; rw[ks] ^= STAGE3_BYTES; }
+    };
+    // STEADY: the DMA cursor stays inside the current tile and there is always something to fetch / read
+    auto kstage = [&](auto steady_c, bool more, bool rd) {
+        constexpr bool STEADY = decltype(steady_c)::value;
+        const bool dma = STEADY || more, rdn = STEADY || rd;
+        static_for<0, 64>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            constexpr int KS = I >> 4, NB = (I >> 2) & 3, MB = I & 3;
+            acc[MB][NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[KS][NB], fa[KS][MB], acc[MB][NB], 0, 0, 0);
+            W4_SB();
+            if constexpr (I < 16 * W4_R1S && I % W4_R1S == 0) {
+                constexpr int R = I / W4_R1S;
+                frag_read(std::integral_constant<int, 2 + (R >> 3)>{}, std::integral_constant<int, R & 7>{});
+            }
+            if constexpr (I == W4_B1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                W4_SB();
+                toggle();
+            }
+            if constexpr (I >= W4_D0 && (I - W4_D0) % W4_DS == 0 && (I - W4_D0) / W4_DS < 16) {
+#if W4_ABL != 1
+                if (dma) dma_piece((I - W4_D0) / W4_DS);
+#endif
+            }
+            if constexpr (I == W4_B2) {
+                constexpr int ISSUED = (W4_B2 - W4_D0) / W4_DS + 1 > 16 ? 16 : (W4_B2 - W4_D0) / W4_DS + 1;
+                if (dma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ISSUED) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                W4_SB();
+            }
+            if constexpr (I >= W4_R20 && I - W4_R20 < 16) {
+                constexpr int R = I - W4_R20;
+                if (rdn) frag_read(std::integral_constant<int, (R >> 3)>{}, std::integral_constant<int, R & 7>{});
+            }
+            W4_SB();
+        });
+        if (dma) dma_advance();
+        W4_SB();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W4_SB();
+    };
+
+    int tile = blockIdx.x;
+    set_dma_tile(tile);
+    Coord cc = nc;
+    // prologue: stages 0 and 1 in flight, fragment sets 0,1 of stage 0 in registers
+    static_for<0, 16>([&](auto qc) { dma_piece(decltype(qc)::value); });
+    dma_advance();
+    static_for<0, 16>([&](auto qc) { dma_piece(decltype(qc)::value); });
+    dma_advance();
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    W4_SB();
+
+    for (; tile < nwg; tile += gridDim.x) {
+        // fragment sets 0,1 of this tile's stage 0 (its buffer landed: waited in the previous tile's last stage / the prologue).  Read
+        // here and not under the previous epilogue: 64 live fragment registers there would be spilled, and a VMEM reload into a
+        // fragment register makes the compiler guard the k loop's first ds_reads with vmcnt(1..3), i.e. wait for the DMA just issued.
+        static_for<0, 16>([&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+            frag_read(std::integral_constant<int, (R >> 3)>{}, std::integral_constant<int, R & 7>{});
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W4_SB();
+        // the 128 bias values of this wave's columns go to LDS by one more DMA piece (256 B), retired by the counted waits of the first
+        // stage; the epilogue then reads them with ds_read_b64.  (Global loads in the epilogue each cost a serialising vmcnt(0) that also
+        // waits for the previous block's stores and the next tile's DMA; loads issued here into registers get the same vmcnt(0) at their
+        // first use.)
+        const bf16_t* ebias = cc.sec ? p.bias2 : p.bias;
+        if (ebias)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ebias + cc.n0 + wn * 128 + lane * 2),
+                                             (__attribute__((address_space(3))) void*)(smem + W4_BIAS_OFF + wave * 256), 4, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+        {
+            int st = 0;
+            for (; st + 2 < nst; ++st) kstage(std::true_type{}, true, true);
+            const bool has_next = tile + (int)gridDim.x < nwg;
+            dma_next_tile();
+            kstage(std::false_type{}, has_next, true);
+            kstage(std::false_type{}, has_next, false);
+        }
+        const Coord ec = cc;
+        if (tile + (int)gridDim.x < nwg) cc = nc;
+
+        // ---- epilogue through LDS (4 KiB per wave behind the stages, 16-B slots XOR-swizzled by row&7): MFMA layout -> full rows ----
+        // per 32x32 block a lane holds D[n = 8*(r>>2) + 4*hi + (r&3)][m = lane&31].  The staging accesses are asm so that the compiler's
+        // LDS-DMA alias rule (vmcnt(0) before any LDS access while a DMA is in flight) does not serialise them behind the global stores
+        if (W4_ABL == 3 && p.M > 0) continue;
+        bf16_t* Cb = ec.sec ? p.C2 + (long)ec.b * p.sCb2 : p.C + (long)ec.b * p.sCb;
+        const int eM = ec.sec ? p.M2 : p.M;
+        const int stg = W4_STG_OFF + wave * 4096;
+        const int wbase = (stg + j31 * 128 + hi * 8) | ((j31 & 7) << 4);
+        const int rbase = stg + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);
+        u32x2 bb[4][4];                                   // bias of this lane's 16 column quads (n = nb*32 + r4*8 + hi*4 ..+3)
+        if (ebias) {
+            const int ba = W4_BIAS_OFF + wave * 256 + hi * 8;
+            static_for<0, 16>([&](auto qc) {
+                constexpr int Q = decltype(qc)::value;
+                u32x2& d = bb[Q >> 2][Q & 3];
+                const int ad = ba;
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(ad), "n"(((Q >> 2) * 32 + (Q & 3) * 8) * 2));
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            W4_SB();
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) bb[q >> 2][q & 3] = u32x2{0u, 0u};
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x16& a = acc[mt][nh * 2 + nt];
+                        const u32x2 bq = bb[nh * 2 + nt][r4];
+                        float v[4] = {a[r4 * 4 + 0] + bf16lo_to_f32(bq.x), a[r4 * 4 + 1] + bf16hi_to_f32(bq.x),
+                                      a[r4 * 4 + 2] + bf16lo_to_f32(bq.y), a[r4 * 4 + 3] + bf16hi_to_f32(bq.y)};
+                        if (EPI == TG_EPI_BIAS_GELU) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = gelu_tanh(round_bf16(v[i]));
+                        } else if (EPI == TG_EPI_BIAS_SILU) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = silu(round_bf16(v[i]));
+                        }
+                        u32x2 o;
+                        o.x = pack_bf16x2(v[0], v[1]);
+                        o.y = pack_bf16x2(v[2], v[3]);
+                        const int wa = wbase ^ ((nt * 4 + r4) << 4);
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(wa), "v"(o));
+                    }
+                u32x4 val[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(val[it]) : "v"(rbase), "n"(it * 1024));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                W4_SB();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                    const int m = ec.m0 + wm * 128 + mt * 32 + row;
+                    const int n = ec.n0 + wn * 128 + nh * 64 + ch * 8;
+                    if (m < eM) {
+                        uint4 o = uint4{val[it].x, val[it].y, val[it].z, val[it].w};
+                        if (EPI == TG_EPI_BIAS_GATE_RES) {   // y = residual + gate[group(m)] * bf16(linear)
+                            const int g = p.g.tok_group[m];
+                            const bf16_t* gate_row = (const bf16_t*)p.g.mod + (long)ec.b * p.g.mod_batch_stride + (long)p.g.row[g] * p.g.mod_ld + p.g.gate_col[g];
+                            const uint4 gg = *(const uint4*)(gate_row + n);
+                            const uint4 rr = *(const uint4*)(p.R + (long)ec.b * p.sRb + (long)m * p.ldr + n);
+                            const uint32_t vu[4] = {o.x, o.y, o.z, o.w}, gu[4] = {gg.x, gg.y, gg.z, gg.w}, ru[4] = {rr.x, rr.y, rr.z, rr.w};
+                            uint32_t ou[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                ou[i] = pack_bf16x2(bf16lo_to_f32(ru[i]) + bf16lo_to_f32(gu[i]) * bf16lo_to_f32(vu[i]),
+                                                    bf16hi_to_f32(ru[i]) + bf16hi_to_f32(gu[i]) * bf16hi_to_f32(vu[i]));
+                            o = uint4{ou[0], ou[1], ou[2], ou[3]};
+                        }
+                        *(uint4*)(Cb + (long)m * p.ldc + n) = o;
+                    }
+                }
+            }
+        }
+    }
+#undef W4_SB
+#undef W4_DSR
+}
+
 template <int EPI>
 int launch(GemmParams p, hipStream_t stream) {
     if (p.M >= 1024 && p.N % BN2 == 0 && !g_force_128) {   // large-M shapes: 256^2 ping-pong kernel
@@ -483,6 +826,17 @@ int launch(GemmParams p, hipStream_t stream) {
         }
         static const int abl = [] { const char* e = getenv("TG_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
         const dim3 grid2(tiles2 < n_cu ? tiles2 : n_cu);
+        static const int w4 = [] { const char* e = getenv("TG_GEMM_W4"); return e ? atoi(e) : 0; }();
+        if (w4 && p.K >= 4 * BK3 && !abl) {
+            static bool attr4 = false;
+            if (!attr4) {
+                (void)hipFuncSetAttribute((const void*)gemm256w4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES);
+                attr4 = true;
+            }
+            hipLaunchKernelGGL(gemm256w4_kernel<EPI>, grid2, dim3(256), W4_LDS_BYTES, stream, p);
+            TG_LAUNCH_CHECK("tg_gemm_bf16(256w4)");
+            return TG_OK;
+        }
         if (abl == 1) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2_BYTES);
                         hipLaunchKernelGGL((gemm256_kernel<EPI, 1>), grid2, dim3(512), RING2_BYTES, stream, p); }
         else if (abl == 2) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2_BYTES);

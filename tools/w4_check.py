@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Experiment harness: the 4-wave GEMM (TG_GEMM_W4=1) against the shipped 8-wave kernel and an fp32 reference.
+Run once per mode (the env knob is read once per process); the second run compares bitwise with the first run's outputs."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tokensgen_amd import kernels as K  # noqa: E402
+from tokensgen_amd import lib as L  # noqa: E402
+
+DEV, BF = "cuda", torch.bfloat16
+mode = os.environ.get("TG_GEMM_W4", "0")
+outdir = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/w4"
+os.makedirs(outdir, exist_ok=True)
+
+
+def rnd(*shape, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF).to(DEV)
+
+
+res = {}
+ok = True
+for (M, N, Kk, B, epi) in [(1031, 512, 320, 3, 0), (2050, 768, 1024, 2, 0), (1500, 256, 256, 1, 1), (4096, 1024, 512, 1, 2),
+                           (17776, 3072, 3072, 1, 0), (5000, 2048, 12288, 1, 0), (1111, 256, 448, 2, 0)]:
+    a_full = rnd(B, M + 5, Kk + 8, seed=1)
+    a = a_full[:, 2:2 + M, :Kk]
+    w = rnd(N, Kk, seed=2, scale=0.05)
+    bias = rnd(N, seed=3)
+    out_full = torch.zeros(B, M, N + 16, dtype=BF, device=DEV)
+    out = out_full[:, :, 8:8 + N]
+    K.gemm(a, w, bias, out, epi)
+    torch.cuda.synchronize()
+    pre = a.float() @ w.float().T + bias.float()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(pre.to(BF).float(), approximate="tanh")
+    elif epi == 2:
+        ref = torch.nn.functional.silu(pre.to(BF).float())
+    else:
+        ref = pre
+    rel = ((out.float() - ref).norm() / ref.norm()).item()
+    pad_ok = bool((out_full[:, :, :8] == 0).all() and (out_full[:, :, 8 + N:] == 0).all())
+    print(f"mode={mode} M={M} N={N} K={Kk} B={B} epi={epi} rel={rel:.2e} pad_ok={pad_ok}", flush=True)
+    ok &= rel < 6e-3 and pad_ok
+    res[(M, N, Kk, B, epi)] = out.contiguous().cpu()
+torch.save(res, f"{outdir}/out_{mode}.pt")
+other = f"{outdir}/out_{'0' if mode != '0' else '1'}.pt"
+if os.path.exists(other):
+    o = torch.load(other)
+    for k, v in res.items():
+        same = torch.equal(v, o[k])
+        print("bitwise vs other mode", k, same)
+        ok &= same
+print("OK" if ok else "FAILED")
+sys.exit(0 if ok else 1)
