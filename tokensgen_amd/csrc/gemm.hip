@@ -471,7 +471,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 // anything, so the wave software-pipelines itself: every MFMA is followed by at most one LDS-DMA piece or one ds_read_b128.
 //
 //   LDS: 2 stages x (A[256 rows][128 B] | W[256 rows][128 B]) = 128 KiB, + 4 x 4 KiB epilogue staging.  16-B slot of a row
-//   XOR-swizzled by row&7 (applied on the DMA source address; conflict-free b128 reads).  DMA piece = 8 rows x 128 B: every
+//   XOR-swizzled by row&15 over the 256-B bank line (applied on the DMA source address; conflict-free b128 reads).  DMA piece = 8 rows x 128 B: every
 //   global access of the fill is a full 128-byte row segment; `buffer_load_dwordx4 ... lds` with a per-tile resource whose
 //   num_records ends at the last valid row, so M-edge rows read zeros (no clamping arithmetic).
 //   stage s (buffer b = s&1), k16-steps 0..3 with fragment sets 0..3:
@@ -488,7 +488,9 @@ constexpr int OPER3_BYTES = 256 * BK3 * 2;       // 32 KiB per operand per stage
 constexpr int STAGE3_BYTES = 2 * OPER3_BYTES;    // 64 KiB
 constexpr int W4_STG_OFF = 2 * STAGE3_BYTES;     // epilogue staging behind the two stages
 constexpr int W4_BIAS_OFF = W4_STG_OFF + 4 * 4096;   // 256 B of bias per wave
-constexpr int W4_LDS_BYTES = W4_BIAS_OFF + 4 * 256;
+constexpr int W4_TOK_OFF = W4_BIAS_OFF + 4 * 256;    // gated-residual epilogue: group id of this wave's 128 rows, one dword each
+constexpr int W4_GTAB_OFF = W4_TOK_OFF + 4 * 512;    // ... and the gate-row element offset of every group (16 dwords per wave)
+constexpr int W4_LDS_BYTES = W4_GTAB_OFF + 4 * 64;
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -536,9 +538,18 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
 
     // ---- DMA side: a cursor (tile, k-stage) that runs two stages ahead of the MFMAs ----
     // lane -> row lane>>3 of the piece, physical slot lane&7 holds logical slot (lane&7)^(row&7); row&7 == lane>>3
-    const int dslot = (lane & 7) ^ (lane >> 3);
-    const int voffA = (int)(((long)(wave * 64 + (lane >> 3)) * p.lda + dslot * 8) * 2);
-    const int voffW = (int)(((long)(wave * 64 + (lane >> 3)) * p.ldw + dslot * 8) * 2);
+    // LDS image: element (row, 16-B slot s) of an operand tile lives at byte (row*128 + s*16) ^ ((row & 15) << 4): ds_read_b128 is served
+    // in four 16-lane groups against a 256-B (two-row) bank line, and the rows of a group are distinct mod 16, so this XOR is
+    // conflict-free (XOR by row&7 alone is a 2-way conflict: rows r and r+8 of a group share a slot).  Bit 3 of the row flips address
+    // bit 7, i.e. swaps the two rows of a pair; a DMA piece (8 rows, lane-linear 1 KiB) therefore fetches, at physical row
+    // pr = lane>>3 and physical slot lane&7 of piece i, source row pr ^ (i & 1) and source slot (lane&7) ^ (row & 7).
+    int voffA[2], voffW[2];
+#pragma unroll
+    for (int odd = 0; odd < 2; ++odd) {
+        const int row = (lane >> 3) ^ odd, dslot = (lane & 7) ^ row;
+        voffA[odd] = (int)(((long)(wave * 64 + row) * p.lda + dslot * 8) * 2);
+        voffW[odd] = (int)(((long)(wave * 64 + row) * p.ldw + dslot * 8) * 2);
+    }
     const int pieceA = (int)(p.lda * 16), pieceW = (int)(p.ldw * 16);      // 8 rows, bytes
     __amdgpu_buffer_rsrc_t rA, rW;
     Coord nc;                                      // coordinates of the tile the DMA cursor is in (= the next tile once it left this one)
@@ -555,9 +566,9 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
     auto dma_piece = [&](int q) {                  // q = 0..7: A pieces, 8..15: W pieces of the cursor's stage
         char* dst = smem + dbuf * STAGE3_BYTES + (q >> 3) * OPER3_BYTES + (wave * 64 + (q & 7) * 8) * 128;
         if (q < 8)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)dst, 16, voffA + (q & 7) * pieceA, dk * (BK3 * 2), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)dst, 16, voffA[q & 1] + (q & 7) * pieceA, dk * (BK3 * 2), 0, 0);
         else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)dst, 16, voffW + (q & 7) * pieceW, dk * (BK3 * 2), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)dst, 16, voffW[q & 1] + (q & 7) * pieceW, dk * (BK3 * 2), 0, 0);
     };
     auto dma_advance = [&]() { dbuf ^= 1; ++dk; };
     auto dma_next_tile = [&]() {                   // the cursor leaves the current tile (called once per tile, before its last two stages)
@@ -568,12 +579,12 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
 
     // ---- fragment addresses (32x32x16 operands: lane -> row lane&31, logical 16-B slot ks*2 + (lane>>5)) ----
     const int j31 = lane & 31, hi = lane >> 5;
-    const int swz = (hi ^ (j31 & 7)) << 4;
+    const int swz = ((j31 * 128) | (hi << 4)) ^ ((j31 & 15) << 4);   // row j31 of a 32-row block, slot hi, swizzled (see the DMA side)
     int ra[4], rw[4];                              // byte address of k-step ks; + mb*4096 / nb*4096 as the immediate
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        ra[ks] = ((wm * 128 + j31) * 128 + swz) ^ (ks << 5);
-        rw[ks] = (OPER3_BYTES + (wn * 128 + j31) * 128 + swz) ^ (ks << 5);
+        ra[ks] = (wm * 128 * 128 + swz) ^ (ks << 5);
+        rw[ks] = (OPER3_BYTES + wn * 128 * 128 + swz) ^ (ks << 5);
     }
     bf16x8 fa[4][4], fw[4][4];                     // [k-step][32-row block]
     f32x16 acc[4][4];                              // [m block][n block]
@@ -616,7 +627,7 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
 #define W4_D0 18
 #endif
 #ifndef W4_DS
-#define W4_DS 2
+#define W4_DS 3
 #endif
 #ifndef W4_B2
 #define W4_B2 46
@@ -672,6 +683,13 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
         W4_SB();
     };
 
+    if (EPI == TG_EPI_BIAS_GATE_RES) {             // per-wave LDS table: element offset of group g's gate row inside one batch item of `mod`
+        int v = 0;
+#pragma unroll
+        for (int g = 0; g < TG_MAX_GROUPS; ++g) v = lane == g ? (int)(p.g.row[g] * p.g.mod_ld + p.g.gate_col[g]) : v;
+        const int ga = W4_GTAB_OFF + wave * 64 + (lane & 15) * 4;
+        if (lane < TG_MAX_GROUPS) asm volatile("ds_write_b32 %0, %1" ::"v"(ga), "v"(v));
+    }
     int tile = blockIdx.x;
     set_dma_tile(tile);
     Coord cc = nc;
@@ -702,6 +720,12 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
         if (ebias)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ebias + cc.n0 + wn * 128 + lane * 2),
                                              (__attribute__((address_space(3))) void*)(smem + W4_BIAS_OFF + wave * 256), 4, 0, 0);
+        if (EPI == TG_EPI_BIAS_GATE_RES) {           // group ids of the wave's 128 rows (bytes, zero-extended to one dword per lane by the DMA)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.g.tok_group + min(cc.m0 + wm * 128 + h * 64 + lane, p.M - 1)),
+                                                 (__attribute__((address_space(3))) void*)(smem + W4_TOK_OFF + wave * 512 + h * 256), 1, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -743,10 +767,46 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) bb[q >> 2][q & 3] = u32x2{0u, 0u};
         }
+        // gated residual: y = residual + gate[group(m)] * bf16(linear).  Per lane the 16 read-back rows (mt, it) -> gate-row offsets via
+        // the two LDS tables; the gate / residual chunks of block k+1 are requested before block k is converted and stored
+        int goff[4][4];
+        uint4 gq[2][4], rq[2][4];
+        const bf16_t* gbase = (const bf16_t*)p.g.mod + (long)ec.b * p.g.mod_batch_stride + ec.n0 + wn * 128 + (lane & 7) * 8;
+        const bf16_t* rbase_g = p.R + (long)ec.b * p.sRb + (long)(ec.m0 + wm * 128 + (lane >> 3)) * p.ldr + ec.n0 + wn * 128 + (lane & 7) * 8;
+        const int rowclamp = eM - 1 - (ec.m0 + wm * 128 + (lane >> 3));      // rows past M re-read the last valid row (never stored)
+        auto gate_issue = [&](auto blkc) {
+            constexpr int BLK = decltype(blkc)::value, MT = BLK >> 1, NH = BLK & 1;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-            for (int nh = 0; nh < 2; ++nh) {
+            for (int it = 0; it < 4; ++it) {
+                gq[BLK & 1][it] = *(const uint4*)(gbase + goff[MT][it] + NH * 64);
+                rq[BLK & 1][it] = *(const uint4*)(rbase_g + (long)min(MT * 32 + it * 8, rowclamp) * p.ldr + NH * 64);
+            }
+        };
+        if (EPI == TG_EPI_BIAS_GATE_RES) {
+            const int ta = W4_TOK_OFF + wave * 512 + (lane >> 3) * 4;
+            int gid[4][4];
+            static_for<0, 16>([&](auto qc) {
+                constexpr int Q = decltype(qc)::value;
+                int& d = gid[Q >> 2][Q & 3];
+                const int ad = ta;
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d) : "v"(ad), "n"(((Q >> 2) * 32 + (Q & 3) * 8) * 4));
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            W4_SB();
+            static_for<0, 16>([&](auto qc) {
+                constexpr int Q = decltype(qc)::value;
+                int& d = goff[Q >> 2][Q & 3];
+                const int ad = W4_GTAB_OFF + wave * 64 + gid[Q >> 2][Q & 3] * 4;
+                asm volatile("ds_read_b32 %0, %1" : "=v"(d) : "v"(ad));
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            W4_SB();
+            gate_issue(std::integral_constant<int, 0>{});
+        }
+        static_for<0, 8>([&](auto blkc) {
+            constexpr int BLK = decltype(blkc)::value, mt = BLK >> 1, nh = BLK & 1;
+            {
+                if constexpr (EPI == TG_EPI_BIAS_GATE_RES && BLK < 7) gate_issue(std::integral_constant<int, (BLK < 7 ? BLK + 1 : 7)>{});
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -780,11 +840,8 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
                     const int n = ec.n0 + wn * 128 + nh * 64 + ch * 8;
                     if (m < eM) {
                         uint4 o = uint4{val[it].x, val[it].y, val[it].z, val[it].w};
-                        if (EPI == TG_EPI_BIAS_GATE_RES) {   // y = residual + gate[group(m)] * bf16(linear)
-                            const int g = p.g.tok_group[m];
-                            const bf16_t* gate_row = (const bf16_t*)p.g.mod + (long)ec.b * p.g.mod_batch_stride + (long)p.g.row[g] * p.g.mod_ld + p.g.gate_col[g];
-                            const uint4 gg = *(const uint4*)(gate_row + n);
-                            const uint4 rr = *(const uint4*)(p.R + (long)ec.b * p.sRb + (long)m * p.ldr + n);
+                        if (EPI == TG_EPI_BIAS_GATE_RES) {
+                            const uint4 gg = gq[BLK & 1][it], rr = rq[BLK & 1][it];
                             const uint32_t vu[4] = {o.x, o.y, o.z, o.w}, gu[4] = {gg.x, gg.y, gg.z, gg.w}, ru[4] = {rr.x, rr.y, rr.z, rr.w};
                             uint32_t ou[4];
 #pragma unroll
@@ -797,7 +854,7 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
                     }
                 }
             }
-        }
+        });
     }
 #undef W4_SB
 #undef W4_DSR
@@ -826,7 +883,7 @@ int launch(GemmParams p, hipStream_t stream) {
         }
         static const int abl = [] { const char* e = getenv("TG_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
         const dim3 grid2(tiles2 < n_cu ? tiles2 : n_cu);
-        static const int w4 = [] { const char* e = getenv("TG_GEMM_W4"); return e ? atoi(e) : 0; }();
+        static const int w4 = [] { const char* e = getenv("TG_GEMM_W4"); return e ? atoi(e) : 1; }();   // 0: the 8-wave kernel for every shape
         if (w4 && p.K >= 4 * BK3 && !abl) {
             static bool attr4 = false;
             if (!attr4) {

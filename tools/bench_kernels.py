@@ -65,6 +65,15 @@ def bench_gemm():
         out = torch.empty(B, M, Nn, dtype=BF, device=DEV)
         ms = timeit(lambda: K.gemm(a, w, bias, out, epi))
         print(json.dumps({"kernel": f"gemm_{name}_M{M}_N{Nn}_K{Kk}", "ms": ms, "tflops": 2.0 * B * M * Nn * Kk / ms / 1e9}))
+    # the block's two gated-residual GEMMs as the DiT runs them (in place on the hidden states, 2 token groups)
+    mod = rnd(B, 2, 6 * D, scale=0.5)
+    tok_group = (torch.arange(N, device=DEV) >= N - N1).to(torch.uint8)
+    tab = K.GroupTable(mod, tok_group, [0, 1], [0, 0], [D, D], [2 * D, 2 * D])
+    for (Kk, name) in [(D, "out(gate)"), (4 * D, "ff2(gate)")]:
+        a, w, bias = rnd(B, N, Kk), rnd(D, Kk, scale=0.02), rnd(D)
+        x = rnd(B, N, D)
+        ms = timeit(lambda: K.gemm(a, w, bias, x, L.EPI_BIAS_GATE_RES, residual=x, gate=tab))
+        print(json.dumps({"kernel": f"gemm_{name}_M{N}_N{D}_K{Kk}", "ms": ms, "tflops": 2.0 * B * N * D * Kk / ms / 1e9}))
 
 
 def bench_norm():

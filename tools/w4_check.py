@@ -45,6 +45,27 @@ for (M, N, Kk, B, epi) in [(1031, 512, 320, 3, 0), (2050, 768, 1024, 2, 0), (150
     print(f"mode={mode} M={M} N={N} K={Kk} B={B} epi={epi} rel={rel:.2e} pad_ok={pad_ok}", flush=True)
     ok &= rel < 6e-3 and pad_ok
     res[(M, N, Kk, B, epi)] = out.contiguous().cpu()
+# gated residual epilogue (in place), incl. an M edge and two batch items
+for (M, N, Kk, B) in [(1111, 512, 512, 2), (2500, 256, 1024, 1), (17776, 3072, 3072, 1)]:
+    a, w, bias = rnd(B, M, Kk, seed=11), rnd(N, Kk, seed=12, scale=0.05), rnd(N, seed=13)
+    x = rnd(B, M, N, seed=14)
+    rows, ngroups = 7, 5
+    mod = rnd(B, rows, 3 * N * ngroups, seed=15, scale=0.5)
+    g = torch.Generator().manual_seed(16)
+    tok_group = torch.randint(0, ngroups, (M,), generator=g, dtype=torch.uint8).to(DEV)
+    r = [int(v) for v in torch.randint(0, rows, (ngroups,), generator=g)]
+    ga = [3 * N * i + 2 * N for i in range(ngroups)]
+    tab = K.GroupTable(mod, tok_group, r, [3 * N * i for i in range(ngroups)], [3 * N * i + N for i in range(ngroups)], ga)
+    tg = tok_group.long()
+    idx = torch.tensor(ga, device=DEV)[tg][:, None] + torch.arange(N, device=DEV)[None]
+    gate = mod.float()[:, torch.tensor(r, device=DEV)[tg][:, None], idx]
+    ref = x.float() + gate * (a.float() @ w.float().T + bias.float()).to(BF).float()
+    K.gemm(a, w, bias, x, L.EPI_BIAS_GATE_RES, residual=x, gate=tab)
+    torch.cuda.synchronize()
+    rel = ((x.float() - ref).norm() / ref.norm()).item()
+    print(f"mode={mode} gate_res M={M} N={N} K={Kk} B={B} rel={rel:.2e}", flush=True)
+    ok &= rel < 4e-3
+    res[("gate", M, N, Kk, B)] = x.contiguous().cpu()
 torch.save(res, f"{outdir}/out_{mode}.pt")
 other = f"{outdir}/out_{'0' if mode != '0' else '1'}.pt"
 if os.path.exists(other):
