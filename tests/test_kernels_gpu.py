@@ -408,11 +408,12 @@ def test_gemm_pair_equals_two_launches(K):
         assert torch.equal(a1, c1) and torch.equal(a2, c2) and a1.abs().sum() > 0
 
 
-def test_gemm_4wave_kernel_bitwise_equals_8wave_kernel(tmp_path):
-    """The 256x256x64 4-wave kernel (default for M >= 1024, K >= 256) accumulates k in the same order as the 8-wave 256x256x32
-    kernel (TG_GEMM_W4=0), so the two must agree bit for bit — bias / GELU / SiLU / gated-residual epilogues, M edges, strided
-    views, several tiles per workgroup (the DMA cursor crossing tile boundaries), K = 12288.  The knob is read once per process:
-    tools/w4_check.py runs once per mode, checks each mode against fp32 torch and the second run against the first run's outputs."""
+def test_gemm_4wave_kernel_matches_8wave_kernel(tmp_path):
+    """The 256x256x64 4-wave kernel (default for M >= 1024, K >= 256; 16x16x32 MFMA) against the 8-wave 256x256x32 kernel
+    (TG_GEMM_W4=0; 32x32x16 MFMA) and fp32 torch — bias / GELU / SiLU / gated-residual epilogues, M edges, strided views, several
+    tiles per workgroup (the DMA cursor crossing tile boundaries), K = 12288.  The knob is read once per process: tools/w4_check.py
+    runs once per mode, checks each mode against fp32 torch and the second run against the first run's outputs (equal up to the
+    bf16 rounding of differently chunked fp32 sums)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -420,4 +421,4 @@ def test_gemm_4wave_kernel_bitwise_equals_8wave_kernel(tmp_path):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "w4_check.py"), str(tmp_path)], env=dict(os.environ, TG_GEMM_W4=mode),
                            capture_output=True, text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "bitwise vs other mode" in r.stdout and "False" not in r.stdout
+    assert "vs other mode" in r.stdout

@@ -462,22 +462,28 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 }
 
 // ================================================================================================
-// 256x256x64 tile, FOUR waves (one per SIMD), each 128x128 = 4x4 MFMA 32x32x16 with the 256 accumulators in AGPRs.
+// 256x256x64 tile, FOUR waves (one per SIMD), each 128x128 = 8x8 MFMA 16x16x32 with the 256 accumulators in AGPRs.
 //
-// Why: LDS bandwidth.  In the 8-wave kernel above a wave owns 128x64 of the tile and reads 6 KiB of fragments per 8 MFMAs: at
-// full MFMA rate that is 94 B/clk/CU of ds_read traffic plus 32 B/clk of LDS-DMA writes against the 128 B/clk the LDS has.
-// With 128x128 per wave the fragment traffic is 8 KiB per 16 MFMAs = 64 B/clk/CU (the same trade the vendor's hand-written
-// gfx950 kernel makes: MT256x256x64, 4 waves, 8x8 16x16x32 blocks per wave).  There is no second wave on the SIMD to hide
-// anything, so the wave software-pipelines itself: every MFMA is followed by at most one LDS-DMA piece or one ds_read_b128.
+// Why 128x128 per wave: LDS traffic and issue slots.  In the 8-wave kernel above a wave owns 128x64 of the tile and reads 6 KiB of
+// fragments per 8 MFMAs; here it is 8 KiB per 16 (the same trade the vendor's hand-written gfx950 kernel makes: MT256x256x64,
+// 4 waves, 8x8 16x16x32 blocks per wave).  There is no second wave on the SIMD to hide anything, so the wave software-pipelines
+// itself: every MFMA is followed by at most one LDS-DMA piece or one ds_read_b128.
+// Why 16x16x32 and not 32x32x16: POWER.  These GEMMs run against the socket power cap (1300-1400 W), so the shader clock is what
+// the kernel's energy per flop allows.  tools/ubench/mfma_power.hip (registers only, 1 wave per SIMD, 256 accumulators): the
+// 32x32x16 loop sustains 1.79 PFLOP/s at 1.79 GHz, the 16x16x32 loop 2.05 PFLOP/s at 2.04 GHz under the same cap — half the
+// accumulator-file traffic per flop.  (tools/clock_probe.py: the vendor's 16x16x32 kernel ran FF1 at 1.90 GHz, the 32x32x16
+// version of this kernel at 1.72 GHz with a HIGHER per-clock MFMA utilisation.)
 //
-//   LDS: 2 stages x (A[256 rows][128 B] | W[256 rows][128 B]) = 128 KiB, + 4 x 4 KiB epilogue staging.  16-B slot of a row
-//   XOR-swizzled by row&15 over the 256-B bank line (applied on the DMA source address; conflict-free b128 reads).  DMA piece = 8 rows x 128 B: every
-//   global access of the fill is a full 128-byte row segment; `buffer_load_dwordx4 ... lds` with a per-tile resource whose
-//   num_records ends at the last valid row, so M-edge rows read zeros (no clamping arithmetic).
-//   stage s (buffer b = s&1), k16-steps 0..3 with fragment sets 0..3:
-//     H0: 32 MFMAs of steps 0,1 | ds_reads of sets 2,3 of stage s            (buffer b)
-//     s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier      -> stage s+1 landed everywhere, buffer b has no reader left
-//     H1: 32 MFMAs of steps 2,3 | 16 DMA pieces of stage s+2 -> buffer b | ds_reads of sets 0,1 of stage s+1 (buffer b^1)
+//   LDS: 2 stages x (A[256 rows][128 B] | W[256 rows][128 B]) = 128 KiB, + 4 x 4 KiB epilogue staging + bias / group tables.
+//   16-B slot of a row XOR-swizzled by (row>>1)&7 (applied on the DMA source address): ds_read_b128 is served in four 16-lane groups
+//   against a 256-B (two-row) bank line; a group of the 16x16x32 fragment read is 8 rows at k-chunk c and 8 other rows at chunk c^1,
+//   which this swizzle spreads over all 16 slots.  DMA piece = 8 rows x 128 B: every global access of the fill is a full 128-byte
+//   row segment; `buffer_load_dwordx4 ... lds` with a per-tile resource whose num_records ends at the last valid row, so M-edge rows
+//   read zeros (no clamping arithmetic).
+//   stage s (buffer b = s&1) = 128 MFMA slots, k32-steps 0,1 with fragment sets 0,1 (16 ds_read_b128 each):
+//     slots 0..31   (every 2nd) reads of set 1 of THIS stage (buffer b); then lgkmcnt(0) + s_barrier: buffer b has no reader left
+//     slots 36..126 (every 6th) the 16 DMA pieces of stage s+2 -> buffer b
+//     slot 93       vmcnt(pieces issued so far) + s_barrier: stage s+1 landed everywhere; then (every 2nd slot) reads of set 0 of s+1
 //   The stage stream runs across output tiles (persistent): the last two stages of a tile fetch the first two of the next.
 // ================================================================================================
 #ifndef W4_ABL
@@ -537,16 +543,13 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
     };
 
     // ---- DMA side: a cursor (tile, k-stage) that runs two stages ahead of the MFMAs ----
-    // lane -> row lane>>3 of the piece, physical slot lane&7 holds logical slot (lane&7)^(row&7); row&7 == lane>>3
-    // LDS image: element (row, 16-B slot s) of an operand tile lives at byte (row*128 + s*16) ^ ((row & 15) << 4): ds_read_b128 is served
-    // in four 16-lane groups against a 256-B (two-row) bank line, and the rows of a group are distinct mod 16, so this XOR is
-    // conflict-free (XOR by row&7 alone is a 2-way conflict: rows r and r+8 of a group share a slot).  Bit 3 of the row flips address
-    // bit 7, i.e. swaps the two rows of a pair; a DMA piece (8 rows, lane-linear 1 KiB) therefore fetches, at physical row
-    // pr = lane>>3 and physical slot lane&7 of piece i, source row pr ^ (i & 1) and source slot (lane&7) ^ (row & 7).
+    // LDS image: element (row, 16-B slot s) of an operand tile lives at byte row*128 + ((s ^ ((row>>1)&7)) << 4).  A DMA piece is 8 rows,
+    // written lane-linear (1 KiB): the lane at physical row pr = lane>>3, physical slot lane&7 of piece i fetches source slot
+    // (lane&7) ^ ((row>>1)&7) with row = wave*64 + i*8 + pr, i.e. (lane&7) ^ (4*(i&1) + (pr>>1)): one offset per piece parity.
     int voffA[2], voffW[2];
 #pragma unroll
     for (int odd = 0; odd < 2; ++odd) {
-        const int row = (lane >> 3) ^ odd, dslot = (lane & 7) ^ row;
+        const int row = lane >> 3, dslot = (lane & 7) ^ (odd * 4 + (row >> 1));
         voffA[odd] = (int)(((long)(wave * 64 + row) * p.lda + dslot * 8) * 2);
         voffW[odd] = (int)(((long)(wave * 64 + row) * p.ldw + dslot * 8) * 2);
     }
@@ -577,82 +580,85 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
         if (dtile < nwg) set_dma_tile(dtile);
     };
 
-    // ---- fragment addresses (32x32x16 operands: lane -> row lane&31, logical 16-B slot ks*2 + (lane>>5)) ----
-    const int j31 = lane & 31, hi = lane >> 5;
-    const int swz = ((j31 * 128) | (hi << 4)) ^ ((j31 & 15) << 4);   // row j31 of a 32-row block, slot hi, swizzled (see the DMA side)
-    int ra[4], rw[4];                              // byte address of k-step ks; + mb*4096 / nb*4096 as the immediate
+    // ---- fragment addresses (16x16x32 operands: lane -> row lane&15 of a 16-row block, logical 16-B slot ks*4 + (lane>>4)) ----
+    const int l15 = lane & 15, ch = lane >> 4;
+    const int swz = l15 * 128 + ((ch ^ ((l15 >> 1) & 7)) << 4);
+    int ra[2], rw[2];                              // byte address of k-step ks; + mb*2048 / nb*2048 as the immediate
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        ra[ks] = (wm * 128 * 128 + swz) ^ (ks << 5);
-        rw[ks] = (OPER3_BYTES + wn * 128 * 128 + swz) ^ (ks << 5);
+    for (int ks = 0; ks < 2; ++ks) {
+        ra[ks] = (wm * 128 * 128 + swz) ^ (ks << 6);
+        rw[ks] = (OPER3_BYTES + wn * 128 * 128 + swz) ^ (ks << 6);
     }
-    bf16x8 fa[4][4], fw[4][4];                     // [k-step][32-row block]
-    f32x16 acc[4][4];                              // [m block][n block]
+    bf16x8 fa[2][8], fw[2][8];                     // [k-step][16-row block]
+    f32x4 acc[8][8];                               // [m block][n block]; lane holds D[n = 4*(lane>>4) + r][m = lane&15]
     if (W4_ABL == 2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { fa[i][j] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; fw[i][j] = fa[i][j]; }
+            for (int j = 0; j < 8; ++j) { fa[i][j] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; fw[i][j] = fa[i][j]; }
     }
 
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
 #define W4_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
-    // fragment read r (0..7) of k-step KS: 0..3 -> W blocks, 4..7 -> A blocks
+    // fragment read r (0..15) of k-step KS: 0..7 -> W blocks, 8..15 -> A blocks
     auto frag_read = [&](auto ksc, auto rc) {
         constexpr int KS = decltype(ksc)::value, R = decltype(rc)::value;
         if constexpr (W4_ABL == 2) return;
-        if constexpr (R < 4) {
+        if constexpr (R < 8) {
             bf16x8& d = fw[KS][R];
             const int ad = rw[KS];
-            W4_DSR(d, ad, R * 4096);
+            W4_DSR(d, ad, R * 2048);
         } else {
-            bf16x8& d = fa[KS][R - 4];
+            bf16x8& d = fa[KS][R - 8];
             const int ad = ra[KS];
-            W4_DSR(d, ad, (R - 4) * 4096);
+            W4_DSR(d, ad, (R - 8) * 2048);
         }
     };
-    // one stage = 64 MFMA slots (k-steps 0..3 x 16 blocks); after MFMA I the slot may carry one ds_read / one DMA piece / a barrier:
-    //   slots [0, 16*R1S)      every R1S-th: fragment read r of sets 2,3 of THIS stage                     (buffer b)
+    // one stage = 128 MFMA slots (k-steps 0,1 x 64 blocks, 16 cycles each); after MFMA I the slot may carry one ds_read / one DMA
+    // piece / a barrier:
+    //   slots [0, 16*R1S)      every R1S-th: fragment read r of set 1 of THIS stage                        (buffer b)
     //   slot  B1               lgkmcnt(0); s_barrier -> buffer b has no reader left; fragment addresses flip to buffer b^1
     //   slots [D0, D0+16*DS)   every DS-th: DMA piece of stage s+2 -> buffer b
     //   slot  B2               vmcnt(pieces issued so far in this stage); s_barrier -> stage s+1 landed everywhere
-    //   slots [R20, R20+16)    fragment read r of sets 0,1 of stage s+1                                    (buffer b^1)
+    //   slots [R20, R20+16*R2S) every R2S-th: fragment read r of set 0 of stage s+1                        (buffer b^1)
 #ifndef W4_R1S
-#define W4_R1S 1
+#define W4_R1S 2
 #endif
 #ifndef W4_B1
-#define W4_B1 17
+#define W4_B1 35
 #endif
 #ifndef W4_D0
-#define W4_D0 18
+#define W4_D0 36
 #endif
 #ifndef W4_DS
-#define W4_DS 3
+#define W4_DS 6
 #endif
 #ifndef W4_B2
-#define W4_B2 46
+#define W4_B2 93
 #endif
 #ifndef W4_R20
-#define W4_R20 47
+#define W4_R20 94
 #endif
-    static_assert(W4_B1 >= 16 * W4_R1S - W4_R1S && W4_B1 < 32 && W4_D0 > W4_B1 && W4_R20 > W4_B2 && W4_R20 + 16 <= 64 && W4_B2 >= 32, "schedule");
+#ifndef W4_R2S
+#define W4_R2S 2
+#endif
+    static_assert(W4_B1 >= 16 * W4_R1S - W4_R1S && W4_B1 < 64 && W4_D0 > W4_B1 && W4_D0 + 15 * W4_DS < 128 && W4_R20 > W4_B2 &&
+                  W4_R20 + 15 * W4_R2S < 128 && W4_B2 >= 64, "schedule");
     auto toggle = [&]() {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { ra[ks] ^= STAGE3_BYTES; rw[ks] ^= STAGE3_BYTES; }
+        for (int ks = 0; ks < 2; ++ks) { ra[ks] ^= STAGE3_BYTES; rw[ks] ^= STAGE3_BYTES; }
     };
     // STEADY: the DMA cursor stays inside the current tile and there is always something to fetch / read
     auto kstage = [&](auto steady_c, bool more, bool rd) {
         constexpr bool STEADY = decltype(steady_c)::value;
         const bool dma = STEADY || more, rdn = STEADY || rd;
-        static_for<0, 64>([&](auto ic) {
+        static_for<0, 128>([&](auto ic) {
             constexpr int I = decltype(ic)::value;
-            constexpr int KS = I >> 4, NB = (I >> 2) & 3, MB = I & 3;
-            acc[MB][NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[KS][NB], fa[KS][MB], acc[MB][NB], 0, 0, 0);
+            constexpr int KS = I >> 6, NB = (I >> 3) & 7, MB = I & 7;
+            acc[MB][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[KS][NB], fa[KS][MB], acc[MB][NB], 0, 0, 0);
             W4_SB();
-            if constexpr (I < 16 * W4_R1S && I % W4_R1S == 0) {
-                constexpr int R = I / W4_R1S;
-                frag_read(std::integral_constant<int, 2 + (R >> 3)>{}, std::integral_constant<int, R & 7>{});
-            }
+            if constexpr (I < 16 * W4_R1S && I % W4_R1S == 0)
+                frag_read(std::integral_constant<int, 1>{}, std::integral_constant<int, I / W4_R1S>{});
             if constexpr (I == W4_B1) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -671,9 +677,8 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
                 __builtin_amdgcn_s_barrier();
                 W4_SB();
             }
-            if constexpr (I >= W4_R20 && I - W4_R20 < 16) {
-                constexpr int R = I - W4_R20;
-                if (rdn) frag_read(std::integral_constant<int, (R >> 3)>{}, std::integral_constant<int, R & 7>{});
+            if constexpr (I >= W4_R20 && (I - W4_R20) % W4_R2S == 0 && (I - W4_R20) / W4_R2S < 16) {
+                if (rdn) frag_read(std::integral_constant<int, 0>{}, std::integral_constant<int, (I - W4_R20) / W4_R2S>{});
             }
             W4_SB();
         });
@@ -703,13 +708,10 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
     W4_SB();
 
     for (; tile < nwg; tile += gridDim.x) {
-        // fragment sets 0,1 of this tile's stage 0 (its buffer landed: waited in the previous tile's last stage / the prologue).  Read
+        // fragment set 0 of this tile's stage 0 (its buffer landed: waited in the previous tile's last stage / the prologue).  Read
         // here and not under the previous epilogue: 64 live fragment registers there would be spilled, and a VMEM reload into a
         // fragment register makes the compiler guard the k loop's first ds_reads with vmcnt(1..3), i.e. wait for the DMA just issued.
-        static_for<0, 16>([&](auto rc) {
-            constexpr int R = decltype(rc)::value;
-            frag_read(std::integral_constant<int, (R >> 3)>{}, std::integral_constant<int, R & 7>{});
-        });
+        static_for<0, 16>([&](auto rc) { frag_read(std::integral_constant<int, 0>{}, rc); });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         W4_SB();
         // the 128 bias values of this wave's columns go to LDS by one more DMA piece (256 B), retired by the counted waits of the first
@@ -727,11 +729,9 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
                                                  (__attribute__((address_space(3))) void*)(smem + W4_TOK_OFF + wave * 512 + h * 256), 1, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int jn = 0; jn < 4; ++jn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+            for (int jn = 0; jn < 8; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
         {
             int st = 0;
             for (; st + 2 < nst; ++st) kstage(std::true_type{}, true, true);
@@ -744,28 +744,28 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
         if (tile + (int)gridDim.x < nwg) cc = nc;
 
         // ---- epilogue through LDS (4 KiB per wave behind the stages, 16-B slots XOR-swizzled by row&7): MFMA layout -> full rows ----
-        // per 32x32 block a lane holds D[n = 8*(r>>2) + 4*hi + (r&3)][m = lane&31].  The staging accesses are asm so that the compiler's
+        // per 16x16 block a lane holds D[n = 4*(lane>>4) + r][m = lane&15].  The staging accesses are asm so that the compiler's
         // LDS-DMA alias rule (vmcnt(0) before any LDS access while a DMA is in flight) does not serialise them behind the global stores
         if (W4_ABL == 3 && p.M > 0) continue;
         bf16_t* Cb = ec.sec ? p.C2 + (long)ec.b * p.sCb2 : p.C + (long)ec.b * p.sCb;
         const int eM = ec.sec ? p.M2 : p.M;
         const int stg = W4_STG_OFF + wave * 4096;
-        const int wbase = (stg + j31 * 128 + hi * 8) | ((j31 & 7) << 4);
+        const int wbase = (stg + l15 * 128 + (ch & 1) * 8) | (((ch >> 1) ^ (l15 & 7)) << 4);
         const int rbase = stg + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);
-        u32x2 bb[4][4];                                   // bias of this lane's 16 column quads (n = nb*32 + r4*8 + hi*4 ..+3)
+        u32x2 bb[8];                                      // bias of this lane's 8 column quads (n = nb*16 + 4*(lane>>4) ..+3)
         if (ebias) {
-            const int ba = W4_BIAS_OFF + wave * 256 + hi * 8;
-            static_for<0, 16>([&](auto qc) {
+            const int ba = W4_BIAS_OFF + wave * 256 + ch * 8;
+            static_for<0, 8>([&](auto qc) {
                 constexpr int Q = decltype(qc)::value;
-                u32x2& d = bb[Q >> 2][Q & 3];
+                u32x2& d = bb[Q];
                 const int ad = ba;
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(ad), "n"(((Q >> 2) * 32 + (Q & 3) * 8) * 2));
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(ad), "n"(Q * 32));
             });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             W4_SB();
         } else {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) bb[q >> 2][q & 3] = u32x2{0u, 0u};
+            for (int q = 0; q < 8; ++q) bb[q] = u32x2{0u, 0u};
         }
         // gated residual: y = residual + gate[group(m)] * bf16(linear).  Per lane the 16 read-back rows (mt, it) -> gate-row offsets via
         // the two LDS tables; the gate / residual chunks of block k+1 are requested before block k is converted and stored
@@ -807,27 +807,24 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
             constexpr int BLK = decltype(blkc)::value, mt = BLK >> 1, nh = BLK & 1;
             {
                 if constexpr (EPI == TG_EPI_BIAS_GATE_RES && BLK < 7) gate_issue(std::integral_constant<int, (BLK < 7 ? BLK + 1 : 7)>{});
+                static_for<0, 8>([&](auto wc) {
+                    constexpr int MB2 = decltype(wc)::value >> 2, NB4 = decltype(wc)::value & 3;
+                    const f32x4 a = acc[mt * 2 + MB2][nh * 4 + NB4];
+                    const u32x2 bq = bb[nh * 4 + NB4];
+                    float v[4] = {a[0] + bf16lo_to_f32(bq.x), a[1] + bf16hi_to_f32(bq.x), a[2] + bf16lo_to_f32(bq.y), a[3] + bf16hi_to_f32(bq.y)};
+                    if (EPI == TG_EPI_BIAS_GELU) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                        for (int i = 0; i < 4; ++i) v[i] = gelu_tanh(round_bf16(v[i]));
+                    } else if (EPI == TG_EPI_BIAS_SILU) {
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x16& a = acc[mt][nh * 2 + nt];
-                        const u32x2 bq = bb[nh * 2 + nt][r4];
-                        float v[4] = {a[r4 * 4 + 0] + bf16lo_to_f32(bq.x), a[r4 * 4 + 1] + bf16hi_to_f32(bq.x),
-                                      a[r4 * 4 + 2] + bf16lo_to_f32(bq.y), a[r4 * 4 + 3] + bf16hi_to_f32(bq.y)};
-                        if (EPI == TG_EPI_BIAS_GELU) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) v[i] = gelu_tanh(round_bf16(v[i]));
-                        } else if (EPI == TG_EPI_BIAS_SILU) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) v[i] = silu(round_bf16(v[i]));
-                        }
-                        u32x2 o;
-                        o.x = pack_bf16x2(v[0], v[1]);
-                        o.y = pack_bf16x2(v[2], v[3]);
-                        const int wa = wbase ^ ((nt * 4 + r4) << 4);
-                        asm volatile("ds_write_b64 %0, %1" ::"v"(wa), "v"(o));
+                        for (int i = 0; i < 4; ++i) v[i] = silu(round_bf16(v[i]));
                     }
+                    u32x2 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    const int wa = wbase ^ (NB4 << 5);
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(wa), "v"(o), "n"(MB2 * 2048));
+                });
                 u32x4 val[4];
 #pragma unroll
                 for (int it = 0; it < 4; ++it) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(val[it]) : "v"(rbase), "n"(it * 1024));

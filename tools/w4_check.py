@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Experiment harness: the 4-wave GEMM (TG_GEMM_W4=1) against the shipped 8-wave kernel and an fp32 reference.
-Run once per mode (the env knob is read once per process); the second run compares bitwise with the first run's outputs."""
+Run once per mode (the env knob is read once per process); the second run compares with the first run's outputs."""
 import os
 import sys
 
@@ -11,7 +11,7 @@ from tokensgen_amd import kernels as K  # noqa: E402
 from tokensgen_amd import lib as L  # noqa: E402
 
 DEV, BF = "cuda", torch.bfloat16
-mode = os.environ.get("TG_GEMM_W4", "0")
+mode = os.environ.get("TG_GEMM_W4", "1")
 outdir = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/w4"
 os.makedirs(outdir, exist_ok=True)
 
@@ -70,9 +70,10 @@ torch.save(res, f"{outdir}/out_{mode}.pt")
 other = f"{outdir}/out_{'0' if mode != '0' else '1'}.pt"
 if os.path.exists(other):
     o = torch.load(other)
-    for k, v in res.items():
-        same = torch.equal(v, o[k])
-        print("bitwise vs other mode", k, same)
-        ok &= same
+    for k, v in res.items():      # the two kernels accumulate k in different chunkings (16x16x32 vs 32x32x16 MFMA): equal up to bf16 rounding
+        d = ((v.float() - o[k].float()).norm() / o[k].float().norm()).item()
+        frac = (v != o[k]).float().mean().item()
+        print(f"vs other mode {k}: rel {d:.2e}, differing elements {frac:.4f}")
+        ok &= d < 1.5e-3 and frac < 0.2
 print("OK" if ok else "FAILED")
 sys.exit(0 if ok else 1)
