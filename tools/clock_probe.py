@@ -21,6 +21,20 @@ w = (torch.randn(N, Kk, device="cuda") * 0.02).to(torch.bfloat16)
 b = torch.randn(N, device="cuda").to(torch.bfloat16)
 out = torch.empty(1, M, N, dtype=torch.bfloat16, device="cuda")
 fn = (lambda: K.gemm(a, w, b, out, L.EPI_BIAS)) if which == "tg" else (lambda: torch.nn.functional.linear(a[0], w, b))
+if which == "attn":          # the DiT's main attention launch (2 x 48 heads, 17776 queries x 17776 keys + 480 vip keys)
+    B, H, N1, NP = 2, 48, 17776, 480
+    D = H * 64
+    qkv = (torch.randn(B, N1, 3 * D, device="cuda") * 0.4).to(torch.bfloat16)
+    qkvv = (torch.randn(B, N1 + NP, 3 * D, device="cuda") * 0.4).to(torch.bfloat16)
+    pad = lambda n: (n + 63) // 64 * 64
+    vt1 = torch.empty(B, H, 64, pad(N1), dtype=torch.bfloat16, device="cuda")
+    vt2 = torch.empty(B, H, 64, pad(NP), dtype=torch.bfloat16, device="cuda")
+    K.transpose_v(qkv[:, :, 2 * D:], H, 0, N1, vt1)
+    K.transpose_v(qkvv[:, :, 2 * D:], H, N1, NP, vt2)
+    ao = torch.empty(B, N1, D, dtype=torch.bfloat16, device="cuda")
+    fn = lambda: K.attention(qkv[:, :, :D], qkv[:, :, D:2 * D], vt1, N1, ao, H, 0.125, qkvv[:, :N1, :D], qkvv[:, N1:, D:2 * D], vt2, NP, 0.6,
+                             k_prescaled=True)
+    M, N, Kk = 1, 1, (B * (4.0 * N1 * N1 * D + 4.0 * N1 * NP * D)) / 2.0
 samples, stop = [], False
 
 
