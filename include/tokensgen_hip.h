@@ -70,6 +70,17 @@ int tg_gemm_bf16_pair(const void* A1, long strideA1, const void* W1, const void*
                       const void* A2, long strideA2, const void* W2, const void* bias2, void* C2, long strideC2, int M2,
                       long lda, long ldw, long ldc, int N, int K, int batch, int epilogue, hipStream_t stream);
 
+/* The QKV projection(s) of an attention block with the V third delivered TRANSPOSED: like tg_gemm_bf16_pair with the bias epilogue
+ * (second problem optional: A2 == NULL), except that output columns n >= v_col0 are not written to C but to
+ * Vt[b][n - v_col0][m] (row stride vt_ld elements, a multiple of 64 >= M; columns M..vt_ld-1 are written as zeros; batch stride
+ * (N - v_col0)*vt_ld) — the [head][64][keys] image tg_attention_fwd reads, i.e. tg_transpose_v fused into the GEMM epilogue (the
+ * tile's MFMA operands are exchanged so that a lane holds consecutive tokens; no extra pass over V).  Values are bitwise those of
+ * tg_gemm_bf16 + tg_transpose_v.  Needs the 4-wave kernel's shapes: M >= 1024, N % 256 == 0, K % 64 == 0, K >= 256, v_col0 % 256 == 0.
+ * Replaces attention_processor.py:2009-2018 (to_q/k/v, vip_to_q/k/v) + the .view(...).transpose(1, 2) of value at :2024-2029. */
+int tg_gemm_bf16_qkv(const void* A1, long strideA1, const void* W1, const void* bias1, void* C1, long strideC1, int M1, void* Vt1, long vt_ld1,
+                     const void* A2, long strideA2, const void* W2, const void* bias2, void* C2, long strideC2, int M2, void* Vt2, long vt_ld2,
+                     long lda, long ldw, long ldc, int N, int K, int batch, int v_col0, hipStream_t stream);
+
 /* y = LayerNorm(x; w, b, eps) * (1 + scale[g]) + shift[g], g = group of the token.  One pass, fp32 stats.
  * modulate == 0: plain affine LayerNorm (norm_final, cogvideox_transformer_3d.py:741).
  * Replaces normalization.py:441-460 (CogVideoXLayerNormZero), :477-488 (VIP), :70-92 (AdaLayerNorm).

@@ -408,6 +408,40 @@ def test_gemm_pair_equals_two_launches(K):
         assert torch.equal(a1, c1) and torch.equal(a2, c2) and a1.abs().sum() > 0
 
 
+@pytest.mark.parametrize("two", [False, True])
+def test_gemm_qkv_vt_equals_gemm_plus_transpose(K, two):
+    """tg_gemm_bf16_qkv: the V third of a QKV projection written transposed by the GEMM epilogue (operands exchanged for those tiles)
+    is bitwise tg_gemm_bf16 + tg_transpose_v, including the zero padding of the key axis out to a multiple of 64; the q/k columns
+    are bitwise the plain GEMM's; the V columns of the C buffer are left untouched.  Ragged last m-tiles, two batch items, one and
+    two problems per launch, several tiles per workgroup."""
+    from tokensgen_amd import lib as L
+    B, H, Kd = 2, 12, 512
+    D = H * 64
+    N = 3 * D
+    M1, M2 = 1100, 1230
+    pad = lambda n: (n + 63) // 64 * 64
+    x = _rand(B, M2, Kd, seed=41)
+    w1, w2, b1, b2 = _rand(N, Kd, seed=42, scale=0.05), _rand(N, Kd, seed=43, scale=0.05), _rand(N, seed=44), _rand(N, seed=45)
+    ref1, ref2 = torch.zeros(B, M1, N, dtype=torch.bfloat16, device=DEV), torch.zeros(B, M2, N, dtype=torch.bfloat16, device=DEV)
+    K.gemm(x[:, :M1], w1, b1, ref1, L.EPI_BIAS)
+    K.gemm(x, w2, b2, ref2, L.EPI_BIAS)
+    rvt1 = torch.full((B, H, 64, pad(M1)), 7.0, dtype=torch.bfloat16, device=DEV)
+    rvt2 = torch.full((B, H, 64, pad(M2)), 7.0, dtype=torch.bfloat16, device=DEV)
+    K.transpose_v(ref1[:, :, 2 * D:], H, 0, M1, rvt1)
+    K.transpose_v(ref2[:, :, 2 * D:], H, 0, M2, rvt2)
+    c1, c2 = torch.full_like(ref1, 3.0), torch.full_like(ref2, 3.0)
+    vt1, vt2 = torch.full_like(rvt1, 5.0), torch.full_like(rvt2, 5.0)
+    if two:
+        K.gemm_qkv(x[:, :M1], w1, b1, c1, vt1, x, w2, b2, c2, vt2)
+    else:
+        K.gemm_qkv(x[:, :M1], w1, b1, c1, vt1)
+        K.gemm_qkv(x, w2, b2, c2, vt2)
+    for c, ref, vt, rvt, M in ((c1, ref1, vt1, rvt1, M1), (c2, ref2, vt2, rvt2, M2)):
+        assert torch.equal(c[:, :, :2 * D], ref[:, :, :2 * D])
+        assert (c[:, :, 2 * D:] == 3.0).all()                      # V columns of C: never written
+        assert torch.equal(vt, rvt) and (vt[:, :, :, M:] == 0).all() and vt[:, :, :, :M].abs().sum() > 0
+
+
 def test_gemm_4wave_kernel_matches_8wave_kernel(tmp_path):
     """The 256x256x64 4-wave kernel (default for M >= 1024, K >= 256; 16x16x32 MFMA) against the 8-wave 256x256x32 kernel
     (TG_GEMM_W4=0; 32x32x16 MFMA) and fp32 torch — bias / GELU / SiLU / gated-residual epilogues, M edges, strided views, several

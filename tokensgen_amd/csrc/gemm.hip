@@ -43,6 +43,10 @@ struct GemmParams {
     // optional second problem of the same N, K, batch, leading dimensions and epilogue (256^2 kernel only): its tiles are appended to
     // the persistent tile list, so the two problems share ONE partial last round of CUs instead of paying one each
     const bf16_t* A2; const bf16_t* W2; const bf16_t* bias2; bf16_t* C2; long sAb2, sCb2; int M2;
+    // optional (4-wave kernel only): output columns n >= vt_col0 are NOT written to C but transposed to Vt[b][n - vt_col0][m]
+    // (row stride vt_ld elements, a multiple of 64 >= M; columns M..vt_ld-1 are written as zeros): the V third of a QKV projection
+    // delivered in the [head][64][keys] layout tg_attention_fwd reads
+    bf16_t* Vt; bf16_t* Vt2; long vt_ld, vt_ld2; int vt_col0;
     int tiles1;                                   // tiles of the first problem
     int group_m;                                  // m-tiles per n sweep of the 256^2 kernel's tile order (see launch())
 };
@@ -583,12 +587,19 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
     // ---- fragment addresses (16x16x32 operands: lane -> row lane&15 of a 16-row block, logical 16-B slot ks*4 + (lane>>4)) ----
     const int l15 = lane & 15, ch = lane >> 4;
     const int swz = l15 * 128 + ((ch ^ ((l15 >> 1) & 7)) << 4);
-    int ra[2], rw[2];                              // byte address of k-step ks; + mb*2048 / nb*2048 as the immediate
+    // rw: first MFMA operand (lane ends up holding 4 consecutive indices of it), ra: second operand (index lane&15).  Normally the first
+    // operand is the W rows (-> 4 consecutive output columns per lane); for a V^T tile the two are exchanged (-> 4 consecutive tokens per
+    // lane), which only changes WHERE the fragments are read from: the k loop and the accumulator indexing are the same code
+    int ra[2], rw[2];                              // byte address of k-step ks; + block*2048 as the immediate
+    int bufpar = 0;                                // 0 / STAGE3_BYTES: the stage buffer the fragment addresses point into
+    auto set_frag_bases = [&](bool vtile) {
+        const int aoff = wm * 128 * 128, woff = OPER3_BYTES + wn * 128 * 128;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        ra[ks] = (wm * 128 * 128 + swz) ^ (ks << 6);
-        rw[ks] = (OPER3_BYTES + wn * 128 * 128 + swz) ^ (ks << 6);
-    }
+        for (int ks = 0; ks < 2; ++ks) {
+            ra[ks] = (((vtile ? woff : aoff) + swz) ^ (ks << 6)) ^ bufpar;
+            rw[ks] = (((vtile ? aoff : woff) + swz) ^ (ks << 6)) ^ bufpar;
+        }
+    };
     bf16x8 fa[2][8], fw[2][8];                     // [k-step][16-row block]
     f32x4 acc[8][8];                               // [m block][n block]; lane holds D[n = 4*(lane>>4) + r][m = lane&15]
     if (W4_ABL == 2) {
@@ -645,6 +656,7 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
     static_assert(W4_B1 >= 16 * W4_R1S - W4_R1S && W4_B1 < 64 && W4_D0 > W4_B1 && W4_D0 + 15 * W4_DS < 128 && W4_R20 > W4_B2 &&
                   W4_R20 + 15 * W4_R2S < 128 && W4_B2 >= 64, "schedule");
     auto toggle = [&]() {
+        bufpar ^= STAGE3_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) { ra[ks] ^= STAGE3_BYTES; rw[ks] ^= STAGE3_BYTES; }
     };
@@ -711,6 +723,8 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
         // fragment set 0 of this tile's stage 0 (its buffer landed: waited in the previous tile's last stage / the prologue).  Read
         // here and not under the previous epilogue: 64 live fragment registers there would be spilled, and a VMEM reload into a
         // fragment register makes the compiler guard the k loop's first ds_reads with vmcnt(1..3), i.e. wait for the DMA just issued.
+        const bool vtile = p.Vt && cc.n0 >= p.vt_col0;
+        set_frag_bases(vtile);
         static_for<0, 16>([&](auto rc) { frag_read(std::integral_constant<int, 0>{}, rc); });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         W4_SB();
@@ -752,21 +766,49 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
         const int stg = W4_STG_OFF + wave * 4096;
         const int wbase = (stg + l15 * 128 + (ch & 1) * 8) | (((ch >> 1) ^ (l15 & 7)) << 4);
         const int rbase = stg + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);
+        // V^T tile (bias epilogue only): the operands were exchanged, so acc[i][j] is (W n-block i, activation m-block j) and a lane holds
+        // D[m = 16 j + 4 (lane>>4) + r][n = 16 i + (lane&15)] — the same staging code with rows = n and columns = m; what differs is
+        // tile-uniform: where the bias comes from, the zeroing of tokens >= M, and the base / stride / bounds of the store
+        const bool evt = EPI == TG_EPI_BIAS && vtile;
         u32x2 bb[8];                                      // bias of this lane's 8 column quads (n = nb*16 + 4*(lane>>4) ..+3)
+        float bv[8];                                      // V^T tile: bias of n = i*16 + (lane&15)
         if (ebias) {
-            const int ba = W4_BIAS_OFF + wave * 256 + ch * 8;
-            static_for<0, 8>([&](auto qc) {
-                constexpr int Q = decltype(qc)::value;
-                u32x2& d = bb[Q];
-                const int ad = ba;
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(ad), "n"(Q * 32));
-            });
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            W4_SB();
+            const int ba = W4_BIAS_OFF + wave * 256 + (evt ? l15 * 2 : ch * 8);
+            if (evt) {
+                uint32_t raw[8];
+                static_for<0, 8>([&](auto qc) {
+                    constexpr int Q = decltype(qc)::value;
+                    uint32_t& d = raw[Q];
+                    const int ad = ba;
+                    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(d) : "v"(ad), "n"(Q * 32));
+                });
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                W4_SB();
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { bv[q] = __uint_as_float(raw[q] << 16); bb[q] = u32x2{0u, 0u}; }
+            } else {
+                static_for<0, 8>([&](auto qc) {
+                    constexpr int Q = decltype(qc)::value;
+                    u32x2& d = bb[Q];
+                    const int ad = ba;
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(ad), "n"(Q * 32));
+                });
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                W4_SB();
+#pragma unroll
+                for (int q = 0; q < 8; ++q) bv[q] = 0.f;
+            }
         } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) bb[q] = u32x2{0u, 0u};
+            for (int q = 0; q < 8; ++q) { bb[q] = u32x2{0u, 0u}; bv[q] = 0.f; }
         }
+        // store geometry: row = block row of the staging image (tokens, or V^T rows n - vt_col0), col = its 64-wide column block
+        const long ostride = evt ? (ec.sec ? p.vt_ld2 : p.vt_ld) : p.ldc;
+        bf16_t* obase = evt ? (ec.sec ? p.Vt2 : p.Vt) + (long)ec.b * (p.N - p.vt_col0) * ostride : Cb;
+        const int orow0 = evt ? ec.n0 - p.vt_col0 + wn * 128 : ec.m0 + wm * 128;
+        const int ocol0 = evt ? ec.m0 + wm * 128 : ec.n0 + wn * 128;
+        const int orow_lim = evt ? 0x7fffffff : eM, ocol_lim = evt ? (int)ostride : 0x7fffffff;
+        const int mzero = evt ? eM - (ec.m0 + wm * 128 + ch * 4) : 0x7fffffff;   // V^T: token 16 j + r of this lane is real iff < mzero
         // gated residual: y = residual + gate[group(m)] * bf16(linear).  Per lane the 16 read-back rows (mt, it) -> gate-row offsets via
         // the two LDS tables; the gate / residual chunks of block k+1 are requested before block k is converted and stored
         int goff[4][4];
@@ -812,6 +854,11 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
                     const f32x4 a = acc[mt * 2 + MB2][nh * 4 + NB4];
                     const u32x2 bq = bb[nh * 4 + NB4];
                     float v[4] = {a[0] + bf16lo_to_f32(bq.x), a[1] + bf16hi_to_f32(bq.x), a[2] + bf16lo_to_f32(bq.y), a[3] + bf16hi_to_f32(bq.y)};
+                    if (EPI == TG_EPI_BIAS) {          // V^T tile: bb is zero, the bias is per row; tokens >= M become zeros
+                        const float bs = bv[mt * 2 + MB2];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = (nh * 4 + NB4) * 16 + i < mzero ? v[i] + bs : 0.f;
+                    }
                     if (EPI == TG_EPI_BIAS_GELU) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = gelu_tanh(round_bf16(v[i]));
@@ -832,10 +879,9 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
                 W4_SB();
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    const int row = it * 8 + (lane >> 3), ch = lane & 7;
-                    const int m = ec.m0 + wm * 128 + mt * 32 + row;
-                    const int n = ec.n0 + wn * 128 + nh * 64 + ch * 8;
-                    if (m < eM) {
+                    const int m = orow0 + mt * 32 + it * 8 + (lane >> 3);          // row / column of the staging image in the output
+                    const int n = ocol0 + nh * 64 + (lane & 7) * 8;
+                    if (m < orow_lim && n < ocol_lim) {
                         uint4 o = uint4{val[it].x, val[it].y, val[it].z, val[it].w};
                         if (EPI == TG_EPI_BIAS_GATE_RES) {
                             const uint4 gg = gq[BLK & 1][it], rr = rq[BLK & 1][it];
@@ -847,7 +893,7 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
                                                     bf16hi_to_f32(ru[i]) + bf16hi_to_f32(gu[i]) * bf16hi_to_f32(vu[i]));
                             o = uint4{ou[0], ou[1], ou[2], ou[3]};
                         }
-                        *(uint4*)(Cb + (long)m * p.ldc + n) = o;
+                        *(uint4*)(obase + (long)m * ostride + n) = o;
                     }
                 }
             }
@@ -983,4 +1029,34 @@ extern "C" int tg_gemm_bf16_pair(const void* A1, long strideA1, const void* W1, 
         case TG_EPI_BIAS_GELU: return launch<TG_EPI_BIAS_GELU>(p, stream);
         default: return launch<TG_EPI_BIAS_SILU>(p, stream);
     }
+}
+
+extern "C" int tg_gemm_bf16_qkv(const void* A1, long strideA1, const void* W1, const void* bias1, void* C1, long strideC1, int M1, void* Vt1, long vt_ld1,
+                                const void* A2, long strideA2, const void* W2, const void* bias2, void* C2, long strideC2, int M2, void* Vt2, long vt_ld2,
+                                long lda, long ldw, long ldc, int N, int K, int batch, int v_col0, hipStream_t stream) {
+    TG_REQUIRE(A1 && W1 && C1 && Vt1, TG_ERR_ARG, "tg_gemm_bf16_qkv: null pointer");
+    TG_REQUIRE(!A2 || (W2 && C2 && Vt2), TG_ERR_ARG, "tg_gemm_bf16_qkv: second problem needs W2, C2 and Vt2");
+    TG_REQUIRE(M1 >= 1024 && (!A2 || M2 >= 1024) && N > 0 && batch > 0 && N % BN2 == 0 && K % BK3 == 0 && K >= 4 * BK3, TG_ERR_SHAPE,
+               "tg_gemm_bf16_qkv: needs the 4-wave kernel's shapes (M >= 1024, N%%256 == 0, K%%64 == 0, K >= 256)");
+    TG_REQUIRE(v_col0 > 0 && v_col0 < N && v_col0 % BN2 == 0, TG_ERR_SHAPE, "tg_gemm_bf16_qkv: v_col0 must be a multiple of 256 inside (0, N)");
+    TG_REQUIRE(vt_ld1 % 64 == 0 && vt_ld1 >= M1 && (!A2 || (vt_ld2 % 64 == 0 && vt_ld2 >= M2)), TG_ERR_SHAPE,
+               "tg_gemm_bf16_qkv: vt_ld must be a multiple of 64 and >= M");
+    TG_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && strideA1 % 8 == 0 && strideC1 % 8 == 0 && strideA2 % 8 == 0 && strideC2 % 8 == 0 &&
+               tg_aligned16(A1) && tg_aligned16(W1) && tg_aligned16(C1) && tg_aligned16(Vt1) && tg_aligned16(A2) && tg_aligned16(W2) &&
+               tg_aligned16(C2) && tg_aligned16(Vt2), TG_ERR_ALIGN, "tg_gemm_bf16_qkv: alignment");
+    static const bool w4_off = [] { const char* e = getenv("TG_GEMM_W4"); return e && atoi(e) == 0; }();
+    static const bool f128 = [] { const char* e = getenv("TG_GEMM_FORCE_128"); return e && e[0] == '1'; }();
+    TG_REQUIRE(!w4_off && !f128 && !getenv("TG_GEMM_ABLATE"), TG_ERR_ARG, "tg_gemm_bf16_qkv: only the 4-wave GEMM kernel has the V^T epilogue (TG_GEMM_W4=0 / FORCE_128 / ABLATE set)");
+    GemmParams p{};
+    p.A = (const bf16_t*)A1; p.lda = lda; p.sAb = strideA1;
+    p.W = (const bf16_t*)W1; p.ldw = ldw;
+    p.bias = (const bf16_t*)bias1;
+    p.C = (bf16_t*)C1; p.ldc = ldc; p.sCb = strideC1;
+    p.M = M1; p.N = N; p.K = K; p.batch = batch;
+    p.Vt = (bf16_t*)Vt1; p.vt_ld = vt_ld1; p.vt_col0 = v_col0;
+    if (A2) {
+        p.A2 = (const bf16_t*)A2; p.W2 = (const bf16_t*)W2; p.bias2 = (const bf16_t*)bias2; p.C2 = (bf16_t*)C2; p.sAb2 = strideA2; p.sCb2 = strideC2;
+        p.M2 = M2; p.Vt2 = (bf16_t*)Vt2; p.vt_ld2 = vt_ld2;
+    }
+    return launch<TG_EPI_BIAS>(p, stream);
 }

@@ -127,6 +127,42 @@ def gemm_pair(a1, w1, bias1, out1, a2, w2, bias2, out2, epilogue=L.EPI_BIAS):
     return out1, out2
 
 
+def gemm_qkv_supported(M, N, K, v_col0):
+    """Shapes the fused QKV + V^T launch (tg_gemm_bf16_qkv) takes; the debugging knobs that disable the 4-wave GEMM disable it too."""
+    import os
+    return (M >= 1024 and N % 256 == 0 and K % 64 == 0 and K >= 256 and v_col0 % 256 == 0 and os.environ.get("TG_GEMM_W4", "1") != "0"
+            and os.environ.get("TG_GEMM_FORCE_128") != "1" and not os.environ.get("TG_GEMM_ABLATE"))
+
+
+def gemm_qkv(a1, w1, bias1, out1, vt1, a2=None, w2=None, bias2=None, out2=None, vt2=None, v_col0=None):
+    """QKV projection(s) with the V third (columns >= v_col0, default 2N/3) written transposed into vt [B, H, 64, ld] instead of out
+    (tg_gemm_bf16_qkv): out[:, :, :v_col0] = a @ w[:v_col0]^T + bias, vt[b, h, d, m] = (a @ w^T + bias)[b, m, v_col0 + 64 h + d], zero for
+    m >= M.  One or two problems (same N, K, batch, leading dimensions) in one launch."""
+    two = a2 is not None
+    for n, t in (("a1", a1), ("w1", w1), ("out1", out1), ("vt1", vt1)) + ((("a2", a2), ("w2", w2), ("out2", out2), ("vt2", vt2)) if two else ()):
+        _chk(t, n)
+    B, M1, Kd, lda, sa1 = _bmk(a1)
+    _, _, N, ldc, sc1 = _bmk(out1)
+    v_col0 = 2 * N // 3 if v_col0 is None else v_col0
+    assert w1.shape == (N, Kd)
+
+    def vt_ld(vt, M):
+        assert vt.dim() == 4 and vt.shape[0] == B and vt.shape[1] * vt.shape[2] == N - v_col0 and vt.is_contiguous() and vt.shape[3] >= M
+        return vt.shape[3]
+    ld1 = vt_ld(vt1, M1)
+    M2 = sa2 = sc2 = ld2 = 0
+    if two:
+        B2, M2, Kd2, lda2, sa2 = _bmk(a2)
+        _, _, N2, ldc2, sc2 = _bmk(out2)
+        assert (B, Kd, lda, N, ldc) == (B2, Kd2, lda2, N2, ldc2) and w2.shape == (N, Kd) and w1.stride(0) == w2.stride(0)
+        ld2 = vt_ld(vt2, M2)
+    name = f"gemm_qkv_M{M1}+{M2}_N{N}_K{Kd}" if two else f"gemm_qkv_M{M1}_N{N}_K{Kd}"
+    L.check(_launch(name, L.load().tg_gemm_bf16_qkv, _p(a1), sa1, _p(w1), _p(bias1), _p(out1), sc1, M1, _p(vt1), ld1,
+                    _p(a2) if two else None, sa2, _p(w2) if two else None, _p(bias2) if two else None, _p(out2) if two else None, sc2, M2,
+                    _p(vt2) if two else None, ld2, lda, w1.stride(0), ldc, N, Kd, B, v_col0, _stream()), "tg_gemm_bf16_qkv")
+    return out1, vt1
+
+
 def adaln_modulate(x, out, ln_weight, ln_bias, eps, table=None):
     """out = LN(x)*(1+scale[g])+shift[g] (table given) or plain affine LN (table None). x/out [B,T,D] views."""
     _chk(x, "x"); _chk(out, "out")

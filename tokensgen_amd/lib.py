@@ -22,6 +22,7 @@ _vp, _l, _i, _f = C.c_void_p, C.c_long, C.c_int, C.c_float
 PROTOTYPES = {
     "tg_gemm_bf16": [_vp, _l, _l, _vp, _l, _vp, _vp, _l, _l, _i, _i, _i, _i, _i, _vp, _l, _l, C.POINTER(GroupTable), _vp],
     "tg_gemm_bf16_pair": [_vp, _l, _vp, _vp, _vp, _l, _i, _vp, _l, _vp, _vp, _vp, _l, _i, _l, _l, _l, _i, _i, _i, _i, _vp],
+    "tg_gemm_bf16_qkv": [_vp, _l, _vp, _vp, _vp, _l, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _l, _i, _vp, _l, _l, _l, _l, _i, _i, _i, _i, _vp],
     "tg_adaln_modulate": [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _f, _i, _i, _i, _i, C.POINTER(GroupTable), _vp],
     "tg_qk_layernorm_rope": [_vp, _l, _l, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _vp],
     "tg_qk_layernorm_rope_pair": [_vp, _vp, _l, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _f, _vp],

@@ -458,21 +458,29 @@ class CogVideoXTransformer3DModel(nn.Module):
         p = f"l{i}."
         # QKV projections (+ vip-weight projections over ALL tokens: x rows and vip rows share vip_to_*)
         paired = use_vip and N1 >= 1024 and (3 * D) % 256 == 0       # both projections in one launch of the 256^2 kernel
-        if paired:
+        # ... with V written transposed by the GEMM epilogue (no transpose_v pass; the V columns of QKV / QKVv are then never written)
+        fused_vt = K.gemm_qkv_supported(N1, 3 * D, D, 2 * D) and (not use_vip or N1 % 8 == 0)
+        qn = F[p + "qknorm"]
+        kscale = sm_scale * 1.4426950408889634       # softmax scale * log2(e) folded into K before its single bf16 rounding
+        if fused_vt and use_vip:
+            K.gemm_qkv(ws.Xn[:, :N1], F[p + "qkv.w"], F[p + "qkv.b"], ws.QKV, ws.Vt1, ws.Xn, F[p + "vqkv.w"], F[p + "vqkv.b"], ws.QKVv, ws.Vt3)
+        elif fused_vt:
+            K.gemm_qkv(ws.Xn[:, :N1], F[p + "qkv.w"], F[p + "qkv.b"], ws.QKV, ws.Vt1)
+        elif paired:
             K.gemm_pair(ws.Xn[:, :N1], F[p + "qkv.w"], F[p + "qkv.b"], ws.QKV, ws.Xn, F[p + "vqkv.w"], F[p + "vqkv.b"], ws.QKVv, L.EPI_BIAS)
         else:
             K.gemm(ws.Xn[:, :N1], F[p + "qkv.w"], F[p + "qkv.b"], ws.QKV, L.EPI_BIAS)
-        qn = F[p + "qknorm"]
-        kscale = sm_scale * 1.4426950408889634       # softmax scale * log2(e) folded into K before its single bf16 rounding
         K.qk_layernorm_rope_pair(ws.QKV[:, :, :D], ws.QKV[:, :, D:2 * D], H, qn[0], qn[1], qn[2], qn[3], 1e-6, (Nt, rope), k_scale=kscale)
-        K.transpose_v(ws.QKV[:, :, 2 * D:], H, 0, N1, ws.Vt1)
+        if not fused_vt:
+            K.transpose_v(ws.QKV[:, :, 2 * D:], H, 0, N1, ws.Vt1)
         if use_vip:
-            if not paired:
+            if not paired and not fused_vt:
                 K.gemm(ws.Xn, F[p + "vqkv.w"], F[p + "vqkv.b"], ws.QKVv, L.EPI_BIAS)
             vqn = F[p + "vqknorm"]
             K.qk_layernorm_rope_pair(ws.QKVv[:, :, :D], ws.QKVv[:, :, D:2 * D], H, vqn[0], vqn[1], vqn[2], vqn[3], 1e-6, (Nt, vrope),
                                      (N1, crope), k_scale=kscale)
-            K.transpose_v(ws.QKVv[:, :, 2 * D:], H, 0, N, ws.Vt3)
+            if not fused_vt:
+                K.transpose_v(ws.QKVv[:, :, 2 * D:], H, 0, N, ws.Vt3)
             if N1 % 8 == 0:
                 vt2 = ws.Vt3[:, :, :, N1:]     # V^T of the vip keys = the tail columns of the all-keys image (16-B aligned start;
             else:                              # its zero padding out to a multiple of 64 keys is the image's own)
