@@ -742,6 +742,8 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.g.tok_group + min(cc.m0 + wm * 128 + h * 64 + lane, p.M - 1)),
                                                  (__attribute__((address_space(3))) void*)(smem + W4_TOK_OFF + wave * 512 + h * 256), 1, 0, 0);
         }
+        // (starting k-step 0 from a zero C operand instead of these 256 v_accvgpr_write was tried: the compiler then keeps the first
+        // results in VGPRs and copies them to the AGPRs before k-step 1 — more moves, not fewer)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -927,7 +929,7 @@ int launch(GemmParams p, hipStream_t stream) {
         static const int abl = [] { const char* e = getenv("TG_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
         const dim3 grid2(tiles2 < n_cu ? tiles2 : n_cu);
         static const int w4 = [] { const char* e = getenv("TG_GEMM_W4"); return e ? atoi(e) : 1; }();   // 0: the 8-wave kernel for every shape
-        if (w4 && p.K >= 4 * BK3 && !abl) {
+        if (w4 && p.K >= 4 * BK3 && !abl && p.lda < (1L << 21) && p.ldw < (1L << 21)) {   // 32-bit buffer offsets: 256 rows * ld * 2 B < 2^31
             static bool attr4 = false;
             if (!attr4) {
                 (void)hipFuncSetAttribute((const void*)gemm256w4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES);
@@ -1046,6 +1048,7 @@ extern "C" int tg_gemm_bf16_qkv(const void* A1, long strideA1, const void* W1, c
                tg_aligned16(C2) && tg_aligned16(Vt2), TG_ERR_ALIGN, "tg_gemm_bf16_qkv: alignment");
     static const bool w4_off = [] { const char* e = getenv("TG_GEMM_W4"); return e && atoi(e) == 0; }();
     static const bool f128 = [] { const char* e = getenv("TG_GEMM_FORCE_128"); return e && e[0] == '1'; }();
+    TG_REQUIRE(lda < (1L << 21) && ldw < (1L << 21), TG_ERR_SHAPE, "tg_gemm_bf16_qkv: leading dimensions must be < 2^21 elements");
     TG_REQUIRE(!w4_off && !f128 && !getenv("TG_GEMM_ABLATE"), TG_ERR_ARG, "tg_gemm_bf16_qkv: only the 4-wave GEMM kernel has the V^T epilogue (TG_GEMM_W4=0 / FORCE_128 / ABLATE set)");
     GemmParams p{};
     p.A = (const bf16_t*)A1; p.lda = lda; p.sAb = strideA1;
