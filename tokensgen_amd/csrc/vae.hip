@@ -144,7 +144,25 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
     }
 
     // ---- epilogue: bias (+ residual), only columns < cout are stored ----
+    // All bias / residual chunks of the lane are requested FIRST (one batch of loads in flight), then converted and stored: written the
+    // naive way (load, use, store per chunk) the stores order the next chunk's loads behind them (they may alias) and every chunk pays
+    // a full memory round trip behind a vmcnt(0).
     float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};   // GroupNorm partials of this lane's channel quad per ni
+    uint2 bq[4], rq[4][4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+        bq[ni] = (p.bias && n + 4 <= p.cout) ? *(const uint2*)(p.bias + n) : uint2{0u, 0u};
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const long m = m0 + wm * 64 + mi * 16 + (lane & 15);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+            rq[mi][ni] = (p.residual && m < M && n + 4 <= p.cout) ? *(const uint2*)(p.residual + m * p.ldy + n) : uint2{0u, 0u};
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const long m = m0 + wm * 64 + mi * 16 + (lane & 15);
@@ -158,12 +176,12 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
             const bf16_t* res = p.residual ? p.residual + m * p.ldy + n : nullptr;
             if (n + 4 <= p.cout) {
                 if (p.bias) {
-                    const uint2 bb = *(const uint2*)(p.bias + n);
+                    const uint2 bb = bq[ni];
                     v[0] += bf16lo_to_f32(bb.x); v[1] += bf16hi_to_f32(bb.x);
                     v[2] += bf16lo_to_f32(bb.y); v[3] += bf16hi_to_f32(bb.y);
                 }
                 if (res) {   // conv output is a bf16 tensor in the reference before `hidden_states + inputs`
-                    const uint2 rr = *(const uint2*)res;
+                    const uint2 rr = rq[mi][ni];
                     v[0] = round_bf16(v[0]) + bf16lo_to_f32(rr.x); v[1] = round_bf16(v[1]) + bf16hi_to_f32(rr.x);
                     v[2] = round_bf16(v[2]) + bf16lo_to_f32(rr.y); v[3] = round_bf16(v[3]) + bf16hi_to_f32(rr.y);
                 }
