@@ -59,6 +59,14 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     const float t = x * (-2.f * 0.7978845608028654f * 1.4426950408889634f) * (1.f + 0.044715f * x2);   // -2u log2(e)
     return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(t));   // t -> +inf: x * 0; t -> -inf: x
 }
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+// two elements at a time: the polynomial part maps onto v_pk_mul_f32 / v_pk_fma_f32 (same operations, same results as gelu_tanh)
+__device__ __forceinline__ f32x2v gelu_tanh2(f32x2v x) {
+    const f32x2v x2 = x * x;
+    const f32x2v t = x * (-2.f * 0.7978845608028654f * 1.4426950408889634f) * (1.f + 0.044715f * x2);
+    const f32x2v d = f32x2v{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.f;
+    return x * f32x2v{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
 __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
 template <int EPI>
@@ -862,8 +870,8 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
                         for (int i = 0; i < 4; ++i) v[i] = (nh * 4 + NB4) * 16 + i < mzero ? v[i] + bs : 0.f;
                     }
                     if (EPI == TG_EPI_BIAS_GELU) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = gelu_tanh(round_bf16(v[i]));
+                        const f32x2v g0 = gelu_tanh2(f32x2v{round_bf16(v[0]), round_bf16(v[1])}), g1 = gelu_tanh2(f32x2v{round_bf16(v[2]), round_bf16(v[3])});
+                        v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
                     } else if (EPI == TG_EPI_BIAS_SILU) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = silu(round_bf16(v[i]));
