@@ -43,7 +43,7 @@ struct AttnParams {
     int nq, heads, batch;
     float scale_log2;   // softmax scale * log2(e)
     int prescaled;      // 1: K already carries scale*log2(e) (tg_qk_layernorm_rope out_scale): scores are log2-domain as produced
-    int knob;           // TG_ATTN_KNOB experiment bits (1: static s_setprio 1 for the second-dispatched wave group)
+    int knob;           // TG_ATTN_KNOB experiment bits (1: static s_setprio 1 for the second-dispatched wave group; 2: wave groups in phase)
     // "rider": a second, single-segment problem of the same heads/batch whose workgroups are appended to the launch (ping-pong
     // kernel only).  The main attention leaves 3360 - 13*256 = 32 workgroups for its last round of 256 CUs; the To2V block's
     // vip-query attention (96 workgroups of the same length) rides in that round instead of costing a launch of its own.
@@ -308,6 +308,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 //   tile's row SUM instead of a row max (30 fewer VALU per tile, yet 8.3 vs 7.9 ms); ONE barrier per tile with 3-deep K/V rings
 //   (group 0: X|B|Y, group 1: B|X|Y — nobody waits for the partner's longer segment): 8.54 vs 8.12 ms, the per-wave X+Y issue
 //   time (~3600 cycles per tile) did not change, only where the waiting happens; fragment prefetch depth 2/3/4: 7.95/7.89/7.92.
+//   Both groups IN phase (TG_ATTN_KNOB bit 1: X together, then Y together — two vector segments would share the VALU at the
+//   two-wave issue rate while the matrix segments queue on the MFMA pipe): 9.16 vs 7.69 ms, the anti-phase pairing stays.
 //   Code generation is fragile here: a workgroup-uniform `if (knob) xseg(t)` around the matrix segment (for an ablation) made the
 //   whole kernel 60 % slower, fencing the closing s_setprio with sched_barrier(0) 2.5 % — so the TG_ATTN_TIMING build (which adds
 //   s_memtime reads and fences) is good for the RATIO of the segments, not for absolute cycles; one copy of the tile loop per wave
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         PP_BAR();
         if (grp == 1) {
             dma_pair(0);
-            PP_BAR();
+            if (!(p.knob & 2)) PP_BAR();          // knob bit 1 (experiment): both groups IN phase (X together, then Y together)
             if (p.knob & 1) __builtin_amdgcn_s_setprio(1);
         }
         long long tc[4] = {0, 0, 0, 0}, c0 = 0, c1;
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
 #undef PP_TICK
         pv(ntiles - 1);                                                            // X(nt): last P.V
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (grp == 0) PP_BAR();                                                    // barrier counts of the two groups meet again
+        if (grp == 0 && !(p.knob & 2)) PP_BAR();                                   // barrier counts of the two groups meet again
         PP_BAR();                                                                  // all LDS reads of this segment done
 
         // ---- segment epilogue: O through LDS so that every global access is a whole 128-byte row of this head.  A lane owns ONE query
