@@ -740,6 +740,35 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
         const int rc = attention_launch(p, scale, k_prescaled, who, stream);
         return rc ? rc : attention_launch(r, scale, k_prescaled, who, stream);
     }
+    // ---- ragged last query tile: every ping-pong workgroup takes the same time, so a launch of G workgroups costs ceil(G / CUs) rounds.
+    // When dropping the ragged last tile of every (head, batch) saves a round, those rows go to the 4-wave kernel in 128-row workgroups
+    // right behind the ping-pong launch (same stream): N = 17776 without a rider 7.69 -> 7.53 ms, the T2To stage's N = 9442 (19 -> 18
+    // tiles: 8 -> 7 rounds).  With a rider problem the riders already fill the last round, and the split loses (measured 8.0 vs 7.75 ms).
+    // Putting the small launch on a second (lower- or equal-priority) stream to pack the last round's idle CUs did NOT overlap here:
+    // two streams 7.62 ms vs 7.53 back to back.
+    static const int tail_split = [] { const char* e = getenv("TG_ATTN_TAIL"); return e ? atoi(e) : 1; }();
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    const int full_rows = (nq / 512) * 512;
+    const long wg_full = (long)(nq / 512) * heads * batch;
+    if (pp && tail_split && !timing && p.r_nq == 0 && full_rows < nq && wg_full >= pp_min && (wg_full + n_cu - 1) / n_cu < (wg512 + n_cu - 1) / n_cu) {
+        AttnParams m = p;                                   // the full 512-row tiles: ping-pong kernel
+        m.nq = full_rows;
+        const int rc = attention_launch(m, scale, k_prescaled, who, stream);
+        if (rc) return rc;
+        AttnParams t = p;                                   // the ragged remainder: 128-row workgroups of the 4-wave kernel
+        t.nq = nq - full_rows;
+        for (int sg = 0; sg < p.nseg; ++sg) t.s[sg].q = p.s[sg].q + (long)full_rows * p.s[sg].q_ld;
+        t.out = p.out + (long)full_rows * p.o_ld;
+        const int nqt = (t.nq + 127) / 128;
+        hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3((unsigned)(nqt * heads * batch)), dim3(256), 0, stream, t);
+        TG_LAUNCH_CHECK(who);
+        return TG_OK;
+    }
     p.main_wgs = (int)wg512;
     const long grid512 = wg512 + (p.r_nq > 0 ? (long)((p.r_nq + 511) / 512) * heads * batch : 0);
     constexpr size_t PP_LDS = 4 * TILE_B + 8 * 8192;
