@@ -180,7 +180,7 @@ def main():
         achieved = ATTN_FLOP_PER_LAUNCH / attn_s / 1e12 if attn["n"] else float("nan")
         traffic = None          # HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
         try:
-            with open(os.path.join(ROOT, "profiles", "r1m_pmc_summary.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r1n_pmc_summary.json")) as f:
                 traffic = json.load(f)["_derived"]["attention_main_traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
