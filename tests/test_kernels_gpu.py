@@ -456,3 +456,27 @@ def test_gemm_4wave_kernel_matches_8wave_kernel(tmp_path):
                            capture_output=True, text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "vs other mode" in r.stdout
+
+
+def test_gemm_4wave_random_shapes(K):
+    """Seeded sweep of the 4-wave GEMM's corner parameters against fp32 torch: odd and even numbers of K stages (the two LDS buffers
+    alternate across tile boundaries), M one row short of / past a tile edge, more tiles than CUs (several tiles per workgroup, the DMA
+    cursor crossing tiles and batch items), strided A and C views, every epilogue."""
+    from tokensgen_amd import lib as L
+    rng = np.random.RandomState(7)
+    cases = [(1024, 256, 256, 1), (1025, 256, 320, 1), (1279, 512, 448, 2), (1281, 256, 832, 3), (4095, 768, 256, 1), (9000, 2560, 320, 1),
+             (2304, 1024, 1088, 2)]
+    rng = np.random.RandomState(7)
+    for i, (M, N, Kd, B) in enumerate(cases):
+        epi = [L.EPI_BIAS, L.EPI_BIAS_GELU, L.EPI_BIAS_SILU][i % 3]
+        a_full = _rand(B, M + 3, Kd + 16, seed=100 + i)
+        a = a_full[:, 1:1 + M, 8:8 + Kd]
+        w, bias = _rand(N, Kd, seed=200 + i, scale=0.05), _rand(N, seed=300 + i)
+        use_bias = rng.rand() < 0.8
+        out_full = torch.full((B, M + 2, N + 8), 9.0, dtype=torch.bfloat16, device=DEV)
+        out = out_full[:, 1:1 + M, :N]
+        K.gemm(a, w, bias if use_bias else None, out, epi)
+        pre = (a.float() @ w.float().T + (bias.float() if use_bias else 0.0)).to(torch.bfloat16).float()
+        ref = pre if epi == L.EPI_BIAS else torch.nn.functional.gelu(pre, approximate="tanh") if epi == L.EPI_BIAS_GELU else torch.nn.functional.silu(pre)
+        assert _rel(out, ref) < 6e-3, (M, N, Kd, B, epi)
+        assert (out_full[:, 0] == 9.0).all() and (out_full[:, M + 1] == 9.0).all() and (out_full[:, :, N:] == 9.0).all(), (M, N, Kd, B)
