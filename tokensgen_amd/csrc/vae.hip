@@ -7,6 +7,9 @@
 //   * no cat(conv_cache, x): frames before the window are read straight from the cache tensor (or frame 0, replicated);
 //   * no F.pad: out-of-range taps read a zero page;
 //   * no materialised F.interpolate: the nearest-neighbour x2 upsample (spatial, and temporal through t_map) is index math.
+#include <stdlib.h>
+
+#include <type_traits>
 #include "common.h"
 #include "tokensgen_hip.h"
 
@@ -233,6 +236,298 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
                 for (int wm_ = 0; wm_ < 2; ++wm_) a += red[(((wm_ * 2 + wn_) * 4 + ni_) * 4 + quad_) * 2 + stat];
             }
             p.gn_partial[(long)tm * 2 * GN_GROUPS + stat * GN_GROUPS + n0 / cg + gl] = a;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same convolution on the 4-wave structure of the DiT GEMM (gemm.hip: gemm256w4_kernel): 256 voxels x 256 output channels per
+// workgroup, four waves (one per SIMD) of 128x128 = 8x8 MFMA 16x16x32 with the accumulators in AGPRs, two LDS stages of K = 64
+// (one tap x 64 input channels), 8 rows x 128 B per LDS-DMA piece, the wave software-pipelines itself (128 MFMA slots per stage, each
+// followed by at most one ds_read_b128 or one DMA piece).  Only the A side differs from the GEMM: its pieces are fetched through
+// per-lane pointers (tap_src: padding -> zero page, frames before the window -> cache tensor) that are recomputed when the tap
+// changes, every Cin/64 stages.  Used for Cout % 256 == 0 without a temporal index map; everything else stays on conv3d_cl_kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int CW_OPER = 256 * 64 * 2;            // 32 KiB per operand per stage
+constexpr int CW_STAGE = 2 * CW_OPER;            // 64 KiB
+constexpr int CW_LDS = 2 * CW_STAGE;             // 128 KiB
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const long M = (long)p.To * p.Ho * p.Wo;
+    const int tiles_m = (int)((M + 255) / 256), tiles_n = p.cout_pad / 256;
+    const int nwg = tiles_m * tiles_n;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int tn = t % tiles_n, tm = t / tiles_n;     // n fastest: the tiles_n blocks sharing an A tile run on one XCD
+    const long m0 = (long)tm * 256;
+    const int n0 = tn * 256;
+    const int Kw = p.kt * p.kh * p.kw * p.Cin;        // row length of the packed weights
+
+    // ---- A side: piece i (0..7) of this wave = tile rows [wave*64 + i*8, +8); lane -> row + (lane>>3), physical slot lane&7 ----
+    // Per tile and piece the lane keeps its voxel (t << 22 | h << 11 | w) and, for the plain case (stride 1, no upsampling), the element
+    // offset of that voxel and a 9-bit mask of the (dh, dw) taps that stay inside the image: a tap change (every Cin/64 stages, with
+    // the matrix pipe idle - there is no second wave to cover it) is then ~10 VALU per piece instead of ~28 through tap_src.
+    int vthw[8], cen[8], vmask[8];
+    const bool plain = p.stride == 1 && p.up == 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        long m = m0 + wave * 64 + i * 8 + (lane >> 3);
+        if (m >= M) m = M - 1;
+        const int wo = (int)(m % p.Wo);
+        const long q = m / p.Wo;
+        const int ho = (int)(q % p.Ho), to = (int)(q / p.Ho);
+        vthw[i] = (to << 22) | (ho << 11) | wo;
+        cen[i] = ((to * p.H + ho) * p.W + wo) * p.Cin;
+        int mk = 0;
+        for (int dh = 0; dh < p.kh; ++dh)
+            for (int dw = 0; dw < p.kw; ++dw)
+                if ((unsigned)(ho + dh - p.pad) < (unsigned)p.H && (unsigned)(wo + dw - p.pad) < (unsigned)p.W) mk |= 1 << (dh * 3 + dw);
+        vmask[i] = mk;
+    }
+    const int Hv = p.H * p.up, Wv = p.W * p.up;
+    const long frame = (long)p.H * p.W * p.Cin;
+    const int prow = lane >> 3;
+    const int slotA[2] = {((lane & 7) ^ (prow >> 1)) * 8, ((lane & 7) ^ (4 + (prow >> 1))) * 8};   // logical slot by piece parity (elements)
+    auto tap_src = [&](int i, int dt, int dh, int dw) -> const char* {
+        const int to = vthw[i] >> 22, ho = (vthw[i] >> 11) & 2047, wo = vthw[i] & 2047;
+        const int hv = ho * p.stride + dh - p.pad, wv = wo * p.stride + dw - p.pad;
+        if (hv < 0 || hv >= Hv || wv < 0 || wv >= Wv) return (const char*)(p.zeros + slotA[i & 1]);
+        int tv = to + dt - (p.kt - 1);
+        const bf16_t* base = p.x;
+        if (tv < 0) {
+            if (p.cache) { base = p.cache; tv += p.kt - 1; } else tv = 0;   // cached frames, or replicate the first frame
+        }
+        const int h = (p.up == 2) ? (hv >> 1) : hv, w = (p.up == 2) ? (wv >> 1) : wv;
+        return (const char*)(base + (long)tv * frame + ((long)h * p.W + w) * p.Cin + slotA[i & 1]);
+    };
+    const int cpt = p.Cin / 64;                      // stages per tap
+    const int nk = p.kt * p.kh * p.kw * cpt;
+    const char* srcA[8];
+    auto set_tap = [&](int tap) {
+        const int dw = tap % p.kw, q = tap / p.kw;
+        const int dh = q % p.kh, dt = q / p.kh;
+        if (plain) {
+            // in-window frames: x + cen + doff.  Frames before the window (to + dt < kt-1): the cache tensor holds frames -(kt-1)..-1 at
+            // indices 0.., i.e. cache + cen + doff + (kt-1)*frame; without a cache frame 0 is replicated: x + cen + doff - tv*frame
+            const int doff = ((dt - (p.kt - 1)) * p.H + (dh - p.pad)) * p.W * p.Cin + (dw - p.pad) * p.Cin;
+            const int bit = 1 << (dh * 3 + dw), tneed = p.kt - 1 - dt;     // the tap reads frame to - tneed
+            const bf16_t* early = p.cache ? p.cache + (long)(p.kt - 1) * frame : p.x;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int to = vthw[i] >> 22;
+                int off = cen[i] + doff;
+                const bool before = to < tneed;
+                if (before && !p.cache) off += (tneed - to) * (int)frame;   // replicate frame 0
+                const bf16_t* src = (before ? early : p.x) + off + slotA[i & 1];
+                srcA[i] = (const char*)((vmask[i] & bit) ? src : p.zeros + slotA[i & 1]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) srcA[i] = tap_src(i, dt, dh, dw);
+        }
+    };
+    // ---- W side: buffer loads exactly as in the GEMM ----
+    int voffW[2];
+#pragma unroll
+    for (int odd = 0; odd < 2; ++odd) {
+        const int dslot = (lane & 7) ^ (odd * 4 + (prow >> 1));
+        voffW[odd] = (int)(((long)(wave * 64 + prow) * Kw + dslot * 8) * 2);
+    }
+    const int pieceW = Kw * 16;
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long)n0 * Kw), 0, (int)(256L * Kw * 2), 0x00020000);
+    int dk = 0, dcc = 0, dtap = 0, dbuf = 0;          // DMA cursor: stage, channel block inside the tap, tap, LDS buffer
+    auto dma_piece = [&](int q) {                    // q = 0..7: A pieces, 8..15: W pieces of the cursor's stage
+        char* dst = smem + dbuf * CW_STAGE + (q >> 3) * CW_OPER + (wave * 64 + (q & 7) * 8) * 128;
+        if (q < 8)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[q & 7] + (long)dcc * 128),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)dst, 16, voffW[q & 1], dk * 128 + (q & 7) * pieceW, 0, 0);   // piece offset in the SCALAR offset: 2 VGPRs, not 8
+    };
+    auto dma_advance = [&]() {
+        dbuf ^= 1; ++dk;
+        if (++dcc == cpt) { dcc = 0; ++dtap; }
+    };
+
+    // ---- fragment addresses (16x16x32 operands: lane -> row lane&15 of a 16-row block, logical 16-B slot ks*4 + (lane>>4)) ----
+    const int l15 = lane & 15, ch = lane >> 4;
+    const int swz = l15 * 128 + ((ch ^ ((l15 >> 1) & 7)) << 4);
+    int ra[2], rw[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        ra[ks] = (wm * 128 * 128 + swz) ^ (ks << 6);
+        rw[ks] = (CW_OPER + wn * 128 * 128 + swz) ^ (ks << 6);
+    }
+    bf16x8 fa[2][8], fw[2][8];
+    f32x4 acc[8][8];                                 // [m block][n block]; lane holds D[n = 4*(lane>>4) + r][m = lane&15]
+#define CW_SB() __builtin_amdgcn_sched_barrier(0)
+    auto frag_read = [&](auto ksc, auto rc) {        // read r (0..15) of k-step KS: 0..7 -> W blocks, 8..15 -> A blocks
+        constexpr int KS = decltype(ksc)::value, R = decltype(rc)::value;
+        if constexpr (R < 8) {
+            bf16x8& d = fw[KS][R];
+            const int ad = rw[KS];
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(ad), "n"(R * 2048));
+        } else {
+            bf16x8& d = fa[KS][R - 8];
+            const int ad = ra[KS];
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(ad), "n"((R - 8) * 2048));
+        }
+    };
+    // the GEMM's slot schedule (gemm.hip): reads of set 1 in slots 0..30, barrier at 35, DMA from 36 every 6th, vmcnt + barrier at 93,
+    // reads of the next stage's set 0 from 94
+    auto kstage = [&](auto steady_c, bool rd) {
+        constexpr bool STEADY = decltype(steady_c)::value;
+        if (STEADY && dcc == 0) set_tap(dtap);
+        static_for<0, 128>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            constexpr int KS = I >> 6, NB = (I >> 3) & 7, MB = I & 7;
+            acc[MB][NB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[KS][NB], fa[KS][MB], acc[MB][NB], 0, 0, 0);
+            CW_SB();
+            if constexpr (I < 32 && I % 2 == 0) frag_read(std::integral_constant<int, 1>{}, std::integral_constant<int, I / 2>{});
+            if constexpr (I == 35) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                CW_SB();
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) { ra[ks] ^= CW_STAGE; rw[ks] ^= CW_STAGE; }
+            }
+            if constexpr (I >= 36 && (I - 36) % 6 == 0 && (I - 36) / 6 < 16) {
+                if (STEADY) dma_piece((I - 36) / 6);
+            }
+            if constexpr (I == 93) {
+                if (STEADY) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                CW_SB();
+            }
+            if constexpr (I >= 94 && (I - 94) % 2 == 0 && (I - 94) / 2 < 16) {
+                if (STEADY || rd) frag_read(std::integral_constant<int, 0>{}, std::integral_constant<int, (I - 94) / 2>{});
+            }
+            CW_SB();
+        });
+        if (STEADY) dma_advance();
+        CW_SB();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        CW_SB();
+    };
+
+    // prologue: stages 0 and 1 in flight, fragment set 0 of stage 0 in registers
+    set_tap(0);
+    static_for<0, 16>([&](auto qc) { dma_piece(decltype(qc)::value); });
+    dma_advance();
+    if (dcc == 0) set_tap(dtap);
+    static_for<0, 16>([&](auto qc) { dma_piece(decltype(qc)::value); });
+    dma_advance();
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    CW_SB();
+    static_for<0, 16>([&](auto rc) { frag_read(std::integral_constant<int, 0>{}, rc); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CW_SB();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 8; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        int st = 0;
+        for (; st + 2 < nk; ++st) kstage(std::true_type{}, true);
+        kstage(std::false_type{}, true);
+        kstage(std::false_type{}, false);
+    }
+#undef CW_SB
+
+    // ---- epilogue: bias (+ residual), GroupNorm partial sums of the stored bf16 values; all chunks of the lane are requested first ----
+    uint2 bq[8], rq[2][8];                            // residual chunks: the next 16-row block's are in flight while this one is stored
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+        const int n = n0 + wn * 128 + nb * 16 + ch * 4;
+        bq[nb] = p.bias ? *(const uint2*)(p.bias + n) : uint2{0u, 0u};
+    }
+    auto res_load = [&](auto mbc) {
+        constexpr int MB = decltype(mbc)::value;
+        const long m = m0 + wm * 128 + MB * 16 + l15;
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+            const int n = n0 + wn * 128 + nb * 16 + ch * 4;
+            rq[MB & 1][nb] = (p.residual && m < M) ? *(const uint2*)(p.residual + m * p.ldy + n) : uint2{0u, 0u};
+        }
+    };
+    float gs[8], gq[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) gs[nb] = gq[nb] = 0.f;
+    res_load(std::integral_constant<int, 0>{});
+    static_for<0, 8>([&](auto mbc) {
+        constexpr int mb = decltype(mbc)::value;
+        if constexpr (mb < 7) res_load(std::integral_constant<int, (mb < 7 ? mb + 1 : 7)>{});
+        const long m = m0 + wm * 128 + mb * 16 + l15;
+        if (m < M) {
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) {
+                const int n = n0 + wn * 128 + nb * 16 + ch * 4;
+                float v[4] = {acc[mb][nb][0], acc[mb][nb][1], acc[mb][nb][2], acc[mb][nb][3]};
+                const uint2 bb = bq[nb];
+                v[0] += bf16lo_to_f32(bb.x); v[1] += bf16hi_to_f32(bb.x);
+                v[2] += bf16lo_to_f32(bb.y); v[3] += bf16hi_to_f32(bb.y);
+                if (p.residual) {   // conv output is a bf16 tensor in the reference before `hidden_states + inputs`
+                    const uint2 rr = rq[mb & 1][nb];
+                    v[0] = round_bf16(v[0]) + bf16lo_to_f32(rr.x); v[1] = round_bf16(v[1]) + bf16hi_to_f32(rr.x);
+                    v[2] = round_bf16(v[2]) + bf16lo_to_f32(rr.y); v[3] = round_bf16(v[3]) + bf16hi_to_f32(rr.y);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *(uint2*)(p.y + m * p.ldy + n) = o;
+                if (p.gn_partial) {
+                    const float r0 = bf16lo_to_f32(o.x), r1 = bf16hi_to_f32(o.x), r2 = bf16lo_to_f32(o.y), r3 = bf16hi_to_f32(o.y);
+                    gs[nb] += (r0 + r1) + (r2 + r3);
+                    gq[nb] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+                }
+            }
+        }
+    });
+    // GroupNorm partial sums in the layout of the 128-row kernel: one row of [2][32] per 128 voxels = per (tile, wm half); fixed order
+    if (p.gn_partial) {
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                gs[nb] += __shfl_xor(gs[nb], off, 64);
+                gq[nb] += __shfl_xor(gq[nb], off, 64);
+            }
+        }
+        __syncthreads();                                    // every wave is past its last fragment read: the stage buffers are free
+        float* red = (float*)smem;                          // [wave][nb][ch][2]
+        if (l15 == 0) {
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) {
+                red[((wave * 8 + nb) * 4 + ch) * 2 + 0] = gs[nb];
+                red[((wave * 8 + nb) * 4 + ch) * 2 + 1] = gq[nb];
+            }
+        }
+        __syncthreads();
+        const int cg = p.cout / GN_GROUPS, qpg = cg >> 2, gpt = 256 / cg;    // channels per group, quads per group, groups per tile
+        if (tid < 4 * gpt) {
+            const int wm_ = tid / (2 * gpt), stat = (tid / gpt) & 1, gl = tid % gpt;
+            float a = 0.f;
+            for (int qd = 0; qd < qpg; ++qd) {
+                const int cq = gl * qpg + qd;                // tile-local channel quad 0..63 = wn*32 + nb*4 + ch
+                a += red[(((wm_ * 2 + (cq >> 5)) * 8 + ((cq >> 2) & 7)) * 4 + (cq & 3)) * 2 + stat];
+            }
+            const long prow_ = (long)tm * 2 + wm_;
+            if (prow_ * 128 < M) p.gn_partial[prow_ * 2 * GN_GROUPS + stat * GN_GROUPS + n0 / cg + gl] = a;
         }
     }
 }
@@ -476,6 +771,24 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
     const long M = (long)To * Ho * Wo;
     const long tiles = ((M + BM - 1) / BM) * (cout_pad / BN);
     TG_REQUIRE(tiles < (1L << 31), TG_ERR_SHAPE, "tg_conv3d_cl: too many tiles");
+    // 4-wave kernel: 256x256 tiles need enough of them to fill the chip (>= 2 per CU; the 512-channel layers of the VAE have 128 and stay on
+    // the 128x128 kernel: measured 161 vs 142 ms there, 226 vs 248 ms on the 256-channel layers).  TG_CONV_W4=0: never, 2: whenever legal
+    static const int w4 = [] { const char* e = getenv("TG_CONV_W4"); return e ? atoi(e) : 1; }();
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    if (w4 && (w4 == 2 || ((M + 255) / 256) * (cout / 256) >= 2L * n_cu) && cout == cout_pad && cout % 256 == 0 && !t_map && M >= 1024 && (long)kt * kh * kw * (Cin / 64) >= 4 && H * up < 2048 && W * up < 2048 &&
+        To < 512 && Ho < 2048 && Wo < 2048 && (long)kt * kh * kw * Cin < (1L << 21) && (long)(T + 2) * H * W * Cin < (1L << 31)) {
+        static bool attr4 = false;
+        if (!attr4) { (void)hipFuncSetAttribute((const void*)conv3d_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS); attr4 = true; }
+        const long tiles4 = ((M + 255) / 256) * (cout / 256);
+        hipLaunchKernelGGL(conv3d_w4_kernel, dim3((unsigned)tiles4), dim3(256), CW_LDS, stream, p);
+        TG_LAUNCH_CHECK("tg_conv3d_cl(w4)");
+        return TG_OK;
+    }
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES); attr = true; }
     hipLaunchKernelGGL(conv3d_cl_kernel, dim3((unsigned)tiles), dim3(256), 2 * STAGE_BYTES, stream, p);

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Experiment / test harness: the 4-wave convolution kernel (TG_CONV_W4=2: whenever legal) against the 128x128 kernel (TG_CONV_W4=0).
+Run once per mode (the knob is read once per process); the second run compares with the first run's outputs: the two kernels add the
+same products in the same order (tap-major, 32 channels per MFMA), so the tensors must be bitwise equal; the fused GroupNorm statistics
+are partitioned differently (128 rows per wave instead of 64) and agree to fp32 rounding."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tokensgen_amd import kernels as K  # noqa: E402
+
+DEV, BF = "cuda", torch.bfloat16
+mode = os.environ.get("TG_CONV_W4", "1")
+outdir = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/convw4"
+os.makedirs(outdir, exist_ok=True)
+
+
+def r(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def pack(w):
+    co, ci = w.shape[:2]
+    p = torch.zeros((co + 127) // 128 * 128, int(np.prod(w.shape[2:])), (ci + 63) // 64 * 64, dtype=BF)
+    p[:co, :, :ci] = w.reshape(co, ci, -1).permute(0, 2, 1)
+    return p.contiguous()
+
+
+res, ok = {}, True
+#        ci   co   T  H   W   k        up  cache  residual
+cases = [(256, 256, 3, 20, 24, (3, 3, 3), 1, True, True), (128, 512, 2, 33, 31, (3, 3, 3), 1, False, True), (64, 256, 4, 18, 30, (3, 3, 3), 1, True, False),
+         (256, 256, 2, 17, 19, (1, 3, 3), 2, False, False), (192, 256, 1, 40, 52, (3, 3, 3), 1, False, True)]
+for i, (ci, co, T, H, W, k, up, use_cache, use_res) in enumerate(cases):
+    w, b = r(co, ci, *k, seed=10 + i, scale=0.05), r(co, seed=20 + i)
+    x = r(T, H, W, ci, seed=30 + i).to(DEV)
+    cache = r(k[0] - 1, H, W, ci, seed=40 + i).to(DEV) if use_cache and k[0] > 1 else None
+    To, Ho, Wo = T, H * up, W * up
+    resid = r(To, Ho, Wo, co, seed=50 + i).to(DEV) if use_res else None
+    y = K.conv3d_cl(x, pack(w).to(DEV), b.to(DEV), co, *k, cache=cache, up=up, residual=resid, out_dims=(To, Ho, Wo), gn_stats_eps=1e-6)
+    torch.cuda.synchronize()
+    want = K.groupnorm_stats(y.view(-1, co), 1e-6)
+    gerr = (y.gn_stats - want).abs().max().item()
+    print(f"mode={mode} case {i}: ci={ci} co={co} T={T} H={H} W={W} k={k} up={up} finite={bool(torch.isfinite(y.float()).all())} gn_err={gerr:.2e}", flush=True)
+    ok &= bool(torch.isfinite(y.float()).all()) and gerr < 1e-4
+    res[i] = (y.cpu(), y.gn_stats.cpu())
+torch.save(res, f"{outdir}/out_{mode}.pt")
+others = [m for m in ("0", "2", "1") if m != mode and os.path.exists(f"{outdir}/out_{m}.pt")]
+for m in others:
+    o = torch.load(f"{outdir}/out_{m}.pt")
+    for i in res:
+        same = torch.equal(res[i][0], o[i][0])
+        gd = (res[i][1] - o[i][1]).abs().max().item()
+        print(f"vs mode {m} case {i}: tensors bitwise {same}, gn stats max diff {gd:.2e}")
+        ok &= same and gd < 1e-4
+print("OK" if ok else "FAILED")
+sys.exit(0 if ok else 1)
