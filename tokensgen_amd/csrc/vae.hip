@@ -260,31 +260,39 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// NT = 256: 256 voxels x 256 channels, waves 2 x 2.  NT = 128 (Cout = 128): 512 voxels x 128 channels, waves 4 x 1 - the same 128x128 per
+// wave, every wave reads the whole W tile; 80 KiB per stage, i.e. all 160 KiB of LDS for the two stages.
+template <int NT>
 __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
+    constexpr int TM = NT == 256 ? 256 : 512;            // voxels per tile
+    constexpr int NA = TM / 32, NW = NT / 32;            // A / W pieces (8 rows each) per wave and stage
+    constexpr int OPER_A = TM * 128, STAGE = OPER_A + NT * 128;
+    constexpr int DS = NT == 256 ? 6 : 4;                // MFMA slots between DMA pieces: NA + NW pieces from slot 36
+    constexpr int ISSUED_AT_93 = (93 - 36) / DS + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = NT == 256 ? wave >> 1 : wave, wn = NT == 256 ? wave & 1 : 0;
 
     const long M = (long)p.To * p.Ho * p.Wo;
-    const int tiles_m = (int)((M + 255) / 256), tiles_n = p.cout_pad / 256;
+    const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = p.cout_pad / NT;
     const int nwg = tiles_m * tiles_n;
     const int t = xcd_remap(blockIdx.x, nwg);
     const int tn = t % tiles_n, tm = t / tiles_n;     // n fastest: the tiles_n blocks sharing an A tile run on one XCD
-    const long m0 = (long)tm * 256;
-    const int n0 = tn * 256;
+    const long m0 = (long)tm * TM;
+    const int n0 = tn * NT;
     const int Kw = p.kt * p.kh * p.kw * p.Cin;        // row length of the packed weights
 
     // ---- A side: piece i (0..7) of this wave = tile rows [wave*64 + i*8, +8); lane -> row + (lane>>3), physical slot lane&7 ----
     // Per tile and piece the lane keeps its voxel (t << 22 | h << 11 | w) and, for the plain case (stride 1, no upsampling), the element
     // offset of that voxel and a 9-bit mask of the (dh, dw) taps that stay inside the image: a tap change (every Cin/64 stages, with
     // the matrix pipe idle - there is no second wave to cover it) is then ~10 VALU per piece instead of ~28 through tap_src.
-    int vthw[8], cen[8], vmask[8];
+    int vthw[NA], cen[NA], vmask[NA];
     const bool plain = p.stride == 1 && p.up == 1;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        long m = m0 + wave * 64 + i * 8 + (lane >> 3);
+    for (int i = 0; i < NA; ++i) {
+        long m = m0 + wave * (NA * 8) + i * 8 + (lane >> 3);
         if (m >= M) m = M - 1;
         const int wo = (int)(m % p.Wo);
         const long q = m / p.Wo;
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
     };
     const int cpt = p.Cin / 64;                      // stages per tap
     const int nk = p.kt * p.kh * p.kw * cpt;
-    const char* srcA[8];
+    const char* srcA[NA];
     auto set_tap = [&](int tap) {
         const int dw = tap % p.kw, q = tap / p.kw;
         const int dh = q % p.kh, dt = q / p.kh;
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
             const int bit = 1 << (dh * 3 + dw), tneed = p.kt - 1 - dt;     // the tap reads frame to - tneed
             const bf16_t* early = p.cache ? p.cache + (long)(p.kt - 1) * frame : p.x;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NA; ++i) {
                 const int to = vthw[i] >> 22;
                 int off = cen[i] + doff;
                 const bool before = to < tneed;
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) srcA[i] = tap_src(i, dt, dh, dw);
+            for (int i = 0; i < NA; ++i) srcA[i] = tap_src(i, dt, dh, dw);
         }
     };
     // ---- W side: buffer loads exactly as in the GEMM ----
@@ -344,18 +352,21 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
 #pragma unroll
     for (int odd = 0; odd < 2; ++odd) {
         const int dslot = (lane & 7) ^ (odd * 4 + (prow >> 1));
-        voffW[odd] = (int)(((long)(wave * 64 + prow) * Kw + dslot * 8) * 2);
+        voffW[odd] = (int)(((long)(wave * (NW * 8) + prow) * Kw + dslot * 8) * 2);
     }
     const int pieceW = Kw * 16;
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long)n0 * Kw), 0, (int)(256L * Kw * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long)n0 * Kw), 0, (int)((long)NT * Kw * 2), 0x00020000);
     int dk = 0, dcc = 0, dtap = 0, dbuf = 0;          // DMA cursor: stage, channel block inside the tap, tap, LDS buffer
-    auto dma_piece = [&](int q) {                    // q = 0..7: A pieces, 8..15: W pieces of the cursor's stage
-        char* dst = smem + dbuf * CW_STAGE + (q >> 3) * CW_OPER + (wave * 64 + (q & 7) * 8) * 128;
-        if (q < 8)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[q & 7] + (long)dcc * 128),
+    auto dma_piece = [&](int q) {                    // q = 0..NA-1: A pieces, NA..NA+NW-1: W pieces of the cursor's stage
+        if (q < NA) {
+            char* dst = smem + dbuf * STAGE + (wave * (NA * 8) + q * 8) * 128;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[q] + (long)dcc * 128),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)dst, 16, voffW[q & 1], dk * 128 + (q & 7) * pieceW, 0, 0);   // piece offset in the SCALAR offset: 2 VGPRs, not 8
+        } else {
+            const int qw = q - NA;
+            char* dst = smem + dbuf * STAGE + OPER_A + (wave * (NW * 8) + qw * 8) * 128;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)dst, 16, voffW[qw & 1], dk * 128 + qw * pieceW, 0, 0);   // piece offset in the SCALAR offset: 2 VGPRs
+        }
     };
     auto dma_advance = [&]() {
         dbuf ^= 1; ++dk;
@@ -369,8 +380,9 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         ra[ks] = (wm * 128 * 128 + swz) ^ (ks << 6);
-        rw[ks] = (CW_OPER + wn * 128 * 128 + swz) ^ (ks << 6);
+        rw[ks] = (OPER_A + wn * 128 * 128 + swz) ^ (ks << 6);
     }
+    int flip = STAGE;                                // the fragment addresses alternate between the two stage buffers
     bf16x8 fa[2][8], fw[2][8];
     f32x4 acc[8][8];                                 // [m block][n block]; lane holds D[n = 4*(lane>>4) + r][m = lane&15]
 #define CW_SB() __builtin_amdgcn_sched_barrier(0)
@@ -402,13 +414,14 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
                 __builtin_amdgcn_s_barrier();
                 CW_SB();
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) { ra[ks] ^= CW_STAGE; rw[ks] ^= CW_STAGE; }
+                for (int ks = 0; ks < 2; ++ks) { ra[ks] += flip; rw[ks] += flip; }
+                flip = -flip;
             }
-            if constexpr (I >= 36 && (I - 36) % 6 == 0 && (I - 36) / 6 < 16) {
-                if (STEADY) dma_piece((I - 36) / 6);
+            if constexpr (I >= 36 && (I - 36) % DS == 0 && (I - 36) / DS < NA + NW) {
+                if (STEADY) dma_piece((I - 36) / DS);
             }
             if constexpr (I == 93) {
-                if (STEADY) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                if (STEADY) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ISSUED_AT_93) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 CW_SB();
@@ -426,12 +439,12 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
 
     // prologue: stages 0 and 1 in flight, fragment set 0 of stage 0 in registers
     set_tap(0);
-    static_for<0, 16>([&](auto qc) { dma_piece(decltype(qc)::value); });
+    static_for<0, NA + NW>([&](auto qc) { dma_piece(decltype(qc)::value); });
     dma_advance();
     if (dcc == 0) set_tap(dtap);
-    static_for<0, 16>([&](auto qc) { dma_piece(decltype(qc)::value); });
+    static_for<0, NA + NW>([&](auto qc) { dma_piece(decltype(qc)::value); });
     dma_advance();
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NW) : "memory");
     __builtin_amdgcn_s_barrier();
     CW_SB();
     static_for<0, 16>([&](auto rc) { frag_read(std::integral_constant<int, 0>{}, rc); });
@@ -518,15 +531,16 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
             }
         }
         __syncthreads();
-        const int cg = p.cout / GN_GROUPS, qpg = cg >> 2, gpt = 256 / cg;    // channels per group, quads per group, groups per tile
-        if (tid < 4 * gpt) {
+        const int cg = p.cout / GN_GROUPS, qpg = cg >> 2, gpt = NT / cg;     // channels per group, quads per group, groups per tile
+        constexpr int RB = TM / 128, CW = NT / 128;         // 128-voxel row blocks and 128-column waves of the tile
+        if (tid < RB * 2 * gpt) {
             const int wm_ = tid / (2 * gpt), stat = (tid / gpt) & 1, gl = tid % gpt;
             float a = 0.f;
             for (int qd = 0; qd < qpg; ++qd) {
-                const int cq = gl * qpg + qd;                // tile-local channel quad 0..63 = wn*32 + nb*4 + ch
-                a += red[(((wm_ * 2 + (cq >> 5)) * 8 + ((cq >> 2) & 7)) * 4 + (cq & 3)) * 2 + stat];
+                const int cq = gl * qpg + qd;                // tile-local channel quad = wn*32 + nb*4 + ch
+                a += red[(((wm_ * CW + (cq >> 5)) * 8 + ((cq >> 2) & 7)) * 4 + (cq & 3)) * 2 + stat];
             }
-            const long prow_ = (long)tm * 2 + wm_;
+            const long prow_ = (long)tm * RB + wm_;
             if (prow_ * 128 < M) p.gn_partial[prow_ * 2 * GN_GROUPS + stat * GN_GROUPS + n0 / cg + gl] = a;
         }
     }
@@ -874,10 +888,22 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
     if (w4 && (w4 == 2 || ((M + 255) / 256) * (cout / 256) >= 2L * n_cu) && cout == cout_pad && cout % 256 == 0 && !t_map && M >= 1024 && (long)kt * kh * kw * (Cin / 64) >= 4 && H * up < 2048 && W * up < 2048 &&
         To < 512 && Ho < 2048 && Wo < 2048 && (long)kt * kh * kw * Cin < (1L << 21) && (long)(T + 2) * H * W * Cin < (1L << 31)) {
         static bool attr4 = false;
-        if (!attr4) { (void)hipFuncSetAttribute((const void*)conv3d_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS); attr4 = true; }
+        if (!attr4) { (void)hipFuncSetAttribute((const void*)conv3d_w4_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS); attr4 = true; }
         const long tiles4 = ((M + 255) / 256) * (cout / 256);
-        hipLaunchKernelGGL(conv3d_w4_kernel, dim3((unsigned)tiles4), dim3(256), CW_LDS, stream, p);
+        hipLaunchKernelGGL(conv3d_w4_kernel<256>, dim3((unsigned)tiles4), dim3(256), CW_LDS, stream, p);
         TG_LAUNCH_CHECK("tg_conv3d_cl(w4)");
+        return TG_OK;
+    }
+    // Cout = 128: the 512x128 variant (plain 3x3x3 / 1x3x3 convolutions only: 16 A pieces per wave are too many for the general address path)
+    static const int w4n = [] { const char* e = getenv("TG_CONV_W4N"); return e ? atoi(e) : 1; }();    // measured: 128->128 layers 203 -> 187 ms (decode), 181 -> 162 ms (encode)
+    if (w4n && (w4n == 2 || (M + 511) / 512 >= 2L * n_cu) && cout == 128 && cout_pad == 128 && !t_map && stride == 1 && up == 1 && M >= 2048 &&
+        (long)kt * kh * kw * (Cin / 64) >= 4 && H < 2048 && W < 2048 && To < 512 && Ho < 2048 && Wo < 2048 && (long)kt * kh * kw * Cin < (1L << 21) &&
+        (long)(T + 2) * H * W * Cin < (1L << 31)) {
+        constexpr int LDS_N = 2 * (512 * 128 + 128 * 128);
+        static bool attrn = false;
+        if (!attrn) { (void)hipFuncSetAttribute((const void*)conv3d_w4_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_N); attrn = true; }
+        hipLaunchKernelGGL(conv3d_w4_kernel<128>, dim3((unsigned)((M + 511) / 512)), dim3(256), LDS_N, stream, p);
+        TG_LAUNCH_CHECK("tg_conv3d_cl(w4n)");
         return TG_OK;
     }
     static bool attr = false;
