@@ -25,12 +25,15 @@ what = sys.argv[1:] or ["decode", "encode"]
 for name in what:
     fn = (lambda: vae.decode(z).sample) if name == "decode" else (lambda: vae.encode(x).latent_dist.mode())
     out = fn(); torch.cuda.synchronize()
+    dt = 1e9
+    for _ in range(2):        # wall time WITHOUT the per-launch profiling events (~8300 launches: the events alone cost ~80 ms)
+        t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize(); dt = min(dt, time.perf_counter() - t0)
     K.PROFILE.clear(); K.PROFILE_ON[0] = True
-    t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize(); dt_prof = time.perf_counter() - t0
     K.PROFILE_ON[0] = False
     prof = K.profile_summary()
     flop = {"decode": 3.1e14, "encode": 1.5e14}[name]      # untiled algorithmic count; executed = x1.40
     top = sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:8]
-    print(json.dumps({"op": f"vae_{name}", "out_shape": list(out.shape), "seconds": dt, "clips_per_s": 1 / dt,
+    print(json.dumps({"op": f"vae_{name}", "out_shape": list(out.shape), "seconds": dt, "seconds_with_profiling_events": dt_prof, "clips_per_s": 1 / dt,
                       "algorithmic_TFLOPs": flop / dt / 1e12, "executed_TFLOPs": 1.4 * flop / dt / 1e12, "finite": bool(torch.isfinite(out).all()),
                       "kernel_total_ms": {k: round(v["total_ms"], 1) for k, v in top}, "launches": sum(v["n"] for v in prof.values())}))
