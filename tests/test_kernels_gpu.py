@@ -480,3 +480,28 @@ def test_gemm_4wave_random_shapes(K):
         ref = pre if epi == L.EPI_BIAS else torch.nn.functional.gelu(pre, approximate="tanh") if epi == L.EPI_BIAS_GELU else torch.nn.functional.silu(pre)
         assert _rel(out, ref) < 6e-3, (M, N, Kd, B, epi)
         assert (out_full[:, 0] == 9.0).all() and (out_full[:, M + 1] == 9.0).all() and (out_full[:, :, N:] == 9.0).all(), (M, N, Kd, B)
+
+
+def test_attention_ragged_tile_split_at_launch_scale(K):
+    """At launch scale (>= 1024 ping-pong workgroups) a single-problem call whose ragged last query tile would cost a whole extra round
+    of workgroups hands that tile to the 4-wave kernel behind the ping-pong launch (attention.hip, TG_ATTN_TAIL): 48 heads x 2, nq =
+    13 x 512 + 150 (1248 -> 5 rounds instead of 1344 -> 6).  Both parts against fp32 torch on a few heads: rows of full tiles, the
+    ragged rows, two key segments."""
+    B, H, nq, nk2 = 2, 48, 13 * 512 + 150, 200
+    D = H * 64
+    qkv = _rand(B, nq, 3 * D, seed=61, scale=0.6)
+    qkv2 = _rand(B, nq, 3 * D, seed=62, scale=0.6)
+    pad = lambda n: (n + 63) // 64 * 64
+    vt1 = torch.empty(B, H, 64, pad(nq), dtype=torch.bfloat16, device=DEV)
+    vt2 = torch.empty(B, H, 64, pad(nk2), dtype=torch.bfloat16, device=DEV)
+    K.transpose_v(qkv[:, :, 2 * D:], H, 0, nq, vt1)
+    K.transpose_v(qkv2[:, :, 2 * D:], H, 0, nk2, vt2)
+    out = torch.zeros(B, nq, D, dtype=torch.bfloat16, device=DEV)
+    K.attention(qkv[:, :, :D], qkv[:, :, D:2 * D], vt1, nq, out, H, 0.125, qkv2[:, :, :D], qkv2[:, :nk2, D:2 * D], vt2, nk2, 0.6)
+    rows = torch.cat([torch.arange(0, 40), torch.arange(6000, 6040), torch.arange(13 * 512 - 20, nq)]).to(DEV)
+    for h in (0, 17, 47):
+        sl = slice(h * 64, h * 64 + 64)
+        q1, k1, v1 = qkv[:, rows, sl].float(), qkv[:, :, D + h * 64:D + h * 64 + 64].float(), qkv[:, :, 2 * D + h * 64:2 * D + h * 64 + 64].float()
+        q2, k2, v2 = qkv2[:, rows, sl].float(), qkv2[:, :nk2, D + h * 64:D + h * 64 + 64].float(), qkv2[:, :nk2, 2 * D + h * 64:2 * D + h * 64 + 64].float()
+        ref = torch.softmax(q1 @ k1.transpose(1, 2) * 0.125, -1) @ v1 + 0.6 * (torch.softmax(q2 @ k2.transpose(1, 2) * 0.125, -1) @ v2)
+        assert _rel(out[:, rows, sl], ref) < 8e-3, h
