@@ -1,3 +1,4 @@
+import json
 import os
 import sys
 
@@ -8,12 +9,47 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# every parity test records the rel-L2 (or max-abs) it measured next to the tolerance it asserts; on the GPU box the file lands under
+# gpurun_out/ (merged back by gpurun) and the per-round copy is committed as profiles/rNN_parity_report.json
+PARITY_REPORT = os.path.join(ROOT, "gpurun_out", "parity_report.json")
+_PARITY = {}
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:
+        import pytest_timeout  # noqa: F401
+    except ImportError:      # keep `@pytest.mark.timeout` a known marker when the plugin is missing (it is installed in this image)
+        config.addinivalue_line("markers", "timeout(seconds): per-test limit (pytest-timeout)")
 
 
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def parity(request):
+    """parity(measured, tol, what="") -> asserts measured < tol and appends {test, what, measured, tol} to the parity report."""
+    def rec(measured, tol, what=""):
+        measured = float(measured)
+        _PARITY.setdefault(request.node.nodeid, []).append({"what": what, "measured": measured, "tol": float(tol)})
+        assert measured < tol, f"{what or request.node.name}: measured {measured:.4e} >= tolerance {tol:.1e}"
+        return measured
+    return rec
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _PARITY:
+        return
+    try:
+        os.makedirs(os.path.dirname(PARITY_REPORT), exist_ok=True)
+        old = {}
+        if os.path.exists(PARITY_REPORT):
+            with open(PARITY_REPORT) as f:
+                old = json.load(f)
+        old.update(_PARITY)
+        with open(PARITY_REPORT, "w") as f:
+            json.dump(old, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

@@ -1,0 +1,46 @@
+"""CPU (gloo, 2 ranks): worker-failure surfacing of the multi-GPU runtime (tokensgen_amd/runtime.py) — the reference's parent blocks forever in
+`output_queue.get()` when a worker dies (cogvideo_sampling_mp_fifo.py:308-311); here (a) a rank that raises inside an iteration makes every rank
+raise RankFailure in that same iteration, (b) a rank that dies gets the others terminated by the launcher with its exit code reported,
+(c) a rank that silently stops makes its peers' next collective time out."""
+import os
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "rank_worker.py")
+
+
+def _read(d, r):
+    with open(os.path.join(d, f"rank{r}.txt")) as f:
+        return f.read()
+
+
+@pytest.mark.timeout(280)
+def test_exception_in_one_rank_raises_on_every_rank(tmp_path):
+    from tokensgen_amd.runtime import launch
+    launch(2, [sys.executable, WORKER, "raise", str(tmp_path)])
+    for r in (0, 1):
+        msg = _read(tmp_path, r)
+        assert msg.startswith("RankFailure after 4 iterations"), msg          # iterations 0..3: raised in the iteration the failure happened
+        assert "rank 1 failed: ValueError: injected failure in window of iteration 3" in msg
+
+
+@pytest.mark.timeout(120)
+def test_dead_rank_terminates_the_job(tmp_path):
+    from tokensgen_amd.runtime import launch
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match=r"rank 1 of 2 exited with code 3; the other ranks were terminated"):
+        launch(2, [sys.executable, WORKER, "die", str(tmp_path)])
+    assert time.time() - t0 < 60          # rank 0 sleeps 120 s: it was terminated, not waited for
+
+
+@pytest.mark.timeout(120)
+def test_silent_rank_times_out(tmp_path):
+    from tokensgen_amd.runtime import launch
+    try:
+        launch(2, [sys.executable, WORKER, "silent", str(tmp_path)])
+    except RuntimeError:
+        pass                              # gloo may tear rank 1 down when rank 0 leaves; what matters is rank 0's report
+    assert _read(tmp_path, 0).startswith("timeout surfaced after"), _read(tmp_path, 0)

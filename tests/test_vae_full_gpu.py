@@ -1,0 +1,90 @@
+"""GPU: BASELINE config 4 — the 3-D causal VAE at FULL size (49 x 480 x 720, tiling + slicing on, like the pipeline:
+infer_cogvideo_mp_fifo.py:131-132), and the real channel widths (128/256/256/512, 3 resnets per encoder block, 4 per decoder
+block) against the oracle on a tile the CPU finishes in seconds.
+
+Full size has no CPU oracle run (3e14 FLOP): it is covered by size-independent properties — shape, finiteness, run-to-run bitwise
+equality, and locality: a pixel of the interior of tile (0,0) away from every blended seam only depends on that tile, so the full
+tiled run must reproduce a stand-alone run of that tile bit for bit (same kernels, same GroupNorm partition).
+Reference: autoencoder_kl_cogvideox.py:1085-1108 (_encode), :1138-1163 (_decode), :1206-1359 (tiled_*), :1028-1062 (enable_tiling)."""
+import pytest
+import torch
+
+from oracle import vae_ref as V
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+FULL = dict(block_out_channels=(128, 256, 256, 512), layers_per_block=3, latent_channels=16, sample_height=480, sample_width=720)
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+@pytest.fixture(scope="module")
+def vae_full():
+    from tokensgen_amd.vae import AutoencoderKLCogVideoX
+    vae = AutoencoderKLCogVideoX(device=DEV).init_random(seed=1)
+    vae.enable_tiling()
+    vae.enable_slicing()
+    return vae
+
+
+@pytest.mark.timeout(900)
+def test_full_size_decode_properties(vae_full):
+    vae = vae_full
+    g = torch.Generator(device=DEV).manual_seed(0)
+    z = (torch.randn(1, 16, 13, 60, 90, generator=g, device=DEV) / 1.15258426).to(BF)
+    d1 = vae.decode(z).sample
+    assert tuple(d1.shape) == (1, 3, 49, 480, 720) and d1.dtype == BF
+    assert torch.isfinite(d1).all()
+    d2 = vae.decode(z).sample
+    assert torch.equal(d1, d2), "decode is not run-to-run deterministic"
+    # locality: tile (0,0) = latent rows 0..29, cols 0..44 -> 240 x 360 px, kept 200 x 288, never blended INTO (it has no upper/left
+    # neighbour): the full run's top-left 200 x 288 block is that tile's own output
+    vae.disable_tiling()
+    alone = vae.decode(z[:, :, :, :30, :45].contiguous()).sample
+    vae.enable_tiling()
+    assert torch.equal(d1[..., :200, :288], alone[..., :200, :288])
+    assert d1.float().std() > 1e-3
+
+
+@pytest.mark.timeout(900)
+def test_full_size_encode_properties(vae_full):
+    vae = vae_full
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = (torch.rand(1, 3, 49, 480, 720, generator=g, device=DEV) * 2 - 1).to(BF)
+    h1 = vae.encode(x).latent_dist.parameters
+    assert tuple(h1.shape) == (1, 32, 13, 60, 90) and torch.isfinite(h1).all()
+    h2 = vae.encode(x).latent_dist.parameters
+    assert torch.equal(h1, h2), "encode is not run-to-run deterministic"
+    vae.disable_tiling()
+    alone = vae.encode(x[..., :240, :360].contiguous()).latent_dist.parameters
+    vae.enable_tiling()
+    assert torch.equal(h1[..., :25, :36], alone[..., :25, :36])     # tile (0,0): 30 x 45 latent, kept 25 x 36
+    post = vae.encode(x).latent_dist
+    assert post.mode().shape == (1, 16, 13, 60, 90) and torch.isfinite(post.sample(generator=torch.Generator(device=DEV).manual_seed(2))).all()
+
+
+@pytest.mark.timeout(1500)
+def test_real_width_tile_vs_oracle(parity):
+    """Channels 128/256/256/512 with 3 (encoder) / 4 (decoder) resnets per block — the shipped VAE — on ONE FULL-SIZE TILE (30 x 45 latent = 240 x 360 px, the tile of the 480 x 720 geometry) over
+    two temporal batches (latent frames (0,3),(3,5) / sample frames (0,9),(9,17): first-frame replication, the carried cache, odd-T up/down
+    sampling) vs the oracle run in bf16 on the same bf16 weights.  ~45 convolutions deep in bf16: rel-L2 <= 5e-2 (SURVEY §8c end-to-end)."""
+    from tokensgen_amd.vae import AutoencoderKLCogVideoX
+    sd = V.make_state_dict(FULL, seed=5, dtype=BF)
+    vae = AutoencoderKLCogVideoX(device=DEV)
+    vae.load_state_dict(sd)
+    g = torch.Generator().manual_seed(6)
+    z = (torch.randn(1, 16, 5, 30, 45, generator=g) / 1.15258426).to(BF)
+    x = (torch.rand(1, 3, 17, 240, 360, generator=g) * 2 - 1).to(BF)
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    with torch.no_grad():
+        ref_d = V.decode(sd, FULL, z, tiling=False)
+        ref_h = V.encode(sd, FULL, x, tiling=False)
+    d = vae.decode(z.to(DEV)).sample
+    h = vae.encode(x.to(DEV)).latent_dist.parameters
+    assert d.shape == ref_d.shape and h.shape == ref_h.shape
+    parity(_rel(d, ref_d), 5e-2, "decode, real widths, 5 latent frames of 30x45 (one full tile)")
+    parity(_rel(h, ref_h), 5e-2, "encode, real widths, 17 frames of 240x360 (one full tile)")

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from . import rope as R
+from .runtime import RankGuard
 
 BF16 = torch.bfloat16
 
@@ -219,22 +220,31 @@ def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None
         plan = window_plan(queue_start, nf, num_partitions)
         mine = [(k, w) for k, w in enumerate(plan) if k % world == me]
         per_rank = (len(plan) + world - 1) // world
-        buf = torch.zeros(per_rank, 2, nf, C, H, W, dtype=BF16, device=dev)
-        for slot, (k, w) in enumerate(mine):
-            s, e = w["start"], w["end"]
-            kw = dict(latents=latents[:, s:e].clone(), old_x0=x0q[s:e].clone(), has_old=has_old[s:e], t=t_tab[s:e],
-                      prev_t=p_tab[s:e], next_t=n_tab[s:e], noise=step_noise_fn(i, w["rank"], (nf, 2, C, H, W)))
-            if use_vip:
-                vs = int(np.searchsorted(cond_t, q_grid_t[s] + bo.video_ipadapter_start_frame_idx, side="right") - 1)   # :110-115
-                kw.update(grid_t=q_grid_t[s:e].copy(), cond_grid_t=cond_t[vs:vs + n_c].copy(), image_embeddings=emb[:, vs:vs + n_c].contiguous())
-                if trace is not None:
-                    trace.append((i, w["rank"], s, w["mid"], e, w["real_end"], vs))
-            x_out, x0_out = window_fn(**kw)
-            buf[slot, 0], buf[slot, 1] = x_out[0], x0_out
-        if world > 1:                                   # the path's one exchange: kept windows of every rank
-            allbuf = torch.empty(world * per_rank, *buf.shape[1:], dtype=BF16, device=dev)   # rank-major concat
-            dist.all_gather_into_tensor(allbuf, buf)
+        n_el = per_rank * 2 * nf * C * H * W
+        xbuf = torch.zeros(n_el + 8, dtype=BF16, device=dev)                   # payload + this rank's failure flag (runtime.RankGuard)
+        buf = xbuf[:n_el].view(per_rank, 2, nf, C, H, W)
+        guard = RankGuard(f"FIFO iteration {i}")
+        with guard:
+            for slot, (k, w) in enumerate(mine):
+                s, e = w["start"], w["end"]
+                kw = dict(latents=latents[:, s:e].clone(), old_x0=x0q[s:e].clone(), has_old=has_old[s:e], t=t_tab[s:e],
+                          prev_t=p_tab[s:e], next_t=n_tab[s:e], noise=step_noise_fn(i, w["rank"], (nf, 2, C, H, W)))
+                if use_vip:
+                    vs = int(np.searchsorted(cond_t, q_grid_t[s] + bo.video_ipadapter_start_frame_idx, side="right") - 1)   # :110-115
+                    kw.update(grid_t=q_grid_t[s:e].copy(), cond_grid_t=cond_t[vs:vs + n_c].copy(), image_embeddings=emb[:, vs:vs + n_c].contiguous())
+                    if trace is not None:
+                        trace.append((i, w["rank"], s, w["mid"], e, w["real_end"], vs))
+                x_out, x0_out = window_fn(**kw)
+                buf[slot, 0], buf[slot, 1] = x_out[0], x0_out
+        if world > 1:                                   # the path's one exchange: kept windows of every rank (+ the failure flags)
+            xbuf[n_el:n_el + 1] = guard.flag(dev)
+            flat = torch.empty(world * (n_el + 8), dtype=BF16, device=dev)     # rank-major concat
+            dist.all_gather_into_tensor(flat, xbuf)
+            allx = flat.view(world, n_el + 8)
+            guard.check(allx[:, n_el])                  # a rank that raised above makes EVERY rank raise here, this iteration
+            allbuf = allx[:, :n_el].reshape(world * per_rank, 2, nf, C, H, W)
         else:
+            guard.check(None)
             allbuf = buf
         new_lat, new_x0, new_has = latents.clone(), x0q.clone(), list(has_old)
         for k, w in enumerate(plan):                    # identical write-back on every rank (:308-334)

@@ -92,6 +92,12 @@ class AutoencoderKLCogVideoX:
 
     def load_state_dict(self, sd, strict=True):
         """Keeps the bf16 originals under the diffusers names and builds the packed GEMM operands."""
+        want = self.param_shapes()
+        missing = [k for k in want if k not in sd]
+        unexpected = [k for k in sd if k not in want]
+        bad = [k for k in want if k in sd and tuple(sd[k].shape) != tuple(want[k])]
+        if bad or (strict and (missing or unexpected)):
+            raise RuntimeError(f"AutoencoderKLCogVideoX.load_state_dict: missing {missing[:4]}, unexpected {unexpected[:4]}, shape mismatch {bad[:4]}")
         self._sd = {k: v.detach().to(self.device, BF16).contiguous() for k, v in sd.items()}
         self._packed = {}
         for k, v in self._sd.items():
@@ -116,7 +122,76 @@ class AutoencoderKLCogVideoX:
                 b = torch.zeros(2 * Cp, dtype=BF16, device=self.device)
                 b[:C], b[Cp:Cp + C] = self._sd[base + ".conv_y.conv.bias"], self._sd[base + ".conv_b.conv.bias"]
                 self._packed[base + ".yb.weight"], self._packed[base + ".yb.bias"] = w, b
-        return SimpleNamespace(missing_keys=[], unexpected_keys=[])
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
+
+
+    def param_shapes(self):
+        """name -> shape of every parameter of this configuration, under the diffusers key names (what load_state_dict expects)."""
+        c = self.config
+        boc, lpb, lat = list(c.block_out_channels), c.layers_per_block, c.latent_channels
+        out = {}
+
+        def conv(name, co, ci, taps):
+            out[name + ".weight"], out[name + ".bias"] = (co, ci) + taps, (co,)
+
+        def res(name, ci, co, zq):
+            for n, ch in (("norm1", ci), ("norm2", co)):
+                if zq:
+                    out[f"{name}.{n}.norm_layer.weight"] = out[f"{name}.{n}.norm_layer.bias"] = (ch,)
+                    conv(f"{name}.{n}.conv_y.conv", ch, lat, (1, 1, 1))
+                    conv(f"{name}.{n}.conv_b.conv", ch, lat, (1, 1, 1))
+                else:
+                    out[f"{name}.{n}.weight"] = out[f"{name}.{n}.bias"] = (ch,)
+            conv(name + ".conv1.conv", co, ci, (3, 3, 3))
+            conv(name + ".conv2.conv", co, co, (3, 3, 3))
+            if ci != co:
+                conv(name + ".conv_shortcut", co, ci, (1, 1, 1))
+
+        conv("encoder.conv_in.conv", boc[0], c.in_channels, (3, 3, 3))
+        ch = boc[0]
+        for i, co in enumerate(boc):
+            for j in range(lpb):
+                res(f"encoder.down_blocks.{i}.resnets.{j}", ch if j == 0 else co, co, False)
+            ch = co
+            if i != len(boc) - 1:
+                conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", co, co, (3, 3))
+        for j in range(2):
+            res(f"encoder.mid_block.resnets.{j}", ch, ch, False)
+        out["encoder.norm_out.weight"] = out["encoder.norm_out.bias"] = (ch,)
+        conv("encoder.conv_out.conv", 2 * lat, ch, (3, 3, 3))
+        rb = boc[::-1]
+        conv("decoder.conv_in.conv", rb[0], lat, (3, 3, 3))
+        for j in range(2):
+            res(f"decoder.mid_block.resnets.{j}", rb[0], rb[0], True)
+        ch = rb[0]
+        for i, co in enumerate(rb):
+            for j in range(lpb + 1):
+                res(f"decoder.up_blocks.{i}.resnets.{j}", ch if j == 0 else co, co, True)
+            ch = co
+            if i != len(rb) - 1:
+                conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", co, co, (3, 3))
+        out["decoder.norm_out.norm_layer.weight"] = out["decoder.norm_out.norm_layer.bias"] = (ch,)
+        conv("decoder.norm_out.conv_y.conv", ch, lat, (1, 1, 1))
+        conv("decoder.norm_out.conv_b.conv", ch, lat, (1, 1, 1))
+        conv("decoder.conv_out.conv", c.out_channels, ch, (3, 3, 3))
+        return out
+
+    def init_random(self, seed=0):
+        """Seeded random weights at this configuration's shapes (benchmarks: real checkpoints are not available offline):
+        fan-in scaled convolutions, norm scales near 1, SpatialNorm conv_y biased to 1."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        sd = {}
+        for k, shp in self.param_shapes().items():
+            r = torch.randn(shp, generator=g, device=self.device, dtype=torch.float32)
+            if len(shp) > 1:
+                r = r / float(np.prod(shp[1:])) ** 0.5
+            elif k.endswith(".weight"):
+                r = 1 + 0.1 * r
+            else:
+                r = 0.05 * r + (1.0 if k.endswith("conv_y.conv.bias") else 0.0)
+            sd[k] = r.to(BF16)
+        self.load_state_dict(sd)
+        return self
 
     # ---- building blocks -----------------------------------------------------------------------------------
     def _conv(self, name, x, cache, residual=None):
