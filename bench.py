@@ -7,7 +7,8 @@ CFG-batched (B=2) DiT forward over one 13-latent-frame window (226 text + 17 550
 random-init weights of the real architecture (no checkpoints offline).  Inputs are resident in HBM when the
 timed region starts.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank runs its own window of the same
+N > 1 (one rank per GPU, RCCL; launched by torch.distributed.run, or — when RANK is not in the environment — by bench.py itself
+through tokensgen_amd.runtime.launch): every rank runs its own window of the same
 FIFO iteration (weak scaling, windows are independent) and the kept half-windows (7 latent frames + 7 x0
 frames per rank) are exchanged with ONE all_gather per step — the path's real exchange.
 
@@ -30,6 +31,7 @@ PEAK_BF16 = 2.5e15                # MI355X dense bf16 MFMA peak (MI355X_MICROARC
 # dominant kernel = fused main attention (SDPA#1 + SDPA#2 of the To2V processor), per launch (B=2):
 N1, NP, D_MODEL = 17776, 480, 3072
 # + the vip-query attention (SDPA#3), whose workgroups ride in the same launch (tg_attention_fwd_multi)
+PMC_SUMMARY = "r1n_pmc_summary.json"     # committed rocprofv3 PMC passes the `traffic` figure is read from
 ATTN_FLOP_PER_LAUNCH = 2 * (4.0 * N1 * N1 * D_MODEL + 4.0 * N1 * NP * D_MODEL + 4.0 * NP * (N1 + NP) * D_MODEL)
 
 
@@ -51,29 +53,171 @@ def build_model(device, layers):
     return m
 
 
-def cpu_baseline(seconds_budget=40.0):
-    """The oracle (CPU restatement of the reference, validated against it) timed on this box's host cores on a
-    bounded sample of the same workload: ONE full-width block forward (B=1) of the 84 a step needs."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _physical_cores():
+    """Distinct (physical id, core id) pairs of /proc/cpuinfo restricted to this process's affinity; falls back to os.cpu_count()."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        cores, cpu, phys = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "processor":
+                    cpu = int(v)
+                elif k == "physical id":
+                    phys = v
+                elif k == "core id" and cpu in allowed:
+                    cores.add((phys, v))
+        if cores:
+            return len(cores)
+    except (OSError, ValueError, AttributeError):
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_baseline(seconds_budget=150.0):
+    """SURVEY §8(d) protocol: the oracle (CPU restatement of the reference, validated against it) timed on this box's host cores on a
+    bounded sample of the same workload — ONE full-width block forward (B=1) of the 84 a step needs — bf16 and fp32, 1 warm-up + up to 3
+    timed runs each (median; fewer runs only if `seconds_budget` runs out), on the thread count that is fastest among {physical cores / 2,
+    physical cores, logical cores} in a short GEMM probe (256 logical threads oversubscribed the round-1 baseline 3x)."""
     from oracle import dit_ref as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    physical = min(_physical_cores(), logical)
+    t_start = time.perf_counter()
+    a, b = torch.randn(4096, 3072).bfloat16(), torch.randn(3072, 3072).bfloat16()
+    probe = {}
+    for n in sorted({max(1, physical // 2), physical, logical}):
+        torch.set_num_threads(n)
+        a @ b
+        t0 = time.perf_counter()
+        for _ in range(3):
+            a @ b
+        probe[n] = (time.perf_counter() - t0) / 3
+    threads = min(probe, key=probe.get)
+    torch.set_num_threads(threads)
     cfg = dict(num_attention_heads=48, attention_head_dim=64, num_layers=1, time_embed_dim=512)
-    sd = {k: v.to(torch.bfloat16) for k, v in O.make_state_dict(cfg, n_vip_dim=3072, seed=500).items()
-          if k.startswith("transformer_blocks.0.")}
+    sd32 = {k: v for k, v in O.make_state_dict(cfg, n_vip_dim=3072, seed=500).items() if k.startswith("transformer_blocks.0.")}
     g = torch.Generator().manual_seed(501)
-    hid = torch.randn(1, 17550, 3072, generator=g).bfloat16()
-    enc = torch.randn(1, 706, 3072, generator=g).bfloat16()
-    temb = torch.randn(1, 13, 512, generator=g).bfloat16()
+    hid, enc, temb = torch.randn(1, 17550, 3072, generator=g), torch.randn(1, 706, 3072, generator=g), torch.randn(1, 13, 512, generator=g)
     f32 = np.float32
     rope = O.rope_3d(64, np.arange(13, dtype=f32), np.arange(30, dtype=f32), np.arange(45, dtype=f32))
     crope = O.rope_3d(64, np.linspace(1000, 1016.25, 5, dtype=f32), np.linspace(0, 30, 8, endpoint=False, dtype=f32),
                       np.linspace(0, 45, 12, endpoint=False, dtype=f32))
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        O.block_forward(sd, "transformer_blocks.0", hid, enc, temb, 48, 480, [0.6], rope, rope, crope)
-        dt = time.perf_counter() - t0
-    return {"value": 1.0 / (dt * 84.0), "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"1 full-width CogVideoXBlock forward (B=1, bf16, {dt:.1f} s) of the 84 per step, extrapolated x84"}
+    res = {}
+    for name, dt_ in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        sd = {k: v.to(dt_) for k, v in sd32.items()}
+        args = (sd, "transformer_blocks.0", hid.to(dt_), enc.to(dt_), temb.to(dt_), 48, 480, [0.6], rope, rope, crope)
+        times = []
+        with torch.no_grad():
+            O.block_forward(*args)                                   # warm-up
+            # bf16 gets the first 60 % of the budget, fp32 the rest; always at least one timed run
+            limit = t_start + seconds_budget * (0.6 if name == "bf16" else 1.0)
+            while len(times) < 3 and (not times or time.perf_counter() + times[-1] < limit):
+                t0 = time.perf_counter()
+                O.block_forward(*args)
+                times.append(time.perf_counter() - t0)
+        res[name] = (sorted(times)[len(times) // 2], len(times))
+    med, n = res["bf16"]
+    return {"value": 1.0 / (med * 84.0), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"1 full-width CogVideoXBlock forward (B=1) of the 84 per step, extrapolated x84: bf16 median {med:.2f} s over {n} runs, "
+                      f"fp32 median {res['fp32'][0]:.2f} s over {res['fp32'][1]} runs (1 warm-up each)",
+            "fp32_value": 1.0 / (res["fp32"][0] * 84.0), "cpu_model": _cpu_model(), "physical_cores": physical, "logical_cores": logical,
+            "threads_probe_s": {str(k): round(v, 4) for k, v in probe.items()}}
+
+
+VAE_FLOP = {"decode": 3.1e14, "encode": 1.5e14}     # untiled algorithmic count per 49-frame clip, SURVEY §8(d); executed = x1.40 (9-tile overlap)
+
+
+def vae_record(device, reps=2):
+    """BASELINE config 4 (outside the timed DiT region): 3-D causal VAE decode [1,16,13,60,90] -> [1,3,49,480,720] and encode back,
+    tiling + slicing on like the pipeline, random weights at the real widths.  Wall seconds = best of `reps` after one warm-up."""
+    from tokensgen_amd.vae import AutoencoderKLCogVideoX
+    vae = AutoencoderKLCogVideoX(device=device).init_random(seed=1)
+    vae.enable_tiling(); vae.enable_slicing()
+    g = torch.Generator(device=device).manual_seed(0)
+    z = (torch.randn(1, 16, 13, 60, 90, generator=g, device=device) / 1.15258426).to(torch.bfloat16)
+    x = (torch.rand(1, 3, 49, 480, 720, generator=g, device=device) * 2 - 1).to(torch.bfloat16)
+    out = {"workload": "AutoencoderKLCogVideoX 49x480x720 (13x60x90 latent), 9 spatial tiles x 6 temporal batches, bf16", "peak_TFLOPs": PEAK_BF16 / 1e12}
+    for name, fn in (("decode", lambda: vae.decode(z).sample), ("encode", lambda: vae.encode(x).latent_dist.parameters)):
+        y = fn(); torch.cuda.synchronize()
+        best = float("inf")
+        for _ in range(reps):
+            t0 = time.perf_counter(); y = fn(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        out[name] = {"seconds": best, "algorithmic_TFLOPs": VAE_FLOP[name] / best / 1e12, "executed_TFLOPs": 1.4 * VAE_FLOP[name] / best / 1e12,
+                     "frac_of_peak_algorithmic": VAE_FLOP[name] / best / PEAK_BF16, "frac_of_peak_executed": 1.4 * VAE_FLOP[name] / best / PEAK_BF16,
+                     "out_shape": list(y.shape), "finite": bool(torch.isfinite(y).all())}
+    del vae
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_e2e(a, rank, world, device, dist):
+    """--mode e2e: ONE full To2V run on synthetic inputs — the 52-step base stage on chunk 0 (CFG-parallel over ranks 0/1 when world >= 2),
+    the FIFO stage over `--chunks` clips INCLUDING the ramp (windows dealt round-robin to the ranks, one all_gather per iteration), and the
+    chunk-sharded VAE decode with its all_gather of frames.  value = DiT window-forwards / wall / N (steps/s/GPU end to end); the base stage's
+    scalar-timestep forwards count as window-forwards (same shape)."""
+    from tokensgen_amd import fifo as F
+    from tokensgen_amd.pipeline import MPFIFOVideoIPAdapterCogVideoXPipeline
+    from tokensgen_amd.scheduler import CogVideoXDPMScheduler
+    from tokensgen_amd.vae import AutoencoderKLCogVideoX
+    model = build_model(device, a.layers)
+    sched = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
+    vae = AutoencoderKLCogVideoX(device=device).init_random(seed=1)
+    vae.enable_tiling(); vae.enable_slicing()
+    pipe = MPFIFOVideoIPAdapterCogVideoXPipeline(model, sched, vae=vae)
+    g = torch.Generator(device=device).manual_seed(42)           # same inputs on every rank (the reference ships them to its workers)
+    bf = torch.bfloat16
+    pe = (torch.randn(1, 226, 4096, generator=g, device=device) * 0.1).to(bf)
+    ne = (torch.randn(1, 226, 4096, generator=g, device=device) * 0.1).to(bf)
+    emb = torch.nn.functional.layer_norm(torch.randn(1, 4 * a.chunks, 8, 12, 3072, generator=g, device=device), (3072,))
+    emb = emb.permute(0, 1, 4, 2, 3).to(bf).contiguous()         # [1, 4*chunks, 3072, 8, 12] as the T2To stage / Resampler hands it over
+    counts = {"fifo": 0}
+    orig_plan = F.window_plan
+
+    def counting_plan(qs, nf=13, num_partitions=4):
+        plan = orig_plan(qs, nf, num_partitions)
+        counts["fifo"] += len(plan)
+        return plan
+    F.window_plan = counting_plan
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier(); torch.cuda.synchronize()
+    fence()
+    t0 = time.perf_counter()
+    base = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image_embeddings=emb, num_chunks=a.chunks, num_inference_steps=52,
+                guidance_scale=6.0, video_ipadapter_scale=[0.6], output_type="pt")
+    fence(); t_base = time.perf_counter() - t0
+    orig, video, _ = F.cogvideo_fifo_mp_v2([pipe], base, noise_seed=7)
+    fence(); dt = time.perf_counter() - t0
+    F.window_plan = orig_plan
+    if dist is not None:
+        tm = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dt = float(tm.item())
+    if rank == 0:
+        fwd = 52 + counts["fifo"]
+        print(json.dumps({
+            "metric": "DiT denoising steps/sec/GPU END TO END (base stage + FIFO incl. ramp + sharded VAE decode), CogVideoX-5B To2V 720x480",
+            "value": fwd / dt / world, "unit": "steps/s/GPU", "n_gpus": world, "steps": fwd, "warmup": 0, "ms_per_step": 1e3 * dt / fwd,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic embeddings, random-init weights at CogVideoX-5B shapes",
+            "config": {"workload": f"To2V end to end, {a.chunks} clip(s) of 49 frames: 52 base steps + {counts['fifo']} FIFO window-forwards "
+                                   f"+ VAE decode of {a.chunks + 1} clips", "layers": a.layers, "chunks": a.chunks},
+            "seconds": {"total": dt, "base_stage": t_base, "fifo_and_decode": dt - t_base},
+            "frames_out": list(video.shape), "finite": bool(torch.isfinite(video).all())}))
 
 
 def main():
@@ -82,23 +226,33 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--layers", type=int, default=42, help="debug only: anything but 42 is not the benchmark")
+    ap.add_argument("--mode", choices=("window", "e2e"), default="window",
+                    help="window (default, the headline): steady-state FIFO window steps; e2e: one whole To2V run incl. ramp, base stage, VAE decode")
+    ap.add_argument("--chunks", type=int, default=12, help="--mode e2e: number of 49-frame clips (edit.yaml: 12)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the VAE (BASELINE config 4) sub-record")
     a = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # not under torch.distributed.run: start the N ranks ourselves (one process per GPU, RCCL) and supervise them
+        if torch.cuda.device_count() < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+        from tokensgen_amd.runtime import launch
+        launch(a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    use_dist = "RANK" in os.environ            # launched by torch.distributed.run (also exercised with 1 rank)
+    use_dist = "RANK" in os.environ            # launched by torch.distributed.run or by the branch above (also exercised with 1 rank)
     if use_dist:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        from tokensgen_amd.runtime import init_distributed
+        init_distributed("nccl", device=device)
 
     from tokensgen_amd import kernels as K
     from tokensgen_amd import lib
@@ -106,6 +260,11 @@ def main():
     from tokensgen_amd.scheduler import CogVideoXDPMScheduler
     from tokensgen_amd import rope as R
     lib.load()
+    if a.mode == "e2e":
+        run_e2e(a, rank, world, device, dist)
+        if use_dist:
+            dist.destroy_process_group()
+        return
 
     model = build_model(device, a.layers)
     sched = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0,
@@ -169,10 +328,13 @@ def main():
     step()
     fence()
     K.PROFILE_ON[0] = False
+    rank_ms = [1e3 * dt / a.steps]
     if use_dist:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        mine = torch.tensor([dt], device=device, dtype=torch.float64)
+        every = torch.empty(world, device=device, dtype=torch.float64)
+        dist.all_gather_into_tensor(every, mine)
+        rank_ms = [1e3 * v / a.steps for v in every.tolist()]
+        dt = float(every.max().item())
     if rank == 0:
         prof = K.profile_summary()
         attn = attn_prof
@@ -180,7 +342,7 @@ def main():
         achieved = ATTN_FLOP_PER_LAUNCH / attn_s / 1e12 if attn["n"] else float("nan")
         traffic = None          # HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
         try:
-            with open(os.path.join(ROOT, "profiles", "r1n_pmc_summary.json")) as f:
+            with open(os.path.join(ROOT, "profiles", PMC_SUMMARY)) as f:
                 traffic = json.load(f)["_derived"]["attention_main_traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
@@ -197,7 +359,10 @@ def main():
                          "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16 / 1e12), "traffic": traffic,
                          "launch_ms": attn["ms"], "launches_timed": attn["n"]},
             "kernel_ms": {k: round(v["ms"], 4) for k, v in prof.items()},
+            "rank_ms_per_step": [round(v, 3) for v in rank_ms],
         }
+        if not a.no_vae and world == 1:
+            out["vae"] = vae_record(device)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -9,25 +9,26 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import vae_ref as V  # noqa: E402  (seeded weight initialiser with the diffusers key names only)
 from tokensgen_amd import kernels as K  # noqa: E402
 from tokensgen_amd.vae import AutoencoderKLCogVideoX  # noqa: E402
 
 DEV = "cuda"
-cfg = dict(block_out_channels=(128, 256, 256, 512), layers_per_block=3, latent_channels=16, sample_height=480, sample_width=720)
-vae = AutoencoderKLCogVideoX(device=DEV)
-vae.load_state_dict(V.make_state_dict(cfg, seed=1, dtype=torch.bfloat16))
+vae = AutoencoderKLCogVideoX(device=DEV).init_random(seed=1)
 vae.enable_tiling(); vae.enable_slicing()
 g = torch.Generator(device=DEV).manual_seed(0)
 z = (torch.randn(1, 16, 13, 60, 90, generator=g, device=DEV) / 1.15258426).to(torch.bfloat16)
 x = (torch.rand(1, 3, 49, 480, 720, generator=g, device=DEV) * 2 - 1).to(torch.bfloat16)
-what = sys.argv[1:] or ["decode", "encode"]
+PLAIN = "--plain" in sys.argv       # no per-launch events (for runs under rocprofv3)
+what = [w for w in sys.argv[1:] if not w.startswith("--")] or ["decode", "encode"]
 for name in what:
     fn = (lambda: vae.decode(z).sample) if name == "decode" else (lambda: vae.encode(x).latent_dist.mode())
     out = fn(); torch.cuda.synchronize()
     dt = 1e9
     for _ in range(2):        # wall time WITHOUT the per-launch profiling events (~8300 launches: the events alone cost ~80 ms)
         t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize(); dt = min(dt, time.perf_counter() - t0)
+    if PLAIN:
+        print(json.dumps({"op": f"vae_{name}", "seconds": dt, "out_shape": list(out.shape)}))
+        continue
     K.PROFILE.clear(); K.PROFILE_ON[0] = True
     t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize(); dt_prof = time.perf_counter() - t0
     K.PROFILE_ON[0] = False
