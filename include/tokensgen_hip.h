@@ -205,6 +205,14 @@ int tg_pca_inverse(const void* lat, const float* std16, const float* mean16, con
                    void* out, int frames, int ncoef, int hw, int cout, hipStream_t stream);
 
 
+/* Resampler's optional PCA low-rank filter (video_ipadapter/resampler.py:230-237: `pca.transform` -> zero every coefficient from 16 on ->
+ * `pca.inverse_transform`, in the PCA's dtype = fp32, pca.py:56-66), per token:
+ *   y_j = sum_c (x[r][c] - mean[c]) * comp[j][c]   (j < keep)        out[r][c] = bf16( mean[c] + sum_j y_j * comp[j][c] )
+ * x / out bf16 [rows][D] (row strides ldx / ldo, in place allowed); comp fp32 [keep][D] (the first `keep` <= 16 rows of components_);
+ * mean fp32 [D]. */
+int tg_pca_lowrank_filter(const void* x, long ldx, const float* comp, const float* mean, void* out, long ldo, int rows, int D,
+                          int keep, hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * 3-D causal VAE (AutoencoderKLCogVideoX).  Activations are channels-last bf16: x[t][h][w][c], C % 64 == 0.
  * --------------------------------------------------------------------------------------------------------- */

@@ -2,8 +2,9 @@
 
 Restates longvgen/video_ipadapter/resampler.py:66-244 functionally over a state dict with the reference's key names
 (`latents`, `proj_in`, `layers.{i}.0.{norm1,norm2,to_q,to_kv,to_out,norm_q,norm_k}`, `layers.{i}.1.net.{0.proj,2}`,
-`proj_out`, `norm_out`).  The PCA low-rank filter (:230-237) is not on the To2V path (set_pca is never called by
-infer_cogvideo_mp_fifo.py) and is not restated.  diffusers' FeedForward is restated (unpinned, see dit_ref.py)."""
+`proj_out`, `norm_out`), including the optional PCA low-rank filter (:230-237 with pca.py:56-66; gen.yaml passes a real `longvgen_pca`
+path to `set_pca`, infer_cogvideo_mp_fifo.py:118).  Pinned bit-exact against the reference class (tests/golden/resampler_tiny.pt: fp32 and
+bf16, batch 1 and 2, with and without the filter).  diffusers' FeedForward is restated (unpinned, see dit_ref.py)."""
 import math
 
 import torch
@@ -45,8 +46,9 @@ def perceiver_attention(sd, pre, x, latents, heads, image_rope, sampling_rope):
     return _lin(sd, pre + ".to_out", out)
 
 
-def resampler_forward(sd, cfg, x, image_rope=None, sampling_rope=None):
-    """Resampler.forward, :209-244.  x [b, f, n, embedding_dim] -> [b, Tq, output_dim, Hq, Wq]."""
+def resampler_forward(sd, cfg, x, image_rope=None, sampling_rope=None, pca=None):
+    """Resampler.forward, :209-244.  x [b, f, n, embedding_dim] -> [b, Tq, output_dim, Hq, Wq].
+    pca: optional (components_ [d, D], mean_ [1, D]) of a fitted pca.PCA -> the low-rank filter of :230-237."""
     b = x.shape[0]
     x = _lin(sd, "proj_in", x.flatten(0, 1)).reshape(b, -1, sd["proj_in.weight"].shape[0])
     lat = sd["latents"].expand(b, -1, -1)
@@ -55,6 +57,12 @@ def resampler_forward(sd, cfg, x, image_rope=None, sampling_rope=None):
         h = F.gelu(_lin(sd, f"layers.{i}.1.net.0.proj", lat), approximate="tanh")
         lat = _lin(sd, f"layers.{i}.1.net.2", h) + lat
     lat = _ln(sd, "norm_out", _lin(sd, "proj_out", lat))
+    if pca is not None:
+        comp, mean = pca
+        dt = lat.dtype
+        y = torch.matmul(lat.flatten(0, 1).to(comp.dtype) - mean, comp.t())          # pca.transform, pca.py:56-58
+        y[:, 16:] = 0.0
+        lat = (torch.matmul(y, comp) + mean).reshape(lat.shape).to(dt)              # pca.inverse_transform, :64-66
     tq, hq, wq = cfg["num_temporal_queries"], cfg["num_height_queries"], cfg["num_width_queries"]
     return lat.reshape(b, tq, hq, wq, -1).permute(0, 1, 4, 2, 3)
 

@@ -122,7 +122,7 @@ def test_full_width_block_vs_reference_samples(golden_dir):
         assert abs(oh.float().std().item() - r["h_std"]) < 2e-2 * r["h_std"]
 
 
-def test_resampler_vs_reference_golden(golden_dir):
+def test_resampler_vs_reference_golden(golden_dir, tmp_path, parity):
     """Condensed-token encoder on the HIP kernels vs the reference Resampler's outputs."""
     from oracle import resampler_ref as RR
     from tokensgen_amd.resampler import Resampler
@@ -143,8 +143,33 @@ def test_resampler_vs_reference_golden(golden_dir):
     assert _rel(y, g["bf16"]) < 2e-2 and _rel(y, g["fp32"]) < 2e-2
     y2 = m(x.to(DEV, torch.bfloat16), image_rotary_emb=img, sampling_rotary_emb=smp)      # the learned queries must not be updated in place
     assert torch.equal(y, y2) and torch.equal(m.state_dict()["latents"].cpu(), sd["latents"].to(torch.bfloat16))
-    with pytest.raises(NotImplementedError):
-        m.set_pca("pca.pt")
+    # batch 2 (the gate-of-ones table must be batch invariant) and the PCA low-rank filter set up like gen.yaml does:
+    # a pickled pca.PCA loaded by set_pca(path) (resampler.py:201-207, 230-237) — vs the reference Resampler's own outputs
+    x2 = torch.randn(2, 13, 24, 128, generator=gen)
+    y = m(x2.to(DEV, torch.bfloat16), image_rotary_emb=img, sampling_rotary_emb=smp)
+    parity(_rel(y, g["bf16_b2"]), 2e-2, "Resampler b=2 vs reference bf16")
+    parity(_rel(y[1], g["fp32_b2"][1]), 2e-2, "Resampler b=2, second batch item vs reference fp32")
+    from tokensgen_amd import compat
+    from tokensgen_amd.pca import PCA
+    compat.ensure_pca_module()
+    pc = PCA(None)
+    pc.register_buffer("mean_", g["pca_mean"].clone())
+    pc.register_buffer("components_", g["pca_components"].clone())
+    path = os.path.join(str(tmp_path), "pca.pt")
+    torch.save(pc, path)
+    m.set_pca(path)
+    y = m(x2.to(DEV, torch.bfloat16), image_rotary_emb=img, sampling_rotary_emb=smp)
+    parity(_rel(y, g["bf16_b2_pca"]), 2e-2, "Resampler b=2 + PCA filter vs reference bf16")
+    parity(_rel(y, g["fp32_b2_pca"]), 2e-2, "Resampler b=2 + PCA filter vs reference fp32")
+    # the filter kernel alone against the fp32 formula on the same bf16 input
+    from tokensgen_amd import kernels as K
+    xin = torch.randn(37, 128, generator=gen).to(torch.bfloat16)
+    comp, mean = g["pca_components"][:16].contiguous(), g["pca_mean"].reshape(-1).contiguous()
+    want = ((xin.float() - mean) @ comp.t()) @ comp + mean
+    got = K.pca_lowrank_filter(xin.to(DEV), comp.to(DEV), mean.to(DEV))
+    parity(_rel(got, want), 4e-3, "tg_pca_lowrank_filter vs fp32 torch")
+    m.set_pca(None)
+    assert m.pca is None
 
 
 def test_processor_operator_seam_vs_reference_processor(golden_dir):

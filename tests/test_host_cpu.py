@@ -224,3 +224,43 @@ def test_scheduler_from_config_like_the_entry_script(tmp_path):
                                  rescale_betas_zero_snr=True, snr_shift_scale=3.0, beta_schedule="scaled_linear")))
     c = CogVideoXDPMScheduler.from_config(str(f), timestep_spacing="trailing")
     assert c.config.snr_shift_scale == 3.0 and c.alphas_cumprod[-1] == 0.0
+
+
+def test_resampler_checkpoint_roundtrip_and_set_pca(tmp_path):
+    """Host side of the gen.yaml loading contract (infer_cogvideo_mp_fifo.py:113-118): Resampler.from_pretrained(dir, subfolder="resampler")
+    reads what save_pretrained wrote; set_pca(path) unpickles a `pca.PCA` (resampler.py:201-207) and keeps its first 16 components; strict
+    loading reports missing keys.  No kernel is launched (device "cpu" holds the tensors only)."""
+    from oracle import resampler_ref as RR
+    from tokensgen_amd import compat
+    from tokensgen_amd.pca import PCA
+    from tokensgen_amd.resampler import Resampler
+    cfg = dict(dim=128, depth=2, dim_head=64, heads=2, num_height_queries=2, num_width_queries=3, num_temporal_queries=4, embedding_dim=128,
+               output_dim=128, ff_mult=4, max_height_seq_len=4, max_width_seq_len=6, max_temporal_seq_len=5)
+    sd = RR.make_state_dict(cfg, seed=1)
+    r = Resampler(**cfg, device="cpu")
+    r.load_state_dict(sd)
+    assert sorted(r.expected_keys()) == sorted(sd)
+    r.save_pretrained(str(tmp_path / "resampler"))
+    r2 = Resampler.from_pretrained(str(tmp_path), subfolder="resampler", torch_dtype=torch.bfloat16, device="cpu").to("cpu")
+    assert vars(r2.config) == vars(r.config)
+    assert all(torch.equal(r2.state_dict()[k], v.to(torch.bfloat16)) for k, v in sd.items())
+    with pytest.raises(RuntimeError, match="missing"):
+        Resampler(**cfg, device="cpu").load_state_dict({k: v for k, v in sd.items() if k != "latents"})
+    compat.ensure_pca_module()
+    p = PCA(None).fit(torch.randn(300, 128, generator=torch.Generator().manual_seed(2)))
+    torch.save(p, str(tmp_path / "pca.pt"))
+    r2.set_pca(str(tmp_path / "pca.pt"))
+    assert torch.equal(r2._pca_dev[0], p.components_[:16]) and torch.equal(r2._pca_dev[1], p.mean_.reshape(-1))
+    r2.set_pca(None)
+    assert r2.pca is None and r2._pca_dev is None
+    with pytest.raises(ValueError, match="width"):
+        Resampler(**dict(cfg, output_dim=256), device="cpu").set_pca(str(tmp_path / "pca.pt"))
+
+
+def test_vae_param_shapes_match_the_diffusers_layout():
+    from oracle import vae_ref as V
+    from tokensgen_amd.vae import AutoencoderKLCogVideoX
+    for cfg in (dict(block_out_channels=(128, 256, 256, 512), layers_per_block=3, latent_channels=16),
+                dict(block_out_channels=(64, 128), layers_per_block=1, latent_channels=16)):
+        vae = AutoencoderKLCogVideoX(block_out_channels=cfg["block_out_channels"], layers_per_block=cfg["layers_per_block"], device="cpu")
+        assert vae.param_shapes() == {k: tuple(v.shape) for k, v in V.make_state_dict(cfg).items()}

@@ -48,6 +48,19 @@ def test_full_size_decode_properties(vae_full):
     vae.enable_tiling()
     assert torch.equal(d1[..., :200, :288], alone[..., :200, :288])
     assert d1.float().std() > 1e-3
+    # the tiles run on several HIP streams (vae.tile_streams); the result must not depend on how many
+    n = vae.tile_streams
+    vae.tile_streams = 1
+    d3 = vae.decode(z).sample
+    vae.tile_streams = n
+    assert torch.equal(d1, d3), "decode depends on the number of tile streams"
+    # ... nor on whether the tile programs are replayed from captured HIP graphs (d1 = eager first sight, d2 = capture + replay)
+    assert vae.use_graphs and any(k[0] for k in vae._graphs), "the second decode should have captured the tile graphs"
+    d4 = vae.decode(z).sample                                  # pure replay
+    vae.use_graphs = False
+    d5 = vae.decode(z).sample
+    vae.use_graphs = True
+    assert torch.equal(d4, d1) and torch.equal(d5, d1)
 
 
 @pytest.mark.timeout(900)
@@ -63,6 +76,11 @@ def test_full_size_encode_properties(vae_full):
     alone = vae.encode(x[..., :240, :360].contiguous()).latent_dist.parameters
     vae.enable_tiling()
     assert torch.equal(h1[..., :25, :36], alone[..., :25, :36])     # tile (0,0): 30 x 45 latent, kept 25 x 36
+    n = vae.tile_streams
+    vae.tile_streams = 1
+    h3 = vae.encode(x).latent_dist.parameters
+    vae.tile_streams = n
+    assert torch.equal(h1, h3), "encode depends on the number of tile streams"
     post = vae.encode(x).latent_dist
     assert post.mode().shape == (1, 16, 13, 60, 90) and torch.isfinite(post.sample(generator=torch.Generator(device=DEV).manual_seed(2))).all()
 

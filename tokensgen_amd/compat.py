@@ -15,6 +15,17 @@ import sys
 import types
 
 
+def ensure_pca_module():
+    """Register tokensgen_amd.pca as the top-level module `pca` unless one is importable already (the reference pickles `pca.PCA` objects whole:
+    resampler.py:207, pipeline_cogvideox_t2to.py:698,771)."""
+    if "pca" not in sys.modules:
+        try:
+            import pca  # noqa: F401  (the reference's own pca.py, when the entry script runs from its tree)
+        except ImportError:
+            from . import pca as _pca
+            sys.modules["pca"] = _pca
+
+
 def install_longvgen_alias(force=False):
     if "longvgen" in sys.modules and not force:
         raise RuntimeError("a `longvgen` package is already imported; refusing to shadow it (pass force=True to override)")

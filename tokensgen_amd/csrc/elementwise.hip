@@ -152,6 +152,43 @@ __global__ void pca_inverse_kernel(const bf16_t* __restrict__ lat, const float* 
     }
 }
 
+
+// Resampler's optional PCA low-rank filter (video_ipadapter/resampler.py:230-237 with pca.py:56-66): per token, in fp32 like the reference
+// (`latents.to(self.pca.components_.dtype)`):  y_j = sum_c (x_c - mean_c) comp[j][c]  (j < keep; the reference computes every component and
+// zeroes y[:, 16:]),  out_c = mean_c + sum_j y_j comp[j][c].  One workgroup per token row.
+__global__ __launch_bounds__(256) void pca_filter_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ comp,
+                                                         const float* __restrict__ mean, bf16_t* __restrict__ out, long ldo, int D, int keep) {
+    __shared__ float red[4][16];
+    __shared__ float sy[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bf16_t* xr = x + (long)blockIdx.x * ldx;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int c = tid; c < D; c += 256) {
+        const float v = bf16_to_f32(xr[c]) - mean[c];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < keep) acc[j] = fmaf(v, comp[(long)j * D + c], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float t = wave_sum(acc[j]);
+        if (lane == 0) red[wave][j] = t;
+    }
+    __syncthreads();
+    if (tid < 16) sy[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    __syncthreads();
+    bf16_t* orow = out + (long)blockIdx.x * ldo;
+    for (int c = tid; c < D; c += 256) {
+        float o = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < keep) o = fmaf(sy[j], comp[(long)j * D + c], o);
+        orow[c] = f32_to_bf16(o + mean[c]);
+    }
+}
+
 }  // namespace
 
 extern "C" int tg_timestep_sinusoid(const int64_t* t, int n, int dim, void* emb, hipStream_t stream) {
@@ -217,6 +254,16 @@ extern "C" int tg_pca_inverse(const void* lat, const float* std16, const float* 
     hipLaunchKernelGGL(pca_inverse_kernel<16>, dim3((unsigned)frames, (unsigned)((cout + 63) / 64)), dim3(256), (size_t)16 * hw * 4, stream,
                        (const bf16_t*)lat, std16, mean16, comp, pmean, (bf16_t*)out, hw, cout);
     TG_LAUNCH_CHECK("tg_pca_inverse");
+    return TG_OK;
+}
+
+extern "C" int tg_pca_lowrank_filter(const void* x, long ldx, const float* comp, const float* mean, void* out, long ldo, int rows, int D,
+                                     int keep, hipStream_t stream) {
+    TG_REQUIRE(x && comp && mean && out, TG_ERR_ARG, "tg_pca_lowrank_filter: null pointer");
+    TG_REQUIRE(rows > 0 && D > 0 && ldx >= D && ldo >= D, TG_ERR_SHAPE, "tg_pca_lowrank_filter: bad shape rows=%d D=%d", rows, D);
+    TG_REQUIRE(keep >= 1 && keep <= 16, TG_ERR_SHAPE, "tg_pca_lowrank_filter: keep=%d (the reference keeps 16 components)", keep);
+    hipLaunchKernelGGL(pca_filter_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const bf16_t*)x, ldx, comp, mean, (bf16_t*)out, ldo, D, keep);
+    TG_LAUNCH_CHECK("tg_pca_lowrank_filter");
     return TG_OK;
 }
 

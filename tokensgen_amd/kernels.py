@@ -339,6 +339,16 @@ def pca_inverse(lat, std, mean, comp, pmean, out):
     return out
 
 
+def pca_lowrank_filter(x, comp, mean, out=None):
+    """x bf16 [rows, D] (rows may be strided) -> bf16 [rows, D]: project onto the first comp.shape[0] (<= 16) PCA components and back, fp32."""
+    _chk(x, "x"); _chk(comp, "comp", torch.float32); _chk(mean, "mean", torch.float32)
+    assert x.dim() == 2 and comp.is_contiguous() and mean.is_contiguous() and comp.shape[1] == x.shape[1] and mean.numel() == x.shape[1]
+    out = torch.empty_like(x) if out is None else _chk(out, "out")
+    L.check(_launch("pca_lowrank_filter", L.load().tg_pca_lowrank_filter, _p(x), x.stride(0), _p(comp), _p(mean), _p(out), out.stride(0), x.shape[0],
+                    x.shape[1], comp.shape[0], _stream()), "tg_pca_lowrank_filter")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------
 # VAE (channels-last bf16 activations)
 # ---------------------------------------------------------------------------------------------------------

@@ -37,6 +37,7 @@ PROTOTYPES = {
     "tg_cfg_dpm_step": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _l, _vp],
     "tg_cfg_dpm_step_f32": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _l, _vp],
     "tg_pca_inverse": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "tg_pca_lowrank_filter": [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _vp],
     "tg_conv3d_cl": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp],
     "tg_groupnorm_finalize": [_vp, _l, _i, _f, _vp, _vp],
     "tg_groupnorm_stats": [_vp, _l, _i, _f, _vp, _vp, _vp],

@@ -5,6 +5,7 @@ are on the hot path: the 52-step base stage on chunk 0 that see
 `prompt_embeds` / `negative_prompt_embeds` / `image_embeddings` tensors (as the reference's own `image_embeddings is not
 None` branch does, :611-616); passing raw prompts or frames raises NotImplementedError.
 """
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -27,6 +28,33 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
         self.resampler = resampler if resampler is not None else SimpleNamespace(config=SimpleNamespace(**(resampler_config or dict(
             num_temporal_queries=4, num_height_queries=8, num_width_queries=12))))
         self._guidance_scale = 6.0
+
+    @classmethod
+    def from_pretrained(cls, path, transformer=None, resampler=None, torch_dtype=BF16, device="cuda", **unused):
+        """DiffusionPipeline.from_pretrained as the entry script calls it (infer_cogvideo_mp_fifo.py:122-127, 171-176): the transformer and the
+        resampler are handed in; the VAE comes from `<path>/vae`, the scheduler configuration from `<path>/scheduler/scheduler_config.json`.
+        The T5 tokenizer / text encoder are NOT loaded: prompt encoding stays on the reference side and `prompt_embeds`
+        are passed in."""
+        from .scheduler import CogVideoXDPMScheduler
+        from .transformer import CogVideoXTransformer3DModel
+        from .vae import AutoencoderKLCogVideoX
+        dev = transformer.device if transformer is not None else torch.device(device)
+        if transformer is None:
+            transformer = CogVideoXTransformer3DModel.from_pretrained(path, subfolder="transformer", torch_dtype=torch_dtype, device=dev)
+        vae = AutoencoderKLCogVideoX.from_pretrained(path, subfolder="vae", device=dev) if os.path.isdir(os.path.join(path, "vae")) else None
+        sched = CogVideoXDPMScheduler.from_config(os.path.join(path, "scheduler", "scheduler_config.json"))
+        return cls(transformer, sched, vae=vae, resampler=resampler, device=dev)
+
+    def to(self, device=None, *unused, **kw):
+        """`pipe.to(device)`: the modules already live on the device they were built on; a different device moves them."""
+        if device is not None and not isinstance(device, torch.dtype) and torch.device(device) != self.device:
+            self.device = torch.device(device)
+            self.transformer.to(self.device)
+            if self.vae is not None:
+                self.vae.to(self.device)
+            if self._resampler is not None:
+                self._resampler.to(self.device)
+        return self
 
     @property
     def guidance_scale(self):

@@ -7,6 +7,7 @@ DPM-solver++ loop with fp32 solver state (:845-870) and the de-normalise + PCA-i
 goes through libtokensgen_hip.so.  T5 prompt encoding is upstream of the path: pass prompt_embeds / negative_prompt_embeds.
 """
 import math
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -24,6 +25,8 @@ class CogVideoXPipelineOutput(SimpleNamespace):
 
 
 def _load(x):
+    from . import compat
+    compat.ensure_pca_module()
     return torch.load(x, weights_only=False) if isinstance(x, (str, bytes)) or hasattr(x, "read") else x
 
 
@@ -36,6 +39,22 @@ class LongVGenCogVideoXPipeline:
         self._num_timesteps = 0
         if transformer.use_vip:
             raise ValueError("the T2To model is a plain CogVideoX DiT: do not call set_vip_layers on it")
+
+    @classmethod
+    def from_pretrained(cls, path, transformer=None, torch_dtype=BF16, device="cuda", **unused):
+        """DiffusionPipeline.from_pretrained as the entry script calls it (infer_cogvideo_mp_fifo.py:225-229): the T2To transformer is handed
+        in, the scheduler configuration comes from `<path>/scheduler/scheduler_config.json`; T5 stays on the reference side."""
+        from .scheduler import CogVideoXDPMScheduler
+        from .transformer import CogVideoXTransformer3DModel
+        if transformer is None:
+            transformer = CogVideoXTransformer3DModel.from_pretrained(path, subfolder="transformer", torch_dtype=torch_dtype, device=device)
+        return cls(transformer, CogVideoXDPMScheduler.from_config(os.path.join(path, "scheduler", "scheduler_config.json")))
+
+    def to(self, device=None, *unused, **kw):
+        if device is not None and not isinstance(device, torch.dtype) and torch.device(device) != self.device:
+            self.device = torch.device(device)
+            self.transformer.to(self.device)
+        return self
 
     @property
     def guidance_scale(self):

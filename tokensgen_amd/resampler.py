@@ -6,8 +6,11 @@ Runs entirely on the DiT kernels: LayerNorm = tg_adaln_modulate (no modulation),
 residuals are the GEMM's gated-residual epilogue with a gate of ones), per-head QK-LayerNorm + the two RoPE tables in one
 tg_qk_layernorm_rope launch per operand, attention = tg_attention_fwd (16 heads x 64).  K/V of image tokens and of the
 queries live in one [b, Nx + Nq, 2*inner] buffer (the reference concatenates them, :100-101).
-The optional PCA low-rank filter (:230-237, `set_pca`) is not called on the To2V path and raises NotImplementedError."""
+The optional PCA low-rank filter (:201-207, 230-237; gen.yaml passes a real `longvgen_pca` path to `set_pca`, infer_cogvideo_mp_fifo.py:118,167)
+runs as one fp32 kernel per forward (tg_pca_lowrank_filter)."""
+import json
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -32,26 +35,100 @@ class Resampler:
         self.device = torch.device(device)
         self.dtype = BF16
         self.pca = None
+        self._pca_dev = None
         self._sd = {}
         self._ones = None
 
-    def set_pca(self, pca_path=None, device="cuda"):
-        if pca_path is not None:
-            raise NotImplementedError("the PCA filter (resampler.py:230-237) is only used by the T2To tooling, not by the To2V hot path")
-        self.pca = None
+    def set_pca(self, pca_path=None, device=None):
+        """resampler.py:201-207 — `self.pca = torch.load(pca_path).to(device)`: the file is a pickled `pca.PCA` module (pca.py:6-66; the class
+        is importable as `pca.PCA` through tokensgen_amd.compat / tokensgen_amd.pca).  Only its buffers are used: forward() projects every
+        token onto the first 16 components and back (:230-237)."""
+        if pca_path is None:
+            self.pca = None
+            self._pca_dev = None
+            return
+        from . import compat
+        compat.ensure_pca_module()
+        obj = torch.load(pca_path, map_location="cpu", weights_only=False) if isinstance(pca_path, (str, os.PathLike)) else pca_path
+        if not (hasattr(obj, "components_") and hasattr(obj, "mean_")):
+            raise ValueError(f"{pca_path}: expected a fitted pca.PCA (buffers mean_, components_)")
+        if obj.components_.shape[1] != self.config.output_dim:
+            raise ValueError(f"PCA width {obj.components_.shape[1]} != Resampler output_dim {self.config.output_dim}")
+        self.pca = obj
+        keep = min(16, obj.components_.shape[0])                       # `latents[:, 16:] = 0.0`
+        dev = self.device if device is None else torch.device(device)
+        self._pca_dev = (obj.components_[:keep].to(dev, torch.float32).contiguous(), obj.mean_.reshape(-1).to(dev, torch.float32).contiguous())
+        print(f"Successfully set pca: {pca_path}")
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=BF16, device="cuda", **unused):
+        """diffusers' ModelMixin.from_pretrained as the entry script uses it (infer_cogvideo_mp_fifo.py:113-117, 162-166):
+        <path>/<subfolder>/config.json + diffusion_pytorch_model.safetensors (or the sharded index)."""
+        from safetensors.torch import load_file
+        d = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(d, "config.json")) as f:
+            cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        m = cls(**cfg, device=device)
+        idx = os.path.join(d, "diffusion_pytorch_model.safetensors.index.json")
+        if os.path.exists(idx):
+            with open(idx) as f:
+                files = sorted(set(json.load(f)["weight_map"].values()))
+        else:
+            files = ["diffusion_pytorch_model.safetensors"]
+        sd = {}
+        for fn in files:
+            sd.update(load_file(os.path.join(d, fn)))
+        m.load_state_dict(sd)
+        return m
+
+    def save_pretrained(self, path):
+        """config.json + diffusion_pytorch_model.safetensors in diffusers' layout (what from_pretrained reads)."""
+        from safetensors.torch import save_file
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(dict(vars(self.config), _class_name="Resampler"), f, indent=1)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self._sd.items()}, os.path.join(path, "diffusion_pytorch_model.safetensors"))
+
+    def to(self, *args, **kwargs):
+        """`.to(device)` / `.to(dtype)` of the reference call sites; the arithmetic is bf16 on the GPU whatever dtype is asked for."""
+        dev = kwargs.get("device")
+        for a in args:
+            if isinstance(a, (str, torch.device)):
+                dev = a
+        if dev is not None and torch.device(dev) != self.device:
+            self.device = torch.device(dev)
+            self._sd = {k: v.to(self.device) for k, v in self._sd.items()}
+            self._ones = None
+            if self._pca_dev is not None:
+                self._pca_dev = tuple(t.to(self.device) for t in self._pca_dev)
+        return self
+
+    def expected_keys(self):
+        c = self.config
+        keys = ["latents", "proj_in.weight", "proj_in.bias", "proj_out.weight", "proj_out.bias", "norm_out.weight", "norm_out.bias"]
+        for i in range(c.depth):
+            keys += [f"layers.{i}.0.{n}.{wb}" for n in ("norm1", "norm2", "norm_q", "norm_k") for wb in ("weight", "bias")]
+            keys += [f"layers.{i}.0.{n}.weight" for n in ("to_q", "to_kv", "to_out")]
+            keys += [f"layers.{i}.1.net.0.proj.weight", f"layers.{i}.1.net.0.proj.bias", f"layers.{i}.1.net.2.weight", f"layers.{i}.1.net.2.bias"]
+        return keys
 
     def state_dict(self):
         return dict(self._sd)
 
     def load_state_dict(self, sd, strict=True):
+        want = self.expected_keys()
+        missing, unexpected = [k for k in want if k not in sd], [k for k in sd if k not in want]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Resampler.load_state_dict: missing {missing[:4]}, unexpected {unexpected[:4]}")
         self._sd = {k: v.detach().to(self.device, BF16).contiguous() for k, v in sd.items()}
-        return SimpleNamespace(missing_keys=[], unexpected_keys=[])
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
 
-    def _ones_gate(self, tokens, width):
+    def _ones_gate(self, tokens, width, batch=1):
         """Gate table of ones: turns the gated-residual GEMM epilogue into `y = residual + linear`."""
         if self._ones is None or self._ones[0].shape[-1] < width or self._ones[1].shape[0] < tokens:
             self._ones = (torch.ones(1, 1, width, dtype=BF16, device=self.device), torch.zeros(max(tokens, 1024), dtype=torch.uint8, device=self.device))
-        return K.GroupTable(self._ones[0], self._ones[1], [0], [0], [0], [0])
+        # expand: batch stride 0 — the GATE_RES epilogue reads mod + b * mod_batch_stride, every batch item must see the same ones
+        return K.GroupTable(self._ones[0].expand(max(batch, 1), 1, -1), self._ones[1], [0], [0], [0], [0])
 
     @torch.no_grad()
     def forward(self, x, image_rotary_emb=None, sampling_rotary_emb=None):
@@ -77,7 +154,7 @@ class Resampler:
         dev = lambda t: t.to(self.device, torch.float32).contiguous()
         img = None if image_rotary_emb is None else tuple(dev(t) for t in image_rotary_emb)
         smp = None if sampling_rotary_emb is None else tuple(dev(t) for t in sampling_rotary_emb)
-        ones = self._ones_gate(Nq, dim)
+        ones = self._ones_gate(Nq, dim, b)
         for i in range(c.depth):
             p = f"layers.{i}.0"
             K.adaln_modulate(xp, cat[:, :Nx], sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5, None)
@@ -97,6 +174,9 @@ class Resampler:
         K.gemm(lat, sd["proj_out.weight"], sd["proj_out.bias"], po, L.EPI_BIAS)
         out = e(b, Nq, c.output_dim)
         K.adaln_modulate(po, out, sd["norm_out.weight"], sd["norm_out.bias"], 1e-5, None)
+        if self._pca_dev is not None:                      # :230-237, fp32 like the reference (`.to(self.pca.components_.dtype)`)
+            comp, mean = self._pca_dev
+            K.pca_lowrank_filter(out.view(-1, c.output_dim), comp, mean, out.view(-1, c.output_dim))
         return out.reshape(b, self.num_temporal_queries, self.num_height_queries, self.num_width_queries, -1).permute(0, 1, 4, 2, 3)
 
     __call__ = forward

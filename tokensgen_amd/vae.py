@@ -9,6 +9,7 @@ GroupNorm|SpatialNorm+SiLU.  The reference's result-defining structure is kept e
 seam blending, temporal batches of 2 latent (8 sample) frames with the remainder folded into the first batch, GroupNorm
 statistics per (tile, temporal batch), causal cache carried across the batches of a tile and cleared per tile.
 """
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -61,6 +62,14 @@ class AutoencoderKLCogVideoX:
         self.tile_overlap_factor_height, self.tile_overlap_factor_width = 1 / 6, 1 / 5
         self._retile()
         self._sd, self._packed = {}, {}
+        self.tile_streams = int(os.environ.get("TG_VAE_STREAMS", "4"))     # concurrent spatial tiles (see _run_tiles)
+        self._streams = []
+        self._tmaps = {}
+        # HIP graphs: a tile program (all temporal batches of one spatial tile: ~950 launches) is captured the second time its shape is seen
+        # and replayed afterwards — the host then issues 9 graph launches per clip instead of ~8 500 kernel launches, which is what lets the
+        # tile streams actually overlap (the decode was bound by Python's launch rate, not by the GPU, once the tiles ran concurrently)
+        self.use_graphs = os.environ.get("TG_VAE_GRAPHS", "1") != "0"
+        self._graphs, self._seen = {}, {}
         self._tl = int(np.log2(temporal_compression_ratio))
 
     # ---- reference API -----------------------------------------------------------------------------------
@@ -100,6 +109,7 @@ class AutoencoderKLCogVideoX:
             raise RuntimeError(f"AutoencoderKLCogVideoX.load_state_dict: missing {missing[:4]}, unexpected {unexpected[:4]}, shape mismatch {bad[:4]}")
         self._sd = {k: v.detach().to(self.device, BF16).contiguous() for k, v in sd.items()}
         self._packed = {}
+        K.zero_page(self.device)          # created on the caller's stream before any tile stream can race for it
         for k, v in self._sd.items():
             if k.endswith(".weight") and v.dim() >= 4:
                 co, ci = v.shape[:2]
@@ -124,6 +134,41 @@ class AutoencoderKLCogVideoX:
                 self._packed[base + ".yb.weight"], self._packed[base + ".yb.bias"] = w, b
         return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
 
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=BF16, device="cuda", **unused):
+        """diffusers' ModelMixin.from_pretrained for `<CogVideoX-5b>/vae`: config.json + diffusion_pytorch_model.safetensors."""
+        import json
+        from safetensors.torch import load_file
+        d = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(d, "config.json")) as f:
+            cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        if "down_block_types" in cfg:          # diffusers lists block types; CogVideoX has exactly one kind of each
+            cfg.pop("down_block_types"), cfg.pop("up_block_types", None)
+        vae = cls(**cfg, device=device)
+        vae.load_state_dict(load_file(os.path.join(d, "diffusion_pytorch_model.safetensors")))
+        return vae
+
+    def save_pretrained(self, path):
+        import json
+        from safetensors.torch import save_file
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(dict({k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(self.config).items()}, _class_name="AutoencoderKLCogVideoX"), f, indent=1)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self._sd.items()}, os.path.join(path, "diffusion_pytorch_model.safetensors"))
+
+    def to(self, *args, **kwargs):
+        """`.to(device)` of the reference call sites (`pipe.to(device)`); bf16 on the GPU whatever dtype is asked for."""
+        dev = kwargs.get("device")
+        for a in args:
+            if isinstance(a, (str, torch.device)):
+                dev = a
+        if dev is not None and torch.device(dev) != self.device:
+            self.device = torch.device(dev)
+            if self._sd:
+                self.load_state_dict(self._sd)
+            self._streams, self._tmaps, self._graphs, self._seen = [], {}, {}, {}
+        return self
 
     def param_shapes(self):
         """name -> shape of every parameter of this configuration, under the diffusers key names (what load_state_dict expects)."""
@@ -242,7 +287,9 @@ class AutoencoderKLCogVideoX:
         if compress_time and T > 1:
             idx = [0] + [t for t in range(1, T) for _ in (0, 1)] if T % 2 == 1 else [t for t in range(T) for _ in (0, 1)]
             To = len(idx)
-            tmap = torch.tensor(idx, dtype=torch.int32, device=x.device)
+            tmap = self._tmaps.get(T)
+            if tmap is None:                      # cached: a host->device copy cannot sit inside a captured tile program
+                tmap = self._tmaps[T] = torch.tensor(idx, dtype=torch.int32, device=x.device)
         w = self._sd[name + ".conv.weight"]
         return K.conv3d_cl(x, self._packed[name + ".conv.weight"], self._sd[name + ".conv.bias"], w.shape[0], 1, 3, 3, stride=1, pad=1, up=2,
                            t_map=tmap, out_dims=(To, 2 * H, 2 * W), gn_stats_eps=self.config.norm_eps)
@@ -315,6 +362,66 @@ class AutoencoderKLCogVideoX:
             t0 += o.shape[0]
         return tile
 
+    def _run_tile_maybe_graph(self, src, i, j, th, tw, decode, slot):
+        """_run_tile, replayed from a captured HIP graph once the same (direction, dtype, tile shape, slot) has been seen before.
+        `slot` separates tiles that may be in flight at the same time (a graph owns its buffers).  The graph reads a private staging copy
+        of the tile's input window and returns its private output tile: the caller consumes it (blend, crop, cat) before the next replay
+        of that slot, which the stream order of _run_tiles / _process guarantees."""
+        if not self.use_graphs or K.PROFILE_ON[0]:
+            return self._run_tile(src, i, j, th, tw, decode)
+        C, Tt, Ht, Wt = src.shape
+        Hc, Wc = min(th, Ht - i), min(tw, Wt - j)
+        key = (decode, src.dtype, C, Tt, Hc, Wc, slot)
+        g = self._graphs.get(key)
+        if g is None:
+            if not self._seen.get(key):            # first sight: run eagerly (this is also the warm-up a capture needs)
+                self._seen[key] = True
+                return self._run_tile(src, i, j, th, tw, decode)
+            cur = torch.cuda.current_stream(self.device)
+            inp = torch.empty(C, Tt, Hc, Wc, dtype=src.dtype, device=self.device)
+            graph = torch.cuda.CUDAGraph()
+            cap = torch.cuda.Stream(device=self.device)
+            cap.wait_stream(cur)
+            with torch.cuda.graph(graph, stream=cap):
+                out = self._run_tile(inp, 0, 0, Hc, Wc, decode)
+            cur.wait_stream(cap)
+            g = self._graphs[key] = (graph, inp, out)
+        graph, inp, out = g
+        inp.copy_(src[:, :, i:i + Hc, j:j + Wc])
+        graph.replay()
+        return out
+
+    def _run_tiles(self, src, origins, th, tw, decode):
+        """The spatial tiles are independent until the blend (cache cleared per tile, :1240/:1321): they are dealt round-robin to
+        `tile_streams` HIP streams so that the small launches of one tile (the 512-channel layers have 88 workgroups on 256 CUs; the
+        statistics finalise launches and cache copies are a few microseconds) run beside another tile's large convolutions instead of
+        leaving most of the chip idle.  Each tile's arithmetic is unchanged, so the result does not depend on the stream count."""
+        n = max(1, int(self.tile_streams))
+        if n == 1:
+            flat = [ij for row in origins for ij in row]            # slot = tile index: every tile keeps its own graph buffers until the blend
+            outs = [self._run_tile_maybe_graph(src, i, j, th, tw, decode, k) for k, (i, j) in enumerate(flat)]
+            it = iter(outs)
+            return [[next(it) for _ in row] for row in origins]
+        main = torch.cuda.current_stream(self.device)
+        if len(self._streams) < n:
+            self._streams += [torch.cuda.Stream(device=self.device) for _ in range(n - len(self._streams))]
+        out, k = [], 0
+        # largest tiles first within the round-robin does not matter for correctness; keep the reference's row-major order
+        for row in origins:
+            orow = []
+            for (i, j) in row:
+                st = self._streams[k % n]
+                k += 1
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    t = self._run_tile_maybe_graph(src, i, j, th, tw, decode, k - 1)
+                t.record_stream(main)
+                orow.append(t)
+            out.append(orow)
+        for st in self._streams[:n]:
+            main.wait_stream(st)
+        return out
+
     def _process(self, src, decode):
         """_encode/_decode incl. tiled_encode/tiled_decode (:1085-1108, 1138-1163, 1206-1359) for one batch item [C,T,H,W]."""
         if decode:
@@ -325,11 +432,11 @@ class AutoencoderKLCogVideoX:
             tsh, tsw = self.tile_latent_min_height, self.tile_latent_min_width
         H, W = src.shape[2:]
         if not (self.use_tiling and (W > tw or H > th)):
-            return self._run_tile(src, 0, 0, H, W, decode)
+            return self._run_tile_maybe_graph(src, 0, 0, H, W, decode, 0).clone()      # a graph's output buffer is reused by its next replay
         st_h, st_w = int(th * (1 - self.tile_overlap_factor_height)), int(tw * (1 - self.tile_overlap_factor_width))
         bh, bw = int(tsh * self.tile_overlap_factor_height), int(tsw * self.tile_overlap_factor_width)
         lim_h, lim_w = tsh - bh, tsw - bw
-        rows = [[self._run_tile(src, i, j, th, tw, decode) for j in range(0, W, st_w)] for i in range(0, H, st_h)]
+        rows = self._run_tiles(src, [[(i, j) for j in range(0, W, st_w)] for i in range(0, H, st_h)], th, tw, decode)
         out_rows = []
         for i, row in enumerate(rows):
             out = []

@@ -24,7 +24,7 @@ for name in what:
     fn = (lambda: vae.decode(z).sample) if name == "decode" else (lambda: vae.encode(x).latent_dist.mode())
     out = fn(); torch.cuda.synchronize()
     dt = 1e9
-    for _ in range(2):        # wall time WITHOUT the per-launch profiling events (~8300 launches: the events alone cost ~80 ms)
+    for _ in range(4):        # (the 1st repeat captures the tile graphs) wall time WITHOUT the per-launch profiling events (~8300 launches: the events alone cost ~80 ms)
         t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize(); dt = min(dt, time.perf_counter() - t0)
     if PLAIN:
         print(json.dumps({"op": f"vae_{name}", "seconds": dt, "out_shape": list(out.shape)}))

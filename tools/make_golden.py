@@ -348,8 +348,26 @@ def gen_resampler():
     out = dict(cfg=cfg, weight_seed=700, input_seed=701, sd_checksum=sd_checksum(sd))
     out["fp32"] = m(x, image_rotary_emb=img, sampling_rotary_emb=smp).clone()
     out["bf16"] = m.to(torch.bfloat16)(x.bfloat16(), image_rotary_emb=img, sampling_rotary_emb=smp).clone()
+    # batch 2 (the gate-of-ones residual epilogue must be batch invariant) and the optional PCA low-rank filter (resampler.py:201-207,
+    # 230-237) exactly as gen.yaml sets it up: a pca.PCA fitted by the reference's own class, pickled whole, loaded by set_pca(path)
+    import tempfile
+    refpca = load_ref_module("pca.py", "pca")
+    sys.modules["pca"] = refpca
+    torch.serialization.add_safe_globals([refpca.PCA])
+    x2 = torch.randn(2, 13, 24, 128, generator=g)
+    pca = refpca.PCA(n_components=None).fit(torch.randn(800, 128, generator=g) * torch.linspace(2.0, 0.1, 128))
+    out["pca_mean"], out["pca_components"] = pca.mean_.clone(), pca.components_.clone()
+    for tag, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m2 = rs.Resampler(**cfg)
+        m2.load_state_dict(sd, strict=True)
+        m2 = m2.eval().to(dt)
+        out[tag + "_b2"] = m2(x2.to(dt), image_rotary_emb=img, sampling_rotary_emb=smp).clone()
+        with tempfile.TemporaryDirectory() as td:
+            torch.save(pca, os.path.join(td, "pca.pt"))
+            m2.set_pca(os.path.join(td, "pca.pt"), device="cpu")
+        out[tag + "_b2_pca"] = m2(x2.to(dt), image_rotary_emb=img, sampling_rotary_emb=smp).clone()
     torch.save(out, os.path.join(GOLD, "resampler_tiny.pt"))
-    print("resampler_tiny.pt", tuple(out["fp32"].shape))
+    print("resampler_tiny.pt", tuple(out["fp32"].shape), tuple(out["fp32_b2_pca"].shape))
 
 
 
