@@ -23,6 +23,19 @@ def pytest_configure(config):
         config.addinivalue_line("markers", "timeout(seconds): per-test limit (pytest-timeout)")
 
 
+class Measured(float):
+    """A measured parity figure: `assert measured(x) < tol` records (x, tol) under the running test in the parity report."""
+
+    def __lt__(self, tol):
+        node = os.environ.get("PYTEST_CURRENT_TEST", "?").rsplit(" (", 1)[0]
+        _PARITY.setdefault(node, []).append({"what": "", "measured": float(self), "tol": float(tol)})
+        return float(self) < float(tol)
+
+
+def measured(x):
+    return Measured(float(x))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 import torch
+from conftest import measured
 
 pytestmark = pytest.mark.gpu
 
@@ -13,7 +14,7 @@ DEV = "cuda"
 
 def _rel(a, b):
     a, b = a.float(), b.float()
-    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+    return measured(((a - b).norm() / (b.norm() + 1e-12)).item())     # `< tol` records (measured, tol) in the parity report
 
 
 def _rand(*shape, seed=0, scale=1.0):

@@ -138,7 +138,7 @@ def test_entry_script_loading_sequence(tmp_path):
                    generator=torch.Generator().manual_seed(42), longvgen_mean=args.longvgen_mean, longvgen_std=args.longvgen_std,
                    longvgen_pca=args.longvgen_pca).frames
     assert emb.shape == (1, 4, 128, 2, 3) and torch.isfinite(emb).all()
-    base_out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image_embeddings=emb, height=32, width=48, num_frames_per_chunk=49, num_chunks=1,
+    base_out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image_embeddings=emb, height=8, width=12, num_frames_per_chunk=49, num_chunks=1,
                     num_inference_steps=52, guidance_scale=6.0, video_ipadapter_scale=vip_params["scale"], output_type="latent")
     assert base_out.fifo_latents.shape == (1, 52, 16, 4, 6) and torch.isfinite(base_out.fifo_latents).all()
     _, video, _ = cogvideo_fifo_mp_v2([pipe], base_out)

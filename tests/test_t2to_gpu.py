@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 import torch
+from conftest import measured
 
 from oracle import dit_ref as O
 from oracle import scheduler_ref as S
@@ -18,7 +19,7 @@ BF = torch.bfloat16
 
 def _rel(a, b):
     a, b = a.float().cpu(), b.float().cpu()
-    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+    return measured(((a - b).norm() / (b.norm() + 1e-12)).item())     # `< tol` records (measured, tol) in the parity report
 
 
 def _gold(golden_dir):

@@ -8,6 +8,7 @@ tiled run must reproduce a stand-alone run of that tile bit for bit (same kernel
 Reference: autoencoder_kl_cogvideox.py:1085-1108 (_encode), :1138-1163 (_decode), :1206-1359 (tiled_*), :1028-1062 (enable_tiling)."""
 import pytest
 import torch
+from conftest import measured
 
 from oracle import vae_ref as V
 
@@ -19,7 +20,7 @@ FULL = dict(block_out_channels=(128, 256, 256, 512), layers_per_block=3, latent_
 
 def _rel(a, b):
     a, b = a.float().cpu(), b.float().cpu()
-    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+    return measured(((a - b).norm() / (b.norm() + 1e-12)).item())     # `< tol` records (measured, tol) in the parity report
 
 
 @pytest.fixture(scope="module")

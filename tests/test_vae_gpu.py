@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 import torch
+from conftest import measured
 import torch.nn.functional as F
 
 from oracle import vae_ref as V
@@ -16,7 +17,7 @@ BF = torch.bfloat16
 
 def _rel(a, b):
     a, b = a.float().cpu(), b.float().cpu()
-    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+    return measured(((a - b).norm() / (b.norm() + 1e-12)).item())     # `< tol` records (measured, tol) in the parity report
 
 
 def _r(*shape, seed=0, scale=1.0):
@@ -246,3 +247,34 @@ def test_conv_4wave_kernel_bitwise_equals_128_kernel(tmp_path):
                            capture_output=True, text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "vs mode 0" in r.stdout and "bitwise False" not in r.stdout
+
+
+def test_unvendored_classes_known_answers_on_the_kernels():
+    """a20 on the HIP path: the conv loader's folded nearest-x2 / frame map / stride-2 taps / implied (0,1,0,1) pad and the temporal
+    average pool against the hand-derived known answers of tests/kat_vae.py (T in {1,2,3,9}; exact: small integers), and the product's
+    DiagonalGaussianDistribution against its known answer."""
+    import kat_vae as Kv
+    from tokensgen_amd import kernels as K
+    from tokensgen_amd.vae import AutoencoderKLCogVideoX, DiagonalGaussianDistribution
+    vae = AutoencoderKLCogVideoX(block_out_channels=(64, 128), layers_per_block=1, device=DEV)     # host methods only (_upsample/_downsample)
+    ident = torch.zeros(64, 64, 3, 3); ident[0, 0, 1, 1] = 1.0          # channel 0 -> channel 0, centre tap; the 63 pad channels stay zero
+    ones = torch.zeros(64, 64, 3, 3); ones[0, 0] = 1.0
+    for name, w in (("u", ident), ("d", ones)):
+        vae._sd[name + ".conv.weight"] = w.to(DEV, BF)
+        vae._sd[name + ".conv.bias"] = torch.zeros(64, dtype=BF, device=DEV)
+        vae._packed[name + ".conv.weight"] = _pack(w.to(BF)).to(DEV)
+    for T in Kv.CASES_T:
+        x = Kv.video(T, 4, 6)
+        xc = torch.zeros(T, 4, 6, 64, dtype=BF, device=DEV)
+        xc[..., 0] = torch.from_numpy(x[0]).to(DEV, BF)
+        for ct in (True, False):
+            up = vae._upsample("u", xc, ct)
+            assert np.array_equal(up[..., 0].float().cpu().numpy(), Kv.upsample_expected(x, ct)[0]), (T, ct)
+            assert (up[..., 1:] == 0).all()
+            dn = vae._downsample("d", xc, ct)
+            assert np.array_equal(dn[..., 0].float().cpu().numpy(), Kv.downsample_expected(x, ct)[0]), (T, ct)
+    G = Kv.GAUSS
+    h = torch.tensor(G["mean"] + G["logvar"], device=DEV).view(1, 8, 1, 1, 1)
+    d = DiagonalGaussianDistribution(h)
+    assert torch.allclose((d.mean + d.std * torch.tensor(G["noise"], device=DEV).view(1, 4, 1, 1, 1)).flatten().cpu(), torch.tensor(G["sample"]), rtol=1e-6)
+    assert torch.equal(d.mode().flatten().cpu(), torch.tensor(G["mean"]))

@@ -70,10 +70,18 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
         return latents.to(self.device, BF16) * self.scheduler.init_noise_sigma
 
     def _prepare_rotary_positional_embeddings(self, height, width, num_frames, device=None):
-        """:769-795 (720x480 base size: the crop region is the full grid)."""
+        """:769-795 with the crop region of `get_resize_crop_region_for_grid` (:81-96) against the 720x480 base grid: the full grid at
+        720x480 (and at every size of the same 3:2 shape the positions are the base grid's, resampled)."""
         p = self.transformer.config.patch_size
-        gh, gw = height // (self.vae_scale_factor_spatial * p), width // (self.vae_scale_factor_spatial * p)
-        return R.rope_3d_crop(self.transformer.config.attention_head_dim, (0, 0, 0), (num_frames, gh, gw), (num_frames, gh, gw))
+        f = self.vae_scale_factor_spatial * p
+        gh, gw = height // f, width // f
+        tw, th = 720 // f, 480 // f
+        if gh / gw > th / tw:
+            rh, rw = th, int(round(th / gh * gw))
+        else:
+            rw, rh = tw, int(round(tw / gw * gh))
+        top, left = int(round((th - rh) / 2.0)), int(round((tw - rw) / 2.0))
+        return R.rope_3d_crop(self.transformer.config.attention_head_dim, (0, top, left), (num_frames, top + rh, left + rw), (num_frames, gh, gw))
 
     def _prepare_vip_rotary_positional_embeddings(self, grid_t, grid_h, grid_w, device=None):
         """:797-813"""

@@ -459,7 +459,10 @@ class CogVideoXTransformer3DModel(nn.Module):
         # QKV projections (+ vip-weight projections over ALL tokens: x rows and vip rows share vip_to_*)
         paired = use_vip and N1 >= 1024 and (3 * D) % 256 == 0       # both projections in one launch of the 256^2 kernel
         # ... with V written transposed by the GEMM epilogue (no transpose_v pass; the V columns of QKV / QKVv are then never written)
-        fused_vt = K.gemm_qkv_supported(N1, 3 * D, D, 2 * D) and (not use_vip or N1 % 8 == 0)
+        pad64 = lambda n: (n + 63) // 64 * 64
+        # the vip keys' V^T can be read as the tail columns of the all-keys image only if pad64(Np) keys from column N1 stay inside a row
+        vt2_view_ok = N1 % 8 == 0 and N1 + pad64(Np) <= pad64(N)
+        fused_vt = K.gemm_qkv_supported(N1, 3 * D, D, 2 * D) and (not use_vip or vt2_view_ok)
         qn = F[p + "qknorm"]
         kscale = sm_scale * 1.4426950408889634       # softmax scale * log2(e) folded into K before its single bf16 rounding
         if fused_vt and use_vip:
@@ -481,12 +484,21 @@ class CogVideoXTransformer3DModel(nn.Module):
                                      (N1, crope), k_scale=kscale)
             if not fused_vt:
                 K.transpose_v(ws.QKVv[:, :, 2 * D:], H, 0, N, ws.Vt3)
-            if N1 % 8 == 0:
-                vt2 = ws.Vt3[:, :, :, N1:]     # V^T of the vip keys = the tail columns of the all-keys image (16-B aligned start;
-            else:                              # its zero padding out to a multiple of 64 keys is the image's own)
+            if vt2_view_ok and N1 + pad64(Np) <= ws.Vt3.shape[3]:
+                # V^T of the vip keys = the tail columns of the all-keys image (16-B aligned start; its zero padding out to a multiple of
+                # 64 keys is the image's own).  The kernel reads pad64(Np) keys from that offset: only when they stay inside the row
+                # (not e.g. N1 % 64 = 8, Np % 64 = 8, where N1 + pad64(Np) > pad64(N) runs into the next d-row / past the allocation)
+                vt2 = ws.Vt3[:, :, :, N1:]
+            else:
                 vt2 = K.transpose_v(ws.QKVv[:, :, 2 * D:], H, N1, Np, ws.Vt2)
             s = blk.attn1.processor.scale
-            s = float(s[0] if isinstance(s, (list, tuple)) else s)
+            if isinstance(s, (list, tuple)):
+                # the reference applies a per-batch-element scale when len(scale) == batch (attention_processor.py:2126-2131); the shipped
+                # configs pass one value ([0.6] / [1.0]) and the fused launch takes one
+                if len(set(float(v) for v in s)) != 1:
+                    raise NotImplementedError(f"per-batch-element vip scale {s}: the fused attention launch takes one scale for the batch")
+                s = s[0]
+            s = float(s)
             # text+video rows: softmax(q k^T) v  +  s * softmax(qx kv^T) vv   (attention_processor.py:2066-2069,2117-2134)
             # vip rows: qv against cat(kx, kv) / cat(vx, vv)                  (:2120-2125) — rides in the main launch's last round
             K.attention_multi(dict(q1=ws.QKV[:, :, :D], k1=ws.QKV[:, :, D:2 * D], vt1=ws.Vt1, nk1=N1, out=ws.AO[:, :N1],

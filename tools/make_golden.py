@@ -451,13 +451,162 @@ def gen_t2to():
     print("t2to_tiny.pt", tuple(results[str(torch.float32)]["frames"].shape), len(results[str(torch.float32)]["step_draws"]), "draws")
 
 
+@torch.no_grad()
+def gen_base_stage():
+    """the reference's OWN `MPFIFOVideoIPAdapterCogVideoXPipeline.__call__` (pipeline_cogvideox_mp_fifo.py:837-1344, the
+    52-step base stage that seeds the FIFO queue, :1186-1307) run on CPU with the tiny To2V DiT.  Only the constructor is bypassed
+    (DiffusionPipeline.register_modules / T5 / VAE weights): `vae.encode` and the Resampler are touched solely by the zero-video "uncond"
+    branch of vae_encode_image (:618-646), whose result the reference discards unless use_separate_guidance — they are stubs returning
+    zeros of the right shape.  Every gaussian (initial latents + per-step SDE draws) is recorded in draw order.  Stored: inputs, draws,
+    fifo_latents, fifo_old_pred_original_sample, orig_latents, the position grids and the RoPE table the pipeline built."""
+    import contextlib
+    ref = load_ref_module("longvgen/pipeline/pipeline_cogvideox_mp_fifo.py", "ref_pipe_mp_fifo")
+    H, W, nf, T, chunks = 4, 6, 13, 52, 2
+    rq = types.SimpleNamespace(num_temporal_queries=4, num_height_queries=2, num_width_queries=3, max_temporal_seq_len=13, max_height_seq_len=2,
+                               max_width_seq_len=3)
+
+    class _Resampler:
+        config = rq
+
+        def __call__(self, x, image_rotary_emb=None, sampling_rotary_emb=None):
+            return torch.zeros(x.shape[0], 4, 128, 2, 3, dtype=x.dtype)
+
+    class _Vae:
+        config = types.SimpleNamespace(scaling_factor=1.15258426)
+
+        def __init__(self, dt):
+            self.p = torch.nn.Parameter(torch.zeros(1, dtype=dt))
+
+        def parameters(self):
+            return iter([self.p])
+
+        def encode(self, video):
+            z = torch.zeros(video.shape[0], 16, (video.shape[2] - 1) // 4 + 1, H, W, dtype=video.dtype)
+            return types.SimpleNamespace(latent_dist=types.SimpleNamespace(sample=lambda: z))
+
+    class Pipe(ref.MPFIFOVideoIPAdapterCogVideoXPipeline):
+        def __init__(self, transformer, scheduler, dt):
+            self.transformer, self.scheduler = transformer, scheduler
+            self.resampler, self.image_encoder, self.vae = _Resampler(), None, _Vae(dt)
+            self.vae_scale_factor_spatial, self.vae_scale_factor_temporal, self.vae_scaling_factor_image = 8, 4, 1.15258426
+        _execution_device = property(lambda self: torch.device("cpu"))
+
+        @contextlib.contextmanager
+        def progress_bar(self, total=None):
+            yield types.SimpleNamespace(update=lambda *a: None, set_description=lambda *a: None)
+
+        def maybe_free_model_hooks(self):
+            pass
+
+    cases = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m, sd = tiny_model(900)
+        m = m.to(dt)
+        sched = make_sched()
+        g = torch.Generator().manual_seed(901)
+        prompt = torch.randn(1, 8, TINY["text_embed_dim"], generator=g).to(dt)
+        negative = torch.randn(1, 8, TINY["text_embed_dim"], generator=g).to(dt)
+        emb = torch.randn(1, 4 * chunks, 128, 2, 3, generator=g).to(dt)               # what the T2To stage / Resampler hands over (:611-616)
+        draws = []
+        sched_mod = sys.modules[CogVideoXDPMScheduler.__module__]
+        real_pipe_randn, real_sched_randn = ref.randn_tensor, sched_mod.randn_tensor
+
+        def spy(shape, generator=None, device=None, dtype=None, layout=None):
+            t = real_sched_randn(shape, generator=generator, device=device, dtype=dtype)
+            draws.append(t.clone())
+            return t
+        ref.randn_tensor = sched_mod.randn_tensor = spy
+        try:
+            out = Pipe(m, sched, dt)(prompt_embeds=prompt, negative_prompt_embeds=negative, image_embeddings=emb, height=8 * H, width=8 * W,
+                                     num_frames_per_chunk=49, max_num_chunks=chunks, max_num_chunks_wo_fifo=1, num_inference_steps=T,
+                                     guidance_scale=6.0, use_dynamic_cfg=False, generator=torch.Generator().manual_seed(902), vip_scale=[0.6],
+                                     sampling_mode="fifo", sampling_params=dict(use_adaptive_padding=True, num_partitions=4), output_type="latent",
+                                     video_ipadapter_start_frame_idx=1000)
+        finally:
+            ref.randn_tensor, sched_mod.randn_tensor = real_pipe_randn, real_sched_randn
+        assert out.fifo_latents.shape == (1, T, 16, H, W) and out.nf_per_chunk == nf and out.num_frames == chunks * nf
+        cases[str(dt)] = dict(prompt=prompt, negative=negative, emb_in=emb, init_latents=draws[0], step_draws=draws[1:],
+                              fifo_latents=out.fifo_latents.clone(), fifo_old=[None if o is None else o.clone() for o in out.fifo_old_pred_original_sample],
+                              orig_latents=out.orig_latents.clone(), image_embeddings=out.image_embeddings.clone(), prompt_embeds=out.prompt_embeds.clone())
+        if dt == torch.float32:
+            common = dict(timesteps=out.timesteps.clone(), image_rotary_emb=tuple(t.clone() for t in out.image_rotary_emb),
+                          vip_image_rotary_grid=[np.asarray(a).copy() for a in out.vip_image_rotary_grid],
+                          vip_condition_rotary_grid=[np.asarray(a).copy() for a in out.vip_condition_rotary_grid],
+                          vip_nf_per_chunk=out.vip_nf_per_chunk, sd_checksum=sd_checksum(sd))
+    torch.save(dict(weight_seed=900, input_seed=901, gen_seed=902, H=H, W=W, chunks=chunks, steps=T, guidance_scale=6.0, vip_scale=[0.6],
+                    **common, cases=cases), os.path.join(GOLD, "base_stage_tiny.pt"))
+    c = cases[str(torch.float32)]
+    print("base_stage_tiny.pt", tuple(c["fifo_latents"].shape), len(c["step_draws"]), "step draws", tuple(c["image_embeddings"].shape))
+
+
+@torch.no_grad()
+def gen_vae_geometry():
+    """the tile / temporal-batch geometry of the reference VAE object AT 480 x 720 x 49 (13 x 60 x 90 latent), read from the
+    reference's own loops instead of typed in: the vendored AutoencoderKLCogVideoX is built at sample 480 x 720 with 4 (narrow) blocks, tiling
+    enabled (autoencoder_kl_cogvideox.py:1028-1062), and its `encoder` / `decoder` are replaced by recorders that log the exact slice
+    tiled_encode (:1225-1259) / tiled_decode (:1303-1336) hands them and return zeros of the right output shape; blend_v / blend_h are
+    wrapped to log the extents.  Stored: attributes, per-call slices (frame range, tile shape, in order), blend extents, output shapes."""
+    rv = load_ref_module("longvgen/models/autoencoder_kl_cogvideox.py", "ref_vae_geom")
+    vae = rv.AutoencoderKLCogVideoX(in_channels=3, out_channels=3, block_out_channels=(32, 32, 32, 32), latent_channels=16, layers_per_block=1,
+                                    sample_height=480, sample_width=720, temporal_compression_ratio=4)
+    vae.eval()
+    vae.enable_tiling()
+    attrs = {k: getattr(vae, k) for k in ("tile_sample_min_height", "tile_sample_min_width", "tile_latent_min_height", "tile_latent_min_width",
+                                          "tile_overlap_factor_height", "tile_overlap_factor_width", "num_latent_frames_batch_size",
+                                          "num_sample_frames_batch_size")}
+    log = {"encode": [], "decode": [], "blend_v": [], "blend_h": []}
+
+    class Enc(torch.nn.Module):
+        def forward(self, x):
+            b, c, t, h, w = x.shape
+            log["encode"].append((t, h, w))
+            return torch.zeros(b, 32, (t - 1) // 4 + 1 if t % 2 else t // 4, h // 8, w // 8)
+
+    class Dec(torch.nn.Module):
+        def forward(self, z):
+            b, c, t, h, w = z.shape
+            log["decode"].append((t, h, w))
+            return torch.zeros(b, 3, 4 * (t - 1) + 1 if t % 2 else 4 * t, 8 * h, 8 * w)
+    vae.encoder, vae.decoder = Enc(), Dec()
+    bv, bh = vae.blend_v, vae.blend_h
+    vae.blend_v = lambda a, b, e: (log["blend_v"].append((e, tuple(a.shape[-2:]), tuple(b.shape[-2:]))), bv(a, b, e))[1]
+    vae.blend_h = lambda a, b, e: (log["blend_h"].append((e, tuple(a.shape[-2:]), tuple(b.shape[-2:]))), bh(a, b, e))[1]
+    # frame ranges: mark every frame with its index so the recorder's slices can be mapped back
+    x = torch.zeros(1, 3, 49, 480, 720)
+    z = torch.zeros(1, 16, 13, 60, 90)
+    enc = vae.tiled_encode(x)
+    dec = vae.tiled_decode(z).sample
+    out = dict(attrs=attrs, encode_calls=list(log["encode"]), decode_calls=list(log["decode"]), blend_v=list(log["blend_v"]), blend_h=list(log["blend_h"]),
+               encode_out=tuple(enc.shape), decode_out=tuple(dec.shape))
+    # the temporal batch boundaries themselves: re-run with a recorder that sees WHICH frames arrive (frame index written into the data)
+    fr = {"encode": [], "decode": []}
+    x = torch.arange(49, dtype=torch.float32).view(1, 1, 49, 1, 1).expand(1, 3, 49, 480, 720)
+    z = torch.arange(13, dtype=torch.float32).view(1, 1, 13, 1, 1).expand(1, 16, 13, 60, 90)
+
+    class Enc2(Enc):
+        def forward(self, x):
+            fr["encode"].append((int(x[0, 0, 0, 0, 0]), int(x[0, 0, -1, 0, 0]) + 1))
+            return super().forward(x)
+
+    class Dec2(Dec):
+        def forward(self, z):
+            fr["decode"].append((int(z[0, 0, 0, 0, 0]), int(z[0, 0, -1, 0, 0]) + 1))
+            return super().forward(z)
+    log["encode"], log["decode"] = [], []
+    vae.encoder, vae.decoder = Enc2(), Dec2()
+    vae.tiled_encode(x); vae.tiled_decode(z)
+    out["encode_frames"], out["decode_frames"] = fr["encode"], fr["decode"]
+    torch.save(out, os.path.join(GOLD, "vae_geometry_480x720.pt"))
+    print("vae_geometry_480x720.pt", attrs, len(out["encode_calls"]), len(out["decode_calls"]), out["encode_out"], out["decode_out"])
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full-block", action="store_true")
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    jobs = dict(dit=gen_dit_tiny, vip=gen_vip_processor, sched=gen_scheduler, fifo=gen_fifo, vae=gen_vae, resampler=gen_resampler, t2to=gen_t2to)
+    jobs = dict(dit=gen_dit_tiny, vip=gen_vip_processor, sched=gen_scheduler, fifo=gen_fifo, vae=gen_vae, resampler=gen_resampler, t2to=gen_t2to, base=gen_base_stage, vae_geom=gen_vae_geometry)
     if a.only:
         jobs = {a.only: jobs.get(a.only, gen_full_block)}
     for k, fn in jobs.items():
