@@ -61,7 +61,7 @@ def test_dit_tiny_vs_reference_golden(golden_dir):
               vip_image_rotary_emb=vrope, vip_condition_rotary_emb=crope, return_dict=False)[0]
         assert y.shape == c["out"].shape and torch.isfinite(y).all()
         r = _rel(y, c["out"])
-        assert r < 3e-2, f"ts{tuple(c['ts'].shape)} rel-L2 {r}"
+        assert r < 8.5e-3, f"ts{tuple(c['ts'].shape)} rel-L2 {r}"       # SURVEY 8c end-to-end bound 3e-2; measured 4.0-4.2e-3 (profiles/r2b_parity_report.json)
         # and against the fp32 reference run of the same case (bf16 drift bound, SURVEY §8c: 5e-2)
         n += 1
     assert n == 4
@@ -77,7 +77,7 @@ def test_dit_tiny_plain_processor(golden_dir):
     inp = _tiny_inputs(p["input_seed"])
     y = m(inp["hs"].to(DEV, torch.bfloat16), inp["enc"].to(DEV, torch.bfloat16), inp["ts"][:, 0].to(DEV),
           image_rotary_emb=_tiny_ropes()[0], return_dict=False)[0]
-    assert _rel(y, p["out"]) < 3e-2      # golden is the fp32 reference run
+    assert _rel(y, p["out"]) < 1.1e-2      # golden is the fp32 reference run; measured 5.7e-3
 
 
 @pytest.mark.parametrize("nvid_hw,heads,layers", [((6, 10), 4, 3)])
@@ -101,7 +101,7 @@ def test_dit_medium_vs_oracle(nvid_hw, heads, layers):
     ref = O.dit_forward(sdb, cfg, hs.bfloat16(), enc.bfloat16(), ts, vip.bfloat16(), rope, vrope, crope, vip_scale=[0.6], taps=taps)
     y = m(hs.to(DEV, torch.bfloat16), enc.to(DEV, torch.bfloat16), ts.to(DEV), vip_encoder_hidden_states=vip.to(DEV, torch.bfloat16),
           image_rotary_emb=rope, vip_image_rotary_emb=vrope, vip_condition_rotary_emb=crope, return_dict=False)[0]
-    assert _rel(y, ref) < 3e-2
+    assert _rel(y, ref) < 8.5e-3           # measured 4.2e-3
 
 
 @pytest.mark.timeout(900)
@@ -133,8 +133,8 @@ def test_dit_42_layers_depth_drift_vs_oracle(parity):
     assert torch.isfinite(y).all()
     floor = float(_rel(ref16, ref32))
     parity(floor, 1.0, "reference-arithmetic noise floor at 42 layers: bf16 oracle vs fp32 oracle (informative)")
-    parity(_rel(y, ref32), 5e-2, "42-layer DiT, HIP bf16 vs fp32 oracle (SURVEY 8c: 5e-2)")
-    parity(_rel(y, ref16), 3e-2, "42-layer DiT, HIP bf16 vs bf16 oracle (SURVEY 8c: 3e-2)")
+    parity(_rel(y, ref32), 2.2e-2, "42-layer DiT, HIP bf16 vs fp32 oracle (SURVEY 8c bound 5e-2; measured 1.10e-2 = the floor)")
+    parity(_rel(y, ref16), 1e-2, "42-layer DiT, HIP bf16 vs bf16 oracle (SURVEY 8c bound 3e-2; measured 4.8e-3)")
 
 
 def test_full_width_block_vs_reference_samples(golden_dir):
@@ -147,7 +147,7 @@ def test_full_width_block_vs_reference_samples(golden_dir):
     chk = float(sum(v.double().abs().sum() for k, v in sd.items() if k.startswith("transformer_blocks.0.")))
     assert chk == g["sd_checksum"], "weight RNG drifted from the fixture generator"
     oh, oe = block_runner.run_full_width_block(sd, g["input_seed"], DEV)
-    for key, tol in (("torch.bfloat16", 1.5e-2), ("torch.float32", 1.5e-2)):
+    for key, tol in (("torch.bfloat16", 1e-2), ("torch.float32", 1e-2)):      # SURVEY 8c per-block bound; measured 5.2-5.6e-3
         r = g[key]
         hs = oh.flatten()[g["idx_h"].to(DEV)].float().cpu()
         es = oe.flatten()[g["idx_e"].to(DEV)].float().cpu()
@@ -174,15 +174,15 @@ def test_resampler_vs_reference_golden(golden_dir, tmp_path, parity):
                     np.linspace(0, 6, 3, endpoint=False, dtype=f32))
     y = m(x.to(DEV, torch.bfloat16), image_rotary_emb=img, sampling_rotary_emb=smp)
     assert y.shape == g["bf16"].shape
-    assert _rel(y, g["bf16"]) < 2e-2 and _rel(y, g["fp32"]) < 2e-2
+    assert _rel(y, g["bf16"]) < 1e-2 and _rel(y, g["fp32"]) < 1e-2          # measured 3.9e-3 / 4.7e-3
     y2 = m(x.to(DEV, torch.bfloat16), image_rotary_emb=img, sampling_rotary_emb=smp)      # the learned queries must not be updated in place
     assert torch.equal(y, y2) and torch.equal(m.state_dict()["latents"].cpu(), sd["latents"].to(torch.bfloat16))
     # batch 2 (the gate-of-ones table must be batch invariant) and the PCA low-rank filter set up like gen.yaml does:
     # a pickled pca.PCA loaded by set_pca(path) (resampler.py:201-207, 230-237) — vs the reference Resampler's own outputs
     x2 = torch.randn(2, 13, 24, 128, generator=gen)
     y = m(x2.to(DEV, torch.bfloat16), image_rotary_emb=img, sampling_rotary_emb=smp)
-    parity(_rel(y, g["bf16_b2"]), 2e-2, "Resampler b=2 vs reference bf16")
-    parity(_rel(y[1], g["fp32_b2"][1]), 2e-2, "Resampler b=2, second batch item vs reference fp32")
+    parity(_rel(y, g["bf16_b2"]), 1e-2, "Resampler b=2 vs reference bf16")
+    parity(_rel(y[1], g["fp32_b2"][1]), 1e-2, "Resampler b=2, second batch item vs reference fp32")
     from tokensgen_amd import compat
     from tokensgen_amd.pca import PCA
     compat.ensure_pca_module()
@@ -193,8 +193,8 @@ def test_resampler_vs_reference_golden(golden_dir, tmp_path, parity):
     torch.save(pc, path)
     m.set_pca(path)
     y = m(x2.to(DEV, torch.bfloat16), image_rotary_emb=img, sampling_rotary_emb=smp)
-    parity(_rel(y, g["bf16_b2_pca"]), 2e-2, "Resampler b=2 + PCA filter vs reference bf16")
-    parity(_rel(y, g["fp32_b2_pca"]), 2e-2, "Resampler b=2 + PCA filter vs reference fp32")
+    parity(_rel(y, g["bf16_b2_pca"]), 1e-2, "Resampler b=2 + PCA filter vs reference bf16")
+    parity(_rel(y, g["fp32_b2_pca"]), 1.1e-2, "Resampler b=2 + PCA filter vs reference fp32")
     # the filter kernel alone against the fp32 formula on the same bf16 input
     from tokensgen_amd import kernels as K
     xin = torch.randn(37, 128, generator=gen).to(torch.bfloat16)
@@ -224,7 +224,7 @@ def test_processor_operator_seam_vs_reference_processor(golden_dir):
     oh, oe = attn(bf(g["hid"]), encoder_hidden_states=bf(g["enc"]), image_rotary_emb=g["rope"], vip_image_rotary_emb=g["vrope"],
                   vip_condition_rotary_emb=g["crope"], some_unrelated_kwarg=1)
     assert oh.shape == g["out_hidden"].shape and oe.shape == g["out_enc"].shape
-    assert _rel(oh, g["out_hidden"]) < 2e-2 and _rel(oe, g["out_enc"]) < 2e-2
+    assert _rel(oh, g["out_hidden"]) < 7e-3 and _rel(oe, g["out_enc"]) < 7e-3      # measured 3.0e-3 / 3.4e-3
     with pytest.raises(NotImplementedError):
         attn(bf(g["hid"]), encoder_hidden_states=bf(g["enc"]), attention_mask=torch.ones(1), image_rotary_emb=g["rope"],
              vip_image_rotary_emb=g["vrope"], vip_condition_rotary_emb=g["crope"])

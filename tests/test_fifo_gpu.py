@@ -69,7 +69,7 @@ def test_fifo_queue_evolution_vs_oracle(golden_dir):
     assert trace == ref_trace and len(trace) == 274
     assert out.shape == ref.shape == (1, num_frames, 16, H, W) and torch.isfinite(out).all()
     rel = measured(((out.float().cpu() - ref.float()).norm() / ref.float().norm()).item())
-    assert rel < 0.1, rel
+    assert rel < 1.5e-2, rel          # 274 window steps of a stochastic bf16 solver, identical keyed noise; measured 6.5e-3
 
 
 @pytest.mark.timeout(900)
@@ -105,7 +105,7 @@ def test_base_stage_seeds_fifo_like_reference(golden_dir):
                latents=lat0, step_noise=lambda i: _noise(i, 5, (nf, 2, 16, H, W)))
     assert out.fifo_latents.shape == ref_lat.shape == (1, T, 16, H, W)
     rel = lambda a, b: measured(((a.float().cpu() - b.float()).norm() / b.float().norm()).item())
-    assert rel(out.fifo_latents, ref_lat) < 0.1 and rel(out.orig_latents, ref_final) < 0.1
+    assert rel(out.fifo_latents, ref_lat) < 2e-2 and rel(out.orig_latents, ref_final) < 2e-2      # measured 4.3e-3 / 8.5e-3
     assert [o is None for o in out.fifo_old_pred_original_sample] == [o is None for o in ref_old]
     assert np.array_equal(out.vip_condition_rotary_grid[0], g["cond_t"][:8]) and np.array_equal(out.vip_image_rotary_grid[0], g["grid_t"][:13])
     with pytest.raises(NotImplementedError):
@@ -116,7 +116,7 @@ def test_base_stage_seeds_fifo_like_reference(golden_dir):
 def test_base_stage_vs_reference_pipeline_golden(golden_dir, parity):
     """SURVEY §8c G11 on the HIP path: the product's base stage (tokensgen_amd.pipeline.__call__) against the reference's OWN pipeline run
     stored in tests/golden/base_stage_tiny.pt (bf16 case), with the reference's gaussian draws replayed in order: FIFO seed latents, the
-    None pattern of the x0 list, final chunk-0 latents, position grids and token padding.  52 stochastic bf16 steps: rel-L2 <= 0.1."""
+    None pattern of the x0 list, final chunk-0 latents, position grids and token padding.  52 stochastic bf16 steps: rel-L2 <= 2e-2 (measured 4.5e-3 / 8.3e-3 / 7.7e-3)."""
     from tokensgen_amd.pipeline import MPFIFOVideoIPAdapterCogVideoXPipeline
     from tokensgen_amd.scheduler import CogVideoXDPMScheduler
     from tokensgen_amd.transformer import CogVideoXTransformer3DModel
@@ -147,8 +147,8 @@ def test_base_stage_vs_reference_pipeline_golden(golden_dir, parity):
     assert [int(t) for t in out.timesteps] == [int(t) for t in g["timesteps"]] and out.num_frames == g["chunks"] * nf
     assert [o is None for o in out.fifo_old_pred_original_sample] == [o is None for o in c["fifo_old"]]
     rel = lambda a, b: ((a.float().cpu() - b.float()).norm() / b.float().norm()).item()
-    parity(rel(out.fifo_latents, c["fifo_latents"]), 0.1, "base stage FIFO seed latents vs reference pipeline run (bf16, 52 SDE steps)")
-    parity(rel(out.orig_latents, c["orig_latents"]), 0.1, "base stage final latents vs reference pipeline run")
+    parity(rel(out.fifo_latents, c["fifo_latents"]), 2e-2, "base stage FIFO seed latents vs reference pipeline run (bf16, 52 SDE steps)")
+    parity(rel(out.orig_latents, c["orig_latents"]), 2e-2, "base stage final latents vs reference pipeline run")
     x0 = torch.cat([o for o in out.fifo_old_pred_original_sample if o is not None], dim=1)
     x0r = torch.cat([o for o in c["fifo_old"] if o is not None], dim=1)
-    parity(rel(x0, x0r), 0.1, "base stage x0 seed list vs reference pipeline run")
+    parity(rel(x0, x0r), 2e-2, "base stage x0 seed list vs reference pipeline run")

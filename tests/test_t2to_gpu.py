@@ -95,7 +95,7 @@ def test_patch1_dit_forward_vs_oracle(golden_dir):
     want = O.dit_forward({k: v.to(BF) for k, v in sd.items()}, g["cfg"], x, emb, t, image_rotary_emb=rope)
     got = m(x.to(DEV), emb.to(DEV), t.to(DEV), image_rotary_emb=rope, return_dict=False)[0]
     assert got.shape == want.shape and torch.isfinite(got).all()
-    assert _rel(got, want) < 3e-2
+    assert _rel(got, want) < 8.5e-3          # measured 4.1e-3
 
 
 def test_t2to_pipeline_vs_reference_fixture(golden_dir):
@@ -123,12 +123,12 @@ def test_t2to_pipeline_vs_reference_fixture(golden_dir):
                latents=c["init_latents"], longvgen_mean=g["mean"], longvgen_std=g["std"], longvgen_pca=pca, step_noise=step_noise).frames
     assert order == [(0, 0)] + [(i, k) for i in range(1, g["steps"] - 1) for k in (0, 1)] + [(g["steps"] - 1, 0)]
     assert out.shape == c["frames"].shape and out.dtype == BF
-    assert _rel(out, c["frames"]) < 6e-2
+    assert _rel(out, c["frames"]) < 1.2e-2      # 6 stochastic bf16 steps + PCA tail vs the reference pipeline run; measured 5.6e-3
     # same seed through a CPU generator reproduces the reference's start and draw order without the replay hooks
     out2 = pipe(prompt_embeds=c["prompt"], negative_prompt_embeds=c["negative"], height=g["H"], width=g["W"], num_frames_per_chunk=g["nfc"],
                 num_chunks=g["chunks"], num_inference_steps=g["steps"], use_dynamic_cfg=True, guidance_scale=g["guidance_scale"],
                 generator=torch.Generator().manual_seed(g["gen_seed"]), longvgen_mean=g["mean"], longvgen_std=g["std"], longvgen_pca=pca).frames
-    assert _rel(out2, c["frames"]) < 6e-2
+    assert _rel(out2, c["frames"]) < 1.2e-2
 
 
 def test_t2to_argument_errors(golden_dir):

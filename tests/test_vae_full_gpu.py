@@ -90,7 +90,7 @@ def test_full_size_encode_properties(vae_full):
 def test_real_width_tile_vs_oracle(parity):
     """Channels 128/256/256/512 with 3 (encoder) / 4 (decoder) resnets per block — the shipped VAE — on ONE FULL-SIZE TILE (30 x 45 latent = 240 x 360 px, the tile of the 480 x 720 geometry) over
     two temporal batches (latent frames (0,3),(3,5) / sample frames (0,9),(9,17): first-frame replication, the carried cache, odd-T up/down
-    sampling) vs the oracle run in bf16 on the same bf16 weights.  ~45 convolutions deep in bf16: rel-L2 <= 5e-2 (SURVEY §8c end-to-end)."""
+    sampling) vs the oracle run in bf16 on the same bf16 weights.  ~45 convolutions deep in bf16: SURVEY §8c end-to-end bound 5e-2; asserted 2.8e-2 = 2x the measured 1.2e-2 / 1.4e-2."""
     from tokensgen_amd.vae import AutoencoderKLCogVideoX
     sd = V.make_state_dict(FULL, seed=5, dtype=BF)
     vae = AutoencoderKLCogVideoX(device=DEV)
@@ -105,5 +105,5 @@ def test_real_width_tile_vs_oracle(parity):
     d = vae.decode(z.to(DEV)).sample
     h = vae.encode(x.to(DEV)).latent_dist.parameters
     assert d.shape == ref_d.shape and h.shape == ref_h.shape
-    parity(_rel(d, ref_d), 5e-2, "decode, real widths, 5 latent frames of 30x45 (one full tile)")
-    parity(_rel(h, ref_h), 5e-2, "encode, real widths, 17 frames of 240x360 (one full tile)")
+    parity(_rel(d, ref_d), 2.8e-2, "decode, real widths, 5 latent frames of 30x45 (one full tile)")
+    parity(_rel(h, ref_h), 2.8e-2, "encode, real widths, 17 frames of 240x360 (one full tile)")

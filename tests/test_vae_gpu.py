@@ -146,21 +146,21 @@ def test_vae_tiny_encode_decode_vs_reference(golden_dir):
     z5 = torch.randn(1, 16, 5, 8, 12, generator=gen)
     z13 = torch.randn(1, 16, 13, 8, 12, generator=gen)
     h = vae.encode(x.to(DEV, BF)).latent_dist.parameters
-    assert h.shape == g["encode_plain"].shape and _rel(h, g["encode_plain"]) < 4e-2
+    assert h.shape == g["encode_plain"].shape and _rel(h, g["encode_plain"]) < 2.6e-2
     d = vae.decode(z5.to(DEV, BF)).sample
     f = d.flatten().cpu()
-    assert tuple(d.shape) == g["decode_plain"]["shape"] and _rel(f[g["idx"] % f.numel()], g["decode_plain"]["samples"]) < 5e-2
+    assert tuple(d.shape) == g["decode_plain"]["shape"] and _rel(f[g["idx"] % f.numel()], g["decode_plain"]["samples"]) < 2.5e-2
     vae.enable_tiling()
     h = vae.encode(x.to(DEV, BF)).latent_dist.parameters
-    assert h.shape == g["encode_tiled"].shape and _rel(h, g["encode_tiled"]) < 4e-2
+    assert h.shape == g["encode_tiled"].shape and _rel(h, g["encode_tiled"]) < 2.6e-2
     d = vae.decode(z13.to(DEV, BF)).sample
     f = d.flatten().cpu()
-    assert tuple(d.shape) == g["decode_tiled"]["shape"] and _rel(f[g["idx"] % f.numel()], g["decode_tiled"]["samples"]) < 5e-2
+    assert tuple(d.shape) == g["decode_tiled"]["shape"] and _rel(f[g["idx"] % f.numel()], g["decode_tiled"]["samples"]) < 2.5e-2
     # and against the oracle run in bf16 on the same bf16 inputs
     sdb = {k: v.to(BF) for k, v in sd.items()}
     ref = V.decode(sdb, cfg, z5.to(BF), tiling=False)
     vae.disable_tiling()
-    assert _rel(vae.decode(z5.to(DEV, BF)).sample, ref) < 5e-2
+    assert _rel(vae.decode(z5.to(DEV, BF)).sample, ref) < 2.5e-2          # measured: encode 1.25e-2, decode 0.9-1.25e-2 (~40 convolutions deep in bf16)
 
 
 @pytest.mark.timeout(900)
@@ -209,7 +209,7 @@ def test_condensed_token_front_end_vs_oracle(golden_dir):
     pipe = MPFIFOVideoIPAdapterCogVideoXPipeline(m, sched, vae=vae, resampler=rs)
     emb = pipe.vae_encode_image(frames.to(DEV), nf_per_chunk=17, compressed_nf_per_chunk=nfc, sample_posterior=False)
     assert emb.shape == (2, 8, 128, 2, 3) and torch.equal(emb[0], emb[1])
-    assert _rel(emb[:1], ref) < 6e-2
+    assert _rel(emb[:1], ref) < 1.2e-2           # measured 5.5e-3
 
 
 @pytest.mark.parametrize("ci,co,T,H,W", [(64, 128, 3, 9, 11), (128, 256, 2, 16, 24), (64, 512, 1, 13, 10)])
