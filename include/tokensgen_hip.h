@@ -205,6 +205,21 @@ int tg_pca_inverse(const void* lat, const float* std16, const float* mean16, con
                    void* out, int frames, int ncoef, int hw, int cout, hipStream_t stream);
 
 
+/* Attention BACKWARD (training step): what autograd runs for F.scaled_dot_product_attention in the reference's training
+ * loop (attention_processor.py:2066-2125 under train_cogvideo_to2v.py:1995-2010), head_dim 64, no mask, no dropout.
+ *   P = softmax(scale q k^T)   dV = P^T dO   dP = dO v^T   dS = P o (dP - rowsum(dO o O))   dQ = scale dS k   dK = scale dS^T q
+ * q, o, dout: bf16 [batch][nq][heads*64] views (row stride *_ld, batch stride *_sb; head h occupies columns 64h..64h+63);
+ * k, v: likewise with nk rows (v row-major here, not the transposed image of the forward).  dq / dk / dv: fp32, same indexing;
+ * accumulate != 0 adds to what is there (the To2V processor's three attention calls share K / V tensors: their gradients sum).
+ * ws: fp32 workspace of tg_attention_bwd_ws_floats(nq, heads, batch) floats (row log-sum-exp and rowsum(dO o O)).
+ * P is recomputed from the log-sum-exp tile by tile; three launches (statistics, dK/dV per key tile, dQ per query tile), no atomics:
+ * run-to-run deterministic. */
+int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void* k, long k_ld, long k_sb, const void* v, long v_ld, long v_sb,
+                     const void* o, long o_ld, long o_sb, const void* dout, long do_ld, long do_sb,
+                     float* dq, long dq_ld, long dq_sb, float* dk, long dk_ld, long dk_sb, float* dv, long dv_ld, long dv_sb,
+                     int nq, int nk, int heads, int batch, float scale, int accumulate, float* ws, hipStream_t stream);
+long tg_attention_bwd_ws_floats(int nq, int heads, int batch);
+
 /* Resampler's optional PCA low-rank filter (video_ipadapter/resampler.py:230-237: `pca.transform` -> zero every coefficient from 16 on ->
  * `pca.inverse_transform`, in the PCA's dtype = fp32, pca.py:56-66), per token:
  *   y_j = sum_c (x[r][c] - mean[c]) * comp[j][c]   (j < keep)        out[r][c] = bf16( mean[c] + sum_j y_j * comp[j][c] )
@@ -223,17 +238,22 @@ int tg_pca_lowrank_filter(const void* x, long ldx, const float* comp, const floa
  *   xv(t,h,w) = x[t_map ? t_map[t] : t][h/up][w/up]      nearest-neighbour upsampling folded into the loader
  * Replaces CogVideoXCausalConv3d (cat(cache, x) + F.pad + Conv3d, autoencoder_kl_cogvideox.py:120-145), the Conv2d of
  * CogVideoXUpsample3D after F.interpolate (up=2, kt=1, pad=1) and of CogVideoXDownsample3D (stride=2, pad=0 with the
- * (0,1,0,1) zero pad implied).  w is repacked [Cout_pad][kt*kh*kw][Cin] (Cout_pad % 128 == 0); only columns < cout
+ * (0,1,0,1) zero pad implied).  w is repacked [Cout_pad][kt*kh*kw][Cin] (Cout_pad % 128 == 0, or Cout_pad in {16, 32, ..., 112} for the
+ * narrow output layers — conv_out: 3 / 32 channels — which run 128 x 16 tiles); only columns < cout
  * are stored (row stride ldy).  residual (optional, same layout as y) is added in the epilogue (ResnetBlock3D :309).
  * zeros: >= 2*Cin + 128 bytes of device zeros (source of out-of-range taps).  Cin % 64 == 0.
  * gn_partial (optional, tg_conv3d_gn_partial_floats(To,Ho,Wo) floats; needs cout % 128 == 0): per 128-voxel tile row the sums and
  * sums of squares, per GroupNorm(32) group, of the bf16 values this launch stores — summed in a fixed order — so that the
  * GroupNorm / SpatialNorm that reads y next needs no statistics pass of its own: tg_groupnorm_finalize turns them into
- * (mean, rstd) exactly like the second stage of tg_groupnorm_stats. */
+ * (mean, rstd) exactly like the second stage of tg_groupnorm_stats.
+ * splitk_ws: fp32 workspace of tg_conv3d_splitk_floats(...) floats (may be NULL when that returns 0).  Layers with fewer 128 x 128 tiles
+ * than CUs and a long reduction (the 512-channel layers of a 30 x 45 latent tile) cut the (tap, channel) sum into ranges, one workgroup
+ * each, and a second launch adds the partial tensors in a fixed order and runs the epilogue — deterministic, like everything else here. */
 int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const void* cache, const void* w, const void* bias,
                  int cout, int cout_pad, int kt, int kh, int kw, int stride, int pad, int up, const int32_t* t_map,
                  const void* residual, void* y, long ldy, int To, int Ho, int Wo, const void* zeros, float* gn_partial,
-                 hipStream_t stream);
+                 float* splitk_ws, hipStream_t stream);
+long tg_conv3d_splitk_floats(int Cin, int cout, int cout_pad, int kt, int kh, int kw, int To, int Ho, int Wo);
 long tg_conv3d_gn_partial_floats(int To, int Ho, int Wo);
 int tg_groupnorm_finalize(const float* partial, long V, int C, float eps, float* stats, hipStream_t stream);
 

@@ -243,7 +243,7 @@ def test_conv_4wave_kernel_bitwise_equals_128_kernel(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for mode in ("0", "2"):
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_w4_check.py"), str(tmp_path)], env=dict(os.environ, TG_CONV_W4=mode, TG_CONV_W4N=mode),
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_w4_check.py"), str(tmp_path)], env=dict(os.environ, TG_CONV_W4=mode, TG_CONV_W4N=mode, TG_CONV_SPLITK="0"),
                            capture_output=True, text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "vs mode 0" in r.stdout and "bitwise False" not in r.stdout
@@ -278,3 +278,50 @@ def test_unvendored_classes_known_answers_on_the_kernels():
     d = DiagonalGaussianDistribution(h)
     assert torch.allclose((d.mean + d.std * torch.tensor(G["noise"], device=DEV).view(1, 4, 1, 1, 1)).flatten().cpu(), torch.tensor(G["sample"]), rtol=1e-6)
     assert torch.equal(d.mode().flatten().cpu(), torch.tensor(G["mean"]))
+
+
+def _pack16(w):
+    co, ci = w.shape[:2]
+    cop, cip = (co + 15) // 16 * 16, (ci + 63) // 64 * 64
+    p = torch.zeros(cop, int(np.prod(w.shape[2:])), cip, dtype=BF)
+    p[:co, :, :ci] = w.reshape(co, ci, -1).permute(0, 2, 1)
+    return p.contiguous()
+
+
+@pytest.mark.parametrize("ci,co,T,H,W", [(128, 3, 3, 9, 7), (512, 32, 2, 5, 6), (64, 16, 4, 11, 5)])
+def test_narrow_output_conv(ci, co, T, H, W):
+    """conv_out (Cout = 3 decoder / 32 encoder) on the 128 x 16 tile (weights packed to a multiple of 16 output channels instead of 128):
+    against the fp32 oracle, and equal to the 128-wide path on the same inputs up to the summation order (same products, one K loop)."""
+    from tokensgen_amd import kernels as K
+    w, b, x = _r(co, ci, 3, 3, 3, seed=1, scale=0.05), _r(co, seed=2), _r(1, ci, T, H, W, seed=3)
+    sd = {"c.conv.weight": w.float(), "c.conv.bias": b.float()}
+    ref = V.causal_conv3d(sd, "c", x.float(), V.ConvCache())
+    xc = _cl(x).to(DEV)
+    y16 = K.conv3d_cl(xc, _pack16(w).to(DEV), b.to(DEV), co, 3, 3, 3)
+    y128 = K.conv3d_cl(xc, _pack(w).to(DEV), b.to(DEV), co, 3, 3, 3)
+    assert y16.shape == (T, H, W, co)
+    assert _rel(_ncdhw(y16), ref) < 5e-3
+    assert torch.equal(y16, y128)
+
+
+@pytest.mark.parametrize("ci,co,T,H,W", [(512, 512, 2, 6, 8), (256, 512, 3, 9, 11), (512, 256, 1, 13, 10)])
+def test_splitk_conv_small_m(ci, co, T, H, W):
+    """The small-M layers (fewer 128 x 128 tiles than CUs, long reduction) run split-K + a fixed-order reduce launch that also does the
+    epilogue: bias, residual (with the reference's bf16 rounding before the add), GroupNorm sums — against the fp32 oracle, run-to-run bitwise."""
+    from tokensgen_amd import kernels as K
+    from tokensgen_amd import lib as L
+    assert L.load().tg_conv3d_splitk_floats(ci, co, co, 3, 3, 3, T, H, W) > 0, "this shape is meant to take the split-K path"
+    w, b, x = _r(co, ci, 3, 3, 3, seed=1, scale=0.02), _r(co, seed=2), _r(1, ci, T, H, W, seed=3)
+    sd = {"c.conv.weight": w.float(), "c.conv.bias": b.float()}
+    cache = V.ConvCache()
+    ref = V.causal_conv3d(sd, "c", x.float(), cache)
+    wp, bd, xc = _pack(w).to(DEV), b.to(DEV), _cl(x).to(DEV)
+    res = _r(T, H, W, co, seed=9).to(DEV)
+    y = K.conv3d_cl(xc, wp, bd, co, 3, 3, 3, gn_stats_eps=1e-6)
+    assert _rel(_ncdhw(y), ref) < 5e-3
+    torch.testing.assert_close(y.gn_stats, K.groupnorm_stats(y.view(-1, co), 1e-6), rtol=2e-5, atol=2e-6)
+    yr = K.conv3d_cl(xc, wp, bd, co, 3, 3, 3, residual=res, gn_stats_eps=1e-6)
+    assert _rel(yr, y.float() + res.float()) < 5e-3
+    torch.testing.assert_close(yr.gn_stats, K.groupnorm_stats(yr.view(-1, co), 1e-6), rtol=2e-5, atol=2e-6)
+    y2 = K.conv3d_cl(xc, wp, bd, co, 3, 3, 3, gn_stats_eps=1e-6)
+    assert torch.equal(y, y2) and torch.equal(y.gn_stats, y2.gn_stats)

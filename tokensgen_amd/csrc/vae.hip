@@ -31,19 +31,28 @@ struct ConvParams {
     int To, Ho, Wo;
     const bf16_t* zeros;
     float* gn_partial;    // optional [tiles_m][2][32]: per-tile GroupNorm(32) sums / sums of squares of the STORED bf16 values
+    int ksplit;           // > 1: the (tap, channel) reduction is cut into ksplit ranges, one workgroup each; raw fp32 sums go to kpart
+    float* kpart;         // [ksplit][M][cout_pad] fp32 (conv_splitk_reduce_kernel adds them in a fixed order and runs the epilogue)
 };
 
+// WN x (4 / WN) waves; a wave owns FM x FN MFMA 16x16 blocks: <2, 4, 4> = the 128 x 128 tile, <1, 2, 1> = 128 voxels x 16 output channels
+// (conv_out: Cout = 3 / 32 — with N padded to 128 the launch spent 42x / 4x the MFMA work and 8x the weight traffic it needed)
+template <int WN, int FM, int FN>
 __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
+    constexpr int WM = 4 / WN;
+    constexpr int BN = WN * FN * 16;
+    static_assert(WM * FM * 16 == BM, "the tile is 128 voxels");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     const long M = (long)p.To * p.Ho * p.Wo;
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = p.cout_pad / BN;
     const int nwg = tiles_m * tiles_n;
-    const int t = xcd_remap(blockIdx.x, nwg);
+    const int split = __builtin_amdgcn_readfirstlane((int)blockIdx.x / nwg);      // 0 unless ksplit > 1
+    const int t = xcd_remap((int)blockIdx.x - split * nwg, nwg);
     const int tn = t % tiles_n, tm = t / tiles_n;     // n fastest: the tiles_n blocks sharing an A tile run on one XCD
     const long m0 = (long)tm * BM;
     const int n0 = tn * BN;
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
         const int wo = (int)(m % p.Wo);
         const long q = m / p.Wo;
         vw[i] = wo; vh[i] = (int)(q % p.Ho); vt[i] = (int)(q / p.Ho);
-        srcW[i] = (const char*)(p.w + (long)(n0 + r) * Kw + slot * 8);
+        srcW[i] = (const char*)(p.w + (long)(n0 + (r < BN ? r : 0)) * Kw + slot * 8);
     }
     const int Hv = p.H * p.up, Wv = p.W * p.up;
     const long frame = (long)p.H * p.W * p.Cin;
@@ -90,89 +99,112 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) srcA[i] = tap_src(i, dt, dh, dw);
     };
+    const int kt_begin = (int)((long)nk * split / p.ksplit), kt_end = (int)((long)nk * (split + 1) / p.ksplit);
     auto stage = [&](int buf, int kt_) {
         const int tap = kt_ / cpt, cc = kt_ - tap * cpt;
-        if (cc == 0) set_tap(tap);
+        if (cc == 0 || kt_ == kt_begin) set_tap(tap);
         char* base = smem + buf * STAGE_BYTES + wave * (32 * 128);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + (long)cc * (BK * 2)),
                                              (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + (long)kt_ * (BK * 2)),
-                                             (__attribute__((address_space(3))) void*)(base + TILE_BYTES + i * 1024), 16, 0, 0);
+            if (wave * 32 + i * 8 < BN)       // wave-uniform: the W tile has BN rows
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + (long)kt_ * (BK * 2)),
+                                                 (__attribute__((address_space(3))) void*)(base + TILE_BYTES + i * 1024), 16, 0, 0);
         }
     };
 
-    int offA[4][2], offW[4][2];
+    int offA[FM][2], offW[FN][2];
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int ks = 0; ks < 2; ++ks) {
+        const int sl = ks * 4 + (lane >> 4);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ra = wm * 64 + f * 16 + (lane & 15), rw = wn * 64 + f * 16 + (lane & 15);
-            const int sl = ks * 4 + (lane >> 4);
+        for (int f = 0; f < FM; ++f) {
+            const int ra = wm * (FM * 16) + f * 16 + (lane & 15);
             offA[f][ks] = ra * 128 + ((sl ^ ((ra >> 1) & 7)) << 4);
+        }
+#pragma unroll
+        for (int f = 0; f < FN; ++f) {
+            const int rw = wn * (FN * 16) + f * 16 + (lane & 15);
             offW[f][ks] = rw * 128 + ((sl ^ ((rw >> 1) & 7)) << 4);
         }
+    }
 
-    f32x4 acc[4][4];
+    f32x4 acc[FN][FM];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FN; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    stage(0, 0);
+    stage(0, kt_begin);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt_ = 0; kt_ < nk; ++kt_) {
-        const int cur = kt_ & 1;
-        if (kt_ + 1 < nk) stage(cur ^ 1, kt_ + 1);
+    for (int kt_ = kt_begin; kt_ < kt_end; ++kt_) {
+        const int cur = (kt_ - kt_begin) & 1;
+        if (kt_ + 1 < kt_end) stage(cur ^ 1, kt_ + 1);
         const char* tA = smem + cur * STAGE_BYTES;
         const char* tW = tA + TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fw[4];
+            bf16x8 fa[FM], fw[FN];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                fa[f] = *(const bf16x8*)(tA + offA[f][ks]);
-                fw[f] = *(const bf16x8*)(tW + offW[f][ks]);
-            }
+            for (int f = 0; f < FM; ++f) fa[f] = *(const bf16x8*)(tA + offA[f][ks]);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int f = 0; f < FN; ++f) fw[f] = *(const bf16x8*)(tW + offW[f][ks]);
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+            for (int ni = 0; ni < FN; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < FM; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
+    if (p.ksplit > 1) {      // raw fp32 sums of this K range; bias / residual / GroupNorm sums happen in conv_splitk_reduce_kernel
+        float* part = p.kpart + (long)split * M * p.cout_pad;
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi) {
+            const long m = m0 + wm * (FM * 16) + mi * 16 + (lane & 15);
+            if (m >= M) continue;
+#pragma unroll
+            for (int ni = 0; ni < FN; ++ni) {
+                const int n = n0 + wn * (FN * 16) + ni * 16 + (lane >> 4) * 4;
+                *(f32x4*)(part + m * p.cout_pad + n) = acc[ni][mi];
+            }
+        }
+        return;
+    }
+
     // ---- epilogue: bias (+ residual), only columns < cout are stored ----
     // All bias / residual chunks of the lane are requested FIRST (one batch of loads in flight), then converted and stored: written the
     // naive way (load, use, store per chunk) the stores order the next chunk's loads behind them (they may alias) and every chunk pays
     // a full memory round trip behind a vmcnt(0).
-    float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};   // GroupNorm partials of this lane's channel quad per ni
-    uint2 bq[4], rq[4][4];
+    float gs[FN], gq[FN];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+    for (int i = 0; i < FN; ++i) gs[i] = gq[i] = 0.f;   // GroupNorm partials of this lane's channel quad per ni
+    uint2 bq[FN], rq[FM][FN];
+#pragma unroll
+    for (int ni = 0; ni < FN; ++ni) {
+        const int n = n0 + wn * (FN * 16) + ni * 16 + (lane >> 4) * 4;
         bq[ni] = (p.bias && n + 4 <= p.cout) ? *(const uint2*)(p.bias + n) : uint2{0u, 0u};
     }
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const long m = m0 + wm * 64 + mi * 16 + (lane & 15);
+    for (int mi = 0; mi < FM; ++mi) {
+        const long m = m0 + wm * (FM * 16) + mi * 16 + (lane & 15);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+        for (int ni = 0; ni < FN; ++ni) {
+            const int n = n0 + wn * (FN * 16) + ni * 16 + (lane >> 4) * 4;
             rq[mi][ni] = (p.residual && m < M && n + 4 <= p.cout) ? *(const uint2*)(p.residual + m * p.ldy + n) : uint2{0u, 0u};
         }
     }
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const long m = m0 + wm * 64 + mi * 16 + (lane & 15);
+    for (int mi = 0; mi < FM; ++mi) {
+        const long m = m0 + wm * (FM * 16) + mi * 16 + (lane & 15);
         if (m >= M) continue;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 64 + ni * 16 + (lane >> 4) * 4;
+        for (int ni = 0; ni < FN; ++ni) {
+            const int n = n0 + wn * (FN * 16) + ni * 16 + (lane >> 4) * 4;
             if (n >= p.cout) continue;
             float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
             bf16_t* dst = p.y + m * p.ldy + n;
@@ -208,9 +240,9 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
     }
     // ---- GroupNorm partial sums of this tile, summed in a fixed order (no atomics): lanes of a 16-lane row group -> per
     // (wave, ni, channel quad) in LDS -> one thread per (statistic, group) walks the quads of its group and both row halves
-    if (p.gn_partial) {
+    if constexpr (BN == 128) if (p.gn_partial) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < FN; ++ni) {
 #pragma unroll
             for (int off = 1; off < 16; off <<= 1) {
                 gs[ni] += __shfl_xor(gs[ni], off, 64);
@@ -220,7 +252,7 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
         float* red = (float*)smem;                          // the stage buffers are idle: the k loop ended with a __syncthreads
         if ((lane & 15) == 0) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
+            for (int ni = 0; ni < FN; ++ni) {
                 red[((wave * 4 + ni) * 4 + (lane >> 4)) * 2 + 0] = gs[ni];
                 red[((wave * 4 + ni) * 4 + (lane >> 4)) * 2 + 1] = gq[ni];
             }
@@ -237,6 +269,57 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
             }
             p.gn_partial[(long)tm * 2 * GN_GROUPS + stat * GN_GROUPS + n0 / cg + gl] = a;
         }
+    }
+}
+
+
+// Split-K epilogue: sum the ksplit fp32 partial tensors in a fixed order, then exactly what conv3d_cl_kernel's own epilogue does (bias, the
+// reference's bf16 rounding before the residual add, bf16 store, per-128-voxel-tile GroupNorm sums of the stored values).  One workgroup per
+// 128-voxel tile over ALL output channels; cout == cout_pad in {128, 256, 512}.
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ kpart, int ksplit, long M, int cout,
+                                                                 const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
+                                                                 bf16_t* __restrict__ y, long ldy, float* __restrict__ gn_partial) {
+    __shared__ float red[256][2];
+    const int tid = threadIdx.x;
+    const int nq = cout >> 2;                       // channel quads per voxel: 32 / 64 / 128
+    const int cq = tid % nq, rl = tid / nq, rstep = 256 / nq;
+    const int n = cq * 4;
+    const long m0 = (long)blockIdx.x * BM;
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+        const uint2 bb = *(const uint2*)(bias + n);
+        b4[0] = bf16lo_to_f32(bb.x); b4[1] = bf16hi_to_f32(bb.x); b4[2] = bf16lo_to_f32(bb.y); b4[3] = bf16hi_to_f32(bb.y);
+    }
+    float gs = 0.f, gq = 0.f;
+    for (int r = rl; r < BM; r += rstep) {
+        const long m = m0 + r;
+        if (m >= M) break;
+        f32x4 v = *(const f32x4*)(kpart + m * cout + n);
+        for (int sp = 1; sp < ksplit; ++sp) v += *(const f32x4*)(kpart + ((long)sp * M + m) * cout + n);
+        float u[4] = {v[0] + b4[0], v[1] + b4[1], v[2] + b4[2], v[3] + b4[3]};
+        if (residual) {
+            const uint2 rr = *(const uint2*)(residual + m * ldy + n);
+            u[0] = round_bf16(u[0]) + bf16lo_to_f32(rr.x); u[1] = round_bf16(u[1]) + bf16hi_to_f32(rr.x);
+            u[2] = round_bf16(u[2]) + bf16lo_to_f32(rr.y); u[3] = round_bf16(u[3]) + bf16hi_to_f32(rr.y);
+        }
+        uint2 o;
+        o.x = pack_bf16x2(u[0], u[1]);
+        o.y = pack_bf16x2(u[2], u[3]);
+        *(uint2*)(y + m * ldy + n) = o;
+        const float r0 = bf16lo_to_f32(o.x), r1 = bf16hi_to_f32(o.x), r2 = bf16lo_to_f32(o.y), r3 = bf16hi_to_f32(o.y);
+        gs += (r0 + r1) + (r2 + r3);
+        gq += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+    }
+    if (!gn_partial) return;
+    red[tid][0] = gs; red[tid][1] = gq;
+    __syncthreads();
+    if (tid < 2 * GN_GROUPS) {                      // fixed order: quads of the group, then the row lanes
+        const int stat = tid / GN_GROUPS, g = tid % GN_GROUPS;
+        const int qpg = (cout / GN_GROUPS) >> 2;
+        float a = 0.f;
+        for (int qd = 0; qd < qpg; ++qd)
+            for (int r = 0; r < rstep; ++r) a += red[r * nq + g * qpg + qd][stat];
+        gn_partial[(long)blockIdx.x * 2 * GN_GROUPS + stat * GN_GROUPS + g] = a;
     }
 }
 
@@ -855,25 +938,48 @@ __global__ void tile_blend_kernel(const TT* __restrict__ a, TT* __restrict__ b, 
 
 inline unsigned grid_for(long total, int block = 256) { return (unsigned)min((total + block - 1) / block, (long)256 * 16); }
 
+// K ranges per tile for the 128 x 128 kernel: only when the plain launch would leave most CUs idle (fewer tiles than CUs) and the reduction
+// is long; aims at ~2 workgroups per CU (the kernel waits on every stage: a second resident workgroup hides that), >= 8 K steps per range.
+// TG_CONV_SPLITK=0 disables it (A/B runs, and the bitwise 4-wave-vs-128 test).  The w4 kernels are chosen first where they apply.
+static int conv_ksplit(long M, int cout, int cout_pad, long nk, int n_cu) {
+    static const int on = [] { const char* e = getenv("TG_CONV_SPLITK"); return e ? atoi(e) : 1; }();
+    if (!on || cout != cout_pad || cout_pad % BN != 0 || cout > 512 || nk < 32) return 1;
+    const long tiles = ((M + BM - 1) / BM) * (cout_pad / BN);
+    if (tiles >= n_cu) return 1;
+    long ks = (2L * n_cu + tiles - 1) / tiles;
+    if (ks > 8) ks = 8;
+    if (ks > nk / 8) ks = nk / 8;
+    return ks < 2 ? 1 : (int)ks;
+}
+
 }  // namespace
 
 extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const void* cache, const void* w, const void* bias,
                             int cout, int cout_pad, int kt, int kh, int kw, int stride, int pad, int up, const int32_t* t_map,
                             const void* residual, void* y, long ldy, int To, int Ho, int Wo, const void* zeros, float* gn_partial,
-                            hipStream_t stream) {
+                            float* splitk_ws, hipStream_t stream) {
     TG_REQUIRE(x && w && y && zeros, TG_ERR_ARG, "tg_conv3d_cl: null pointer");
     TG_REQUIRE(T > 0 && H > 0 && W > 0 && To > 0 && Ho > 0 && Wo > 0, TG_ERR_SHAPE, "tg_conv3d_cl: bad spatial shape");
-    TG_REQUIRE(Cin % BK == 0 && cout_pad % BN == 0 && cout > 0 && cout <= cout_pad, TG_ERR_SHAPE,
-               "tg_conv3d_cl: need Cin%%64==0, cout_pad%%128==0 (Cin=%d cout=%d cout_pad=%d)", Cin, cout, cout_pad);
+    TG_REQUIRE(Cin % BK == 0 && (cout_pad % BN == 0 || (cout_pad < BN && cout_pad % 16 == 0)) && cout > 0 && cout <= cout_pad, TG_ERR_SHAPE,
+               "tg_conv3d_cl: need Cin%%64==0 and cout_pad%%128==0 (or cout_pad in {16, 32, ..., 112}) (Cin=%d cout=%d cout_pad=%d)", Cin, cout, cout_pad);
     TG_REQUIRE(kt >= 1 && kt <= 3 && kh >= 1 && kh <= 3 && kw >= 1 && kw <= 3 && (stride == 1 || stride == 2) && (up == 1 || up == 2) &&
                pad >= 0 && pad <= 1, TG_ERR_SHAPE, "tg_conv3d_cl: unsupported kernel/stride/pad/up");
     TG_REQUIRE(tg_aligned16(x) && tg_aligned16(w) && tg_aligned16(zeros) && (!cache || tg_aligned16(cache)) && (((uintptr_t)y) & 1) == 0 &&
                (cout % 4 != 0 || ((((uintptr_t)y) & 7) == 0 && ldy % 4 == 0)), TG_ERR_ALIGN, "tg_conv3d_cl: alignment");
     ConvParams p{(const bf16_t*)x, T, H, W, Cin, (const bf16_t*)cache, (const bf16_t*)w, (const bf16_t*)bias, cout, cout_pad, kt, kh, kw,
-                 stride, pad, up, t_map, (const bf16_t*)residual, (bf16_t*)y, ldy, To, Ho, Wo, (const bf16_t*)zeros, gn_partial};
+                 stride, pad, up, t_map, (const bf16_t*)residual, (bf16_t*)y, ldy, To, Ho, Wo, (const bf16_t*)zeros, gn_partial, 1, nullptr};
     TG_REQUIRE(!gn_partial || (cout == cout_pad && cout % BN == 0 && (cout / GN_GROUPS) % 4 == 0), TG_ERR_SHAPE,
                "tg_conv3d_cl: fused GroupNorm sums need cout in {128, 256, 512, ...} (cout=%d)", cout);
     const long M = (long)To * Ho * Wo;
+    if (cout_pad % BN != 0) {          // narrow output (conv_out): 128 voxels x 16 channels per workgroup
+        const long tiles16 = ((M + BM - 1) / BM) * (cout_pad / 16);
+        TG_REQUIRE(tiles16 < (1L << 31), TG_ERR_SHAPE, "tg_conv3d_cl: too many tiles");
+        static bool attr16 = false;
+        if (!attr16) { (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel<1, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES); attr16 = true; }
+        hipLaunchKernelGGL((conv3d_cl_kernel<1, 2, 1>), dim3((unsigned)tiles16), dim3(256), 2 * STAGE_BYTES, stream, p);
+        TG_LAUNCH_CHECK("tg_conv3d_cl(n16)");
+        return TG_OK;
+    }
     const long tiles = ((M + BM - 1) / BM) * (cout_pad / BN);
     TG_REQUIRE(tiles < (1L << 31), TG_ERR_SHAPE, "tg_conv3d_cl: too many tiles");
     // 4-wave kernel: 256x256 tiles need enough of them to fill the chip (>= 2 per CU; the 512-channel layers of the VAE have 128 and stay on
@@ -907,10 +1013,30 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
         return TG_OK;
     }
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES); attr = true; }
-    hipLaunchKernelGGL(conv3d_cl_kernel, dim3((unsigned)tiles), dim3(256), 2 * STAGE_BYTES, stream, p);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel<2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES); attr = true; }
+    // split-K: the small-M layers (the 512-channel layers at 30 x 45 latent: 88 tiles for 256 CUs, each walking 216 K steps alone on its CU)
+    p.ksplit = conv_ksplit(M, cout, cout_pad, (long)kt * kh * kw * (Cin / BK), n_cu);
+    if (p.ksplit > 1) {
+        TG_REQUIRE(splitk_ws, TG_ERR_ARG, "tg_conv3d_cl: this shape runs split-K (tg_conv3d_splitk_floats > 0) and needs the workspace");
+        p.kpart = splitk_ws;
+        hipLaunchKernelGGL((conv3d_cl_kernel<2, 4, 4>), dim3((unsigned)(tiles * p.ksplit)), dim3(256), 2 * STAGE_BYTES, stream, p);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((M + BM - 1) / BM)), dim3(256), 0, stream, (const float*)splitk_ws, p.ksplit, M, cout,
+                           (const bf16_t*)bias, (const bf16_t*)residual, (bf16_t*)y, ldy, gn_partial);
+        TG_LAUNCH_CHECK("tg_conv3d_cl(split-K)");
+        return TG_OK;
+    }
+    hipLaunchKernelGGL((conv3d_cl_kernel<2, 4, 4>), dim3((unsigned)tiles), dim3(256), 2 * STAGE_BYTES, stream, p);
     TG_LAUNCH_CHECK("tg_conv3d_cl");
     return TG_OK;
+}
+
+extern "C" long tg_conv3d_splitk_floats(int Cin, int cout, int cout_pad, int kt, int kh, int kw, int To, int Ho, int Wo) {
+    int n_cu = 0, dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    const long M = (long)To * Ho * Wo;
+    const int ks = conv_ksplit(M, cout, cout_pad, (long)kt * kh * kw * (Cin / BK), n_cu);
+    return ks > 1 ? (long)ks * M * cout_pad : 0;
 }
 
 extern "C" long tg_groupnorm_partial_floats(long V, int C) {

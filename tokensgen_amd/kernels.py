@@ -241,6 +241,28 @@ def attention(q1, k1, vt1, nk1, out, heads, scale, q2=None, k2=None, vt2=None, n
     return out
 
 
+def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, accumulate=False):
+    """Gradients of o = softmax(scale q k^T) v per head (tg_attention_bwd).  q/o/dout [B,nq,heads*64], k/v [B,nk,heads*64] bf16 views;
+    returns fp32 (dq, dk, dv) shaped like q, k, v (given tensors are written, or added to with accumulate=True)."""
+    for n, t in (("q", q), ("k", k), ("v", v), ("o", o), ("dout", dout)):
+        _chk(t, n)
+    B, nq, HD, qld, qsb = _bmk(q)
+    _, nk, _, kld, ksb = _bmk(k)
+    _, _, _, vld, vsb = _bmk(v)
+    _, _, _, old, osb = _bmk(o)
+    _, _, _, gld, gsb = _bmk(dout)
+    assert HD == heads * 64 and o.shape == q.shape == dout.shape and v.shape == k.shape
+    f32 = torch.float32
+    dq = torch.empty(B, nq, HD, dtype=f32, device=q.device) if dq is None else _chk(dq, "dq", f32)
+    dk = torch.empty(B, nk, HD, dtype=f32, device=q.device) if dk is None else _chk(dk, "dk", f32)
+    dv = torch.empty(B, nk, HD, dtype=f32, device=q.device) if dv is None else _chk(dv, "dv", f32)
+    ws = torch.empty(L.load().tg_attention_bwd_ws_floats(nq, heads, B), dtype=f32, device=q.device)
+    L.check(_launch("attention_bwd", L.load().tg_attention_bwd, _p(q), qld, qsb, _p(k), kld, ksb, _p(v), vld, vsb, _p(o), old, osb, _p(dout), gld, gsb,
+                    _p(dq), dq.stride(1), dq.stride(0), _p(dk), dk.stride(1), dk.stride(0), _p(dv), dv.stride(1), dv.stride(0), nq, nk, heads, B,
+                    float(scale), 1 if accumulate else 0, _p(ws), _stream()), "tg_attention_bwd")
+    return dq, dk, dv
+
+
 def _attn_problem(q1, k1, vt1, nk1, out, q2=None, k2=None, vt2=None, nk2=0, seg2_scale=0.0):
     import ctypes
     for n, t in (("q1", q1), ("k1", k1), ("vt1", vt1), ("out", out)):
@@ -362,6 +384,16 @@ def zero_page(device):
     return z
 
 
+_SPLITK = {}
+
+
+def _splitk_floats(*key):
+    n = _SPLITK.get(key)
+    if n is None:
+        n = _SPLITK[key] = int(L.load().tg_conv3d_splitk_floats(*key))
+    return n
+
+
 def conv3d_cl(x, w_packed, bias, cout, kt, kh, kw, cache=None, stride=1, pad=1, up=1, t_map=None, residual=None, out_dims=None,
               gn_stats_eps=None):
     """x [T,H,W,Cin] channels-last; w_packed [Cout_pad, kt*kh*kw, Cin]; returns y [To,Ho,Wo,cout].
@@ -380,9 +412,11 @@ def conv3d_cl(x, w_packed, bias, cout, kt, kh, kw, cache=None, stride=1, pad=1, 
         _chk(t_map, "t_map", torch.int32)
     fuse = gn_stats_eps is not None and cout % 128 == 0 and w_packed.shape[0] == cout
     partial = torch.empty(L.load().tg_conv3d_gn_partial_floats(To, Ho, Wo), dtype=torch.float32, device=x.device) if fuse else None
+    nws = _splitk_floats(Cin, cout, w_packed.shape[0], kt, kh, kw, To, Ho, Wo)
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
     L.check(_launch(f"conv3d_cl_Cin{Cin}_Cout{cout}_k{kt}{kh}{kw}_s{stride}_u{up}", L.load().tg_conv3d_cl, _p(x), T, H, W, Cin, _p(cache),
                     _p(w_packed), _p(bias), cout, w_packed.shape[0], kt, kh, kw, stride, pad, up, _p(t_map), _p(residual), _p(y), cout, To, Ho,
-                    Wo, _p(zero_page(x.device)), _p(partial), _stream()), "tg_conv3d_cl")
+                    Wo, _p(zero_page(x.device)), _p(partial), _p(ws), _stream()), "tg_conv3d_cl")
     if fuse:
         stats = torch.empty(32, 2, dtype=torch.float32, device=x.device)
         L.check(_launch("groupnorm_finalize", L.load().tg_groupnorm_finalize, _p(partial), To * Ho * Wo, cout, float(gn_stats_eps), _p(stats),

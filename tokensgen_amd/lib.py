@@ -30,6 +30,8 @@ PROTOTYPES = {
     "tg_attention_fwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _f, _vp, _l, _l,
                          _i, _i, _i, _f, _i, _vp],
     "tg_attention_fwd_multi": [_vp, _i, _i, _i, _f, _i, _vp],
+    "tg_attention_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l,
+                         _i, _i, _i, _i, _f, _i, _vp, _vp],
     "tg_timestep_sinusoid": [_vp, _i, _i, _vp, _vp],
     "tg_rope_table_3d": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "tg_patchify": [_vp, _vp, _l, _i, _i, _i, _i, _i, _vp],
@@ -38,7 +40,7 @@ PROTOTYPES = {
     "tg_cfg_dpm_step_f32": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _l, _vp],
     "tg_pca_inverse": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "tg_pca_lowrank_filter": [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _vp],
-    "tg_conv3d_cl": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp],
+    "tg_conv3d_cl": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp],
     "tg_groupnorm_finalize": [_vp, _l, _i, _f, _vp, _vp],
     "tg_groupnorm_stats": [_vp, _l, _i, _f, _vp, _vp, _vp],
     "tg_groupnorm_silu": [_vp, _l, _i, _vp, _vp, _vp, _vp, _i, _vp],
@@ -67,6 +69,10 @@ def load():
         fn.restype = C.c_int
     lib.tg_groupnorm_partial_floats.argtypes = [C.c_long, C.c_int]
     lib.tg_groupnorm_partial_floats.restype = C.c_long
+    lib.tg_attention_bwd_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.tg_attention_bwd_ws_floats.restype = C.c_long
+    lib.tg_conv3d_splitk_floats.argtypes = [C.c_int] * 9
+    lib.tg_conv3d_splitk_floats.restype = C.c_long
     lib.tg_conv3d_gn_partial_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.tg_conv3d_gn_partial_floats.restype = C.c_long
     lib.tg_version.restype = C.c_char_p

@@ -62,7 +62,7 @@ class AutoencoderKLCogVideoX:
         self.tile_overlap_factor_height, self.tile_overlap_factor_width = 1 / 6, 1 / 5
         self._retile()
         self._sd, self._packed = {}, {}
-        self.tile_streams = int(os.environ.get("TG_VAE_STREAMS", "4"))     # concurrent spatial tiles (see _run_tiles)
+        self.tile_streams = int(os.environ.get("TG_VAE_STREAMS", "3"))     # concurrent spatial tiles (see _run_tiles)
         self._streams = []
         self._tmaps = {}
         # HIP graphs: a tile program (all temporal batches of one spatial tile: ~950 launches) is captured the second time its shape is seen
@@ -116,7 +116,8 @@ class AutoencoderKLCogVideoX:
                 taps = v.shape[2:]
                 if all(t == 1 for t in taps) and ci == 16 and (k.endswith("conv_y.conv.weight") or k.endswith("conv_b.conv.weight")):
                     continue                                                               # SpatialNorm convs: fused below
-                cin_p, cout_p = _pad_to(ci, 64), _pad_to(co, 128)
+                cin_p = _pad_to(ci, 64)
+                cout_p = _pad_to(co, 16) if co <= 32 else _pad_to(co, 128)     # conv_out (3 / 32 channels): the narrow 128 x 16 tile
                 w = torch.zeros(cout_p, int(np.prod(taps)), cin_p, dtype=BF16, device=self.device)
                 w[:co, :, :ci] = v.reshape(co, ci, -1).permute(0, 2, 1)
                 self._packed[k] = w.contiguous()
@@ -405,19 +406,30 @@ class AutoencoderKLCogVideoX:
         main = torch.cuda.current_stream(self.device)
         if len(self._streams) < n:
             self._streams += [torch.cuda.Stream(device=self.device) for _ in range(n - len(self._streams))]
-        out, k = [], 0
-        # largest tiles first within the round-robin does not matter for correctness; keep the reference's row-major order
-        for row in origins:
-            orow = []
-            for (i, j) in row:
-                st = self._streams[k % n]
-                k += 1
-                st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    t = self._run_tile_maybe_graph(src, i, j, th, tw, decode, k - 1)
-                t.record_stream(main)
-                orow.append(t)
-            out.append(orow)
+        # stream assignment: round-robin in the reference's row-major tile order (measured best at 480 x 720 on 3 streams: the two streams
+        # that carry the full-size tiles and the one that carries the edge tiles drift out of phase, so small-kernel phases of one tile meet
+        # large convolutions of another; longest-processing-time-first balancing measured 3 % slower).  TG_VAE_ASSIGN / TG_VAE_ENQ
+        # ("0,1,2,..." stream per tile / enqueue order of the tiles) are experiment knobs.
+        flat = [(i, j) for row in origins for (i, j) in row]
+        assign = [k % n for k in range(len(flat))]
+        order = list(range(len(flat)))
+        if os.environ.get("TG_VAE_ASSIGN"):
+            a_ = [int(v) % n for v in os.environ["TG_VAE_ASSIGN"].split(",")]
+            assign = a_ if len(a_) == len(flat) else assign
+        if os.environ.get("TG_VAE_ENQ"):
+            o_ = [int(v) for v in os.environ["TG_VAE_ENQ"].split(",")]
+            order = o_ if sorted(o_) == order else order
+        res = [None] * len(flat)
+        for k in order:
+            i, j = flat[k]
+            st = self._streams[assign[k]]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                t = self._run_tile_maybe_graph(src, i, j, th, tw, decode, k)
+            t.record_stream(main)
+            res[k] = t
+        it = iter(res)
+        out = [[next(it) for _ in row] for row in origins]
         for st in self._streams[:n]:
             main.wait_stream(st)
         return out
