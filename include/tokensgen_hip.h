@@ -220,6 +220,17 @@ int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void* k, long k_
                      int nq, int nk, int heads, int batch, float scale, int accumulate, float* ws, hipStream_t stream);
 long tg_attention_bwd_ws_floats(int nq, int heads, int batch);
 
+/* Training loss of the To2V step and its gradient w.r.t. the model output (train_cogvideo_to2v.py:1995-2004; get_velocity
+ * scheduling_dpm_cogvideox.py:521-538), per frame f (per-frame timesteps) over frame_elems elements:
+ *   pred = bf16(bf16(sa_f * noisy) - bf16(sb_f * out))    sa_f = sqrt(acp_t), sb_f = sqrt(1 - acp_t), both cast to bf16 like the reference
+ *   partial[f][block] = sum over the block's 256 elements of w_f * bf16(bf16(pred - target)^2)      w_f = 1 / (1 - acp_t), fp32
+ *   grad = bf16( -sb_f * 2 w_f (pred - target) * inv_count )         inv_count = 1 / (elements per batch item * batch size)
+ * coef fp32 [frames][3] = (sa, sb, w); model_out / noisy / target / grad bf16 [frames][frame_elems]; partial fp32, tg_vpred_loss_partial_floats
+ * floats (summed per batch item on the host: fixed order, deterministic). */
+int tg_vpred_loss_grad(const void* model_out, const void* noisy, const void* target, const float* coef, int frames, long frame_elems,
+                       float inv_count, void* grad, float* partial, hipStream_t stream);
+long tg_vpred_loss_partial_floats(int frames, long frame_elems);
+
 /* Resampler's optional PCA low-rank filter (video_ipadapter/resampler.py:230-237: `pca.transform` -> zero every coefficient from 16 on ->
  * `pca.inverse_transform`, in the PCA's dtype = fp32, pca.py:56-66), per token:
  *   y_j = sum_c (x[r][c] - mean[c]) * comp[j][c]   (j < keep)        out[r][c] = bf16( mean[c] + sum_j y_j * comp[j][c] )

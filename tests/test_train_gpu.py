@@ -94,3 +94,31 @@ def test_to2v_processor_attention_gradients():
     got = dict(q=dq, k=dk, v=dv, qx=dqx, kx=dkcat[:, :N1], vx=dvcat[:, :N1], qv=dqv, kv=dkcat[:, N1:], vv=dvcat[:, N1:])
     for n in names:
         assert _rel(got[n], f[n].grad) < 2e-2, n
+
+
+def test_vpred_loss_and_gradient_vs_autograd():
+    """tg_vpred_loss_grad against autograd of the oracle's restatement of train_cogvideo_to2v.py:1990-2010 (bf16 tensors, per-frame timesteps)."""
+    from oracle import scheduler_ref as S
+    from oracle import train_ref as T
+    from tokensgen_amd import train
+    _, ac = S.alphas_cumprod()
+    ac = torch.as_tensor(ac, dtype=torch.float32)
+    B, F, C, H, W = 2, 13, 16, 6, 10
+    g = torch.Generator().manual_seed(5)
+    out, noisy, x0 = (torch.randn(B, F, C, H, W, generator=g).to(BF) for _ in range(3))
+    ts = torch.randint(20, 980, (B, F), generator=g)
+    o = out.clone().requires_grad_(True)
+    loss, per_item = T.vpred_loss(ac, o, noisy, x0, ts)
+    loss.backward()
+    l2, p2, grad = train.vpred_loss_and_grad(out.to(DEV), noisy.to(DEV), x0.to(DEV), ts, ac)
+    assert grad.shape == out.shape and grad.dtype == BF
+    assert abs(l2.item() - loss.item()) < 2e-3 * abs(loss.item())
+    assert torch.allclose(p2.cpu(), per_item.detach().float(), rtol=2e-3)
+    assert _rel(grad, o.grad) < 1e-2
+    # scalar timestep per batch item
+    ts1 = torch.tensor([100, 900])
+    o = out.clone().requires_grad_(True)
+    loss, _ = T.vpred_loss(ac, o, noisy, x0, ts1)
+    loss.backward()
+    l3, _, grad3 = train.vpred_loss_and_grad(out.to(DEV), noisy.to(DEV), x0.to(DEV), ts1, ac)
+    assert abs(l3.item() - loss.item()) < 2e-3 * abs(loss.item()) and _rel(grad3, o.grad) < 1e-2

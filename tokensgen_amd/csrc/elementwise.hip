@@ -189,6 +189,32 @@ __global__ __launch_bounds__(256) void pca_filter_kernel(const bf16_t* __restric
     }
 }
 
+// Training loss of the To2V step and its gradient w.r.t. the model output (train_cogvideo_to2v.py:1995-2004 with scheduling_dpm_cogvideox.py:521-538):
+//   pred = sqrt(acp_t) * noisy - sqrt(1 - acp_t) * out     (get_velocity in the sample dtype: every product / difference is a bf16 tensor)
+//   loss_b = mean over the batch item of w_t (pred - target)^2,  w_t = 1 / (1 - acp_t) in fp32;   loss = mean_b loss_b
+//   dloss/dout = -sqrt(1 - acp_t) * 2 w_t (pred - target) / (elements per item * batch)
+// One thread per element; per-block partial loss sums in a fixed order (deterministic), summed per batch item on the host.
+__global__ __launch_bounds__(256) void vpred_loss_grad_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ noisy,
+                                                              const bf16_t* __restrict__ target, const float* __restrict__ coef, long E,
+                                                              float inv_count, bf16_t* __restrict__ grad, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int f = blockIdx.y;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const float sa = round_bf16(coef[3 * f]), sb = round_bf16(coef[3 * f + 1]), w = coef[3 * f + 2];
+    float term = 0.f;
+    if (e < E) {
+        const long i = (long)f * E + e;
+        const float pred = round_bf16(round_bf16(sa * bf16_to_f32(noisy[i])) - round_bf16(sb * bf16_to_f32(out[i])));
+        const float diff = round_bf16(pred - bf16_to_f32(target[i]));
+        term = w * round_bf16(diff * diff);
+        grad[i] = f32_to_bf16(-sb * (2.f * w * diff * inv_count));
+    }
+    term = wave_sum(term);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(long)f * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 }  // namespace
 
 extern "C" int tg_timestep_sinusoid(const int64_t* t, int n, int dim, void* emb, hipStream_t stream) {
@@ -264,6 +290,18 @@ extern "C" int tg_pca_lowrank_filter(const void* x, long ldx, const float* comp,
     TG_REQUIRE(keep >= 1 && keep <= 16, TG_ERR_SHAPE, "tg_pca_lowrank_filter: keep=%d (the reference keeps 16 components)", keep);
     hipLaunchKernelGGL(pca_filter_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const bf16_t*)x, ldx, comp, mean, (bf16_t*)out, ldo, D, keep);
     TG_LAUNCH_CHECK("tg_pca_lowrank_filter");
+    return TG_OK;
+}
+
+extern "C" long tg_vpred_loss_partial_floats(int frames, long frame_elems) { return (long)frames * ((frame_elems + 255) / 256); }
+
+extern "C" int tg_vpred_loss_grad(const void* model_out, const void* noisy, const void* target, const float* coef, int frames, long frame_elems,
+                                  float inv_count, void* grad, float* partial, hipStream_t stream) {
+    TG_REQUIRE(model_out && noisy && target && coef && grad && partial, TG_ERR_ARG, "tg_vpred_loss_grad: null pointer");
+    TG_REQUIRE(frames > 0 && frames < 65536 && frame_elems > 0, TG_ERR_SHAPE, "tg_vpred_loss_grad: bad shape");
+    hipLaunchKernelGGL(vpred_loss_grad_kernel, dim3((unsigned)((frame_elems + 255) / 256), (unsigned)frames), dim3(256), 0, stream,
+                       (const bf16_t*)model_out, (const bf16_t*)noisy, (const bf16_t*)target, coef, frame_elems, inv_count, (bf16_t*)grad, partial);
+    TG_LAUNCH_CHECK("tg_vpred_loss_grad");
     return TG_OK;
 }
 

@@ -700,6 +700,14 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+// the streaming norm passes are VALU-bound before they are HBM-bound (~30 VALU per element with a true division and per-value bf16 round
+// trips): pairwise rounding through one v_cvt_pk_bf16_f32, exp2 + v_rcp_f32 instead of expf + division (the result is rounded to bf16 next)
+__device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ void round_bf16_pair(float& a, float& b) {
+    const uint32_t p = pack_bf16x2(a, b);
+    a = bf16lo_to_f32(p);
+    b = bf16hi_to_f32(p);
+}
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, long V, int C, const float* __restrict__ stats,
                                                        const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
@@ -723,15 +731,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
             const int g = (cv * 8 + j) / cg;
             mu[j] = stats[2 * g]; rs[j] = stats[2 * g + 1];
         }
+        float ga[8], gb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ga[j] = rs[j] * gm[j]; gb[j] = bt[j] - mu[j] * ga[j]; }
         for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long)gridDim.x * 256) {
             const uint4 raw = *(const uint4*)(x + v * 8);
             const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
             uint32_t o[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float a = round_bf16((bf16lo_to_f32(u[i]) - mu[2 * i]) * rs[2 * i] * gm[2 * i] + bt[2 * i]);
-                float b = round_bf16((bf16hi_to_f32(u[i]) - mu[2 * i + 1]) * rs[2 * i + 1] * gm[2 * i + 1] + bt[2 * i + 1]);
-                if (apply_silu) { a = silu_f(a); b = silu_f(b); }
+                float a = fmaf(bf16lo_to_f32(u[i]), ga[2 * i], gb[2 * i]), b = fmaf(bf16hi_to_f32(u[i]), ga[2 * i + 1], gb[2 * i + 1]);
+                if (apply_silu) {
+                    round_bf16_pair(a, b);
+                    a = silu_fast(a); b = silu_fast(b);
+                }
                 o[i] = pack_bf16x2(a, b);
             }
             *(uint4*)(y + v * 8) = uint4{o[0], o[1], o[2], o[3]};
@@ -817,7 +830,7 @@ __global__ __launch_bounds__(256) void spatialnorm_row_kernel(const bf16_t* __re
     if (split_first) tz = (t_ == 0) ? 0 : 1 + (int)(((long)(t_ - 1) * (Tz - 1)) / (T - 1));
     else tz = (int)(((long)t_ * Tz) / T);
     const int hz = (int)(((long)h_ * Hz) / H);
-    for (int w = tid; w < W; w += 256) wzs[w] = (int)(((long)w * Wz) / W);
+    for (int w = tid; w < W; w += 256) wzs[w] = (w * Wz) / W;          // W <= 2048, Wz <= W: 32-bit
     __syncthreads();
     const int vpr = C >> 3, cg = C / GN_GROUPS;
     const int cv = tid % vpr, wstep = 256 / vpr;
@@ -836,6 +849,10 @@ __global__ __launch_bounds__(256) void spatialnorm_row_kernel(const bf16_t* __re
             mu[j] = stats[2 * g]; rs[j] = stats[2 * g + 1];
         }
     }
+    // GroupNorm affine folded per channel: (x - mu) rs g + b = x (rs g) + (b - mu rs g)
+    float ga[8], gb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ga[j] = rs[j] * gm[j]; gb[j] = bt[j] - mu[j] * ga[j]; }
     const bf16_t* frow = f + ((long)(t_ * H + h_) * W) * C + cv * 8;
     bf16_t* yrow = y + ((long)(t_ * H + h_) * W) * C + cv * 8;
     const long zbase = ((long)tz * Hz + hz) * Wz;
@@ -847,11 +864,15 @@ __global__ __launch_bounds__(256) void spatialnorm_row_kernel(const bf16_t* __re
         uint32_t o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float n0 = round_bf16((bf16lo_to_f32(u[i]) - mu[2 * i]) * rs[2 * i] * gm[2 * i] + bt[2 * i]);
-            const float n1 = round_bf16((bf16hi_to_f32(u[i]) - mu[2 * i + 1]) * rs[2 * i + 1] * gm[2 * i + 1] + bt[2 * i + 1]);
-            float a = round_bf16(n0 * bf16lo_to_f32(yu[i])) + bf16lo_to_f32(zu[i]);
-            float b = round_bf16(n1 * bf16hi_to_f32(yu[i])) + bf16hi_to_f32(zu[i]);
-            if (apply_silu) { a = silu_f(round_bf16(a)); b = silu_f(round_bf16(b)); }
+            float a = fmaf(bf16lo_to_f32(u[i]), ga[2 * i], gb[2 * i]), b = fmaf(bf16hi_to_f32(u[i]), ga[2 * i + 1], gb[2 * i + 1]);
+            round_bf16_pair(a, b);                                   // GroupNorm output is a bf16 tensor in the reference
+            a *= bf16lo_to_f32(yu[i]); b *= bf16hi_to_f32(yu[i]);
+            round_bf16_pair(a, b);                                   // norm_f * conv_y(zq)
+            a += bf16lo_to_f32(zu[i]); b += bf16hi_to_f32(zu[i]);
+            if (apply_silu) {
+                round_bf16_pair(a, b);                               // ... + conv_b(zq)
+                a = silu_fast(a); b = silu_fast(b);
+            }
             o[i] = pack_bf16x2(a, b);
         }
         *(uint4*)(yrow + (long)w * C) = uint4{o[0], o[1], o[2], o[3]};

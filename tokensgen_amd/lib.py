@@ -32,6 +32,7 @@ PROTOTYPES = {
     "tg_attention_fwd_multi": [_vp, _i, _i, _i, _f, _i, _vp],
     "tg_attention_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l,
                          _i, _i, _i, _i, _f, _i, _vp, _vp],
+    "tg_vpred_loss_grad": [_vp, _vp, _vp, _vp, _i, _l, _f, _vp, _vp, _vp],
     "tg_timestep_sinusoid": [_vp, _i, _i, _vp, _vp],
     "tg_rope_table_3d": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "tg_patchify": [_vp, _vp, _l, _i, _i, _i, _i, _i, _vp],
@@ -69,6 +70,8 @@ def load():
         fn.restype = C.c_int
     lib.tg_groupnorm_partial_floats.argtypes = [C.c_long, C.c_int]
     lib.tg_groupnorm_partial_floats.restype = C.c_long
+    lib.tg_vpred_loss_partial_floats.argtypes = [C.c_int, C.c_long]
+    lib.tg_vpred_loss_partial_floats.restype = C.c_long
     lib.tg_attention_bwd_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.tg_attention_bwd_ws_floats.restype = C.c_long
     lib.tg_conv3d_splitk_floats.argtypes = [C.c_int] * 9
