@@ -142,6 +142,13 @@ typedef struct tg_attn_segment {
     const void* k; long k_ld, k_strideB;
     const void* vt; long vt_ld;
     int nk;
+    /* Optional (0 = unknown): an upper bound B on |q_i . k_j| in the units the kernel exponentiates (log2 domain; with k_prescaled the
+     * plain dot product).  The softmax is shift invariant, so when every segment of a k_prescaled launch carries a bound with 2 B < 96
+     * the kernel subtracts the CONSTANT B instead of a running row maximum — no per-tile max / rescale (the row-max chain was 15 % of the
+     * launch at the CogVideoX-5B shape) and no overflow or underflow is possible: s - B lies in [-2B, 0].  For this model the bound is
+     * static: q and k leave a per-head LayerNorm(64) (||x_hat|| <= 8) with affine (g, b) and a norm-preserving rotation, so
+     * |q . k| <= (8 max|g_q| + ||b_q||) (8 max|g_k| + ||b_k||) * out_scale_k.  Larger or missing bounds take the running-max path. */
+    float score_bound;
 } tg_attn_segment;
 typedef struct tg_attn_problem {
     tg_attn_segment seg[2];
@@ -219,6 +226,25 @@ int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void* k, long k_
                      float* dq, long dq_ld, long dq_sb, float* dk, long dk_ld, long dk_sb, float* dv, long dv_ld, long dv_sb,
                      int nq, int nk, int heads, int batch, float scale, int accumulate, float* ws, hipStream_t stream);
 long tg_attention_bwd_ws_floats(int nq, int heads, int batch);
+
+/* Backward of tg_qk_layernorm_rope (y = rope(bf16(LN64(x) g + b)) * out_scale; attention_processor.py:2031-2056) for the trainable vip_norm_q /
+ * vip_norm_k and the projections behind them.  x: the PRE-norm projection output (bf16, element (b, t, h, d) at x[b*strideB + t*ld + h*64 + d]);
+ * dy: gradient w.r.t. y (fp32, same indexing with dy_ld / dy_strideB); dx: gradient w.r.t. x (bf16).  Rotary segments as in the forward.
+ * partial: tg_qk_layernorm_rope_bwd_partial_floats floats = [blocks][2][64] per-block sums of (dL/dg, dL/db); the caller adds the blocks. */
+int tg_qk_layernorm_rope_bwd(const void* x, long ld, long strideB, const float* dy, long dy_ld, long dy_strideB, void* dx, long dx_ld,
+                             long dx_strideB, int tokens, int heads, int batch, const void* ln_weight, float eps, int start0, int len0,
+                             const float* cos0, const float* sin0, int start1, int len1, const float* cos1, const float* sin1,
+                             float out_scale, float* partial, hipStream_t stream);
+long tg_qk_layernorm_rope_bwd_partial_floats(int tokens, int heads, int batch);
+
+/* dst[c][r] = src[r][c] (bf16), r < rows; columns rows..rows_pad-1 of dst are written as zeros.  Weight gradients through tg_gemm_bf16
+ * (C = A W^T, both operands K-contiguous): dW[out][in] = dY^T X = tg_gemm(A = dY^T [out][tokens], W = X^T [in][tokens]) with the token axis
+ * padded to the GEMM's K granule; input gradients dX = dY W = tg_gemm(A = dY, W = W^T). */
+int tg_transpose_2d(const void* src, long ld, int rows, int cols, void* dst, long ld_dst, int rows_pad, hipStream_t stream);
+
+/* Bias gradients: partial[blk][c] = sum of src[r][c] over the block's 256 rows (bf16 in, fp32 out; tg_colsum_partial_floats floats). */
+int tg_colsum(const void* src, long ld, int rows, int cols, float* partial, hipStream_t stream);
+long tg_colsum_partial_floats(int rows, int cols);
 
 /* Training loss of the To2V step and its gradient w.r.t. the model output (train_cogvideo_to2v.py:1995-2004; get_velocity
  * scheduling_dpm_cogvideox.py:521-538), per frame f (per-frame timesteps) over frame_elems elements:

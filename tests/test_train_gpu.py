@@ -122,3 +122,98 @@ def test_vpred_loss_and_gradient_vs_autograd():
     loss.backward()
     l3, _, grad3 = train.vpred_loss_and_grad(out.to(DEV), noisy.to(DEV), x0.to(DEV), ts1, ac)
     assert abs(l3.item() - loss.item()) < 2e-3 * abs(loss.item()) and _rel(grad3, o.grad) < 1e-2
+
+
+def _rope_tables(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    ang = torch.rand(n, 32, generator=g) * 6.28
+    return ang.cos().repeat_interleave(2, dim=1).float().contiguous(), ang.sin().repeat_interleave(2, dim=1).float().contiguous()
+
+
+def test_qk_layernorm_rope_backward_and_linear_backward_vs_autograd():
+    """tg_qk_layernorm_rope_bwd (per-head LayerNorm + interleaved-pair RoPE, two rotary segments + un-rotated text rows, output scale) and the
+    GEMM weight / bias / input gradients (tg_transpose_2d + tg_gemm_bf16 + tg_colsum) against autograd of the fp32 restatement."""
+    from oracle import dit_ref as O
+    from tokensgen_amd import train
+    B, T, H, Nt, n0 = 2, 90, 3, 11, 50
+    D = H * 64
+    x = _rand(B, T, D, seed=1, scale=1.3)
+    dy = _rand(B, T, D, seed=2).float()
+    gw, gb = (_rand(64, seed=3, scale=0.2).float() + 1).to(BF), _rand(64, seed=4, scale=0.2)
+    r0, r1 = _rope_tables(n0, 5), _rope_tables(T - Nt - n0, 6)
+    xf, wf, bfv = x.float().clone().requires_grad_(True), gw.float().clone().requires_grad_(True), gb.float().clone().requires_grad_(True)
+    xh = xf.view(B, T, H, 64).transpose(1, 2)
+    ln = torch.nn.functional.layer_norm(xh, (64,), wf, bfv, 1e-6)
+    y = torch.cat([ln[:, :, :Nt], O.apply_rope(ln[:, :, Nt:Nt + n0], r0), O.apply_rope(ln[:, :, Nt + n0:], r1)], dim=2) * 0.37
+    (y.transpose(1, 2).reshape(B, T, D) * dy).sum().backward()
+    dx, dg, db = train.qk_layernorm_rope_backward(x.to(DEV), dy.to(DEV), H, gw.to(DEV), 1e-6, (Nt, tuple(t.to(DEV) for t in r0)),
+                                                 (Nt + n0, tuple(t.to(DEV) for t in r1)), out_scale=0.37)
+    assert _rel(dx, xf.grad) < 6e-3 and _rel(dg, wf.grad) < 2e-3 and _rel(db, bfv.grad) < 2e-3
+    # linear backward
+    M, cin, cout = 333, 192, 256
+    xi, dyo, w = _rand(M, cin, seed=7), _rand(M, cout, seed=8), _rand(cout, cin, seed=9, scale=0.1)
+    dW, dbias, dxi = train.linear_backward(xi.to(DEV), dyo.to(DEV), w.to(DEV), need_dx=True)
+    assert _rel(dW, dyo.float().t() @ xi.float()) < 4e-3
+    assert _rel(dbias, dyo.float().sum(0)) < 1e-3
+    assert _rel(dxi, dyo.float() @ w.float()) < 4e-3
+
+
+def test_vip_processor_trainable_parameter_gradients_vs_autograd_of_the_oracle():
+    """End of the chain for the attention sub-block: from the gradient of the processor's pre-`to_out` output to the gradients of every TRAINABLE
+    processor parameter (vip_to_{q,k,v}.{weight,bias}, vip_norm_{q,k}.{weight,bias}; cogvideox_transformer_3d.py:207-218, train_cogvideo_to2v.py:
+    1456-1481) — HIP forward pieces (projection GEMM, QK-norm+RoPE, attention) + tg_attention_bwd + tg_qk_layernorm_rope_bwd + GEMM wgrad —
+    against autograd through oracle.dit_ref.vip_attention's arithmetic in fp32 on the same bf16-rounded weights and inputs."""
+    import numpy as np
+    from oracle import dit_ref as O
+    from tokensgen_amd import kernels as K
+    from tokensgen_amd import lib as L
+    from tokensgen_amd import train
+    B, H, Nt, Nv, Np = 2, 2, 9, 120, 30
+    D, N1, N = H * 64, 9 + 120, 9 + 120 + 30
+    f32 = np.float32
+    cfg = dict(num_attention_heads=H, attention_head_dim=64, num_layers=1, patch_size=2, time_embed_dim=128, text_embed_dim=64, in_channels=16, out_channels=16)
+    sd = {k: v.to(BF).float() for k, v in O.make_state_dict(cfg, n_vip_dim=128, seed=51, std=0.08).items() if k.startswith("transformer_blocks.0.attn1.")}
+    pre = "transformer_blocks.0.attn1"
+    P = pre + ".processor"
+    train_keys = [f"{P}.vip_to_{n}.{wb}" for n in "qkv" for wb in ("weight", "bias")] + [f"{P}.vip_norm_{n}.{wb}" for n in "qk" for wb in ("weight", "bias")]
+    for k in train_keys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    hidden, enc = _rand(B, Nv, D, seed=52), _rand(B, Nt + Np, D, seed=53)
+    rope = O.rope_3d(64, np.arange(4, dtype=f32), np.arange(5, dtype=f32), np.arange(6, dtype=f32))
+    vrope = O.rope_3d(64, np.arange(4, dtype=f32) + f32(3), np.arange(5, dtype=f32), np.arange(6, dtype=f32))
+    crope = O.rope_3d(64, np.linspace(1000, 1016.25, 5, dtype=f32), np.arange(2, dtype=f32), np.arange(3, dtype=f32))
+    taps = {}
+    # the oracle's processor without its final to_out: re-run its arithmetic up to the concatenated attention output
+    sd_no_out = dict(sd)
+    sd_no_out[pre + ".to_out.0.weight"], sd_no_out[pre + ".to_out.0.bias"] = torch.eye(D), torch.zeros(D)
+    oh, oe = O.vip_attention(sd_no_out, pre, hidden.float(), enc.float(), H, Np, [0.6], rope, vrope, crope, taps=taps)
+    ao_ref = torch.cat([oe[:, :Nt], oh, oe[:, Nt:]], dim=1)                      # text | video | vip rows
+    G = _rand(B, N, D, seed=54)
+    (ao_ref * G.float()).sum().backward()
+    # ---- HIP: forward pieces with the pre-norm projections kept, then the backward chain ----
+    dev = lambda t: t.detach().to(BF).to(DEV).contiguous()
+    xn = torch.cat([enc[:, :Nt], hidden, enc[:, Nt:]], dim=1).to(DEV)          # the processor's inputs in residual-stream row order
+    Wv = torch.cat([dev(sd[f"{P}.vip_to_{n}.weight"]) for n in "qkv"]); bv = torch.cat([dev(sd[f"{P}.vip_to_{n}.bias"]) for n in "qkv"])
+    Wb = torch.cat([dev(sd[f"{pre}.to_{n}.weight"]) for n in "qkv"]); bb = torch.cat([dev(sd[f"{pre}.to_{n}.bias"]) for n in "qkv"])
+    qkvv_pre = torch.empty(B, N, 3 * D, dtype=BF, device=DEV); K.gemm(xn, Wv, bv, qkvv_pre, L.EPI_BIAS)
+    qkv = torch.empty(B, N1, 3 * D, dtype=BF, device=DEV); K.gemm(xn[:, :N1].contiguous(), Wb, bb, qkv, L.EPI_BIAS)
+    qkvv = qkvv_pre.clone()
+    tab = lambda r: tuple(t.to(DEV) for t in r)
+    K.qk_layernorm_rope(qkv[:, :, :D], H, dev(sd[pre + ".norm_q.weight"]), dev(sd[pre + ".norm_q.bias"]), 1e-6, (Nt, tab(rope)))
+    K.qk_layernorm_rope(qkv[:, :, D:2 * D], H, dev(sd[pre + ".norm_k.weight"]), dev(sd[pre + ".norm_k.bias"]), 1e-6, (Nt, tab(rope)))
+    gq, bq_, gk, bk_ = (dev(sd[f"{P}.vip_norm_{n}.{wb}"]) for n in "qk" for wb in ("weight", "bias"))
+    K.qk_layernorm_rope(qkvv[:, :, :D], H, gq, bq_, 1e-6, (Nt, tab(vrope)), (N1, tab(crope)))
+    K.qk_layernorm_rope(qkvv[:, :, D:2 * D], H, gk, bk_, 1e-6, (Nt, tab(vrope)), (N1, tab(crope)))
+    sl = lambda t, a, b_, c: t[:, a:b_, c * D:(c + 1) * D]
+    q, k, v = (sl(qkv, 0, N1, c) for c in range(3))
+    qx, kx, vx = (sl(qkvv, 0, N1, c) for c in range(3))
+    qv, kv, vv = (sl(qkvv, N1, N, c) for c in range(3))
+    merge = lambda o: o.transpose(1, 2).reshape(B, -1, D)
+    o1, o2, o3 = (dev(merge(taps[n])) for n in ("o1", "o2", "o3"))               # the saved forward outputs (bf16)
+    Gd = G.to(DEV)
+    d_out = torch.cat([Gd[:, :N1], Gd[:, N1:]], dim=1)                          # gradient of cat(O1 + s O2, O3) in row order text|video | vip
+    grads = train.to2v_attention_backward(q, k, v, qx, kx, vx, qv, kv, vv, o1, o2, o3, d_out, H, 1.0 / math.sqrt(64), 0.6)
+    got = train.vip_projection_backward(xn, qkvv_pre, grads, H, Nt, N1, gq, gk, tab(vrope), tab(crope))
+    for name, g_ in got.items():
+        want = sd[f"{P}.{name}"].grad
+        assert _rel(g_, want) < 3e-2, name

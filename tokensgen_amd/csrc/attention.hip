@@ -20,6 +20,7 @@
 //   * blocks are ordered so that the 8 XCDs work on different (batch, head) pairs: one head's K/V
 //     (4.5 MB at N=17776) stays resident in that XCD's 4 MiB L2 while its query tiles stream by.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 #include "tokensgen_hip.h"
@@ -34,6 +35,7 @@ struct Seg {
     const bf16_t* k; long k_ld, k_sb;
     const bf16_t* vt; long vt_ld;
     int nk;
+    float bound;        // FIXEDM kernels: the constant subtracted from every score (bf16-representable upper bound on |q . k|)
 };
 struct AttnParams {
     Seg s[2];
@@ -320,7 +322,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #endif
 __device__ long long tg_attn_dbg[16];   // TG_ATTN_TIMING: cycles {X work, X barrier wait, Y work, Y barrier wait} of block 0, waves 0 and 4
 
-template <bool PRESCALED, bool TIMING = false>
+// FIXEDM 1: every score has the segment's constant `bound` subtracted instead of a running row maximum (tg_attn_segment.score_bound);
+// FIXEDM 2: bounds below 40 need no shift at all — P = 2^s stays within 2^+-40 — so the four MFMAs that seed the accumulators go too
+template <bool PRESCALED, bool TIMING = false, int FIXEDM = 0>
 __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
     // K[2], Vt[2] tiles (32 KiB) + the output staging area: 8 waves x 64 query rows x 128 B (64 KiB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -401,7 +405,8 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         bf16x8 ones = {0, 0, 0, 0, 0, 0, 0, 0}, negm[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
         if (hi == 0) {
             ones[0] = (bf16_t)0x3F80;
-            if (PRESCALED) negm[0][0] = negm[1][0] = (bf16_t)0x4680;      // +2^14 = -m
+            if (FIXEDM == 1) negm[0][0] = negm[1][0] = f32_to_bf16(-S.bound);  // the constant shift (bf16-representable by construction)
+            else if (PRESCALED) negm[0][0] = negm[1][0] = (bf16_t)0x4680; // +2^14 = -m
         }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             // tile's true row max — upward OR downward, so rows whose scores all sit below -126 do not underflow to l = 0 — with no
             // first-tile test in the hot loop (an explicit `t == 0` there cost 1.5-2 %).  Price: the first tile's 64 scores are
             // formed as s + 2^14 in fp32, i.e. to 2^-9 absolute (0.14 % on their weights, below the bf16 rounding of P).
-            m[qb] = PRESCALED ? -16384.f : -1e30f;
+            m[qb] = FIXEDM == 2 ? 0.f : FIXEDM == 1 ? S.bound : PRESCALED ? -16384.f : -1e30f;
             l[qb] = 0.f;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
@@ -492,10 +497,10 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             };
 #pragma unroll
             for (int i = 0; i < NFR; ++i) ld(i);
-            if (PRESCALED) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (PRESCALED && FIXEDM != 2) {
                 // seed S with -m through the matrix pipe: ones[key][k=0] x negm[k=0][query] = -m[query] in every register of
                 // the lane's row, 4 MFMAs that run under the first fragments' ds_read latency (no 64 v_mov per tile)
-                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
                     if (g < 4) acc_o[qb][xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % NFR], pf[qb][g], acc_o[qb][xb], 0, 0, 0);
-                    else sc[qb][xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % NFR], qf[qb][g - 4], sc[qb][xb], 0, 0, 0);
+                    else sc[qb][xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % NFR], qf[qb][g - 4], (FIXEDM == 2 && g == 4) ? z : sc[qb][xb], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (i + NFR < 16) ld(i + NFR);
@@ -540,6 +545,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         auto softmax = [&]() {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
+              if constexpr (FIXEDM == 0) {
                 // row max: two independent v_max3 chains (one per key block), halves joined by v_permlane32_swap (no LDS trip);
                 float ma = vmax3(sc[qb][0][0], sc[qb][0][1], sc[qb][0][2]);
                 float mb = vmax3(sc[qb][1][0], sc[qb][1][1], sc[qb][1][2]);
@@ -554,6 +560,9 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
                     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
                     mx = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
                 }
+#ifdef TG_ABL_NOMAX          // timing-only ablation (wrong results): no row max
+                mx = 0.f;
+#endif
                 if (PRESCALED) {
                     if (__any(mx > RESCALE_THR)) {                       // rare: the row max grew by more than 2^THR
                         const float m_new = round_bf16(m[qb] + fmaxf(mx, 0.f));
@@ -584,6 +593,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
                             for (int r = 0; r < 16; ++r) acc_o[qb][db][r] *= alpha;
                     }
                 }
+              }
                 const float mq = m[qb];
                 // row sums as packed f32 adds: plain v_add_f32 on two chains measured slower here (8.94 vs 8.63 ms)
                 f32x2 ls2[4];          // one row-sum chain per k-step: no dependent packed adds back to back
@@ -593,7 +603,11 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
                     const int kb = ks >> 1, rb = (ks & 1) * 8;
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
+#ifdef TG_ABL_NOEXP          // timing-only ablation (wrong results): a full-rate VALU op in place of the transcendental
+                        e[ks][i] = sc[qb][kb][rb + i] * 0.25f;
+#else
                         e[ks][i] = PRESCALED ? __builtin_amdgcn_exp2f(sc[qb][kb][rb + i]) : __builtin_amdgcn_exp2f(sc[qb][kb][rb + i] * p.scale_log2 - mq);
+#endif
                 }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
@@ -602,6 +616,9 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
                     for (int i = 0; i < 4; ++i) pk.u[i] = pack_bf16x2(e[ks][2 * i], e[ks][2 * i + 1]);
                     pf[qb][ks] = pk.v;
                 }
+#ifdef TG_ABL_NOSUM          // timing-only ablation (wrong results): no row sums
+                l[qb] += e[0][0];
+#else
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) ls2[ks] = f32x2{e[ks][0], e[ks][1]};
 #pragma unroll
@@ -610,6 +627,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
                     for (int ks = 0; ks < 4; ++ks) ls2[ks] += f32x2{e[ks][2 * i], e[ks][2 * i + 1]};
                 const f32x2 lsum = (ls2[0] + ls2[1]) + (ls2[2] + ls2[3]);
                 l[qb] += lsum[0] + lsum[1];
+#endif
             }
         };
 
@@ -769,6 +787,23 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
         TG_LAUNCH_CHECK(who);
         return TG_OK;
     }
+    // constant-shift softmax: every segment in the launch carries a usable bound (s - B in [-2B, 0] must stay far from the fp32 / bf16
+    // exponent limits: 2B < 96).  TG_ATTN_FIXEDM=0 forces the running-max path.
+    // 0: always the running max; 1 (default): constant shift through the seed MFMAs; 2: additionally the no-shift kernel for bounds < 40 —
+    // measured SLOWER than 1 (7.51 vs 7.10 ms in the DiT step, 7.59 for the running max): the four seed MFMAs sit under the first fragment
+    // reads' latency, and without them the matrix segment starts with a stall
+    static const int fixedm_on = [] { const char* e = getenv("TG_ATTN_FIXEDM"); return e ? atoi(e) : 1; }();
+    bool fixedm = fixedm_on && p.prescaled && pp && !timing;
+    auto usable = [&](Seg& S) {
+        if (!(S.bound > 0.f) || !(2.f * S.bound < 96.f)) return false;
+        uint32_t u;                                        // round UP to a bf16-representable value: the MFMA seed is then exactly -bound
+        memcpy(&u, &S.bound, 4);
+        if (u & 0xffffu) u = (u + 0x10000u) & 0xffff0000u;
+        memcpy(&S.bound, &u, 4);
+        return true;
+    };
+    for (int sg = 0; sg < p.nseg && fixedm; ++sg) fixedm = usable(p.s[sg]);
+    if (fixedm && p.r_nq > 0) fixedm = usable(p.r_s);
     p.main_wgs = (int)wg512;
     const long grid512 = wg512 + (p.r_nq > 0 ? (long)((p.r_nq + 511) / 512) * heads * batch : 0);
     constexpr size_t PP_LDS = 4 * TILE_B + 8 * 8192;
@@ -776,6 +811,8 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
         (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         return true;
     }();
     (void)pp_attr;
@@ -785,6 +822,12 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(tg_attn_dbg), sizeof(h));
         fprintf(stderr, "[tg_attention timing] g0: X %lld Xwait %lld Y %lld Ywait %lld | g1: X %lld Xwait %lld Y %lld Ywait %lld (s_memtime ticks, seg 0)\n",
                 h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    } else if (pp && fixedm) {
+        float bmax = p.s[0].bound;
+        if (p.nseg == 2) bmax = fmaxf(bmax, p.s[1].bound);
+        if (p.r_nq > 0) bmax = fmaxf(bmax, p.r_s.bound);
+        if (bmax < 40.f && fixedm_on == 2) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 2>), dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
+        else hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1>), dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
     } else if (pp) {
         if (p.prescaled) hipLaunchKernelGGL(attn_fwd_pp_kernel<true>, dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
         else hipLaunchKernelGGL(attn_fwd_pp_kernel<false>, dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
@@ -808,7 +851,7 @@ static int fill_segment(Seg& S, const tg_attn_segment& g, const char* what) {
     TG_REQUIRE(g.q_ld % 8 == 0 && g.k_ld % 8 == 0 && g.vt_ld % 64 == 0 && g.q_strideB % 8 == 0 && g.k_strideB % 8 == 0 && tg_aligned16(g.q) &&
                tg_aligned16(g.k) && tg_aligned16(g.vt), TG_ERR_ALIGN, "tg_attention: %s alignment", what);
     TG_REQUIRE(g.vt_ld >= ((g.nk + 63) / 64) * 64, TG_ERR_SHAPE, "tg_attention: %s: vt_ld must cover nk rounded up to 64", what);
-    S = Seg{(const bf16_t*)g.q, g.q_ld, g.q_strideB, (const bf16_t*)g.k, g.k_ld, g.k_strideB, (const bf16_t*)g.vt, g.vt_ld, g.nk};
+    S = Seg{(const bf16_t*)g.q, g.q_ld, g.q_strideB, (const bf16_t*)g.k, g.k_ld, g.k_strideB, (const bf16_t*)g.vt, g.vt_ld, g.nk, g.score_bound};
     return TG_OK;
 }
 
@@ -846,11 +889,11 @@ extern "C" int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
     TG_REQUIRE(q1 && k1 && vt1 && out, TG_ERR_ARG, "tg_attention_fwd: null pointer");
     TG_REQUIRE(nq > 0 && nk1 > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_attention_fwd: bad shape nq=%d nk1=%d", nq, nk1);
     tg_attn_problem A{};
-    A.seg[0] = tg_attn_segment{q1, q1_ld, q1_strideB, k1, k1_ld, k1_strideB, vt1, vt1_ld, nk1};
+    A.seg[0] = tg_attn_segment{q1, q1_ld, q1_strideB, k1, k1_ld, k1_strideB, vt1, vt1_ld, nk1, 0.f};
     A.nseg = 1;
     if (q2) {
         TG_REQUIRE(k2 && vt2 && nk2 > 0, TG_ERR_ARG, "tg_attention_fwd: segment 2 incomplete");
-        A.seg[1] = tg_attn_segment{q2, q2_ld, q2_strideB, k2, k2_ld, k2_strideB, vt2, vt2_ld, nk2};
+        A.seg[1] = tg_attn_segment{q2, q2_ld, q2_strideB, k2, k2_ld, k2_strideB, vt2, vt2_ld, nk2, 0.f};
         A.nseg = 2;
     }
     A.seg2_scale = seg2_scale;

@@ -253,9 +253,10 @@ def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, acc
     _, _, _, gld, gsb = _bmk(dout)
     assert HD == heads * 64 and o.shape == q.shape == dout.shape and v.shape == k.shape
     f32 = torch.float32
-    dq = torch.empty(B, nq, HD, dtype=f32, device=q.device) if dq is None else _chk(dq, "dq", f32)
-    dk = torch.empty(B, nk, HD, dtype=f32, device=q.device) if dk is None else _chk(dk, "dk", f32)
-    dv = torch.empty(B, nk, HD, dtype=f32, device=q.device) if dv is None else _chk(dv, "dv", f32)
+    new = torch.zeros if accumulate else torch.empty       # accumulate adds to the buffer: a fresh one must start at zero
+    dq = new(B, nq, HD, dtype=f32, device=q.device) if dq is None else _chk(dq, "dq", f32)
+    dk = new(B, nk, HD, dtype=f32, device=q.device) if dk is None else _chk(dk, "dk", f32)
+    dv = new(B, nk, HD, dtype=f32, device=q.device) if dv is None else _chk(dv, "dv", f32)
     ws = torch.empty(L.load().tg_attention_bwd_ws_floats(nq, heads, B), dtype=f32, device=q.device)
     L.check(_launch("attention_bwd", L.load().tg_attention_bwd, _p(q), qld, qsb, _p(k), kld, ksb, _p(v), vld, vsb, _p(o), old, osb, _p(dout), gld, gsb,
                     _p(dq), dq.stride(1), dq.stride(0), _p(dk), dk.stride(1), dk.stride(0), _p(dv), dv.stride(1), dv.stride(0), nq, nk, heads, B,
@@ -263,7 +264,7 @@ def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, acc
     return dq, dk, dv
 
 
-def _attn_problem(q1, k1, vt1, nk1, out, q2=None, k2=None, vt2=None, nk2=0, seg2_scale=0.0):
+def _attn_problem(q1, k1, vt1, nk1, out, q2=None, k2=None, vt2=None, nk2=0, seg2_scale=0.0, bound1=0.0, bound2=0.0):
     import ctypes
     for n, t in (("q1", q1), ("k1", k1), ("vt1", vt1), ("out", out)):
         _chk(t, n)
@@ -271,13 +272,13 @@ def _attn_problem(q1, k1, vt1, nk1, out, q2=None, k2=None, vt2=None, nk2=0, seg2
     B, nq, _, qld, qsb = _bmk(q1)
     _, _, _, kld, ksb = _bmk(k1)
     _, _, _, old, osb = _bmk(out)
-    pr.seg[0] = L.AttnSegment(_p(q1), qld, qsb, _p(k1), kld, ksb, _p(vt1), vt1.stride(2), nk1)
+    pr.seg[0] = L.AttnSegment(_p(q1), qld, qsb, _p(k1), kld, ksb, _p(vt1), vt1.stride(2), nk1, float(bound1))
     pr.nseg = 1
     if q2 is not None:
         _chk(q2, "q2"); _chk(k2, "k2"); _chk(vt2, "vt2")
         _, _, _, q2ld, q2sb = _bmk(q2)
         _, _, _, k2ld, k2sb = _bmk(k2)
-        pr.seg[1] = L.AttnSegment(_p(q2), q2ld, q2sb, _p(k2), k2ld, k2sb, _p(vt2), vt2.stride(2), nk2)
+        pr.seg[1] = L.AttnSegment(_p(q2), q2ld, q2sb, _p(k2), k2ld, k2sb, _p(vt2), vt2.stride(2), nk2, float(bound2))
         pr.nseg = 2
     pr.seg2_scale = float(seg2_scale)
     pr.out, pr.out_ld, pr.out_strideB, pr.nq = _p(out), old, osb, nq
@@ -286,7 +287,8 @@ def _attn_problem(q1, k1, vt1, nk1, out, q2=None, k2=None, vt2=None, nk2=0, seg2
 
 def attention_multi(main, rider, heads, scale, k_prescaled=False):
     """One launch for two attention problems of the same heads/batch (tg_attention_fwd_multi).  main / rider: dicts of the
-    keyword arguments of `attention` (q1, k1, vt1, nk1, out [, q2, k2, vt2, nk2, seg2_scale]); the rider has one key segment."""
+    keyword arguments of `attention` (q1, k1, vt1, nk1, out [, q2, k2, vt2, nk2, seg2_scale, bound1, bound2]); the rider has one key segment.
+    bound1 / bound2: optional upper bounds on |q . k| per segment (tg_attn_segment.score_bound): the constant-shift softmax path."""
     import ctypes
     pa, B = _attn_problem(**main)
     pb, B2 = _attn_problem(**rider)

@@ -32,6 +32,9 @@ PROTOTYPES = {
     "tg_attention_fwd_multi": [_vp, _i, _i, _i, _f, _i, _vp],
     "tg_attention_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l,
                          _i, _i, _i, _i, _f, _i, _vp, _vp],
+    "tg_qk_layernorm_rope_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _vp, _f, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _vp, _vp],
+    "tg_transpose_2d": [_vp, _l, _i, _i, _vp, _l, _i, _vp],
+    "tg_colsum": [_vp, _l, _i, _i, _vp, _vp],
     "tg_vpred_loss_grad": [_vp, _vp, _vp, _vp, _i, _l, _f, _vp, _vp, _vp],
     "tg_timestep_sinusoid": [_vp, _i, _i, _vp, _vp],
     "tg_rope_table_3d": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
@@ -70,6 +73,10 @@ def load():
         fn.restype = C.c_int
     lib.tg_groupnorm_partial_floats.argtypes = [C.c_long, C.c_int]
     lib.tg_groupnorm_partial_floats.restype = C.c_long
+    lib.tg_qk_layernorm_rope_bwd_partial_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.tg_qk_layernorm_rope_bwd_partial_floats.restype = C.c_long
+    lib.tg_colsum_partial_floats.argtypes = [C.c_int, C.c_int]
+    lib.tg_colsum_partial_floats.restype = C.c_long
     lib.tg_vpred_loss_partial_floats.argtypes = [C.c_int, C.c_long]
     lib.tg_vpred_loss_partial_floats.restype = C.c_long
     lib.tg_attention_bwd_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -93,7 +100,7 @@ class AttnSegment(C.Structure):
     """tg_attn_segment (include/tokensgen_hip.h)"""
     _fields_ = [("q", C.c_void_p), ("q_ld", C.c_long), ("q_strideB", C.c_long),
                 ("k", C.c_void_p), ("k_ld", C.c_long), ("k_strideB", C.c_long),
-                ("vt", C.c_void_p), ("vt_ld", C.c_long), ("nk", C.c_int)]
+                ("vt", C.c_void_p), ("vt_ld", C.c_long), ("nk", C.c_int), ("score_bound", C.c_float)]
 
 
 class AttnProblem(C.Structure):

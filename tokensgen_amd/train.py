@@ -56,3 +56,104 @@ def to2v_attention_backward(q, k, v, qx, kx, vx, qv, kv, vv, o1, o2, o3, d_out, 
     dkc[:, N1:], dvc[:, N1:] = dkv, dvv
     dqv, _, _ = K.attention_bwd(qv, torch.cat([kx, kv], 1), torch.cat([vx, vv], 1), o3, d_out[:, N1:], heads, sm_scale, dk=dkc, dv=dvc, accumulate=True)
     return dict(q=dq, k=dk, v=dv, qx=dqx, kx=dkc[:, :N1], vx=dvc[:, :N1], qv=dqv, kv=dkc[:, N1:], vv=dvc[:, N1:])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# projection / norm backward around the attention (the trainable vip_to_{q,k,v}, vip_norm_{q,k}: cogvideox_transformer_3d.py:207-218)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def transpose_2d(src, rows_pad=None):
+    """bf16 [R, C] (row stride may exceed C) -> [C, rows_pad] with zero columns R.. (tg_transpose_2d)."""
+    K._chk(src, "src")
+    R, C_ = src.shape
+    rp = R if rows_pad is None else rows_pad
+    dst = torch.empty(C_, rp, dtype=BF16, device=src.device)
+    L.check(L.load().tg_transpose_2d(src.data_ptr(), src.stride(0), R, C_, dst.data_ptr(), rp, rp, K._stream()), "tg_transpose_2d")
+    return dst
+
+
+def colsum(src):
+    """fp32 [C] column sums of a bf16 [R, C] matrix (tg_colsum + a fixed-order sum of the per-block partials)."""
+    K._chk(src, "src")
+    R, C_ = src.shape
+    lib = L.load()
+    part = torch.empty(lib.tg_colsum_partial_floats(R, C_), dtype=torch.float32, device=src.device)
+    L.check(lib.tg_colsum(src.data_ptr(), src.stride(0), R, C_, part.data_ptr(), K._stream()), "tg_colsum")
+    return part.view(-1, C_).sum(dim=0)
+
+
+def linear_backward(x2d, dy2d, weight=None, need_dx=False):
+    """y = x W^T + b with W [out, in]:  dW = dy^T x (bf16, through the MFMA GEMM with both operands transposed so the token axis is the
+    contiguous reduction axis), db = column sums of dy (fp32), dx = dy W (bf16, only when asked).  x2d [M, in], dy2d [M, out] bf16."""
+    M, cin = x2d.shape
+    cout = dy2d.shape[1]
+    Mp, cin_p, cout_p = _pad_to(M, 64), _pad_to(cin, 128), _pad_to(cout, 64)     # the GEMM wants N % 128 == 0 and K % 64 == 0
+    dyT = transpose_2d(dy2d, Mp)                                                 # [out, Mp]
+    xT = torch.zeros(cin_p, Mp, dtype=BF16, device=x2d.device) if cin_p != cin else None
+    if xT is None:
+        xT = transpose_2d(x2d, Mp)                                               # [in, Mp]
+    else:
+        L.check(L.load().tg_transpose_2d(x2d.data_ptr(), x2d.stride(0), M, cin, xT.data_ptr(), Mp, Mp, K._stream()), "tg_transpose_2d")
+    dWp = torch.empty(cout, cin_p, dtype=BF16, device=x2d.device)
+    K.gemm(dyT, xT, None, dWp, L.EPI_BIAS)                                       # dW[o, i] = sum_m dy[m, o] x[m, i]
+    dW = dWp[:, :cin]
+    db = colsum(dy2d)
+    dx = None
+    if need_dx:
+        wT = torch.zeros(cin_p, cout_p, dtype=BF16, device=x2d.device)            # W^T [in, out], zero padded
+        L.check(L.load().tg_transpose_2d(weight.data_ptr(), weight.stride(0), cout, cin, wT.data_ptr(), cout_p, cout_p, K._stream()), "tg_transpose_2d")
+        dyp = dy2d if cout_p == cout else torch.nn.functional.pad(dy2d, (0, cout_p - cout))
+        dxp = torch.empty(M, cin_p, dtype=BF16, device=x2d.device)
+        K.gemm(dyp, wT, None, dxp, L.EPI_BIAS)                                   # dx[m, i] = sum_o dy[m, o] W[o, i]
+        dx = dxp[:, :cin]
+    return dW, db, dx
+
+
+def qk_layernorm_rope_backward(x_pre, dy, heads, ln_weight, eps, seg0=None, seg1=None, out_scale=1.0):
+    """Backward of kernels.qk_layernorm_rope.  x_pre: the PRE-norm projection [B, T, heads*64] bf16 (a column slice of the fused QKV buffer
+    is fine); dy fp32 [B, T, heads*64].  Returns (dx bf16 contiguous, dgamma fp32 [64], dbeta fp32 [64])."""
+    K._chk(x_pre, "x_pre"); K._chk(dy, "dy", torch.float32)
+    B, T, HD, ld, sb = K._bmk(x_pre)
+    assert HD == heads * 64 and dy.shape == x_pre.shape
+
+    def unpack(seg):
+        if seg is None:
+            return 0, 0, None, None
+        start, (cos, sin) = seg
+        return int(start), int(cos.shape[0]), cos, sin
+    s0, l0, c0, n0 = unpack(seg0)
+    s1, l1, c1, n1 = unpack(seg1)
+    dx = torch.empty(B, T, HD, dtype=BF16, device=x_pre.device)
+    lib = L.load()
+    part = torch.empty(lib.tg_qk_layernorm_rope_bwd_partial_floats(T, heads, B), dtype=torch.float32, device=x_pre.device)
+    L.check(lib.tg_qk_layernorm_rope_bwd(x_pre.data_ptr(), ld, sb, dy.data_ptr(), dy.stride(1), dy.stride(0), dx.data_ptr(), dx.stride(1), dx.stride(0),
+                                         T, heads, B, ln_weight.data_ptr(), float(eps), s0, l0, K._p(c0), K._p(n0), s1, l1, K._p(c1), K._p(n1),
+                                         float(out_scale), part.data_ptr(), K._stream()), "tg_qk_layernorm_rope_bwd")
+    sums = part.view(-1, 2, 64).sum(dim=0)
+    return dx, sums[0], sums[1]
+
+
+@torch.no_grad()
+def vip_projection_backward(xn_all, qkvv_pre, grads, heads, Nt, N1, vip_norm_q_w, vip_norm_k_w, vip_rope, cond_rope):
+    """From the attention gradients of the vip-weight branch to the gradients of the TRAINABLE processor parameters.
+    xn_all [B, N, D] bf16: the normalised inputs (text | video | vip rows) the projection read; qkvv_pre [B, N, 3D] bf16: its raw output
+    (before vip_norm_q / vip_norm_k and RoPE); grads: to2v_attention_backward(...) (fp32, UNSCALED keys: the training forward keeps the softmax
+    scale in the attention call).  Returns dict: vip_to_{q,k,v}.{weight,bias}, vip_norm_{q,k}.{weight,bias}."""
+    B, N, D = xn_all.shape
+    f32 = torch.float32
+    dq = torch.cat([grads["qx"], grads["qv"]], dim=1).contiguous()            # rows: text+video (x-branch) | vip tokens
+    dk = torch.cat([grads["kx"], grads["kv"]], dim=1).contiguous()
+    dv = torch.cat([grads["vx"], grads["vv"]], dim=1)
+    segs = ((Nt, vip_rope), (N1, cond_rope))
+    dq_pre, dgq, dbq = qk_layernorm_rope_backward(qkvv_pre[:, :, :D], dq, heads, vip_norm_q_w, 1e-6, *segs)
+    dk_pre, dgk, dbk = qk_layernorm_rope_backward(qkvv_pre[:, :, D:2 * D], dk, heads, vip_norm_k_w, 1e-6, *segs)
+    d_pre = torch.cat([dq_pre, dk_pre, dv.to(BF16)], dim=2).view(B * N, 3 * D)
+    dW, db, _ = linear_backward(xn_all.reshape(B * N, D), d_pre)
+    out = {}
+    for j, n in enumerate(("q", "k", "v")):
+        out[f"vip_to_{n}.weight"], out[f"vip_to_{n}.bias"] = dW[j * D:(j + 1) * D], db[j * D:(j + 1) * D]
+    out["vip_norm_q.weight"], out["vip_norm_q.bias"], out["vip_norm_k.weight"], out["vip_norm_k.bias"] = dgq, dbq, dgk, dbk
+    return out

@@ -167,6 +167,7 @@ class CogVideoXTransformer3DModel(nn.Module):
         self._fused = {}          # name -> storage tensor
         self._views = []          # (holder module, attr, fused name, row slice, shape)
         self._ws = {}
+        self._bounds = None
         D = num_attention_heads * attention_head_dim
         self.inner_dim = D
         self.patch_embed = _PatchEmbed()
@@ -283,6 +284,7 @@ class CogVideoXTransformer3DModel(nn.Module):
             raise NotImplementedError("tokensgen_amd kernels are bf16-only")
         self._device = any_t.device
         self._ws = {}
+        self._bounds = None
         return self
 
     @property
@@ -333,6 +335,7 @@ class CogVideoXTransformer3DModel(nn.Module):
             self._fused[p + "vln"][0].fill_(1.0); self._fused[p + "vln"][2].fill_(1.0)
         self._build_mod_storage()
         self._ws = {}
+        self._bounds = None
         if vip_ckpt_dir is not None:
             path = os.path.join(vip_ckpt_dir, "vip.pt")
             if not os.path.exists(path):
@@ -363,6 +366,34 @@ class CogVideoXTransformer3DModel(nn.Module):
         for fn in files:
             m.load_state_dict(load_file(os.path.join(d, fn)), strict=False)
         return m
+
+    # ------------------------------------------------------------------------------------------ score bounds
+    def _score_bounds(self, kscale):
+        """Per layer, an upper bound on |q . k| in the units the attention kernel exponentiates (K carries kscale = softmax scale * log2 e):
+        q and k leave a per-head LayerNorm(64) — ||x_hat||_2 <= 8 — with affine (g, b) and a rotation that preserves the norm, so
+        ||q|| <= 8 max|g_q| + ||b_q|| and likewise for k (2 % margin for the bf16 roundings).  With such a bound the kernel subtracts a
+        CONSTANT instead of tracking the row maximum (tg_attn_segment.score_bound).  One device->host read per weight load; the softmax
+        is shift invariant, so a bound that has gone stale after an in-place weight update can cost range, never correctness."""
+        if self._bounds is None:
+            L_ = len(self.transformer_blocks)
+
+            def bound(name):
+                if f"l0.{name}" not in self._fused:
+                    return [0.0] * L_
+                w = torch.stack([self._fused[f"l{i}.{name}"] for i in range(L_)]).float()          # [L, 4, 64]: q.w, q.b, k.w, k.b
+                nq = 8.0 * w[:, 0].abs().amax(dim=1) + w[:, 1].norm(dim=1)
+                nk = 8.0 * w[:, 2].abs().amax(dim=1) + w[:, 3].norm(dim=1)
+                return (nq * nk * (1.02 * kscale)).tolist()
+            self._bounds = (bound("qknorm"), bound("vqknorm"))
+        return self._bounds
+
+    def invalidate_score_bounds(self):
+        self._bounds = None
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._bounds = None
+        return r
 
     # ------------------------------------------------------------------------------------------ workspace
     def _workspace(self, B, Nt, Nv, Np, Fm):
@@ -501,9 +532,10 @@ class CogVideoXTransformer3DModel(nn.Module):
             s = float(s)
             # text+video rows: softmax(q k^T) v  +  s * softmax(qx kv^T) vv   (attention_processor.py:2066-2069,2117-2134)
             # vip rows: qv against cat(kx, kv) / cat(vx, vv)                  (:2120-2125) — rides in the main launch's last round
+            b1, b2 = self._score_bounds(kscale)
             K.attention_multi(dict(q1=ws.QKV[:, :, :D], k1=ws.QKV[:, :, D:2 * D], vt1=ws.Vt1, nk1=N1, out=ws.AO[:, :N1],
-                                   q2=ws.QKVv[:, :N1, :D], k2=ws.QKVv[:, N1:, D:2 * D], vt2=vt2, nk2=Np, seg2_scale=s),
-                              dict(q1=ws.QKVv[:, N1:, :D], k1=ws.QKVv[:, :, D:2 * D], vt1=ws.Vt3, nk1=N, out=ws.AO[:, N1:]),
+                                   q2=ws.QKVv[:, :N1, :D], k2=ws.QKVv[:, N1:, D:2 * D], vt2=vt2, nk2=Np, seg2_scale=s, bound1=b1[i], bound2=b2[i]),
+                              dict(q1=ws.QKVv[:, N1:, :D], k1=ws.QKVv[:, :, D:2 * D], vt1=ws.Vt3, nk1=N, out=ws.AO[:, N1:], bound1=b2[i]),
                               H, sm_scale, k_prescaled=True)
         else:
             K.attention(ws.QKV[:, :, :D], ws.QKV[:, :, D:2 * D], ws.Vt1, N1, ws.AO[:, :N1], H, sm_scale, k_prescaled=True)
