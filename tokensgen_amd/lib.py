@@ -55,6 +55,17 @@ PROTOTYPES = {
     "tg_tile_blend": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
 }
 
+# name -> argtypes of the `long tg_*_floats(...)` workspace-size queries
+QUERIES = {
+    "tg_groupnorm_partial_floats": [C.c_long, C.c_int],
+    "tg_conv3d_gn_partial_floats": [C.c_int, C.c_int, C.c_int],
+    "tg_conv3d_splitk_floats": [C.c_int] * 9,
+    "tg_attention_bwd_ws_floats": [C.c_int, C.c_int, C.c_int],
+    "tg_qk_layernorm_rope_bwd_partial_floats": [C.c_int, C.c_int, C.c_int],
+    "tg_colsum_partial_floats": [C.c_int, C.c_int],
+    "tg_vpred_loss_partial_floats": [C.c_int, C.c_long],
+}
+
 _lib = None
 
 
@@ -71,20 +82,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.argtypes = argtypes
         fn.restype = C.c_int
-    lib.tg_groupnorm_partial_floats.argtypes = [C.c_long, C.c_int]
-    lib.tg_groupnorm_partial_floats.restype = C.c_long
-    lib.tg_qk_layernorm_rope_bwd_partial_floats.argtypes = [C.c_int, C.c_int, C.c_int]
-    lib.tg_qk_layernorm_rope_bwd_partial_floats.restype = C.c_long
-    lib.tg_colsum_partial_floats.argtypes = [C.c_int, C.c_int]
-    lib.tg_colsum_partial_floats.restype = C.c_long
-    lib.tg_vpred_loss_partial_floats.argtypes = [C.c_int, C.c_long]
-    lib.tg_vpred_loss_partial_floats.restype = C.c_long
-    lib.tg_attention_bwd_ws_floats.argtypes = [C.c_int, C.c_int, C.c_int]
-    lib.tg_attention_bwd_ws_floats.restype = C.c_long
-    lib.tg_conv3d_splitk_floats.argtypes = [C.c_int] * 9
-    lib.tg_conv3d_splitk_floats.restype = C.c_long
-    lib.tg_conv3d_gn_partial_floats.argtypes = [C.c_int, C.c_int, C.c_int]
-    lib.tg_conv3d_gn_partial_floats.restype = C.c_long
+    for name, argtypes in QUERIES.items():   # workspace-size queries: pure host functions returning a count of floats
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_long
     lib.tg_version.restype = C.c_char_p
     lib.tg_last_error_string.restype = C.c_char_p
     _lib = lib
