@@ -275,27 +275,41 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
 
 // Split-K epilogue: sum the ksplit fp32 partial tensors in a fixed order, then exactly what conv3d_cl_kernel's own epilogue does (bias, the
 // reference's bf16 rounding before the residual add, bf16 store, per-128-voxel-tile GroupNorm sums of the stored values).  One workgroup per
-// 128-voxel tile over ALL output channels; cout == cout_pad in {128, 256, 512}.
+// (128-voxel tile, 128-channel slab) — a slab holds whole GroupNorm groups (cout / 32 <= 16 channels each) — so a 30 x 45 latent tile's 512-channel
+// layer runs 88-128 workgroups of 16 row passes; the first version (one workgroup per voxel tile over all channels, 64 serial passes of 8
+// dependent loads) took 110 us per call on the tile's critical path.  cout == cout_pad in {128, 256, 512}.
+template <int KS>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ kpart, int ksplit, long M, int cout,
                                                                  const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual,
                                                                  bf16_t* __restrict__ y, long ldy, float* __restrict__ gn_partial) {
     __shared__ float red[256][2];
     const int tid = threadIdx.x;
-    const int nq = cout >> 2;                       // channel quads per voxel: 32 / 64 / 128
-    const int cq = tid % nq, rl = tid / nq, rstep = 256 / nq;
-    const int n = cq * 4;
+    const int cq = tid & 31, rl = tid >> 5;         // 32 channel quads = 128 channels, 8 rows per pass
+    const int n = blockIdx.y * 128 + cq * 4;
     const long m0 = (long)blockIdx.x * BM;
     float b4[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias) {
         const uint2 bb = *(const uint2*)(bias + n);
         b4[0] = bf16lo_to_f32(bb.x); b4[1] = bf16hi_to_f32(bb.x); b4[2] = bf16lo_to_f32(bb.y); b4[3] = bf16hi_to_f32(bb.y);
     }
+    const long plane = M * cout;
     float gs = 0.f, gq = 0.f;
-    for (int r = rl; r < BM; r += rstep) {
+    for (int r = rl; r < BM; r += 8) {
         const long m = m0 + r;
         if (m >= M) break;
-        f32x4 v = *(const f32x4*)(kpart + m * cout + n);
-        for (int sp = 1; sp < ksplit; ++sp) v += *(const f32x4*)(kpart + ((long)sp * M + m) * cout + n);
+        const float* src = kpart + m * cout + n;
+        f32x4 part[KS > 0 ? KS : 1];
+        f32x4 v;
+        if constexpr (KS > 0) {                     // all partial loads in flight together, summed in the fixed order 0, 1, 2, ...
+#pragma unroll
+            for (int sp = 0; sp < KS; ++sp) part[sp] = *(const f32x4*)(src + sp * plane);
+            v = part[0];
+#pragma unroll
+            for (int sp = 1; sp < KS; ++sp) v += part[sp];
+        } else {
+            v = *(const f32x4*)src;
+            for (int sp = 1; sp < ksplit; ++sp) v += *(const f32x4*)(src + sp * plane);
+        }
         float u[4] = {v[0] + b4[0], v[1] + b4[1], v[2] + b4[2], v[3] + b4[3]};
         if (residual) {
             const uint2 rr = *(const uint2*)(residual + m * ldy + n);
@@ -313,13 +327,13 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
     if (!gn_partial) return;
     red[tid][0] = gs; red[tid][1] = gq;
     __syncthreads();
-    if (tid < 2 * GN_GROUPS) {                      // fixed order: quads of the group, then the row lanes
-        const int stat = tid / GN_GROUPS, g = tid % GN_GROUPS;
-        const int qpg = (cout / GN_GROUPS) >> 2;
+    const int cg = cout / GN_GROUPS, qpg = cg >> 2, gps = 128 / cg;      // channels per group, quads per group, groups per 128-channel slab
+    if (tid < 2 * gps) {                            // fixed order: quads of the group, then the 8 row lanes
+        const int stat = tid / gps, gl = tid % gps;
         float a = 0.f;
         for (int qd = 0; qd < qpg; ++qd)
-            for (int r = 0; r < rstep; ++r) a += red[r * nq + g * qpg + qd][stat];
-        gn_partial[(long)blockIdx.x * 2 * GN_GROUPS + stat * GN_GROUPS + g] = a;
+            for (int r = 0; r < 8; ++r) a += red[r * 32 + gl * qpg + qd][stat];
+        gn_partial[(long)blockIdx.x * 2 * GN_GROUPS + stat * GN_GROUPS + blockIdx.y * gps + gl] = a;
     }
 }
 
@@ -1041,8 +1055,17 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
         TG_REQUIRE(splitk_ws, TG_ERR_ARG, "tg_conv3d_cl: this shape runs split-K (tg_conv3d_splitk_floats > 0) and needs the workspace");
         p.kpart = splitk_ws;
         hipLaunchKernelGGL((conv3d_cl_kernel<2, 4, 4>), dim3((unsigned)(tiles * p.ksplit)), dim3(256), 2 * STAGE_BYTES, stream, p);
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((M + BM - 1) / BM)), dim3(256), 0, stream, (const float*)splitk_ws, p.ksplit, M, cout,
-                           (const bf16_t*)bias, (const bf16_t*)residual, (bf16_t*)y, ldy, gn_partial);
+        const dim3 rgrid((unsigned)((M + BM - 1) / BM), (unsigned)(cout / 128));
+#define TG_SPLITK_REDUCE(KS)                                                                                                                \
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel<KS>, rgrid, dim3(256), 0, stream, (const float*)splitk_ws, p.ksplit, M, cout, (const bf16_t*)bias, \
+                       (const bf16_t*)residual, (bf16_t*)y, ldy, gn_partial)
+        switch (p.ksplit) {
+            case 2: TG_SPLITK_REDUCE(2); break;
+            case 4: TG_SPLITK_REDUCE(4); break;
+            case 8: TG_SPLITK_REDUCE(8); break;
+            default: TG_SPLITK_REDUCE(0); break;
+        }
+#undef TG_SPLITK_REDUCE
         TG_LAUNCH_CHECK("tg_conv3d_cl(split-K)");
         return TG_OK;
     }

@@ -250,7 +250,7 @@ class AutoencoderKLCogVideoX:
         if kt > 1:
             need = kt - 1
             if x.shape[0] >= need:
-                cache[name] = x[-need:].clone()
+                cache[name] = x[-need:]            # a view: x (a fresh norm output / staging tensor) is never written again — no copy launch per conv
             else:
                 head = prev if prev is not None else x[:1].expand(need, -1, -1, -1)
                 cache[name] = torch.cat([head, x], dim=0)[-need:].contiguous()
