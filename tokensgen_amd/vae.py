@@ -133,6 +133,16 @@ class AutoencoderKLCogVideoX:
                 b = torch.zeros(2 * Cp, dtype=BF16, device=self.device)
                 b[:C], b[Cp:Cp + C] = self._sd[base + ".conv_y.conv.bias"], self._sd[base + ".conv_b.conv.bias"]
                 self._packed[base + ".yb.weight"], self._packed[base + ".yb.bias"] = w, b
+        # ... and ALL SpatialNorm layers of the decoder -> one [sum 2*Cpad, 64] weight: every one of them reads the same latent tile, so one
+        # GEMM per (tile, temporal batch) replaces 37 small ones (43 us each on the tile's critical path, 1 400 launches per clip)
+        names = [k[: -len(".yb.weight")] for k in self._packed if k.endswith(".yb.weight")]
+        self._yb_off, off = {}, 0
+        for nme in names:
+            self._yb_off[nme] = off
+            off += self._packed[nme + ".yb.weight"].shape[0]
+        if names:
+            self._packed["yb_all.weight"] = torch.cat([self._packed[nme + ".yb.weight"] for nme in names]).contiguous()
+            self._packed["yb_all.bias"] = torch.cat([self._packed[nme + ".yb.bias"] for nme in names]).contiguous()
         return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
 
 
@@ -262,13 +272,18 @@ class AutoencoderKLCogVideoX:
             stats = K.groupnorm_stats(x.view(-1, x.shape[-1]), self.config.norm_eps)
         if zq is None:
             return K.groupnorm_silu(x, stats, self._sd[name + ".weight"], self._sd[name + ".bias"], silu)
-        z64, zdims = zq                                    # latent tile, channels-last padded to 64: [Vz, 64]
-        w, b = self._packed[name + ".yb.weight"], self._packed[name + ".yb.bias"]
-        yb = torch.empty(z64.shape[0], w.shape[0], dtype=BF16, device=x.device)
-        K.gemm(z64, w, b, yb, L.EPI_BIAS)                 # conv_y(z) | conv_b(z) per latent voxel (1x1x1 conv commutes with nearest resize)
-        Cp = w.shape[0] // 2
-        return K.spatialnorm_silu(x, stats, self._sd[name + ".norm_layer.weight"], self._sd[name + ".norm_layer.bias"], yb[:, :Cp], yb[:, Cp:],
-                                  zdims, silu)
+        z64, zdims, yb_all = zq                            # latent tile [Vz, 64] (channels-last, padded), its dims, conv_y|conv_b of every norm layer
+        off, Cp = self._yb_off[name], self._packed[name + ".yb.weight"].shape[0] // 2
+        return K.spatialnorm_silu(x, stats, self._sd[name + ".norm_layer.weight"], self._sd[name + ".norm_layer.bias"],
+                                  yb_all[:, off:off + Cp], yb_all[:, off + Cp:off + 2 * Cp], zdims, silu)
+
+    def _spatialnorm_tables(self, z64):
+        """conv_y(z) | conv_b(z) per LATENT voxel for all SpatialNorm layers at once (a 1x1x1 conv commutes with the nearest resize of zq,
+        autoencoder_kl_cogvideox.py:171-188): [Vz, sum 2*Cpad] bf16."""
+        w, b = self._packed["yb_all.weight"], self._packed["yb_all.bias"]
+        yb = torch.empty(z64.shape[0], w.shape[0], dtype=BF16, device=z64.device)
+        K.gemm(z64, w, b, yb, L.EPI_BIAS)
+        return yb
 
     def _resnet(self, name, x, zq, cache):
         """CogVideoXResnetBlock3D.forward (:277-309): the `+ inputs` is the second conv's epilogue."""
@@ -350,7 +365,8 @@ class AutoencoderKLCogVideoX:
         for a, b in self._frame_batches(Tt, self.num_latent_frames_batch_size if decode else self.num_sample_frames_batch_size):
             if decode:
                 z64 = K.ncdhw_to_cl(src, a, b - a, i, Hc, j, Wc, 64)
-                y = self._decoder(z64, (z64.view(-1, 64), (b - a, Hc, Wc)), cache)
+                z2 = z64.view(-1, 64)
+                y = self._decoder(z64, (z2, (b - a, Hc, Wc), self._spatialnorm_tables(z2)), cache)
             else:
                 y = self._encoder(K.ncdhw_to_cl(src, a, b - a, i, Hc, j, Wc, 64), cache)
             outs.append(y)
