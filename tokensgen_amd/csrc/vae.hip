@@ -31,6 +31,7 @@ struct ConvParams {
     int To, Ho, Wo;
     const bf16_t* zeros;
     float* gn_partial;    // optional [tiles_m][2][32]: per-tile GroupNorm(32) sums / sums of squares of the STORED bf16 values
+    int order;            // 4-wave kernels: 1 = temporal-locality tile order (see conv3d_w4_kernel)
     int ksplit;           // > 1: the (tap, channel) reduction is cut into ksplit ranges, one workgroup each; raw fp32 sums go to kpart
     float* kpart;         // [ksplit][M][cout_pad] fp32 (conv_splitk_reduce_kernel adds them in a fixed order and runs the epilogue)
 };
@@ -374,9 +375,30 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
 
     const long M = (long)p.To * p.Ho * p.Wo;
     const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = p.cout_pad / NT;
-    const int nwg = tiles_m * tiles_n;
-    const int t = xcd_remap(blockIdx.x, nwg);
-    const int tn = t % tiles_n, tm = t / tiles_n;     // n fastest: the tiles_n blocks sharing an A tile run on one XCD
+    int tn, tm;
+    if (p.order) {
+        // Temporal-locality tile order.  The linear voxel index is frame-major, so "contiguous chunk of tiles per XCD" gave every XCD ONE
+        // frame: the causal taps (frames t-2, t-1, t) of the same rows were then fetched by three different XCDs' L2s, and PMC showed
+        // 5-6x the algorithmic HBM-side bytes on these launches.  Here an XCD's consecutive workgroups walk (chunk of G tiles ~ 2048 voxels
+        // of a frame) x (all frames) x (tile in chunk): a spatial stripe through all frames stays in one L2.  Frames are the ranges
+        // [b_t, b_t+1) of the linear tile index (b_t = t * tiles_m / F); the grid is padded to F * Jmax and the <= F - 1 empty slots exit.
+        constexpr int G = 2048 / TM;
+        const int F = p.To, Jmax = (tiles_m + F - 1) / F;
+        const int o_all = xcd_remap(blockIdx.x, F * Jmax * tiles_n);
+        tn = o_all % tiles_n;
+        const int o = o_all / tiles_n;
+        const int full = Jmax / G;
+        int c = o / (F * G), rem, gw;
+        if (c < full) { rem = o - c * F * G; gw = G; }
+        else { c = full; rem = o - full * F * G; gw = Jmax - full * G; }
+        const int tf = rem / gw, j = c * G + (rem - tf * gw);
+        const int b0 = (int)((long)tf * tiles_m / F), b1 = (int)((long)(tf + 1) * tiles_m / F);
+        if (j >= b1 - b0) return;                     // padded slot (workgroup-uniform, before any barrier)
+        tm = b0 + j;
+    } else {
+        const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+        tn = t % tiles_n; tm = t / tiles_n;           // n fastest: the tiles_n blocks sharing an A tile run on one XCD
+    }
     const long m0 = (long)tm * TM;
     const int n0 = tn * NT;
     const int Kw = p.kt * p.kh * p.kw * p.Cin;        // row length of the packed weights
@@ -1002,7 +1024,7 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
     TG_REQUIRE(tg_aligned16(x) && tg_aligned16(w) && tg_aligned16(zeros) && (!cache || tg_aligned16(cache)) && (((uintptr_t)y) & 1) == 0 &&
                (cout % 4 != 0 || ((((uintptr_t)y) & 7) == 0 && ldy % 4 == 0)), TG_ERR_ALIGN, "tg_conv3d_cl: alignment");
     ConvParams p{(const bf16_t*)x, T, H, W, Cin, (const bf16_t*)cache, (const bf16_t*)w, (const bf16_t*)bias, cout, cout_pad, kt, kh, kw,
-                 stride, pad, up, t_map, (const bf16_t*)residual, (bf16_t*)y, ldy, To, Ho, Wo, (const bf16_t*)zeros, gn_partial, 1, nullptr};
+                 stride, pad, up, t_map, (const bf16_t*)residual, (bf16_t*)y, ldy, To, Ho, Wo, (const bf16_t*)zeros, gn_partial, 0, 1, nullptr};
     TG_REQUIRE(!gn_partial || (cout == cout_pad && cout % BN == 0 && (cout / GN_GROUPS) % 4 == 0), TG_ERR_SHAPE,
                "tg_conv3d_cl: fused GroupNorm sums need cout in {128, 256, 512, ...} (cout=%d)", cout);
     const long M = (long)To * Ho * Wo;
@@ -1020,6 +1042,10 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
     // 4-wave kernel: 256x256 tiles need enough of them to fill the chip (>= 2 per CU; the 512-channel layers of the VAE have 128 and stay on
     // the 128x128 kernel: measured 161 vs 142 ms there, 226 vs 248 ms on the 256-channel layers).  TG_CONV_W4=0: never, 2: whenever legal
     static const int w4 = [] { const char* e = getenv("TG_CONV_W4"); return e ? atoi(e) : 1; }();
+    // 1: temporal-locality tile order in the 4-wave kernels.  Measured NEUTRAL (256->256 layers 200.2 vs 199.9 ms, 128->128 182.9 vs 182.2 ms per
+    // decode): the 5-6x algorithmic HBM-side bytes PMC shows for these launches are absorbed behind L2 (MALL) and their latency is already
+    // hidden — the Cout = 128 kernel is bound by the L2 -> LDS fill (39 of the ~43 B/clk/CU the path delivers), not by misses.  Off by default.
+    static const int conv_order = [] { const char* e = getenv("TG_CONV_ORDER"); return e ? atoi(e) : 0; }();
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -1030,7 +1056,9 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
         To < 512 && Ho < 2048 && Wo < 2048 && (long)kt * kh * kw * Cin < (1L << 21) && (long)(T + 2) * H * W * Cin < (1L << 31)) {
         static bool attr4 = false;
         if (!attr4) { (void)hipFuncSetAttribute((const void*)conv3d_w4_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS); attr4 = true; }
-        const long tiles4 = ((M + 255) / 256) * (cout / 256);
+        long tiles4 = ((M + 255) / 256) * (cout / 256);
+        p.order = conv_order && To > 1;
+        if (p.order) tiles4 = (long)To * (((M + 255) / 256 + To - 1) / To) * (cout / 256);
         hipLaunchKernelGGL(conv3d_w4_kernel<256>, dim3((unsigned)tiles4), dim3(256), CW_LDS, stream, p);
         TG_LAUNCH_CHECK("tg_conv3d_cl(w4)");
         return TG_OK;
@@ -1043,7 +1071,9 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
         constexpr int LDS_N = 2 * (512 * 128 + 128 * 128);
         static bool attrn = false;
         if (!attrn) { (void)hipFuncSetAttribute((const void*)conv3d_w4_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_N); attrn = true; }
-        hipLaunchKernelGGL(conv3d_w4_kernel<128>, dim3((unsigned)((M + 511) / 512)), dim3(256), LDS_N, stream, p);
+        p.order = conv_order && To > 1;
+        const long tiles5 = p.order ? (long)To * (((M + 511) / 512 + To - 1) / To) : (M + 511) / 512;
+        hipLaunchKernelGGL(conv3d_w4_kernel<128>, dim3((unsigned)tiles5), dim3(256), LDS_N, stream, p);
         TG_LAUNCH_CHECK("tg_conv3d_cl(w4n)");
         return TG_OK;
     }
