@@ -243,7 +243,7 @@ def test_conv_4wave_kernel_bitwise_equals_128_kernel(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for mode in ("0", "2"):
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_w4_check.py"), str(tmp_path)], env=dict(os.environ, TG_CONV_W4=mode, TG_CONV_W4N=mode, TG_CONV_SPLITK="0"),
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_w4_check.py"), str(tmp_path)], env=dict(os.environ, TG_CONV_W4=mode, TG_CONV_W4N=mode, TG_CONV_SPLITK="0", TG_CONV_HALO="0"),
                            capture_output=True, text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "vs mode 0" in r.stdout and "bitwise False" not in r.stdout
@@ -325,3 +325,18 @@ def test_splitk_conv_small_m(ci, co, T, H, W):
     torch.testing.assert_close(yr.gn_stats, K.groupnorm_stats(yr.view(-1, co), 1e-6), rtol=2e-5, atol=2e-6)
     y2 = K.conv3d_cl(xc, wp, bd, co, 3, 3, 3, gn_stats_eps=1e-6)
     assert torch.equal(y, y2) and torch.equal(y.gn_stats, y2.gn_stats)
+
+
+def test_halo_tiled_conv_kernel(tmp_path):
+    """conv3d_halo_kernel (Cout = 128, 3x3 spatial taps: an 8 x 32 output patch per workgroup, the 10 x 34 input halo staged once per (temporal tap,
+    channel chunk) and read shifted by all nine taps) is picked by default only at launch scale; TG_CONV_HALO=2 forces it whenever legal.  A child
+    process per mode runs tools/conv_halo_check.py: ragged patches, 1 / 2 / 4 channel chunks, 1x3x3 and 3x3x3, replicated first frame and carried
+    cache, residual add, GroupNorm sums from its epilogue, run-to-run bitwise — vs the fp32 oracle and vs the default dispatch's outputs."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("0", "2"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_halo_check.py"), str(tmp_path)], env=dict(os.environ, TG_CONV_HALO=mode),
+                           capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "vs default dispatch" in r.stdout and "ok 2" in r.stdout

@@ -274,6 +274,213 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Halo-tiled convolution for the Cout = 128 layers (the 128-channel resnets at full resolution: a third of the decode, half of the encode).
+// The GEMM-shaped kernels above fetch a fresh [voxels x 64 channels] A tile from L2 for EVERY (tap, channel chunk): with N = 128 the
+// 512 x 128 tile needs 39 B/clk/CU of L2 -> LDS fill at the full MFMA rate, against the ~43 the path delivers — fill-bound at
+// 0.84 PFLOP/s.  Here a workgroup owns an 8 x 32 patch of ONE output frame; for each (temporal tap dt, 64-channel chunk) the 10 x 34 input
+// halo is brought into LDS ONCE and all nine (dh, dw) taps read it shifted: A traffic / 9, the fill drops to ~21 B/clk/CU (weights 16 +
+// halo 4.7).  Halo voxel rows are 144 B apart (128 B of channels + 16 B pad): 16 consecutive voxels x one 16-byte k-slot hit 64 distinct
+// banks, and — unlike an XOR swizzle — the address is LINEAR in the voxel index, so a tap is a workgroup-uniform byte offset: a tap change
+// costs no VALU at all.  The halo arrives by LDS-DMA as 48 pieces of 1 KiB = 7.1 rows each (lane -> (row, slot); the pad slot and
+// out-of-image voxels read the zero page); the source frame of a temporal tap is uniform per workgroup (x, the cache tensor, or frame 0
+// replicated).  4 waves x (64 voxels x 128 channels), MFMA 16x16x32, halo and weight stages double-buffered (128 KiB of LDS); fragment reads
+// are inline asm (a C++ LDS load would make the compiler wait vmcnt(0) for the DMA in flight).
+// ------------------------------------------------------------------------------------------------
+constexpr int HP_H = 8, HP_W = 32, HL_W = HP_W + 2, HL_ROWS = (HP_H + 2) * HL_W;      // 340 halo voxels
+constexpr int HROW = 144;
+constexpr int HALO_PIECES = (HL_ROWS * HROW + 1023) / 1024;                              // 48
+constexpr int HALO_BYTES = HALO_PIECES * 1024;                                           // 49152
+constexpr int HW_BYTES = 128 * 128;                                                      // one weight stage: 128 couts x 64 k
+constexpr int HALO_LDS = 2 * HALO_BYTES + 2 * HW_BYTES;                                  // 131072
+
+__global__ __launch_bounds__(256) void conv3d_halo_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sH = smem;                       // halo[2]
+    char* const sW = smem + 2 * HALO_BYTES;      // W[2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (p.Wo + HP_W - 1) / HP_W, tiles_y = (p.Ho + HP_H - 1) / HP_H;
+    const int ntiles = p.To * tiles_y * tiles_x;
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tf = tile / (tiles_x * tiles_y);
+    const int x0 = tx * HP_W, y0 = ty * HP_H;
+    const int Kw = p.kt * 9 * p.Cin;
+    const int ncc = p.Cin / 64;
+    const long frame = (long)p.H * p.W * p.Cin;
+
+    // ---- halo DMA: this wave's 12 pieces; per lane the element offset of its (voxel, slot) inside a frame, or -1 (pad slot / outside) ----
+    int hoff[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int o = (wave * 12 + i) * 1024 + lane * 16;
+        const int hr = o / HROW, slot = (o - hr * HROW) >> 4;
+        const int hy = hr / HL_W, hx = hr - hy * HL_W;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        hoff[i] = (slot < 8 && hr < HL_ROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? (y * p.W + x) * p.Cin + slot * 8 : -1;
+    }
+    // source frame of temporal tap dt for output frame tf (uniform): x, the cache tensor (frames -(kt-1)..-1), or frame 0 replicated
+    auto frame_base = [&](int dt) -> const bf16_t* {
+        const int tv = tf + dt - (p.kt - 1);
+        if (tv >= 0) return p.x + (long)tv * frame;
+        return p.cache ? p.cache + (long)(tv + p.kt - 1) * frame : p.x;
+    };
+    auto dma_halo = [&](int buf, int g, int i) {          // piece i (0..11) of this wave for group g = dt * ncc + cc
+        const int dt = g / ncc, cc = g - dt * ncc;
+        const bf16_t* src = hoff[i] >= 0 ? frame_base(dt) + hoff[i] + cc * 64 : p.zeros + (lane & 7) * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sH + buf * HALO_BYTES + (wave * 12 + i) * 1024), 16, 0, 0);
+    };
+    // ---- weight DMA: rows [wave*32 + i*8, +8) of the 128 x 64 stage, slots XOR-swizzled by (row >> 1) & 7 like the GEMM tiles ----
+    const bf16_t* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave * 32 + i * 8 + (lane >> 3);
+        wsrc[i] = p.w + (long)r * Kw + (((lane & 7) ^ ((r >> 1) & 7)) * 8);
+    }
+    auto dma_w = [&](int buf, int kidx) {                 // kidx = (dt*9 + tap9) * ncc + cc  -> k offset kidx * 64... (tap-major, chunk-minor)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (long)kidx * 64),
+                                             (__attribute__((address_space(3))) void*)(sW + buf * HW_BYTES + wave * 4096 + i * 1024), 16, 0, 0);
+    };
+    // ---- fragment addresses (LDS byte offsets as 32-bit values: the low half of a flat LDS pointer) ----
+    const uint32_t ldsH = (uint32_t)(uintptr_t)sH, ldsW = (uint32_t)(uintptr_t)sW;
+    uint32_t aoff[4], woff[8][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+        aoff[mi] = (uint32_t)(((2 * wave + (mi >> 1)) * HL_W + (mi & 1) * 16 + (lane & 15)) * HROW + (lane >> 4) * 16);
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int rw = ni * 16 + (lane & 15), sl = ks * 4 + (lane >> 4);
+            woff[ni][ks] = (uint32_t)(rw * 128 + ((sl ^ ((rw >> 1) & 7)) << 4));
+        }
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ngroups = p.kt * ncc;                        // (dt, cc) groups, 9 stages each
+    // prologue: halo of group 0 and the weights of stage 0
+#pragma unroll
+    for (int i = 0; i < 12; ++i) dma_halo(0, 0, i);
+    dma_w(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int st = 0;                                            // global stage counter (weight buffer = st & 1)
+    for (int g = 0; g < ngroups; ++g) {
+        const int dt = g / ncc, cc = g - dt * ncc;
+        const uint32_t hb = ldsH + (uint32_t)((g & 1) * HALO_BYTES);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++st) {
+            // loads of the NEXT stage's weights and a slice of the NEXT group's halo, in flight under this stage's MFMAs
+            const bool last_stage = (g + 1 == ngroups) && tap == 8;
+            if (!last_stage) {
+                const int ntap = tap == 8 ? 0 : tap + 1, ng = tap == 8 ? g + 1 : g;
+                const int ndt = ng / ncc, ncc_ = ng - ndt * ncc;
+                dma_w((st + 1) & 1, (ndt * 9 + ntap) * ncc + ncc_);
+            }
+            if (g + 1 < ngroups) {                         // 12 halo pieces over 9 stages: 2,1,1,2,1,1,2,1,1
+                const int first = tap + tap / 3 + (tap % 3 != 0), cnt = (tap % 3 == 0) ? 2 : 1;
+#pragma unroll
+                for (int i = 0; i < 12; ++i)
+                    if (i >= first && i < first + cnt) dma_halo((g + 1) & 1, g + 1, i);
+            }
+            const uint32_t ha = hb + (uint32_t)(((tap / 3) * HL_W + (tap % 3)) * HROW);
+            const uint32_t wb = ldsW + (uint32_t)((st & 1) * HW_BYTES);
+            bf16x8 fa[2][4], fw[2][8];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[ks][mi]) : "v"(ha + aoff[mi] + (uint32_t)(ks * 64)));
+#pragma unroll
+                for (int ni = 0; ni < 8; ++ni) asm volatile("ds_read_b128 %0, %1" : "=v"(fw[ks][ni]) : "v"(wb + woff[ni][ks]));
+            }
+            // 24 reads in flight; the first 12 (ks = 0) are complete when at most 12 younger ones are outstanding
+            asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fw[0][0]), "+v"(fw[0][1]),
+                         "+v"(fw[0][2]), "+v"(fw[0][3]), "+v"(fw[0][4]), "+v"(fw[0][5]), "+v"(fw[0][6]), "+v"(fw[0][7]));
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][ni], fa[0][mi], acc[ni][mi], 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]), "+v"(fw[1][0]), "+v"(fw[1][1]),
+                         "+v"(fw[1][2]), "+v"(fw[1][3]), "+v"(fw[1][4]), "+v"(fw[1][5]), "+v"(fw[1][6]), "+v"(fw[1][7]));
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1][ni], fa[1][mi], acc[ni][mi], 0, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        (void)dt; (void)cc;
+    }
+
+    // ---- epilogue (the arithmetic of conv3d_cl_kernel's): bias, bf16 rounding before the residual add, bf16 store, GroupNorm sums ----
+    float gs[8], gq[8];
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) gs[ni] = gq[ni] = 0.f;
+    uint2 bq[8];
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) bq[ni] = p.bias ? *(const uint2*)(p.bias + ni * 16 + (lane >> 4) * 4) : uint2{0u, 0u};
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int y = y0 + 2 * wave + (mi >> 1), x = x0 + (mi & 1) * 16 + (lane & 15);
+        if (y >= p.Ho || x >= p.Wo) continue;
+        const long m = ((long)tf * p.Ho + y) * p.Wo + x;
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+            const int n = ni * 16 + (lane >> 4) * 4;
+            float v[4] = {acc[ni][mi][0] + bf16lo_to_f32(bq[ni].x), acc[ni][mi][1] + bf16hi_to_f32(bq[ni].x),
+                          acc[ni][mi][2] + bf16lo_to_f32(bq[ni].y), acc[ni][mi][3] + bf16hi_to_f32(bq[ni].y)};
+            if (p.residual) {
+                const uint2 rr = *(const uint2*)(p.residual + m * p.ldy + n);
+                v[0] = round_bf16(v[0]) + bf16lo_to_f32(rr.x); v[1] = round_bf16(v[1]) + bf16hi_to_f32(rr.x);
+                v[2] = round_bf16(v[2]) + bf16lo_to_f32(rr.y); v[3] = round_bf16(v[3]) + bf16hi_to_f32(rr.y);
+            }
+            uint2 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            *(uint2*)(p.y + m * p.ldy + n) = o;
+            const float r0 = bf16lo_to_f32(o.x), r1 = bf16hi_to_f32(o.x), r2 = bf16lo_to_f32(o.y), r3 = bf16hi_to_f32(o.y);
+            gs[ni] += (r0 + r1) + (r2 + r3);
+            gq[ni] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+        }
+    }
+    if (p.gn_partial) {
+        // Cout = 128: 4 channels per group, so a lane's channel quad IS one group (ni * 4 + (lane >> 4)); 16 voxel lanes -> wave -> workgroup,
+        // every step in a fixed order.  The partial buffer has ceil(V / 128) rows (tg_conv3d_gn_partial_floats) and tg_groupnorm_finalize
+        // sums all of them: tile i writes row i and zeroes row i + ntiles when that exists (ntiles <= rows <= 2 ntiles).
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                gs[ni] += __shfl_xor(gs[ni], off, 64);
+                gq[ni] += __shfl_xor(gq[ni], off, 64);
+            }
+        }
+        float* red = (float*)smem;                        // LDS is idle: the loop ended with a barrier
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) {
+                red[(wave * 32 + ni * 4 + (lane >> 4)) * 2 + 0] = gs[ni];
+                red[(wave * 32 + ni * 4 + (lane >> 4)) * 2 + 1] = gq[ni];
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int stat = tid >> 5, grp = tid & 31;
+            float a = 0.f;
+            for (int w_ = 0; w_ < 4; ++w_) a += red[(w_ * 32 + grp) * 2 + stat];
+            p.gn_partial[(long)tile * 64 + stat * 32 + grp] = a;
+            const long rows = ((long)p.To * p.Ho * p.Wo + BM - 1) / BM;
+            if ((long)tile + ntiles < rows) p.gn_partial[((long)tile + ntiles) * 64 + stat * 32 + grp] = 0.f;
+        }
+    }
+}
+
 // Split-K epilogue: sum the ksplit fp32 partial tensors in a fixed order, then exactly what conv3d_cl_kernel's own epilogue does (bias, the
 // reference's bf16 rounding before the residual add, bf16 store, per-128-voxel-tile GroupNorm sums of the stored values).  One workgroup per
 // (128-voxel tile, 128-channel slab) — a slab holds whole GroupNorm groups (cout / 32 <= 16 channels each) — so a 30 x 45 latent tile's 512-channel
@@ -1062,6 +1269,25 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
         hipLaunchKernelGGL(conv3d_w4_kernel<256>, dim3((unsigned)tiles4), dim3(256), CW_LDS, stream, p);
         TG_LAUNCH_CHECK("tg_conv3d_cl(w4)");
         return TG_OK;
+    }
+    // Cout = 128, 3x3 spatial taps, stride 1, no upsampling: the halo-tiled kernel.  Measured per clip (single stream): Cin = 64 (encoder conv_in)
+    // 13.9 vs 17.2 ms on the 128 x 128 kernel -> used; Cin = 128 (the 128-channel resnets) 192 vs 184 ms on the hand-scheduled 512 x 128 kernel
+    // -> not used: with its simple stage loop (24 fragment reads up front, one barrier per stage) the halo kernel is LDS-bound instead of
+    // fill-bound — 96 KB of fragment reads per 1024 MFMA cycles is 73 % of the LDS pipe and sits in front of the MFMAs rather than under them.
+    // TG_CONV_HALO: 0 never, 1 (default) Cin = 64 only, 2 whenever legal (tests), 3 whenever legal at launch scale.
+    static const int halo_on = [] { const char* e = getenv("TG_CONV_HALO"); return e ? atoi(e) : 1; }();
+    {
+        const long htiles = (long)To * ((Ho + HP_H - 1) / HP_H) * ((Wo + HP_W - 1) / HP_W);
+        const long rows128 = (M + BM - 1) / BM;
+        if (halo_on && cout == 128 && cout_pad == 128 && kh == 3 && kw == 3 && pad == 1 && stride == 1 && up == 1 && !t_map && (kt == 1 || kt == 3) &&
+            To == T && Ho == H && Wo == W && (halo_on == 2 || (htiles >= 2L * n_cu && (halo_on == 3 || Cin == 64))) && htiles <= rows128 && rows128 <= 2 * htiles &&
+            (long)(T + 2) * H * W * Cin < (1L << 31) && htiles < (1L << 31)) {
+            static bool attrh = false;
+            if (!attrh) { (void)hipFuncSetAttribute((const void*)conv3d_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS); attrh = true; }
+            hipLaunchKernelGGL(conv3d_halo_kernel, dim3((unsigned)htiles), dim3(256), HALO_LDS, stream, p);
+            TG_LAUNCH_CHECK("tg_conv3d_cl(halo)");
+            return TG_OK;
+        }
     }
     // Cout = 128: the 512x128 variant (plain 3x3x3 / 1x3x3 convolutions only: 16 A pieces per wave are too many for the general address path)
     static const int w4n = [] { const char* e = getenv("TG_CONV_W4N"); return e ? atoi(e) : 1; }();    // measured: 128->128 layers 203 -> 187 ms (decode), 181 -> 162 ms (encode)
