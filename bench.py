@@ -139,9 +139,9 @@ def cpu_baseline(seconds_budget=150.0):
 VAE_FLOP = {"decode": 3.1e14, "encode": 1.5e14}     # untiled algorithmic count per 49-frame clip; executed = x1.40 (9-tile overlap)
 
 
-def vae_record(device, reps=2):
+def vae_record(device, reps=3):
     """BASELINE config 4 (outside the timed DiT region): 3-D causal VAE decode [1,16,13,60,90] -> [1,3,49,480,720] and encode back,
-    tiling + slicing on like the pipeline, random weights at the real widths.  Wall seconds = best of `reps` after one warm-up."""
+    tiling + slicing on like the pipeline, random weights at the real widths.  Wall seconds = best of `reps` after one warm-up (the first repeat captures the tile graphs)."""
     from tokensgen_amd.vae import AutoencoderKLCogVideoX
     vae = AutoencoderKLCogVideoX(device=device).init_random(seed=1)
     vae.enable_tiling(); vae.enable_slicing()
