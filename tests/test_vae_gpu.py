@@ -328,8 +328,8 @@ def test_splitk_conv_small_m(ci, co, T, H, W):
 
 
 def test_halo_tiled_conv_kernel(tmp_path):
-    """conv3d_halo_kernel (Cout = 128, 3x3 spatial taps: an 8 x 32 output patch per workgroup, the 10 x 34 input halo staged once per (temporal tap,
-    channel chunk) and read shifted by all nine taps) is picked by default only at launch scale; TG_CONV_HALO=2 forces it whenever legal.  A child
+    """conv3d_halo2_kernel (Cout = 128, 3x3 spatial taps: a 16 x 32 output patch per workgroup, the 18 x 34 input halo staged once per (temporal tap,
+    32-channel chunk) and read shifted by all nine taps) is picked by default only at launch scale; TG_CONV_HALO=2 forces it whenever legal.  A child
     process per mode runs tools/conv_halo_check.py: ragged patches, 1 / 2 / 4 channel chunks, 1x3x3 and 3x3x3, replicated first frame and carried
     cache, residual add, GroupNorm sums from its epilogue, run-to-run bitwise — vs the fp32 oracle and vs the default dispatch's outputs."""
     import subprocess

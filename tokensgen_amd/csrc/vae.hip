@@ -15,6 +15,14 @@
 
 namespace {
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int GN_GROUPS = 32;
 constexpr int TILE_BYTES = BM * BK * 2;
@@ -275,150 +283,204 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
 
 
 // ------------------------------------------------------------------------------------------------
-// Halo-tiled convolution for the Cout = 128 layers (the 128-channel resnets at full resolution: a third of the decode, half of the encode).
-// The GEMM-shaped kernels above fetch a fresh [voxels x 64 channels] A tile from L2 for EVERY (tap, channel chunk): with N = 128 the
-// 512 x 128 tile needs 39 B/clk/CU of L2 -> LDS fill at the full MFMA rate, against the ~43 the path delivers — fill-bound at
-// 0.84 PFLOP/s.  Here a workgroup owns an 8 x 32 patch of ONE output frame; for each (temporal tap dt, 64-channel chunk) the 10 x 34 input
-// halo is brought into LDS ONCE and all nine (dh, dw) taps read it shifted: A traffic / 9, the fill drops to ~21 B/clk/CU (weights 16 +
-// halo 4.7).  Halo voxel rows are 144 B apart (128 B of channels + 16 B pad): 16 consecutive voxels x one 16-byte k-slot hit 64 distinct
-// banks, and — unlike an XOR swizzle — the address is LINEAR in the voxel index, so a tap is a workgroup-uniform byte offset: a tap change
-// costs no VALU at all.  The halo arrives by LDS-DMA as 48 pieces of 1 KiB = 7.1 rows each (lane -> (row, slot); the pad slot and
-// out-of-image voxels read the zero page); the source frame of a temporal tap is uniform per workgroup (x, the cache tensor, or frame 0
-// replicated).  4 waves x (64 voxels x 128 channels), MFMA 16x16x32, halo and weight stages double-buffered (128 KiB of LDS); fragment reads
-// are inline asm (a C++ LDS load would make the compiler wait vmcnt(0) for the DMA in flight).
+// Halo-tiled convolution for the Cout = 128 layers.  The GEMM-shaped kernels above fetch a fresh [voxels x 64 channels] A tile from L2 for
+// EVERY (tap, channel chunk); here a workgroup owns a 16 x 32 patch of ONE output frame, and for each (temporal tap dt, 32-channel chunk) the
+// 18 x 34 input halo is brought into LDS ONCE and all nine (dh, dw) taps read it shifted: A traffic / 9, and a tap change costs no VALU at all
+// (the source frame of a temporal tap is uniform per workgroup: x, the cache tensor, or frame 0 replicated).
+// 128 voxels x 128 channels PER WAVE (4 waves x 4 patch rows), stages of 32 input channels (one MFMA 16x16x32 k-step): 16 KB of fragment reads
+// per wave per 1024 MFMA cycles = 49 % of the LDS pipe at the full matrix rate (a first version with 64-voxel waves needed 73 %), and the reads
+// of stage s+1 are issued BETWEEN the MFMAs of stage s into a second fragment set, so the matrix pipe never waits for LDS.  Weights ride a ring of
+// four stage buffers (the DMA of stage s+3 is issued at the top of stage s; stage s+1 is resident while stage s computes, so its fragments can
+// be prefetched); the 18 x 34 halo of the next (temporal tap, 32-channel chunk) group arrives in slices during stages 0..6 of the current group.
+// Voxel rows (64 B of channels) and weight rows sit at an 80-byte stride: 16 consecutive rows x one 16-byte slot = 64 distinct banks, and the
+// address stays linear in the voxel index, so a tap is still a uniform offset (the immediate offset field of the read).
 // ------------------------------------------------------------------------------------------------
-constexpr int HP_H = 8, HP_W = 32, HL_W = HP_W + 2, HL_ROWS = (HP_H + 2) * HL_W;      // 340 halo voxels
-constexpr int HROW = 144;
-constexpr int HALO_PIECES = (HL_ROWS * HROW + 1023) / 1024;                              // 48
-constexpr int HALO_BYTES = HALO_PIECES * 1024;                                           // 49152
-constexpr int HW_BYTES = 128 * 128;                                                      // one weight stage: 128 couts x 64 k
-constexpr int HALO_LDS = 2 * HALO_BYTES + 2 * HW_BYTES;                                  // 131072
+constexpr int H2_PH = 16, H2_PW = 32, H2_LW = H2_PW + 2, H2_ROWS = (H2_PH + 2) * H2_LW;      // 612 halo voxels
+constexpr int H2_STRIDE = 80;
+constexpr int H2_HALO_PIECES = (H2_ROWS * H2_STRIDE + 1023) / 1024;                            // 48
+constexpr int H2_HALO_BYTES = H2_HALO_PIECES * 1024;                                           // 49152
+constexpr int H2_W_PIECES = (128 * H2_STRIDE + 1023) / 1024;                                   // 10
+constexpr int H2_W_BYTES = 12 * 1024;                 // ring slot: the 10 pieces of a stage + 2 pad pieces (every wave issues exactly 3: counted vmcnt)
+constexpr int H2_RING = 4;                            // weight stages in flight: the DMA of stage s+3 is issued at the top of stage s
+constexpr int H2_LDS = 2 * H2_HALO_BYTES + H2_RING * H2_W_BYTES;                               // 147456
 
-__global__ __launch_bounds__(256) void conv3d_halo_kernel(ConvParams p) {
+__global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const sH = smem;                       // halo[2]
-    char* const sW = smem + 2 * HALO_BYTES;      // W[2]
+    char* const sH = smem;
+    char* const sW = smem + 2 * H2_HALO_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_x = (p.Wo + HP_W - 1) / HP_W, tiles_y = (p.Ho + HP_H - 1) / HP_H;
+    const int tiles_x = (p.Wo + H2_PW - 1) / H2_PW, tiles_y = (p.Ho + H2_PH - 1) / H2_PH;
     const int ntiles = p.To * tiles_y * tiles_x;
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tf = tile / (tiles_x * tiles_y);
-    const int x0 = tx * HP_W, y0 = ty * HP_H;
+    const int x0 = tx * H2_PW, y0 = ty * H2_PH;
     const int Kw = p.kt * 9 * p.Cin;
-    const int ncc = p.Cin / 64;
+    const int nc32 = p.Cin / 32;
     const long frame = (long)p.H * p.W * p.Cin;
+    const int ngroups = p.kt * nc32, nst = ngroups * 9;
 
-    // ---- halo DMA: this wave's 12 pieces; per lane the element offset of its (voxel, slot) inside a frame, or -1 (pad slot / outside) ----
-    int hoff[12];
+    // ---- DMA maps: lane -> (row, slot) of a 1 KiB piece under the 80-byte row stride; slot 4 is the pad ----
+    int hoff[12], woffs[3];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         const int o = (wave * 12 + i) * 1024 + lane * 16;
-        const int hr = o / HROW, slot = (o - hr * HROW) >> 4;
-        const int hy = hr / HL_W, hx = hr - hy * HL_W;
+        const int hr = o / H2_STRIDE, slot = (o - hr * H2_STRIDE) >> 4;
+        const int hy = hr / H2_LW, hx = hr - hy * H2_LW;
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-        hoff[i] = (slot < 8 && hr < HL_ROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? (y * p.W + x) * p.Cin + slot * 8 : -1;
+        hoff[i] = (slot < 4 && hr < H2_ROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? (y * p.W + x) * p.Cin + slot * 8 : -1;
     }
-    // source frame of temporal tap dt for output frame tf (uniform): x, the cache tensor (frames -(kt-1)..-1), or frame 0 replicated
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int piece = wave + 4 * i;
+        const int o = piece * 1024 + lane * 16;
+        const int row = o / H2_STRIDE, slot = (o - row * H2_STRIDE) >> 4;
+        woffs[i] = (piece < H2_W_PIECES && slot < 4 && row < 128) ? row * Kw + slot * 8 : -1;
+    }
     auto frame_base = [&](int dt) -> const bf16_t* {
         const int tv = tf + dt - (p.kt - 1);
         if (tv >= 0) return p.x + (long)tv * frame;
         return p.cache ? p.cache + (long)(tv + p.kt - 1) * frame : p.x;
     };
-    auto dma_halo = [&](int buf, int g, int i) {          // piece i (0..11) of this wave for group g = dt * ncc + cc
-        const int dt = g / ncc, cc = g - dt * ncc;
-        const bf16_t* src = hoff[i] >= 0 ? frame_base(dt) + hoff[i] + cc * 64 : p.zeros + (lane & 7) * 8;
+    auto dma_halo = [&](int buf, int g, int i) {          // piece i (0..11) of this wave for group g = dt * nc32 + c32
+        const int dt = g / nc32, c32 = g - dt * nc32;
+        const bf16_t* src = hoff[i] >= 0 ? frame_base(dt) + hoff[i] + c32 * 32 : p.zeros + (lane & 7) * 8;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(sH + buf * HALO_BYTES + (wave * 12 + i) * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(sH + buf * H2_HALO_BYTES + (wave * 12 + i) * 1024), 16, 0, 0);
     };
-    // ---- weight DMA: rows [wave*32 + i*8, +8) of the 128 x 64 stage, slots XOR-swizzled by (row >> 1) & 7 like the GEMM tiles ----
-    const bf16_t* wsrc[4];
+    auto dma_w = [&](int slot3, int st_) {                // weights of stage st_ = g * 9 + tap into ring slot slot3
+        const int g = st_ / 9, tap = st_ - g * 9;
+        const int dt = g / nc32, c32 = g - dt * nc32;
+        const long koff = (long)(dt * 9 + tap) * p.Cin + c32 * 32;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wave * 32 + i * 8 + (lane >> 3);
-        wsrc[i] = p.w + (long)r * Kw + (((lane & 7) ^ ((r >> 1) & 7)) * 8);
-    }
-    auto dma_w = [&](int buf, int kidx) {                 // kidx = (dt*9 + tap9) * ncc + cc  -> k offset kidx * 64... (tap-major, chunk-minor)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (long)kidx * 64),
-                                             (__attribute__((address_space(3))) void*)(sW + buf * HW_BYTES + wave * 4096 + i * 1024), 16, 0, 0);
-    };
-    // ---- fragment addresses (LDS byte offsets as 32-bit values: the low half of a flat LDS pointer) ----
-    const uint32_t ldsH = (uint32_t)(uintptr_t)sH, ldsW = (uint32_t)(uintptr_t)sW;
-    uint32_t aoff[4], woff[8][2];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-        aoff[mi] = (uint32_t)(((2 * wave + (mi >> 1)) * HL_W + (mi & 1) * 16 + (lane & 15)) * HROW + (lane >> 4) * 16);
-#pragma unroll
-    for (int ni = 0; ni < 8; ++ni)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int rw = ni * 16 + (lane & 15), sl = ks * 4 + (lane >> 4);
-            woff[ni][ks] = (uint32_t)(rw * 128 + ((sl ^ ((rw >> 1) & 7)) << 4));
+        for (int i = 0; i < 3; ++i) {                     // pieces 10, 11 (waves 2, 3, i = 2) are pad: zeros into the slot's spare 2 KiB
+            const bf16_t* src = woffs[i] >= 0 ? p.w + woffs[i] + koff : p.zeros + (lane & 7) * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sW + slot3 * H2_W_BYTES + (wave + 4 * i) * 1024), 16, 0, 0);
         }
-    f32x4 acc[8][4];
+    };
+    const uint32_t ldsH = (uint32_t)(uintptr_t)sH, ldsW = (uint32_t)(uintptr_t)sW;
+    uint32_t aoff[8], woff[8];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+        aoff[mi] = (uint32_t)(((4 * wave + (mi >> 1)) * H2_LW + (mi & 1) * 16 + (lane & 15)) * H2_STRIDE + (lane >> 4) * 16);
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) woff[ni] = (uint32_t)((ni * 16 + (lane & 15)) * H2_STRIDE + (lane >> 4) * 16);
+
+    f32x4 acc[8][8];
 #pragma unroll
     for (int ni = 0; ni < 8; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Fragment registers: the voxel (A) fragments are needed by every MFMA block of a stage -> two sets by stage parity, the next set filled
+    // during the current stage; the weight (W) fragments are needed one block (8 MFMAs) at a time -> a ring of three, W fragment q = stage * 8 + ni
+    // in slot q % 3, read two blocks ahead (the full double set of both spilled: 512 VGPRs + 81 to scratch, 341 vs 182 ms)
+    constexpr int WD = 5;                                  // W fragments are read WD blocks (8 MFMAs = 128 cycles each) ahead of their use; ring of WD + 1
+    bf16x8 fa[2][8], fwr[WD + 1];
+    // The LDS byte address of a fragment = a per-lane base (runtime, 8 + 8 registers) + a COMPILE-TIME immediate (halo buffer, tap offset /
+    // weight ring slot) in the instruction's 16-bit offset field: no address arithmetic per read — and nothing for the optimizer to hoist
+    // (with the addresses computed in C++ it pre-computed all 144 (stage, fragment) addresses of the unrolled loop into VGPRs and spilled)
+    uint32_t abase[8], wbase[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { abase[i] = ldsH + aoff[i]; wbase[i] = ldsW + woff[i]; }
+    auto read_a = [&](auto setc, auto immc, int mi) {       // immc: (group parity) * H2_HALO_BYTES + ((tap / 3) * H2_LW + tap % 3) * H2_STRIDE
+        constexpr int set = decltype(setc)::value, imm = decltype(immc)::value;
+        static_assert(imm >= 0 && imm < 65536, "ds_read offset field");
+        bf16x8& dst = fa[set][mi];
+        const uint32_t a = abase[mi];
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(a), "n"(imm));
+    };
+    auto read_w = [&](auto slotc, auto immc, int ni) {      // slotc: register ring slot; immc: LDS ring slot * H2_W_BYTES
+        constexpr int rs = decltype(slotc)::value, imm = decltype(immc)::value;
+        bf16x8& dst = fwr[rs];
+        const uint32_t a = wbase[ni];
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(a), "n"(imm));
+    };
+#define H2_AIMM(kk) std::integral_constant<int, (((kk) / 9) & 1) * H2_HALO_BYTES + ((((kk) % 9) / 3) * H2_LW + ((kk) % 9) % 3) * H2_STRIDE>{}
+#define H2_WIMM(kk) std::integral_constant<int, ((kk) % H2_RING) * H2_W_BYTES>{}
 
-    const int ngroups = p.kt * ncc;                        // (dt, cc) groups, 9 stages each
-    // prologue: halo of group 0 and the weights of stage 0
+    // ---- prologue: halo of group 0, weights of stages 0 and 1; A fragments of stage 0, W fragments 0 and 1 ----
 #pragma unroll
     for (int i = 0; i < 12; ++i) dma_halo(0, 0, i);
     dma_w(0, 0);
+    dma_w(1, 1);
+    dma_w(2, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int st = 0;                                            // global stage counter (weight buffer = st & 1)
-    for (int g = 0; g < ngroups; ++g) {
-        const int dt = g / ncc, cc = g - dt * ncc;
-        const uint32_t hb = ldsH + (uint32_t)((g & 1) * HALO_BYTES);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap, ++st) {
-            // loads of the NEXT stage's weights and a slice of the NEXT group's halo, in flight under this stage's MFMAs
-            const bool last_stage = (g + 1 == ngroups) && tap == 8;
-            if (!last_stage) {
-                const int ntap = tap == 8 ? 0 : tap + 1, ng = tap == 8 ? g + 1 : g;
-                const int ndt = ng / ncc, ncc_ = ng - ndt * ncc;
-                dma_w((st + 1) & 1, (ndt * 9 + ntap) * ncc + ncc_);
-            }
-            if (g + 1 < ngroups) {                         // 12 halo pieces over 9 stages: 2,1,1,2,1,1,2,1,1
-                const int first = tap + tap / 3 + (tap % 3 != 0), cnt = (tap % 3 == 0) ? 2 : 1;
+    for (int i = 0; i < 8; ++i) read_a(std::integral_constant<int, 0>{}, H2_AIMM(0), i);
+    static_for<0, WD>([&](auto ic) { read_w(ic, H2_WIMM(0), decltype(ic)::value); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // Four groups = 36 stages per loop iteration: the fragment-set parity (36 % 2), the halo buffer (group parity) and the weight ring slot
+    // (36 % 4) of every stage are compile-time constants; stages past the end (ngroups % 4 != 0) are skipped by a uniform test.
+    // DMA budget: everything issued in stage s-1 or earlier has landed when stage s ends (counted vmcnt: only the pieces of stage s itself may
+    // still be in flight), so a piece has a full stage beyond its own to arrive — with a plain vmcnt(0) per stage the stage time WAS the DMA
+    // latency (2200 cycles for 1024 cycles of MFMA, whatever the LDS schedule: the first two versions and the 4-wave kernel all ran alike).
+    for (int g0 = 0; g0 < ngroups; g0 += 4) {
+        static_for<0, 36>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;          // stage within the four groups
+            constexpr int cur = k & 1, nxt = cur ^ 1;
+            constexpr int tap = k % 9;
+            const int g = g0 + k / 9;
+            const int st = g0 * 9 + k;
+            if (st >= nst) return;                          // workgroup-uniform
+            __builtin_amdgcn_sched_barrier(0);
+            const bool w_iss = st + 3 < nst, h_iss = tap < 7 && g + 1 < ngroups;
+            if (w_iss) dma_w((k + 3) % H2_RING, st + 3);
+            constexpr int hfirst = tap < 5 ? 2 * tap : tap + 5, hcnt = tap < 5 ? 2 : (tap < 7 ? 1 : 0);     // 12 halo pieces over taps 0..6: 2,2,2,2,2,1,1
+            if (h_iss) {
 #pragma unroll
                 for (int i = 0; i < 12; ++i)
-                    if (i >= first && i < first + cnt) dma_halo((g + 1) & 1, g + 1, i);
+                    if (i >= hfirst && i < hfirst + hcnt) dma_halo((g + 1) & 1, g + 1, i);
             }
-            const uint32_t ha = hb + (uint32_t)(((tap / 3) * HL_W + (tap % 3)) * HROW);
-            const uint32_t wb = ldsW + (uint32_t)((st & 1) * HW_BYTES);
-            bf16x8 fa[2][4], fw[2][8];
+            const bool more = st + 1 < nst;
+            // 8 blocks of 8 MFMAs (one W fragment x the 8 voxel fragments).  After the first half of block ni: W fragment ni + 2 (of this stage,
+            // or 0 / 1 of the next one); after the second half: voxel fragment ni of the NEXT stage.  Reads return in order, so before block ni
+            // the W fragment it needs (issued two blocks earlier) is complete once at most 3 younger reads are outstanding.
+            static_for<0, 8>([&](auto nc) {
+                constexpr int ni = decltype(nc)::value;
+                constexpr int q = k * 8 + ni;               // W fragment sequence number within the 36-stage iteration (288 % (WD + 1) == 0)
+                static_assert(288 % (WD + 1) == 0 && 2 * WD - 1 <= 15, "ring slot must be static; lgkmcnt is a 4-bit counter");
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    // fragment ni was issued WD blocks ago; since then 2 WD - 1 younger reads went out (LDS returns in order).  With WD = 2 the
+                    // fragment was 256 cycles old — less than the LDS latency under this kernel's own 60 % LDS load — and every block stalled
+                    bf16x8& need = fwr[q % (WD + 1)];
+                    if constexpr (ni >= WD) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(need) : "n"(2 * WD - 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwr[q % (WD + 1)], fa[cur][mi], acc[ni][mi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ni + WD < 8) read_w(std::integral_constant<int, (q + WD) % (WD + 1)>{}, H2_WIMM(k), ni + WD);
+                else if (more) read_w(std::integral_constant<int, (q + WD) % (WD + 1)>{}, H2_WIMM(k + 1), ni + WD - 8);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[ks][mi]) : "v"(ha + aoff[mi] + (uint32_t)(ks * 64)));
-#pragma unroll
-                for (int ni = 0; ni < 8; ++ni) asm volatile("ds_read_b128 %0, %1" : "=v"(fw[ks][ni]) : "v"(wb + woff[ni][ks]));
+                for (int mi = 4; mi < 8; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwr[q % (WD + 1)], fa[cur][mi], acc[ni][mi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) read_a(std::integral_constant<int, nxt>{}, H2_AIMM(k + 1), ni);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                bf16x8 &a0 = fa[nxt][0], &a1 = fa[nxt][1], &a2 = fa[nxt][2], &a3 = fa[nxt][3], &a4 = fa[nxt][4], &a5 = fa[nxt][5], &a6 = fa[nxt][6],
+                       &a7 = fa[nxt][7], &w0 = fwr[0], &w1 = fwr[1], &w2 = fwr[2], &w3 = fwr[3], &w4 = fwr[4], &w5 = fwr[5];
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(w0), "+v"(w1), "+v"(w2),
+                             "+v"(w3), "+v"(w4), "+v"(w5));
             }
-            // 24 reads in flight; the first 12 (ks = 0) are complete when at most 12 younger ones are outstanding
-            asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fw[0][0]), "+v"(fw[0][1]),
-                         "+v"(fw[0][2]), "+v"(fw[0][3]), "+v"(fw[0][4]), "+v"(fw[0][5]), "+v"(fw[0][6]), "+v"(fw[0][7]));
-#pragma unroll
-            for (int ni = 0; ni < 8; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][ni], fa[0][mi], acc[ni][mi], 0, 0, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]), "+v"(fw[1][0]), "+v"(fw[1][1]),
-                         "+v"(fw[1][2]), "+v"(fw[1][3]), "+v"(fw[1][4]), "+v"(fw[1][5]), "+v"(fw[1][6]), "+v"(fw[1][7]));
-#pragma unroll
-            for (int ni = 0; ni < 8; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1][ni], fa[1][mi], acc[ni][mi], 0, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        (void)dt; (void)cc;
+            // allowed in flight: this stage's own pieces (3 weight pieces, hcnt halo pieces) — all wave-uniform, compile-time counts
+            if (w_iss && h_iss) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + hcnt) : "memory");
+            else if (w_iss) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (h_iss) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(hcnt) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        });
     }
 
-    // ---- epilogue (the arithmetic of conv3d_cl_kernel's): bias, bf16 rounding before the residual add, bf16 store, GroupNorm sums ----
+    // ---- epilogue: bias, bf16 rounding before the residual add, bf16 store, GroupNorm sums (Cout = 128: a lane's channel quad is one group) ----
     float gs[8], gq[8];
 #pragma unroll
     for (int ni = 0; ni < 8; ++ni) gs[ni] = gq[ni] = 0.f;
@@ -426,8 +488,8 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(ConvParams p) {
 #pragma unroll
     for (int ni = 0; ni < 8; ++ni) bq[ni] = p.bias ? *(const uint2*)(p.bias + ni * 16 + (lane >> 4) * 4) : uint2{0u, 0u};
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int y = y0 + 2 * wave + (mi >> 1), x = x0 + (mi & 1) * 16 + (lane & 15);
+    for (int mi = 0; mi < 8; ++mi) {
+        const int y = y0 + 4 * wave + (mi >> 1), x = x0 + (mi & 1) * 16 + (lane & 15);
         if (y >= p.Ho || x >= p.Wo) continue;
         const long m = ((long)tf * p.Ho + y) * p.Wo + x;
 #pragma unroll
@@ -450,9 +512,6 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(ConvParams p) {
         }
     }
     if (p.gn_partial) {
-        // Cout = 128: 4 channels per group, so a lane's channel quad IS one group (ni * 4 + (lane >> 4)); 16 voxel lanes -> wave -> workgroup,
-        // every step in a fixed order.  The partial buffer has ceil(V / 128) rows (tg_conv3d_gn_partial_floats) and tg_groupnorm_finalize
-        // sums all of them: tile i writes row i and zeroes row i + ntiles when that exists (ntiles <= rows <= 2 ntiles).
 #pragma unroll
         for (int ni = 0; ni < 8; ++ni) {
 #pragma unroll
@@ -461,7 +520,7 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(ConvParams p) {
                 gq[ni] += __shfl_xor(gq[ni], off, 64);
             }
         }
-        float* red = (float*)smem;                        // LDS is idle: the loop ended with a barrier
+        float* red = (float*)smem;                        // LDS is idle: the stage loop ended with a barrier
         if ((lane & 15) == 0) {
 #pragma unroll
             for (int ni = 0; ni < 8; ++ni) {
@@ -471,12 +530,14 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(ConvParams p) {
         }
         __syncthreads();
         if (tid < 64) {
+            // tile i owns row i of the partial buffer and zeroes rows i + ntiles, i + 2 ntiles, i + 3 ntiles (ntiles <= rows <= 4 ntiles):
+            // tg_groupnorm_finalize sums all ceil(V / 128) rows
             const int stat = tid >> 5, grp = tid & 31;
             float a = 0.f;
             for (int w_ = 0; w_ < 4; ++w_) a += red[(w_ * 32 + grp) * 2 + stat];
-            p.gn_partial[(long)tile * 64 + stat * 32 + grp] = a;
             const long rows = ((long)p.To * p.Ho * p.Wo + BM - 1) / BM;
-            if ((long)tile + ntiles < rows) p.gn_partial[((long)tile + ntiles) * 64 + stat * 32 + grp] = 0.f;
+            p.gn_partial[(long)tile * 64 + stat * 32 + grp] = a;
+            for (long r = (long)tile + ntiles; r < rows; r += ntiles) p.gn_partial[r * 64 + stat * 32 + grp] = 0.f;
         }
     }
 }
@@ -556,14 +617,6 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
 constexpr int CW_OPER = 256 * 64 * 2;            // 32 KiB per operand per stage
 constexpr int CW_STAGE = 2 * CW_OPER;            // 64 KiB
 constexpr int CW_LDS = 2 * CW_STAGE;             // 128 KiB
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 
 // NT = 256: 256 voxels x 256 channels, waves 2 x 2.  NT = 128 (Cout = 128): 512 voxels x 128 channels, waves 4 x 1 - the same 128x128 per
 // wave, every wave reads the whole W tile; 80 KiB per stage, i.e. all 160 KiB of LDS for the two stages.
@@ -1270,21 +1323,22 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
         TG_LAUNCH_CHECK("tg_conv3d_cl(w4)");
         return TG_OK;
     }
-    // Cout = 128, 3x3 spatial taps, stride 1, no upsampling: the halo-tiled kernel.  Measured per clip (single stream): Cin = 64 (encoder conv_in)
-    // 13.9 vs 17.2 ms on the 128 x 128 kernel -> used; Cin = 128 (the 128-channel resnets) 192 vs 184 ms on the hand-scheduled 512 x 128 kernel
-    // -> not used: with its simple stage loop (24 fragment reads up front, one barrier per stage) the halo kernel is LDS-bound instead of
-    // fill-bound — 96 KB of fragment reads per 1024 MFMA cycles is 73 % of the LDS pipe and sits in front of the MFMAs rather than under them.
-    // TG_CONV_HALO: 0 never, 1 (default) Cin = 64 only, 2 whenever legal (tests), 3 whenever legal at launch scale.
+    // Cout = 128, 3x3 spatial taps, stride 1, no upsampling: the halo-tiled kernel.  Measured per clip against the GEMM-shaped kernels (single
+    // stream): Cin = 64 (encoder conv_in) 13.3 vs 17.5 ms, Cin = 256 (first conv of the 128-channel block) 45.6 vs 51.2 ms -> used;
+    // Cin = 128 (the 128-channel resnets) 180-184 vs 180-186 ms -> parity, the hand-scheduled 512 x 128 kernel stays.  Both designs — and two
+    // intermediate versions of this one, with and without counted vmcnt, fragment prefetch distance 2 or 5 blocks — take 0.73-0.75 ms for the
+    // 8 x 240 x 360 x 128 -> 128 layer (0.82-0.84 PFLOP/s, MFMA pipe 38 % busy at 2.09 GHz: not power-bound): DESIGN §7.
+    // TG_CONV_HALO: 0 never, 1 (default) Cin != 128 at launch scale, 2 whenever legal (tests), 3 every Cin at launch scale.
     static const int halo_on = [] { const char* e = getenv("TG_CONV_HALO"); return e ? atoi(e) : 1; }();
     {
-        const long htiles = (long)To * ((Ho + HP_H - 1) / HP_H) * ((Wo + HP_W - 1) / HP_W);
+        const long h2tiles = (long)To * ((Ho + H2_PH - 1) / H2_PH) * ((Wo + H2_PW - 1) / H2_PW);
         const long rows128 = (M + BM - 1) / BM;
         if (halo_on && cout == 128 && cout_pad == 128 && kh == 3 && kw == 3 && pad == 1 && stride == 1 && up == 1 && !t_map && (kt == 1 || kt == 3) &&
-            To == T && Ho == H && Wo == W && (halo_on == 2 || (htiles >= 2L * n_cu && (halo_on == 3 || Cin == 64))) && htiles <= rows128 && rows128 <= 2 * htiles &&
-            (long)(T + 2) * H * W * Cin < (1L << 31) && htiles < (1L << 31)) {
+            To == T && Ho == H && Wo == W && (halo_on == 2 || (h2tiles >= n_cu && (halo_on == 3 || Cin != 128))) && h2tiles <= rows128 &&
+            rows128 <= 4 * h2tiles && (long)(T + 2) * H * W * Cin < (1L << 31) && h2tiles < (1L << 31)) {
             static bool attrh = false;
-            if (!attrh) { (void)hipFuncSetAttribute((const void*)conv3d_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS); attrh = true; }
-            hipLaunchKernelGGL(conv3d_halo_kernel, dim3((unsigned)htiles), dim3(256), HALO_LDS, stream, p);
+            if (!attrh) { (void)hipFuncSetAttribute((const void*)conv3d_halo2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS); attrh = true; }
+            hipLaunchKernelGGL(conv3d_halo2_kernel, dim3((unsigned)h2tiles), dim3(256), H2_LDS, stream, p);
             TG_LAUNCH_CHECK("tg_conv3d_cl(halo)");
             return TG_OK;
         }

@@ -31,8 +31,8 @@ def pack(w):
 
 rel = lambda a, b: ((a.float().cpu() - b.float().cpu()).norm() / (b.float().cpu().norm() + 1e-12)).item()
 res = {}
-# (Cin, T, H, W, kt): ragged patches in both directions (H % 8, W % 32 != 0), one and several channel chunks, 1x3x3 and 3x3x3, T = 1
-for ci, T, H, W, kt in [(128, 3, 19, 45, 3), (64, 2, 8, 32, 3), (256, 2, 17, 70, 3), (128, 1, 9, 33, 3), (128, 2, 10, 40, 1)]:
+# (Cin, T, H, W, kt): ragged patches in both directions (H % 16, W % 32 != 0), one and several channel chunks, 1x3x3 and 3x3x3, T = 1
+for ci, T, H, W, kt in [(128, 3, 19, 45, 3), (64, 2, 16, 32, 3), (256, 2, 17, 70, 3), (128, 1, 9, 33, 3), (128, 2, 10, 40, 1), (192, 2, 33, 20, 3)]:
     w = r(128, ci, kt, 3, 3, seed=1, scale=0.04)
     b = r(128, seed=2)
     x = r(1, ci, T + 2, H, W, seed=3)
