@@ -7,6 +7,7 @@
 //   * no cat(conv_cache, x): frames before the window are read straight from the cache tensor (or frame 0, replicated);
 //   * no F.pad: out-of-range taps read a zero page;
 //   * no materialised F.interpolate: the nearest-neighbour x2 upsample (spatial, and temporal through t_map) is index math.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -299,10 +300,14 @@ constexpr int H2_PH = 16, H2_PW = 32, H2_LW = H2_PW + 2, H2_ROWS = (H2_PH + 2) *
 constexpr int H2_STRIDE = 80;
 constexpr int H2_HALO_PIECES = (H2_ROWS * H2_STRIDE + 1023) / 1024;                            // 48
 constexpr int H2_HALO_BYTES = H2_HALO_PIECES * 1024;                                           // 49152
-constexpr int H2_W_PIECES = (128 * H2_STRIDE + 1023) / 1024;                                   // 10
-constexpr int H2_W_BYTES = 12 * 1024;                 // ring slot: the 10 pieces of a stage + 2 pad pieces (every wave issues exactly 3: counted vmcnt)
+constexpr int H2_W_BYTES = 128 * 64;                  // ring slot: 128 output channels x 32 k, 64-byte rows (16-byte slots XOR-swizzled by (row >> 2) & 3): 8 pieces, 2 per wave
 constexpr int H2_RING = 4;                            // weight stages in flight: the DMA of stage s+3 is issued at the top of stage s
 constexpr int H2_LDS = 2 * H2_HALO_BYTES + H2_RING * H2_W_BYTES;                               // 147456
+
+// TG_CONV_TIMING=1 (a -DTG_CONV_TIMING build, tools/ab_build.sh): s_memtime totals of workgroup 0 / wave 0 per stage segment
+#ifdef TG_CONV_TIMING
+__device__ long long tg_conv_dbg[8];
+#endif
 
 __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
     const int ngroups = p.kt * nc32, nst = ngroups * 9;
 
     // ---- DMA maps: lane -> (row, slot) of a 1 KiB piece under the 80-byte row stride; slot 4 is the pad ----
-    int hoff[12], woffs[3];
+    int hoff[12], woffs[2];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         const int o = (wave * 12 + i) * 1024 + lane * 16;
@@ -331,11 +336,9 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
         hoff[i] = (slot < 4 && hr < H2_ROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? (y * p.W + x) * p.Cin + slot * 8 : -1;
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int piece = wave + 4 * i;
-        const int o = piece * 1024 + lane * 16;
-        const int row = o / H2_STRIDE, slot = (o - row * H2_STRIDE) >> 4;
-        woffs[i] = (piece < H2_W_PIECES && slot < 4 && row < 128) ? row * Kw + slot * 8 : -1;
+    for (int i = 0; i < 2; ++i) {                          // weight pieces 2 * wave + i: 16 rows x 64 B; the lane's physical slot holds logical slot ^ swizzle
+        const int row = (2 * wave + i) * 16 + (lane >> 2);
+        woffs[i] = row * Kw + (((lane & 3) ^ ((row >> 2) & 3)) * 8);
     }
     auto frame_base = [&](int dt) -> const bf16_t* {
         const int tv = tf + dt - (p.kt - 1);
@@ -348,16 +351,12 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(sH + buf * H2_HALO_BYTES + (wave * 12 + i) * 1024), 16, 0, 0);
     };
-    auto dma_w = [&](int slot3, int st_) {                // weights of stage st_ = g * 9 + tap into ring slot slot3
+    auto dma_w = [&](int slot3, int st_, int i) {         // weight piece i (0, 1) of this wave for stage st_ = g * 9 + tap into ring slot slot3
         const int g = st_ / 9, tap = st_ - g * 9;
         const int dt = g / nc32, c32 = g - dt * nc32;
         const long koff = (long)(dt * 9 + tap) * p.Cin + c32 * 32;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {                     // pieces 10, 11 (waves 2, 3, i = 2) are pad: zeros into the slot's spare 2 KiB
-            const bf16_t* src = woffs[i] >= 0 ? p.w + woffs[i] + koff : p.zeros + (lane & 7) * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sW + slot3 * H2_W_BYTES + (wave + 4 * i) * 1024), 16, 0, 0);
-        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.w + woffs[i] + koff),
+                                         (__attribute__((address_space(3))) void*)(sW + slot3 * H2_W_BYTES + (2 * wave + i) * 1024), 16, 0, 0);
     };
     const uint32_t ldsH = (uint32_t)(uintptr_t)sH, ldsW = (uint32_t)(uintptr_t)sW;
     uint32_t aoff[8], woff[8];
@@ -365,7 +364,10 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
     for (int mi = 0; mi < 8; ++mi)
         aoff[mi] = (uint32_t)(((4 * wave + (mi >> 1)) * H2_LW + (mi & 1) * 16 + (lane & 15)) * H2_STRIDE + (lane >> 4) * 16);
 #pragma unroll
-    for (int ni = 0; ni < 8; ++ni) woff[ni] = (uint32_t)((ni * 16 + (lane & 15)) * H2_STRIDE + (lane >> 4) * 16);
+    for (int ni = 0; ni < 8; ++ni) {
+        const int rw = ni * 16 + (lane & 15);
+        woff[ni] = (uint32_t)(rw * 64 + (((lane >> 4) ^ ((rw >> 2) & 3)) << 4));
+    }
 
     f32x4 acc[8][8];
 #pragma unroll
@@ -402,9 +404,8 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
     // ---- prologue: halo of group 0, weights of stages 0 and 1; A fragments of stage 0, W fragments 0 and 1 ----
 #pragma unroll
     for (int i = 0; i < 12; ++i) dma_halo(0, 0, i);
-    dma_w(0, 0);
-    dma_w(1, 1);
-    dma_w(2, 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { dma_w(0, 0, i); dma_w(1, 1, i); dma_w(2, 2, i); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
@@ -412,6 +413,10 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
     static_for<0, WD>([&](auto ic) { read_w(ic, H2_WIMM(0), decltype(ic)::value); });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
+#ifdef TG_CONV_TIMING
+    long long tacc[4] = {0, 0, 0, 0};
+    const long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     // Four groups = 36 stages per loop iteration: the fragment-set parity (36 % 2), the halo buffer (group parity) and the weight ring slot
     // (36 % 4) of every stage are compile-time constants; stages past the end (ngroups % 4 != 0) are skipped by a uniform test.
     // DMA budget: everything issued in stage s-1 or earlier has landed when stage s ends (counted vmcnt: only the pieces of stage s itself may
@@ -426,15 +431,31 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
             const int st = g0 * 9 + k;
             if (st >= nst) return;                          // workgroup-uniform
             __builtin_amdgcn_sched_barrier(0);
+#ifdef TG_CONV_TIMING
+            long long tc0 = __builtin_amdgcn_s_memtime();
+#endif
             const bool w_iss = st + 3 < nst, h_iss = tap < 7 && g + 1 < ngroups;
-            if (w_iss) dma_w((k + 3) % H2_RING, st + 3);
             constexpr int hfirst = tap < 5 ? 2 * tap : tap + 5, hcnt = tap < 5 ? 2 : (tap < 7 ? 1 : 0);     // 12 halo pieces over taps 0..6: 2,2,2,2,2,1,1
+            // The stage's DMA pieces (2 weight pieces of stage s+3, up to 2 halo pieces of the next group) go out together at the top of the stage.
+            // In-kernel timers (TG_CONV_TIMING builds): a pure MFMA stage is 1021 cycles (= 64 x 16); the fragment reads add ~250; each LDS-DMA
+            // piece blocks its wave's issue for ~128 cycles when all four waves issue together — and ~300 when a wave issues alone between its
+            // MFMAs (a staggered one-wave-at-a-time schedule was 20 % SLOWER).  On this part the L2 -> LDS fill of a wave does not overlap with that
+            // wave's MFMAs, and with one wave per SIMD nobody else fills the gap: stage time = MFMA + fill / (~32 B/clk/CU) + LDS.  That one
+            // relation reproduces every kernel here: this one, the GEMM-shaped 512 x 128 convolution (80 KB per 2048 MFMA cycles: 0.83 PFLOP/s)
+            // and the DiT's 256 x 256 GEMM (64 KB per 2048: 1.4 PFLOP/s).  Hence: as few fill bytes per MFMA as the tile allows.
+#ifndef TG_H2_NODMA
+            if (w_iss) { dma_w((k + 3) % H2_RING, st + 3, 0); dma_w((k + 3) % H2_RING, st + 3, 1); }
             if (h_iss) {
 #pragma unroll
                 for (int i = 0; i < 12; ++i)
                     if (i >= hfirst && i < hfirst + hcnt) dma_halo((g + 1) & 1, g + 1, i);
             }
+#endif
+#ifdef TG_H2_NOLDS         // timing-only ablation (wrong results): no fragment reads inside the stage loop
+            const bool more = false;
+#else
             const bool more = st + 1 < nst;
+#endif
             // 8 blocks of 8 MFMAs (one W fragment x the 8 voxel fragments).  After the first half of block ni: W fragment ni + 2 (of this stage,
             // or 0 / 1 of the next one); after the second half: voxel fragment ni of the NEXT stage.  Reads return in order, so before block ni
             // the W fragment it needs (issued two blocks earlier) is complete once at most 3 younger reads are outstanding.
@@ -454,7 +475,11 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
                 for (int mi = 0; mi < 4; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwr[q % (WD + 1)], fa[cur][mi], acc[ni][mi], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef TG_H2_NOLDS
                 if constexpr (ni + WD < 8) read_w(std::integral_constant<int, (q + WD) % (WD + 1)>{}, H2_WIMM(k), ni + WD);
+#else
+                if constexpr (false) {}
+#endif
                 else if (more) read_w(std::integral_constant<int, (q + WD) % (WD + 1)>{}, H2_WIMM(k + 1), ni + WD - 8);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -464,21 +489,42 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
                 if (more) read_a(std::integral_constant<int, nxt>{}, H2_AIMM(k + 1), ni);
             });
             __builtin_amdgcn_sched_barrier(0);
+#ifdef TG_CONV_TIMING
+            long long tc1 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             {
                 bf16x8 &a0 = fa[nxt][0], &a1 = fa[nxt][1], &a2 = fa[nxt][2], &a3 = fa[nxt][3], &a4 = fa[nxt][4], &a5 = fa[nxt][5], &a6 = fa[nxt][6],
                        &a7 = fa[nxt][7], &w0 = fwr[0], &w1 = fwr[1], &w2 = fwr[2], &w3 = fwr[3], &w4 = fwr[4], &w5 = fwr[5];
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(w0), "+v"(w1), "+v"(w2),
                              "+v"(w3), "+v"(w4), "+v"(w5));
             }
-            // allowed in flight: this stage's own pieces (3 weight pieces, hcnt halo pieces) — all wave-uniform, compile-time counts
-            if (w_iss && h_iss) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + hcnt) : "memory");
-            else if (w_iss) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            // allowed in flight: this stage's own pieces (2 weight pieces, hcnt halo pieces) — all wave-uniform, compile-time counts
+#ifdef TG_H2_NODMA
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+            if (w_iss && h_iss) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + hcnt) : "memory");
+            else if (w_iss) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else if (h_iss) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(hcnt) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifdef TG_CONV_TIMING
+            __builtin_amdgcn_sched_barrier(0);
+            long long tc2 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+#ifdef TG_CONV_TIMING
+            long long tc3 = __builtin_amdgcn_s_memtime();
+            tacc[0] += tc1 - tc0; tacc[1] += tc2 - tc1; tacc[2] += tc3 - tc2; tacc[3] += 1;
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         });
     }
+#ifdef TG_CONV_TIMING
+    if (blockIdx.x == 0 && tid == 0) { for (int i = 0; i < 4; ++i) tg_conv_dbg[i] = tacc[i]; tg_conv_dbg[4] = __builtin_amdgcn_s_memtime() - t_begin; }
+#endif
 
     // ---- epilogue: bias, bf16 rounding before the residual add, bf16 store, GroupNorm sums (Cout = 128: a lane's channel quad is one group) ----
     float gs[8], gq[8];
@@ -1323,22 +1369,28 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
         TG_LAUNCH_CHECK("tg_conv3d_cl(w4)");
         return TG_OK;
     }
-    // Cout = 128, 3x3 spatial taps, stride 1, no upsampling: the halo-tiled kernel.  Measured per clip against the GEMM-shaped kernels (single
-    // stream): Cin = 64 (encoder conv_in) 13.3 vs 17.5 ms, Cin = 256 (first conv of the 128-channel block) 45.6 vs 51.2 ms -> used;
-    // Cin = 128 (the 128-channel resnets) 180-184 vs 180-186 ms -> parity, the hand-scheduled 512 x 128 kernel stays.  Both designs — and two
-    // intermediate versions of this one, with and without counted vmcnt, fragment prefetch distance 2 or 5 blocks — take 0.73-0.75 ms for the
-    // 8 x 240 x 360 x 128 -> 128 layer (0.82-0.84 PFLOP/s, MFMA pipe 38 % busy at 2.09 GHz: not power-bound): DESIGN §7.
-    // TG_CONV_HALO: 0 never, 1 (default) Cin != 128 at launch scale, 2 whenever legal (tests), 3 every Cin at launch scale.
+    // Cout = 128, 3x3 spatial taps, stride 1, no upsampling: the halo-tiled kernel.  Against the GEMM-shaped kernels on the 8 x 240 x 360 layers:
+    // 128 -> 128: 0.70 vs 0.74 ms per launch; per clip 64 -> 128 (encoder conv_in) 13.3 vs 17.5 ms, 256 -> 128 45.6 vs 51.2 ms.  Why not more:
+    // see the stage loop's comment (the fill does not overlap with the issuing wave's MFMAs).
+    // TG_CONV_HALO: 0 never, 1 (default) at launch scale, 2 whenever legal (tests).
     static const int halo_on = [] { const char* e = getenv("TG_CONV_HALO"); return e ? atoi(e) : 1; }();
     {
         const long h2tiles = (long)To * ((Ho + H2_PH - 1) / H2_PH) * ((Wo + H2_PW - 1) / H2_PW);
         const long rows128 = (M + BM - 1) / BM;
         if (halo_on && cout == 128 && cout_pad == 128 && kh == 3 && kw == 3 && pad == 1 && stride == 1 && up == 1 && !t_map && (kt == 1 || kt == 3) &&
-            To == T && Ho == H && Wo == W && (halo_on == 2 || (h2tiles >= n_cu && (halo_on == 3 || Cin != 128))) && h2tiles <= rows128 &&
+            To == T && Ho == H && Wo == W && (halo_on == 2 || h2tiles >= n_cu) && h2tiles <= rows128 &&
             rows128 <= 4 * h2tiles && (long)(T + 2) * H * W * Cin < (1L << 31) && h2tiles < (1L << 31)) {
             static bool attrh = false;
             if (!attrh) { (void)hipFuncSetAttribute((const void*)conv3d_halo2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS); attrh = true; }
             hipLaunchKernelGGL(conv3d_halo2_kernel, dim3((unsigned)h2tiles), dim3(256), H2_LDS, stream, p);
+#ifdef TG_CONV_TIMING
+            {
+                long long h[8];
+                (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(tg_conv_dbg), sizeof(h));
+                fprintf(stderr, "[tg_conv halo timing] stages %lld: issue+MFMA %lld  lgkm+vmcnt wait %lld  barrier %lld  | kernel total %lld (s_memtime ticks, 100 MHz)\n",
+                        h[3], h[0], h[1], h[2], h[4]);
+            }
+#endif
             TG_LAUNCH_CHECK("tg_conv3d_cl(halo)");
             return TG_OK;
         }
