@@ -61,7 +61,7 @@ def test_dit_tiny_vs_reference_golden(golden_dir):
               vip_image_rotary_emb=vrope, vip_condition_rotary_emb=crope, return_dict=False)[0]
         assert y.shape == c["out"].shape and torch.isfinite(y).all()
         r = _rel(y, c["out"])
-        assert r < 8.5e-3, f"ts{tuple(c['ts'].shape)} rel-L2 {r}"       # SURVEY 8c end-to-end bound 3e-2; measured 4.0-4.2e-3 (profiles/r2b_parity_report.json)
+        assert r < 8.5e-3, f"ts{tuple(c['ts'].shape)} rel-L2 {r}"       # SURVEY 8c end-to-end bound 3e-2; measured 4.0-4.2e-3 (profiles/r2_parity_report.json)
         # and against the fp32 reference run of the same case (bf16 drift bound, SURVEY §8c: 5e-2)
         n += 1
     assert n == 4
