@@ -340,3 +340,26 @@ def test_halo_tiled_conv_kernel(tmp_path):
                            capture_output=True, text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "vs default dispatch" in r.stdout and "ok 2" in r.stdout
+
+
+def test_vae_batch_of_two_matches_single_items(golden_dir):
+    """enable_slicing semantics: a batch is processed item by item (autoencoder_kl_cogvideox.py:1117-1121, 1171-1175).  The items reuse the same
+    captured tile graphs and staging buffers on the same tile streams: item 1 must not disturb item 0's result (bitwise equal to single-item calls),
+    eager first call and graph replay alike."""
+    from tokensgen_amd.vae import AutoencoderKLCogVideoX
+    g = torch.load(os.path.join(golden_dir, "vae_tiny.pt"), weights_only=False)
+    cfg = g["cfg"]
+    vae = AutoencoderKLCogVideoX(block_out_channels=cfg["block_out_channels"], layers_per_block=cfg["layers_per_block"], sample_height=64,
+                                 sample_width=96, device=DEV)
+    vae.load_state_dict(V.make_state_dict(cfg, seed=g["weight_seed"]))
+    vae.enable_tiling(); vae.enable_slicing()
+    gen = torch.Generator().manual_seed(5)
+    z = torch.randn(2, 16, 13, 8, 12, generator=gen).to(DEV, BF)
+    x = (torch.rand(2, 3, 17, 64, 96, generator=gen) * 2 - 1).to(DEV, BF)
+    for _ in range(3):                                   # eager first sight, capture, replay
+        d = vae.decode(z).sample
+        h = vae.encode(x).latent_dist.parameters
+        for i in range(2):
+            assert torch.equal(d[i], vae.decode(z[i:i + 1]).sample[0]), i
+            assert torch.equal(h[i], vae.encode(x[i:i + 1]).latent_dist.parameters[0]), i
+    assert not torch.equal(d[0], d[1])
