@@ -246,6 +246,24 @@ int tg_transpose_2d(const void* src, long ld, int rows, int cols, void* dst, lon
 int tg_colsum(const void* src, long ld, int rows, int cols, float* partial, hipStream_t stream);
 long tg_colsum_partial_floats(int rows, int cols);
 
+/* Backward of tg_adaln_modulate (y = ln (1 + scale[g]) + shift[g], ln = bf16(x_hat gamma + beta); normalization.py:441-460, 477-488): dx (bf16) and the
+ * per-element products whose column sums are the parameter gradients — t_dln = dy (1 + scale) [-> d beta], t_dlnx = t_dln x_hat [-> d gamma],
+ * t_dyln = dy ln [-> d scale[g] over the rows of group g]; d shift[g] = column sums of dy.  t_*: fp32 [batch*tokens][dim], caller-allocated. */
+int tg_adaln_modulate_bwd(const void* x, long ldx, long strideX, const void* dy, long ld_dy, long stride_dy, void* dx, long ld_dx, long stride_dx,
+                          const void* ln_weight, const void* ln_bias, float eps, int tokens, int dim, int batch, int modulate,
+                          const tg_group_table* g, float* t_dln, float* t_dlnx, float* t_dyln, hipStream_t stream);
+
+/* Backward of the gated residual out = res + gate[g] y (cogvideox_transformer_3d.py:290-293, 318-324): dy = gate[g] dout (bf16), t_dgate = dout y (fp32
+ * [batch*tokens][dim]; column sums over a group's rows = d gate[g]); d res = dout. */
+int tg_gate_residual_bwd(const void* dout, long ld_dout, long stride_dout, const void* y, long ldy, long strideY, void* dy, long ld_dy, long stride_dy,
+                         int tokens, int dim, int batch, const tg_group_table* gate, float* t_dgate, hipStream_t stream);
+
+/* Elementwise: mode 0 out = silu(x); mode 1 out = dy * gelu_tanh'(x) (the FeedForward activation's derivative). bf16, n elements. */
+int tg_act(const void* x, const void* dy, void* out, long n, int mode, hipStream_t stream);
+
+/* tg_colsum for an fp32 matrix (same partial layout). */
+int tg_colsum_f32(const float* src, long ld, int rows, int cols, float* partial, hipStream_t stream);
+
 /* Training loss of the To2V step and its gradient w.r.t. the model output (train_cogvideo_to2v.py:1995-2004; get_velocity
  * scheduling_dpm_cogvideox.py:521-538), per frame f (per-frame timesteps) over frame_elems elements:
  *   pred = bf16(bf16(sa_f * noisy) - bf16(sb_f * out))    sa_f = sqrt(acp_t), sb_f = sqrt(1 - acp_t), both cast to bf16 like the reference

@@ -148,7 +148,7 @@ def test_qk_layernorm_rope_backward_and_linear_backward_vs_autograd():
     (y.transpose(1, 2).reshape(B, T, D) * dy).sum().backward()
     dx, dg, db = train.qk_layernorm_rope_backward(x.to(DEV), dy.to(DEV), H, gw.to(DEV), 1e-6, (Nt, tuple(t.to(DEV) for t in r0)),
                                                  (Nt + n0, tuple(t.to(DEV) for t in r1)), out_scale=0.37)
-    assert _rel(dx, xf.grad) < 6e-3 and _rel(dg, wf.grad) < 2e-3 and _rel(db, bfv.grad) < 2e-3
+    assert _rel(dx, xf.grad) < 4e-3 and _rel(dg, wf.grad) < 2e-3 and _rel(db, bfv.grad) < 2e-3
     # linear backward
     M, cin, cout = 333, 192, 256
     xi, dyo, w = _rand(M, cin, seed=7), _rand(M, cout, seed=8), _rand(cout, cin, seed=9, scale=0.1)
@@ -217,3 +217,85 @@ def test_vip_processor_trainable_parameter_gradients_vs_autograd_of_the_oracle()
     for name, g_ in got.items():
         want = sd[f"{P}.{name}"].grad
         assert _rel(g_, want) < 3e-2, name
+
+
+def test_adaln_gate_and_activation_backward_kernels_vs_autograd():
+    """tg_adaln_modulate_bwd / tg_gate_residual_bwd / tg_act / tg_colsum_f32 one by one against autograd of the fp32 formulas
+    (normalization.py:441-488, cogvideox_transformer_3d.py:290-324, FeedForward gelu-approximate)."""
+    import torch.nn.functional as F
+    from tokensgen_amd import kernels as K
+    from tokensgen_amd import train
+    B, T, D, Fr = 2, 40, 128, 4
+    x, dy = _rand(B, T, D, seed=71), _rand(B, T, D, seed=72)
+    w, bvec = (1 + 0.2 * _rand(D, seed=73).float()).to(BF), _rand(D, seed=74, scale=0.2)
+    mod = _rand(B, Fr, 6 * D, seed=75, scale=0.3)
+    tg = torch.empty(T, dtype=torch.uint8)
+    tg[:8], tg[8:] = Fr, (torch.arange(T - 8) // 8).to(torch.uint8)
+    table = K.GroupTable(mod.to(DEV), tg.to(DEV), list(range(Fr)) + [0], [0] * Fr + [3 * D], [D] * Fr + [4 * D], [2 * D] * Fr + [5 * D])
+    # fp32 reference with per-token modulation rows
+    rows = torch.tensor([0] * 8 + [int(i) for i in tg[8:]])
+    base = torch.tensor([3 * D] * 8 + [0] * (T - 8))
+    pick = lambda m, col: torch.stack([torch.stack([m[b, rows[t], base[t] + col: base[t] + col + D] for t in range(T)]) for b in range(B)])
+    xf, wf, bf_, mf = x.float().requires_grad_(True), w.float().requires_grad_(True), bvec.float().requires_grad_(True), mod.float().requires_grad_(True)
+    ln = F.layer_norm(xf, (D,), wf, bf_, 1e-5)
+    y = ln * (1 + pick(mf, D)) + pick(mf, 0)
+    (y * dy.float()).sum().backward()
+    dx = torch.empty(B, T, D, dtype=BF, device=DEV)
+    t_dln, t_dlnx, t_dyln = train._adaln_bwd(x.to(DEV), dy.to(DEV), dx, w.to(DEV), bvec.to(DEV), 1e-5, table)
+    assert _rel(dx, xf.grad) < 4e-3
+    assert _rel(train._colsum_f32(t_dln), bf_.grad) < 1e-5 and _rel(train._colsum_f32(t_dlnx), wf.grad) < 1e-5
+    # d scale of frame 1, batch 1: its rows are 16..24
+    got = train._colsum_f32(t_dyln.view(B, T, D)[1, 16:24])
+    assert _rel(got, mf.grad[1, 1, D:2 * D]) < 4e-3
+    # gated residual
+    yv, dout = _rand(B, T, D, seed=76), _rand(B, T, D, seed=77)
+    mg = mod.float().requires_grad_(True)
+    yf = yv.float().requires_grad_(True)
+    ((pick(mg, 2 * D) * yf) * dout.float()).sum().backward()
+    dyk, tgate = train._gate_res_bwd(dout.to(DEV), yv.to(DEV), table)
+    assert _rel(dyk, yf.grad) < 4e-3
+    assert _rel(train._colsum_f32(tgate.view(B, T, D)[0, :8]), mg.grad[0, 0, 5 * D:6 * D]) < 1e-5
+    # activations
+    v = _rand(3000, seed=78, scale=2.0)
+    g_ = _rand(3000, seed=79)
+    vf = v.float().requires_grad_(True)
+    (F.gelu(vf, approximate="tanh") * g_.float()).sum().backward()
+    assert _rel(train._act(v.to(DEV), g_.to(DEV)), vf.grad) < 4e-3
+    assert _rel(train._act(v.to(DEV)), F.silu(v.float())) < 4e-3
+
+
+def test_to2v_block_backward_vs_autograd_of_the_oracle_block():
+    """one whole CogVideoXBlock with the vip branch.  HIP forward (the product kernels, intermediates kept) + HIP backward
+    (train.To2VBlockTrainer) against torch.autograd through oracle.dit_ref.block_forward in fp32 on the same bf16-rounded weights and inputs:
+    the gradient of every trainable parameter of the block (vip_norm1 / vip_norm2 linear + LayerNorm, processor.vip_to_{q,k,v},
+    processor.vip_norm_{q,k}; train_cogvideo_to2v.py:1456-1481) and the gradients handed to the previous block (hidden, text | vip rows)."""
+    import numpy as np
+    from oracle import dit_ref as O
+    from tokensgen_amd import train
+    B, H, Nt, Fr, hw, Np = 2, 2, 9, 4, 30, 30
+    Nv, D = Fr * hw, H * 64
+    f32 = np.float32
+    cfg = dict(num_attention_heads=H, attention_head_dim=64, num_layers=1, patch_size=2, time_embed_dim=128, text_embed_dim=64, in_channels=16, out_channels=16)
+    pre = "transformer_blocks.0"
+    sd = {k: v.to(BF).float() for k, v in O.make_state_dict(cfg, n_vip_dim=128, seed=81, std=0.08).items() if k.startswith(pre + ".")}
+    train_keys = [k for k in sd if "vip_" in k]
+    assert len(train_keys) == 8 + 10
+    for k in train_keys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    hidden, enc, temb = _rand(B, Nv, D, seed=82), _rand(B, Nt + Np, D, seed=83), _rand(B, Fr, 128, seed=84)
+    rope = O.rope_3d(64, np.arange(4, dtype=f32), np.arange(5, dtype=f32), np.arange(6, dtype=f32))
+    vrope = O.rope_3d(64, np.arange(4, dtype=f32) + f32(3), np.arange(5, dtype=f32), np.arange(6, dtype=f32))
+    crope = O.rope_3d(64, np.linspace(1000, 1016.25, 5, dtype=f32), np.arange(2, dtype=f32), np.arange(3, dtype=f32))
+    hf, ef = hidden.float().requires_grad_(True), enc.float().requires_grad_(True)
+    oh, oe = O.block_forward(sd, pre, hf, ef, temb.float(), H, Np, [0.6], rope, vrope, crope)
+    Gh, Ge = _rand(B, Nv, D, seed=85), _rand(B, Nt + Np, D, seed=86)
+    ((oh * Gh.float()).sum() + (oe * Ge.float()).sum()).backward()
+    sd_dev = {k: v.detach().to(BF).to(DEV).contiguous() for k, v in sd.items()}
+    blk = train.To2VBlockTrainer(sd_dev, pre, H, Nt, Np, Fr, 0.6)
+    gh, ge = blk.forward(hidden.to(DEV), enc.to(DEV), temb.to(DEV), rope, vrope, crope)
+    assert _rel(gh, oh.detach()) < 6e-3 and _rel(ge, oe.detach()) < 6e-3
+    grads, dh, de = blk.backward(Gh.to(DEV), Ge.to(DEV))
+    assert set(pre + "." + k for k in grads) == set(train_keys)
+    assert _rel(dh, hf.grad) < 7e-3 and _rel(de, ef.grad) < 7e-3
+    for name, g_ in grads.items():
+        assert _rel(g_, sd[pre + "." + name].grad) < 2e-2, name

@@ -132,6 +132,94 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
     partial[(long)blockIdx.x * cols + c] = a;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward of tg_adaln_modulate:  y = ln * (1 + scale[g]) + shift[g],  ln = bf16(x_hat * gamma + beta),  x_hat = (x - mean) * rstd
+// (normalization.py:441-460, 477-488).  One wave per token row.  Per element it also emits the three products whose column sums (over all
+// rows, or over the rows of one group) are the parameter gradients:  t_dln = dy (1 + scale)  [-> d beta],  t_dlnx = t_dln * x_hat  [-> d gamma],
+// t_dyln = dy * ln  [-> d scale[g]]  (d shift[g] = column sums of dy itself).  fp32 [rows][dim]; summed by tg_colsum_f32 in a fixed order.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adaln_bwd_kernel(const bf16_t* __restrict__ x, long ldx, long sxb, const bf16_t* __restrict__ dy, long ldd, long sdb,
+                                                        bf16_t* __restrict__ dx, long ldo, long sob, const bf16_t* __restrict__ w,
+                                                        const bf16_t* __restrict__ bvec, float eps, int tokens, int dim, int batch, int modulate,
+                                                        tg_group_table g, float* __restrict__ t_dln, float* __restrict__ t_dlnx,
+                                                        float* __restrict__ t_dyln) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)tokens * batch) return;
+    const int b = (int)(row / tokens), t = (int)(row % tokens);
+    const bf16_t* xr = x + (long)b * sxb + (long)t * ldx;
+    const bf16_t* dr = dy + (long)b * sdb + (long)t * ldd;
+    bf16_t* outr = dx + (long)b * sob + (long)t * ldo;
+    float s = 0.f;
+    for (int c = lane; c < dim; c += 64) s += bf16_to_f32(xr[c]);
+    const float mean = wave_sum(s) / dim;
+    float q = 0.f;
+    for (int c = lane; c < dim; c += 64) { const float d = bf16_to_f32(xr[c]) - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / dim + eps);
+    const bf16_t* scale = nullptr;
+    if (modulate) {
+        const int gi = g.tok_group[t];
+        scale = (const bf16_t*)g.mod + (long)b * g.mod_batch_stride + (long)g.row[gi] * g.mod_ld + g.scale_col[gi];
+    }
+    float m1 = 0.f, m2 = 0.f;
+    for (int c = lane; c < dim; c += 64) {
+        const float xh = (bf16_to_f32(xr[c]) - mean) * rstd;
+        const float gam = w ? bf16_to_f32(w[c]) : 1.f, bet = bvec ? bf16_to_f32(bvec[c]) : 0.f;
+        const float ln = round_bf16(xh * gam + bet);
+        const float d = bf16_to_f32(dr[c]);
+        const float dln = d * (1.f + (scale ? bf16_to_f32(scale[c]) : 0.f));
+        const long o = row * dim + c;
+        t_dln[o] = dln; t_dlnx[o] = dln * xh; t_dyln[o] = d * ln;
+        const float dxh = dln * gam;
+        m1 += dxh; m2 += dxh * xh;
+    }
+    m1 = wave_sum(m1) / dim; m2 = wave_sum(m2) / dim;
+    for (int c = lane; c < dim; c += 64) {
+        const float xh = (bf16_to_f32(xr[c]) - mean) * rstd;
+        const float dxh = t_dln[row * dim + c] * (w ? bf16_to_f32(w[c]) : 1.f);
+        outr[c] = f32_to_bf16(rstd * (dxh - m1 - xh * m2));
+    }
+}
+
+// Backward of the gated residual  out = res + gate[g] * y  (cogvideox_transformer_3d.py:290-293, 318-324):  dy = gate[g] * dout (bf16),
+// t_dgate = dout * y (fp32; its column sums over the rows of group g are d gate[g]);  d res = dout.
+__global__ __launch_bounds__(256) void gate_res_bwd_kernel(const bf16_t* __restrict__ dout, long ldd, long sdb, const bf16_t* __restrict__ y, long ldy,
+                                                           long syb, bf16_t* __restrict__ dyo, long ldo, long sob, int tokens, int dim, int batch,
+                                                           tg_group_table g, float* __restrict__ t_dgate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)batch * tokens * dim;
+    if (i >= total) return;
+    const int c = (int)(i % dim);
+    const long row = i / dim;
+    const int b = (int)(row / tokens), t = (int)(row % tokens);
+    const int gi = g.tok_group[t];
+    const float gate = bf16_to_f32(((const bf16_t*)g.mod)[(long)b * g.mod_batch_stride + (long)g.row[gi] * g.mod_ld + g.gate_col[gi] + c]);
+    const float d = bf16_to_f32(dout[(long)b * sdb + (long)t * ldd + c]);
+    dyo[(long)b * sob + (long)t * ldo + c] = f32_to_bf16(gate * d);
+    t_dgate[i] = d * bf16_to_f32(y[(long)b * syb + (long)t * ldy + c]);
+}
+
+// mode 0: y = silu(x);  mode 1: dx = dy * gelu_tanh'(x)  (F.gelu(approximate="tanh"), diffusers FeedForward)
+__global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ out, long n, int mode) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = bf16_to_f32(x[i]);
+    if (mode == 0) { out[i] = f32_to_bf16(v / (1.f + __expf(-v))); return; }
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float u = k0 * (v + k1 * v * v * v), th = tanhf(u);
+    const float dg = 0.5f * (1.f + th) + 0.5f * v * (1.f - th * th) * k0 * (1.f + 3.f * k1 * v * v);
+    out[i] = f32_to_bf16(bf16_to_f32(dy[i]) * dg);
+}
+
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ src, long ld, int rows, int cols, float* __restrict__ partial) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int r0 = blockIdx.x * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+    float a = 0.f;
+    for (int r = r0; r < r1; ++r) a += src[(long)r * ld + c];
+    partial[(long)blockIdx.x * cols + c] = a;
+}
+
 }  // namespace
 
 extern "C" long tg_qk_layernorm_rope_bwd_partial_floats(int tokens, int heads, int batch) {
@@ -174,5 +262,46 @@ extern "C" int tg_colsum(const void* src, long ld, int rows, int cols, float* pa
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + CS_ROWS - 1) / CS_ROWS), (unsigned)((cols + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)src, ld,
                        rows, cols, partial);
     TG_LAUNCH_CHECK("tg_colsum");
+    return TG_OK;
+}
+
+extern "C" int tg_adaln_modulate_bwd(const void* x, long ldx, long strideX, const void* dy, long ld_dy, long stride_dy, void* dx, long ld_dx, long stride_dx,
+                                     const void* ln_weight, const void* ln_bias, float eps, int tokens, int dim, int batch, int modulate,
+                                     const tg_group_table* g, float* t_dln, float* t_dlnx, float* t_dyln, hipStream_t stream) {
+    TG_REQUIRE(x && dy && dx && t_dln && t_dlnx && t_dyln, TG_ERR_ARG, "tg_adaln_modulate_bwd: null pointer");
+    TG_REQUIRE(tokens > 0 && dim > 0 && batch > 0 && (!modulate || g), TG_ERR_SHAPE, "tg_adaln_modulate_bwd: bad shape");
+    tg_group_table gt{};
+    if (g) gt = *g;
+    const long rows = (long)tokens * batch;
+    hipLaunchKernelGGL(adaln_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, strideX, (const bf16_t*)dy, ld_dy, stride_dy,
+                       (bf16_t*)dx, ld_dx, stride_dx, (const bf16_t*)ln_weight, (const bf16_t*)ln_bias, eps, tokens, dim, batch, modulate, gt, t_dln, t_dlnx, t_dyln);
+    TG_LAUNCH_CHECK("tg_adaln_modulate_bwd");
+    return TG_OK;
+}
+
+extern "C" int tg_gate_residual_bwd(const void* dout, long ld_dout, long stride_dout, const void* y, long ldy, long strideY, void* dy, long ld_dy, long stride_dy,
+                                    int tokens, int dim, int batch, const tg_group_table* gate, float* t_dgate, hipStream_t stream) {
+    TG_REQUIRE(dout && y && dy && gate && t_dgate, TG_ERR_ARG, "tg_gate_residual_bwd: null pointer");
+    TG_REQUIRE(tokens > 0 && dim > 0 && batch > 0, TG_ERR_SHAPE, "tg_gate_residual_bwd: bad shape");
+    const long total = (long)batch * tokens * dim;
+    hipLaunchKernelGGL(gate_res_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)dout, ld_dout, stride_dout, (const bf16_t*)y,
+                       ldy, strideY, (bf16_t*)dy, ld_dy, stride_dy, tokens, dim, batch, *gate, t_dgate);
+    TG_LAUNCH_CHECK("tg_gate_residual_bwd");
+    return TG_OK;
+}
+
+extern "C" int tg_act(const void* x, const void* dy, void* out, long n, int mode, hipStream_t stream) {
+    TG_REQUIRE(x && out && (mode == 0 || dy), TG_ERR_ARG, "tg_act: null pointer");
+    TG_REQUIRE(n > 0 && (mode == 0 || mode == 1), TG_ERR_SHAPE, "tg_act: bad arguments");
+    hipLaunchKernelGGL(act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)out, n, mode);
+    TG_LAUNCH_CHECK("tg_act");
+    return TG_OK;
+}
+
+extern "C" int tg_colsum_f32(const float* src, long ld, int rows, int cols, float* partial, hipStream_t stream) {
+    TG_REQUIRE(src && partial, TG_ERR_ARG, "tg_colsum_f32: null pointer");
+    TG_REQUIRE(rows > 0 && cols > 0 && ld >= cols, TG_ERR_SHAPE, "tg_colsum_f32: bad shape");
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)((rows + CS_ROWS - 1) / CS_ROWS), (unsigned)((cols + 255) / 256)), dim3(256), 0, stream, src, ld, rows, cols, partial);
+    TG_LAUNCH_CHECK("tg_colsum_f32");
     return TG_OK;
 }

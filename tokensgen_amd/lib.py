@@ -35,6 +35,10 @@ PROTOTYPES = {
     "tg_qk_layernorm_rope_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _vp, _f, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _vp, _vp],
     "tg_transpose_2d": [_vp, _l, _i, _i, _vp, _l, _i, _vp],
     "tg_colsum": [_vp, _l, _i, _i, _vp, _vp],
+    "tg_adaln_modulate_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _vp, _f, _i, _i, _i, _i, C.POINTER(GroupTable), _vp, _vp, _vp, _vp],
+    "tg_gate_residual_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, C.POINTER(GroupTable), _vp, _vp],
+    "tg_act": [_vp, _vp, _vp, _l, _i, _vp],
+    "tg_colsum_f32": [_vp, _l, _i, _i, _vp, _vp],
     "tg_vpred_loss_grad": [_vp, _vp, _vp, _vp, _i, _l, _f, _vp, _vp, _vp],
     "tg_timestep_sinusoid": [_vp, _i, _i, _vp, _vp],
     "tg_rope_table_3d": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],

@@ -112,6 +112,19 @@ def linear_backward(x2d, dy2d, weight=None, need_dx=False):
     return dW, db, dx
 
 
+def linear_backward_dx(dy2d, weight):
+    """dx = dy W only (frozen layers): [M, out] x [out, in] -> [M, in] bf16."""
+    M, cout = dy2d.shape
+    cin = weight.shape[1]
+    cin_p, cout_p = _pad_to(cin, 128), _pad_to(cout, 64)
+    wT = torch.zeros(cin_p, cout_p, dtype=BF16, device=dy2d.device)
+    L.check(L.load().tg_transpose_2d(weight.data_ptr(), weight.stride(0), cout, cin, wT.data_ptr(), cout_p, cout_p, K._stream()), "tg_transpose_2d")
+    dyp = dy2d if cout_p == cout else torch.nn.functional.pad(dy2d, (0, cout_p - cout))
+    dxp = torch.empty(M, cin_p, dtype=BF16, device=dy2d.device)
+    K.gemm(dyp, wT, None, dxp, L.EPI_BIAS)
+    return dxp[:, :cin]
+
+
 def qk_layernorm_rope_backward(x_pre, dy, heads, ln_weight, eps, seg0=None, seg1=None, out_scale=1.0):
     """Backward of kernels.qk_layernorm_rope.  x_pre: the PRE-norm projection [B, T, heads*64] bf16 (a column slice of the fused QKV buffer
     is fine); dy fp32 [B, T, heads*64].  Returns (dx bf16 contiguous, dgamma fp32 [64], dbeta fp32 [64])."""
@@ -137,7 +150,7 @@ def qk_layernorm_rope_backward(x_pre, dy, heads, ln_weight, eps, seg0=None, seg1
 
 
 @torch.no_grad()
-def vip_projection_backward(xn_all, qkvv_pre, grads, heads, Nt, N1, vip_norm_q_w, vip_norm_k_w, vip_rope, cond_rope):
+def vip_projection_backward(xn_all, qkvv_pre, grads, heads, Nt, N1, vip_norm_q_w, vip_norm_k_w, vip_rope, cond_rope, return_dpre=False):
     """From the attention gradients of the vip-weight branch to the gradients of the TRAINABLE processor parameters.
     xn_all [B, N, D] bf16: the normalised inputs (text | video | vip rows) the projection read; qkvv_pre [B, N, 3D] bf16: its raw output
     (before vip_norm_q / vip_norm_k and RoPE); grads: to2v_attention_backward(...) (fp32, UNSCALED keys: the training forward keeps the softmax
@@ -156,4 +169,202 @@ def vip_projection_backward(xn_all, qkvv_pre, grads, heads, Nt, N1, vip_norm_q_w
     for j, n in enumerate(("q", "k", "v")):
         out[f"vip_to_{n}.weight"], out[f"vip_to_{n}.bias"] = dW[j * D:(j + 1) * D], db[j * D:(j + 1) * D]
     out["vip_norm_q.weight"], out["vip_norm_q.bias"], out["vip_norm_k.weight"], out["vip_norm_k.bias"] = dgq, dbq, dgk, dbk
+    return (out, d_pre.view(B, N, 3 * D)) if return_dpre else out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# One whole To2V block: forward with the intermediates kept, backward to every trainable parameter and to the block inputs
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _colsum_f32(src2d):
+    lib = L.load()
+    R, C_ = src2d.shape
+    part = torch.empty(lib.tg_colsum_partial_floats(R, C_), dtype=torch.float32, device=src2d.device)
+    L.check(lib.tg_colsum_f32(src2d.data_ptr(), src2d.stride(0), R, C_, part.data_ptr(), K._stream()), "tg_colsum_f32")
+    return part.view(-1, C_).sum(dim=0)
+
+
+def _act(x, dy=None):
+    """silu(x) (dy None) or dy * gelu_tanh'(x) (tg_act)."""
+    out = torch.empty_like(x)
+    L.check(L.load().tg_act(x.data_ptr(), K._p(dy), out.data_ptr(), x.numel(), 0 if dy is None else 1, K._stream()), "tg_act")
     return out
+
+
+def _adaln_bwd(x, dy, dx, w, b, eps, table):
+    """tg_adaln_modulate_bwd on [B, T, D] views; returns the three fp32 product tensors [B*T, D]."""
+    B, T, D, ldx, sx = K._bmk(x)
+    _, _, _, ldd, sd_ = K._bmk(dy)
+    _, _, _, ldo, so = K._bmk(dx)
+    t = [torch.empty(B * T, D, dtype=torch.float32, device=x.device) for _ in range(3)]
+    L.check(L.load().tg_adaln_modulate_bwd(x.data_ptr(), ldx, sx, dy.data_ptr(), ldd, sd_, dx.data_ptr(), ldo, so, K._p(w), K._p(b), float(eps), T, D, B,
+                                           1 if table is not None else 0, table.ref() if table is not None else None, t[0].data_ptr(), t[1].data_ptr(),
+                                           t[2].data_ptr(), K._stream()), "tg_adaln_modulate_bwd")
+    return t
+
+
+def _gate_res_bwd(dout, y, table):
+    B, T, D, ldd, sd_ = K._bmk(dout)
+    _, _, _, ldy, sy = K._bmk(y)
+    dy = torch.empty(B, T, D, dtype=BF16, device=dout.device)
+    tg = torch.empty(B * T, D, dtype=torch.float32, device=dout.device)
+    L.check(L.load().tg_gate_residual_bwd(dout.data_ptr(), ldd, sd_, y.data_ptr(), ldy, sy, dy.data_ptr(), dy.stride(1), dy.stride(0), T, D, B, table.ref(),
+                                          tg.data_ptr(), K._stream()), "tg_gate_residual_bwd")
+    return dy, tg
+
+
+class To2VBlockTrainer:
+    """One CogVideoXBlock with the vip branch (cogvideox_transformer_3d.py:221-332 + attention_processor.py:1982-2155) for the training step:
+    `forward` runs the product kernels and keeps what the backward needs; `backward` returns dL/d(parameter) for every TRAINABLE parameter of the
+    block (names containing "vip_": vip_norm1 / vip_norm2 (modulation linear + LayerNorm affine), processor.vip_to_{q,k,v}, processor.vip_norm_{q,k};
+    train_cogvideo_to2v.py:1456-1481) and dL/d(block inputs) for chaining to the previous block.  Frozen parameters get input gradients only.
+    Weights come as a state dict with the reference's key names under `pre` (bf16 on the GPU).  Correct-first: separate launches, fp32 product
+    tensors for the reductions; nothing in the inference path uses this class."""
+
+    def __init__(self, sd, pre, heads, n_text, n_vip, frames, vip_scale, eps=1e-5):
+        self.sd, self.pre, self.H, self.Nt, self.Np, self.F, self.s, self.eps = sd, pre, heads, n_text, n_vip, frames, float(vip_scale), eps
+        g = lambda n: sd[f"{pre}.{n}"]
+        P = "attn1.processor."
+        self.Wqkv = torch.cat([g(f"attn1.to_{n}.weight") for n in "qkv"]).contiguous()
+        self.bqkv = torch.cat([g(f"attn1.to_{n}.bias") for n in "qkv"]).contiguous()
+        self.Wv = torch.cat([g(f"{P}vip_to_{n}.weight") for n in "qkv"]).contiguous()
+        self.bv = torch.cat([g(f"{P}vip_to_{n}.bias") for n in "qkv"]).contiguous()
+
+    def _mod(self, emb, which):
+        """[B, F, 9D] modulation tensor of norm{which}: columns 0..6D from norm.linear (per frame), 6D..9D from vip_norm.linear (frame 0 only)."""
+        sd, pre = self.sd, self.pre
+        B, F_, _ = emb.shape
+        D = self.D
+        mod = torch.zeros(B, F_, 9 * D, dtype=BF16, device=emb.device)
+        K.gemm(emb, sd[f"{pre}.norm{which}.linear.weight"], sd[f"{pre}.norm{which}.linear.bias"], mod[:, :, :6 * D], L.EPI_BIAS)
+        K.gemm(emb[:, :1], sd[f"{pre}.vip_norm{which}.linear.weight"], sd[f"{pre}.vip_norm{which}.linear.bias"], mod[:, :1, 6 * D:], L.EPI_BIAS)
+        D_, Fr = D, self.F
+        rows = list(range(Fr)) + [0, 0]
+        tab = K.GroupTable(mod, self.tok_group, rows, [0] * Fr + [3 * D_, 6 * D_], [D_] * Fr + [4 * D_, 7 * D_], [2 * D_] * Fr + [5 * D_, 8 * D_])
+        return mod, tab
+
+    @torch.no_grad()
+    def forward(self, hidden, enc, temb, rope, vrope, crope):
+        sd, pre, H, Nt, Np = self.sd, self.pre, self.H, self.Nt, self.Np
+        B, Nv, D = hidden.shape
+        self.D = D
+        N1, N = Nt + Nv, Nt + Nv + Np
+        dev = hidden.device
+        e = lambda *s: torch.empty(*s, dtype=BF16, device=dev)
+        hw = Nv // self.F
+        tg = torch.empty(N, dtype=torch.uint8)
+        tg[:Nt], tg[Nt:N1], tg[N1:] = self.F, (torch.arange(Nv) // hw).to(torch.uint8), self.F + 1
+        self.tok_group = tg.to(dev)
+        S = self.saved = {}
+        X0 = torch.cat([enc[:, :Nt], hidden, enc[:, Nt:]], dim=1).contiguous()
+        emb = _act(temb.contiguous())
+        mod1, t1 = self._mod(emb, 1)
+        Xn = e(B, N, D)
+        K.adaln_modulate(X0[:, :N1], Xn[:, :N1], sd[f"{pre}.norm1.norm.weight"], sd[f"{pre}.norm1.norm.bias"], self.eps, t1)
+        K.adaln_modulate(X0[:, N1:], Xn[:, N1:], sd[f"{pre}.vip_norm1.norm.weight"], sd[f"{pre}.vip_norm1.norm.bias"], self.eps, t1.offset(N1))
+        qkv_pre, qkvv_pre = e(B, N1, 3 * D), e(B, N, 3 * D)
+        K.gemm(Xn[:, :N1], self.Wqkv, self.bqkv, qkv_pre, L.EPI_BIAS)
+        K.gemm(Xn, self.Wv, self.bv, qkvv_pre, L.EPI_BIAS)
+        qkv, qkvv = qkv_pre.clone(), qkvv_pre.clone()
+        A = f"{pre}.attn1."
+        tab = lambda r: tuple(t.to(dev, torch.float32).contiguous() for t in r)
+        rope, vrope, crope = tab(rope), tab(vrope), tab(crope)
+        K.qk_layernorm_rope(qkv[:, :, :D], H, sd[A + "norm_q.weight"], sd[A + "norm_q.bias"], 1e-6, (Nt, rope))
+        K.qk_layernorm_rope(qkv[:, :, D:2 * D], H, sd[A + "norm_k.weight"], sd[A + "norm_k.bias"], 1e-6, (Nt, rope))
+        K.qk_layernorm_rope(qkvv[:, :, :D], H, sd[A + "processor.vip_norm_q.weight"], sd[A + "processor.vip_norm_q.bias"], 1e-6, (Nt, vrope), (N1, crope))
+        K.qk_layernorm_rope(qkvv[:, :, D:2 * D], H, sd[A + "processor.vip_norm_k.weight"], sd[A + "processor.vip_norm_k.bias"], 1e-6, (Nt, vrope), (N1, crope))
+        pad = lambda n: (n + 63) // 64 * 64
+        vt = lambda v, n0, n: K.transpose_v(v, H, n0, n, torch.zeros(B, H, 64, pad(n), dtype=BF16, device=dev))
+        sm = 1.0 / 8.0
+        q, k, v = (qkv[:, :, c * D:(c + 1) * D] for c in range(3))
+        qx, kx, vx = (qkvv[:, :N1, c * D:(c + 1) * D] for c in range(3))
+        qv, kv, vv = (qkvv[:, N1:, c * D:(c + 1) * D] for c in range(3))
+        o1, o2, o3 = e(B, N1, D), e(B, N1, D), e(B, Np, D)
+        vt1, vt2, vt3 = vt(qkv[:, :, 2 * D:], 0, N1), vt(qkvv[:, :, 2 * D:], N1, Np), vt(qkvv[:, :, 2 * D:], 0, N)
+        K.attention(q, k, vt1, N1, o1, H, sm)
+        K.attention(qx, kv, vt2, Np, o2, H, sm)
+        K.attention(qv, qkvv[:, :, D:2 * D], vt3, N, o3, H, sm)
+        AO = e(B, N, D)
+        K.attention(q, k, vt1, N1, AO[:, :N1], H, sm, qx, kv, vt2, Np, self.s)          # O1 + s O2 exactly as the inference path forms it
+        AO[:, N1:] = o3
+        y_attn = e(B, N, D)
+        K.gemm(AO, sd[A + "to_out.0.weight"], sd[A + "to_out.0.bias"], y_attn, L.EPI_BIAS)
+        X1 = e(B, N, D)
+        K.gemm(AO, sd[A + "to_out.0.weight"], sd[A + "to_out.0.bias"], X1, L.EPI_BIAS_GATE_RES, residual=X0, gate=t1)
+        mod2, t2 = self._mod(emb, 2)
+        Xn2 = e(B, N, D)
+        K.adaln_modulate(X1[:, :N1], Xn2[:, :N1], sd[f"{pre}.norm2.norm.weight"], sd[f"{pre}.norm2.norm.bias"], self.eps, t2)
+        K.adaln_modulate(X1[:, N1:], Xn2[:, N1:], sd[f"{pre}.vip_norm2.norm.weight"], sd[f"{pre}.vip_norm2.norm.bias"], self.eps, t2.offset(N1))
+        Fw1, Fb1, Fw2, Fb2 = (sd[f"{pre}.ff.net.{n}"] for n in ("0.proj.weight", "0.proj.bias", "2.weight", "2.bias"))
+        ffpre, ffh = e(B, N, Fw1.shape[0]), e(B, N, Fw1.shape[0])
+        K.gemm(Xn2, Fw1, Fb1, ffpre, L.EPI_BIAS)
+        K.gemm(Xn2, Fw1, Fb1, ffh, L.EPI_BIAS_GELU)
+        y_ff = e(B, N, D)
+        K.gemm(ffh, Fw2, Fb2, y_ff, L.EPI_BIAS)
+        X2 = e(B, N, D)
+        K.gemm(ffh, Fw2, Fb2, X2, L.EPI_BIAS_GATE_RES, residual=X1, gate=t2)
+        S.update(X0=X0, X1=X1, Xn=Xn, Xn2=Xn2, emb=emb, t1=t1, t2=t2, mod1=mod1, mod2=mod2, qkv_pre=qkv_pre, qkvv_pre=qkvv_pre, q=q, k=k, v=v, qx=qx, kx=kx,
+                 vx=vx, qv=qv, kv=kv, vv=vv, o1=o1, o2=o2, o3=o3, y_attn=y_attn, y_ff=y_ff, ffpre=ffpre, rope=rope, vrope=vrope, crope=crope, dims=(B, Nv, D, N1, N))
+        return X2[:, Nt:N1], torch.cat([X2[:, :Nt], X2[:, N1:]], dim=1)
+
+    def _vip_norm_grads(self, which, t_dln, t_dlnx, t_dyln, dxn, t_dgate, grads):
+        """vip_norm{which}: LayerNorm affine from the vip rows' products; the modulation linear from d(shift | scale | gate) of the vip group."""
+        S = self.saved
+        B, Nv, D, N1, N = S["dims"]
+        Np = N - N1
+        rows = lambda t, b: t.view(B, N, D)[b, N1:]
+        name = f"vip_norm{which}"
+        grads[f"{name}.norm.weight"] = sum(_colsum_f32(rows(t_dlnx, b)) for b in range(B))
+        grads[f"{name}.norm.bias"] = sum(_colsum_f32(rows(t_dln, b)) for b in range(B))
+        dmod = torch.stack([torch.cat([colsum(dxn[b, N1:]), _colsum_f32(rows(t_dyln, b)), _colsum_f32(rows(t_dgate, b))]) for b in range(B)])   # [B, 3D]: shift | scale | gate
+        dW, db, _ = linear_backward(S["emb"][:, 0].contiguous(), dmod.to(BF16).contiguous())
+        grads[f"{name}.linear.weight"], grads[f"{name}.linear.bias"] = dW, db
+
+    @torch.no_grad()
+    def backward(self, d_hidden, d_enc):
+        """d_hidden [B, Nv, D], d_enc [B, Nt + Np, D] (bf16): gradients of the loss w.r.t. the block's two outputs.  Returns (grads: dict of the
+        trainable parameters under their names relative to the block, d_hidden_in, d_enc_in)."""
+        sd, pre, H, Nt = self.sd, self.pre, self.H, self.Nt
+        S = self.saved
+        B, Nv, D, N1, N = S["dims"]
+        A = f"{pre}.attn1."
+        grads = {}
+        dX2 = torch.cat([d_enc[:, :Nt], d_hidden, d_enc[:, Nt:]], dim=1).to(BF16).contiguous()
+        # ---- feed-forward residual (step 7), FeedForward, norm2 ----
+        dy_ff, tg2 = _gate_res_bwd(dX2, S["y_ff"], S["t2"])
+        Fw1, Fw2 = sd[f"{pre}.ff.net.0.proj.weight"], sd[f"{pre}.ff.net.2.weight"]
+        dhid = _dgrad(dy_ff.view(B * N, D), Fw2)
+        dpre = _act(S["ffpre"].view(B * N, -1), dhid)
+        dXn2 = _dgrad(dpre, Fw1).view(B, N, D)
+        dX1 = torch.empty(B, N, D, dtype=BF16, device=dX2.device)
+        ta = _adaln_bwd(S["X1"][:, :N1], dXn2[:, :N1], dX1[:, :N1], sd[f"{pre}.norm2.norm.weight"], sd[f"{pre}.norm2.norm.bias"], self.eps, S["t2"])
+        tb = _adaln_bwd(S["X1"][:, N1:], dXn2[:, N1:], dX1[:, N1:], sd[f"{pre}.vip_norm2.norm.weight"], sd[f"{pre}.vip_norm2.norm.bias"], self.eps, S["t2"].offset(N1))
+        full = lambda a, b_: torch.cat([a.view(B, N1, D), b_.view(B, N - N1, D)], dim=1).reshape(B * N, D)
+        self._vip_norm_grads(2, full(ta[0], tb[0]), full(ta[1], tb[1]), full(ta[2], tb[2]), dXn2, tg2, grads)
+        dX1 = (dX1.float() + dX2.float()).to(BF16)                                   # residual: X2 = X1 + gate * FF(norm2(X1))
+        # ---- attention residual (step 5), to_out ----
+        dy_attn, tg1 = _gate_res_bwd(dX1, S["y_attn"], S["t1"])
+        dAO = _dgrad(dy_attn.view(B * N, D), sd[A + "to_out.0.weight"]).view(B, N, D)
+        # ---- the three attention calls, QK-norm + RoPE, projections ----
+        ga = to2v_attention_backward(S["q"], S["k"], S["v"], S["qx"], S["kx"], S["vx"], S["qv"], S["kv"], S["vv"], S["o1"], S["o2"], S["o3"], dAO, H, 1.0 / 8.0, self.s)
+        pg, d_pre_v = vip_projection_backward(S["Xn"], S["qkvv_pre"], ga, H, Nt, N1, sd[A + "processor.vip_norm_q.weight"], sd[A + "processor.vip_norm_k.weight"],
+                                              S["vrope"], S["crope"], return_dpre=True)
+        for kname, val in pg.items():
+            grads["attn1.processor." + kname] = val
+        dq_pre, _, _ = qk_layernorm_rope_backward(S["qkv_pre"][:, :, :D], ga["q"].contiguous(), H, sd[A + "norm_q.weight"], 1e-6, (Nt, S["rope"]))
+        dk_pre, _, _ = qk_layernorm_rope_backward(S["qkv_pre"][:, :, D:2 * D], ga["k"].contiguous(), H, sd[A + "norm_k.weight"], 1e-6, (Nt, S["rope"]))
+        d_pre_b = torch.cat([dq_pre, dk_pre, ga["v"].to(BF16)], dim=2)
+        dXn = _dgrad(d_pre_v.view(B * N, 3 * D), self.Wv).view(B, N, D).float()
+        dXn[:, :N1] += _dgrad(d_pre_b.reshape(B * N1, 3 * D), self.Wqkv).view(B, N1, D).float()
+        dXn = dXn.to(BF16)
+        # ---- norm1 ----
+        dX0 = torch.empty(B, N, D, dtype=BF16, device=dX2.device)
+        ta = _adaln_bwd(S["X0"][:, :N1], dXn[:, :N1], dX0[:, :N1], sd[f"{pre}.norm1.norm.weight"], sd[f"{pre}.norm1.norm.bias"], self.eps, S["t1"])
+        tb = _adaln_bwd(S["X0"][:, N1:], dXn[:, N1:], dX0[:, N1:], sd[f"{pre}.vip_norm1.norm.weight"], sd[f"{pre}.vip_norm1.norm.bias"], self.eps, S["t1"].offset(N1))
+        self._vip_norm_grads(1, full(ta[0], tb[0]), full(ta[1], tb[1]), full(ta[2], tb[2]), dXn, tg1, grads)
+        dX0 = (dX0.float() + dX1.float()).to(BF16)
+        return grads, dX0[:, Nt:N1], torch.cat([dX0[:, :Nt], dX0[:, N1:]], dim=1)
+
+
+def _dgrad(dy2d, weight):
+    """dx = dy W for y = x W^T (bf16 [M, out] x [out, in] -> [M, in]) through the MFMA GEMM."""
+    return linear_backward_dx(dy2d.contiguous(), weight)
