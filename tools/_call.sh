@@ -1,2 +1,2 @@
 set -x
-timeout 900 python -m pytest tests/test_train_gpu.py -m gpu -x -q 2>&1 | tail -40
+timeout 800 bash tools/ab_gemm_traffic.sh "1 4 8" 2>&1 | tail -150
