@@ -299,3 +299,50 @@ def test_to2v_block_backward_vs_autograd_of_the_oracle_block():
     assert _rel(dh, hf.grad) < 7e-3 and _rel(de, ef.grad) < 7e-3
     for name, g_ in grads.items():
         assert _rel(g_, sd[pre + "." + name].grad) < 2e-2, name
+
+
+def test_to2v_model_training_forward_backward_vs_autograd_of_the_oracle_model():
+    """The transformer's share of one training micro-step (train_cogvideo_to2v.py:1930-2010): embeddings -> 2 blocks with per-block checkpointing
+    -> final norms / proj_out -> v-prediction loss, then backward to EVERY trainable transformer parameter (all names containing "vip_", incl.
+    patch_embed.vip_proj) and to the vip tokens (the Resampler's output).  Against autograd through oracle.dit_ref.dit_forward +
+    oracle.train_ref.vpred_loss in fp32 on the same bf16-rounded weights and inputs."""
+    import numpy as np
+    from oracle import dit_ref as O
+    from oracle import scheduler_ref as S
+    from oracle import train_ref as T
+    from tokensgen_amd import train
+    B, H, Nt, Fr, Hh, Ww = 2, 2, 9, 4, 10, 12
+    f32 = np.float32
+    cfg = dict(num_attention_heads=H, attention_head_dim=64, num_layers=2, patch_size=2, time_embed_dim=128, text_embed_dim=64, in_channels=16, out_channels=16)
+    sd = {k: v.to(BF).float() for k, v in O.make_state_dict(cfg, n_vip_dim=128, seed=91, std=0.08).items()}
+    train_keys = sorted(k for k in sd if "vip_" in k)
+    assert len(train_keys) == 2 * 18 + 2
+    for k in train_keys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    _, ac = S.alphas_cumprod()
+    ac = torch.as_tensor(ac, dtype=torch.float32)
+    g = torch.Generator().manual_seed(92)
+    noisy, x0 = (torch.randn(B, Fr, 16, Hh, Ww, generator=g).to(BF) for _ in range(2))
+    text = _rand(B, Nt, 64, seed=93)
+    vip = _rand(B, 5, 128, 2, 3, seed=94)
+    ts = torch.randint(20, 980, (B, Fr), generator=g)
+    rope = O.rope_3d(64, np.arange(4, dtype=f32), np.arange(5, dtype=f32), np.arange(6, dtype=f32))
+    vrope = O.rope_3d(64, np.arange(4, dtype=f32) + f32(3), np.arange(5, dtype=f32), np.arange(6, dtype=f32))
+    crope = O.rope_3d(64, np.linspace(1000, 1016.25, 5, dtype=f32), np.arange(2, dtype=f32), np.arange(3, dtype=f32))
+    vf = vip.float().requires_grad_(True)
+    out_ref = O.dit_forward(sd, cfg, noisy.float(), text.float(), ts, vf, rope, vrope, crope, vip_scale=[0.7])
+    loss_ref, _ = T.vpred_loss(ac, out_ref, noisy.float(), x0.float(), ts)
+    loss_ref.backward()
+    sd_dev = {k: v.detach().to(BF).to(DEV).contiguous() for k, v in sd.items()}
+    tr = train.To2VTrainer(sd_dev, H, 2, patch_size=2, vip_scale=0.7)
+    assert tr.trainable == train_keys
+    out = tr.forward(noisy.to(DEV), text.to(DEV), ts, vip.to(DEV), rope, vrope, crope)
+    assert _rel(out, out_ref.detach()) < 1e-2
+    loss, _, d_out = train.vpred_loss_and_grad(out, noisy.to(DEV), x0.to(DEV), ts, ac)
+    assert abs(loss.item() - loss_ref.item()) < 2e-2 * abs(loss_ref.item())
+    grads, d_vip = tr.backward(d_out)
+    assert sorted(grads) == train_keys
+    want_vip = vf.grad.permute(0, 1, 3, 4, 2).reshape(B, -1, 128)
+    assert _rel(d_vip, want_vip) < 2e-2
+    for name in train_keys:
+        assert _rel(grads[name], sd[name].grad) < 4e-2, name

@@ -222,6 +222,7 @@ class To2VBlockTrainer:
 
     def __init__(self, sd, pre, heads, n_text, n_vip, frames, vip_scale, eps=1e-5):
         self.sd, self.pre, self.H, self.Nt, self.Np, self.F, self.s, self.eps = sd, pre, heads, n_text, n_vip, frames, float(vip_scale), eps
+        self.keep = True          # False: forward only (the checkpointed pass of To2VTrainer keeps nothing but the block inputs)
         g = lambda n: sd[f"{pre}.{n}"]
         P = "attn1.processor."
         self.Wqkv = torch.cat([g(f"attn1.to_{n}.weight") for n in "qkv"]).contiguous()
@@ -302,6 +303,9 @@ class To2VBlockTrainer:
         K.gemm(ffh, Fw2, Fb2, y_ff, L.EPI_BIAS)
         X2 = e(B, N, D)
         K.gemm(ffh, Fw2, Fb2, X2, L.EPI_BIAS_GATE_RES, residual=X1, gate=t2)
+        if not self.keep:
+            self.saved = None
+            return X2[:, Nt:N1], torch.cat([X2[:, :Nt], X2[:, N1:]], dim=1)
         S.update(X0=X0, X1=X1, Xn=Xn, Xn2=Xn2, emb=emb, t1=t1, t2=t2, mod1=mod1, mod2=mod2, qkv_pre=qkv_pre, qkvv_pre=qkvv_pre, q=q, k=k, v=v, qx=qx, kx=kx,
                  vx=vx, qv=qv, kv=kv, vv=vv, o1=o1, o2=o2, o3=o3, y_attn=y_attn, y_ff=y_ff, ffpre=ffpre, rope=rope, vrope=vrope, crope=crope, dims=(B, Nv, D, N1, N))
         return X2[:, Nt:N1], torch.cat([X2[:, :Nt], X2[:, N1:]], dim=1)
@@ -368,3 +372,122 @@ class To2VBlockTrainer:
 def _dgrad(dy2d, weight):
     """dx = dy W for y = x W^T (bf16 [M, out] x [out, in] -> [M, in]) through the MFMA GEMM."""
     return linear_backward_dx(dy2d.contiguous(), weight)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The whole To2V DiT for the training step: forward with per-block checkpointing (cogvideox_transformer_3d.py:700-719), backward to every
+# trainable transformer parameter (names containing "vip_": train_cogvideo_to2v.py:1456-1481) and to the vip tokens (-> Resampler)
+# ---------------------------------------------------------------------------------------------------------------------------------
+class To2VTrainer:
+    """sd: the transformer's state dict under the reference's key names (bf16, on the GPU; `set_vip_layers` keys included).  `forward` keeps only
+    each block's two inputs; `backward` re-runs a block's forward with its intermediates kept, then its backward (the reference's
+    torch.utils.checkpoint per block), so the live set is one block's activations + (layers x 2 residual streams)."""
+
+    def __init__(self, sd, num_attention_heads, num_layers, patch_size=2, vip_scale=1.0, eps=1e-5):
+        self.sd, self.H, self.L, self.ps, self.s, self.eps = sd, num_attention_heads, num_layers, patch_size, float(vip_scale), eps
+        self.D = sd["norm_final.weight"].shape[0]
+        self.trainable = sorted(k for k in sd if "vip_" in k)
+        self._blocks = None
+
+    def _front(self, latents, text, timestep, vip_tokens):
+        sd, D, ps = self.sd, self.D, self.ps
+        dev = latents.device
+        B, Fr, C, Hh, Ww = latents.shape
+        e = lambda *s: torch.empty(*s, dtype=BF16, device=dev)
+        ts = torch.as_tensor(timestep, device=dev)
+        ts = ts.expand(B) if ts.ndim == 0 else ts
+        Fm = ts.shape[1] if ts.ndim == 2 else 1
+        sin = e(B * Fm, D)
+        K.timestep_sinusoid(ts.reshape(-1).to(torch.int64).contiguous(), D, sin)
+        te = sd["time_embedding.linear_1.weight"].shape[0]
+        t1, temb = e(B * Fm, te), e(B * Fm, te)
+        K.gemm(sin, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"], t1, L.EPI_BIAS_SILU)
+        K.gemm(t1, sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"], temb, L.EPI_BIAS)
+        hw = (Hh // ps) * (Ww // ps)
+        Nt, Nv = text.shape[1], Fr * hw
+        vb, vf, vc, vh, vw = vip_tokens.shape
+        Np = vf * vh * vw
+        X = e(B, Nt + Nv + Np, D)
+        patches = e(B, Nv, C * ps * ps)
+        K.patchify(latents.to(BF16).reshape(B * Fr, C, Hh, Ww).contiguous(), patches.view(B * Nv, -1), ps)
+        K.gemm(patches, sd["patch_embed.proj.weight"].reshape(D, -1), sd["patch_embed.proj.bias"], X[:, Nt:Nt + Nv], L.EPI_BIAS)
+        K.gemm(text.to(BF16).contiguous(), sd["patch_embed.text_proj.weight"], sd["patch_embed.text_proj.bias"], X[:, :Nt], L.EPI_BIAS)
+        vtok = vip_tokens.to(BF16).permute(0, 1, 3, 4, 2).reshape(B, Np, vc).contiguous()
+        K.gemm(vtok, sd["patch_embed.vip_proj.weight"], sd["patch_embed.vip_proj.bias"], X[:, Nt + Nv:], L.EPI_BIAS)
+        return X, temb.view(B, Fm, te), vtok, (B, Fr, C, Hh, Ww, Nt, Nv, Np, Fm)
+
+    def _final_tables(self, temb_silu, Nv, Fm):
+        sd, D = self.sd, self.D
+        B = temb_silu.shape[0]
+        mod = torch.empty(B, Fm, 2 * D, dtype=BF16, device=temb_silu.device)
+        K.gemm(temb_silu, sd["norm_out.linear.weight"], sd["norm_out.linear.bias"], mod, L.EPI_BIAS)
+        hw = Nv // Fm
+        tg = (torch.arange(Nv) // hw).to(torch.uint8).to(temb_silu.device)
+        return K.GroupTable(mod, tg, list(range(Fm)), [0] * Fm, [D] * Fm, [0] * Fm)       # AdaLayerNorm: shift | scale (normalization.py:70-92)
+
+    @torch.no_grad()
+    def forward(self, latents, text, timestep, vip_tokens, rope, vrope, crope):
+        sd, D = self.sd, self.D
+        X, temb, vtok, dims = self._front(latents, text, timestep, vip_tokens)
+        B, Fr, C, Hh, Ww, Nt, Nv, Np, Fm = dims
+        N1 = Nt + Nv
+        if self._blocks is None or self._blocks[0].Nt != Nt or self._blocks[0].Np != Np or self._blocks[0].F != Fm:
+            self._blocks = [To2VBlockTrainer(sd, f"transformer_blocks.{i}", self.H, Nt, Np, Fm, self.s, self.eps) for i in range(self.L)]
+        hidden, enc = X[:, Nt:N1].contiguous(), torch.cat([X[:, :Nt], X[:, N1:]], dim=1)
+        self._ropes = (rope, vrope, crope)
+        self._ckpt = []
+        for blk in self._blocks:
+            self._ckpt.append((hidden, enc))
+            blk.keep = False
+            hidden, enc = blk.forward(hidden, enc, temb, rope, vrope, crope)
+            hidden = hidden.contiguous()
+        # final norm (per token: only the video rows matter), AdaLayerNorm, proj_out, unpatchify (cogvideox_transformer_3d.py:736-759)
+        semb = _act(temb.contiguous())
+        tout = self._final_tables(semb, Nv, Fm)
+        vidn, vid2 = torch.empty_like(hidden), torch.empty_like(hidden)
+        K.adaln_modulate(hidden, vidn, sd["norm_final.weight"], sd["norm_final.bias"], self.eps, None)
+        K.adaln_modulate(vidn, vid2, sd["norm_out.norm.weight"], sd["norm_out.norm.bias"], self.eps, tout)
+        Wp, bp = sd["proj_out.weight"], sd["proj_out.bias"]
+        co = Wp.shape[0]
+        cop = _pad_to(co, 128)
+        if cop != co:
+            Wp, bp = torch.nn.functional.pad(Wp, (0, 0, 0, cop - co)), torch.nn.functional.pad(bp, (0, cop - co))
+        po = torch.empty(B, Nv, cop, dtype=BF16, device=X.device)
+        K.gemm(vid2, Wp.contiguous(), bp.contiguous(), po, L.EPI_BIAS)
+        out = torch.empty(B, Fr, co // (self.ps * self.ps), Hh, Ww, dtype=BF16, device=X.device)
+        K.unpatchify(po.view(B * Nv, -1), out.view(B * Fr, -1, Hh, Ww), self.ps)
+        self._saved = dict(temb=temb, semb=semb, tout=tout, hidden_L=hidden, vidn=vidn, vtok=vtok, dims=dims)
+        return out
+
+    @torch.no_grad()
+    def backward(self, d_out):
+        """d_out: dL/d(model output) bf16 [B, F, C, H, W].  Returns (grads: {full parameter name: gradient} for every trainable transformer
+        parameter, d_vip_tokens bf16 [B, f*h*w, c]: the gradient handed to the Resampler)."""
+        sd, D, S = self.sd, self.D, self._saved
+        B, Fr, C, Hh, Ww, Nt, Nv, Np, Fm = S["dims"]
+        dev = d_out.device
+        co = sd["proj_out.weight"].shape[0]
+        d_po = torch.empty(B * Nv, co, dtype=BF16, device=dev)
+        K.patchify(d_out.to(BF16).reshape(B * Fr, -1, Hh, Ww).contiguous(), d_po, self.ps)
+        d_vid2 = _dgrad(d_po, sd["proj_out.weight"]).view(B, Nv, D)
+        d_vidn, d_hid = torch.empty(B, Nv, D, dtype=BF16, device=dev), torch.empty(B, Nv, D, dtype=BF16, device=dev)
+        _adaln_bwd(S["vidn"], d_vid2, d_vidn, sd["norm_out.norm.weight"], sd["norm_out.norm.bias"], self.eps, S["tout"])
+        _adaln_bwd(S["hidden_L"], d_vidn, d_hid, sd["norm_final.weight"], sd["norm_final.bias"], self.eps, None)
+        d_enc = torch.zeros(B, Nt + Np, D, dtype=BF16, device=dev)
+        grads = {}
+        rope, vrope, crope = self._ropes
+        for i in reversed(range(self.L)):
+            blk = self._blocks[i]
+            hidden, enc = self._ckpt[i]
+            blk.keep = True
+            blk.forward(hidden, enc, S["temb"], rope, vrope, crope)           # recompute with the intermediates kept
+            g, d_hid, d_enc = blk.backward(d_hid, d_enc)
+            blk.saved = None
+            for k, v in g.items():
+                grads[f"transformer_blocks.{i}.{k}"] = v
+            d_hid = d_hid.contiguous()
+        self._ckpt = []
+        d_vip = d_enc[:, Nt:].reshape(B * Np, D)
+        dW, db, dx = linear_backward(S["vtok"].view(B * Np, -1), d_vip.contiguous(), sd["patch_embed.vip_proj.weight"], need_dx=True)
+        grads["patch_embed.vip_proj.weight"], grads["patch_embed.vip_proj.bias"] = dW, db
+        return grads, dx.reshape(B, Np, -1)
