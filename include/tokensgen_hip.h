@@ -264,6 +264,19 @@ int tg_act(const void* x, const void* dy, void* out, long n, int mode, hipStream
 /* tg_colsum for an fp32 matrix (same partial layout). */
 int tg_colsum_f32(const float* src, long ld, int rows, int cols, float* partial, hipStream_t stream);
 
+/* Optimizer step on flat arenas (train_cogvideo_to2v.py:2012-2021: accelerator.clip_grad_norm_(transformer.parameters(), max_grad_norm), AdamW
+ * (:1091-1098; betas / eps / weight decay of the yaml), zero_grad).  The reference's use_8bit_adam (bitsandbytes block-wise 8-bit moments, not under
+ * /root/reference) exists to fit 80 GB parts; with 288 GB the moments stay fp32 (12.7 GB for the 1.6 B trainable parameters), which is torch.optim.AdamW.
+ *   tg_grad_accumulate: acc = (overwrite ? 0 : acc) + scale * grad   (grad bf16 or fp32; scale = 1 / gradient_accumulation_steps)
+ *   tg_grad_clip_coef:  coef[0] = ||grad||_2 (fixed-order sum), coef[1] = min(1, max_norm / (coef[0] + 1e-6)); ws: tg_grad_norm_ws_floats() floats
+ *   tg_adamw_step:      torch.optim.AdamW update of bf16 parameters with fp32 moments, gradient scaled by *clip_coef when given (device pointer,
+ *                       no host synchronisation); zero_grad != 0 clears grad in the same pass. */
+int tg_grad_accumulate(const void* grad, int grad_is_bf16, float* acc, long n, float scale, int overwrite, hipStream_t stream);
+long tg_grad_norm_ws_floats(void);
+int tg_grad_clip_coef(const float* grad, long n, float max_norm, float* ws, float* coef, hipStream_t stream);
+int tg_adamw_step(void* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, int step, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, const float* clip_coef, int zero_grad, hipStream_t stream);
+
 /* Training loss of the To2V step and its gradient w.r.t. the model output (train_cogvideo_to2v.py:1995-2004; get_velocity
  * scheduling_dpm_cogvideox.py:521-538), per frame f (per-frame timesteps) over frame_elems elements:
  *   pred = bf16(bf16(sa_f * noisy) - bf16(sb_f * out))    sa_f = sqrt(acp_t), sb_f = sqrt(1 - acp_t), both cast to bf16 like the reference

@@ -28,6 +28,29 @@ if mode == "die":                       # rank 1 dies without raising; rank 0 wo
 import torch.distributed as dist  # noqa: E402
 from tokensgen_amd.runtime import RankFailure, init_distributed  # noqa: E402
 
+if mode == "gradsync":                  # DDP gradient exchange of the training step (optim.GradSync): bucketed, incremental, averaged by the scale
+    init_distributed("gloo", timeout_s=120)
+    from tokensgen_amd.optim import GradSync
+    n = 1000
+    g = torch.Generator().manual_seed(7)
+    both = torch.randn(2, n, generator=g)
+    flat = both[rank].clone() * 0.5                    # the accumulation scale carries 1 / world_size
+    sync = GradSync(flat, bucket_elems=300)
+    assert sync.bounds == [(0, 300), (300, 600), (600, 900), (900, 1000)] and sync.world == 2
+    launched = []
+    for end in (100, 299, 300, 650, 650, 899):         # the backward passing arena offsets: only complete buckets may go
+        sync.ready(end)
+        launched.append(sync._next)
+    assert launched == [0, 0, 1, 2, 2, 2], launched
+    sync.finish()
+    want = both.sum(0) * 0.5
+    ok = torch.allclose(flat, want, atol=1e-6) and sync._next == 0 and not sync._work
+    sync.ready(1000); sync.finish()                    # a second window works on the same object
+    ok = ok and torch.allclose(flat, want * 2, atol=1e-6)
+    done("ok" if ok else "mismatch")
+    dist.destroy_process_group()
+    sys.exit(0)
+
 if mode == "raise":                     # rank 1's denoiser raises in FIFO iteration 3: EVERY rank must get RankFailure in that iteration
     init_distributed("gloo", timeout_s=120)
     import test_fifo_cpu as T

@@ -44,3 +44,24 @@ def test_silent_rank_times_out(tmp_path):
     except RuntimeError:
         pass                              # gloo may tear rank 1 down when rank 0 leaves; what matters is rank 0's report
     assert _read(tmp_path, 0).startswith("timeout surfaced after"), _read(tmp_path, 0)
+
+
+@pytest.mark.timeout(120)
+def test_gradient_all_reduce_buckets_two_ranks(tmp_path):
+    """Training step, DDP leg (train_cogvideo_to2v.py:1157-1164): optim.GradSync on gloo — buckets are launched only once the backward has passed
+    their end, every element is reduced exactly once, and the result is the rank average (scale folded in by the accumulation)."""
+    from tokensgen_amd.runtime import launch
+    launch(2, [sys.executable, WORKER, "gradsync", str(tmp_path)])
+    assert _read(tmp_path, 0) == "ok" and _read(tmp_path, 1) == "ok"
+
+
+def test_arena_order_is_backward_order_and_keeps_qkv_adjacent():
+    from tokensgen_amd.optim import arena_order
+    names = [f"transformer_blocks.{i}.{n}" for i in range(3) for n in
+             ("vip_norm1.linear.weight", "attn1.processor.vip_to_v.weight", "attn1.processor.vip_to_q.weight", "attn1.processor.vip_to_k.weight",
+              "attn1.processor.vip_to_k.bias", "attn1.processor.vip_to_q.bias", "attn1.processor.vip_to_v.bias")]
+    names += ["patch_embed.vip_proj.weight", "resampler.latents", "resampler.proj_in.weight"]
+    order = arena_order(names, 3)
+    assert order[0].startswith("transformer_blocks.2.") and order[7].startswith("transformer_blocks.1.") and order[14].startswith("transformer_blocks.0.")
+    assert [n.split("processor.")[1] for n in order[:6]] == ["vip_to_q.weight", "vip_to_k.weight", "vip_to_v.weight", "vip_to_q.bias", "vip_to_k.bias", "vip_to_v.bias"]
+    assert order[-3:] == ["patch_embed.vip_proj.weight", "resampler.latents", "resampler.proj_in.weight"]

@@ -346,3 +346,82 @@ def test_to2v_model_training_forward_backward_vs_autograd_of_the_oracle_model():
     assert _rel(d_vip, want_vip) < 2e-2
     for name in train_keys:
         assert _rel(grads[name], sd[name].grad) < 4e-2, name
+
+
+def test_optimizer_step_vs_torch_adamw_with_clipping():
+    """optim.ParamArena + optim.AdamW (tg_grad_accumulate / tg_grad_clip_coef / tg_adamw_step) against torch.optim.AdamW + clip_grad_norm_ on fp32
+    copies (train_cogvideo_to2v.py:1091-1098, 2012-2021; yaml betas 0.9 / 0.95, eps 1e-8, weight decay 1e-4, max_grad_norm 1.0): three steps with two
+    accumulated micro-gradients each; the clipped prefix (the transformer's parameters) and the unclipped rest (the Resampler) as in the reference."""
+    from tokensgen_amd import optim
+    g = torch.Generator().manual_seed(11)
+    shapes = {"transformer_blocks.0.a.vip_w": (37, 50), "transformer_blocks.0.a.vip_b": (129,), "patch_embed.vip_proj.weight": (64, 64), "resampler.latents": (1, 7, 33)}
+    params = {k: (torch.randn(*s, generator=g) * 0.1).to(BF) for k, s in shapes.items()}
+    order = optim.arena_order(list(params), 1)
+    arena = optim.ParamArena({k: v.to(DEV) for k, v in params.items()}, order, DEV)
+    n_clip = arena.prefix_elems(lambda n: not n.startswith("resampler."))
+    assert 0 < n_clip < arena.numel and arena.param.data_ptr() % 128 == 0
+    lr = 3e-2                                                # large enough that a bf16 parameter moves every step
+    opt = optim.AdamW(arena, lr=lr, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-4, max_grad_norm=1.0, clip_elems=n_clip)
+    ref = {k: torch.nn.Parameter(v.float().clone()) for k, v in params.items()}
+    topt = torch.optim.AdamW(list(ref.values()), lr=lr, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-4)
+    for step in range(3):
+        g1 = {k: (torch.randn(*s, generator=g) * (3.0 if step == 1 else 0.005)).to(BF) for k, s in shapes.items()}     # step 1 clips, the others do not
+        g2 = {k: torch.randn(*s, generator=g) * 0.005 for k, s in shapes.items()}                                      # fp32 gradients are accepted too
+        arena.accumulate({k: v.to(DEV) for k, v in g1.items()}, 0.5)
+        arena.accumulate({k: v.to(DEV) for k, v in g2.items()}, 0.5)
+        for k in ref:
+            ref[k].grad = 0.5 * g1[k].float() + 0.5 * g2[k]
+        assert _rel(arena.grad_view("resampler.latents"), ref["resampler.latents"].grad) < 1e-6
+        norm = torch.nn.utils.clip_grad_norm_([ref[k] for k in ref if not k.startswith("resampler.")], 1.0)
+        topt.step()
+        opt.step()
+        assert abs(opt.coef[0].item() - norm.item()) < 1e-4 * norm.item()
+        assert (opt.coef[1].item() < 1.0) == (step == 1)
+        assert float(arena.grad.abs().max()) == 0.0                          # zero_grad in the same pass
+        for k in ref:
+            got, want = arena.views[k].float().cpu(), ref[k].detach().to(BF).float()
+            ulp = want.abs().clamp_min(1e-30).log2().floor().exp2() * 2.0 ** -7
+            assert ((got - want).abs() <= ulp).all(), (k, step)              # at most one bf16 ulp (fp32 operation order)
+            assert measured(((got != want).float().mean()).item()) < 2e-2, (k, step)
+            ref[k].data.copy_(got)                                           # the reference continues from the bf16 parameters, moments carry over
+
+
+def test_training_steps_reduce_the_loss_and_update_only_trainable_parameters():
+    """train.To2VTrainStep end to end on a 2-layer model: three optimizer steps of two micro-steps each on one fixed batch — the loss falls, the
+    arena-backed views are what the next forward reads (the fused vip_to_qkv weight is a view, not a stale copy), frozen tensors are untouched."""
+    import numpy as np
+    from oracle import dit_ref as O
+    from oracle import scheduler_ref as S
+    from tokensgen_amd import optim, train
+    B, H, Nt, Fr, Hh, Ww = 1, 2, 9, 4, 10, 12
+    f32 = np.float32
+    cfg = dict(num_attention_heads=H, attention_head_dim=64, num_layers=2, patch_size=2, time_embed_dim=128, text_embed_dim=64, in_channels=16, out_channels=16)
+    sd = {k: v.to(BF).to(DEV).contiguous() for k, v in O.make_state_dict(cfg, n_vip_dim=128, seed=95, std=0.08).items()}
+    frozen_before = {k: v.clone() for k, v in sd.items() if "vip_" not in k}
+    tr = train.To2VTrainer(sd, H, 2, patch_size=2, vip_scale=1.0)
+    arena = optim.ParamArena({k: sd[k] for k in tr.trainable}, optim.arena_order(tr.trainable, 2), DEV)
+    tr.use_arena(arena)
+    start = arena.param.clone()
+    opt = optim.AdamW(arena, lr=2e-3, max_grad_norm=1.0)
+    _, ac = S.alphas_cumprod()
+    ac = torch.as_tensor(ac, dtype=torch.float32)
+    step = train.To2VTrainStep(tr, arena, opt, ac, accumulation_steps=2)
+    g = torch.Generator().manual_seed(96)
+    x0, noise = (torch.randn(B, Fr, 16, Hh, Ww, generator=g).to(BF).to(DEV) for _ in range(2))
+    text, vip = _rand(B, Nt, 64, seed=97).to(DEV), _rand(B, 5, 128, 2, 3, seed=98).to(DEV)
+    ts = torch.tensor([[500, 520, 480, 510]])
+    rope = O.rope_3d(64, np.arange(4, dtype=f32), np.arange(5, dtype=f32), np.arange(6, dtype=f32))
+    vrope = O.rope_3d(64, np.arange(4, dtype=f32) + f32(3), np.arange(5, dtype=f32), np.arange(6, dtype=f32))
+    crope = O.rope_3d(64, np.linspace(1000, 1016.25, 5, dtype=f32), np.arange(2, dtype=f32), np.arange(3, dtype=f32))
+    losses, stepped = [], []
+    for i in range(8):
+        loss, did = step.micro_step(x0, noise, ts, text, vip, rope, vrope, crope)
+        losses.append(loss.item()); stepped.append(did)
+    assert stepped == [False, True] * 4 and opt.t == 4
+    assert losses[0] == losses[1]                                             # same batch, no step in between: bitwise the same loss
+    assert losses[2] < losses[0] and losses[6] < losses[2], losses
+    assert (arena.param != start).float().mean().item() > 0.5                 # the parameters moved
+    blk = tr._blocks[0]
+    assert blk.Wv.data_ptr() == arena.views["transformer_blocks.0.attn1.processor.vip_to_q.weight"].data_ptr()
+    for k, v in frozen_before.items():
+        assert torch.equal(sd[k], v), k

@@ -305,3 +305,94 @@ extern "C" int tg_colsum_f32(const float* src, long ld, int rows, int cols, floa
     TG_LAUNCH_CHECK("tg_colsum_f32");
     return TG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Optimizer step on a flat arena (train_cogvideo_to2v.py:2012-2021: clip_grad_norm_ on the transformer's parameters, AdamW, zero_grad).
+// All HBM-bound streaming passes: 16-byte accesses, grid-stride, no host synchronisation (the clip coefficient stays on the device).
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int OPT_BLOCK = 256, OPT_PER_THREAD = 8, OPT_MAX_BLOCKS = 2048;
+
+// acc[i] += scale * g[i]   (g bf16 or fp32): gradient accumulation over micro-steps (accelerate's `accumulate`: loss / accumulation steps)
+template <bool SRC_BF16>
+__global__ __launch_bounds__(OPT_BLOCK) void grad_accum_kernel(const void* __restrict__ g, float* __restrict__ acc, long n, float scale, int overwrite) {
+    for (long i = (long)blockIdx.x * OPT_BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * OPT_BLOCK) {
+        const float v = SRC_BF16 ? bf16_to_f32(((const bf16_t*)g)[i]) : ((const float*)g)[i];
+        acc[i] = overwrite ? scale * v : acc[i] + scale * v;
+    }
+}
+
+__global__ __launch_bounds__(OPT_BLOCK) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
+    float a = 0.f;
+    for (long i = (long)blockIdx.x * OPT_BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * OPT_BLOCK) { const float v = g[i]; a += v * v; }
+    a = wave_sum(a);
+    __shared__ float red[OPT_BLOCK / 64];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// coef[0] = total norm, coef[1] = min(1, max_norm / (norm + 1e-6))  (torch.nn.utils.clip_grad_norm_); fixed summation order
+__global__ void clip_coef_kernel(const float* __restrict__ partial, int n_partial, float max_norm, float* __restrict__ coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int i = 0; i < n_partial; ++i) s += (double)partial[i];
+    const float norm = (float)sqrt(s);
+    coef[0] = norm;
+    coef[1] = max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
+}
+
+// torch.optim.AdamW (decoupled weight decay, bias correction, eps outside the corrected sqrt) on fp32 moments; parameters are bf16 and are
+// read / written once (fp32 arithmetic in between).  clip: optional device pointer to the coefficient of clip_coef_kernel (coef + 1).
+__global__ __launch_bounds__(OPT_BLOCK) void adamw_kernel(bf16_t* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                                                          float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                          const float* __restrict__ clip, int zero_grad, float* __restrict__ g_rw) {
+    const float cs = clip ? *clip : 1.f;
+    for (long i = (long)blockIdx.x * OPT_BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * OPT_BLOCK) {
+        const float gi = g[i] * cs;
+        float pi = bf16_to_f32(p[i]);
+        pi *= 1.f - lr * wd;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = f32_to_bf16(pi);
+        if (zero_grad) g_rw[i] = 0.f;
+    }
+}
+
+inline unsigned opt_blocks(long n) { const long b = (n + OPT_BLOCK - 1) / OPT_BLOCK; return (unsigned)(b < OPT_MAX_BLOCKS ? (b > 0 ? b : 1) : OPT_MAX_BLOCKS); }
+}  // namespace
+
+extern "C" int tg_grad_accumulate(const void* grad, int grad_is_bf16, float* acc, long n, float scale, int overwrite, hipStream_t stream) {
+    TG_REQUIRE(grad && acc, TG_ERR_ARG, "tg_grad_accumulate: null pointer");
+    TG_REQUIRE(n > 0, TG_ERR_SHAPE, "tg_grad_accumulate: n must be positive");
+    if (grad_is_bf16) hipLaunchKernelGGL(grad_accum_kernel<true>, dim3(opt_blocks(n)), dim3(OPT_BLOCK), 0, stream, grad, acc, n, scale, overwrite);
+    else hipLaunchKernelGGL(grad_accum_kernel<false>, dim3(opt_blocks(n)), dim3(OPT_BLOCK), 0, stream, grad, acc, n, scale, overwrite);
+    TG_LAUNCH_CHECK("tg_grad_accumulate");
+    return TG_OK;
+}
+
+extern "C" long tg_grad_norm_ws_floats(void) { return OPT_MAX_BLOCKS; }
+
+extern "C" int tg_grad_clip_coef(const float* grad, long n, float max_norm, float* ws, float* coef, hipStream_t stream) {
+    TG_REQUIRE(grad && ws && coef, TG_ERR_ARG, "tg_grad_clip_coef: null pointer");
+    TG_REQUIRE(n > 0, TG_ERR_SHAPE, "tg_grad_clip_coef: n must be positive");
+    const unsigned nb = opt_blocks(n);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(OPT_BLOCK), 0, stream, grad, n, ws);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws, (int)nb, max_norm, coef);
+    TG_LAUNCH_CHECK("tg_grad_clip_coef");
+    return TG_OK;
+}
+
+extern "C" int tg_adamw_step(void* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, int step, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, const float* clip_coef, int zero_grad, hipStream_t stream) {
+    TG_REQUIRE(param && grad && exp_avg && exp_avg_sq, TG_ERR_ARG, "tg_adamw_step: null pointer");
+    TG_REQUIRE(n > 0 && step >= 1, TG_ERR_SHAPE, "tg_adamw_step: n and step must be positive");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(opt_blocks(n)), dim3(OPT_BLOCK), 0, stream, (bf16_t*)param, (const float*)grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                       weight_decay, bc1, bc2s, clip_coef, zero_grad, grad);
+    TG_LAUNCH_CHECK("tg_adamw_step");
+    return TG_OK;
+}

@@ -39,6 +39,9 @@ PROTOTYPES = {
     "tg_gate_residual_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, C.POINTER(GroupTable), _vp, _vp],
     "tg_act": [_vp, _vp, _vp, _l, _i, _vp],
     "tg_colsum_f32": [_vp, _l, _i, _i, _vp, _vp],
+    "tg_grad_accumulate": [_vp, _i, _vp, _l, _f, _i, _vp],
+    "tg_grad_clip_coef": [_vp, _l, _f, _vp, _vp, _vp],
+    "tg_adamw_step": [_vp, _vp, _vp, _vp, _l, _i, _f, _f, _f, _f, _f, _vp, _i, _vp],
     "tg_vpred_loss_grad": [_vp, _vp, _vp, _vp, _i, _l, _f, _vp, _vp, _vp],
     "tg_timestep_sinusoid": [_vp, _i, _i, _vp, _vp],
     "tg_rope_table_3d": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
@@ -68,6 +71,7 @@ QUERIES = {
     "tg_qk_layernorm_rope_bwd_partial_floats": [C.c_int, C.c_int, C.c_int],
     "tg_colsum_partial_floats": [C.c_int, C.c_int],
     "tg_vpred_loss_partial_floats": [C.c_int, C.c_long],
+    "tg_grad_norm_ws_floats": [],
 }
 
 _lib = None

@@ -212,6 +212,18 @@ def _gate_res_bwd(dout, y, table):
     return dy, tg
 
 
+def _cat_or_view(ts):
+    """Row-wise concatenation of same-width tensors: a VIEW when they already sit back to back in memory (the parameter arena lays vip_to_q/k/v
+    out that way, so an optimizer step is seen without re-concatenating), else a copy."""
+    t0 = ts[0]
+    adjacent = all(t.is_contiguous() for t in ts) and all(ts[i + 1].data_ptr() == ts[i].data_ptr() + ts[i].numel() * ts[i].element_size()
+                                                            for i in range(len(ts) - 1))
+    if adjacent and t0.numel() % 64 == 0:
+        rows = sum(t.shape[0] for t in ts)
+        return torch.as_strided(t0, (rows,) + tuple(t0.shape[1:]), t0.stride())
+    return torch.cat(ts).contiguous()
+
+
 class To2VBlockTrainer:
     """One CogVideoXBlock with the vip branch (cogvideox_transformer_3d.py:221-332 + attention_processor.py:1982-2155) for the training step:
     `forward` runs the product kernels and keeps what the backward needs; `backward` returns dL/d(parameter) for every TRAINABLE parameter of the
@@ -225,10 +237,10 @@ class To2VBlockTrainer:
         self.keep = True          # False: forward only (the checkpointed pass of To2VTrainer keeps nothing but the block inputs)
         g = lambda n: sd[f"{pre}.{n}"]
         P = "attn1.processor."
-        self.Wqkv = torch.cat([g(f"attn1.to_{n}.weight") for n in "qkv"]).contiguous()
-        self.bqkv = torch.cat([g(f"attn1.to_{n}.bias") for n in "qkv"]).contiguous()
-        self.Wv = torch.cat([g(f"{P}vip_to_{n}.weight") for n in "qkv"]).contiguous()
-        self.bv = torch.cat([g(f"{P}vip_to_{n}.bias") for n in "qkv"]).contiguous()
+        self.Wqkv = _cat_or_view([g(f"attn1.to_{n}.weight") for n in "qkv"])
+        self.bqkv = _cat_or_view([g(f"attn1.to_{n}.bias") for n in "qkv"])
+        self.Wv = _cat_or_view([g(f"{P}vip_to_{n}.weight") for n in "qkv"])           # views of the parameter arena when q, k, v are adjacent there
+        self.bv = _cat_or_view([g(f"{P}vip_to_{n}.bias") for n in "qkv"])
 
     def _mod(self, emb, which):
         """[B, F, 9D] modulation tensor of norm{which}: columns 0..6D from norm.linear (per frame), 6D..9D from vip_norm.linear (frame 0 only)."""
@@ -389,6 +401,13 @@ class To2VTrainer:
         self.trainable = sorted(k for k in sd if "vip_" in k)
         self._blocks = None
 
+    def use_arena(self, arena):
+        """Move the trainable parameters into a ParamArena (optim.py): the state-dict entries become views of its flat bf16 buffer, so an
+        optimizer step on the arena is what the next forward reads."""
+        for n in self.trainable:
+            self.sd[n] = arena.views[n]
+        self._blocks = None
+
     def _front(self, latents, text, timestep, vip_tokens):
         sd, D, ps = self.sd, self.D, self.ps
         dev = latents.device
@@ -460,9 +479,10 @@ class To2VTrainer:
         return out
 
     @torch.no_grad()
-    def backward(self, d_out):
+    def backward(self, d_out, on_block_done=None):
         """d_out: dL/d(model output) bf16 [B, F, C, H, W].  Returns (grads: {full parameter name: gradient} for every trainable transformer
-        parameter, d_vip_tokens bf16 [B, f*h*w, c]: the gradient handed to the Resampler)."""
+        parameter, d_vip_tokens bf16 [B, f*h*w, c]: the gradient handed to the Resampler).  on_block_done(i, block_grads): called as soon as
+        block i's gradients are final (gradient accumulation / bucketed all-reduce overlap)."""
         sd, D, S = self.sd, self.D, self._saved
         B, Fr, C, Hh, Ww, Nt, Nv, Np, Fm = S["dims"]
         dev = d_out.device
@@ -483,11 +503,60 @@ class To2VTrainer:
             blk.forward(hidden, enc, S["temb"], rope, vrope, crope)           # recompute with the intermediates kept
             g, d_hid, d_enc = blk.backward(d_hid, d_enc)
             blk.saved = None
-            for k, v in g.items():
-                grads[f"transformer_blocks.{i}.{k}"] = v
+            g = {f"transformer_blocks.{i}.{k}": v for k, v in g.items()}
+            if on_block_done is not None:
+                on_block_done(i, g)
+            else:
+                grads.update(g)
             d_hid = d_hid.contiguous()
         self._ckpt = []
         d_vip = d_enc[:, Nt:].reshape(B * Np, D)
         dW, db, dx = linear_backward(S["vtok"].view(B * Np, -1), d_vip.contiguous(), sd["patch_embed.vip_proj.weight"], need_dx=True)
         grads["patch_embed.vip_proj.weight"], grads["patch_embed.vip_proj.bias"] = dW, db
         return grads, dx.reshape(B, Np, -1)
+
+
+class To2VTrainStep:
+    """Host mirror of the reference loop body (train_cogvideo_to2v.py:1721-2021) for the transformer: add_noise -> forward (checkpointed) ->
+    v-prediction loss -> backward -> gradient accumulation (`accelerator.accumulate`, loss / accumulation steps) -> on the last micro-step of
+    the window: bucketed all-reduce (DDP), clip_grad_norm_ on the transformer's parameters, AdamW, zero_grad.
+    `resampler_backward(d_vip_tokens) -> {name: grad}` (optional) chains the Resampler (its parameters sit behind the transformer's in the arena)."""
+
+    def __init__(self, trainer, arena, optimizer, alphas_cumprod, accumulation_steps=9, sync=None, resampler_backward=None):
+        self.tr, self.arena, self.opt, self.acp, self.accum, self.sync, self.rbwd = trainer, arena, optimizer, alphas_cumprod, accumulation_steps, sync, resampler_backward
+        self.micro = 0
+        self.world = sync.world if sync is not None else 1
+
+    @torch.no_grad()
+    def add_noise(self, x0, noise, timesteps):
+        """scheduling_dpm_cogvideox.py:498-519 (the table is cast to the sample dtype before the square roots); per-frame timesteps [B, F] index frames."""
+        acp = self.acp.to(x0.device, torch.float32).to(x0.dtype)
+        ts = timesteps.to(x0.device)
+        sa, sb = acp[ts] ** 0.5, (1 - acp[ts]) ** 0.5
+        while sa.dim() < x0.dim():
+            sa, sb = sa.unsqueeze(-1), sb.unsqueeze(-1)
+        return sa * x0 + sb * noise
+
+    @torch.no_grad()
+    def micro_step(self, model_input, noise, timesteps, text, vip_tokens, rope, vrope, crope):
+        """One micro-batch.  Returns (loss tensor on the device, stepped: bool)."""
+        noisy = self.add_noise(model_input, noise, timesteps).contiguous()
+        out = self.tr.forward(noisy, text, timesteps, vip_tokens, rope, vrope, crope)
+        loss, _, d_out = vpred_loss_and_grad(out, noisy, model_input.contiguous(), timesteps, self.acp)
+        self.micro += 1
+        last = self.micro % self.accum == 0
+        scale = 1.0 / (self.accum * self.world)
+
+        def done(i, g):
+            self.arena.accumulate(g, scale)
+            if last and self.sync is not None:
+                self.sync.ready(max(self.arena.end_of(n) for n in g))
+        rest, d_vip = self.tr.backward(d_out, on_block_done=done)
+        self.arena.accumulate(rest, scale)
+        if self.rbwd is not None:
+            self.arena.accumulate(self.rbwd(d_vip), scale)
+        if last:
+            if self.sync is not None:
+                self.sync.finish()
+            self.opt.step()
+        return loss, last
