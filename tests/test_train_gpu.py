@@ -425,3 +425,102 @@ def test_training_steps_reduce_the_loss_and_update_only_trainable_parameters():
     assert blk.Wv.data_ptr() == arena.views["transformer_blocks.0.attn1.processor.vip_to_q.weight"].data_ptr()
     for k, v in frozen_before.items():
         assert torch.equal(sd[k], v), k
+
+
+def test_resampler_backward_vs_autograd_of_the_oracle():
+    """The Resampler is trainable as a whole (train_cogvideo_to2v.py:1479-1481): train.ResamplerTrainer forward + backward (LayerNorms, to_q / to_kv /
+    to_out, per-head QK-norm + the two rotary segments, the 24-query attention over 96 keys, FeedForward, proj_in / proj_out / norm_out, latents) against
+    autograd through oracle.resampler_ref.resampler_forward in fp32 on the same bf16-rounded weights — every parameter of a depth-2 module."""
+    import numpy as np
+    from oracle import dit_ref as O
+    from oracle import resampler_ref as RR
+    from tokensgen_amd import train
+    cfg = dict(dim=128, depth=2, dim_head=64, heads=2, num_height_queries=2, num_width_queries=3, num_temporal_queries=4, embedding_dim=128, output_dim=128, ff_mult=4)
+    sd = {k: v.to(BF).float().requires_grad_(True) for k, v in RR.make_state_dict(cfg, seed=61).items()}
+    b = 2
+    x = _rand(b, 3, 24, 128, seed=62)
+    f32 = np.float32
+    img = O.rope_3d(64, np.arange(3, dtype=f32), np.arange(4, dtype=f32), np.arange(6, dtype=f32))
+    smp = O.rope_3d(64, np.linspace(0, 3, 4, endpoint=False, dtype=f32), np.linspace(0, 4, 2, endpoint=False, dtype=f32), np.linspace(0, 6, 3, endpoint=False, dtype=f32))
+    out_ref = RR.resampler_forward(sd, cfg, x.float(), img, smp)
+    tok_ref = out_ref.permute(0, 1, 3, 4, 2).reshape(b, 24, 128)
+    G = _rand(b, 24, 128, seed=63)
+    (tok_ref * G.float()).sum().backward()
+    sd_dev = {k: v.detach().to(BF).to(DEV).contiguous() for k, v in sd.items()}
+    rt = train.ResamplerTrainer(sd_dev, depth=2, heads=2)
+    tok, ctx = rt.forward(x.to(DEV), img, smp)
+    assert _rel(tok, tok_ref.detach()) < 1e-2
+    grads = rt.backward(ctx, G.to(DEV))
+    assert sorted(grads) == sorted("resampler." + k for k in sd)
+    for k in sd:
+        assert _rel(grads["resampler." + k], sd[k].grad) < 4e-2, k
+
+
+def test_full_micro_step_with_resampler_gradients_vs_autograd_of_the_oracle_chain():
+    """One whole micro-step of the reference loop body (train_cogvideo_to2v.py:1931-2010) on the HIP path: Resampler over two chunks -> five temporal
+    slots per batch item -> add_noise -> transformer (checkpointed) -> v-prediction loss -> backward through the transformer AND both Resampler calls,
+    accumulated into the gradient arena.  Every trainable tensor (38 transformer + 38 Resampler) against autograd through the oracle chain
+    (resampler_ref -> dit_ref -> train_ref) in fp32 on the same bf16-rounded weights / inputs / noise."""
+    import numpy as np
+    from oracle import dit_ref as O
+    from oracle import resampler_ref as RR
+    from oracle import scheduler_ref as S
+    from oracle import train_ref as T
+    from tokensgen_amd import optim, train
+    B, H, Nt, Fr, Hh, Ww = 2, 2, 9, 4, 10, 12
+    f32 = np.float32
+    cfg = dict(num_attention_heads=H, attention_head_dim=64, num_layers=2, patch_size=2, time_embed_dim=128, text_embed_dim=64, in_channels=16, out_channels=16)
+    rcfg = dict(dim=128, depth=2, dim_head=64, heads=2, num_height_queries=2, num_width_queries=3, num_temporal_queries=4, embedding_dim=128, output_dim=128, ff_mult=4)
+    sd = {k: v.to(BF).float() for k, v in O.make_state_dict(cfg, n_vip_dim=128, seed=101, std=0.08).items()}
+    rsd = {k: v.to(BF).float().requires_grad_(True) for k, v in RR.make_state_dict(rcfg, seed=102).items()}
+    tkeys = sorted(k for k in sd if "vip_" in k)
+    for k in tkeys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    _, ac = S.alphas_cumprod()
+    ac = torch.as_tensor(ac, dtype=torch.float32)
+    g = torch.Generator().manual_seed(103)
+    x0, noise = (torch.randn(B, Fr, 16, Hh, Ww, generator=g).to(BF) for _ in range(2))
+    text, emb = _rand(B, Nt, 64, seed=104), _rand(B, 6, 24, 128, seed=105)          # 2 chunks x 3 latent frames x 24 tokens
+    ts = torch.randint(20, 980, (B, Fr), generator=g)
+    start = [1, 3]
+    rope = O.rope_3d(64, np.arange(4, dtype=f32), np.arange(5, dtype=f32), np.arange(6, dtype=f32))
+    vrope = O.rope_3d(64, np.arange(4, dtype=f32) + f32(3), np.arange(5, dtype=f32), np.arange(6, dtype=f32))
+    crope = O.rope_3d(64, np.linspace(1000, 1016.25, 5, dtype=f32), np.arange(2, dtype=f32), np.arange(3, dtype=f32))
+    img = O.rope_3d(64, np.arange(3, dtype=f32), np.arange(4, dtype=f32), np.arange(6, dtype=f32))
+    smp = O.rope_3d(64, np.linspace(0, 3, 4, endpoint=False, dtype=f32), np.linspace(0, 4, 2, endpoint=False, dtype=f32), np.linspace(0, 6, 3, endpoint=False, dtype=f32))
+    # ---- oracle chain ----
+    toks = torch.cat([RR.resampler_forward(rsd, rcfg, emb[:, c * 3:(c + 1) * 3].float(), img, smp) for c in range(2)], dim=1)      # [B, 8, 128, 2, 3]
+    toks = toks.to(BF).float()                                                        # the Resampler's output is a bf16 tensor (the cast passes gradients through)
+    vip = torch.stack([toks[b, start[b]:start[b] + 5] for b in range(B)])
+    acb = ac.to(BF)
+    sa, sb = (acb[ts] ** 0.5)[..., None, None, None], ((1 - acb[ts]) ** 0.5)[..., None, None, None]
+    noisy = (sa * x0 + sb * noise)                                                    # scheduler.add_noise in bf16
+    out_ref = O.dit_forward(sd, cfg, noisy.float(), text.float(), ts, vip, rope, vrope, crope, vip_scale=[1.0])
+    loss_ref, _ = T.vpred_loss(ac, out_ref, noisy.float(), x0.float(), ts)
+    loss_ref.backward()
+    # ---- HIP path ----
+    sd_dev = {k: v.detach().to(BF).to(DEV).contiguous() for k, v in sd.items()}
+    rsd_dev = {k: v.detach().to(BF).to(DEV).contiguous() for k, v in rsd.items()}
+    tr = train.To2VTrainer(sd_dev, H, 2, patch_size=2, vip_scale=1.0)
+    rt = train.ResamplerTrainer(rsd_dev, depth=2, heads=2)
+    params = {k: sd_dev[k] for k in tr.trainable}
+    params.update({"resampler." + k: v for k, v in rsd_dev.items()})
+    arena = optim.ParamArena(params, optim.arena_order(list(params), 2), DEV)
+    tr.use_arena(arena); rt.use_arena(arena)
+    n_clip = arena.prefix_elems(lambda n: not n.startswith("resampler."))
+    opt = optim.AdamW(arena, lr=1e-3, clip_elems=n_clip)
+    step = train.To2VTrainStep(tr, arena, opt, ac, accumulation_steps=2, resampler=rt)
+    step.latent_frames_per_chunk = 3
+    loss, did = step.micro_step(x0.to(DEV), noise.to(DEV), ts, text.to(DEV), None, rope, vrope, crope, image_embeddings=emb.to(DEV), emb_start_idx=start,
+                                resampler_ropes=(img, smp))
+    assert not did and abs(loss.item() - loss_ref.item()) < 2e-2 * abs(loss_ref.item())
+    for k in tkeys:
+        assert _rel(arena.grad_view(k) * 2.0, sd[k].grad) < 5e-2, k             # the arena holds grad / accumulation_steps
+    for k in rsd:
+        assert _rel(arena.grad_view("resampler." + k) * 2.0, rsd[k].grad) < 5e-2, k
+    before = arena.param.clone()
+    _, did = step.micro_step(x0.to(DEV), noise.to(DEV), ts, text.to(DEV), None, rope, vrope, crope, image_embeddings=emb.to(DEV), emb_start_idx=start,
+                             resampler_ropes=(img, smp))
+    assert did and opt.t == 1 and float(arena.grad.abs().max()) == 0.0
+    moved = (arena.param != before)
+    assert moved[:n_clip].float().mean().item() > 0.3 and moved[n_clip:].float().mean().item() > 0.3      # transformer and Resampler parameters both stepped

@@ -297,7 +297,7 @@ class To2VBlockTrainer:
         K.attention(qx, kv, vt2, Np, o2, H, sm)
         K.attention(qv, qkvv[:, :, D:2 * D], vt3, N, o3, H, sm)
         AO = e(B, N, D)
-        K.attention(q, k, vt1, N1, AO[:, :N1], H, sm, qx, kv, vt2, Np, self.s)          # O1 + s O2 exactly as the inference path forms it
+        torch.add(o1, o2 * self.s, out=AO[:, :N1])           # `hidden_states + scale * vip_hidden_states` on bf16 tensors (attention_processor.py:2117-2125)
         AO[:, N1:] = o3
         y_attn = e(B, N, D)
         K.gemm(AO, sd[A + "to_out.0.weight"], sd[A + "to_out.0.bias"], y_attn, L.EPI_BIAS)
@@ -424,14 +424,17 @@ class To2VTrainer:
         K.gemm(t1, sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"], temb, L.EPI_BIAS)
         hw = (Hh // ps) * (Ww // ps)
         Nt, Nv = text.shape[1], Fr * hw
-        vb, vf, vc, vh, vw = vip_tokens.shape
-        Np = vf * vh * vw
+        if vip_tokens.dim() == 3:                          # already token-major [B, Np, c] (the Resampler's own output order)
+            Np, vc = vip_tokens.shape[1:]
+        else:
+            vb, vf, vc, vh, vw = vip_tokens.shape
+            Np = vf * vh * vw
         X = e(B, Nt + Nv + Np, D)
         patches = e(B, Nv, C * ps * ps)
         K.patchify(latents.to(BF16).reshape(B * Fr, C, Hh, Ww).contiguous(), patches.view(B * Nv, -1), ps)
         K.gemm(patches, sd["patch_embed.proj.weight"].reshape(D, -1), sd["patch_embed.proj.bias"], X[:, Nt:Nt + Nv], L.EPI_BIAS)
         K.gemm(text.to(BF16).contiguous(), sd["patch_embed.text_proj.weight"], sd["patch_embed.text_proj.bias"], X[:, :Nt], L.EPI_BIAS)
-        vtok = vip_tokens.to(BF16).permute(0, 1, 3, 4, 2).reshape(B, Np, vc).contiguous()
+        vtok = vip_tokens.to(BF16).contiguous() if vip_tokens.dim() == 3 else vip_tokens.to(BF16).permute(0, 1, 3, 4, 2).reshape(B, Np, vc).contiguous()
         K.gemm(vtok, sd["patch_embed.vip_proj.weight"], sd["patch_embed.vip_proj.bias"], X[:, Nt + Nv:], L.EPI_BIAS)
         return X, temb.view(B, Fm, te), vtok, (B, Fr, C, Hh, Ww, Nt, Nv, Np, Fm)
 
@@ -522,10 +525,15 @@ class To2VTrainStep:
     the window: bucketed all-reduce (DDP), clip_grad_norm_ on the transformer's parameters, AdamW, zero_grad.
     `resampler_backward(d_vip_tokens) -> {name: grad}` (optional) chains the Resampler (its parameters sit behind the transformer's in the arena)."""
 
-    def __init__(self, trainer, arena, optimizer, alphas_cumprod, accumulation_steps=9, sync=None, resampler_backward=None):
-        self.tr, self.arena, self.opt, self.acp, self.accum, self.sync, self.rbwd = trainer, arena, optimizer, alphas_cumprod, accumulation_steps, sync, resampler_backward
+    def __init__(self, trainer, arena, optimizer, alphas_cumprod, accumulation_steps=9, sync=None, resampler=None):
+        self.tr, self.arena, self.opt, self.acp, self.accum, self.sync, self.rs = trainer, arena, optimizer, alphas_cumprod, accumulation_steps, sync, resampler
         self.micro = 0
         self.world = sync.world if sync is not None else 1
+        self.rs_temporal_queries = 4          # resampler_params.num_temporal_queries of the yaml
+        self.latent_frames_per_chunk = 13     # 49 video frames -> 13 latent frames per chunk
+
+    def _frames_per_chunk(self, image_embeddings):
+        return min(self.latent_frames_per_chunk, image_embeddings.shape[1])
 
     @torch.no_grad()
     def add_noise(self, x0, noise, timesteps):
@@ -538,8 +546,26 @@ class To2VTrainStep:
         return sa * x0 + sb * noise
 
     @torch.no_grad()
-    def micro_step(self, model_input, noise, timesteps, text, vip_tokens, rope, vrope, crope):
-        """One micro-batch.  Returns (loss tensor on the device, stepped: bool)."""
+    def micro_step(self, model_input, noise, timesteps, text, vip_tokens, rope, vrope, crope, image_embeddings=None, emb_start_idx=None,
+                   resampler_ropes=(None, None), vip_frames=5):
+        """One micro-batch.  Either `vip_tokens` [B, f, c, h, w] is given (Resampler outside), or `image_embeddings` [B, chunks * f_lat, n, c]
+        (patch-embedded VAE latents, train_cogvideo_to2v.py:1656-1672) with `emb_start_idx[b]`: the Resampler (trainable) runs once per chunk, the
+        chunk outputs are concatenated along time and `vip_frames` temporal slots from emb_start_idx[b] on are handed to the transformer
+        (:1931-1968); their gradient flows back through every chunk that contributed.  Returns (loss tensor on the device, stepped: bool)."""
+        ctxs = None
+        if image_embeddings is not None:
+            rs = self.rs
+            B = image_embeddings.shape[0]
+            n_chunks = image_embeddings.shape[1] // self._frames_per_chunk(image_embeddings)
+            per = image_embeddings.shape[1] // n_chunks
+            outs, ctxs = [], []
+            for c in range(n_chunks):
+                tok, ctx = rs.forward(image_embeddings[:, c * per:(c + 1) * per], *resampler_ropes)
+                outs.append(tok); ctxs.append(ctx)
+            Nq = outs[0].shape[1]
+            slot = Nq // self.rs_temporal_queries
+            alltok = torch.cat(outs, dim=1)
+            vip_tokens = torch.stack([alltok[b, int(emb_start_idx[b]) * slot:(int(emb_start_idx[b]) + vip_frames) * slot] for b in range(B)])
         noisy = self.add_noise(model_input, noise, timesteps).contiguous()
         out = self.tr.forward(noisy, text, timesteps, vip_tokens, rope, vrope, crope)
         loss, _, d_out = vpred_loss_and_grad(out, noisy, model_input.contiguous(), timesteps, self.acp)
@@ -553,10 +579,146 @@ class To2VTrainStep:
                 self.sync.ready(max(self.arena.end_of(n) for n in g))
         rest, d_vip = self.tr.backward(d_out, on_block_done=done)
         self.arena.accumulate(rest, scale)
-        if self.rbwd is not None:
-            self.arena.accumulate(self.rbwd(d_vip), scale)
+        if ctxs is not None:
+            d_all = torch.zeros(alltok.shape, dtype=BF16, device=alltok.device)
+            for b in range(B):
+                d_all[b, int(emb_start_idx[b]) * slot:(int(emb_start_idx[b]) + vip_frames) * slot] = d_vip[b]
+            for c, ctx in enumerate(ctxs):
+                self.arena.accumulate(self.rs.backward(ctx, d_all[:, c * Nq:(c + 1) * Nq].contiguous()), scale)
         if last:
             if self.sync is not None:
                 self.sync.finish()
             self.opt.step()
         return loss, last
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Resampler (the whole module is trainable: train_cogvideo_to2v.py:1479-1481): forward with the intermediates kept + backward
+# ---------------------------------------------------------------------------------------------------------------------------------
+class ResamplerTrainer:
+    """longvgen/video_ipadapter/resampler.py:86-129, 209-244 for the training step (no PCA filter there).  sd: the Resampler's state dict under the
+    reference's key names (bf16 on the GPU; views of the parameter arena after `use_arena`).  `forward` returns (tokens [b, Nq, output_dim], ctx);
+    `backward(ctx, d_tokens)` returns {name: gradient} for every parameter.  Only depth x (one 384-query attention over ~18 k keys + a 384-row
+    FeedForward) — no checkpointing needed."""
+
+    def __init__(self, sd, depth, heads, dim_head=64, prefix="resampler."):
+        if dim_head != 64:
+            raise NotImplementedError("head_dim 64 only")
+        self.sd, self.depth, self.H, self.prefix = sd, depth, heads, prefix
+        self.names = sorted(sd)
+
+    def use_arena(self, arena):
+        for n in self.names:
+            self.sd[n] = arena.views[self.prefix + n]
+
+    @torch.no_grad()
+    def forward(self, x, image_rotary_emb=None, sampling_rotary_emb=None):
+        sd, H = self.sd, self.H
+        dev = x.device
+        b = x.shape[0]
+        e = lambda *s: torch.empty(*s, dtype=BF16, device=dev)
+        xin = x.to(BF16).reshape(b, -1, sd["proj_in.weight"].shape[1]).contiguous()
+        Nx, Nq, dim = xin.shape[1], sd["latents"].shape[1], sd["proj_in.weight"].shape[0]
+        inner = sd["layers.0.0.to_q.weight"].shape[0]
+        xp = e(b, Nx, dim)
+        K.gemm(xin, sd["proj_in.weight"], sd["proj_in.bias"], xp, L.EPI_BIAS)
+        f32c = lambda r: None if r is None else tuple(t.to(dev, torch.float32).contiguous() for t in r)
+        img, smp = f32c(image_rotary_emb), f32c(sampling_rotary_emb)
+        lat = sd["latents"].expand(b, -1, -1).contiguous()
+        layers = []
+        sm = 1.0 / 8.0
+        for i in range(self.depth):
+            p, f = f"layers.{i}.0", f"layers.{i}.1"
+            S = dict(lat_in=lat)
+            cat = e(b, Nx + Nq, dim)
+            K.adaln_modulate(xp, cat[:, :Nx], sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5, None)
+            K.adaln_modulate(lat, cat[:, Nx:], sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5, None)
+            q_pre, kv_pre = e(b, Nq, inner), e(b, Nx + Nq, 2 * inner)
+            K.gemm(cat[:, Nx:], sd[p + ".to_q.weight"], None, q_pre, L.EPI_BIAS)
+            K.gemm(cat, sd[p + ".to_kv.weight"], None, kv_pre, L.EPI_BIAS)
+            q, kv = q_pre.clone(), kv_pre.clone()
+            K.qk_layernorm_rope(q, H, sd[p + ".norm_q.weight"], sd[p + ".norm_q.bias"], 1e-6, None if smp is None else (0, smp))
+            K.qk_layernorm_rope(kv[:, :, :inner], H, sd[p + ".norm_k.weight"], sd[p + ".norm_k.bias"], 1e-6, None if img is None else (0, img),
+                                None if smp is None else (Nx, smp))
+            vt = torch.zeros(b, H, 64, (Nx + Nq + 63) // 64 * 64, dtype=BF16, device=dev)
+            K.transpose_v(kv[:, :, inner:], H, 0, Nx + Nq, vt)
+            ao = e(b, Nq, inner)
+            K.attention(q, kv[:, :, :inner], vt, Nx + Nq, ao, H, sm)
+            lat1 = e(b, Nq, dim)
+            ones = self._ones(Nq, dim, b, dev)
+            K.gemm(ao, sd[p + ".to_out.weight"], None, lat1, L.EPI_BIAS_GATE_RES, residual=lat, gate=ones)
+            ffpre, ffh = e(b, Nq, sd[f + ".net.0.proj.weight"].shape[0]), e(b, Nq, sd[f + ".net.0.proj.weight"].shape[0])
+            K.gemm(lat1, sd[f + ".net.0.proj.weight"], sd[f + ".net.0.proj.bias"], ffpre, L.EPI_BIAS)
+            K.gemm(lat1, sd[f + ".net.0.proj.weight"], sd[f + ".net.0.proj.bias"], ffh, L.EPI_BIAS_GELU)
+            lat2 = e(b, Nq, dim)
+            K.gemm(ffh, sd[f + ".net.2.weight"], sd[f + ".net.2.bias"], lat2, L.EPI_BIAS_GATE_RES, residual=lat1, gate=ones)
+            S.update(cat=cat, q_pre=q_pre, kv_pre=kv_pre, q=q, kv=kv, ao=ao, lat1=lat1, ffpre=ffpre, ffh=ffh)
+            layers.append(S)
+            lat = lat2
+        po, out = e(b, Nq, sd["proj_out.weight"].shape[0]), e(b, Nq, sd["proj_out.weight"].shape[0])
+        K.gemm(lat, sd["proj_out.weight"], sd["proj_out.bias"], po, L.EPI_BIAS)
+        K.adaln_modulate(po, out, sd["norm_out.weight"], sd["norm_out.bias"], 1e-5, None)
+        ctx = dict(xin=xin, xp=xp, layers=layers, lat_L=lat, po=po, img=img, smp=smp, dims=(b, Nx, Nq, dim, inner))
+        return out, ctx
+
+    def _ones(self, tokens, width, batch, dev):
+        key = (tokens, width, batch)
+        if getattr(self, "_ones_key", None) != key:
+            self._ones_key = key
+            self._ones_t = (torch.ones(1, 1, width, dtype=BF16, device=dev), torch.zeros(max(tokens, 1024), dtype=torch.uint8, device=dev))
+        return K.GroupTable(self._ones_t[0].expand(batch, 1, -1), self._ones_t[1], [0], [0], [0], [0])
+
+    @staticmethod
+    def _ln_bwd(x, dy, w, b_, grads, name):
+        dx = torch.empty(x.shape, dtype=BF16, device=x.device)
+        t_dln, t_dlnx, _ = _adaln_bwd(x, dy, dx, w, b_, 1e-5, None)
+        grads[name + ".weight"], grads[name + ".bias"] = _colsum_f32(t_dlnx), _colsum_f32(t_dln)
+        return dx
+
+    @torch.no_grad()
+    def backward(self, ctx, d_out):
+        sd, H = self.sd, self.H
+        b, Nx, Nq, dim, inner = ctx["dims"]
+        img, smp = ctx["img"], ctx["smp"]
+        grads = {}
+        f2 = lambda t: t.reshape(-1, t.shape[-1])
+        d_po = self._ln_bwd(ctx["po"], d_out.to(BF16).contiguous(), sd["norm_out.weight"], sd["norm_out.bias"], grads, "norm_out")
+        dW, db, d_lat = linear_backward(f2(ctx["lat_L"]), f2(d_po), sd["proj_out.weight"], need_dx=True)
+        grads["proj_out.weight"], grads["proj_out.bias"] = dW, db
+        d_lat = d_lat.reshape(b, Nq, dim)
+        d_xp = torch.zeros(b, Nx, dim, dtype=torch.float32, device=d_out.device)
+        for i in reversed(range(self.depth)):
+            p, f = f"layers.{i}.0", f"layers.{i}.1"
+            S = ctx["layers"][i]
+            d_lat = d_lat.contiguous()
+            # lat2 = net.2(gelu(net.0.proj(lat1))) + lat1
+            dW, db, d_ffh = linear_backward(f2(S["ffh"]), f2(d_lat), sd[f + ".net.2.weight"], need_dx=True)
+            grads[f + ".net.2.weight"], grads[f + ".net.2.bias"] = dW, db
+            d_ffpre = _act(f2(S["ffpre"]), d_ffh.contiguous())
+            dW, db, d_l1 = linear_backward(f2(S["lat1"]), d_ffpre, sd[f + ".net.0.proj.weight"], need_dx=True)
+            grads[f + ".net.0.proj.weight"], grads[f + ".net.0.proj.bias"] = dW, db
+            d_lat1 = (d_lat.float() + d_l1.reshape(b, Nq, dim).float()).to(BF16)
+            # lat1 = to_out(ao) + lat
+            dW, _, d_ao = linear_backward(f2(S["ao"]), f2(d_lat1), sd[p + ".to_out.weight"], need_dx=True)
+            grads[p + ".to_out.weight"] = dW
+            kv = S["kv"]
+            dq, dk, dv = K.attention_bwd(S["q"], kv[:, :, :inner], kv[:, :, inner:], S["ao"], d_ao.reshape(b, Nq, inner).contiguous(), H, 1.0 / 8.0)
+            dq_pre, gq, bq = qk_layernorm_rope_backward(S["q_pre"], dq, H, sd[p + ".norm_q.weight"], 1e-6, None if smp is None else (0, smp))
+            dk_pre, gk, bk = qk_layernorm_rope_backward(S["kv_pre"][:, :, :inner], dk, H, sd[p + ".norm_k.weight"], 1e-6, None if img is None else (0, img),
+                                                        None if smp is None else (Nx, smp))
+            grads[p + ".norm_q.weight"], grads[p + ".norm_q.bias"], grads[p + ".norm_k.weight"], grads[p + ".norm_k.bias"] = gq, bq, gk, bk
+            d_kv_pre = torch.cat([dk_pre, dv.to(BF16)], dim=2)
+            cat = S["cat"]
+            dW, _, d_cat = linear_backward(f2(cat), f2(d_kv_pre), sd[p + ".to_kv.weight"], need_dx=True)
+            grads[p + ".to_kv.weight"] = dW
+            d_cat = d_cat.reshape(b, Nx + Nq, dim)
+            dW, _, d_catq = linear_backward(f2(cat[:, Nx:]), f2(dq_pre), sd[p + ".to_q.weight"], need_dx=True)
+            grads[p + ".to_q.weight"] = dW
+            d_latn = (d_cat[:, Nx:].float() + d_catq.reshape(b, Nq, dim).float()).to(BF16)
+            d_lat_in = self._ln_bwd(S["lat_in"], d_latn, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], grads, p + ".norm2")
+            d_xp += self._ln_bwd(ctx["xp"], d_cat[:, :Nx], sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], grads, p + ".norm1").float()
+            d_lat = (d_lat1.float() + d_lat_in.float()).to(BF16)
+        grads["latents"] = d_lat.float().sum(dim=0, keepdim=True)
+        dW, db, _ = linear_backward(f2(ctx["xin"]), f2(d_xp.to(BF16)), None)
+        grads["proj_in.weight"], grads["proj_in.bias"] = dW, db
+        return {self.prefix + k: v for k, v in grads.items()}
