@@ -220,14 +220,125 @@ def run_e2e(a, rank, world, device, dist):
             "frames_out": list(video.shape), "finite": bool(torch.isfinite(video).all())}))
 
 
+def build_resampler_sd(device):
+    """Random-init Resampler at the yaml's shapes (cogvideo_5b_vaevip_4x8x12_to2v.yaml resampler_params) under the reference's key names."""
+    dim, depth, heads, dh, emb, out, mult = 3072, 4, 16, 64, 3072, 3072, 4
+    inner, nq = heads * dh, 4 * 8 * 12
+    g = torch.Generator(device=device).manual_seed(4321)
+    bf = torch.bfloat16
+    rn = lambda *s, sc=0.02: (torch.randn(*s, generator=g, device=device, dtype=torch.float32) * sc).to(bf)
+    ln = lambda n: (1 + rn(n, sc=0.05).float()).to(bf)
+    sd = {"latents": rn(1, nq, dim, sc=dim ** -0.5), "proj_in.weight": rn(dim, emb), "proj_in.bias": rn(dim), "proj_out.weight": rn(out, dim),
+          "proj_out.bias": rn(out), "norm_out.weight": ln(out), "norm_out.bias": rn(out, sc=0.05)}
+    for i in range(depth):
+        p, f = f"layers.{i}.0", f"layers.{i}.1"
+        for n, w in (("norm1", dim), ("norm2", dim), ("norm_q", dh), ("norm_k", dh)):
+            sd[f"{p}.{n}.weight"], sd[f"{p}.{n}.bias"] = ln(w), rn(w, sc=0.05)
+        sd[p + ".to_q.weight"], sd[p + ".to_kv.weight"], sd[p + ".to_out.weight"] = rn(inner, dim), rn(2 * inner, dim), rn(dim, inner)
+        sd[f + ".net.0.proj.weight"], sd[f + ".net.0.proj.bias"] = rn(dim * mult, dim), rn(dim * mult)
+        sd[f + ".net.2.weight"], sd[f + ".net.2.bias"] = rn(dim, dim * mult), rn(dim)
+    return sd, depth, heads
+
+
+def run_train(a, rank, world, device, dist):
+    """--mode train (BASELINE config 5): To2V training micro-steps at the yaml's shapes — per_gpu_batch_size 2, 13 latent frames of 60 x 90, 226 text
+    tokens, the Resampler (trainable) over two 13-frame chunks -> 480 vip tokens, transformer forward with per-block checkpointing, v-prediction
+    loss, backward with recompute, gradient accumulation over `--accum` micro-steps, then bucketed RCCL all-reduce (N > 1), clip, AdamW.
+    A "step" is one micro-step (one micro-batch per rank); the timed region holds exactly `--steps` of them, optimizer steps included when
+    they fall inside.  value = samples / s over all ranks.  Not in the timed region (as in the reference's throughput-relevant part): VAE encode
+    and T5 run under no_grad before the micro-step and are BASELINE config 4 / out of scope respectively."""
+    from tokensgen_amd import kernels as K
+    from tokensgen_amd import optim, train
+    from tokensgen_amd import rope as R
+    from tokensgen_amd.scheduler import CogVideoXDPMScheduler
+    bf = torch.bfloat16
+    model = build_model(device, a.layers)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    tr = train.To2VTrainer(sd, 48, a.layers, patch_size=2, vip_scale=1.0)
+    rsd, depth, heads = build_resampler_sd(device)
+    rt = train.ResamplerTrainer(rsd, depth=depth, heads=heads)
+    params = {k: sd[k] for k in tr.trainable}
+    params.update({"resampler." + k: v for k, v in rsd.items()})
+    arena = optim.ParamArena(params, optim.arena_order(list(params), a.layers), device)
+    tr.use_arena(arena); rt.use_arena(arena)
+    del params
+    n_clip = arena.prefix_elems(lambda n: not n.startswith("resampler."))
+    opt = optim.AdamW(arena, lr=2e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-4, max_grad_norm=1.0, clip_elems=n_clip)
+    sync = optim.GradSync(arena.grad, bucket_elems=64 * 1024 * 1024) if dist is not None else None
+    sched = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
+    step = train.To2VTrainStep(tr, arena, opt, sched.alphas_cumprod.to(torch.float32), accumulation_steps=a.accum, sync=sync, resampler=rt)
+    g = torch.Generator(device=device).manual_seed(7 + rank)
+    B, nf, C, H, W = 2, 13, 16, 60, 90
+    x0, noise = (torch.randn(B, nf, C, H, W, generator=g, device=device, dtype=torch.float32).to(bf) for _ in range(2))
+    text = (torch.randn(B, 226, 4096, generator=g, device=device, dtype=torch.float32) * 0.1).to(bf)
+    emb = (torch.randn(B, 2 * nf, 1350, 3072, generator=g, device=device, dtype=torch.float32) * 0.5).to(bf)       # patch-embedded VAE latents, two chunks
+    f32 = np.float32
+    rope = R.rope_3d_crop(64, (0, 0, 0), (nf, 30, 45), (nf, 30, 45))
+    crope = R.rope_3d(64, np.linspace(1000, 1016.25, 5, dtype=f32), np.linspace(0, 30, 8, endpoint=False, dtype=f32), np.linspace(0, 45, 12, endpoint=False, dtype=f32))
+    img = R.rope_3d(64, np.arange(13, dtype=f32), np.arange(30, dtype=f32), np.arange(45, dtype=f32))
+    smp = R.rope_3d(64, np.linspace(1000, 1013, 4, endpoint=False, dtype=f32), np.linspace(0, 30, 8, endpoint=False, dtype=f32), np.linspace(0, 45, 12, endpoint=False, dtype=f32))
+    tgen = torch.Generator().manual_seed(3 + rank)
+
+    def micro():
+        ts = torch.randint(0, 1000, (B,), generator=tgen)
+        return step.micro_step(x0, noise, ts, text, None, rope, rope, crope, image_embeddings=emb, emb_start_idx=[1, 2], resampler_ropes=(img, smp))
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier(); torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        micro()
+    step.micro = 0                                    # the timed region starts at the beginning of an accumulation window
+    K.PROFILE_ON[0] = True
+    K.PROFILE_FILTER[0] = {"attention_bwd"}
+    fence()
+    t0 = time.perf_counter()
+    n_opt = 0
+    for _ in range(a.steps):
+        loss, did = micro()
+        n_opt += int(did)
+    fence()
+    dt = time.perf_counter() - t0
+    K.PROFILE_ON[0] = False
+    rank_ms = 1e3 * dt / a.steps
+    if dist is not None:
+        tm = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dt = float(tm.item())
+    if rank == 0:
+        prof = K.profile_summary().get("attention_bwd", {"ms": float("nan"), "n": 0, "total_ms": 0.0})
+        # dominant kernel group: the attention backward launches (statistics + dK/dV + dQ).  Algorithmic flops per transformer layer and micro-step:
+        # 5 GEMMs (S, dP, dV, dK, dQ) of 2 * nq * nk * 64 per head for the three calls of the processor.
+        n1, nv = 226 + 17550, 480
+        alg = 5 * 2.0 * 64 * 48 * B * (n1 * n1 + n1 * nv + nv * (n1 + nv)) * a.layers
+        tot_ms = prof["total_ms"] / max(1, a.steps)
+        print(json.dumps({
+            "metric": "To2V training samples/sec (micro-steps of per_gpu_batch_size 2, gradient accumulation, clip + AdamW), CogVideoX-5B + Resampler",
+            "value": B * world * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+            "rank_ms_per_step": rank_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic latents / embeddings, random-init weights at CogVideoX-5B + Resampler(4x8x12) shapes",
+            "config": {"workload": "To2V train micro-step (BASELINE config 5): batch 2 x 13 latent frames 60x90, 226 text + 480 vip tokens, Resampler over 2 chunks of 17550 tokens",
+                       "layers": a.layers, "accumulation_steps": a.accum, "optimizer_steps_in_timed_region": n_opt,
+                       "trainable_parameters": int(sum(v.numel() for v in arena.views.values()))},
+            "roofline": {"bound": "mfma", "kernel": "tg_attention_bwd (statistics + dK/dV + dQ launches, all transformer layers of one micro-step)",
+                         "achieved": alg / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else None, "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": (alg / (tot_ms * 1e-3) / 1e12 / 2500.0) if tot_ms > 0 else None, "traffic": None,
+                         "ms_per_micro_step_in_this_kernel": tot_ms, "launches_per_micro_step": prof["n"] / max(1, a.steps)},
+            "loss": float(loss), "grad_norm_last_step": float(opt.coef[0]) if n_opt else None,
+            "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--layers", type=int, default=42, help="debug only: anything but 42 is not the benchmark")
-    ap.add_argument("--mode", choices=("window", "e2e"), default="window",
-                    help="window (default, the headline): steady-state FIFO window steps; e2e: one whole To2V run incl. ramp, base stage, VAE decode")
+    ap.add_argument("--mode", choices=("window", "e2e", "train"), default="window",
+                    help="window (default, the headline): steady-state FIFO window steps; e2e: one whole To2V run incl. ramp, base stage, VAE decode; "
+                         "train: To2V training micro-steps (BASELINE config 5)")
+    ap.add_argument("--accum", type=int, default=9, help="--mode train: gradient_accumulation_steps (yaml: 9)")
     ap.add_argument("--chunks", type=int, default=12, help="--mode e2e: number of 49-frame clips (edit.yaml: 12)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE (BASELINE config 4) sub-record")
@@ -260,8 +371,8 @@ def main():
     from tokensgen_amd.scheduler import CogVideoXDPMScheduler
     from tokensgen_amd import rope as R
     lib.load()
-    if a.mode == "e2e":
-        run_e2e(a, rank, world, device, dist)
+    if a.mode in ("e2e", "train"):
+        (run_e2e if a.mode == "e2e" else run_train)(a, rank, world, device, dist)
         if use_dist:
             dist.destroy_process_group()
         return
