@@ -218,14 +218,15 @@ int tg_pca_inverse(const void* lat, const float* std16, const float* mean16, con
  * q, o, dout: bf16 [batch][nq][heads*64] views (row stride *_ld, batch stride *_sb; head h occupies columns 64h..64h+63);
  * k, v: likewise with nk rows (v row-major here, not the transposed image of the forward).  dq / dk / dv: fp32, same indexing;
  * accumulate != 0 adds to what is there (the To2V processor's three attention calls share K / V tensors: their gradients sum).
- * ws: fp32 workspace of tg_attention_bwd_ws_floats(nq, heads, batch) floats (row log-sum-exp and rowsum(dO o O)).
- * P is recomputed from the log-sum-exp tile by tile; three launches (statistics, dK/dV per key tile, dQ per query tile), no atomics:
- * run-to-run deterministic. */
+ * ws: 16-byte aligned fp32 workspace of tg_attention_bwd_ws_floats(nq, nk, heads, batch) floats (row log-sum-exp, rowsum(dO o O), and the
+ * transposed bf16 copies Q^T, dO^T, K^T the kernels' [d][row] tiles are loaded from).
+ * P is recomputed from the log-sum-exp tile by tile; three launches (statistics, dK/dV per 256-key workgroup, dQ per 256-query workgroup) behind
+ * three tg_transpose_v passes, no atomics: run-to-run deterministic.  TG_ATTN_BWD_V1=1 selects the earlier correct-first kernels (cross-check). */
 int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void* k, long k_ld, long k_sb, const void* v, long v_ld, long v_sb,
                      const void* o, long o_ld, long o_sb, const void* dout, long do_ld, long do_sb,
                      float* dq, long dq_ld, long dq_sb, float* dk, long dk_ld, long dk_sb, float* dv, long dv_ld, long dv_sb,
                      int nq, int nk, int heads, int batch, float scale, int accumulate, float* ws, hipStream_t stream);
-long tg_attention_bwd_ws_floats(int nq, int heads, int batch);
+long tg_attention_bwd_ws_floats(int nq, int nk, int heads, int batch);
 
 /* Backward of tg_qk_layernorm_rope (y = rope(bf16(LN64(x) g + b)) * out_scale; attention_processor.py:2031-2056) for the trainable vip_norm_q /
  * vip_norm_k and the projections behind them.  x: the PRE-norm projection output (bf16, element (b, t, h, d) at x[b*strideB + t*ld + h*64 + d]);

@@ -13,6 +13,8 @@
 // has to become contiguous) and dO^T, Q^T, K^T (transposed while staging into LDS).
 // Correct-first kernel: LDS-staged 64 x 64 tiles, 4 waves, one 32 x 32 block per wave; gradients are fp32 (accumulate flag: the To2V
 // processor's three attention calls share K/V tensors, so their gradients add up).
+#include <cstdlib>
+
 #include "common.h"
 #include "tokensgen_hip.h"
 
@@ -281,11 +283,369 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdParams p) {
     }
 }
 
+
+// =================================================================================================================================
+// Round-2 kernels (the ones the entry point launches; the three above stay as the TG_ATTN_BWD_V1=1 cross-check).
+//
+// What changed against the correct-first version, and why:
+//  * no LDS round trip for P / dS and no in-kernel transposes.  The 32x32x16 MFMA sums over 16 k values, 8 per lane half; WHICH 16 values a
+//    k-step covers is free as long as both operands agree.  A lane of an S block (rows = queries, column = key j) holds queries
+//    8g + 4hi + e (g, e = 0..3): accumulator elements 8t .. 8t+7 are the queries {16t + 4hi + e} u {16t + 8 + 4hi + e} — used AS the A operand
+//    (row = key j) of k-step t of dV += P^T dO and dK += dS^T Q, straight from registers.  The B operand then needs dO / Q values of those
+//    same queries for one head column: two 8-byte reads from a [d][q] tile.  Q^T, dO^T (and K^T for the dQ kernel) are produced once per
+//    call by tg_transpose_v into the workspace, so the [d][q] tiles are plain 16-byte loads.
+//  * one wave owns 64 keys (dK/dV kernel) or 64 queries (dQ, statistics): its K, V (resp. Q, dO) fragments and the 128 (resp. 64) output
+//    accumulators live in registers for the whole kernel; the 32-row tiles of the other side stream through a double-buffered LDS stage that
+//    all four waves share (one barrier per tile; global loads of tile i+1 are in flight while tile i is consumed).
+//  * per (32 x 32) block: 16 MFMAs (dK/dV) / 12 (dQ) against 8 ds_read_b128 + 16 / 8 ds_read_b64 shared by the wave's two blocks.
+// Still three launches and no atomics: gradients are bitwise reproducible.
+// =================================================================================================================================
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // raw v_exp_f32: arguments are <= 0 or masked to -1e30
+constexpr int BT = 32;                     // rows of the streamed tile
+constexpr int LQ2 = 72;                    // [row][d] tile: row stride in elements (144 B)
+constexpr int LT2 = 40;                    // [d][row] tile: row stride in elements (80 B)
+constexpr int ROWT_EL = BT * LQ2, COLT_EL = 64 * LT2;
+
+struct Bwd2Params {
+    BwdParams p;
+    const bf16_t *qT, *doT, *kT;           // [batch][heads][64][ldq / ldq / ldk] (zero padded)
+    long ldq, ldk;
+};
+
+union Frag { bf16x8 v; uint2 u[2]; uint32_t w[4]; };
+
+__device__ __forceinline__ uint4 ld_row16(const bf16_t* base, long ld, int row, int n, int col) {
+    return row < n ? *(const uint4*)(base + (long)row * ld + col) : uint4{0, 0, 0, 0};
+}
+
+// ---- (1') statistics: one wave per 64 queries, keys streamed in tiles of 32 ----
+__global__ __launch_bounds__(256) void attn_bwd_stats2_kernel(BwdParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t sK[2][ROWT_EL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y % p.heads, b = blockIdx.y / p.heads;
+    const int q0 = blockIdx.x * 256 + wave * 64;
+    const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
+    const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
+    const long stat0 = ((long)b * p.heads + h) * p.nq;
+    {   // D_i = sum_d dO_id O_id: one thread per query row
+        const int r = blockIdx.x * 256 + tid;
+        if (r < p.nq) {
+            const uint4* o = (const uint4*)(p.o + (long)b * p.o_sb + (long)r * p.o_ld + h * HD);
+            const uint4* g = (const uint4*)(p.dout + (long)b * p.do_sb + (long)r * p.do_ld + h * HD);
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint4 a = o[i], c = g[i];
+                const uint32_t au[4] = {a.x, a.y, a.z, a.w}, cu[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d += bf16lo_to_f32(au[e]) * bf16lo_to_f32(cu[e]) + bf16hi_to_f32(au[e]) * bf16hi_to_f32(cu[e]);
+            }
+            p.dsum[stat0 + r] = d;
+        }
+    }
+    Frag qf[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint4 t = ld_row16(Q, p.q_ld, q0 + qb * 32 + j, p.nq, ks * 16 + hi * 8);
+            qf[qb][ks].w[0] = t.x; qf[qb][ks].w[1] = t.y; qf[qb][ks].w[2] = t.z; qf[qb][ks].w[3] = t.w;
+        }
+    float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};
+    const int row = tid >> 3, chunk = (tid & 7) * 8;
+    const int ntile = (p.nk + BT - 1) / BT;
+    uint4 pre = ld_row16(Kp, p.k_ld, row, p.nk, chunk);
+    *(uint4*)(sK[0] + row * LQ2 + chunk) = pre;
+    __syncthreads();
+    for (int it = 0; it < ntile; ++it) {
+        const int k0 = it * BT;
+        if (it + 1 < ntile) pre = ld_row16(Kp, p.k_ld, k0 + BT + row, p.nk, chunk);
+        const bf16_t* cK = sK[it & 1];
+        bf16x8 aK[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) aK[ks] = *(const bf16x8*)(cK + j * LQ2 + ks * 16 + hi * 8);
+        const bool ragged = k0 + BT > p.nk;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 st = zero16();                          // rows = keys, column = query j
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aK[ks], qf[qb][ks].v, st, 0, 0, 0);
+            float sv[16], mx = -1e30f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sv[r] = st[r] * p.scale_log2;
+                if (ragged && k0 + acc_row(r, hi) >= p.nk) sv[r] = -1e30f;
+                mx = fmaxf(mx, sv[r]);
+            }
+            const float mn = fmaxf(m[qb], mx);
+            float add = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) add += fast_exp2(sv[r] - mn);
+            l[qb] = l[qb] * fast_exp2(m[qb] - mn) + add;
+            m[qb] = mn;
+        }
+        if (it + 1 < ntile) *(uint4*)(sK[(it + 1) & 1] + row * LQ2 + chunk) = pre;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float mo = __shfl_xor(m[qb], 32, 64), lo = __shfl_xor(l[qb], 32, 64);
+        const float M = fmaxf(m[qb], mo);
+        const float Lsum = l[qb] * fast_exp2(m[qb] - M) + lo * fast_exp2(mo - M);
+        const int q = q0 + qb * 32 + j;
+        if (hi == 0 && q < p.nq) p.lse[stat0 + q] = M + log2f(Lsum);
+    }
+}
+
+// ---- (2') dK, dV: workgroup = 256 keys (64 per wave), queries streamed in tiles of 32 ----
+__global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(Bwd2Params pp) {
+    const BwdParams& p = pp.p;
+    __shared__ __attribute__((aligned(16))) bf16_t sQ[2][ROWT_EL], sdO[2][ROWT_EL], sQt[2][COLT_EL], sdOt[2][COLT_EL];
+    __shared__ __attribute__((aligned(16))) float sLse[2][BT], sD[2][BT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y % p.heads, b = blockIdx.y / p.heads;
+    const int kw0 = blockIdx.x * 256 + wave * 64;
+    const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
+    const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
+    const bf16_t* qT = pp.qT + ((long)(b * p.heads + h) * 64) * pp.ldq;
+    const bf16_t* doT = pp.doT + ((long)(b * p.heads + h) * 64) * pp.ldq;
+    const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
+    const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
+    const long stat0 = ((long)b * p.heads + h) * p.nq;
+    Frag kf[2][4], vf[2][4];                               // B operands: this wave's keys, resident
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 t = ld_row16(Kp, p.k_ld, kw0 + kb * 32 + j, p.nk, ks * 16 + hi * 8);
+            kf[kb][ks].w[0] = t.x; kf[kb][ks].w[1] = t.y; kf[kb][ks].w[2] = t.z; kf[kb][ks].w[3] = t.w;
+            t = ld_row16(Vp, p.v_ld, kw0 + kb * 32 + j, p.nk, ks * 16 + hi * 8);
+            vf[kb][ks].w[0] = t.x; vf[kb][ks].w[1] = t.y; vf[kb][ks].w[2] = t.z; vf[kb][ks].w[3] = t.w;
+        }
+    f32x16 dk[2][2], dv[2][2];                             // [key block][d block]: rows = keys, column = head dim j
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { dk[a][c] = zero16(); dv[a][c] = zero16(); }
+    const int row = tid >> 3, chunk = (tid & 7) * 8;       // [q][d] tiles: one 16-byte piece per thread
+    const int drow = tid >> 2, part = (tid & 3) * 8;       // [d][q] tiles
+    const int ntile = (p.nq + BT - 1) / BT;
+    uint4 g0, g1, g2, g3;
+    float gs = 0.f;
+    auto fetch = [&](int q0) {
+        g0 = ld_row16(Q, p.q_ld, q0 + row, p.nq, chunk);
+        g1 = ld_row16(dO, p.do_ld, q0 + row, p.nq, chunk);
+        g2 = *(const uint4*)(qT + (long)drow * pp.ldq + q0 + part);
+        g3 = *(const uint4*)(doT + (long)drow * pp.ldq + q0 + part);
+        if (tid < BT) gs = q0 + tid < p.nq ? p.lse[stat0 + q0 + tid] : 1e30f;          // masked query rows: P = exp2(s - 1e30) = 0
+        else if (tid < 2 * BT) gs = q0 + tid - BT < p.nq ? p.dsum[stat0 + q0 + tid - BT] : 0.f;
+    };
+    auto stash = [&](int buf) {
+        *(uint4*)(sQ[buf] + row * LQ2 + chunk) = g0;
+        *(uint4*)(sdO[buf] + row * LQ2 + chunk) = g1;
+        *(uint4*)(sQt[buf] + drow * LT2 + part) = g2;
+        *(uint4*)(sdOt[buf] + drow * LT2 + part) = g3;
+        if (tid < BT) sLse[buf][tid] = gs;
+        else if (tid < 2 * BT) sD[buf][tid - BT] = gs;
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int it = 0; it < ntile; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < ntile) fetch((it + 1) * BT);
+        bf16x8 aQ[4], aO[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            aQ[ks] = *(const bf16x8*)(sQ[buf] + j * LQ2 + ks * 16 + hi * 8);
+            aO[ks] = *(const bf16x8*)(sdO[buf] + j * LQ2 + ks * 16 + hi * 8);
+        }
+        f32x4 l4[4], d4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            l4[g] = *(const f32x4*)(sLse[buf] + 8 * g + 4 * hi);
+            d4[g] = *(const f32x4*)(sD[buf] + 8 * g + 4 * hi);
+        }
+        Frag bO[2][2], bQ[2][2];                           // [k-step t][d block]: B operands of the transposed products
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int o = (db * 32 + j) * LT2 + 16 * t + 4 * hi;
+                bO[t][db].u[0] = *(const uint2*)(sdOt[buf] + o); bO[t][db].u[1] = *(const uint2*)(sdOt[buf] + o + 8);
+                bQ[t][db].u[0] = *(const uint2*)(sQt[buf] + o);  bQ[t][db].u[1] = *(const uint2*)(sQt[buf] + o + 8);
+            }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 s = zero16(), dp = zero16();            // rows = queries, column = key j
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aQ[ks], kf[kb][ks].v, s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aO[ks], vf[kb][ks].v, dp, 0, 0, 0);
+            }
+            Frag pA[2], dA[2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float pv[4], ds[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pv[e] = fast_exp2(s[4 * g + e] * p.scale_log2 - l4[g][e]);
+                    ds[e] = pv[e] * (dp[4 * g + e] - d4[g][e]);
+                }
+                pA[g >> 1].w[(g & 1) * 2] = pack_bf16x2(pv[0], pv[1]); pA[g >> 1].w[(g & 1) * 2 + 1] = pack_bf16x2(pv[2], pv[3]);
+                dA[g >> 1].w[(g & 1) * 2] = pack_bf16x2(ds[0], ds[1]); dA[g >> 1].w[(g & 1) * 2 + 1] = pack_bf16x2(ds[2], ds[3]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dv[kb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA[t].v, bO[t][db].v, dv[kb][db], 0, 0, 0);
+                    dk[kb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dA[t].v, bQ[t][db].v, dk[kb][db], 0, 0, 0);
+                }
+        }
+        if (it + 1 < ntile) stash(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            float* DK = p.dk + (long)b * p.dk_sb + h * HD + db * 32 + j;
+            float* DV = p.dv + (long)b * p.dv_sb + h * HD + db * 32 + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kw0 + kb * 32 + acc_row(r, hi);
+                if (key >= p.nk) continue;
+                float* a = DK + (long)key * p.dk_ld;
+                float* c = DV + (long)key * p.dv_ld;
+                const float vk = dk[kb][db][r] * p.scale, vv = dv[kb][db][r];
+                *a = p.accumulate ? *a + vk : vk;
+                *c = p.accumulate ? *c + vv : vv;
+            }
+        }
+}
+
+// ---- (3') dQ: workgroup = 256 queries (64 per wave), keys streamed in tiles of 32 ----
+__global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
+    const BwdParams& p = pp.p;
+    __shared__ __attribute__((aligned(16))) bf16_t sK[2][ROWT_EL], sV[2][ROWT_EL], sKt[2][COLT_EL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y % p.heads, b = blockIdx.y / p.heads;
+    const int qw0 = blockIdx.x * 256 + wave * 64;
+    const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
+    const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
+    const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
+    const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
+    const bf16_t* kT = pp.kT + ((long)(b * p.heads + h) * 64) * pp.ldk;
+    const long stat0 = ((long)b * p.heads + h) * p.nq;
+    Frag qf[2][4], of[2][4];
+    float lse[2], dsum[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int q = qw0 + qb * 32 + j;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 t = ld_row16(Q, p.q_ld, q, p.nq, ks * 16 + hi * 8);
+            qf[qb][ks].w[0] = t.x; qf[qb][ks].w[1] = t.y; qf[qb][ks].w[2] = t.z; qf[qb][ks].w[3] = t.w;
+            t = ld_row16(dO, p.do_ld, q, p.nq, ks * 16 + hi * 8);
+            of[qb][ks].w[0] = t.x; of[qb][ks].w[1] = t.y; of[qb][ks].w[2] = t.z; of[qb][ks].w[3] = t.w;
+        }
+        lse[qb] = q < p.nq ? p.lse[stat0 + q] : 1e30f;
+        dsum[qb] = q < p.nq ? p.dsum[stat0 + q] : 0.f;
+    }
+    f32x16 dq[2][2];                                       // [query block][d block]: rows = queries, column = head dim j
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) dq[a][c] = zero16();
+    const int row = tid >> 3, chunk = (tid & 7) * 8;
+    const int drow = tid >> 2, part = (tid & 3) * 8;
+    const int ntile = (p.nk + BT - 1) / BT;
+    uint4 g0, g1, g2;
+    auto fetch = [&](int k0) {
+        g0 = ld_row16(Kp, p.k_ld, k0 + row, p.nk, chunk);
+        g1 = ld_row16(Vp, p.v_ld, k0 + row, p.nk, chunk);
+        g2 = *(const uint4*)(kT + (long)drow * pp.ldk + k0 + part);
+    };
+    auto stash = [&](int buf) {
+        *(uint4*)(sK[buf] + row * LQ2 + chunk) = g0;
+        *(uint4*)(sV[buf] + row * LQ2 + chunk) = g1;
+        *(uint4*)(sKt[buf] + drow * LT2 + part) = g2;
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int it = 0; it < ntile; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < ntile) fetch((it + 1) * BT);
+        bf16x8 aK[4], aV[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            aK[ks] = *(const bf16x8*)(sK[buf] + j * LQ2 + ks * 16 + hi * 8);
+            aV[ks] = *(const bf16x8*)(sV[buf] + j * LQ2 + ks * 16 + hi * 8);
+        }
+        Frag bK[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int o = (db * 32 + j) * LT2 + 16 * t + 4 * hi;
+                bK[t][db].u[0] = *(const uint2*)(sKt[buf] + o); bK[t][db].u[1] = *(const uint2*)(sKt[buf] + o + 8);
+            }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 st = zero16(), dpt = zero16();          // rows = keys, column = query j
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aK[ks], qf[qb][ks].v, st, 0, 0, 0);
+                dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aV[ks], of[qb][ks].v, dpt, 0, 0, 0);
+            }
+            Frag dA[2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float ds[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ds[e] = fast_exp2(st[4 * g + e] * p.scale_log2 - lse[qb]) * (dpt[4 * g + e] - dsum[qb]);
+                dA[g >> 1].w[(g & 1) * 2] = pack_bf16x2(ds[0], ds[1]); dA[g >> 1].w[(g & 1) * 2 + 1] = pack_bf16x2(ds[2], ds[3]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    dq[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dA[t].v, bK[t][db].v, dq[qb][db], 0, 0, 0);
+        }
+        if (it + 1 < ntile) stash(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            float* DQ = p.dq + (long)b * p.dq_sb + h * HD + db * 32 + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qw0 + qb * 32 + acc_row(r, hi);
+                if (q >= p.nq) continue;
+                float* a = DQ + (long)q * p.dq_ld;
+                const float vq = dq[qb][db][r] * p.scale;
+                *a = p.accumulate ? *a + vq : vq;
+            }
+        }
+}
+
 }  // namespace
 
-extern "C" long tg_attention_bwd_ws_floats(int nq, int heads, int batch) { return 2L * batch * heads * nq; }
+static inline long pad64(long n) { return (n + 63) / 64 * 64; }
+// statistics (2 floats per query row) + the transposed copies Q^T, dO^T, K^T (bf16 [batch][heads][64][padded length])
+extern "C" long tg_attention_bwd_ws_floats(int nq, int nk, int heads, int batch) {
+    return 2L * batch * heads * nq + 8 + (long)batch * heads * 64 * (2 * pad64(nq) + pad64(nk)) / 2;
+}
 
-extern "C" int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void* k, long k_ld, long k_sb, const void* v, long v_ld, long v_sb,
+
+static int attention_bwd_v1(const void* q, long q_ld, long q_sb, const void* k, long k_ld, long k_sb, const void* v, long v_ld, long v_sb,
                                 const void* o, long o_ld, long o_sb, const void* dout, long do_ld, long do_sb,
                                 float* dq, long dq_ld, long dq_sb, float* dk, long dk_ld, long dk_sb, float* dv, long dv_ld, long dv_sb,
                                 int nq, int nk, int heads, int batch, float scale, int accumulate, float* ws, hipStream_t stream) {
@@ -308,6 +668,40 @@ extern "C" int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void*
     hipLaunchKernelGGL(attn_bwd_stats_kernel, gq, dim3(256), LDS_STATS, stream, p);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, gk, dim3(256), LDS_KV, stream, p);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(256), LDS_Q, stream, p);
+    TG_LAUNCH_CHECK("tg_attention_bwd");
+    return TG_OK;
+}
+
+extern "C" int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void* k, long k_ld, long k_sb, const void* v, long v_ld, long v_sb,
+                                 const void* o, long o_ld, long o_sb, const void* dout, long do_ld, long do_sb,
+                                 float* dq, long dq_ld, long dq_sb, float* dk, long dk_ld, long dk_sb, float* dv, long dv_ld, long dv_sb,
+                                 int nq, int nk, int heads, int batch, float scale, int accumulate, float* ws, hipStream_t stream) {
+    static const bool v1 = [] { const char* e = getenv("TG_ATTN_BWD_V1"); return e && e[0] == '1'; }();
+    if (v1) return attention_bwd_v1(q, q_ld, q_sb, k, k_ld, k_sb, v, v_ld, v_sb, o, o_ld, o_sb, dout, do_ld, do_sb, dq, dq_ld, dq_sb, dk, dk_ld, dk_sb,
+                                    dv, dv_ld, dv_sb, nq, nk, heads, batch, scale, accumulate, ws, stream);
+    TG_REQUIRE(q && k && v && o && dout && dq && dk && dv && ws, TG_ERR_ARG, "tg_attention_bwd: null pointer");
+    TG_REQUIRE(nq > 0 && nk > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_attention_bwd: bad shape nq=%d nk=%d heads=%d batch=%d", nq, nk, heads, batch);
+    TG_REQUIRE(tg_aligned16(q) && tg_aligned16(k) && tg_aligned16(v) && tg_aligned16(o) && tg_aligned16(dout) && tg_aligned16(ws) && q_ld % 8 == 0 &&
+               k_ld % 8 == 0 && v_ld % 8 == 0 && o_ld % 8 == 0 && do_ld % 8 == 0 && q_sb % 8 == 0 && k_sb % 8 == 0 && v_sb % 8 == 0 && o_sb % 8 == 0 &&
+               do_sb % 8 == 0, TG_ERR_ALIGN, "tg_attention_bwd: q/k/v/o/dO need 16-byte aligned rows");
+    const long nstat = ((2L * batch * heads * nq + 7) / 8) * 8;                    // keeps the bf16 arrays behind it 16-byte aligned
+    const long ldq = pad64(nq), ldk = pad64(nk);
+    bf16_t* qT = (bf16_t*)(ws + nstat);
+    bf16_t* doT = qT + (long)batch * heads * 64 * ldq;
+    bf16_t* kT = doT + (long)batch * heads * 64 * ldq;
+    int rc;
+    if ((rc = tg_transpose_v(q, q_ld, q_sb, 0, nq, heads, batch, qT, ldq, stream)) != TG_OK) return rc;
+    if ((rc = tg_transpose_v(dout, do_ld, do_sb, 0, nq, heads, batch, doT, ldq, stream)) != TG_OK) return rc;
+    if ((rc = tg_transpose_v(k, k_ld, k_sb, 0, nk, heads, batch, kT, ldk, stream)) != TG_OK) return rc;
+    Bwd2Params pp{};
+    pp.p = BwdParams{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, q_ld, q_sb, k_ld, k_sb, v_ld, v_sb,
+                     o_ld, o_sb, do_ld, do_sb, dq, dk, dv, dq_ld, dq_sb, dk_ld, dk_sb, dv_ld, dv_sb, ws, ws + (long)batch * heads * nq, nq, nk, heads, batch,
+                     scale * 1.4426950408889634f, scale, accumulate};
+    pp.qT = qT; pp.doT = doT; pp.kT = kT; pp.ldq = ldq; pp.ldk = ldk;
+    const dim3 gq((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), gk((unsigned)((nk + 255) / 256), (unsigned)(batch * heads));
+    hipLaunchKernelGGL(attn_bwd_stats2_kernel, gq, dim3(256), 0, stream, pp.p);
+    hipLaunchKernelGGL(attn_bwd_dkdv2_kernel, gk, dim3(256), 0, stream, pp);
+    hipLaunchKernelGGL(attn_bwd_dq2_kernel, gq, dim3(256), 0, stream, pp);
     TG_LAUNCH_CHECK("tg_attention_bwd");
     return TG_OK;
 }

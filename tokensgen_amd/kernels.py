@@ -257,7 +257,7 @@ def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, acc
     dq = new(B, nq, HD, dtype=f32, device=q.device) if dq is None else _chk(dq, "dq", f32)
     dk = new(B, nk, HD, dtype=f32, device=q.device) if dk is None else _chk(dk, "dk", f32)
     dv = new(B, nk, HD, dtype=f32, device=q.device) if dv is None else _chk(dv, "dv", f32)
-    ws = torch.empty(L.load().tg_attention_bwd_ws_floats(nq, heads, B), dtype=f32, device=q.device)
+    ws = torch.empty(L.load().tg_attention_bwd_ws_floats(nq, nk, heads, B), dtype=f32, device=q.device)
     L.check(_launch("attention_bwd", L.load().tg_attention_bwd, _p(q), qld, qsb, _p(k), kld, ksb, _p(v), vld, vsb, _p(o), old, osb, _p(dout), gld, gsb,
                     _p(dq), dq.stride(1), dq.stride(0), _p(dk), dk.stride(1), dk.stride(0), _p(dv), dv.stride(1), dv.stride(0), nq, nk, heads, B,
                     float(scale), 1 if accumulate else 0, _p(ws), _stream()), "tg_attention_bwd")

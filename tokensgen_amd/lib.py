@@ -67,7 +67,7 @@ QUERIES = {
     "tg_groupnorm_partial_floats": [C.c_long, C.c_int],
     "tg_conv3d_gn_partial_floats": [C.c_int, C.c_int, C.c_int],
     "tg_conv3d_splitk_floats": [C.c_int] * 9,
-    "tg_attention_bwd_ws_floats": [C.c_int, C.c_int, C.c_int],
+    "tg_attention_bwd_ws_floats": [C.c_int, C.c_int, C.c_int, C.c_int],
     "tg_qk_layernorm_rope_bwd_partial_floats": [C.c_int, C.c_int, C.c_int],
     "tg_colsum_partial_floats": [C.c_int, C.c_int],
     "tg_vpred_loss_partial_floats": [C.c_int, C.c_long],

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmarks at the CogVideoX-5B To2V shapes (GPU box only): TFLOP/s per hot kernel.
-Usage: python tools/bench_kernels.py [attn] [gemm] [norm]"""
+Usage: python tools/bench_kernels.py [attn] [attn_bwd] [gemm] [norm]"""
 import json
 import os
 import sys
@@ -58,6 +58,18 @@ def bench_attn():
     print(json.dumps({"kernel": "attention_vip", "ms": ms, "tflops": B * 4.0 * NP * N * D / ms / 1e9}))
 
 
+def bench_attn_bwd():
+    """The training step's main attention call (SDPA #1 of the To2V processor): nq = nk = 17776, 48 heads, batch 2."""
+    qkv = rnd(B, N1, 3 * D, scale=0.6)
+    o, do = rnd(B, N1, D, scale=0.3), rnd(B, N1, D, scale=0.3)
+    f32 = torch.float32
+    dq, dk, dv = (torch.empty(B, N1, D, dtype=f32, device=DEV) for _ in range(3))
+    fn = lambda: K.attention_bwd(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], o, do, H, 0.125, dq=dq, dk=dk, dv=dv)
+    ms = timeit(fn, iters=3, warm=1)
+    fl = 5 * 2.0 * B * N1 * N1 * D
+    print(json.dumps({"kernel": "attention_bwd_main", "ms": ms, "tflops_algorithmic(5 GEMMs)": fl / ms / 1e9, "tflops_executed(7 GEMMs)": fl * 1.4 / ms / 1e9}))
+
+
 def bench_gemm():
     for (M, Nn, Kk, epi, name) in [(N1, 3 * D, D, L.EPI_BIAS, "qkv"), (N, D, D, L.EPI_BIAS, "out(bias)"),
                                    (N, 4 * D, D, L.EPI_BIAS_GELU, "ff1"), (N, D, 4 * D, L.EPI_BIAS, "ff2(bias)")]:
@@ -93,6 +105,8 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["attn", "gemm", "norm"]
     if "attn" in what:
         bench_attn()
+    if "attn_bwd" in what:
+        bench_attn_bwd()
     if "gemm" in what:
         bench_gemm()
     if "norm" in what:
