@@ -301,6 +301,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdParams p) {
 // Still three launches and no atomics: gradients are bitwise reproducible.
 // =================================================================================================================================
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // raw v_exp_f32: arguments are <= 0 or masked to -1e30
+// Accumulate-chain MFMA with the accumulator PINNED to AGPRs ("+a"): the dK / dV / dQ blocks are touched by nothing but these MFMAs until the
+// epilogue, and left to the register allocator they were shuffled between the two register halves every iteration (192 v_accvgpr moves per
+// tile).  hipcc pads nothing inside an asm string: the A operand was just written by v_cvt_pk (VALU -> MFMA operand: 2 wait states, s_nop 1);
+// the chain on C needs none.
+__device__ __forceinline__ void mfma_acc(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+// Resident fragments in the ACCUMULATOR half of the register file: an MFMA may take its B operand from AGPRs, VALU code cannot touch them, so
+// the 64 registers of a wave's K | V (or Q | dO) fragments stop competing with the softmax arithmetic for the 256 architected VGPRs (left to
+// the compiler they were parked in AGPRs anyway and copied back with ~130 v_accvgpr_read per tile).  Loaded straight from global memory.
+__device__ __forceinline__ void load_frag_agpr(bf16x8& dst, const bf16_t* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(dst) : "v"(ptr) : "memory");
+}
+#define TG_WAIT_FRAGS(f) asm volatile("s_waitcnt vmcnt(0)" : "+a"(f[0][0]), "+a"(f[0][1]), "+a"(f[0][2]), "+a"(f[0][3]), "+a"(f[1][0]), "+a"(f[1][1]), "+a"(f[1][2]), "+a"(f[1][3]))
+// X = A0 . B0^T and Y = A1 . B1^T over the 64 head dims (two independent 4-step chains, interleaved), A from VGPRs (LDS tile rows), B resident in
+// AGPRs.  Ends with the 12 wait states an 8-pass MFMA result needs before anything but an accumulate chain reads it.
+__device__ __forceinline__ void mfma_pair(f32x16& x, f32x16& y, const bf16x8 (&a0)[4], const bf16x8 (&a1)[4], const bf16x8 (&b0)[4], const bf16x8 (&b1)[4]) {
+    asm("s_nop 1\n\t"
+        "v_mfma_f32_32x32x16_bf16 %0, %2, %10, 0\n\t"
+        "v_mfma_f32_32x32x16_bf16 %1, %6, %14, 0\n\t"
+        "v_mfma_f32_32x32x16_bf16 %0, %3, %11, %0\n\t"
+        "v_mfma_f32_32x32x16_bf16 %1, %7, %15, %1\n\t"
+        "v_mfma_f32_32x32x16_bf16 %0, %4, %12, %0\n\t"
+        "v_mfma_f32_32x32x16_bf16 %1, %8, %16, %1\n\t"
+        "v_mfma_f32_32x32x16_bf16 %0, %5, %13, %0\n\t"
+        "v_mfma_f32_32x32x16_bf16 %1, %9, %17, %1\n\t"
+        "s_nop 11"
+        : "=&v"(x), "=&v"(y)
+        : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]),
+          "a"(b0[0]), "a"(b0[1]), "a"(b0[2]), "a"(b0[3]), "a"(b1[0]), "a"(b1[1]), "a"(b1[2]), "a"(b1[3]));
+}
 constexpr int BT = 32;                     // rows of the streamed tile
 constexpr int LQ2 = 72;                    // [row][d] tile: row stride in elements (144 B)
 constexpr int LT2 = 40;                    // [d][row] tile: row stride in elements (80 B)
@@ -414,16 +445,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(Bwd2Params pp) {
     const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
     const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
     const long stat0 = ((long)b * p.heads + h) * p.nq;
-    Frag kf[2][4], vf[2][4];                               // B operands: this wave's keys, resident
+    bf16x8 kf[2][4], vf[2][4];                             // B operands: this wave's keys, resident in AGPRs (rows past the end: clamped, never stored)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            uint4 t = ld_row16(Kp, p.k_ld, kw0 + kb * 32 + j, p.nk, ks * 16 + hi * 8);
-            kf[kb][ks].w[0] = t.x; kf[kb][ks].w[1] = t.y; kf[kb][ks].w[2] = t.z; kf[kb][ks].w[3] = t.w;
-            t = ld_row16(Vp, p.v_ld, kw0 + kb * 32 + j, p.nk, ks * 16 + hi * 8);
-            vf[kb][ks].w[0] = t.x; vf[kb][ks].w[1] = t.y; vf[kb][ks].w[2] = t.z; vf[kb][ks].w[3] = t.w;
+            const long r = min(kw0 + kb * 32 + j, p.nk - 1);
+            load_frag_agpr(kf[kb][ks], Kp + r * p.k_ld + ks * 16 + hi * 8);
+            load_frag_agpr(vf[kb][ks], Vp + r * p.v_ld + ks * 16 + hi * 8);
         }
+    TG_WAIT_FRAGS(kf);
+    TG_WAIT_FRAGS(vf);
     f32x16 dk[2][2], dv[2][2];                             // [key block][d block]: rows = keys, column = head dim j
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -479,12 +511,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(Bwd2Params pp) {
             }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            f32x16 s = zero16(), dp = zero16();            // rows = queries, column = key j
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aQ[ks], kf[kb][ks].v, s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aO[ks], vf[kb][ks].v, dp, 0, 0, 0);
-            }
+            f32x16 s, dp;                                  // rows = queries, column = key j
+            mfma_pair(s, dp, aQ, aO, kf[kb], vf[kb]);
             Frag pA[2], dA[2];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -501,13 +529,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(Bwd2Params pp) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    dv[kb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA[t].v, bO[t][db].v, dv[kb][db], 0, 0, 0);
-                    dk[kb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dA[t].v, bQ[t][db].v, dk[kb][db], 0, 0, 0);
+                    mfma_acc(dv[kb][db], pA[t].v, bO[t][db].v);
+                    mfma_acc(dk[kb][db], dA[t].v, bQ[t][db].v);
                 }
         }
         if (it + 1 < ntile) stash(buf ^ 1);
         __syncthreads();
     }
+    asm volatile("s_nop 15" ::: "memory");             // last asm MFMA's D -> the reads below (8-pass XDL: 12 wait states)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -541,21 +570,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
     const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
     const bf16_t* kT = pp.kT + ((long)(b * p.heads + h) * 64) * pp.ldk;
     const long stat0 = ((long)b * p.heads + h) * p.nq;
-    Frag qf[2][4], of[2][4];
+    bf16x8 qf[2][4], of[2][4];                             // B operands: this wave's queries, resident in AGPRs
     float lse[2], dsum[2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int q = qw0 + qb * 32 + j;
+        const long r = min(q, p.nq - 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            uint4 t = ld_row16(Q, p.q_ld, q, p.nq, ks * 16 + hi * 8);
-            qf[qb][ks].w[0] = t.x; qf[qb][ks].w[1] = t.y; qf[qb][ks].w[2] = t.z; qf[qb][ks].w[3] = t.w;
-            t = ld_row16(dO, p.do_ld, q, p.nq, ks * 16 + hi * 8);
-            of[qb][ks].w[0] = t.x; of[qb][ks].w[1] = t.y; of[qb][ks].w[2] = t.z; of[qb][ks].w[3] = t.w;
+            load_frag_agpr(qf[qb][ks], Q + r * p.q_ld + ks * 16 + hi * 8);
+            load_frag_agpr(of[qb][ks], dO + r * p.do_ld + ks * 16 + hi * 8);
         }
-        lse[qb] = q < p.nq ? p.lse[stat0 + q] : 1e30f;
+        lse[qb] = q < p.nq ? p.lse[stat0 + q] : 1e30f;           // masked query rows: P = 0 (their Q / dO fragments are a clamped copy)
         dsum[qb] = q < p.nq ? p.dsum[stat0 + q] : 0.f;
     }
+    TG_WAIT_FRAGS(qf);
+    TG_WAIT_FRAGS(of);
     f32x16 dq[2][2];                                       // [query block][d block]: rows = queries, column = head dim j
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -597,12 +627,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
             }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            f32x16 st = zero16(), dpt = zero16();          // rows = keys, column = query j
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aK[ks], qf[qb][ks].v, st, 0, 0, 0);
-                dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aV[ks], of[qb][ks].v, dpt, 0, 0, 0);
-            }
+            f32x16 st, dpt;                                // rows = keys, column = query j
+            mfma_pair(st, dpt, aK, aV, qf[qb], of[qb]);
             Frag dA[2];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -615,11 +641,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    dq[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dA[t].v, bK[t][db].v, dq[qb][db], 0, 0, 0);
+                    mfma_acc(dq[qb][db], dA[t].v, bK[t][db].v);
         }
         if (it + 1 < ntile) stash(buf ^ 1);
         __syncthreads();
     }
+    asm volatile("s_nop 15" ::: "memory");
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
