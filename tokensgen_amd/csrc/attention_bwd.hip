@@ -332,6 +332,31 @@ __device__ __forceinline__ void mfma_pair(f32x16& x, f32x16& y, const bf16x8 (&a
         : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]),
           "a"(b0[0]), "a"(b0[1]), "a"(b0[2]), "a"(b0[3]), "a"(b1[0]), "a"(b1[1]), "a"(b1[2]), "a"(b1[3]));
 }
+// one k-step of both chains of mfma_pair (FIRST: start from zero; LAST: append the 12 wait states): lets VALU work be placed between the steps
+template <bool FIRST, bool LAST>
+__device__ __forceinline__ void mfma_pair_step(f32x16& x, f32x16& y, const bf16x8& a0, const bf16x8& a1, const bf16x8& b0, const bf16x8& b1) {
+    if (FIRST)
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %4, 0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %5, 0" : "=&v"(x), "=&v"(y) : "v"(a0), "v"(a1), "a"(b0), "a"(b1));
+    else if (LAST)
+        asm("v_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %5, %1\n\ts_nop 11" : "+v"(x), "+v"(y) : "v"(a0), "v"(a1), "a"(b0), "a"(b1));
+    else
+        asm("v_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %5, %1" : "+v"(x), "+v"(y) : "v"(a0), "v"(a1), "a"(b0), "a"(b1));
+}
+#define TG_SB() __builtin_amdgcn_sched_barrier(0)
+// v_cvt_pk of two v_exp_f32 results: the transcendental unit's result needs a wait state before a plain VALU op reads it; hipcc pads that for
+// its own instructions but not in front of an asm statement (measured: dV wrong by orders of magnitude without it once the packed-math form put
+// the conversion right behind the second v_exp)
+__device__ __forceinline__ uint32_t pack_bf16x2_trans(float lo, float hi) {
+    uint32_t r;
+    asm("s_nop 1\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+#ifndef TG_BWD_PK
+#define TG_BWD_PK 1
+#endif
+#ifndef TG_BWD_INTERLEAVE
+#define TG_BWD_INTERLEAVE 1
+#endif
 constexpr int BT = 32;                     // rows of the streamed tile
 constexpr int LQ2 = 72;                    // [row][d] tile: row stride in elements (144 B)
 constexpr int LT2 = 40;                    // [d][row] tile: row stride in elements (80 B)
@@ -348,6 +373,13 @@ union Frag { bf16x8 v; uint2 u[2]; uint32_t w[4]; };
 __device__ __forceinline__ uint4 ld_row16(const bf16_t* base, long ld, int row, int n, int col) {
     return row < n ? *(const uint4*)(base + (long)row * ld + col) : uint4{0, 0, 0, 0};
 }
+// The streamed tiles are fetched UNCONDITIONALLY from a clamped row and masked when they are written to LDS: a load under `if (row < n)` with a
+// zero in the else branch makes hipcc wait for the load right there (the v_mov of the zero may not overtake it), which serialised every tile's
+// global latency in front of its compute.
+__device__ __forceinline__ uint4 ld_row16_clamped(const bf16_t* base, long ld, int row, int n, int col) {
+    return *(const uint4*)(base + (long)min(row, n - 1) * ld + col);
+}
+__device__ __forceinline__ uint4 mask16(uint4 v, bool ok) { return ok ? v : uint4{0, 0, 0, 0}; }
 
 // ---- (1') statistics: one wave per 64 queries, keys streamed in tiles of 32 ----
 __global__ __launch_bounds__(256) void attn_bwd_stats2_kernel(BwdParams p) {
@@ -391,7 +423,7 @@ __global__ __launch_bounds__(256) void attn_bwd_stats2_kernel(BwdParams p) {
     __syncthreads();
     for (int it = 0; it < ntile; ++it) {
         const int k0 = it * BT;
-        if (it + 1 < ntile) pre = ld_row16(Kp, p.k_ld, k0 + BT + row, p.nk, chunk);
+        if (it + 1 < ntile) pre = ld_row16_clamped(Kp, p.k_ld, k0 + BT + row, p.nk, chunk);        // rows past the end are masked to -1e30 below
         const bf16_t* cK = sK[it & 1];
         bf16x8 aK[4];
 #pragma unroll
@@ -466,21 +498,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(Bwd2Params pp) {
     const int ntile = (p.nq + BT - 1) / BT;
     uint4 g0, g1, g2, g3;
     float gs = 0.f;
+    bool okr = false, oks = false;
+    const float* statp = (tid < BT ? p.lse : p.dsum) + stat0;      // threads 0..31 carry the tile's log-sum-exp, 32..63 its D (others: a harmless copy)
     auto fetch = [&](int q0) {
-        g0 = ld_row16(Q, p.q_ld, q0 + row, p.nq, chunk);
-        g1 = ld_row16(dO, p.do_ld, q0 + row, p.nq, chunk);
+        okr = q0 + row < p.nq; oks = q0 + (tid & 31) < p.nq;
+        g0 = ld_row16_clamped(Q, p.q_ld, q0 + row, p.nq, chunk);
+        g1 = ld_row16_clamped(dO, p.do_ld, q0 + row, p.nq, chunk);
         g2 = *(const uint4*)(qT + (long)drow * pp.ldq + q0 + part);
         g3 = *(const uint4*)(doT + (long)drow * pp.ldq + q0 + part);
-        if (tid < BT) gs = q0 + tid < p.nq ? p.lse[stat0 + q0 + tid] : 1e30f;          // masked query rows: P = exp2(s - 1e30) = 0
-        else if (tid < 2 * BT) gs = q0 + tid - BT < p.nq ? p.dsum[stat0 + q0 + tid - BT] : 0.f;
+        gs = statp[min(q0 + (tid & 31), p.nq - 1)];
     };
     auto stash = [&](int buf) {
-        *(uint4*)(sQ[buf] + row * LQ2 + chunk) = g0;
-        *(uint4*)(sdO[buf] + row * LQ2 + chunk) = g1;
+        *(uint4*)(sQ[buf] + row * LQ2 + chunk) = mask16(g0, okr);
+        *(uint4*)(sdO[buf] + row * LQ2 + chunk) = mask16(g1, okr);
         *(uint4*)(sQt[buf] + drow * LT2 + part) = g2;
         *(uint4*)(sdOt[buf] + drow * LT2 + part) = g3;
-        if (tid < BT) sLse[buf][tid] = gs;
-        else if (tid < 2 * BT) sD[buf][tid - BT] = gs;
+        if (tid < BT) sLse[buf][tid] = oks ? gs : 1e30f;            // masked query rows: P = exp2(s - 1e30) = 0
+        else if (tid < 2 * BT) sD[buf][tid - BT] = oks ? gs : 0.f;
     };
     fetch(0);
     stash(0);
@@ -494,6 +528,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(Bwd2Params pp) {
             aQ[ks] = *(const bf16x8*)(sQ[buf] + j * LQ2 + ks * 16 + hi * 8);
             aO[ks] = *(const bf16x8*)(sdO[buf] + j * LQ2 + ks * 16 + hi * 8);
         }
+        TG_SB();                                           // these eight reads first: the S | dP MFMAs wait for them only (counted lgkmcnt)
         f32x4 l4[4], d4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -509,30 +544,69 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(Bwd2Params pp) {
                 bO[t][db].u[0] = *(const uint2*)(sdOt[buf] + o); bO[t][db].u[1] = *(const uint2*)(sdOt[buf] + o + 8);
                 bQ[t][db].u[0] = *(const uint2*)(sQt[buf] + o);  bQ[t][db].u[1] = *(const uint2*)(sQt[buf] + o + 8);
             }
+        TG_SB();
+        // One wave per SIMD: the matrix pipe and the VALU only overlap if their instructions alternate in program order.  Schedule (pinned
+        // with sched_barrier): S|dP of key block 0;  softmax(0) chunk by chunk between the k-steps of S|dP of key block 1;  softmax(1) chunk by
+        // chunk between the dV / dK MFMAs of key block 0;  dV / dK of key block 1.
+        const f32x2 sc2 = {p.scale_log2, p.scale_log2};
+        auto softmax_chunk = [&](int g, const f32x16& sx, const f32x16& dx, Frag (&pA)[2], Frag (&dA)[2]) {
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {               // two elements per VALU instruction (v_pk_fma / v_pk_add / v_pk_mul)
+                const f32x2 sv = {sx[4 * g + e], sx[4 * g + e + 1]}, dpv = {dx[4 * g + e], dx[4 * g + e + 1]};
+                const f32x2 lv = {l4[g][e], l4[g][e + 1]}, dv2 = {d4[g][e], d4[g][e + 1]};
+#if TG_BWD_PK
+                const f32x2 arg = sv * sc2 - lv;
+                const f32x2 pv = {fast_exp2(arg[0]), fast_exp2(arg[1])};
+                const f32x2 ds = pv * (dpv - dv2);
+#else
+                const f32x2 pv = {fast_exp2(sv[0] * p.scale_log2 - lv[0]), fast_exp2(sv[1] * p.scale_log2 - lv[1])};
+                const f32x2 ds = {pv[0] * (dpv[0] - dv2[0]), pv[1] * (dpv[1] - dv2[1])};
+#endif
+                pA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2_trans(pv[0], pv[1]);
+                dA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2(ds[0], ds[1]);
+            }
+        };
+        f32x16 s0, dp0, s1, dp1;
+        Frag pA0[2], dA0[2], pA1[2], dA1[2];
+#if !TG_BWD_INTERLEAVE
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            f32x16 s, dp;                                  // rows = queries, column = key j
-            mfma_pair(s, dp, aQ, aO, kf[kb], vf[kb]);
-            Frag pA[2], dA[2];
+            mfma_pair(s0, dp0, aQ, aO, kf[kb], vf[kb]);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float pv[4], ds[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    pv[e] = fast_exp2(s[4 * g + e] * p.scale_log2 - l4[g][e]);
-                    ds[e] = pv[e] * (dp[4 * g + e] - d4[g][e]);
-                }
-                pA[g >> 1].w[(g & 1) * 2] = pack_bf16x2(pv[0], pv[1]); pA[g >> 1].w[(g & 1) * 2 + 1] = pack_bf16x2(pv[2], pv[3]);
-                dA[g >> 1].w[(g & 1) * 2] = pack_bf16x2(ds[0], ds[1]); dA[g >> 1].w[(g & 1) * 2 + 1] = pack_bf16x2(ds[2], ds[3]);
-            }
+            for (int g = 0; g < 4; ++g) softmax_chunk(g, s0, dp0, pA0, dA0);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    mfma_acc(dv[kb][db], pA[t].v, bO[t][db].v);
-                    mfma_acc(dk[kb][db], dA[t].v, bQ[t][db].v);
+                    mfma_acc(dv[kb][db], pA0[t].v, bO[t][db].v);
+                    mfma_acc(dk[kb][db], dA0[t].v, bQ[t][db].v);
                 }
         }
+#else
+        mfma_pair(s0, dp0, aQ, aO, kf[0], vf[0]);
+        TG_SB();
+        softmax_chunk(0, s0, dp0, pA0, dA0); TG_SB();
+        mfma_pair_step<true, false>(s1, dp1, aQ[0], aO[0], kf[1][0], vf[1][0]); TG_SB();
+        softmax_chunk(1, s0, dp0, pA0, dA0); TG_SB();
+        mfma_pair_step<false, false>(s1, dp1, aQ[1], aO[1], kf[1][1], vf[1][1]); TG_SB();
+        softmax_chunk(2, s0, dp0, pA0, dA0); TG_SB();
+        mfma_pair_step<false, false>(s1, dp1, aQ[2], aO[2], kf[1][2], vf[1][2]); TG_SB();
+        softmax_chunk(3, s0, dp0, pA0, dA0); TG_SB();
+        mfma_pair_step<false, true>(s1, dp1, aQ[3], aO[3], kf[1][3], vf[1][3]); TG_SB();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                       // chunk g of key block 1, then the (k-step g/2, d block g%2) products of key block 0
+            softmax_chunk(g, s1, dp1, pA1, dA1); TG_SB();
+            mfma_acc(dv[0][g & 1], pA0[g >> 1].v, bO[g >> 1][g & 1].v);
+            mfma_acc(dk[0][g & 1], dA0[g >> 1].v, bQ[g >> 1][g & 1].v); TG_SB();
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                mfma_acc(dv[1][db], pA1[t].v, bO[t][db].v);
+                mfma_acc(dk[1][db], dA1[t].v, bQ[t][db].v);
+            }
+#endif
         if (it + 1 < ntile) stash(buf ^ 1);
         __syncthreads();
     }
@@ -595,14 +669,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
     const int drow = tid >> 2, part = (tid & 3) * 8;
     const int ntile = (p.nk + BT - 1) / BT;
     uint4 g0, g1, g2;
+    bool okr = false;
     auto fetch = [&](int k0) {
-        g0 = ld_row16(Kp, p.k_ld, k0 + row, p.nk, chunk);
-        g1 = ld_row16(Vp, p.v_ld, k0 + row, p.nk, chunk);
+        okr = k0 + row < p.nk;
+        g0 = ld_row16_clamped(Kp, p.k_ld, k0 + row, p.nk, chunk);
+        g1 = ld_row16_clamped(Vp, p.v_ld, k0 + row, p.nk, chunk);
         g2 = *(const uint4*)(kT + (long)drow * pp.ldk + k0 + part);
     };
     auto stash = [&](int buf) {
-        *(uint4*)(sK[buf] + row * LQ2 + chunk) = g0;
-        *(uint4*)(sV[buf] + row * LQ2 + chunk) = g1;
+        *(uint4*)(sK[buf] + row * LQ2 + chunk) = mask16(g0, okr);
+        *(uint4*)(sV[buf] + row * LQ2 + chunk) = mask16(g1, okr);
         *(uint4*)(sKt[buf] + drow * LT2 + part) = g2;
     };
     fetch(0);
@@ -617,6 +693,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
             aK[ks] = *(const bf16x8*)(sK[buf] + j * LQ2 + ks * 16 + hi * 8);
             aV[ks] = *(const bf16x8*)(sV[buf] + j * LQ2 + ks * 16 + hi * 8);
         }
+        TG_SB();
         Frag bK[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -630,13 +707,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
             f32x16 st, dpt;                                // rows = keys, column = query j
             mfma_pair(st, dpt, aK, aV, qf[qb], of[qb]);
             Frag dA[2];
+            const f32x2 sc2 = {p.scale_log2, p.scale_log2}, lv = {lse[qb], lse[qb]}, dv2 = {dsum[qb], dsum[qb]};
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float ds[4];
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ds[e] = fast_exp2(st[4 * g + e] * p.scale_log2 - lse[qb]) * (dpt[4 * g + e] - dsum[qb]);
-                dA[g >> 1].w[(g & 1) * 2] = pack_bf16x2(ds[0], ds[1]); dA[g >> 1].w[(g & 1) * 2 + 1] = pack_bf16x2(ds[2], ds[3]);
-            }
+                for (int e = 0; e < 4; e += 2) {
+                    const f32x2 sv = {st[4 * g + e], st[4 * g + e + 1]}, dpv = {dpt[4 * g + e], dpt[4 * g + e + 1]};
+#if TG_BWD_PK
+                    const f32x2 arg = sv * sc2 - lv;
+                    const f32x2 pv = {fast_exp2(arg[0]), fast_exp2(arg[1])};
+                    const f32x2 ds = pv * (dpv - dv2);
+#else
+                    const f32x2 pv = {fast_exp2(sv[0] * p.scale_log2 - lv[0]), fast_exp2(sv[1] * p.scale_log2 - lv[1])};
+                    const f32x2 ds = {pv[0] * (dpv[0] - dv2[0]), pv[1] * (dpv[1] - dv2[1])};
+#endif
+                    dA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2(ds[0], ds[1]);
+                }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
