@@ -212,6 +212,12 @@ int tg_pca_inverse(const void* lat, const float* std16, const float* mean16, con
                    void* out, int frames, int ncoef, int hw, int cout, hipStream_t stream);
 
 
+/* Training forward of one attention call: tg_attention_fwd with a single key segment that ALSO writes, per query row, the log-sum-exp of the
+ * scaled scores in the log2 domain (lse fp32 [batch][heads][nq]): what flash-attention keeps for its backward
+ * (F.scaled_dot_product_attention under autograd, attention_processor.py:2066-2125).  vt: the transposed V image as for tg_attention_fwd. */
+int tg_attention_fwd_lse(const void* q, long q_ld, long q_strideB, const void* k, long k_ld, long k_strideB, const void* vt, long vt_ld, int nk,
+                         void* out, long out_ld, long out_strideB, int nq, int heads, int batch, float scale, float* lse, hipStream_t stream);
+
 /* Attention BACKWARD (training step): what autograd runs for F.scaled_dot_product_attention in the reference's training
  * loop (attention_processor.py:2066-2125 under train_cogvideo_to2v.py:1995-2010), head_dim 64, no mask, no dropout.
  *   P = softmax(scale q k^T)   dV = P^T dO   dP = dO v^T   dS = P o (dP - rowsum(dO o O))   dQ = scale dS k   dK = scale dS^T q
@@ -221,11 +227,13 @@ int tg_pca_inverse(const void* lat, const float* std16, const float* mean16, con
  * ws: 16-byte aligned fp32 workspace of tg_attention_bwd_ws_floats(nq, nk, heads, batch) floats (row log-sum-exp, rowsum(dO o O), and the
  * transposed bf16 copies Q^T, dO^T, K^T the kernels' [d][row] tiles are loaded from).
  * P is recomputed from the log-sum-exp tile by tile; three launches (statistics, dK/dV per 256-key workgroup, dQ per 256-query workgroup) behind
- * three tg_transpose_v passes, no atomics: run-to-run deterministic.  TG_ATTN_BWD_V1=1 selects the earlier correct-first kernels (cross-check). */
+ * three tg_transpose_v passes, no atomics: run-to-run deterministic.  lse: optional [batch][heads][nq] fp32 row log-sum-exp (log2 domain) written by
+ * tg_attention_fwd_lse for the same q / k / scale — the statistics launch then only forms rowsum(dO o O); NULL: recomputed here.
+ * TG_ATTN_BWD_V1=1 selects the earlier correct-first kernels (cross-check). */
 int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void* k, long k_ld, long k_sb, const void* v, long v_ld, long v_sb,
                      const void* o, long o_ld, long o_sb, const void* dout, long do_ld, long do_sb,
                      float* dq, long dq_ld, long dq_sb, float* dk, long dk_ld, long dk_sb, float* dv, long dv_ld, long dv_sb,
-                     int nq, int nk, int heads, int batch, float scale, int accumulate, float* ws, hipStream_t stream);
+                     int nq, int nk, int heads, int batch, float scale, int accumulate, const float* lse, float* ws, hipStream_t stream);
 long tg_attention_bwd_ws_floats(int nq, int nk, int heads, int batch);
 
 /* Backward of tg_qk_layernorm_rope (y = rope(bf16(LN64(x) g + b)) * out_scale; attention_processor.py:2031-2056) for the trainable vip_norm_q /

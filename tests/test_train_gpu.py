@@ -56,6 +56,17 @@ def test_attention_bwd_vs_autograd(B, H, nq, nk):
     assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
     K.attention_bwd(qd, kd, vd, o.detach().to(BF).to(DEV), g.to(DEV), H, scale, dq=dq2, dk=dk2, dv=dv2, accumulate=True)
     assert torch.allclose(dq2, 2 * dq) and torch.allclose(dk2, 2 * dk) and torch.allclose(dv2, 2 * dv)
+    # the forward's own log-sum-exp (tg_attention_fwd_lse) instead of the statistics pass: same row statistics up to fp32 rounding
+    pad = (nk + 63) // 64 * 64
+    vt = K.transpose_v(vd, H, 0, nk, torch.zeros(B, H, 64, pad, dtype=BF, device=DEV))
+    out = torch.empty(B, nq, H * 64, dtype=BF, device=DEV)
+    _, lse = K.attention_lse(qd, kd, vt, nk, out, H, scale)
+    sp = lambda t: t.view(B, t.shape[1], H, 64).transpose(1, 2)
+    want = torch.logsumexp(sp(qf.detach()) @ sp(kf.detach()).transpose(-1, -2) * scale, dim=-1) / math.log(2.0)
+    assert (lse.cpu() - want).abs().max().item() < 2e-3
+    assert _rel(out, o.detach()) < 8e-3
+    dq3, dk3, dv3 = K.attention_bwd(qd, kd, vd, out, g.to(DEV), H, scale, lse=lse)
+    assert _rel(dq3, qf.grad) < 1.5e-2 and _rel(dk3, kf.grad) < 1.5e-2 and _rel(dv3, vf.grad) < 8e-3
 
 
 def test_to2v_processor_attention_gradients():

@@ -53,6 +53,9 @@ struct AttnParams {
     bf16_t* r_out; long r_o_ld, r_o_sb;
     int r_nq;
     int main_wgs;       // workgroups of the main problem (rider workgroups follow); 0 rider workgroups when r_nq == 0
+    // training forward only (tg_attention_fwd_lse; single segment, no rider): per query row the log-sum-exp of the scaled scores in the
+    // log2 domain, [batch][heads][lse_rows] fp32 — what tg_attention_bwd otherwise recomputes with a pass of its own
+    float* lse; long lse_rows;
 };
 
 // plain fmaxf nests: clang fuses them to v_max3_f32 (built with -fno-honor-nans so MFMA outputs are not canonicalised by an
@@ -258,6 +261,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
             const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
             const float w = (sg == 0 ? 1.f : p.seg2_scale) / lt;
             const int q = q0 + qb * 32 + j;
+            if (p.lse && hi == 0 && q < p.nq) p.lse[((long)b * p.heads + h) * p.lse_rows + q] = m[qb] + log2f(lt);
             if (q < p.nq) {
                 bf16_t* op = p.out + (long)b * p.o_sb + (long)q * p.o_ld + h * 64;
 #pragma unroll
@@ -324,7 +328,7 @@ __device__ long long tg_attn_dbg[16];   // TG_ATTN_TIMING: cycles {X work, X bar
 
 // FIXEDM 1: every score has the segment's constant `bound` subtracted instead of a running row maximum (tg_attn_segment.score_bound);
 // FIXEDM 2: bounds below 40 need no shift at all — P = 2^s stays within 2^+-40 — so the four MFMAs that seed the accumulators go too
-template <bool PRESCALED, bool TIMING = false, int FIXEDM = 0>
+template <bool PRESCALED, bool TIMING = false, int FIXEDM = 0, bool LSE = false>
 __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
     // K[2], Vt[2] tiles (32 KiB) + the output staging area: 8 waves x 64 query rows x 128 B (64 KiB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -696,6 +700,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
             const float w = (sg == 0 ? 1.f : p.seg2_scale) / lt;
             const int row = qb * 32 + j;
+            if (LSE && FIXEDM == 0 && hi == 0 && q0 + row < nq_) p.lse[((long)b * p.heads + h) * p.lse_rows + q0 + row] = m[qb] + log2f(lt);
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -782,6 +787,7 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
         t.nq = nq - full_rows;
         for (int sg = 0; sg < p.nseg; ++sg) t.s[sg].q = p.s[sg].q + (long)full_rows * p.s[sg].q_ld;
         t.out = p.out + (long)full_rows * p.o_ld;
+        if (p.lse) t.lse = p.lse + full_rows;
         const int nqt = (t.nq + 127) / 128;
         hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3((unsigned)(nqt * heads * batch)), dim3(256), 0, stream, t);
         TG_LAUNCH_CHECK(who);
@@ -829,7 +835,14 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
         if (bmax < 40.f && fixedm_on == 2) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 2>), dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
         else hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1>), dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
     } else if (pp) {
-        if (p.prescaled) hipLaunchKernelGGL(attn_fwd_pp_kernel<true>, dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
+        if (p.lse) {
+            static bool attr_lse = false;
+            if (!attr_lse) {
+                (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+                attr_lse = true;
+            }
+            hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 0, true>), dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
+        } else if (p.prescaled) hipLaunchKernelGGL(attn_fwd_pp_kernel<true>, dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
         else hipLaunchKernelGGL(attn_fwd_pp_kernel<false>, dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
     } else if (wg256 >= 1024 && abl) {
         if (abl == 1) hipLaunchKernelGGL((attn_fwd_kernel<2, 1>), dim3((unsigned)wg256), dim3(256), 0, stream, p);
@@ -899,4 +912,20 @@ extern "C" int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
     A.seg2_scale = seg2_scale;
     A.out = out; A.out_ld = out_ld; A.out_strideB = out_strideB; A.nq = nq;
     return tg_attention_fwd_multi(&A, 1, heads, batch, scale, k_prescaled, stream);
+}
+
+extern "C" int tg_attention_fwd_lse(const void* q, long q_ld, long q_strideB, const void* k, long k_ld, long k_strideB, const void* vt, long vt_ld, int nk,
+                                    void* out, long out_ld, long out_strideB, int nq, int heads, int batch, float scale, float* lse, hipStream_t stream) {
+    TG_REQUIRE(q && k && vt && out && lse, TG_ERR_ARG, "tg_attention_fwd_lse: null pointer");
+    TG_REQUIRE(nq > 0 && nk > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_attention_fwd_lse: bad shape nq=%d nk=%d", nq, nk);
+    TG_REQUIRE(out_ld % 8 == 0 && out_strideB % 8 == 0 && tg_aligned16(out), TG_ERR_ALIGN, "tg_attention_fwd_lse: output alignment (16 B)");
+    AttnParams p{};
+    const tg_attn_segment g{q, q_ld, q_strideB, k, k_ld, k_strideB, vt, vt_ld, nk, 0.f};
+    int rc = fill_segment(p.s[0], g, "segment");
+    if (rc) return rc;
+    p.nseg = 1;
+    p.out = (bf16_t*)out; p.o_ld = out_ld; p.o_sb = out_strideB;
+    p.nq = nq; p.heads = heads; p.batch = batch;
+    p.lse = lse; p.lse_rows = nq;
+    return attention_launch(p, scale, 0, "tg_attention_fwd_lse", stream);
 }

@@ -33,6 +33,7 @@ struct BwdParams {
     int nq, nk, heads, batch;
     float scale_log2, scale;
     int accumulate;
+    int have_lse;                          // lse was written by the forward (tg_attention_fwd_lse): the statistics launch only computes D
 };
 
 // rows [r0, r0 + 64) x 64 head columns of a [n][ld] bf16 matrix -> dst[row][LDT]; rows >= n are zero
@@ -407,6 +408,7 @@ __global__ __launch_bounds__(256) void attn_bwd_stats2_kernel(BwdParams p) {
             p.dsum[stat0 + r] = d;
         }
     }
+    if (p.have_lse) return;
     Frag qf[2][4];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
@@ -788,7 +790,7 @@ static int attention_bwd_v1(const void* q, long q_ld, long q_sb, const void* k, 
 extern "C" int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void* k, long k_ld, long k_sb, const void* v, long v_ld, long v_sb,
                                  const void* o, long o_ld, long o_sb, const void* dout, long do_ld, long do_sb,
                                  float* dq, long dq_ld, long dq_sb, float* dk, long dk_ld, long dk_sb, float* dv, long dv_ld, long dv_sb,
-                                 int nq, int nk, int heads, int batch, float scale, int accumulate, float* ws, hipStream_t stream) {
+                                 int nq, int nk, int heads, int batch, float scale, int accumulate, const float* lse, float* ws, hipStream_t stream) {
     static const bool v1 = [] { const char* e = getenv("TG_ATTN_BWD_V1"); return e && e[0] == '1'; }();
     if (v1) return attention_bwd_v1(q, q_ld, q_sb, k, k_ld, k_sb, v, v_ld, v_sb, o, o_ld, o_sb, dout, do_ld, do_sb, dq, dq_ld, dq_sb, dk, dk_ld, dk_sb,
                                     dv, dv_ld, dv_sb, nq, nk, heads, batch, scale, accumulate, ws, stream);
@@ -809,7 +811,8 @@ extern "C" int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void*
     Bwd2Params pp{};
     pp.p = BwdParams{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, q_ld, q_sb, k_ld, k_sb, v_ld, v_sb,
                      o_ld, o_sb, do_ld, do_sb, dq, dk, dv, dq_ld, dq_sb, dk_ld, dk_sb, dv_ld, dv_sb, ws, ws + (long)batch * heads * nq, nq, nk, heads, batch,
-                     scale * 1.4426950408889634f, scale, accumulate};
+                     scale * 1.4426950408889634f, scale, accumulate, lse ? 1 : 0};
+    if (lse) pp.p.lse = const_cast<float*>(lse);
     pp.qT = qT; pp.doT = doT; pp.kT = kT; pp.ldq = ldq; pp.ldk = ldk;
     const dim3 gq((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), gk((unsigned)((nk + 255) / 256), (unsigned)(batch * heads));
     hipLaunchKernelGGL(attn_bwd_stats2_kernel, gq, dim3(256), 0, stream, pp.p);

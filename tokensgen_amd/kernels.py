@@ -241,11 +241,28 @@ def attention(q1, k1, vt1, nk1, out, heads, scale, q2=None, k2=None, vt2=None, n
     return out
 
 
-def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, accumulate=False):
+def attention_lse(q, k, vt, nk, out, heads, scale):
+    """Training forward of one attention call: out = softmax(scale q k^T) v AND the per-row log-sum-exp (log2 domain, fp32 [B, heads, nq]) that
+    attention_bwd takes instead of recomputing it (tg_attention_fwd_lse)."""
+    _chk(q, "q"); _chk(k, "k"); _chk(vt, "vt"); _chk(out, "out")
+    B, nq, _, qld, qsb = _bmk(q)
+    _, _, _, kld, ksb = _bmk(k)
+    _, _, _, old, osb = _bmk(out)
+    lse = torch.empty(B, heads, nq, dtype=torch.float32, device=q.device)
+    L.check(_launch(f"attention_lse_nq{nq}", L.load().tg_attention_fwd_lse, _p(q), qld, qsb, _p(k), kld, ksb, _p(vt), vt.stride(2), nk, _p(out), old, osb, nq, heads, B,
+                    float(scale), _p(lse), _stream()), "tg_attention_fwd_lse")
+    return out, lse
+
+
+def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, accumulate=False, lse=None):
     """Gradients of o = softmax(scale q k^T) v per head (tg_attention_bwd).  q/o/dout [B,nq,heads*64], k/v [B,nk,heads*64] bf16 views;
-    returns fp32 (dq, dk, dv) shaped like q, k, v (given tensors are written, or added to with accumulate=True)."""
+    returns fp32 (dq, dk, dv) shaped like q, k, v (given tensors are written, or added to with accumulate=True).  lse: the forward's
+    log-sum-exp from attention_lse (optional; recomputed when None)."""
     for n, t in (("q", q), ("k", k), ("v", v), ("o", o), ("dout", dout)):
         _chk(t, n)
+    if lse is not None:
+        _chk(lse, "lse", torch.float32)
+        assert lse.is_contiguous() and lse.shape == (q.shape[0], heads, q.shape[1])
     B, nq, HD, qld, qsb = _bmk(q)
     _, nk, _, kld, ksb = _bmk(k)
     _, _, _, vld, vsb = _bmk(v)
@@ -260,7 +277,7 @@ def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, acc
     ws = torch.empty(L.load().tg_attention_bwd_ws_floats(nq, nk, heads, B), dtype=f32, device=q.device)
     L.check(_launch("attention_bwd", L.load().tg_attention_bwd, _p(q), qld, qsb, _p(k), kld, ksb, _p(v), vld, vsb, _p(o), old, osb, _p(dout), gld, gsb,
                     _p(dq), dq.stride(1), dq.stride(0), _p(dk), dk.stride(1), dk.stride(0), _p(dv), dv.stride(1), dv.stride(0), nq, nk, heads, B,
-                    float(scale), 1 if accumulate else 0, _p(ws), _stream()), "tg_attention_bwd")
+                    float(scale), 1 if accumulate else 0, _p(lse), _p(ws), _stream()), "tg_attention_bwd")
     return dq, dk, dv
 
 

@@ -39,22 +39,22 @@ def vpred_loss_and_grad(model_output, noisy_model_input, model_input, timesteps,
 
 
 @torch.no_grad()
-def to2v_attention_backward(q, k, v, qx, kx, vx, qv, kv, vv, o1, o2, o3, d_out, heads, sm_scale, vip_scale):
+def to2v_attention_backward(q, k, v, qx, kx, vx, qv, kv, vv, o1, o2, o3, d_out, heads, sm_scale, vip_scale, lse=(None, None, None)):
     """Backward of `cat(sdpa(q, k, v) + vip_scale * sdpa(qx, kv, vv), sdpa(qv, cat(kx, kv), cat(vx, vv)))` (attention_processor.py:2066-2135):
     q..vv are the post-norm / post-RoPE projections [B, n, heads*64] (bf16), o1/o2/o3 the three attention outputs saved by the forward,
     d_out [B, N1 + Np, heads*64] the gradient of the concatenated result.  Returns fp32 gradients keyed like the inputs.  kv / vv receive
-    the sum of two calls' gradients (accumulate)."""
+    the sum of two calls' gradients (accumulate).  lse: the three calls' log-sum-exps from K.attention_lse (optional)."""
     N1, Np = q.shape[1], qv.shape[1]
     f32 = torch.float32
     g1 = d_out[:, :N1]
-    dq, dk, dv = K.attention_bwd(q, k, v, o1, g1, heads, sm_scale)
+    dq, dk, dv = K.attention_bwd(q, k, v, o1, g1, heads, sm_scale, lse=lse[0])
     g2 = (g1.float() * float(vip_scale)).to(BF16)          # `scale * O2` is a bf16 tensor in the forward
-    dqx, dkv, dvv = K.attention_bwd(qx, kv, vv, o2, g2, heads, sm_scale)
+    dqx, dkv, dvv = K.attention_bwd(qx, kv, vv, o2, g2, heads, sm_scale, lse=lse[1])
     B, HD = q.shape[0], q.shape[2]
     dkc = torch.zeros(B, N1 + Np, HD, dtype=f32, device=q.device)
     dvc = torch.zeros_like(dkc)
     dkc[:, N1:], dvc[:, N1:] = dkv, dvv
-    dqv, _, _ = K.attention_bwd(qv, torch.cat([kx, kv], 1), torch.cat([vx, vv], 1), o3, d_out[:, N1:], heads, sm_scale, dk=dkc, dv=dvc, accumulate=True)
+    dqv, _, _ = K.attention_bwd(qv, torch.cat([kx, kv], 1), torch.cat([vx, vv], 1), o3, d_out[:, N1:], heads, sm_scale, dk=dkc, dv=dvc, accumulate=True, lse=lse[2])
     return dict(q=dq, k=dk, v=dv, qx=dqx, kx=dkc[:, :N1], vx=dvc[:, :N1], qv=dqv, kv=dkc[:, N1:], vv=dvc[:, N1:])
 
 
@@ -293,9 +293,9 @@ class To2VBlockTrainer:
         qv, kv, vv = (qkvv[:, N1:, c * D:(c + 1) * D] for c in range(3))
         o1, o2, o3 = e(B, N1, D), e(B, N1, D), e(B, Np, D)
         vt1, vt2, vt3 = vt(qkv[:, :, 2 * D:], 0, N1), vt(qkvv[:, :, 2 * D:], N1, Np), vt(qkvv[:, :, 2 * D:], 0, N)
-        K.attention(q, k, vt1, N1, o1, H, sm)
-        K.attention(qx, kv, vt2, Np, o2, H, sm)
-        K.attention(qv, qkvv[:, :, D:2 * D], vt3, N, o3, H, sm)
+        _, lse1 = K.attention_lse(q, k, vt1, N1, o1, H, sm)
+        _, lse2 = K.attention_lse(qx, kv, vt2, Np, o2, H, sm)
+        _, lse3 = K.attention_lse(qv, qkvv[:, :, D:2 * D], vt3, N, o3, H, sm)
         AO = e(B, N, D)
         torch.add(o1, o2 * self.s, out=AO[:, :N1])           # `hidden_states + scale * vip_hidden_states` on bf16 tensors (attention_processor.py:2117-2125)
         AO[:, N1:] = o3
@@ -319,7 +319,7 @@ class To2VBlockTrainer:
             self.saved = None
             return X2[:, Nt:N1], torch.cat([X2[:, :Nt], X2[:, N1:]], dim=1)
         S.update(X0=X0, X1=X1, Xn=Xn, Xn2=Xn2, emb=emb, t1=t1, t2=t2, mod1=mod1, mod2=mod2, qkv_pre=qkv_pre, qkvv_pre=qkvv_pre, q=q, k=k, v=v, qx=qx, kx=kx,
-                 vx=vx, qv=qv, kv=kv, vv=vv, o1=o1, o2=o2, o3=o3, y_attn=y_attn, y_ff=y_ff, ffpre=ffpre, rope=rope, vrope=vrope, crope=crope, dims=(B, Nv, D, N1, N))
+                 vx=vx, qv=qv, kv=kv, vv=vv, o1=o1, o2=o2, o3=o3, lse=(lse1, lse2, lse3), y_attn=y_attn, y_ff=y_ff, ffpre=ffpre, rope=rope, vrope=vrope, crope=crope, dims=(B, Nv, D, N1, N))
         return X2[:, Nt:N1], torch.cat([X2[:, :Nt], X2[:, N1:]], dim=1)
 
     def _vip_norm_grads(self, which, t_dln, t_dlnx, t_dyln, dxn, t_dgate, grads):
@@ -361,7 +361,7 @@ class To2VBlockTrainer:
         dy_attn, tg1 = _gate_res_bwd(dX1, S["y_attn"], S["t1"])
         dAO = _dgrad(dy_attn.view(B * N, D), sd[A + "to_out.0.weight"]).view(B, N, D)
         # ---- the three attention calls, QK-norm + RoPE, projections ----
-        ga = to2v_attention_backward(S["q"], S["k"], S["v"], S["qx"], S["kx"], S["vx"], S["qv"], S["kv"], S["vv"], S["o1"], S["o2"], S["o3"], dAO, H, 1.0 / 8.0, self.s)
+        ga = to2v_attention_backward(S["q"], S["k"], S["v"], S["qx"], S["kx"], S["vx"], S["qv"], S["kv"], S["vv"], S["o1"], S["o2"], S["o3"], dAO, H, 1.0 / 8.0, self.s, lse=S["lse"])
         pg, d_pre_v = vip_projection_backward(S["Xn"], S["qkvv_pre"], ga, H, Nt, N1, sd[A + "processor.vip_norm_q.weight"], sd[A + "processor.vip_norm_k.weight"],
                                               S["vrope"], S["crope"], return_dpre=True)
         for kname, val in pg.items():
@@ -643,7 +643,7 @@ class ResamplerTrainer:
             vt = torch.zeros(b, H, 64, (Nx + Nq + 63) // 64 * 64, dtype=BF16, device=dev)
             K.transpose_v(kv[:, :, inner:], H, 0, Nx + Nq, vt)
             ao = e(b, Nq, inner)
-            K.attention(q, kv[:, :, :inner], vt, Nx + Nq, ao, H, sm)
+            _, lse = K.attention_lse(q, kv[:, :, :inner], vt, Nx + Nq, ao, H, sm)
             lat1 = e(b, Nq, dim)
             ones = self._ones(Nq, dim, b, dev)
             K.gemm(ao, sd[p + ".to_out.weight"], None, lat1, L.EPI_BIAS_GATE_RES, residual=lat, gate=ones)
@@ -652,7 +652,7 @@ class ResamplerTrainer:
             K.gemm(lat1, sd[f + ".net.0.proj.weight"], sd[f + ".net.0.proj.bias"], ffh, L.EPI_BIAS_GELU)
             lat2 = e(b, Nq, dim)
             K.gemm(ffh, sd[f + ".net.2.weight"], sd[f + ".net.2.bias"], lat2, L.EPI_BIAS_GATE_RES, residual=lat1, gate=ones)
-            S.update(cat=cat, q_pre=q_pre, kv_pre=kv_pre, q=q, kv=kv, ao=ao, lat1=lat1, ffpre=ffpre, ffh=ffh)
+            S.update(cat=cat, q_pre=q_pre, kv_pre=kv_pre, q=q, kv=kv, ao=ao, lse=lse, lat1=lat1, ffpre=ffpre, ffh=ffh)
             layers.append(S)
             lat = lat2
         po, out = e(b, Nq, sd["proj_out.weight"].shape[0]), e(b, Nq, sd["proj_out.weight"].shape[0])
@@ -702,7 +702,7 @@ class ResamplerTrainer:
             dW, _, d_ao = linear_backward(f2(S["ao"]), f2(d_lat1), sd[p + ".to_out.weight"], need_dx=True)
             grads[p + ".to_out.weight"] = dW
             kv = S["kv"]
-            dq, dk, dv = K.attention_bwd(S["q"], kv[:, :, :inner], kv[:, :, inner:], S["ao"], d_ao.reshape(b, Nq, inner).contiguous(), H, 1.0 / 8.0)
+            dq, dk, dv = K.attention_bwd(S["q"], kv[:, :, :inner], kv[:, :, inner:], S["ao"], d_ao.reshape(b, Nq, inner).contiguous(), H, 1.0 / 8.0, lse=S["lse"])
             dq_pre, gq, bq = qk_layernorm_rope_backward(S["q_pre"], dq, H, sd[p + ".norm_q.weight"], 1e-6, None if smp is None else (0, smp))
             dk_pre, gk, bk = qk_layernorm_rope_backward(S["kv_pre"][:, :, :inner], dk, H, sd[p + ".norm_k.weight"], 1e-6, None if img is None else (0, img),
                                                         None if smp is None else (Nx, smp))
