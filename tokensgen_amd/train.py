@@ -216,8 +216,9 @@ def _cat_or_view(ts):
     """Row-wise concatenation of same-width tensors: a VIEW when they already sit back to back in memory (the parameter arena lays vip_to_q/k/v
     out that way, so an optimizer step is seen without re-concatenating), else a copy."""
     t0 = ts[0]
-    adjacent = all(t.is_contiguous() for t in ts) and all(ts[i + 1].data_ptr() == ts[i].data_ptr() + ts[i].numel() * ts[i].element_size()
-                                                            for i in range(len(ts) - 1))
+    same_storage = all(t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() for t in ts)     # neighbours in the allocator do not count
+    adjacent = same_storage and all(t.is_contiguous() for t in ts) and all(
+        ts[i + 1].data_ptr() == ts[i].data_ptr() + ts[i].numel() * ts[i].element_size() for i in range(len(ts) - 1))
     if adjacent and t0.numel() % 64 == 0:
         rows = sum(t.shape[0] for t in ts)
         return torch.as_strided(t0, (rows,) + tuple(t0.shape[1:]), t0.stride())
