@@ -320,6 +320,7 @@ def run_train(a, rank, world, device, dist):
             "data": "synthetic latents / embeddings, random-init weights at CogVideoX-5B + Resampler(4x8x12) shapes",
             "config": {"workload": "To2V train micro-step (BASELINE config 5): batch 2 x 13 latent frames 60x90, 226 text + 480 vip tokens, Resampler over 2 chunks of 17550 tokens",
                        "layers": a.layers, "accumulation_steps": a.accum, "optimizer_steps_in_timed_region": n_opt,
+                       "blocks_keeping_activations": tr.blocks_kept, "blocks_recomputed_in_backward": a.layers - tr.blocks_kept,
                        "trainable_parameters": int(sum(v.numel() for v in arena.views.values()))},
             "roofline": {"bound": "mfma", "kernel": "tg_attention_bwd (statistics + dK/dV + dQ launches, all transformer layers of one micro-step)",
                          "achieved": alg / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else None, "peak": 2500.0, "unit": "TFLOP/s",

@@ -357,6 +357,17 @@ def test_to2v_model_training_forward_backward_vs_autograd_of_the_oracle_model():
     assert _rel(d_vip, want_vip) < 2e-2
     for name in train_keys:
         assert _rel(grads[name], sd[name].grad) < 4e-2, name
+    # the two activation schedules are the same computation: blocks that keep their activations (288 GB: the default when memory allows) and blocks
+    # that re-run their forward inside the backward (the reference's per-block checkpointing) give bitwise the same gradients
+    assert not tr._kept and not tr._ckpt
+    tr.activation_budget_bytes = 0
+    out0 = tr.forward(noisy.to(DEV), text.to(DEV), ts, vip.to(DEV), rope, vrope, crope)
+    assert not tr._kept and torch.equal(out0, out)
+    grads0, d_vip0 = tr.backward(d_out)
+    assert torch.equal(d_vip0, d_vip) and all(torch.equal(grads0[k], grads[k]) for k in train_keys)
+    tr.activation_budget_bytes = None
+    tr.forward(noisy.to(DEV), text.to(DEV), ts, vip.to(DEV), rope, vrope, crope)
+    assert sorted(tr._kept) == [0, 1]
 
 
 def test_optimizer_step_vs_torch_adamw_with_clipping():

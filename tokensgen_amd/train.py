@@ -402,6 +402,16 @@ class To2VTrainer:
         self.trainable = sorted(k for k in sd if "vip_" in k)
         self._blocks = None
 
+    activation_budget_bytes = None        # None: automatic (free device memory minus `activation_reserve_bytes`); 0: checkpoint every block
+    activation_reserve_bytes = 40 << 30
+
+    def _activation_budget(self):
+        if self.activation_budget_bytes is not None:
+            return int(self.activation_budget_bytes)
+        free, _ = torch.cuda.mem_get_info()
+        free += torch.cuda.memory_reserved() - torch.cuda.memory_allocated()      # cached blocks of the allocator are reusable
+        return max(0, free - self.activation_reserve_bytes)
+
     def use_arena(self, arena):
         """Move the trainable parameters into a ParamArena (optim.py): the state-dict entries become views of its flat bf16 buffer, so an
         optimizer step on the arena is what the next forward reads."""
@@ -458,12 +468,28 @@ class To2VTrainer:
             self._blocks = [To2VBlockTrainer(sd, f"transformer_blocks.{i}", self.H, Nt, Np, Fm, self.s, self.eps) for i in range(self.L)]
         hidden, enc = X[:, Nt:N1].contiguous(), torch.cat([X[:, :Nt], X[:, N1:]], dim=1)
         self._ropes = (rope, vrope, crope)
-        self._ckpt = []
-        for blk in self._blocks:
+        # Per-block checkpointing as in the reference (cogvideox_transformer_3d.py:700-719) — except where memory allows otherwise: 80 GB parts
+        # must recompute every block; with 288 GB most blocks can simply KEEP their activations (5 GB per block at batch 2), and only the rest
+        # re-run their forward inside the backward.  `activation_budget_bytes` (None: what the allocator reports free, minus a reserve for the
+        # backward's workspaces) decides how many; 0 = the reference's schedule.
+        self._ckpt, self._kept = [], {}
+        budget, per_block = self._activation_budget(), None
+        for i, blk in enumerate(self._blocks):
             self._ckpt.append((hidden, enc))
-            blk.keep = False
+            blk.keep = budget > 0 and (per_block is None or budget >= per_block)
             hidden, enc = blk.forward(hidden, enc, temb, rope, vrope, crope)
             hidden = hidden.contiguous()
+            if blk.keep:
+                self._kept[i], blk.saved = blk.saved, None
+                if per_block is None:
+                    seen, per_block = set(), 0
+                    for t in self._kept[i].values():
+                        for u in (t if isinstance(t, (tuple, list)) else (t,)):
+                            if torch.is_tensor(u) and u.untyped_storage().data_ptr() not in seen:
+                                seen.add(u.untyped_storage().data_ptr())
+                                per_block += u.untyped_storage().nbytes()
+                budget -= per_block
+        self.blocks_kept = len(self._kept)
         # final norm (per token: only the video rows matter), AdaLayerNorm, proj_out, unpatchify (cogvideox_transformer_3d.py:736-759)
         semb = _act(temb.contiguous())
         tout = self._final_tables(semb, Nv, Fm)
@@ -503,8 +529,11 @@ class To2VTrainer:
         for i in reversed(range(self.L)):
             blk = self._blocks[i]
             hidden, enc = self._ckpt[i]
-            blk.keep = True
-            blk.forward(hidden, enc, S["temb"], rope, vrope, crope)           # recompute with the intermediates kept
+            if i in self._kept:
+                blk.saved = self._kept.pop(i)                                    # activations kept by the forward: nothing to recompute
+            else:
+                blk.keep = True
+                blk.forward(hidden, enc, S["temb"], rope, vrope, crope)       # recompute with the intermediates kept
             g, d_hid, d_enc = blk.backward(d_hid, d_enc)
             blk.saved = None
             g = {f"transformer_blocks.{i}.{k}": v for k, v in g.items()}
