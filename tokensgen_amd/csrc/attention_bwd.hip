@@ -355,6 +355,9 @@ __device__ __forceinline__ uint32_t pack_bf16x2_trans(float lo, float hi) {
 #ifndef TG_BWD_PK
 #define TG_BWD_PK 1
 #endif
+#ifndef TG_BWD_ABL
+#define TG_BWD_ABL 0   // timing-only ablations of the dK/dV kernel (wrong results): 1 no softmax arithmetic, 2 no lse / D reads, 3 no dV / dK MFMAs,
+#endif                 // 4 no global fetch + LDS stage writes (tile 0 re-read), 5 no S | dP MFMAs
 #ifndef TG_BWD_INTERLEAVE
 #define TG_BWD_INTERLEAVE 1
 #endif
@@ -510,20 +513,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(Bwd2Params pp) {
         g3 = *(const uint4*)(doT + (long)drow * pp.ldq + q0 + part);
         gs = statp[min(q0 + (tid & 31), p.nq - 1)];
     };
-    auto stash = [&](int buf) {
-        *(uint4*)(sQ[buf] + row * LQ2 + chunk) = mask16(g0, okr);
-        *(uint4*)(sdO[buf] + row * LQ2 + chunk) = mask16(g1, okr);
-        *(uint4*)(sQt[buf] + drow * LT2 + part) = g2;
-        *(uint4*)(sdOt[buf] + drow * LT2 + part) = g3;
-        if (tid < BT) sLse[buf][tid] = oks ? gs : 1e30f;            // masked query rows: P = exp2(s - 1e30) = 0
-        else if (tid < 2 * BT) sD[buf][tid - BT] = oks ? gs : 0.f;
+    float* const statdst = tid < BT ? &sLse[0][tid] : &sD[0][tid & 31];     // threads >= 64 write D[tid & 31] again with the same value
+    const float statmask = tid < BT ? 1e30f : 0.f;                          // masked query rows: P = exp2(s - 1e30) = 0, D = 0
+    auto stash_part = [&](int k, int buf) {                                 // branch-free pieces, placed between the last MFMAs of a tile
+        if (k == 0) *(uint4*)(sQ[buf] + row * LQ2 + chunk) = mask16(g0, okr);
+        if (k == 1) *(uint4*)(sdO[buf] + row * LQ2 + chunk) = mask16(g1, okr);
+        if (k == 2) *(uint4*)(sQt[buf] + drow * LT2 + part) = g2;
+        if (k == 3) { *(uint4*)(sdOt[buf] + drow * LT2 + part) = g3; statdst[buf * BT] = oks ? gs : statmask; }
     };
+    auto stash = [&](int buf) { for (int k = 0; k < 4; ++k) stash_part(k, buf); };
     fetch(0);
     stash(0);
     __syncthreads();
     for (int it = 0; it < ntile; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < ntile) fetch((it + 1) * BT);
+        const int buf = TG_BWD_ABL == 4 ? 0 : it & 1;
+        if (TG_BWD_ABL != 4) fetch(min(it + 1, ntile - 1) * BT);      // unconditional (the last tile is fetched twice): no branch in the pinned schedule
         bf16x8 aQ[4], aO[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -534,6 +538,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(Bwd2Params pp) {
         f32x4 l4[4], d4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            if (TG_BWD_ABL == 2) { l4[g] = f32x4{1.f, 2.f, 3.f, 4.f}; d4[g] = f32x4{.1f, .2f, .3f, .4f}; continue; }
             l4[g] = *(const f32x4*)(sLse[buf] + 8 * g + 4 * hi);
             d4[g] = *(const f32x4*)(sD[buf] + 8 * g + 4 * hi);
         }
@@ -552,6 +557,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(Bwd2Params pp) {
         // chunk between the dV / dK MFMAs of key block 0;  dV / dK of key block 1.
         const f32x2 sc2 = {p.scale_log2, p.scale_log2};
         auto softmax_chunk = [&](int g, const f32x16& sx, const f32x16& dx, Frag (&pA)[2], Frag (&dA)[2]) {
+            if (TG_BWD_ABL == 1) {
+                pA[g >> 1].w[(g & 1) * 2] = __float_as_uint(sx[4 * g]); pA[g >> 1].w[(g & 1) * 2 + 1] = __float_as_uint(sx[4 * g + 2]);
+                dA[g >> 1].w[(g & 1) * 2] = __float_as_uint(dx[4 * g]); dA[g >> 1].w[(g & 1) * 2 + 1] = __float_as_uint(dx[4 * g + 2]);
+                return;
+            }
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {               // two elements per VALU instruction (v_pk_fma / v_pk_add / v_pk_mul)
                 const f32x2 sv = {sx[4 * g + e], sx[4 * g + e + 1]}, dpv = {dx[4 * g + e], dx[4 * g + e + 1]};
@@ -584,6 +594,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(Bwd2Params pp) {
                     mfma_acc(dk[kb][db], dA0[t].v, bQ[t][db].v);
                 }
         }
+        if (TG_BWD_ABL != 4) stash(buf ^ 1);
 #else
         mfma_pair(s0, dp0, aQ, aO, kf[0], vf[0]);
         TG_SB();
@@ -598,18 +609,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(Bwd2Params pp) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {                       // chunk g of key block 1, then the (k-step g/2, d block g%2) products of key block 0
             softmax_chunk(g, s1, dp1, pA1, dA1); TG_SB();
-            mfma_acc(dv[0][g & 1], pA0[g >> 1].v, bO[g >> 1][g & 1].v);
-            mfma_acc(dk[0][g & 1], dA0[g >> 1].v, bQ[g >> 1][g & 1].v); TG_SB();
+            if (TG_BWD_ABL != 3) {
+                mfma_acc(dv[0][g & 1], pA0[g >> 1].v, bO[g >> 1][g & 1].v);
+                mfma_acc(dk[0][g & 1], dA0[g >> 1].v, bQ[g >> 1][g & 1].v);
+            } else asm volatile("" :: "v"(pA0[g >> 1].v), "v"(dA0[g >> 1].v), "v"(bO[g >> 1][g & 1].v), "v"(bQ[g >> 1][g & 1].v));
+            TG_SB();
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                mfma_acc(dv[1][db], pA1[t].v, bO[t][db].v);
-                mfma_acc(dk[1][db], dA1[t].v, bQ[t][db].v);
+            for (int db = 0; db < 2; ++db) {                // the next tile's LDS stage is written under these last eight MFMAs (buffer buf^1 has had
+                if (TG_BWD_ABL != 3) {                      // no reader since the barrier that ended the previous tile)
+                    mfma_acc(dv[1][db], pA1[t].v, bO[t][db].v);
+                    mfma_acc(dk[1][db], dA1[t].v, bQ[t][db].v);
+                } else asm volatile("" :: "v"(pA1[t].v), "v"(dA1[t].v), "v"(bO[t][db].v), "v"(bQ[t][db].v));
+                TG_SB();
+                if (TG_BWD_ABL != 4) stash_part(t * 2 + db, buf ^ 1);
+                TG_SB();
             }
 #endif
-        if (it + 1 < ntile) stash(buf ^ 1);
         __syncthreads();
     }
     asm volatile("s_nop 15" ::: "memory");             // last asm MFMA's D -> the reads below (8-pass XDL: 12 wait states)

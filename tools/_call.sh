@@ -1,2 +1,4 @@
-timeout 600 python -m pytest tests/test_train_gpu.py -m gpu -x -q 2>&1 | tail -5
-timeout 900 python bench.py --mode train --steps 3 --warmup 1 --accum 3 2>/dev/null | tail -1 | cut -c1-1700
+export TMPDIR=/tmp
+timeout 120 python tools/attn_bwd_check.py 2>&1 | grep "dq"
+(cd /tmp; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_base -o stats -- python $OLDPWD/tools/bench_kernels.py attn_bwd > /dev/null 2>&1)
+echo "dkdv2 $(grep dkdv2 /tmp/p_base/stats_kernel_stats.csv | cut -d, -f4)  dq2 $(grep dq2 /tmp/p_base/stats_kernel_stats.csv | cut -d, -f4)"
