@@ -363,7 +363,9 @@ __device__ __forceinline__ uint32_t pack_bf16x2_trans(float lo, float hi) {
 #endif
 constexpr int BT = 32;                     // rows of the streamed tile
 constexpr int LQ2 = 72;                    // [row][d] tile: row stride in elements (144 B)
-constexpr int LT2 = 40;                    // [d][row] tile: row stride in elements (80 B)
+constexpr int LT2 = 36;                    // [d][row] tile: row stride in elements (72 B = 18 banks: the 32 lanes of an 8-byte read — 32 head columns,
+                                           // one row each — land on 32 distinct bank pairs; 80 B put columns j and j+16 on the same banks: 2-way conflict
+                                           // on every B-operand read).  Rows are 8-byte aligned only: the stage writes them as two 8-byte halves
 constexpr int ROWT_EL = BT * LQ2, COLT_EL = 64 * LT2;
 
 struct Bwd2Params {
@@ -384,6 +386,7 @@ __device__ __forceinline__ uint4 ld_row16_clamped(const bf16_t* base, long ld, i
     return *(const uint4*)(base + (long)min(row, n - 1) * ld + col);
 }
 __device__ __forceinline__ uint4 mask16(uint4 v, bool ok) { return ok ? v : uint4{0, 0, 0, 0}; }
+__device__ __forceinline__ void st_2x8(bf16_t* dst, uint4 v) { ((uint2*)dst)[0] = uint2{v.x, v.y}; ((uint2*)dst)[1] = uint2{v.z, v.w}; }
 
 // ---- (1') statistics: one wave per 64 queries, keys streamed in tiles of 32 ----
 __global__ __launch_bounds__(256) void attn_bwd_stats2_kernel(BwdParams p) {
@@ -518,8 +521,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(Bwd2Params pp) {
     auto stash_part = [&](int k, int buf) {                                 // branch-free pieces, placed between the last MFMAs of a tile
         if (k == 0) *(uint4*)(sQ[buf] + row * LQ2 + chunk) = mask16(g0, okr);
         if (k == 1) *(uint4*)(sdO[buf] + row * LQ2 + chunk) = mask16(g1, okr);
-        if (k == 2) *(uint4*)(sQt[buf] + drow * LT2 + part) = g2;
-        if (k == 3) { *(uint4*)(sdOt[buf] + drow * LT2 + part) = g3; statdst[buf * BT] = oks ? gs : statmask; }
+        if (k == 2) st_2x8(sQt[buf] + drow * LT2 + part, g2);
+        if (k == 3) { st_2x8(sdOt[buf] + drow * LT2 + part, g3); statdst[buf * BT] = oks ? gs : statmask; }
     };
     auto stash = [&](int buf) { for (int k = 0; k < 4; ++k) stash_part(k, buf); };
     fetch(0);
@@ -650,6 +653,125 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(Bwd2Params pp) {
         }
 }
 
+// ---- (2'') dK, dV with TWO waves per SIMD: workgroup = 128 keys (32 per wave), two workgroups per CU ----
+// Same data path as (2'), half the keys per wave: 96 AGPRs (K | V fragments + the 64 accumulators) + ~150 VGPRs fit the 256 registers two
+// co-resident waves may use, so one wave's softmax runs under the other's MFMAs without any hand-placed interleaving.  The price is LDS
+// traffic: every wave still reads the whole Q / dO tile pair, now for 16 MFMAs instead of 32.
+#define TG_WAIT_FRAGS1(f) asm volatile("s_waitcnt vmcnt(0)" : "+a"(f[0]), "+a"(f[1]), "+a"(f[2]), "+a"(f[3]))
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv3_kernel(Bwd2Params pp) {
+    const BwdParams& p = pp.p;
+    __shared__ __attribute__((aligned(16))) bf16_t sQ[2][ROWT_EL], sdO[2][ROWT_EL], sQt[2][COLT_EL], sdOt[2][COLT_EL];
+    __shared__ __attribute__((aligned(16))) float sLse[2][BT], sD[2][BT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y % p.heads, b = blockIdx.y / p.heads;
+    const int kw0 = blockIdx.x * 128 + wave * 32;
+    const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
+    const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
+    const bf16_t* qT = pp.qT + ((long)(b * p.heads + h) * 64) * pp.ldq;
+    const bf16_t* doT = pp.doT + ((long)(b * p.heads + h) * 64) * pp.ldq;
+    const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
+    const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
+    const long stat0 = ((long)b * p.heads + h) * p.nq;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const long r = min(kw0 + j, p.nk - 1);
+        load_frag_agpr(kf[ks], Kp + r * p.k_ld + ks * 16 + hi * 8);
+        load_frag_agpr(vf[ks], Vp + r * p.v_ld + ks * 16 + hi * 8);
+    }
+    TG_WAIT_FRAGS1(kf);
+    TG_WAIT_FRAGS1(vf);
+    f32x16 dk[2], dv[2];                                   // [d block]: rows = keys, column = head dim j
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { dk[c] = zero16(); dv[c] = zero16(); }
+    const int row = tid >> 3, chunk = (tid & 7) * 8;
+    const int drow = tid >> 2, part = (tid & 3) * 8;
+    const int ntile = (p.nq + BT - 1) / BT;
+    uint4 g0, g1, g2, g3;
+    float gs = 0.f;
+    bool okr = false, oks = false;
+    const float* statp = (tid < BT ? p.lse : p.dsum) + stat0;
+    float* const statdst = tid < BT ? &sLse[0][tid] : &sD[0][tid & 31];
+    const float statmask = tid < BT ? 1e30f : 0.f;
+    auto fetch = [&](int q0) {
+        okr = q0 + row < p.nq; oks = q0 + (tid & 31) < p.nq;
+        g0 = ld_row16_clamped(Q, p.q_ld, q0 + row, p.nq, chunk);
+        g1 = ld_row16_clamped(dO, p.do_ld, q0 + row, p.nq, chunk);
+        g2 = *(const uint4*)(qT + (long)drow * pp.ldq + q0 + part);
+        g3 = *(const uint4*)(doT + (long)drow * pp.ldq + q0 + part);
+        gs = statp[min(q0 + (tid & 31), p.nq - 1)];
+    };
+    auto stash = [&](int buf) {
+        *(uint4*)(sQ[buf] + row * LQ2 + chunk) = mask16(g0, okr);
+        *(uint4*)(sdO[buf] + row * LQ2 + chunk) = mask16(g1, okr);
+        st_2x8(sQt[buf] + drow * LT2 + part, g2);
+        st_2x8(sdOt[buf] + drow * LT2 + part, g3);
+        statdst[buf * BT] = oks ? gs : statmask;
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const f32x2 sc2 = {p.scale_log2, p.scale_log2};
+    for (int it = 0; it < ntile; ++it) {
+        const int buf = it & 1;
+        fetch(min(it + 1, ntile - 1) * BT);
+        bf16x8 aQ[4], aO[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            aQ[ks] = *(const bf16x8*)(sQ[buf] + j * LQ2 + ks * 16 + hi * 8);
+            aO[ks] = *(const bf16x8*)(sdO[buf] + j * LQ2 + ks * 16 + hi * 8);
+        }
+        TG_SB();
+        f32x16 s, dp;                                      // rows = queries, column = key j
+        mfma_pair(s, dp, aQ, aO, kf, vf);
+        Frag pA[2], dA[2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 l4 = *(const f32x4*)(sLse[buf] + 8 * g + 4 * hi), d4 = *(const f32x4*)(sD[buf] + 8 * g + 4 * hi);
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const f32x2 sv = {s[4 * g + e], s[4 * g + e + 1]}, dpv = {dp[4 * g + e], dp[4 * g + e + 1]};
+                const f32x2 lv = {l4[e], l4[e + 1]}, dv2 = {d4[e], d4[e + 1]};
+                const f32x2 arg = sv * sc2 - lv;
+                const f32x2 pv = {fast_exp2(arg[0]), fast_exp2(arg[1])};
+                const f32x2 ds = pv * (dpv - dv2);
+                pA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2_trans(pv[0], pv[1]);
+                dA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2(ds[0], ds[1]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int o = (db * 32 + j) * LT2 + 16 * t + 4 * hi;
+                Frag bO, bQ;
+                bO.u[0] = *(const uint2*)(sdOt[buf] + o); bO.u[1] = *(const uint2*)(sdOt[buf] + o + 8);
+                bQ.u[0] = *(const uint2*)(sQt[buf] + o);  bQ.u[1] = *(const uint2*)(sQt[buf] + o + 8);
+                mfma_acc(dv[db], pA[t].v, bO.v);
+                mfma_acc(dk[db], dA[t].v, bQ.v);
+            }
+        stash(buf ^ 1);
+        __syncthreads();
+    }
+    asm volatile("s_nop 15" ::: "memory");
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        float* DK = p.dk + (long)b * p.dk_sb + h * HD + db * 32 + j;
+        float* DV = p.dv + (long)b * p.dv_sb + h * HD + db * 32 + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kw0 + acc_row(r, hi);
+            if (key >= p.nk) continue;
+            float* a = DK + (long)key * p.dk_ld;
+            float* c = DV + (long)key * p.dv_ld;
+            const float vk = dk[db][r] * p.scale, vv = dv[db][r];
+            *a = p.accumulate ? *a + vk : vk;
+            *c = p.accumulate ? *c + vv : vv;
+        }
+    }
+}
+
 // ---- (3') dQ: workgroup = 256 queries (64 per wave), keys streamed in tiles of 32 ----
 __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
     const BwdParams& p = pp.p;
@@ -699,7 +821,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
     auto stash = [&](int buf) {
         *(uint4*)(sK[buf] + row * LQ2 + chunk) = mask16(g0, okr);
         *(uint4*)(sV[buf] + row * LQ2 + chunk) = mask16(g1, okr);
-        *(uint4*)(sKt[buf] + drow * LT2 + part) = g2;
+        st_2x8(sKt[buf] + drow * LT2 + part, g2);
     };
     fetch(0);
     stash(0);
@@ -834,7 +956,9 @@ extern "C" int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void*
     pp.qT = qT; pp.doT = doT; pp.kT = kT; pp.ldq = ldq; pp.ldk = ldk;
     const dim3 gq((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), gk((unsigned)((nk + 255) / 256), (unsigned)(batch * heads));
     hipLaunchKernelGGL(attn_bwd_stats2_kernel, gq, dim3(256), 0, stream, pp.p);
-    hipLaunchKernelGGL(attn_bwd_dkdv2_kernel, gk, dim3(256), 0, stream, pp);
+    static const int dkdv_sel = [] { const char* e = getenv("TG_ATTN_BWD_DKDV"); return e ? atoi(e) : 3; }();   // 2: 64 keys per wave, 1 wave/SIMD; 3: 32 keys, 2 waves/SIMD
+    if (dkdv_sel == 3) hipLaunchKernelGGL(attn_bwd_dkdv3_kernel, dim3((unsigned)((nk + 127) / 128), (unsigned)(batch * heads)), dim3(256), 0, stream, pp);
+    else hipLaunchKernelGGL(attn_bwd_dkdv2_kernel, gk, dim3(256), 0, stream, pp);
     hipLaunchKernelGGL(attn_bwd_dq2_kernel, gq, dim3(256), 0, stream, pp);
     TG_LAUNCH_CHECK("tg_attention_bwd");
     return TG_OK;
