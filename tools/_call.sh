@@ -1,10 +1,7 @@
 export TMPDIR=/tmp
-timeout 120 python tools/attn_bwd_check.py 2>&1 | grep "dq"
-for sel in 3 2; do
-(cd /tmp; rm -rf /tmp/p_$sel; TG_ATTN_BWD_DKDV=$sel timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$sel -o stats -- python $OLDPWD/tools/bench_kernels.py attn_bwd > /dev/null 2>&1)
-python3 -c "
-import csv
-for r in csv.DictReader(open('/tmp/p_$sel/stats_kernel_stats.csv')):
-    if 'attn_bwd' in r['Name']: print('sel $sel', r['Name'][23:50], float(r['AverageNs'])/1e6)
-"
-done
+timeout 900 python bench.py --mode train --steps 9 --warmup 1 > gpurun_out/train_bench.json 2> gpurun_out/train_bench.err; tail -1 gpurun_out/train_bench.json | cut -c1-1900
+R=$PWD; cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_train -o stats -- python $R/bench.py --mode train --steps 2 --warmup 1 --accum 2 > $R/gpurun_out/train_bench_under_rocprof.json 2> $R/gpurun_out/prof_train.err
+rm -rf /tmp/p_ab; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_ab -o stats -- python $R/tools/bench_kernels.py attn_bwd > /dev/null 2>&1; cp /tmp/p_ab/stats_kernel_stats.csv $R/gpurun_out/attn_bwd_kernel_stats.csv
+cd $R; find gpurun_out/prof_train -name "*kernel_trace.csv" -delete
+head -8 gpurun_out/prof_train/stats_kernel_stats.csv | cut -c1-140
