@@ -353,7 +353,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2_trans(float lo, float hi) {
     return r;
 }
 #ifndef TG_BWD_PK
-#define TG_BWD_PK 1
+#define TG_BWD_PK 0   // packed fp32 arithmetic (v_pk_fma / add / mul) measured 3.5 % SLOWER beside the MFMAs than scalar fp32 (18.7 vs 19.3 ms)
 #endif
 #ifndef TG_BWD_ABL
 #define TG_BWD_ABL 0   // timing-only ablations of the dK/dV kernel (wrong results): 1 no softmax arithmetic, 2 no lse / D reads, 3 no dV / dK MFMAs,
@@ -733,9 +733,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv3_kernel(Bwd2Params pp) {
             for (int e = 0; e < 4; e += 2) {
                 const f32x2 sv = {s[4 * g + e], s[4 * g + e + 1]}, dpv = {dp[4 * g + e], dp[4 * g + e + 1]};
                 const f32x2 lv = {l4[e], l4[e + 1]}, dv2 = {d4[e], d4[e + 1]};
+#if TG_BWD_PK
                 const f32x2 arg = sv * sc2 - lv;
                 const f32x2 pv = {fast_exp2(arg[0]), fast_exp2(arg[1])};
                 const f32x2 ds = pv * (dpv - dv2);
+#else
+                const f32x2 pv = {fast_exp2(sv[0] * p.scale_log2 - lv[0]), fast_exp2(sv[1] * p.scale_log2 - lv[1])};
+                const f32x2 ds = {pv[0] * (dpv[0] - dv2[0]), pv[1] * (dpv[1] - dv2[1])};
+#endif
                 pA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2_trans(pv[0], pv[1]);
                 dA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2(ds[0], ds[1]);
             }

@@ -149,8 +149,8 @@ class GradSync:
         self._next, self._work = 0, []
 
     def ready(self, end):
-        if self.world == 1:
-            return
+        if not self.dist.is_initialized():
+            return                                   # single process without a process group: nothing to exchange
         while self._next < len(self.bounds) and self.bounds[self._next][1] <= end:
             lo, hi = self.bounds[self._next]
             self._work.append(self.dist.all_reduce(self.flat[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -1,7 +1,3 @@
-export TMPDIR=/tmp
-timeout 900 python bench.py --mode train --steps 9 --warmup 1 > gpurun_out/train_bench.json 2> gpurun_out/train_bench.err; tail -1 gpurun_out/train_bench.json | cut -c1-1900
-R=$PWD; cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_train -o stats -- python $R/bench.py --mode train --steps 2 --warmup 1 --accum 2 > $R/gpurun_out/train_bench_under_rocprof.json 2> $R/gpurun_out/prof_train.err
-rm -rf /tmp/p_ab; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_ab -o stats -- python $R/tools/bench_kernels.py attn_bwd > /dev/null 2>&1; cp /tmp/p_ab/stats_kernel_stats.csv $R/gpurun_out/attn_bwd_kernel_stats.csv
-cd $R; find gpurun_out/prof_train -name "*kernel_trace.csv" -delete
-head -8 gpurun_out/prof_train/stats_kernel_stats.csv | cut -c1-140
+timeout 300 python -m pytest tests/test_train_gpu.py -m gpu -x -q 2>&1 | tail -3
+# one rank under torch.distributed.run: the RCCL gradient buckets of the training step (init, async all-reduce of arena slices, wait) on a real process group
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --mode train --layers 2 --steps 2 --warmup 1 --accum 2 2>&1 | tail -2 | cut -c1-600
