@@ -264,3 +264,21 @@ def test_vae_param_shapes_match_the_diffusers_layout():
                 dict(block_out_channels=(64, 128), layers_per_block=1, latent_channels=16)):
         vae = AutoencoderKLCogVideoX(block_out_channels=cfg["block_out_channels"], layers_per_block=cfg["layers_per_block"], device="cpu")
         assert vae.param_shapes() == {k: tuple(v.shape) for k, v in V.make_state_dict(cfg).items()}
+
+
+def test_stratified_timestep_sampling_per_rank():
+    """train_cogvideo_to2v.py:1797-1813 (`use_explicit_uniform_sampling`): rank r draws from its own stratum, rank 0 also covers the remainder."""
+    import torch
+    from tokensgen_amd.train import sample_timesteps
+    g = torch.Generator().manual_seed(0)
+    for world in (1, 3, 8):
+        interval, shift = 1000 // world, 1000 % (1000 // world)
+        seen = []
+        for r in range(world):
+            t = sample_timesteps(4096, 1000, r, world, explicit_uniform=True, generator=g)
+            lo, hi = (0, interval + shift) if r == 0 else (r * interval + shift, (r + 1) * interval + shift)
+            assert t.dtype == torch.int64 and int(t.min()) >= lo and int(t.max()) < hi
+            seen.append((int(t.min()), int(t.max())))
+        assert seen[0][0] == 0 and seen[-1][1] == 999            # 4096 draws per stratum of <= 1000 values: the ends are hit
+    t = sample_timesteps(8192, 1000, 5, 8, explicit_uniform=False, generator=g)
+    assert int(t.min()) == 0 and int(t.max()) == 999

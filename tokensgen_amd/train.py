@@ -412,6 +412,13 @@ class To2VTrainer:
         free += torch.cuda.memory_reserved() - torch.cuda.memory_allocated()      # cached blocks of the allocator are reusable
         return max(0, free - self.activation_reserve_bytes)
 
+    def save_vip_layers(self, vip_ckpt_dir):
+        """The reference's save hook for the transformer's trained part (cogvideox_transformer_3d.py:624-634 via train_cogvideo_to2v.py:1346-1390):
+        `<dir>/vip.pt` = {name: fp32 CPU tensor} for every parameter whose name contains "vip_" — what `set_vip_layers(dir, ...)` loads (§A)."""
+        import os
+        os.makedirs(vip_ckpt_dir, exist_ok=True)
+        torch.save({n: self.sd[n].detach().to("cpu").to(torch.float32) for n in self.trainable}, os.path.join(vip_ckpt_dir, "vip.pt"))
+
     def use_arena(self, arena):
         """Move the trainable parameters into a ParamArena (optim.py): the state-dict entries become views of its flat bf16 buffer, so an
         optimizer step on the arena is what the next forward reads."""
@@ -641,6 +648,10 @@ class ResamplerTrainer:
         for n in self.names:
             self.sd[n] = arena.views[self.prefix + n]
 
+    def state_dict(self):
+        """Reference key names -> current (trained) tensors: `Resampler.load_state_dict(...)` + `save_pretrained(dir)` write the `resampler/` folder."""
+        return {n: self.sd[n] for n in self.names}
+
     @torch.no_grad()
     def forward(self, x, image_rotary_emb=None, sampling_rotary_emb=None):
         sd, H = self.sd, self.H
@@ -752,3 +763,16 @@ class ResamplerTrainer:
         dW, db, _ = linear_backward(f2(ctx["xin"]), f2(d_xp.to(BF16)), None)
         grads["proj_in.weight"], grads["proj_in.bias"] = dW, db
         return {self.prefix + k: v for k, v in grads.items()}
+
+
+def sample_timesteps(batch_size, num_train_timesteps=1000, process_index=0, num_processes=1, explicit_uniform=False, generator=None):
+    """train_cogvideo_to2v.py:1797-1818: one timestep per batch item; with `use_explicit_uniform_sampling` every rank draws from its own
+    stratum [r*interval + shift, (r+1)*interval + shift) (rank 0 also covers the remainder [0, shift)), so that one optimizer step sees the whole
+    noise range.  Host logic (int64 on the CPU)."""
+    if explicit_uniform:
+        interval = num_train_timesteps // num_processes
+        shift = num_train_timesteps % interval
+        lo, hi = (0, interval + shift) if process_index == 0 else (process_index * interval + shift, (process_index + 1) * interval + shift)
+    else:
+        lo, hi = 0, num_train_timesteps
+    return torch.randint(lo, hi, (batch_size,), generator=generator).long()
