@@ -866,6 +866,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv4_kernel(Bwd2Params pp) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 l4 = *(const f32x4*)(sLse[buf] + 8 * g + 4 * hi), d4 = *(const f32x4*)(sD[buf] + 8 * g + 4 * hi);
+            if (TG_BWD_ABL == 1) {
+                pA[g >> 1].w[(g & 1) * 2] = __float_as_uint(s[4 * g] + l4[0]); pA[g >> 1].w[(g & 1) * 2 + 1] = __float_as_uint(s[4 * g + 2]);
+                dA[g >> 1].w[(g & 1) * 2] = __float_as_uint(dp[4 * g] + d4[0]); dA[g >> 1].w[(g & 1) * 2 + 1] = __float_as_uint(dp[4 * g + 2]);
+                continue;
+            }
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {
                 const f32x2 pv = {fast_exp2(s[4 * g + e] * p.scale_log2 - l4[e]), fast_exp2(s[4 * g + e + 1] * p.scale_log2 - l4[e + 1])};
@@ -889,6 +894,151 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv4_kernel(Bwd2Params pp) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
+                if (TG_BWD_ABL == 3) { asm volatile("" :: "v"(pA[t].v), "v"(dA[t].v), "v"(bO[t][db].v), "v"(bQ[t][db].v)); continue; }
+                mfma_acc(dv[db], pA[t].v, bO[t][db].v);
+                mfma_acc(dk[db], dA[t].v, bQ[t][db].v);
+            }
+        if (TG_BWD_PRIO) __builtin_amdgcn_s_setprio(0);
+        TG_SB();
+        stash(sbuf);                                       // buffer of tile it-1: no reader since the barrier that ended the previous iteration
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { aQ[ks] = nQ[ks]; aO[ks] = nO[ks]; }
+        buf = nbuf;
+    }
+    asm volatile("s_nop 15" ::: "memory");
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        float* DK = p.dk + (long)b * p.dk_sb + h * HD + db * 32 + j;
+        float* DV = p.dv + (long)b * p.dv_sb + h * HD + db * 32 + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kw0 + acc_row(r, hi);
+            if (key >= p.nk) continue;
+            float* a = DK + (long)key * p.dk_ld;
+            float* c = DV + (long)key * p.dv_ld;
+            const float vk = dk[db][r] * p.scale, vv = dv[db][r];
+            *a = p.accumulate ? *a + vk : vk;
+            *c = p.accumulate ? *c + vv : vv;
+        }
+    }
+}
+
+// ---- (2'''') the same with ONE 512-thread workgroup per CU (8 waves x 32 keys = 256 keys): the two waves of a SIMD now share one tile stage, which
+// halves the global bytes per MFMA — with two 4-wave workgroups per CU the kernel sat at the ~11 B/clk/CU every CU gets when all 256 stream at once ----
+__global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
+    const BwdParams& p = pp.p;
+    __shared__ __attribute__((aligned(16))) bf16_t sQ[3][ROWT_EL], sdO[3][ROWT_EL], sQt[3][COLT_EL], sdOt[3][COLT_EL];
+    __shared__ __attribute__((aligned(16))) float sLse[3][BT], sD[3][BT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y % p.heads, b = blockIdx.y / p.heads;
+    const int kw0 = blockIdx.x * 256 + wave * 32;
+    const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
+    const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
+    const bf16_t* qT = pp.qT + ((long)(b * p.heads + h) * 64) * pp.ldq;
+    const bf16_t* doT = pp.doT + ((long)(b * p.heads + h) * 64) * pp.ldq;
+    const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
+    const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
+    const long stat0 = ((long)b * p.heads + h) * p.nq;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const long r = min(kw0 + j, p.nk - 1);
+        load_frag_agpr(kf[ks], Kp + r * p.k_ld + ks * 16 + hi * 8);
+        load_frag_agpr(vf[ks], Vp + r * p.v_ld + ks * 16 + hi * 8);
+    }
+    TG_WAIT_FRAGS1(kf);
+    TG_WAIT_FRAGS1(vf);
+    f32x16 dk[2], dv[2];                                   // [d block]: rows = keys, column = head dim j
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { dk[c] = zero16(); dv[c] = zero16(); }
+    const int half = tid >> 8, t8 = tid & 255;              // threads 0..255 stage Q and Q^T, 256..511 dO and dO^T
+    const int row = t8 >> 3, chunk = (t8 & 7) * 8;
+    const int drow = t8 >> 2, part = (t8 & 3) * 8;
+    const bf16_t* const srcR = half ? dO : Q;
+    const bf16_t* const srcT = half ? doT : qT;
+    const long ldR = half ? p.do_ld : p.q_ld;
+    const int ntile = (p.nq + BT - 1) / BT;
+    uint4 g0, g2;
+    float gs = 0.f;
+    bool okr = false, oks = false;
+    const float* statp = (tid < BT ? p.lse : p.dsum) + stat0;
+    float* const statdst = tid < BT ? &sLse[0][tid] : &sD[0][tid & 31];
+    const float statmask = tid < BT ? 1e30f : 0.f;
+    auto fetch = [&](int q0) {
+        okr = q0 + row < p.nq; oks = q0 + (tid & 31) < p.nq;
+        g0 = ld_row16_clamped(srcR, ldR, q0 + row, p.nq, chunk);
+        g2 = *(const uint4*)(srcT + (long)drow * pp.ldq + q0 + part);
+        gs = statp[min(q0 + (tid & 31), p.nq - 1)];
+    };
+    auto stash = [&](int buf) {
+        *(uint4*)((half ? sdO[buf] : sQ[buf]) + row * LQ2 + chunk) = mask16(g0, okr);
+        st_2x8((half ? sdOt[buf] : sQt[buf]) + drow * LT2 + part, g2);
+        if (tid < 2 * BT) statdst[buf * BT] = oks ? gs : statmask;
+    };
+    fetch(0);
+    stash(0);
+    fetch(min(1, ntile - 1) * BT);
+    stash(1);
+    __syncthreads();
+    const f32x2 sc2 = {p.scale_log2, p.scale_log2};
+    (void)sc2;
+    bf16x8 aQ[4], aO[4];                                   // A operands of the CURRENT tile: read from LDS one tile ahead (below)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        aQ[ks] = *(const bf16x8*)(sQ[0] + j * LQ2 + ks * 16 + hi * 8);
+        aO[ks] = *(const bf16x8*)(sdO[0] + j * LQ2 + ks * 16 + hi * 8);
+    }
+    int buf = 0;
+    for (int it = 0; it < ntile; ++it) {
+        const int nbuf = buf == 2 ? 0 : buf + 1, sbuf = nbuf == 2 ? 0 : nbuf + 1;     // tile it+1 (staged last iteration), tile it+2 (staged now)
+        fetch(min(it + 2, ntile - 1) * BT);
+        f32x16 s, dp;                                      // rows = queries, column = key j
+        if (TG_BWD_PRIO) __builtin_amdgcn_s_setprio(3);    // a wave in an MFMA block wins the issue port: the partner's softmax fills what is left
+        mfma_pair(s, dp, aQ, aO, kf, vf);
+        if (TG_BWD_PRIO) __builtin_amdgcn_s_setprio(0);
+        TG_SB();
+        bf16x8 nQ[4], nO[4];                               // next tile's A operands: their LDS latency hides under this tile's softmax + MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            nQ[ks] = *(const bf16x8*)(sQ[nbuf] + j * LQ2 + ks * 16 + hi * 8);
+            nO[ks] = *(const bf16x8*)(sdO[nbuf] + j * LQ2 + ks * 16 + hi * 8);
+        }
+        TG_SB();
+        Frag pA[2], dA[2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 l4 = *(const f32x4*)(sLse[buf] + 8 * g + 4 * hi), d4 = *(const f32x4*)(sD[buf] + 8 * g + 4 * hi);
+            if (TG_BWD_ABL == 1) {
+                pA[g >> 1].w[(g & 1) * 2] = __float_as_uint(s[4 * g] + l4[0]); pA[g >> 1].w[(g & 1) * 2 + 1] = __float_as_uint(s[4 * g + 2]);
+                dA[g >> 1].w[(g & 1) * 2] = __float_as_uint(dp[4 * g] + d4[0]); dA[g >> 1].w[(g & 1) * 2 + 1] = __float_as_uint(dp[4 * g + 2]);
+                continue;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const f32x2 pv = {fast_exp2(s[4 * g + e] * p.scale_log2 - l4[e]), fast_exp2(s[4 * g + e + 1] * p.scale_log2 - l4[e + 1])};
+                const f32x2 ds = {pv[0] * (dp[4 * g + e] - d4[e]), pv[1] * (dp[4 * g + e + 1] - d4[e + 1])};
+                pA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2_trans(pv[0], pv[1]);
+                dA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2(ds[0], ds[1]);
+            }
+        }
+        Frag bO[2][2], bQ[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int o = (db * 32 + j) * LT2 + 16 * t + 4 * hi;
+                bO[t][db].u[0] = *(const uint2*)(sdOt[buf] + o); bO[t][db].u[1] = *(const uint2*)(sdOt[buf] + o + 8);
+                bQ[t][db].u[0] = *(const uint2*)(sQt[buf] + o);  bQ[t][db].u[1] = *(const uint2*)(sQt[buf] + o + 8);
+            }
+        TG_SB();
+        if (TG_BWD_PRIO) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                if (TG_BWD_ABL == 3) { asm volatile("" :: "v"(pA[t].v), "v"(dA[t].v), "v"(bO[t][db].v), "v"(bQ[t][db].v)); continue; }
                 mfma_acc(dv[db], pA[t].v, bO[t][db].v);
                 mfma_acc(dk[db], dA[t].v, bQ[t][db].v);
             }
@@ -1102,8 +1252,9 @@ extern "C" int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void*
     pp.qT = qT; pp.doT = doT; pp.kT = kT; pp.ldq = ldq; pp.ldk = ldk;
     const dim3 gq((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), gk((unsigned)((nk + 255) / 256), (unsigned)(batch * heads));
     hipLaunchKernelGGL(attn_bwd_stats2_kernel, gq, dim3(256), 0, stream, pp.p);
-    static const int dkdv_sel = [] { const char* e = getenv("TG_ATTN_BWD_DKDV"); return e ? atoi(e) : 4; }();   // 2: 64 keys per wave, 1 wave/SIMD; 3: 32 keys, 2 waves/SIMD; 4: 3 + three-deep LDS ring
-    if (dkdv_sel == 4) hipLaunchKernelGGL(attn_bwd_dkdv4_kernel, dim3((unsigned)((nk + 127) / 128), (unsigned)(batch * heads)), dim3(256), 0, stream, pp);
+    static const int dkdv_sel = [] { const char* e = getenv("TG_ATTN_BWD_DKDV"); return e ? atoi(e) : 5; }();   // 2: 64 keys per wave, 1 wave/SIMD; 3: 32 keys, 2 waves/SIMD; 4: 3 + three-deep LDS ring; 5: 4 as one 8-wave workgroup
+    if (dkdv_sel == 5) hipLaunchKernelGGL(attn_bwd_dkdv5_kernel, gk, dim3(512), 0, stream, pp);
+    else if (dkdv_sel == 4) hipLaunchKernelGGL(attn_bwd_dkdv4_kernel, dim3((unsigned)((nk + 127) / 128), (unsigned)(batch * heads)), dim3(256), 0, stream, pp);
     else if (dkdv_sel == 3) hipLaunchKernelGGL(attn_bwd_dkdv3_kernel, dim3((unsigned)((nk + 127) / 128), (unsigned)(batch * heads)), dim3(256), 0, stream, pp);
     else hipLaunchKernelGGL(attn_bwd_dkdv2_kernel, gk, dim3(256), 0, stream, pp);
     hipLaunchKernelGGL(attn_bwd_dq2_kernel, gq, dim3(256), 0, stream, pp);
