@@ -257,15 +257,19 @@ long tg_colsum_partial_floats(int rows, int cols);
 
 /* Backward of tg_adaln_modulate (y = ln (1 + scale[g]) + shift[g], ln = bf16(x_hat gamma + beta); normalization.py:441-460, 477-488): dx (bf16) and the
  * per-element products whose column sums are the parameter gradients — t_dln = dy (1 + scale) [-> d beta], t_dlnx = t_dln x_hat [-> d gamma],
- * t_dyln = dy ln [-> d scale[g] over the rows of group g]; d shift[g] = column sums of dy.  t_*: fp32 [batch*tokens][dim], caller-allocated. */
+ * t_dyln = dy ln [-> d scale[g] over the rows of group g]; d shift[g] = column sums of dy.  t_*: fp32 [batch*tokens][dim], caller-allocated, or all
+ * three NULL where the norm's parameters are frozen (text / video rows).  add (optional, bf16, laid out like dx): the gradient arriving over the
+ * residual connection; dx = bf16(bf16(norm gradient) + add) — the sum autograd forms on bf16 tensors. */
 int tg_adaln_modulate_bwd(const void* x, long ldx, long strideX, const void* dy, long ld_dy, long stride_dy, void* dx, long ld_dx, long stride_dx,
                           const void* ln_weight, const void* ln_bias, float eps, int tokens, int dim, int batch, int modulate,
-                          const tg_group_table* g, float* t_dln, float* t_dlnx, float* t_dyln, hipStream_t stream);
+                          const tg_group_table* g, float* t_dln, float* t_dlnx, float* t_dyln, const void* add, long ld_add, long stride_add,
+                          hipStream_t stream);
 
 /* Backward of the gated residual out = res + gate[g] y (cogvideox_transformer_3d.py:290-293, 318-324): dy = gate[g] dout (bf16), t_dgate = dout y (fp32
- * [batch*tokens][dim]; column sums over a group's rows = d gate[g]); d res = dout. */
+ * [batch][tokens - t_row0][dim], written for the token rows >= t_row0 only — the group whose gate trains; column sums over a group's rows =
+ * d gate[g]); d res = dout. */
 int tg_gate_residual_bwd(const void* dout, long ld_dout, long stride_dout, const void* y, long ldy, long strideY, void* dy, long ld_dy, long stride_dy,
-                         int tokens, int dim, int batch, const tg_group_table* gate, float* t_dgate, hipStream_t stream);
+                         int tokens, int dim, int batch, const tg_group_table* gate, float* t_dgate, int t_row0, hipStream_t stream);
 
 /* Elementwise: mode 0 out = silu(x); mode 1 out = dy * gelu_tanh'(x) (the FeedForward activation's derivative). bf16, n elements. */
 int tg_act(const void* x, const void* dy, void* out, long n, int mode, hipStream_t stream);

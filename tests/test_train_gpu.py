@@ -266,6 +266,13 @@ def test_adaln_gate_and_activation_backward_kernels_vs_autograd():
     dyk, tgate = train._gate_res_bwd(dout.to(DEV), yv.to(DEV), table)
     assert _rel(dyk, yf.grad) < 4e-3
     assert _rel(train._colsum_f32(tgate.view(B, T, D)[0, :8]), mg.grad[0, 0, 5 * D:6 * D]) < 1e-5
+    dyk2, tg_tail = train._gate_res_bwd(dout.to(DEV), yv.to(DEV), table, row0=24)        # products only for the trailing rows (the vip group in the block)
+    assert torch.equal(dyk2, dyk) and tg_tail.shape == (B, T - 24, D) and torch.equal(tg_tail, tgate.view(B, T, D)[:, 24:])
+    # the frozen-norm form: no products, the residual gradient summed in the same pass (bf16 + bf16 like autograd on bf16 tensors)
+    res = _rand(B, T, D, seed=80)
+    dx2 = torch.empty(B, T, D, dtype=BF, device=DEV)
+    none3 = train._adaln_bwd(x.to(DEV), dy.to(DEV), dx2, w.to(DEV), bvec.to(DEV), 1e-5, table, products=False, add=res.to(DEV))
+    assert none3 == [None, None, None] and torch.equal(dx2, (dx.float() + res.to(DEV).float()).to(BF))
     # activations
     v = _rand(3000, seed=78, scale=2.0)
     g_ = _rand(3000, seed=79)

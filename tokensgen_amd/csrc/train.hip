@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void adaln_bwd_kernel(const bf16_t* __restrict
                                                         bf16_t* __restrict__ dx, long ldo, long sob, const bf16_t* __restrict__ w,
                                                         const bf16_t* __restrict__ bvec, float eps, int tokens, int dim, int batch, int modulate,
                                                         tg_group_table g, float* __restrict__ t_dln, float* __restrict__ t_dlnx,
-                                                        float* __restrict__ t_dyln) {
+                                                        float* __restrict__ t_dyln, const bf16_t* __restrict__ add, long lda, long sab) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (long)tokens * batch) return;
@@ -168,16 +168,22 @@ __global__ __launch_bounds__(256) void adaln_bwd_kernel(const bf16_t* __restrict
         const float ln = round_bf16(xh * gam + bet);
         const float d = bf16_to_f32(dr[c]);
         const float dln = d * (1.f + (scale ? bf16_to_f32(scale[c]) : 0.f));
-        const long o = row * dim + c;
-        t_dln[o] = dln; t_dlnx[o] = dln * xh; t_dyln[o] = d * ln;
+        if (t_dln) {                                       // the products are wanted only where the norm's parameters train (the vip rows)
+            const long o = row * dim + c;
+            t_dln[o] = dln; t_dlnx[o] = dln * xh; t_dyln[o] = d * ln;
+        }
         const float dxh = dln * gam;
         m1 += dxh; m2 += dxh * xh;
     }
     m1 = wave_sum(m1) / dim; m2 = wave_sum(m2) / dim;
+    const bf16_t* ar = add ? add + (long)b * sab + (long)t * lda : nullptr;
     for (int c = lane; c < dim; c += 64) {
         const float xh = (bf16_to_f32(xr[c]) - mean) * rstd;
-        const float dxh = t_dln[row * dim + c] * (w ? bf16_to_f32(w[c]) : 1.f);
-        outr[c] = f32_to_bf16(rstd * (dxh - m1 - xh * m2));
+        const float dln = bf16_to_f32(dr[c]) * (1.f + (scale ? bf16_to_f32(scale[c]) : 0.f));
+        const float dxh = dln * (w ? bf16_to_f32(w[c]) : 1.f);
+        float v = rstd * (dxh - m1 - xh * m2);
+        if (ar) v = round_bf16(v) + bf16_to_f32(ar[c]);     // + the gradient arriving over the residual connection (both bf16 tensors in the reference)
+        outr[c] = f32_to_bf16(v);
     }
 }
 
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(256) void adaln_bwd_kernel(const bf16_t* __restrict
 // t_dgate = dout * y (fp32; its column sums over the rows of group g are d gate[g]);  d res = dout.
 __global__ __launch_bounds__(256) void gate_res_bwd_kernel(const bf16_t* __restrict__ dout, long ldd, long sdb, const bf16_t* __restrict__ y, long ldy,
                                                            long syb, bf16_t* __restrict__ dyo, long ldo, long sob, int tokens, int dim, int batch,
-                                                           tg_group_table g, float* __restrict__ t_dgate) {
+                                                           tg_group_table g, float* __restrict__ t_dgate, int t_row0) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)batch * tokens * dim;
     if (i >= total) return;
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) void gate_res_bwd_kernel(const bf16_t* __restr
     const float gate = bf16_to_f32(((const bf16_t*)g.mod)[(long)b * g.mod_batch_stride + (long)g.row[gi] * g.mod_ld + g.gate_col[gi] + c]);
     const float d = bf16_to_f32(dout[(long)b * sdb + (long)t * ldd + c]);
     dyo[(long)b * sob + (long)t * ldo + c] = f32_to_bf16(gate * d);
-    t_dgate[i] = d * bf16_to_f32(y[(long)b * syb + (long)t * ldy + c]);
+    if (t >= t_row0) t_dgate[((long)b * (tokens - t_row0) + (t - t_row0)) * dim + c] = d * bf16_to_f32(y[(long)b * syb + (long)t * ldy + c]);
 }
 
 // mode 0: y = silu(x);  mode 1: dx = dy * gelu_tanh'(x)  (F.gelu(approximate="tanh"), diffusers FeedForward)
@@ -267,25 +273,28 @@ extern "C" int tg_colsum(const void* src, long ld, int rows, int cols, float* pa
 
 extern "C" int tg_adaln_modulate_bwd(const void* x, long ldx, long strideX, const void* dy, long ld_dy, long stride_dy, void* dx, long ld_dx, long stride_dx,
                                      const void* ln_weight, const void* ln_bias, float eps, int tokens, int dim, int batch, int modulate,
-                                     const tg_group_table* g, float* t_dln, float* t_dlnx, float* t_dyln, hipStream_t stream) {
-    TG_REQUIRE(x && dy && dx && t_dln && t_dlnx && t_dyln, TG_ERR_ARG, "tg_adaln_modulate_bwd: null pointer");
+                                     const tg_group_table* g, float* t_dln, float* t_dlnx, float* t_dyln, const void* add, long ld_add, long stride_add,
+                                     hipStream_t stream) {
+    TG_REQUIRE(x && dy && dx, TG_ERR_ARG, "tg_adaln_modulate_bwd: null pointer");
+    TG_REQUIRE((t_dln && t_dlnx && t_dyln) || (!t_dln && !t_dlnx && !t_dyln), TG_ERR_ARG, "tg_adaln_modulate_bwd: give all three product tensors or none");
     TG_REQUIRE(tokens > 0 && dim > 0 && batch > 0 && (!modulate || g), TG_ERR_SHAPE, "tg_adaln_modulate_bwd: bad shape");
     tg_group_table gt{};
     if (g) gt = *g;
     const long rows = (long)tokens * batch;
     hipLaunchKernelGGL(adaln_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, strideX, (const bf16_t*)dy, ld_dy, stride_dy,
-                       (bf16_t*)dx, ld_dx, stride_dx, (const bf16_t*)ln_weight, (const bf16_t*)ln_bias, eps, tokens, dim, batch, modulate, gt, t_dln, t_dlnx, t_dyln);
+                       (bf16_t*)dx, ld_dx, stride_dx, (const bf16_t*)ln_weight, (const bf16_t*)ln_bias, eps, tokens, dim, batch, modulate, gt, t_dln, t_dlnx, t_dyln,
+                       (const bf16_t*)add, ld_add, stride_add);
     TG_LAUNCH_CHECK("tg_adaln_modulate_bwd");
     return TG_OK;
 }
 
 extern "C" int tg_gate_residual_bwd(const void* dout, long ld_dout, long stride_dout, const void* y, long ldy, long strideY, void* dy, long ld_dy, long stride_dy,
-                                    int tokens, int dim, int batch, const tg_group_table* gate, float* t_dgate, hipStream_t stream) {
+                                    int tokens, int dim, int batch, const tg_group_table* gate, float* t_dgate, int t_row0, hipStream_t stream) {
     TG_REQUIRE(dout && y && dy && gate && t_dgate, TG_ERR_ARG, "tg_gate_residual_bwd: null pointer");
-    TG_REQUIRE(tokens > 0 && dim > 0 && batch > 0, TG_ERR_SHAPE, "tg_gate_residual_bwd: bad shape");
+    TG_REQUIRE(tokens > 0 && dim > 0 && batch > 0 && t_row0 >= 0 && t_row0 < tokens, TG_ERR_SHAPE, "tg_gate_residual_bwd: bad shape");
     const long total = (long)batch * tokens * dim;
     hipLaunchKernelGGL(gate_res_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)dout, ld_dout, stride_dout, (const bf16_t*)y,
-                       ldy, strideY, (bf16_t*)dy, ld_dy, stride_dy, tokens, dim, batch, *gate, t_dgate);
+                       ldy, strideY, (bf16_t*)dy, ld_dy, stride_dy, tokens, dim, batch, *gate, t_dgate, t_row0);
     TG_LAUNCH_CHECK("tg_gate_residual_bwd");
     return TG_OK;
 }

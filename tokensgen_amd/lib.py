@@ -36,8 +36,8 @@ PROTOTYPES = {
     "tg_qk_layernorm_rope_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _vp, _f, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _vp, _vp],
     "tg_transpose_2d": [_vp, _l, _i, _i, _vp, _l, _i, _vp],
     "tg_colsum": [_vp, _l, _i, _i, _vp, _vp],
-    "tg_adaln_modulate_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _vp, _f, _i, _i, _i, _i, C.POINTER(GroupTable), _vp, _vp, _vp, _vp],
-    "tg_gate_residual_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, C.POINTER(GroupTable), _vp, _vp],
+    "tg_adaln_modulate_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _vp, _f, _i, _i, _i, _i, C.POINTER(GroupTable), _vp, _vp, _vp, _vp, _l, _l, _vp],
+    "tg_gate_residual_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, C.POINTER(GroupTable), _vp, _i, _vp],
     "tg_act": [_vp, _vp, _vp, _l, _i, _vp],
     "tg_colsum_f32": [_vp, _l, _i, _i, _vp, _vp],
     "tg_grad_accumulate": [_vp, _i, _vp, _l, _f, _i, _vp],

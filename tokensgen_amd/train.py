@@ -190,25 +190,30 @@ def _act(x, dy=None):
     return out
 
 
-def _adaln_bwd(x, dy, dx, w, b, eps, table):
-    """tg_adaln_modulate_bwd on [B, T, D] views; returns the three fp32 product tensors [B*T, D]."""
+def _adaln_bwd(x, dy, dx, w, b, eps, table, products=True, add=None):
+    """tg_adaln_modulate_bwd on [B, T, D] views.  products: also return the three fp32 product tensors [B*T, D] (wanted only where the norm's
+    parameters train); add: the gradient arriving over the residual connection (bf16, like dx), summed into dx in the same pass."""
     B, T, D, ldx, sx = K._bmk(x)
     _, _, _, ldd, sd_ = K._bmk(dy)
     _, _, _, ldo, so = K._bmk(dx)
-    t = [torch.empty(B * T, D, dtype=torch.float32, device=x.device) for _ in range(3)]
+    lda = sa = 0
+    if add is not None:
+        _, _, _, lda, sa = K._bmk(add)
+    t = [torch.empty(B * T, D, dtype=torch.float32, device=x.device) for _ in range(3)] if products else [None, None, None]
     L.check(L.load().tg_adaln_modulate_bwd(x.data_ptr(), ldx, sx, dy.data_ptr(), ldd, sd_, dx.data_ptr(), ldo, so, K._p(w), K._p(b), float(eps), T, D, B,
-                                           1 if table is not None else 0, table.ref() if table is not None else None, t[0].data_ptr(), t[1].data_ptr(),
-                                           t[2].data_ptr(), K._stream()), "tg_adaln_modulate_bwd")
+                                           1 if table is not None else 0, table.ref() if table is not None else None, K._p(t[0]), K._p(t[1]), K._p(t[2]),
+                                           K._p(add), lda, sa, K._stream()), "tg_adaln_modulate_bwd")
     return t
 
 
-def _gate_res_bwd(dout, y, table):
+def _gate_res_bwd(dout, y, table, row0=0):
+    """dy = gate[g] * dout (bf16 [B, T, D]) and t_dgate = dout * y for the token rows >= row0 (fp32 [B, T - row0, D])."""
     B, T, D, ldd, sd_ = K._bmk(dout)
     _, _, _, ldy, sy = K._bmk(y)
     dy = torch.empty(B, T, D, dtype=BF16, device=dout.device)
-    tg = torch.empty(B * T, D, dtype=torch.float32, device=dout.device)
+    tg = torch.empty(B, T - row0, D, dtype=torch.float32, device=dout.device)
     L.check(L.load().tg_gate_residual_bwd(dout.data_ptr(), ldd, sd_, y.data_ptr(), ldy, sy, dy.data_ptr(), dy.stride(1), dy.stride(0), T, D, B, table.ref(),
-                                          tg.data_ptr(), K._stream()), "tg_gate_residual_bwd")
+                                          tg.data_ptr(), int(row0), K._stream()), "tg_gate_residual_bwd")
     return dy, tg
 
 
@@ -324,11 +329,12 @@ class To2VBlockTrainer:
         return X2[:, Nt:N1], torch.cat([X2[:, :Nt], X2[:, N1:]], dim=1)
 
     def _vip_norm_grads(self, which, t_dln, t_dlnx, t_dyln, dxn, t_dgate, grads):
-        """vip_norm{which}: LayerNorm affine from the vip rows' products; the modulation linear from d(shift | scale | gate) of the vip group."""
+        """vip_norm{which}: LayerNorm affine from the vip rows' products ([B * Np, D] each); the modulation linear from d(shift | scale | gate) of the
+        vip group."""
         S = self.saved
         B, Nv, D, N1, N = S["dims"]
         Np = N - N1
-        rows = lambda t, b: t.view(B, N, D)[b, N1:]
+        rows = lambda t, b: t.view(B, Np, D)[b]
         name = f"vip_norm{which}"
         grads[f"{name}.norm.weight"] = sum(_colsum_f32(rows(t_dlnx, b)) for b in range(B))
         grads[f"{name}.norm.bias"] = sum(_colsum_f32(rows(t_dln, b)) for b in range(B))
@@ -347,19 +353,20 @@ class To2VBlockTrainer:
         grads = {}
         dX2 = torch.cat([d_enc[:, :Nt], d_hidden, d_enc[:, Nt:]], dim=1).to(BF16).contiguous()
         # ---- feed-forward residual (step 7), FeedForward, norm2 ----
-        dy_ff, tg2 = _gate_res_bwd(dX2, S["y_ff"], S["t2"])
+        dy_ff, tg2 = _gate_res_bwd(dX2, S["y_ff"], S["t2"], row0=N1)          # gate products only for the vip rows (the group whose gate trains)
         Fw1, Fw2 = sd[f"{pre}.ff.net.0.proj.weight"], sd[f"{pre}.ff.net.2.weight"]
         dhid = _dgrad(dy_ff.view(B * N, D), Fw2)
         dpre = _act(S["ffpre"].view(B * N, -1), dhid)
         dXn2 = _dgrad(dpre, Fw1).view(B, N, D)
         dX1 = torch.empty(B, N, D, dtype=BF16, device=dX2.device)
-        ta = _adaln_bwd(S["X1"][:, :N1], dXn2[:, :N1], dX1[:, :N1], sd[f"{pre}.norm2.norm.weight"], sd[f"{pre}.norm2.norm.bias"], self.eps, S["t2"])
-        tb = _adaln_bwd(S["X1"][:, N1:], dXn2[:, N1:], dX1[:, N1:], sd[f"{pre}.vip_norm2.norm.weight"], sd[f"{pre}.vip_norm2.norm.bias"], self.eps, S["t2"].offset(N1))
-        full = lambda a, b_: torch.cat([a.view(B, N1, D), b_.view(B, N - N1, D)], dim=1).reshape(B * N, D)
-        self._vip_norm_grads(2, full(ta[0], tb[0]), full(ta[1], tb[1]), full(ta[2], tb[2]), dXn2, tg2, grads)
-        dX1 = (dX1.float() + dX2.float()).to(BF16)                                   # residual: X2 = X1 + gate * FF(norm2(X1))
+        # norm2 is frozen on the text / video rows (no parameter products); `add`: X2 = X1 + gate * FF(norm2(X1)) also hands dX2 straight to X1
+        _adaln_bwd(S["X1"][:, :N1], dXn2[:, :N1], dX1[:, :N1], sd[f"{pre}.norm2.norm.weight"], sd[f"{pre}.norm2.norm.bias"], self.eps, S["t2"], products=False,
+                   add=dX2[:, :N1])
+        tb = _adaln_bwd(S["X1"][:, N1:], dXn2[:, N1:], dX1[:, N1:], sd[f"{pre}.vip_norm2.norm.weight"], sd[f"{pre}.vip_norm2.norm.bias"], self.eps, S["t2"].offset(N1),
+                        add=dX2[:, N1:])
+        self._vip_norm_grads(2, tb[0], tb[1], tb[2], dXn2, tg2, grads)
         # ---- attention residual (step 5), to_out ----
-        dy_attn, tg1 = _gate_res_bwd(dX1, S["y_attn"], S["t1"])
+        dy_attn, tg1 = _gate_res_bwd(dX1, S["y_attn"], S["t1"], row0=N1)
         dAO = _dgrad(dy_attn.view(B * N, D), sd[A + "to_out.0.weight"]).view(B, N, D)
         # ---- the three attention calls, QK-norm + RoPE, projections ----
         ga = to2v_attention_backward(S["q"], S["k"], S["v"], S["qx"], S["kx"], S["vx"], S["qv"], S["kv"], S["vv"], S["o1"], S["o2"], S["o3"], dAO, H, 1.0 / 8.0, self.s, lse=S["lse"])
@@ -375,10 +382,11 @@ class To2VBlockTrainer:
         dXn = dXn.to(BF16)
         # ---- norm1 ----
         dX0 = torch.empty(B, N, D, dtype=BF16, device=dX2.device)
-        ta = _adaln_bwd(S["X0"][:, :N1], dXn[:, :N1], dX0[:, :N1], sd[f"{pre}.norm1.norm.weight"], sd[f"{pre}.norm1.norm.bias"], self.eps, S["t1"])
-        tb = _adaln_bwd(S["X0"][:, N1:], dXn[:, N1:], dX0[:, N1:], sd[f"{pre}.vip_norm1.norm.weight"], sd[f"{pre}.vip_norm1.norm.bias"], self.eps, S["t1"].offset(N1))
-        self._vip_norm_grads(1, full(ta[0], tb[0]), full(ta[1], tb[1]), full(ta[2], tb[2]), dXn, tg1, grads)
-        dX0 = (dX0.float() + dX1.float()).to(BF16)
+        _adaln_bwd(S["X0"][:, :N1], dXn[:, :N1], dX0[:, :N1], sd[f"{pre}.norm1.norm.weight"], sd[f"{pre}.norm1.norm.bias"], self.eps, S["t1"], products=False,
+                   add=dX1[:, :N1])
+        tb = _adaln_bwd(S["X0"][:, N1:], dXn[:, N1:], dX0[:, N1:], sd[f"{pre}.vip_norm1.norm.weight"], sd[f"{pre}.vip_norm1.norm.bias"], self.eps, S["t1"].offset(N1),
+                        add=dX1[:, N1:])
+        self._vip_norm_grads(1, tb[0], tb[1], tb[2], dXn, tg1, grads)
         return grads, dX0[:, Nt:N1], torch.cat([dX0[:, :Nt], dX0[:, N1:]], dim=1)
 
 
@@ -528,8 +536,8 @@ class To2VTrainer:
         K.patchify(d_out.to(BF16).reshape(B * Fr, -1, Hh, Ww).contiguous(), d_po, self.ps)
         d_vid2 = _dgrad(d_po, sd["proj_out.weight"]).view(B, Nv, D)
         d_vidn, d_hid = torch.empty(B, Nv, D, dtype=BF16, device=dev), torch.empty(B, Nv, D, dtype=BF16, device=dev)
-        _adaln_bwd(S["vidn"], d_vid2, d_vidn, sd["norm_out.norm.weight"], sd["norm_out.norm.bias"], self.eps, S["tout"])
-        _adaln_bwd(S["hidden_L"], d_vidn, d_hid, sd["norm_final.weight"], sd["norm_final.bias"], self.eps, None)
+        _adaln_bwd(S["vidn"], d_vid2, d_vidn, sd["norm_out.norm.weight"], sd["norm_out.norm.bias"], self.eps, S["tout"], products=False)
+        _adaln_bwd(S["hidden_L"], d_vidn, d_hid, sd["norm_final.weight"], sd["norm_final.bias"], self.eps, None, products=False)
         d_enc = torch.zeros(B, Nt + Np, D, dtype=BF16, device=dev)
         grads = {}
         rope, vrope, crope = self._ropes
