@@ -223,7 +223,8 @@ int tg_attention_fwd_lse(const void* q, long q_ld, long q_strideB, const void* k
  *   P = softmax(scale q k^T)   dV = P^T dO   dP = dO v^T   dS = P o (dP - rowsum(dO o O))   dQ = scale dS k   dK = scale dS^T q
  * q, o, dout: bf16 [batch][nq][heads*64] views (row stride *_ld, batch stride *_sb; head h occupies columns 64h..64h+63);
  * k, v: likewise with nk rows (v row-major here, not the transposed image of the forward).  dq / dk / dv: fp32, same indexing;
- * accumulate != 0 adds to what is there (the To2V processor's three attention calls share K / V tensors: their gradients sum).
+ * accumulate: 0 overwrite; 1 (= 3) add to what is there in all three; 2 add into dk / dv only, overwrite dq (the To2V processor's three attention
+ * calls share K / V tensors — their gradients sum — but not queries).
  * ws: 16-byte aligned fp32 workspace of tg_attention_bwd_ws_floats(nq, nk, heads, batch) floats (row log-sum-exp, rowsum(dO o O), and the
  * transposed bf16 copies Q^T, dO^T, K^T the kernels' [d][row] tiles are loaded from).
  * P is recomputed from the log-sum-exp tile by tile; three launches (statistics, dK/dV per 256-key workgroup, dQ per 256-query workgroup) behind

@@ -217,8 +217,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(BwdParams p) {
         float* a = DK + (long)key * p.dk_ld;
         float* c = DV + (long)key * p.dv_ld;
         const float vk = dk[r] * p.scale, vv = dv[r];
-        *a = p.accumulate ? *a + vk : vk;
-        *c = p.accumulate ? *c + vv : vv;
+        *a = (p.accumulate & 2) ? *a + vk : vk;
+        *c = (p.accumulate & 2) ? *c + vv : vv;
     }
 }
 
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdParams p) {
         if (q >= p.nq) continue;
         float* a = DQ + (long)q * p.dq_ld;
         const float vq = dq[r] * p.scale;
-        *a = p.accumulate ? *a + vq : vq;
+        *a = (p.accumulate & 1) ? *a + vq : vq;
     }
 }
 
@@ -650,8 +650,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(Bwd2Params pp) {
                 float* a = DK + (long)key * p.dk_ld;
                 float* c = DV + (long)key * p.dv_ld;
                 const float vk = dk[kb][db][r] * p.scale, vv = dv[kb][db][r];
-                *a = p.accumulate ? *a + vk : vk;
-                *c = p.accumulate ? *c + vv : vv;
+                *a = (p.accumulate & 2) ? *a + vk : vk;
+                *c = (p.accumulate & 2) ? *c + vv : vv;
             }
         }
 }
@@ -774,8 +774,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv3_kernel(Bwd2Params pp) {
             float* a = DK + (long)key * p.dk_ld;
             float* c = DV + (long)key * p.dv_ld;
             const float vk = dk[db][r] * p.scale, vv = dv[db][r];
-            *a = p.accumulate ? *a + vk : vk;
-            *c = p.accumulate ? *c + vv : vv;
+            *a = (p.accumulate & 2) ? *a + vk : vk;
+            *c = (p.accumulate & 2) ? *c + vv : vv;
         }
     }
 }
@@ -918,8 +918,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv4_kernel(Bwd2Params pp) {
             float* a = DK + (long)key * p.dk_ld;
             float* c = DV + (long)key * p.dv_ld;
             const float vk = dk[db][r] * p.scale, vv = dv[db][r];
-            *a = p.accumulate ? *a + vk : vk;
-            *c = p.accumulate ? *c + vv : vv;
+            *a = (p.accumulate & 2) ? *a + vk : vk;
+            *c = (p.accumulate & 2) ? *c + vv : vv;
         }
     }
 }
@@ -1062,8 +1062,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
             float* a = DK + (long)key * p.dk_ld;
             float* c = DV + (long)key * p.dv_ld;
             const float vk = dk[db][r] * p.scale, vv = dv[db][r];
-            *a = p.accumulate ? *a + vk : vk;
-            *c = p.accumulate ? *c + vv : vv;
+            *a = (p.accumulate & 2) ? *a + vk : vk;
+            *c = (p.accumulate & 2) ? *c + vv : vv;
         }
     }
 }
@@ -1182,7 +1182,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
                 if (q >= p.nq) continue;
                 float* a = DQ + (long)q * p.dq_ld;
                 const float vq = dq[qb][db][r] * p.scale;
-                *a = p.accumulate ? *a + vq : vq;
+                *a = (p.accumulate & 1) ? *a + vq : vq;
             }
         }
 }
@@ -1227,6 +1227,7 @@ extern "C" int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void*
                                  const void* o, long o_ld, long o_sb, const void* dout, long do_ld, long do_sb,
                                  float* dq, long dq_ld, long dq_sb, float* dk, long dk_ld, long dk_sb, float* dv, long dv_ld, long dv_sb,
                                  int nq, int nk, int heads, int batch, float scale, int accumulate, const float* lse, float* ws, hipStream_t stream) {
+    accumulate = accumulate == 1 ? 3 : (accumulate & 3);      // bit 0: dq, bit 1: dk and dv; 1 = all three (the original meaning of the flag)
     static const bool v1 = [] { const char* e = getenv("TG_ATTN_BWD_V1"); return e && e[0] == '1'; }();
     if (v1) return attention_bwd_v1(q, q_ld, q_sb, k, k_ld, k_sb, v, v_ld, v_sb, o, o_ld, o_sb, dout, do_ld, do_sb, dq, dq_ld, dq_sb, dk, dk_ld, dk_sb,
                                     dv, dv_ld, dv_sb, nq, nk, heads, batch, scale, accumulate, ws, stream);

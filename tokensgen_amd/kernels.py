@@ -270,14 +270,15 @@ def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, acc
     _, _, _, gld, gsb = _bmk(dout)
     assert HD == heads * 64 and o.shape == q.shape == dout.shape and v.shape == k.shape
     f32 = torch.float32
-    new = torch.zeros if accumulate else torch.empty       # accumulate adds to the buffer: a fresh one must start at zero
+    acc = 3 if accumulate is True else int(accumulate)     # True: all three; 2: dk / dv only (dq overwritten); 0 / False: overwrite
+    new = torch.zeros if acc else torch.empty              # accumulate adds to the buffer: a fresh one must start at zero
     dq = new(B, nq, HD, dtype=f32, device=q.device) if dq is None else _chk(dq, "dq", f32)
     dk = new(B, nk, HD, dtype=f32, device=q.device) if dk is None else _chk(dk, "dk", f32)
     dv = new(B, nk, HD, dtype=f32, device=q.device) if dv is None else _chk(dv, "dv", f32)
     ws = torch.empty(L.load().tg_attention_bwd_ws_floats(nq, nk, heads, B), dtype=f32, device=q.device)
     L.check(_launch("attention_bwd", L.load().tg_attention_bwd, _p(q), qld, qsb, _p(k), kld, ksb, _p(v), vld, vsb, _p(o), old, osb, _p(dout), gld, gsb,
                     _p(dq), dq.stride(1), dq.stride(0), _p(dk), dk.stride(1), dk.stride(0), _p(dv), dv.stride(1), dv.stride(0), nq, nk, heads, B,
-                    float(scale), 1 if accumulate else 0, _p(lse), _p(ws), _stream()), "tg_attention_bwd")
+                    float(scale), acc, _p(lse), _p(ws), _stream()), "tg_attention_bwd")
     return dq, dk, dv
 
 

@@ -39,23 +39,28 @@ def vpred_loss_and_grad(model_output, noisy_model_input, model_input, timesteps,
 
 
 @torch.no_grad()
-def to2v_attention_backward(q, k, v, qx, kx, vx, qv, kv, vv, o1, o2, o3, d_out, heads, sm_scale, vip_scale, lse=(None, None, None)):
+def to2v_attention_backward(q, k, v, qx, kx, vx, qv, kv, vv, o1, o2, o3, d_out, heads, sm_scale, vip_scale, lse=(None, None, None), kcat=None, vcat=None):
     """Backward of `cat(sdpa(q, k, v) + vip_scale * sdpa(qx, kv, vv), sdpa(qv, cat(kx, kv), cat(vx, vv)))` (attention_processor.py:2066-2135):
     q..vv are the post-norm / post-RoPE projections [B, n, heads*64] (bf16), o1/o2/o3 the three attention outputs saved by the forward,
-    d_out [B, N1 + Np, heads*64] the gradient of the concatenated result.  Returns fp32 gradients keyed like the inputs.  kv / vv receive
-    the sum of two calls' gradients (accumulate).  lse: the three calls' log-sum-exps from K.attention_lse (optional)."""
+    d_out [B, N1 + Np, heads*64] the gradient of the concatenated result.  Returns fp32 gradients keyed like the inputs (views of three combined
+    tensors q_all / k_all / v_all over the rows text+video | vip of the vip-weight projection).  kv / vv receive the sum of two calls' gradients.
+    lse: the three calls' log-sum-exps from K.attention_lse (optional); kcat / vcat: cat(kx, kv) / cat(vx, vv) as views when the caller has them
+    (the fused projection buffer), else they are concatenated here."""
     N1, Np = q.shape[1], qv.shape[1]
     f32 = torch.float32
+    B, HD = q.shape[0], q.shape[2]
     g1 = d_out[:, :N1]
     dq, dk, dv = K.attention_bwd(q, k, v, o1, g1, heads, sm_scale, lse=lse[0])
+    dq_all = torch.empty(B, N1 + Np, HD, dtype=f32, device=q.device)
+    dk_all, dv_all = torch.empty_like(dq_all), torch.empty_like(dq_all)
+    kcat = torch.cat([kx, kv], 1) if kcat is None else kcat
+    vcat = torch.cat([vx, vv], 1) if vcat is None else vcat
+    # call 3 first: it writes EVERY row of dk_all / dv_all; call 2 then adds its share into the vip rows (accumulate = 2: dk / dv only)
+    K.attention_bwd(qv, kcat, vcat, o3, d_out[:, N1:], heads, sm_scale, dq=dq_all[:, N1:], dk=dk_all, dv=dv_all, lse=lse[2])
     g2 = (g1.float() * float(vip_scale)).to(BF16)          # `scale * O2` is a bf16 tensor in the forward
-    dqx, dkv, dvv = K.attention_bwd(qx, kv, vv, o2, g2, heads, sm_scale, lse=lse[1])
-    B, HD = q.shape[0], q.shape[2]
-    dkc = torch.zeros(B, N1 + Np, HD, dtype=f32, device=q.device)
-    dvc = torch.zeros_like(dkc)
-    dkc[:, N1:], dvc[:, N1:] = dkv, dvv
-    dqv, _, _ = K.attention_bwd(qv, torch.cat([kx, kv], 1), torch.cat([vx, vv], 1), o3, d_out[:, N1:], heads, sm_scale, dk=dkc, dv=dvc, accumulate=True, lse=lse[2])
-    return dict(q=dq, k=dk, v=dv, qx=dqx, kx=dkc[:, :N1], vx=dvc[:, :N1], qv=dqv, kv=dkc[:, N1:], vv=dvc[:, N1:])
+    K.attention_bwd(qx, kv, vv, o2, g2, heads, sm_scale, dq=dq_all[:, :N1], dk=dk_all[:, N1:], dv=dv_all[:, N1:], accumulate=2, lse=lse[1])
+    return dict(q=dq, k=dk, v=dv, qx=dq_all[:, :N1], kx=dk_all[:, :N1], vx=dv_all[:, :N1], qv=dq_all[:, N1:], kv=dk_all[:, N1:], vv=dv_all[:, N1:],
+                q_all=dq_all, k_all=dk_all, v_all=dv_all)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -112,8 +117,16 @@ def linear_backward(x2d, dy2d, weight=None, need_dx=False):
     return dW, db, dx
 
 
-def linear_backward_dx(dy2d, weight):
-    """dx = dy W only (frozen layers): [M, out] x [out, in] -> [M, in] bf16."""
+def linear_backward_dx(dy2d, weight, accumulate_into=None, ones=None):
+    """dx = dy W only (frozen layers): [M, out] x [out, in] -> [M, in] bf16.  accumulate_into ([B, T, in] bf16 view) + ones (a unit-gate GroupTable):
+    dy is [B, T, out] and dx is ADDED to the view through the GEMM's gated-residual epilogue (in place, no separate pass)."""
+    if accumulate_into is not None:
+        cout, cin = weight.shape
+        assert cin % 128 == 0 and cout % 64 == 0 and dy2d.dim() == 3
+        wT = torch.empty(cin, cout, dtype=BF16, device=dy2d.device)
+        L.check(L.load().tg_transpose_2d(weight.data_ptr(), weight.stride(0), cout, cin, wT.data_ptr(), cout, cout, K._stream()), "tg_transpose_2d")
+        K.gemm(dy2d, wT, None, accumulate_into, L.EPI_BIAS_GATE_RES, residual=accumulate_into, gate=ones)
+        return accumulate_into
     M, cout = dy2d.shape
     cin = weight.shape[1]
     cin_p, cout_p = _pad_to(cin, 128), _pad_to(cout, 64)
@@ -125,9 +138,10 @@ def linear_backward_dx(dy2d, weight):
     return dxp[:, :cin]
 
 
-def qk_layernorm_rope_backward(x_pre, dy, heads, ln_weight, eps, seg0=None, seg1=None, out_scale=1.0):
+def qk_layernorm_rope_backward(x_pre, dy, heads, ln_weight, eps, seg0=None, seg1=None, out_scale=1.0, out=None):
     """Backward of kernels.qk_layernorm_rope.  x_pre: the PRE-norm projection [B, T, heads*64] bf16 (a column slice of the fused QKV buffer
-    is fine); dy fp32 [B, T, heads*64].  Returns (dx bf16 contiguous, dgamma fp32 [64], dbeta fp32 [64])."""
+    is fine); dy fp32 [B, T, heads*64].  Returns (dx bf16 — `out` when given, e.g. a column slice of the fused d(QKV) buffer — dgamma fp32 [64],
+    dbeta fp32 [64])."""
     K._chk(x_pre, "x_pre"); K._chk(dy, "dy", torch.float32)
     B, T, HD, ld, sb = K._bmk(x_pre)
     assert HD == heads * 64 and dy.shape == x_pre.shape
@@ -139,7 +153,8 @@ def qk_layernorm_rope_backward(x_pre, dy, heads, ln_weight, eps, seg0=None, seg1
         return int(start), int(cos.shape[0]), cos, sin
     s0, l0, c0, n0 = unpack(seg0)
     s1, l1, c1, n1 = unpack(seg1)
-    dx = torch.empty(B, T, HD, dtype=BF16, device=x_pre.device)
+    dx = torch.empty(B, T, HD, dtype=BF16, device=x_pre.device) if out is None else K._chk(out, "out")
+    assert dx.shape == x_pre.shape
     lib = L.load()
     part = torch.empty(lib.tg_qk_layernorm_rope_bwd_partial_floats(T, heads, B), dtype=torch.float32, device=x_pre.device)
     L.check(lib.tg_qk_layernorm_rope_bwd(x_pre.data_ptr(), ld, sb, dy.data_ptr(), dy.stride(1), dy.stride(0), dx.data_ptr(), dx.stride(1), dx.stride(0),
@@ -156,14 +171,16 @@ def vip_projection_backward(xn_all, qkvv_pre, grads, heads, Nt, N1, vip_norm_q_w
     (before vip_norm_q / vip_norm_k and RoPE); grads: to2v_attention_backward(...) (fp32, UNSCALED keys: the training forward keeps the softmax
     scale in the attention call).  Returns dict: vip_to_{q,k,v}.{weight,bias}, vip_norm_{q,k}.{weight,bias}."""
     B, N, D = xn_all.shape
-    f32 = torch.float32
-    dq = torch.cat([grads["qx"], grads["qv"]], dim=1).contiguous()            # rows: text+video (x-branch) | vip tokens
-    dk = torch.cat([grads["kx"], grads["kv"]], dim=1).contiguous()
-    dv = torch.cat([grads["vx"], grads["vv"]], dim=1)
+    cat = lambda a, b_: torch.cat([grads[a], grads[b_]], dim=1).contiguous()
+    dq = grads["q_all"] if "q_all" in grads else cat("qx", "qv")             # rows: text+video (x-branch) | vip tokens
+    dk = grads["k_all"] if "k_all" in grads else cat("kx", "kv")
+    dv = grads["v_all"] if "v_all" in grads else cat("vx", "vv")
     segs = ((Nt, vip_rope), (N1, cond_rope))
-    dq_pre, dgq, dbq = qk_layernorm_rope_backward(qkvv_pre[:, :, :D], dq, heads, vip_norm_q_w, 1e-6, *segs)
-    dk_pre, dgk, dbk = qk_layernorm_rope_backward(qkvv_pre[:, :, D:2 * D], dk, heads, vip_norm_k_w, 1e-6, *segs)
-    d_pre = torch.cat([dq_pre, dk_pre, dv.to(BF16)], dim=2).view(B * N, 3 * D)
+    d_pre3 = torch.empty(B, N, 3 * D, dtype=BF16, device=xn_all.device)     # d(fused vip projection output): q | k | v column thirds, written in place
+    _, dgq, dbq = qk_layernorm_rope_backward(qkvv_pre[:, :, :D], dq, heads, vip_norm_q_w, 1e-6, *segs, out=d_pre3[:, :, :D])
+    _, dgk, dbk = qk_layernorm_rope_backward(qkvv_pre[:, :, D:2 * D], dk, heads, vip_norm_k_w, 1e-6, *segs, out=d_pre3[:, :, D:2 * D])
+    d_pre3[:, :, 2 * D:] = dv
+    d_pre = d_pre3.view(B * N, 3 * D)
     dW, db, _ = linear_backward(xn_all.reshape(B * N, D), d_pre)
     out = {}
     for j, n in enumerate(("q", "k", "v")):
@@ -263,18 +280,26 @@ class To2VBlockTrainer:
 
     @torch.no_grad()
     def forward(self, hidden, enc, temb, rope, vrope, crope):
+        """Reference block interface (hidden = video rows, enc = text | vip rows); the trainer chains blocks on the joint stream (forward_x)."""
+        Nt, N1 = self.Nt, self.Nt + hidden.shape[1]
+        X2 = self.forward_x(torch.cat([enc[:, :Nt], hidden, enc[:, Nt:]], dim=1).contiguous(), temb, rope, vrope, crope)
+        return X2[:, Nt:N1], torch.cat([X2[:, :Nt], X2[:, N1:]], dim=1)
+
+    @torch.no_grad()
+    def forward_x(self, X0, temb, rope, vrope, crope):
+        """X0 [B, Nt + Nv + Np, D]: the residual stream in the row order text | video | vip.  Returns the block's output stream (same layout)."""
         sd, pre, H, Nt, Np = self.sd, self.pre, self.H, self.Nt, self.Np
-        B, Nv, D = hidden.shape
+        B, N, D = X0.shape
+        Nv = N - Nt - Np
         self.D = D
-        N1, N = Nt + Nv, Nt + Nv + Np
-        dev = hidden.device
+        N1 = Nt + Nv
+        dev = X0.device
         e = lambda *s: torch.empty(*s, dtype=BF16, device=dev)
         hw = Nv // self.F
         tg = torch.empty(N, dtype=torch.uint8)
         tg[:Nt], tg[Nt:N1], tg[N1:] = self.F, (torch.arange(Nv) // hw).to(torch.uint8), self.F + 1
         self.tok_group = tg.to(dev)
         S = self.saved = {}
-        X0 = torch.cat([enc[:, :Nt], hidden, enc[:, Nt:]], dim=1).contiguous()
         emb = _act(temb.contiguous())
         mod1, t1 = self._mod(emb, 1)
         Xn = e(B, N, D)
@@ -323,10 +348,11 @@ class To2VBlockTrainer:
         K.gemm(ffh, Fw2, Fb2, X2, L.EPI_BIAS_GATE_RES, residual=X1, gate=t2)
         if not self.keep:
             self.saved = None
-            return X2[:, Nt:N1], torch.cat([X2[:, :Nt], X2[:, N1:]], dim=1)
+            return X2
         S.update(X0=X0, X1=X1, Xn=Xn, Xn2=Xn2, emb=emb, t1=t1, t2=t2, mod1=mod1, mod2=mod2, qkv_pre=qkv_pre, qkvv_pre=qkvv_pre, q=q, k=k, v=v, qx=qx, kx=kx,
-                 vx=vx, qv=qv, kv=kv, vv=vv, o1=o1, o2=o2, o3=o3, lse=(lse1, lse2, lse3), y_attn=y_attn, y_ff=y_ff, ffpre=ffpre, rope=rope, vrope=vrope, crope=crope, dims=(B, Nv, D, N1, N))
-        return X2[:, Nt:N1], torch.cat([X2[:, :Nt], X2[:, N1:]], dim=1)
+                 vx=vx, qv=qv, kv=kv, vv=vv, o1=o1, o2=o2, o3=o3, lse=(lse1, lse2, lse3), y_attn=y_attn, y_ff=y_ff, ffpre=ffpre, rope=rope, vrope=vrope, crope=crope, dims=(B, Nv, D, N1, N),
+                 kcat=qkvv[:, :, D:2 * D], vcat=qkvv[:, :, 2 * D:])
+        return X2
 
     def _vip_norm_grads(self, which, t_dln, t_dlnx, t_dyln, dxn, t_dgate, grads):
         """vip_norm{which}: LayerNorm affine from the vip rows' products ([B * Np, D] each); the modulation linear from d(shift | scale | gate) of the
@@ -346,12 +372,25 @@ class To2VBlockTrainer:
     def backward(self, d_hidden, d_enc):
         """d_hidden [B, Nv, D], d_enc [B, Nt + Np, D] (bf16): gradients of the loss w.r.t. the block's two outputs.  Returns (grads: dict of the
         trainable parameters under their names relative to the block, d_hidden_in, d_enc_in)."""
+        Nt, N1 = self.Nt, self.Nt + d_hidden.shape[1]
+        grads, dX0 = self.backward_x(torch.cat([d_enc[:, :Nt], d_hidden, d_enc[:, Nt:]], dim=1).to(BF16).contiguous())
+        return grads, dX0[:, Nt:N1], torch.cat([dX0[:, :Nt], dX0[:, N1:]], dim=1)
+
+    def _ones(self, tokens, width, batch, dev):
+        key = (tokens, width, batch)
+        if getattr(self, "_ones_key", None) != key:
+            self._ones_key = key
+            self._ones_t = (torch.ones(1, 1, width, dtype=BF16, device=dev), torch.zeros(max(tokens, 1024), dtype=torch.uint8, device=dev))
+        return K.GroupTable(self._ones_t[0].expand(batch, 1, -1), self._ones_t[1], [0], [0], [0], [0])
+
+    @torch.no_grad()
+    def backward_x(self, dX2):
+        """dX2 [B, N, D] bf16: gradient w.r.t. the block's output stream (rows text | video | vip).  Returns (grads, dX0)."""
         sd, pre, H, Nt = self.sd, self.pre, self.H, self.Nt
         S = self.saved
         B, Nv, D, N1, N = S["dims"]
         A = f"{pre}.attn1."
         grads = {}
-        dX2 = torch.cat([d_enc[:, :Nt], d_hidden, d_enc[:, Nt:]], dim=1).to(BF16).contiguous()
         # ---- feed-forward residual (step 7), FeedForward, norm2 ----
         dy_ff, tg2 = _gate_res_bwd(dX2, S["y_ff"], S["t2"], row0=N1)          # gate products only for the vip rows (the group whose gate trains)
         Fw1, Fw2 = sd[f"{pre}.ff.net.0.proj.weight"], sd[f"{pre}.ff.net.2.weight"]
@@ -369,17 +408,23 @@ class To2VBlockTrainer:
         dy_attn, tg1 = _gate_res_bwd(dX1, S["y_attn"], S["t1"], row0=N1)
         dAO = _dgrad(dy_attn.view(B * N, D), sd[A + "to_out.0.weight"]).view(B, N, D)
         # ---- the three attention calls, QK-norm + RoPE, projections ----
-        ga = to2v_attention_backward(S["q"], S["k"], S["v"], S["qx"], S["kx"], S["vx"], S["qv"], S["kv"], S["vv"], S["o1"], S["o2"], S["o3"], dAO, H, 1.0 / 8.0, self.s, lse=S["lse"])
+        ga = to2v_attention_backward(S["q"], S["k"], S["v"], S["qx"], S["kx"], S["vx"], S["qv"], S["kv"], S["vv"], S["o1"], S["o2"], S["o3"], dAO, H, 1.0 / 8.0, self.s, lse=S["lse"],
+                                     kcat=S["kcat"], vcat=S["vcat"])
         pg, d_pre_v = vip_projection_backward(S["Xn"], S["qkvv_pre"], ga, H, Nt, N1, sd[A + "processor.vip_norm_q.weight"], sd[A + "processor.vip_norm_k.weight"],
                                               S["vrope"], S["crope"], return_dpre=True)
         for kname, val in pg.items():
             grads["attn1.processor." + kname] = val
-        dq_pre, _, _ = qk_layernorm_rope_backward(S["qkv_pre"][:, :, :D], ga["q"].contiguous(), H, sd[A + "norm_q.weight"], 1e-6, (Nt, S["rope"]))
-        dk_pre, _, _ = qk_layernorm_rope_backward(S["qkv_pre"][:, :, D:2 * D], ga["k"].contiguous(), H, sd[A + "norm_k.weight"], 1e-6, (Nt, S["rope"]))
-        d_pre_b = torch.cat([dq_pre, dk_pre, ga["v"].to(BF16)], dim=2)
-        dXn = _dgrad(d_pre_v.view(B * N, 3 * D), self.Wv).view(B, N, D).float()
-        dXn[:, :N1] += _dgrad(d_pre_b.reshape(B * N1, 3 * D), self.Wqkv).view(B, N1, D).float()
-        dXn = dXn.to(BF16)
+        d_pre_b = torch.empty(B, N1, 3 * D, dtype=BF16, device=dX2.device)       # d(fused base projection output), written third by third
+        qk_layernorm_rope_backward(S["qkv_pre"][:, :, :D], ga["q"], H, sd[A + "norm_q.weight"], 1e-6, (Nt, S["rope"]), out=d_pre_b[:, :, :D])
+        qk_layernorm_rope_backward(S["qkv_pre"][:, :, D:2 * D], ga["k"], H, sd[A + "norm_k.weight"], 1e-6, (Nt, S["rope"]), out=d_pre_b[:, :, D:2 * D])
+        d_pre_b[:, :, 2 * D:] = ga["v"]
+        dXn = _dgrad(d_pre_v.view(B * N, 3 * D), self.Wv).view(B, N, D)
+        if dXn.is_contiguous() and D % 128 == 0:     # the base projection's share lands on the text + video rows through the GEMM's residual epilogue
+            linear_backward_dx(d_pre_b, self.Wqkv, accumulate_into=dXn[:, :N1], ones=self._ones(N1, D, B, dX2.device))
+        else:
+            dXn = dXn.float()
+            dXn[:, :N1] += _dgrad(d_pre_b.reshape(B * N1, 3 * D), self.Wqkv).view(B, N1, D).float()
+            dXn = dXn.to(BF16)
         # ---- norm1 ----
         dX0 = torch.empty(B, N, D, dtype=BF16, device=dX2.device)
         _adaln_bwd(S["X0"][:, :N1], dXn[:, :N1], dX0[:, :N1], sd[f"{pre}.norm1.norm.weight"], sd[f"{pre}.norm1.norm.bias"], self.eps, S["t1"], products=False,
@@ -387,7 +432,7 @@ class To2VBlockTrainer:
         tb = _adaln_bwd(S["X0"][:, N1:], dXn[:, N1:], dX0[:, N1:], sd[f"{pre}.vip_norm1.norm.weight"], sd[f"{pre}.vip_norm1.norm.bias"], self.eps, S["t1"].offset(N1),
                         add=dX1[:, N1:])
         self._vip_norm_grads(1, tb[0], tb[1], tb[2], dXn, tg1, grads)
-        return grads, dX0[:, Nt:N1], torch.cat([dX0[:, :Nt], dX0[:, N1:]], dim=1)
+        return grads, dX0
 
 
 def _dgrad(dy2d, weight):
@@ -481,7 +526,6 @@ class To2VTrainer:
         N1 = Nt + Nv
         if self._blocks is None or self._blocks[0].Nt != Nt or self._blocks[0].Np != Np or self._blocks[0].F != Fm:
             self._blocks = [To2VBlockTrainer(sd, f"transformer_blocks.{i}", self.H, Nt, Np, Fm, self.s, self.eps) for i in range(self.L)]
-        hidden, enc = X[:, Nt:N1].contiguous(), torch.cat([X[:, :Nt], X[:, N1:]], dim=1)
         self._ropes = (rope, vrope, crope)
         # Per-block checkpointing as in the reference (cogvideox_transformer_3d.py:700-719) — except where memory allows otherwise: 80 GB parts
         # must recompute every block; with 288 GB most blocks can simply KEEP their activations (5 GB per block at batch 2), and only the rest
@@ -490,10 +534,9 @@ class To2VTrainer:
         self._ckpt, self._kept = [], {}
         budget, per_block = self._activation_budget(), None
         for i, blk in enumerate(self._blocks):
-            self._ckpt.append((hidden, enc))
+            self._ckpt.append(X)
             blk.keep = budget > 0 and (per_block is None or budget >= per_block)
-            hidden, enc = blk.forward(hidden, enc, temb, rope, vrope, crope)
-            hidden = hidden.contiguous()
+            X = blk.forward_x(X, temb, rope, vrope, crope)
             if blk.keep:
                 self._kept[i], blk.saved = blk.saved, None
                 if per_block is None:
@@ -506,9 +549,10 @@ class To2VTrainer:
                 budget -= per_block
         self.blocks_kept = len(self._kept)
         # final norm (per token: only the video rows matter), AdaLayerNorm, proj_out, unpatchify (cogvideox_transformer_3d.py:736-759)
+        hidden = X[:, Nt:N1]
         semb = _act(temb.contiguous())
         tout = self._final_tables(semb, Nv, Fm)
-        vidn, vid2 = torch.empty_like(hidden), torch.empty_like(hidden)
+        vidn, vid2 = torch.empty(B, Nv, D, dtype=BF16, device=X.device), torch.empty(B, Nv, D, dtype=BF16, device=X.device)
         K.adaln_modulate(hidden, vidn, sd["norm_final.weight"], sd["norm_final.bias"], self.eps, None)
         K.adaln_modulate(vidn, vid2, sd["norm_out.norm.weight"], sd["norm_out.norm.bias"], self.eps, tout)
         Wp, bp = sd["proj_out.weight"], sd["proj_out.bias"]
@@ -535,30 +579,29 @@ class To2VTrainer:
         d_po = torch.empty(B * Nv, co, dtype=BF16, device=dev)
         K.patchify(d_out.to(BF16).reshape(B * Fr, -1, Hh, Ww).contiguous(), d_po, self.ps)
         d_vid2 = _dgrad(d_po, sd["proj_out.weight"]).view(B, Nv, D)
-        d_vidn, d_hid = torch.empty(B, Nv, D, dtype=BF16, device=dev), torch.empty(B, Nv, D, dtype=BF16, device=dev)
+        N1 = Nt + Nv
+        d_vidn = torch.empty(B, Nv, D, dtype=BF16, device=dev)
+        dX = torch.zeros(B, N1 + Np, D, dtype=BF16, device=dev)                 # only the video rows of the last block's output reach the model output
         _adaln_bwd(S["vidn"], d_vid2, d_vidn, sd["norm_out.norm.weight"], sd["norm_out.norm.bias"], self.eps, S["tout"], products=False)
-        _adaln_bwd(S["hidden_L"], d_vidn, d_hid, sd["norm_final.weight"], sd["norm_final.bias"], self.eps, None, products=False)
-        d_enc = torch.zeros(B, Nt + Np, D, dtype=BF16, device=dev)
+        _adaln_bwd(S["hidden_L"], d_vidn, dX[:, Nt:N1], sd["norm_final.weight"], sd["norm_final.bias"], self.eps, None, products=False)
         grads = {}
         rope, vrope, crope = self._ropes
         for i in reversed(range(self.L)):
             blk = self._blocks[i]
-            hidden, enc = self._ckpt[i]
             if i in self._kept:
                 blk.saved = self._kept.pop(i)                                    # activations kept by the forward: nothing to recompute
             else:
                 blk.keep = True
-                blk.forward(hidden, enc, S["temb"], rope, vrope, crope)       # recompute with the intermediates kept
-            g, d_hid, d_enc = blk.backward(d_hid, d_enc)
+                blk.forward_x(self._ckpt[i], S["temb"], rope, vrope, crope)   # recompute with the intermediates kept
+            g, dX = blk.backward_x(dX)
             blk.saved = None
             g = {f"transformer_blocks.{i}.{k}": v for k, v in g.items()}
             if on_block_done is not None:
                 on_block_done(i, g)
             else:
                 grads.update(g)
-            d_hid = d_hid.contiguous()
         self._ckpt = []
-        d_vip = d_enc[:, Nt:].reshape(B * Np, D)
+        d_vip = dX[:, N1:].reshape(B * Np, D)
         dW, db, dx = linear_backward(S["vtok"].view(B * Np, -1), d_vip.contiguous(), sd["patch_embed.vip_proj.weight"], need_dx=True)
         grads["patch_embed.vip_proj.weight"], grads["patch_embed.vip_proj.bias"] = dW, db
         return grads, dx.reshape(B, Np, -1)
