@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 // rows, or over the rows of one group) are the parameter gradients:  t_dln = dy (1 + scale)  [-> d beta],  t_dlnx = t_dln * x_hat  [-> d gamma],
 // t_dyln = dy * ln  [-> d scale[g]]  (d shift[g] = column sums of dy itself).  fp32 [rows][dim]; summed by tg_colsum_f32 in a fixed order.
 // ---------------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void adaln_bwd_kernel(const bf16_t* __restrict__ x, long ldx, long sxb, const bf16_t* __restrict__ dy, long ldd, long sdb,
+__global__ __launch_bounds__(256) void adaln_bwd_scalar_kernel(const bf16_t* __restrict__ x, long ldx, long sxb, const bf16_t* __restrict__ dy, long ldd, long sdb,
                                                         bf16_t* __restrict__ dx, long ldo, long sob, const bf16_t* __restrict__ w,
                                                         const bf16_t* __restrict__ bvec, float eps, int tokens, int dim, int batch, int modulate,
                                                         tg_group_table g, float* __restrict__ t_dln, float* __restrict__ t_dlnx,
@@ -187,9 +187,89 @@ __global__ __launch_bounds__(256) void adaln_bwd_kernel(const bf16_t* __restrict
     }
 }
 
+// The same with 16-byte accesses (8 bf16 per lane per access; needs dim % 8 == 0 and 16-byte aligned rows): the scalar form above moved 2 bytes
+// per lane per load and ran at ~1 TB/s.
+__device__ __forceinline__ void unpack8(uint4 v, float (&f)[8]) {
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bf16lo_to_f32(u[i]); f[2 * i + 1] = bf16hi_to_f32(u[i]); }
+}
+__global__ __launch_bounds__(256) void adaln_bwd_kernel(const bf16_t* __restrict__ x, long ldx, long sxb, const bf16_t* __restrict__ dy, long ldd, long sdb,
+                                                        bf16_t* __restrict__ dx, long ldo, long sob, const bf16_t* __restrict__ w,
+                                                        const bf16_t* __restrict__ bvec, float eps, int tokens, int dim, int batch, int modulate,
+                                                        tg_group_table g, float* __restrict__ t_dln, float* __restrict__ t_dlnx,
+                                                        float* __restrict__ t_dyln, const bf16_t* __restrict__ add, long lda, long sab) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)tokens * batch) return;
+    const int b = (int)(row / tokens), t = (int)(row % tokens);
+    const bf16_t* xr = x + (long)b * sxb + (long)t * ldx;
+    const bf16_t* dr = dy + (long)b * sdb + (long)t * ldd;
+    bf16_t* outr = dx + (long)b * sob + (long)t * ldo;
+    const int nch = dim >> 3;
+    float s = 0.f, f[8], e[8];
+    for (int c = lane; c < nch; c += 64) {
+        unpack8(*(const uint4*)(xr + c * 8), f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += f[i];
+    }
+    const float mean = wave_sum(s) / dim;
+    float q = 0.f;
+    for (int c = lane; c < nch; c += 64) {
+        unpack8(*(const uint4*)(xr + c * 8), f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = f[i] - mean; q += d * d; }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / dim + eps);
+    const bf16_t* scale = nullptr;
+    if (modulate) {
+        const int gi = g.tok_group[t];
+        scale = (const bf16_t*)g.mod + (long)b * g.mod_batch_stride + (long)g.row[gi] * g.mod_ld + g.scale_col[gi];
+    }
+    float m1 = 0.f, m2 = 0.f;
+    for (int c = lane; c < nch; c += 64) {
+        float gam[8], bet[8], sc[8];
+        unpack8(*(const uint4*)(xr + c * 8), f);
+        unpack8(*(const uint4*)(dr + c * 8), e);
+        if (w) unpack8(*(const uint4*)(w + c * 8), gam);
+        if (bvec) unpack8(*(const uint4*)(bvec + c * 8), bet);
+        if (scale) unpack8(*(const uint4*)(scale + c * 8), sc);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xh = (f[i] - mean) * rstd;
+            const float ga = w ? gam[i] : 1.f;
+            const float dln = e[i] * (1.f + (scale ? sc[i] : 0.f));
+            if (t_dln) {
+                const long o = row * dim + c * 8 + i;
+                t_dln[o] = dln; t_dlnx[o] = dln * xh; t_dyln[o] = e[i] * round_bf16(xh * ga + (bvec ? bet[i] : 0.f));
+            }
+            const float dxh = dln * ga;
+            m1 += dxh; m2 += dxh * xh;
+        }
+    }
+    m1 = wave_sum(m1) / dim; m2 = wave_sum(m2) / dim;
+    const bf16_t* ar = add ? add + (long)b * sab + (long)t * lda : nullptr;
+    for (int c = lane; c < nch; c += 64) {
+        float gam[8], sc[8], a8[8], v[8];
+        unpack8(*(const uint4*)(xr + c * 8), f);
+        unpack8(*(const uint4*)(dr + c * 8), e);
+        if (w) unpack8(*(const uint4*)(w + c * 8), gam);
+        if (scale) unpack8(*(const uint4*)(scale + c * 8), sc);
+        if (ar) unpack8(*(const uint4*)(ar + c * 8), a8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xh = (f[i] - mean) * rstd;
+            const float dxh = e[i] * (1.f + (scale ? sc[i] : 0.f)) * (w ? gam[i] : 1.f);
+            v[i] = rstd * (dxh - m1 - xh * m2);
+            if (ar) v[i] = round_bf16(v[i]) + a8[i];
+        }
+        *(uint4*)(outr + c * 8) = uint4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    }
+}
+
 // Backward of the gated residual  out = res + gate[g] * y  (cogvideox_transformer_3d.py:290-293, 318-324):  dy = gate[g] * dout (bf16),
 // t_dgate = dout * y (fp32; its column sums over the rows of group g are d gate[g]);  d res = dout.
-__global__ __launch_bounds__(256) void gate_res_bwd_kernel(const bf16_t* __restrict__ dout, long ldd, long sdb, const bf16_t* __restrict__ y, long ldy,
+__global__ __launch_bounds__(256) void gate_res_bwd_scalar_kernel(const bf16_t* __restrict__ dout, long ldd, long sdb, const bf16_t* __restrict__ y, long ldy,
                                                            long syb, bf16_t* __restrict__ dyo, long ldo, long sob, int tokens, int dim, int batch,
                                                            tg_group_table g, float* __restrict__ t_dgate, int t_row0) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -205,8 +285,32 @@ __global__ __launch_bounds__(256) void gate_res_bwd_kernel(const bf16_t* __restr
     if (t >= t_row0) t_dgate[((long)b * (tokens - t_row0) + (t - t_row0)) * dim + c] = d * bf16_to_f32(y[(long)b * syb + (long)t * ldy + c]);
 }
 
+__global__ __launch_bounds__(256) void gate_res_bwd_kernel(const bf16_t* __restrict__ dout, long ldd, long sdb, const bf16_t* __restrict__ y, long ldy,
+                                                           long syb, bf16_t* __restrict__ dyo, long ldo, long sob, int tokens, int dim, int batch,
+                                                           tg_group_table g, float* __restrict__ t_dgate, int t_row0) {       // 8 elements per thread
+    const int nch = dim >> 3;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)batch * tokens * nch) return;
+    const int c = (int)(i % nch) * 8;
+    const long row = i / nch;
+    const int b = (int)(row / tokens), t = (int)(row % tokens);
+    const int gi = g.tok_group[t];
+    float ga[8], d[8], yv[8], o[8];
+    unpack8(*(const uint4*)((const bf16_t*)g.mod + (long)b * g.mod_batch_stride + (long)g.row[gi] * g.mod_ld + g.gate_col[gi] + c), ga);
+    unpack8(*(const uint4*)(dout + (long)b * sdb + (long)t * ldd + c), d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = ga[k] * d[k];
+    *(uint4*)(dyo + (long)b * sob + (long)t * ldo + c) = uint4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+    if (t >= t_row0) {
+        unpack8(*(const uint4*)(y + (long)b * syb + (long)t * ldy + c), yv);
+        float* dst = t_dgate + ((long)b * (tokens - t_row0) + (t - t_row0)) * dim + c;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[k] = d[k] * yv[k];
+    }
+}
+
 // mode 0: y = silu(x);  mode 1: dx = dy * gelu_tanh'(x)  (F.gelu(approximate="tanh"), diffusers FeedForward)
-__global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ out, long n, int mode) {
+__global__ __launch_bounds__(256) void act_scalar_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ out, long n, int mode) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float v = bf16_to_f32(x[i]);
@@ -215,6 +319,23 @@ __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, 
     const float u = k0 * (v + k1 * v * v * v), th = tanhf(u);
     const float dg = 0.5f * (1.f + th) + 0.5f * v * (1.f - th * th) * k0 * (1.f + 3.f * k1 * v * v);
     out[i] = f32_to_bf16(bf16_to_f32(dy[i]) * dg);
+}
+
+__device__ __forceinline__ float act_one(float v, float dyv, int mode) {
+    if (mode == 0) return v / (1.f + __expf(-v));
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float u = k0 * (v + k1 * v * v * v), th = tanhf(u);
+    return dyv * (0.5f * (1.f + th) + 0.5f * v * (1.f - th * th) * k0 * (1.f + 3.f * k1 * v * v));
+}
+__global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ out, long n8, int mode) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;                  // 8 elements per thread
+    if (i >= n8) return;
+    float v[8], d[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[8];
+    unpack8(*(const uint4*)(x + i * 8), v);
+    if (mode == 1) unpack8(*(const uint4*)(dy + i * 8), d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = act_one(v[k], d[k], mode);
+    *(uint4*)(out + i * 8) = uint4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
 }
 
 __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ src, long ld, int rows, int cols, float* __restrict__ partial) {
@@ -281,9 +402,22 @@ extern "C" int tg_adaln_modulate_bwd(const void* x, long ldx, long strideX, cons
     tg_group_table gt{};
     if (g) gt = *g;
     const long rows = (long)tokens * batch;
-    hipLaunchKernelGGL(adaln_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, strideX, (const bf16_t*)dy, ld_dy, stride_dy,
-                       (bf16_t*)dx, ld_dx, stride_dx, (const bf16_t*)ln_weight, (const bf16_t*)ln_bias, eps, tokens, dim, batch, modulate, gt, t_dln, t_dlnx, t_dyln,
-                       (const bf16_t*)add, ld_add, stride_add);
+    // 16-byte form: every row pointer the kernel forms (x, dy, dx, add, the LayerNorm vectors, the scale row of the group table) must be 16-byte aligned
+    auto al = [](const void* p_, long ld, long sb) { return !p_ || (tg_aligned16(p_) && ld % 8 == 0 && sb % 8 == 0); };
+    bool vec = dim % 8 == 0 && al(x, ldx, strideX) && al(dy, ld_dy, stride_dy) && al(dx, ld_dx, stride_dx) && al(add, ld_add, stride_add) &&
+               al(ln_weight, 0, 0) && al(ln_bias, 0, 0);
+    if (vec && modulate) {
+        vec = tg_aligned16(gt.mod) && gt.mod_ld % 8 == 0 && gt.mod_batch_stride % 8 == 0;
+        for (int i = 0; i < TG_MAX_GROUPS; ++i) vec = vec && gt.scale_col[i] % 8 == 0;
+    }
+    if (vec)
+        hipLaunchKernelGGL(adaln_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, strideX, (const bf16_t*)dy, ld_dy, stride_dy,
+                           (bf16_t*)dx, ld_dx, stride_dx, (const bf16_t*)ln_weight, (const bf16_t*)ln_bias, eps, tokens, dim, batch, modulate, gt, t_dln, t_dlnx,
+                           t_dyln, (const bf16_t*)add, ld_add, stride_add);
+    else
+        hipLaunchKernelGGL(adaln_bwd_scalar_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, strideX, (const bf16_t*)dy, ld_dy,
+                           stride_dy, (bf16_t*)dx, ld_dx, stride_dx, (const bf16_t*)ln_weight, (const bf16_t*)ln_bias, eps, tokens, dim, batch, modulate, gt, t_dln,
+                           t_dlnx, t_dyln, (const bf16_t*)add, ld_add, stride_add);
     TG_LAUNCH_CHECK("tg_adaln_modulate_bwd");
     return TG_OK;
 }
@@ -293,8 +427,16 @@ extern "C" int tg_gate_residual_bwd(const void* dout, long ld_dout, long stride_
     TG_REQUIRE(dout && y && dy && gate && t_dgate, TG_ERR_ARG, "tg_gate_residual_bwd: null pointer");
     TG_REQUIRE(tokens > 0 && dim > 0 && batch > 0 && t_row0 >= 0 && t_row0 < tokens, TG_ERR_SHAPE, "tg_gate_residual_bwd: bad shape");
     const long total = (long)batch * tokens * dim;
-    hipLaunchKernelGGL(gate_res_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)dout, ld_dout, stride_dout, (const bf16_t*)y,
-                       ldy, strideY, (bf16_t*)dy, ld_dy, stride_dy, tokens, dim, batch, *gate, t_dgate, t_row0);
+    bool vec = dim % 8 == 0 && tg_aligned16(dout) && tg_aligned16(y) && tg_aligned16(dy) && tg_aligned16(gate->mod) && tg_aligned16(t_dgate) && ld_dout % 8 == 0 &&
+               stride_dout % 8 == 0 && ldy % 8 == 0 && strideY % 8 == 0 && ld_dy % 8 == 0 && stride_dy % 8 == 0 && gate->mod_ld % 8 == 0 &&
+               gate->mod_batch_stride % 8 == 0;
+    for (int i = 0; i < TG_MAX_GROUPS; ++i) vec = vec && gate->gate_col[i] % 8 == 0;
+    if (vec)
+        hipLaunchKernelGGL(gate_res_bwd_kernel, dim3((unsigned)((total / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)dout, ld_dout, stride_dout,
+                           (const bf16_t*)y, ldy, strideY, (bf16_t*)dy, ld_dy, stride_dy, tokens, dim, batch, *gate, t_dgate, t_row0);
+    else
+        hipLaunchKernelGGL(gate_res_bwd_scalar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)dout, ld_dout, stride_dout,
+                           (const bf16_t*)y, ldy, strideY, (bf16_t*)dy, ld_dy, stride_dy, tokens, dim, batch, *gate, t_dgate, t_row0);
     TG_LAUNCH_CHECK("tg_gate_residual_bwd");
     return TG_OK;
 }
@@ -302,7 +444,10 @@ extern "C" int tg_gate_residual_bwd(const void* dout, long ld_dout, long stride_
 extern "C" int tg_act(const void* x, const void* dy, void* out, long n, int mode, hipStream_t stream) {
     TG_REQUIRE(x && out && (mode == 0 || dy), TG_ERR_ARG, "tg_act: null pointer");
     TG_REQUIRE(n > 0 && (mode == 0 || mode == 1), TG_ERR_SHAPE, "tg_act: bad arguments");
-    hipLaunchKernelGGL(act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)out, n, mode);
+    if (n % 8 == 0 && tg_aligned16(x) && tg_aligned16(out) && (!dy || tg_aligned16(dy)))
+        hipLaunchKernelGGL(act_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)out, n / 8, mode);
+    else
+        hipLaunchKernelGGL(act_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)out, n, mode);
     TG_LAUNCH_CHECK("tg_act");
     return TG_OK;
 }
