@@ -35,6 +35,14 @@ if which == "attn":          # the DiT's main attention launch (2 x 48 heads, 17
     fn = lambda: K.attention(qkv[:, :, :D], qkv[:, :, D:2 * D], vt1, N1, ao, H, 0.125, qkvv[:, :N1, :D], qkvv[:, N1:, D:2 * D], vt2, NP, 0.6,
                              k_prescaled=True)
     M, N, Kk = 1, 1, (B * (4.0 * N1 * N1 * D + 4.0 * N1 * NP * D)) / 2.0
+if which == "attn_bwd":      # the training step's main attention backward call (dK/dV + dQ + statistics)
+    B, H, N1 = 2, 48, 17776
+    D = H * 64
+    qkv = (torch.randn(B, N1, 3 * D, device="cuda") * 0.6).to(torch.bfloat16)
+    o, do = ((torch.randn(B, N1, D, device="cuda") * 0.3).to(torch.bfloat16) for _ in range(2))
+    dq, dk, dv = (torch.empty(B, N1, D, dtype=torch.float32, device="cuda") for _ in range(3))
+    fn = lambda: K.attention_bwd(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], o, do, H, 0.125, dq=dq, dk=dk, dv=dv)
+    M, N, Kk = 1, 1, 7 * B * N1 * N1 * D / 2.0
 samples, stop = [], False
 
 
