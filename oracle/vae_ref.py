@@ -131,8 +131,13 @@ def decoder(sd, cfg, z, cache):
     return causal_conv3d(sd, "decoder.conv_out", h, cache)
 
 
-def frame_batches(num_frames, batch):
-    """:1092-1097 / :1146-1151: the remainder is folded into the first batch."""
+def frame_batches(num_frames, batch, chunk=None):
+    """:1092-1097 / :1146-1151: the remainder is folded into the first batch.  chunk = 13 (tiled_decode, :1313-1325): the rule restarts every 13
+    latent frames (cache carried across the chunks of a tile); used for whole multiples of the chunk beyond one (the reference drops frames past the last
+    whole chunk and fails below one)."""
+    if chunk and num_frames > chunk and num_frames % chunk == 0:
+        rem = chunk % batch
+        return [(c0 + batch * k + (0 if k == 0 else rem), c0 + batch * (k + 1) + rem) for c0 in range(0, num_frames, chunk) for k in range(chunk // batch)]
     n = max(num_frames // batch, 1) if num_frames > 1 else 1
     rem = num_frames % batch
     return [(batch * k + (0 if k == 0 else rem), batch * (k + 1) + rem) for k in range(n)]
@@ -187,7 +192,7 @@ def _tiled(sd, cfg, x, for_decode):
         row = []
         for j in range(0, x.shape[4], st_w):
             cache = ConvCache()
-            parts = [fn(sd, cfg, x[:, :, a:b, i:i + th, j:j + tw], cache) for a, b in frame_batches(x.shape[2], fb)]
+            parts = [fn(sd, cfg, x[:, :, a:b, i:i + th, j:j + tw], cache) for a, b in frame_batches(x.shape[2], fb, 13 if for_decode else None)]
             row.append(torch.cat(parts, dim=2))
         rows.append(row)
     out_rows = []

@@ -156,6 +156,11 @@ def test_vae_tiny_encode_decode_vs_reference(golden_dir):
     d = vae.decode(z13.to(DEV, BF)).sample
     f = d.flatten().cpu()
     assert tuple(d.shape) == g["decode_tiled"]["shape"] and _rel(f[g["idx"] % f.numel()], g["decode_tiled"]["samples"]) < 2.5e-2
+    # two 13-frame chunks through tiled_decode: per-chunk frame batching with the conv cache carried across (reference run, gen_vae_t26)
+    g2 = torch.load(os.path.join(golden_dir, "vae_tiled_decode_t26.pt"), weights_only=False)
+    z26 = torch.randn(1, 16, 26, 8, 12, generator=torch.Generator().manual_seed(g2["input_seed"]))
+    d = vae.decode(z26.to(DEV, BF)).sample
+    assert tuple(d.shape) == g2["shape"] and _rel(d.flatten().cpu()[g2["idx"]], g2["samples"]) < 2.5e-2
     # and against the oracle run in bf16 on the same bf16 inputs
     sdb = {k: v.to(BF) for k, v in sd.items()}
     ref = V.decode(sdb, cfg, z5.to(BF), tiling=False)

@@ -350,8 +350,14 @@ class AutoencoderKLCogVideoX:
         return self._conv("decoder.conv_out", h, cache)
 
     @staticmethod
-    def _frame_batches(n, batch):
-        """:1092-1097, 1146-1151 — remainder folded into the first batch."""
+    def _frame_batches(n, batch, chunk=None):
+        """:1092-1097, 1146-1151 — remainder folded into the first batch.  chunk (tiled_decode only, :1313-1325): the reference restarts that rule
+        every 13 latent frames — (0,3),(3,5),..,(11,13),(13,16),(16,18),.. — with the conv cache carried across the chunks of a tile.  Applied when
+        the frame count is a whole number of chunks > 1 (the reference drops frames past the last whole chunk and fails below one chunk; shorter
+        inputs keep the plain rule, which is identical for exactly one chunk)."""
+        if chunk and n > chunk and n % chunk == 0:
+            rem = chunk % batch
+            return [(c0 + batch * k + (0 if k == 0 else rem), c0 + batch * (k + 1) + rem) for c0 in range(0, n, chunk) for k in range(chunk // batch)]
         nb = max(n // batch, 1) if n > 1 else 1
         rem = n % batch
         return [(batch * k + (0 if k == 0 else rem), batch * (k + 1) + rem) for k in range(nb)]
@@ -362,7 +368,8 @@ class AutoencoderKLCogVideoX:
         Hc, Wc = min(th, Ht - i), min(tw, Wt - j)
         cache = {}
         outs = []
-        for a, b in self._frame_batches(Tt, self.num_latent_frames_batch_size if decode else self.num_sample_frames_batch_size):
+        for a, b in self._frame_batches(Tt, self.num_latent_frames_batch_size if decode else self.num_sample_frames_batch_size,
+                                        13 if (decode and getattr(self, "_tiled_pass", False)) else None):
             if decode:
                 z64 = K.ncdhw_to_cl(src, a, b - a, i, Hc, j, Wc, 64)
                 z2 = z64.view(-1, 64)
@@ -388,7 +395,7 @@ class AutoencoderKLCogVideoX:
             return self._run_tile(src, i, j, th, tw, decode)
         C, Tt, Ht, Wt = src.shape
         Hc, Wc = min(th, Ht - i), min(tw, Wt - j)
-        key = (decode, src.dtype, C, Tt, Hc, Wc, slot)
+        key = (decode, src.dtype, C, Tt, Hc, Wc, slot, bool(getattr(self, "_tiled_pass", False)))
         g = self._graphs.get(key)
         if g is None:
             if not self._seen.get(key):            # first sight: run eagerly (this is also the warm-up a capture needs)
@@ -459,7 +466,8 @@ class AutoencoderKLCogVideoX:
             th, tw = self.tile_sample_min_height, self.tile_sample_min_width
             tsh, tsw = self.tile_latent_min_height, self.tile_latent_min_width
         H, W = src.shape[2:]
-        if not (self.use_tiling and (W > tw or H > th)):
+        self._tiled_pass = bool(self.use_tiling and (W > tw or H > th))
+        if not self._tiled_pass:
             return self._run_tile_maybe_graph(src, 0, 0, H, W, decode, 0).clone()      # a graph's output buffer is reused by its next replay
         st_h, st_w = int(th * (1 - self.tile_overlap_factor_height)), int(tw * (1 - self.tile_overlap_factor_width))
         bh, bw = int(tsh * self.tile_overlap_factor_height), int(tsw * self.tile_overlap_factor_width)

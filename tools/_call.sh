@@ -1,2 +1,1 @@
-timeout 120 python tools/clock_probe.py attn_bwd 5 2>&1 | tail -6
-timeout 120 python tools/clock_probe.py attn 4 2>&1 | tail -4
+timeout 900 python -m pytest tests/test_vae_gpu.py tests/test_vae_full_gpu.py -m gpu -x -q 2>&1 | tail -6

@@ -325,6 +325,36 @@ def gen_vae():
     print("vae_tiny.pt", out["encode_tiled"].shape, out["decode_tiled"]["shape"])
 
 
+@torch.no_grad()
+def gen_vae_t26():
+    """tiled_decode over TWO 13-frame latent chunks (autoencoder_kl_cogvideox.py:1313-1336): the reference restarts its frame batching every 13
+    frames and carries the conv cache across the chunks of a tile.  Same tiny VAE / weights as gen_vae; separate file so that vae_tiny.pt stays as it is."""
+    from oracle import vae_ref as V
+    rv = load_ref_module("longvgen/models/autoencoder_kl_cogvideox.py", "ref_vae_t26")
+    cfg = VAE_TINY
+    vae = rv.AutoencoderKLCogVideoX(in_channels=3, out_channels=3, block_out_channels=cfg["block_out_channels"], latent_channels=16,
+                                    layers_per_block=1, sample_height=64, sample_width=96, temporal_compression_ratio=4)
+    vae.load_state_dict(V.make_state_dict(cfg, seed=600), strict=True)
+    vae.eval()
+    vae.enable_tiling()
+    g = torch.Generator().manual_seed(611)
+    z26 = torch.randn(1, 16, 26, 8, 12, generator=g)
+    calls = []
+    dec = vae.decoder
+    orig = dec.forward
+
+    def rec(z, *a, **k):
+        calls.append(z.shape[2])
+        return orig(z, *a, **k)
+    dec.forward = rec
+    y = vae.tiled_decode(z26).sample
+    idx = torch.randint(0, y.numel(), (8192,), generator=g)
+    out = dict(cfg=cfg, weight_seed=600, input_seed=611, shape=tuple(y.shape), idx=idx, samples=y.flatten()[idx].clone(), frames_per_decoder_call=calls,
+               mean=y.mean().item(), std=y.std().item())
+    torch.save(out, os.path.join(GOLD, "vae_tiled_decode_t26.pt"))
+    print("vae_tiled_decode_t26.pt", out["shape"], calls[:14])
+
+
 RESAMPLER_TINY = dict(dim=128, depth=2, dim_head=64, heads=2, num_height_queries=2, num_width_queries=3, num_temporal_queries=4,
                       embedding_dim=128, output_dim=128, ff_mult=4, max_height_seq_len=4, max_width_seq_len=6, max_temporal_seq_len=13)
 
@@ -606,7 +636,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    jobs = dict(dit=gen_dit_tiny, vip=gen_vip_processor, sched=gen_scheduler, fifo=gen_fifo, vae=gen_vae, resampler=gen_resampler, t2to=gen_t2to, base=gen_base_stage, vae_geom=gen_vae_geometry)
+    jobs = dict(dit=gen_dit_tiny, vip=gen_vip_processor, sched=gen_scheduler, fifo=gen_fifo, vae=gen_vae, resampler=gen_resampler, t2to=gen_t2to, base=gen_base_stage, vae_geom=gen_vae_geometry, vae_t26=gen_vae_t26)
     if a.only:
         jobs = {a.only: jobs.get(a.only, gen_full_block)}
     for k, fn in jobs.items():
