@@ -571,3 +571,39 @@ def test_full_micro_step_with_resampler_gradients_vs_autograd_of_the_oracle_chai
     assert did and opt.t == 1 and float(arena.grad.abs().max()) == 0.0
     moved = (arena.param != before)
     assert moved[:n_clip].float().mean().item() > 0.3 and moved[n_clip:].float().mean().item() > 0.3      # transformer and Resampler parameters both stepped
+
+
+@pytest.mark.timeout(900)
+def test_full_width_block_backward_vs_autograd():
+    """The block backward at the REAL width (48 heads x 64 = 3072 channels, FeedForward 12288: the 256^2 GEMM tiles, the 8-wave backward attention
+    kernels, the 16-byte elementwise kernels) on a short stream (16 text + 2 x 192 video + 64 vip tokens), against autograd through the oracle block
+    in fp32 — run on the GPU for speed, it is still the checker — on the same bf16-rounded weights and inputs."""
+    import numpy as np
+    from oracle import dit_ref as O
+    from tokensgen_amd import train
+    B, H, Nt, Fr, hw, Np = 1, 48, 16, 2, 192, 64
+    Nv, D = Fr * hw, H * 64
+    f32 = np.float32
+    cfg = dict(num_attention_heads=H, attention_head_dim=64, num_layers=1, patch_size=2, time_embed_dim=512, text_embed_dim=64, in_channels=16, out_channels=16)
+    pre = "transformer_blocks.0"
+    sd = {k: v.to(BF).float().to(DEV) for k, v in O.make_state_dict(cfg, n_vip_dim=128, seed=111, std=0.02).items() if k.startswith(pre + ".")}
+    train_keys = [k for k in sd if "vip_" in k]
+    for k in train_keys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    hidden, enc, temb = _rand(B, Nv, D, seed=112).to(DEV), _rand(B, Nt + Np, D, seed=113).to(DEV), _rand(B, Fr, 512, seed=114).to(DEV)
+    dev = lambda r: tuple(t.to(DEV) for t in r)
+    rope = O.rope_3d(64, np.arange(2, dtype=f32), np.arange(12, dtype=f32), np.arange(16, dtype=f32))
+    vrope = O.rope_3d(64, np.arange(2, dtype=f32) + f32(3), np.arange(12, dtype=f32), np.arange(16, dtype=f32))
+    crope = O.rope_3d(64, np.linspace(1000, 1016.25, 4, dtype=f32), np.arange(4, dtype=f32), np.arange(4, dtype=f32))
+    hf, ef = hidden.float().requires_grad_(True), enc.float().requires_grad_(True)
+    oh, oe = O.block_forward(sd, pre, hf, ef, temb.float(), H, Np, [1.0], dev(rope), dev(vrope), dev(crope))
+    Gh, Ge = _rand(B, Nv, D, seed=115).to(DEV), _rand(B, Nt + Np, D, seed=116).to(DEV)
+    ((oh * Gh.float()).sum() + (oe * Ge.float()).sum()).backward()
+    sd_dev = {k: v.detach().to(BF).contiguous() for k, v in sd.items()}
+    blk = train.To2VBlockTrainer(sd_dev, pre, H, Nt, Np, Fr, 1.0)
+    gh, ge = blk.forward(hidden, enc, temb, rope, vrope, crope)
+    assert _rel(gh, oh.detach()) < 1e-2 and _rel(ge, oe.detach()) < 1e-2
+    grads, dh, de = blk.backward(Gh, Ge)
+    assert _rel(dh, hf.grad) < 1.3e-2 and _rel(de, ef.grad) < 1.3e-2          # measured 5.5e-3 / 6.3e-3
+    for name, g_ in grads.items():
+        assert _rel(g_, sd[pre + "." + name].grad) < 3.5e-2, name               # measured <= 1.7e-2
