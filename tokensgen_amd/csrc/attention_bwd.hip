@@ -993,15 +993,19 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
     int buf = 0;
     for (int it = 0; it < ntile; ++it) {
         const int nbuf = buf == 2 ? 0 : buf + 1, sbuf = nbuf == 2 ? 0 : nbuf + 1;     // tile it+1 (staged last iteration), tile it+2 (staged now)
-        fetch(min(it + 2, ntile - 1) * BT);
+        if (TG_BWD_ABL != 7) fetch(min(it + 2, ntile - 1) * BT);
         f32x16 s, dp;                                      // rows = queries, column = key j
         if (TG_BWD_PRIO) __builtin_amdgcn_s_setprio(3);    // a wave in an MFMA block wins the issue port: the partner's softmax fills what is left
-        mfma_pair(s, dp, aQ, aO, kf, vf);
+        if (TG_BWD_ABL == 8) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = __uint_as_float(((const uint32_t*)&aQ[r & 3])[r >> 2]); dp[r] = __uint_as_float(((const uint32_t*)&aO[r & 3])[r >> 2]); }
+        } else mfma_pair(s, dp, aQ, aO, kf, vf);
         if (TG_BWD_PRIO) __builtin_amdgcn_s_setprio(0);
         TG_SB();
         bf16x8 nQ[4], nO[4];                               // next tile's A operands: their LDS latency hides under this tile's softmax + MFMAs
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+            if (TG_BWD_ABL == 6) { nQ[ks] = aQ[ks]; nO[ks] = aO[ks]; continue; }
             nQ[ks] = *(const bf16x8*)(sQ[nbuf] + j * LQ2 + ks * 16 + hi * 8);
             nO[ks] = *(const bf16x8*)(sdO[nbuf] + j * LQ2 + ks * 16 + hi * 8);
         }
@@ -1009,7 +1013,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
         Frag pA[2], dA[2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 l4 = *(const f32x4*)(sLse[buf] + 8 * g + 4 * hi), d4 = *(const f32x4*)(sD[buf] + 8 * g + 4 * hi);
+            const f32x4 l4 = TG_BWD_ABL == 6 ? f32x4{1.f, 2.f, 3.f, 4.f} : *(const f32x4*)(sLse[buf] + 8 * g + 4 * hi);
+            const f32x4 d4 = TG_BWD_ABL == 6 ? f32x4{.1f, .2f, .3f, .4f} : *(const f32x4*)(sD[buf] + 8 * g + 4 * hi);
             if (TG_BWD_ABL == 1) {
                 pA[g >> 1].w[(g & 1) * 2] = __float_as_uint(s[4 * g] + l4[0]); pA[g >> 1].w[(g & 1) * 2 + 1] = __float_as_uint(s[4 * g + 2]);
                 dA[g >> 1].w[(g & 1) * 2] = __float_as_uint(dp[4 * g] + d4[0]); dA[g >> 1].w[(g & 1) * 2 + 1] = __float_as_uint(dp[4 * g + 2]);
@@ -1029,6 +1034,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 const int o = (db * 32 + j) * LT2 + 16 * t + 4 * hi;
+                if (TG_BWD_ABL == 6) { bO[t][db].v = aQ[t * 2 + db]; bQ[t][db].v = aO[t * 2 + db]; continue; }
                 bO[t][db].u[0] = *(const uint2*)(sdOt[buf] + o); bO[t][db].u[1] = *(const uint2*)(sdOt[buf] + o + 8);
                 bQ[t][db].u[0] = *(const uint2*)(sQt[buf] + o);  bQ[t][db].u[1] = *(const uint2*)(sQt[buf] + o + 8);
             }
@@ -1038,18 +1044,168 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                if (TG_BWD_ABL == 3) { asm volatile("" :: "v"(pA[t].v), "v"(dA[t].v), "v"(bO[t][db].v), "v"(bQ[t][db].v)); continue; }
+                if (TG_BWD_ABL == 3 || TG_BWD_ABL == 8) { asm volatile("" :: "v"(pA[t].v), "v"(dA[t].v), "v"(bO[t][db].v), "v"(bQ[t][db].v)); continue; }
                 mfma_acc(dv[db], pA[t].v, bO[t][db].v);
                 mfma_acc(dk[db], dA[t].v, bQ[t][db].v);
             }
         if (TG_BWD_PRIO) __builtin_amdgcn_s_setprio(0);
         TG_SB();
-        stash(sbuf);                                       // buffer of tile it-1: no reader since the barrier that ended the previous iteration
+        if (TG_BWD_ABL != 7) stash(sbuf);                  // buffer of tile it-1: no reader since the barrier that ended the previous iteration
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) { aQ[ks] = nQ[ks]; aO[ks] = nO[ks]; }
         buf = nbuf;
     }
+    asm volatile("s_nop 15" ::: "memory");
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        float* DK = p.dk + (long)b * p.dk_sb + h * HD + db * 32 + j;
+        float* DV = p.dv + (long)b * p.dv_sb + h * HD + db * 32 + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kw0 + acc_row(r, hi);
+            if (key >= p.nk) continue;
+            float* a = DK + (long)key * p.dk_ld;
+            float* c = DV + (long)key * p.dv_ld;
+            const float vk = dk[db][r] * p.scale, vv = dv[db][r];
+            *a = (p.accumulate & 2) ? *a + vk : vk;
+            *c = (p.accumulate & 2) ? *c + vv : vv;
+        }
+    }
+}
+
+// ---- (2-pp) ping-pong: the two waves of a SIMD in ANTI-phase (TG_ATTN_BWD_DKDV=6; measured 5 % SLOWER than the in-phase kernel: 19.7 vs 18.6 ms) ----
+// The 8-wave kernel above runs its two waves per SIMD through the same instruction stream behind the same barrier: both are in their MFMA block,
+// then both in their softmax, and the counters show the matrix and the vector pipe taking turns (MFMA busy 37 %).  Here the waves form two groups
+// (waves 0-3 / 4-7: one of each per SIMD) whose tile is cut into a matrix segment X(i) = dV/dK products of tile i-1 + S|dP of tile i, and a vector
+// segment Y(i) = softmax of tile i + every LDS read (B operands of tile i, A operands of tile i+1) + the stage writes of tile i+2, with a barrier
+// after each; group 1 runs one barrier behind, so X of one group always lies beside Y of the other (the structure of attn_fwd_pp_kernel).
+// Three-deep LDS ring: tile i is read in the Y segments of steps i-1 and i of both groups (four half-steps), tile i+2 is written in Y(i).
+// The barrier is a bare s_barrier behind lgkmcnt(0): __syncthreads() also waits for the global prefetch issued just before it.
+#define TG_BAR_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+__global__ __launch_bounds__(512) void attn_bwd_dkdv6_kernel(Bwd2Params pp) {
+    const BwdParams& p = pp.p;
+    __shared__ __attribute__((aligned(16))) bf16_t sQ[3][ROWT_EL], sdO[3][ROWT_EL], sQt[3][COLT_EL], sdOt[3][COLT_EL];
+    __shared__ __attribute__((aligned(16))) float sLse[3][BT], sD[3][BT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int j = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y % p.heads, b = blockIdx.y / p.heads;
+    const int kw0 = blockIdx.x * 256 + wave * 32;
+    const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
+    const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
+    const bf16_t* qT = pp.qT + ((long)(b * p.heads + h) * 64) * pp.ldq;
+    const bf16_t* doT = pp.doT + ((long)(b * p.heads + h) * 64) * pp.ldq;
+    const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
+    const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
+    const long stat0 = ((long)b * p.heads + h) * p.nq;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const long r = min(kw0 + j, p.nk - 1);
+        load_frag_agpr(kf[ks], Kp + r * p.k_ld + ks * 16 + hi * 8);
+        load_frag_agpr(vf[ks], Vp + r * p.v_ld + ks * 16 + hi * 8);
+    }
+    TG_WAIT_FRAGS1(kf);
+    TG_WAIT_FRAGS1(vf);
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { dk[c] = zero16(); dv[c] = zero16(); }
+    const int half = tid >> 8, t8 = tid & 255;              // group 0's threads stage Q and Q^T, group 1's dO and dO^T
+    const int row = t8 >> 3, chunk = (t8 & 7) * 8;
+    const int drow = t8 >> 2, part = (t8 & 3) * 8;
+    const bf16_t* const srcR = half ? dO : Q;
+    const bf16_t* const srcT = half ? doT : qT;
+    const long ldR = half ? p.do_ld : p.q_ld;
+    const int ntile = (p.nq + BT - 1) / BT;
+    uint4 g0, g2;
+    float gs = 0.f;
+    bool okr = false, oks = false;
+    const float* statp = (tid < BT ? p.lse : p.dsum) + stat0;
+    float* const statdst = tid < BT ? &sLse[0][tid] : &sD[0][tid & 31];
+    const float statmask = tid < BT ? 1e30f : 0.f;
+    auto fetch = [&](int q0) {
+        okr = q0 + row < p.nq; oks = q0 + (tid & 31) < p.nq;
+        g0 = ld_row16_clamped(srcR, ldR, q0 + row, p.nq, chunk);
+        g2 = *(const uint4*)(srcT + (long)drow * pp.ldq + q0 + part);
+        gs = statp[min(q0 + (tid & 31), p.nq - 1)];
+    };
+    auto stash = [&](int buf) {
+        *(uint4*)((half ? sdO[buf] : sQ[buf]) + row * LQ2 + chunk) = mask16(g0, okr);
+        st_2x8((half ? sdOt[buf] : sQt[buf]) + drow * LT2 + part, g2);
+        if (tid < 2 * BT) statdst[buf * BT] = oks ? gs : statmask;
+    };
+    fetch(0);
+    stash(0);
+    fetch(min(1, ntile - 1) * BT);
+    stash(1);
+    __syncthreads();
+    bf16x8 aQ[4], aO[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        aQ[ks] = *(const bf16x8*)(sQ[0] + j * LQ2 + ks * 16 + hi * 8);
+        aO[ks] = *(const bf16x8*)(sdO[0] + j * LQ2 + ks * 16 + hi * 8);
+    }
+    fetch(min(2, ntile - 1) * BT);                          // in flight across X(0): stored to the ring in Y(0)
+    Frag pA[2], dA[2], bO[2][2], bQ[2][2];                  // carried from Y(i) to X(i+1); zero: X(0) multiplies them harmlessly
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { pA[t].w[w] = 0; dA[t].w[w] = 0; bO[t][0].w[w] = 0; bO[t][1].w[w] = 0; bQ[t][0].w[w] = 0; bQ[t][1].w[w] = 0; }
+    }
+    if (grp == 1) TG_BAR_LDS();                             // group 1 falls one barrier (= one segment) behind group 0
+    int buf = 0;
+    for (int it = 0; it < ntile; ++it) {
+        const int nbuf = buf == 2 ? 0 : buf + 1, sbuf = nbuf == 2 ? 0 : nbuf + 1;
+        // ---------------- X(it): matrix segment ----------------
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                mfma_acc(dv[db], pA[t].v, bO[t][db].v);
+                mfma_acc(dk[db], dA[t].v, bQ[t][db].v);
+            }
+        f32x16 s, dp;                                      // rows = queries, column = key j
+        mfma_pair(s, dp, aQ, aO, kf, vf);
+        TG_SB(); TG_BAR_LDS(); TG_SB();                     // pinned: register-only asm MFMAs may otherwise drift across the barrier
+        // ---------------- Y(it): vector segment ----------------
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 l4 = *(const f32x4*)(sLse[buf] + 8 * g + 4 * hi), d4 = *(const f32x4*)(sD[buf] + 8 * g + 4 * hi);
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const f32x2 pv = {fast_exp2(s[4 * g + e] * p.scale_log2 - l4[e]), fast_exp2(s[4 * g + e + 1] * p.scale_log2 - l4[e + 1])};
+                const f32x2 ds = {pv[0] * (dp[4 * g + e] - d4[e]), pv[1] * (dp[4 * g + e + 1] - d4[e + 1])};
+                pA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2_trans(pv[0], pv[1]);
+                dA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2(ds[0], ds[1]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int o = (db * 32 + j) * LT2 + 16 * t + 4 * hi;
+                bO[t][db].u[0] = *(const uint2*)(sdOt[buf] + o); bO[t][db].u[1] = *(const uint2*)(sdOt[buf] + o + 8);
+                bQ[t][db].u[0] = *(const uint2*)(sQt[buf] + o);  bQ[t][db].u[1] = *(const uint2*)(sQt[buf] + o + 8);
+            }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {                    // A operands of tile it+1 (staged during step it-1 by both groups)
+            aQ[ks] = *(const bf16x8*)(sQ[nbuf] + j * LQ2 + ks * 16 + hi * 8);
+            aO[ks] = *(const bf16x8*)(sdO[nbuf] + j * LQ2 + ks * 16 + hi * 8);
+        }
+        stash(sbuf);                                       // tile it+2 -> the buffer tile it-1 left (its last reader: group 1's Y(it-1), two barriers ago)
+        fetch(min(it + 3, ntile - 1) * BT);                 // for Y(it+1)
+        TG_SB(); TG_BAR_LDS(); TG_SB();
+        buf = nbuf;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)                             // X tail: the last tile's dV / dK products
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            mfma_acc(dv[db], pA[t].v, bO[t][db].v);
+            mfma_acc(dk[db], dA[t].v, bQ[t][db].v);
+        }
+    if (grp == 0) TG_BAR_LDS();                             // pairs with group 1's extra barrier
     asm volatile("s_nop 15" ::: "memory");
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
@@ -1254,7 +1410,8 @@ extern "C" int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void*
     const dim3 gq((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), gk((unsigned)((nk + 255) / 256), (unsigned)(batch * heads));
     hipLaunchKernelGGL(attn_bwd_stats2_kernel, gq, dim3(256), 0, stream, pp.p);
     static const int dkdv_sel = [] { const char* e = getenv("TG_ATTN_BWD_DKDV"); return e ? atoi(e) : 5; }();   // 2: 64 keys per wave, 1 wave/SIMD; 3: 32 keys, 2 waves/SIMD; 4: 3 + three-deep LDS ring; 5: 4 as one 8-wave workgroup
-    if (dkdv_sel == 5) hipLaunchKernelGGL(attn_bwd_dkdv5_kernel, gk, dim3(512), 0, stream, pp);
+    if (dkdv_sel == 6) hipLaunchKernelGGL(attn_bwd_dkdv6_kernel, gk, dim3(512), 0, stream, pp);      // 6: 5 as a two-group ping-pong
+    else if (dkdv_sel == 5) hipLaunchKernelGGL(attn_bwd_dkdv5_kernel, gk, dim3(512), 0, stream, pp);
     else if (dkdv_sel == 4) hipLaunchKernelGGL(attn_bwd_dkdv4_kernel, dim3((unsigned)((nk + 127) / 128), (unsigned)(batch * heads)), dim3(256), 0, stream, pp);
     else if (dkdv_sel == 3) hipLaunchKernelGGL(attn_bwd_dkdv3_kernel, dim3((unsigned)((nk + 127) / 128), (unsigned)(batch * heads)), dim3(256), 0, stream, pp);
     else hipLaunchKernelGGL(attn_bwd_dkdv2_kernel, gk, dim3(256), 0, stream, pp);
