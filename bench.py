@@ -182,6 +182,41 @@ def run_e2e(a, rank, world, device, dist):
     ne = (torch.randn(1, 226, 4096, generator=g, device=device) * 0.1).to(bf)
     emb = torch.nn.functional.layer_norm(torch.randn(1, 4 * a.chunks, 8, 12, 3072, generator=g, device=device), (3072,))
     emb = emb.permute(0, 1, 4, 2, 3).to(bf).contiguous()         # [1, 4*chunks, 3072, 8, 12] as the T2To stage / Resampler hands it over
+    t_t2to, t2to_tokens = None, None
+    if a.mode == "gen":
+        # gen.yaml (BASELINE config 3): the condensed tokens come from the T2To stage — a second, patch-1 CogVideoX-5B DiT denoising
+        # [1, 4*chunks, 16, 8, 12] token latents over 52 steps with dynamic CFG, then de-normalisation + PCA inverse (pipeline_cogvideox_t2to.py:768-904).
+        # Every rank runs it (it is not sharded in the reference either: infer_cogvideo_mp_fifo.py runs it before the workers start).
+        from tokensgen_amd.pca import PCA
+        from tokensgen_amd.pipeline_t2to import LongVGenCogVideoXPipeline
+        from tokensgen_amd.transformer import CogVideoXTransformer3DModel
+        m2 = CogVideoXTransformer3DModel(num_attention_heads=48, attention_head_dim=64, num_layers=a.layers, time_embed_dim=512, text_embed_dim=4096,
+                                         patch_size=1, use_rotary_positional_embeddings=True, device=device)
+        g2 = torch.Generator(device=device).manual_seed(4321)
+        for name, t in m2._fused.items():
+            t.copy_(torch.randn(t.shape, generator=g2, device=device, dtype=torch.float32) * 0.02)
+            if name.endswith(("ln", "qknorm")):
+                t[0::2] += 1.0
+        sched2 = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
+        pipe2 = LongVGenCogVideoXPipeline(m2, sched2)
+        cg = torch.Generator().manual_seed(2)
+        pca = PCA()
+        qm, _ = torch.linalg.qr(torch.randn(3072, 16, generator=cg))
+        pca.register_buffer("mean_", torch.randn(1, 3072, generator=cg) * 0.1); pca.register_buffer("components_", qm.t().contiguous())
+        kw2 = dict(prompt_embeds=pe.cpu().float(), negative_prompt_embeds=ne.cpu().float(), height=8, width=12, num_frames_per_chunk=4, num_chunks=a.chunks,
+                   use_dynamic_cfg=True, guidance_scale=6.0, longvgen_mean=torch.randn(1, 16, generator=cg), longvgen_std=torch.rand(1, 16, generator=cg) + 0.5,
+                   longvgen_pca=pca)
+        pipe2(num_inference_steps=1, generator=torch.Generator().manual_seed(3), **kw2)          # warm-up (workspace, tables)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0g = time.perf_counter()
+        emb = pipe2(num_inference_steps=52, generator=torch.Generator().manual_seed(3), **kw2).frames.to(bf).contiguous()
+        torch.cuda.synchronize()
+        t_t2to, t2to_tokens = time.perf_counter() - t0g, 226 + 4 * a.chunks * 96
+        assert emb.shape == (1, 4 * a.chunks, 3072, 8, 12) and torch.isfinite(emb).all()
+        del pipe2, m2
+        torch.cuda.empty_cache()
     counts = {"fifo": 0}
     orig_plan = F.window_plan
 
@@ -202,6 +237,8 @@ def run_e2e(a, rank, world, device, dist):
     fence(); t_base = time.perf_counter() - t0
     orig, video, _ = F.cogvideo_fifo_mp_v2([pipe], base, noise_seed=7)
     fence(); dt = time.perf_counter() - t0
+    if t_t2to is not None:
+        dt += t_t2to                                              # the whole generation: T2To stage + To2V
     F.window_plan = orig_plan
     if dist is not None:
         tm = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -210,13 +247,15 @@ def run_e2e(a, rank, world, device, dist):
     if rank == 0:
         fwd = 52 + counts["fifo"]
         print(json.dumps({
-            "metric": "DiT denoising steps/sec/GPU END TO END (base stage + FIFO incl. ramp + sharded VAE decode), CogVideoX-5B To2V 720x480",
+            "metric": "DiT denoising steps/sec/GPU END TO END (" + ("T2To token stage + " if t_t2to is not None else "") +
+                      "base stage + FIFO incl. ramp + sharded VAE decode), CogVideoX-5B To2V 720x480",
             "value": fwd / dt / world, "unit": "steps/s/GPU", "n_gpus": world, "steps": fwd, "warmup": 0, "ms_per_step": 1e3 * dt / fwd,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic embeddings, random-init weights at CogVideoX-5B shapes",
             "config": {"workload": f"To2V end to end, {a.chunks} clip(s) of 49 frames: 52 base steps + {counts['fifo']} FIFO window-forwards "
                                    f"+ VAE decode of {a.chunks + 1} clips", "layers": a.layers, "chunks": a.chunks},
-            "seconds": {"total": dt, "base_stage": t_base, "fifo_and_decode": dt - t_base},
+            "seconds": {"total": dt, "base_stage": t_base, "fifo_and_decode": dt - t_base - (t_t2to or 0.0), "t2to_stage": t_t2to},
+            "t2to": None if t_t2to is None else {"tokens": t2to_tokens, "steps": 52, "ms_per_cfg_step": 1e3 * t_t2to / 52},
             "frames_out": list(video.shape), "finite": bool(torch.isfinite(video).all())}))
 
 
@@ -336,9 +375,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--layers", type=int, default=42, help="debug only: anything but 42 is not the benchmark")
-    ap.add_argument("--mode", choices=("window", "e2e", "train"), default="window",
+    ap.add_argument("--mode", choices=("window", "e2e", "gen", "train"), default="window",
                     help="window (default, the headline): steady-state FIFO window steps; e2e: one whole To2V run incl. ramp, base stage, VAE decode; "
-                         "train: To2V training micro-steps (BASELINE config 5)")
+                         "gen: e2e preceded by the T2To token stage (gen.yaml, BASELINE config 3); train: To2V training micro-steps (BASELINE config 5)")
     ap.add_argument("--accum", type=int, default=9, help="--mode train: gradient_accumulation_steps (yaml: 9)")
     ap.add_argument("--chunks", type=int, default=12, help="--mode e2e: number of 49-frame clips (edit.yaml: 12)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -372,8 +411,8 @@ def main():
     from tokensgen_amd.scheduler import CogVideoXDPMScheduler
     from tokensgen_amd import rope as R
     lib.load()
-    if a.mode in ("e2e", "train"):
-        (run_e2e if a.mode == "e2e" else run_train)(a, rank, world, device, dist)
+    if a.mode in ("e2e", "gen", "train"):
+        (run_train if a.mode == "train" else run_e2e)(a, rank, world, device, dist)
         if use_dist:
             dist.destroy_process_group()
         return
