@@ -9,8 +9,9 @@ timed region starts.
 
 N > 1 (one rank per GPU, RCCL; launched by torch.distributed.run, or — when RANK is not in the environment — by bench.py itself
 through tokensgen_amd.runtime.launch): every rank runs its own window of the same
-FIFO iteration (weak scaling, windows are independent) and the kept half-windows (7 latent frames + 7 x0
-frames per rank) are exchanged with ONE all_gather per step — the path's real exchange.
+FIFO iteration (weak scaling, windows are independent) and the window outputs are exchanged with ONE
+all_gather per step — the same message tokensgen_amd/fifo.py sends (2 x 13 frames per window + the rank's
+failure flag).
 
 Prints ONE JSON line (rank 0).
 """
@@ -444,15 +445,18 @@ def main():
     has_old = [nt > 0 for nt in next_t]
     grid_t = np.arange(nf, dtype=f32) + f32(start)
     cond_t = np.linspace(1000, 1016.25, 5, dtype=f32)
-    keep = torch.empty(2, 7, C, H, W, device=device, dtype=bf)
-    gathered = torch.empty(world * 2, 7, C, H, W, device=device, dtype=bf) if use_dist else None   # rank-major concat
+    # the exchange of tokensgen_amd/fifo.py:226-243, one window per rank: [x | x0] of the whole window + 8 elements carrying the failure flag
+    n_el = 2 * nf * C * H * W
+    xbuf = torch.zeros(n_el + 8, device=device, dtype=bf)
+    gathered = torch.empty(world * (n_el + 8), device=device, dtype=bf) if use_dist else None   # rank-major concat
 
     def step():
         noise = torch.randn(nf, 2, C, H, W, generator=g, device=device, dtype=torch.float32).to(bf)
         x, x0 = worker.window_step(latents, old_x0, has_old, t, prev_t, next_t, noise, grid_t, cond_t, emb)
         if use_dist:
-            keep[0].copy_(x[0, 6:]); keep[1].copy_(x0[6:])
-            dist.all_gather_into_tensor(gathered, keep)
+            buf = xbuf[:n_el].view(2, nf, C, H, W)
+            buf[0], buf[1] = x[0], x0
+            dist.all_gather_into_tensor(gathered, xbuf)
         return x
 
     def fence():
@@ -470,15 +474,31 @@ def main():
     K.PROFILE.clear(); K.PROFILE_FILTER[0] = {ATTN}; K.PROFILE_ON[0] = True
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        step()
+        x_last = step()
     fence()
     dt = time.perf_counter() - t0
     K.PROFILE_ON[0] = False
     attn_prof = K.profile_summary().get(ATTN, {"ms": float("nan"), "n": 0})
+    attn_path = model.attn_path                      # what the timed region ran on ("constant_shift" unless the retry counter said otherwise)
+    retry_ws = next(iter(model._ws.values())).retry
+    retried = retry_ws.count()
+    finite = bool(torch.isfinite(x_last).all())
     K.PROFILE.clear(); K.PROFILE_FILTER[0] = None; K.PROFILE_ON[0] = True
     step()
     fence()
     K.PROFILE_ON[0] = False
+    all_prof = K.profile_summary()
+    # the other attention path, one untimed step, so that the headline's dependence on the path is on the record
+    other = "running_max" if attn_path == "constant_shift" else "constant_shift"
+    model.attn_path = other
+    K.PROFILE.clear(); K.PROFILE_FILTER[0] = {ATTN}; K.PROFILE_ON[0] = True
+    t1 = time.perf_counter()
+    step()
+    fence()
+    other_step_ms = 1e3 * (time.perf_counter() - t1)
+    K.PROFILE_ON[0] = False
+    other_prof = K.profile_summary().get(ATTN, {"ms": float("nan"), "n": 0})
+    model.attn_path = attn_path
     rank_ms = [1e3 * dt / a.steps]
     if use_dist:
         mine = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -487,7 +507,7 @@ def main():
         rank_ms = [1e3 * v / a.steps for v in every.tolist()]
         dt = float(every.max().item())
     if rank == 0:
-        prof = K.profile_summary()
+        prof = all_prof
         attn = attn_prof
         attn_s = attn["ms"] * 1e-3
         achieved = ATTN_FLOP_PER_LAUNCH / attn_s / 1e12 if attn["n"] else float("nan")
@@ -508,7 +528,11 @@ def main():
             "step_mfma_frac": FLOP_PER_STEP * (a.layers / 42.0) * (a.steps / dt) / PEAK_BF16,
             "roofline": {"bound": "mfma", "kernel": "attn_fwd_pp_kernel (SDPA#1+#2 fused, SDPA#3 riding in the last round)", "achieved": achieved,
                          "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16 / 1e12), "traffic": traffic,
-                         "launch_ms": attn["ms"], "launches_timed": attn["n"]},
+                         "launch_ms": attn["ms"], "launches_timed": attn["n"], "attn_path": attn_path},
+            "attn_path": attn_path, "attn_retried_workgroups": retried, "finite": finite,
+            "roofline_other_attn_path": {"attn_path": other, "launch_ms": other_prof["ms"], "launches_timed": other_prof["n"],
+                                         "achieved": ATTN_FLOP_PER_LAUNCH / (other_prof["ms"] * 1e-3) / 1e12,
+                                         "frac": ATTN_FLOP_PER_LAUNCH / (other_prof["ms"] * 1e-3) / PEAK_BF16, "step_ms_one_untimed_step": other_step_ms},
             "kernel_ms": {k: round(v["ms"], 4) for k, v in prof.items()},
             "rank_ms_per_step": [round(v, 3) for v in rank_ms],
         }

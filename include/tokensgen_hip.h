@@ -109,6 +109,18 @@ int tg_qk_layernorm_rope_pair(void* xq, void* xk, long ld, long strideB, int tok
                               int start1, int len1, const float* cos1, const float* sin1, float q_scale, float k_scale,
                               hipStream_t stream);
 
+/* tg_qk_layernorm_rope_pair that also emits k_norm2_max[batch][heads] (fp32) = max over the tokens of the squared norm of the K rows AS
+ * STORED (after LayerNorm, rotation, k_scale and the bf16 rounding) — the key-side half of the Cauchy-Schwarz range bound the constant-
+ * shift softmax of tg_attention_fwd_multi uses (tg_attn_segment.k_norm2_max; the query-side half is taken from the Q rows inside the
+ * attention kernel).  Deterministic two-stage maximum (no atomics in global memory): ws >= tg_qk_kmax_ws_floats(tokens, heads, batch)
+ * floats of scratch; heads <= 128. */
+long tg_qk_kmax_ws_floats(int tokens, int heads, int batch);
+int tg_qk_layernorm_rope_pair_kmax(void* xq, void* xk, long ld, long strideB, int tokens, int heads, int batch,
+                                   const void* q_weight, const void* q_bias, const void* k_weight, const void* k_bias, float eps,
+                                   int start0, int len0, const float* cos0, const float* sin0,
+                                   int start1, int len1, const float* cos1, const float* sin1, float q_scale, float k_scale,
+                                   float* k_norm2_max, float* ws, hipStream_t stream);
+
 /* vt[b][h][d][j] = v[b*strideB + (key_start + j)*ld + h*64 + d] for j < n_keys, zero for n_keys <= j < ldvt.
  * Lays V out key-contiguous so the PV MFMA operands are plain 16-byte LDS reads (the "transpose" that
  * F.scaled_dot_product_attention does internally).  ldvt % 64 == 0, ldvt >= n_keys. */
@@ -142,13 +154,15 @@ typedef struct tg_attn_segment {
     const void* k; long k_ld, k_strideB;
     const void* vt; long vt_ld;
     int nk;
-    /* Optional (0 = unknown): an upper bound B on |q_i . k_j| in the units the kernel exponentiates (log2 domain; with k_prescaled the
-     * plain dot product).  The softmax is shift invariant, so when every segment of a k_prescaled launch carries a bound with 2 B < 96
-     * the kernel subtracts the CONSTANT B instead of a running row maximum — no per-tile max / rescale (the row-max chain was 15 % of the
-     * launch at the CogVideoX-5B shape) and no overflow or underflow is possible: s - B lies in [-2B, 0].  For this model the bound is
-     * static: q and k leave a per-head LayerNorm(64) (||x_hat|| <= 8) with affine (g, b) and a norm-preserving rotation, so
-     * |q . k| <= (8 max|g_q| + ||b_q||) (8 max|g_k| + ||b_k||) * out_scale_k.  Larger or missing bounds take the running-max path. */
-    float score_bound;
+    /* Optional (NULL = none): [batch][heads] fp32, an upper bound on max_j ||k_j||^2 over this segment's keys in the units the kernel
+     * exponentiates (k_prescaled launches: the squared norm of the stored K rows) — tg_qk_layernorm_rope_pair_kmax writes it.  When every
+     * segment of a k_prescaled launch carries one and a retry workspace is given, the 512-row kernel runs the CONSTANT-SHIFT softmax: each
+     * query row subtracts c = max(0, ||q_row|| sqrt(k_norm2_max) - 64) instead of tracking a running row maximum (the max chain / vote /
+     * rescale was 15 % of the launch at the CogVideoX-5B shape).  Valid for any weights: s - c <= 64 holds by Cauchy-Schwarz, so nothing can
+     * overflow; a row whose scores all sit far below c is caught by the epilogue's verification (row sum >= 2^-64) and its workgroup is
+     * recomputed with the running maximum by the retry launch that follows in the same call (attention_processor.py:2066-2069 semantics
+     * either way). */
+    const float* k_norm2_max;
 } tg_attn_segment;
 typedef struct tg_attn_problem {
     tg_attn_segment seg[2];
@@ -157,8 +171,13 @@ typedef struct tg_attn_problem {
     void* out; long out_ld, out_strideB;
     int nq;
 } tg_attn_problem;
+/* retry_ws (optional, with every segment's k_norm2_max: enables the constant-shift path): >= tg_attention_retry_ints(nq0, nq1, heads,
+ * batch) ints, zero-initialised ONCE by the caller and reusable by every later launch on the same stream; retry_ws[0] accumulates the
+ * number of workgroups that failed the verification and were recomputed (a host that sees it grow should stop passing retry_ws: the
+ * Cauchy-Schwarz shift is a poor range estimate for those weights and the running maximum is the right tool). */
+long tg_attention_retry_ints(int nq0, int nq1, int heads, int batch);
 int tg_attention_fwd_multi(const tg_attn_problem* problems, int nproblems, int heads, int batch, float scale, int k_prescaled,
-                           hipStream_t stream);
+                           int* retry_ws, long retry_ints, hipStream_t stream);
 
 /* emb[i][:] = bf16( [cos(t_i w_k) | sin(t_i w_k)] ), w_k = exp(-ln(1e4) k / (dim/2)), k < dim/2
  * (flip_sin_to_cos=True, freq_shift=0).  Replaces embeddings.py:28-79 + dit:678.  t: int64[n]. */

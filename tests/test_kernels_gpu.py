@@ -508,45 +508,63 @@ def test_attention_ragged_tile_split_at_launch_scale(K):
         assert _rel(out[:, rows, sl], ref) < 8e-3, h
 
 
+@pytest.mark.parametrize("gain", [1.0, 3.0, 8.0])
 @pytest.mark.parametrize("B,H,N1,NP", [(2, 2, 700, 70), (2, 48, 7 * 512 + 150, 480)])
-def test_attention_constant_shift_softmax(K, B, H, N1, NP):
-    """tg_attn_segment.score_bound: with a valid upper bound on |q . k| the ping-pong kernel subtracts a CONSTANT instead of a running row
-    maximum (no max chain / rescale).  The softmax is shift invariant, so the result must agree with the running-max path to rounding and
-    with fp32 torch to the usual tolerance — main problem with two key segments + the rider, prescaled keys.  The second shape is at launch
-    scale (>= 1024 ping-pong workgroups: the constant-shift kernel really runs); the first one reaches it in the forced child run of
-    test_attention_cases_again_on_the_pingpong_kernel.  A bound too large for the safe range (2 B >= 96) must fall back, not misbehave."""
+def test_attention_constant_shift_softmax(K, B, H, N1, NP, gain):
+    """tg_attn_segment.k_norm2_max + retry workspace: the 512-row kernel subtracts a per-row CONSTANT c = max(0, ||q|| max||k|| - 64) instead of
+    a running row maximum, for ANY LayerNorm weights (the round-2 bound came from the weights and silently fell back for
+    gains above ~1.7).  q / k come from the real K-norm kernel (tg_qk_layernorm_rope_pair_kmax) with gains `gain` * (1 +- 10 %):
+      gain 1: B ~ 12, c = 0 — safe by construction;  gain 3: B ~ 105, c ~ 40 — the fast path still engages, verified per row, nothing retried;
+      gain 8: B ~ 740 — every row's scores sit hundreds of units below c, the verification fails everywhere and the retry launch recomputes
+      every workgroup with the running maximum: bitwise the running-max result.
+    Main problem with two key segments + the rider.  The second shape is at launch scale (>= 1024 workgroups of 512 rows: the kernel really
+    runs); the first reaches it in the forced child run of test_attention_cases_again_on_the_pingpong_kernel."""
     BF = torch.bfloat16
     D, N = H * 64, N1 + NP
     kscale = 0.125 * 1.4426950408889634
-    qkv = _rand(B, N1, 3 * D, seed=71, scale=0.7)
-    qkvv = _rand(B, N, 3 * D, seed=72, scale=0.7)
-    qkv[:, :, D:2 * D] = (qkv[:, :, D:2 * D].float() * kscale).to(BF)          # what tg_qk_layernorm_rope(out_scale) leaves in K
-    qkvv[:, :, D:2 * D] = (qkvv[:, :, D:2 * D].float() * kscale).to(BF)
+    g = torch.Generator().manual_seed(5)
+    qkv = _rand(B, N1, 3 * D, seed=71)
+    qkvv = _rand(B, N, 3 * D, seed=72)
+    w = lambda: ((1.0 + 0.1 * torch.randn(64, generator=g)) * gain).to(BF).to(DEV)
+    bb = lambda: (0.1 * torch.randn(64, generator=g)).to(BF).to(DEV)
+    km1 = torch.zeros(B, H, dtype=torch.float32, device=DEV)
+    km2 = torch.zeros(B, H, dtype=torch.float32, device=DEV)
+    kws = K.kmax_workspace(N, H, B, DEV)
+    K.qk_layernorm_rope_pair(qkv[:, :, :D], qkv[:, :, D:2 * D], H, w(), bb(), w(), bb(), 1e-6, k_scale=kscale, kmax=km1, kmax_ws=kws)
+    K.qk_layernorm_rope_pair(qkvv[:, :, :D], qkvv[:, :, D:2 * D], H, w(), bb(), w(), bb(), 1e-6, k_scale=kscale, kmax=km2, kmax_ws=kws)
+    n2 = lambda t: t.float().reshape(t.shape[0], t.shape[1], H, 64).pow(2).sum(-1).amax(dim=1)       # [B, H] max_t ||row||^2 of the stored rows
+    assert torch.allclose(km1, n2(qkv[:, :, D:2 * D]), rtol=1e-5) and torch.allclose(km2, n2(qkvv[:, :, D:2 * D]), rtol=1e-5)
     pad = lambda n: (n + 63) // 64 * 64
     vt1 = torch.zeros(B, H, 64, pad(N1), dtype=BF, device=DEV); K.transpose_v(qkv[:, :, 2 * D:], H, 0, N1, vt1)
     vt2 = torch.zeros(B, H, 64, pad(NP), dtype=BF, device=DEV); K.transpose_v(qkvv[:, :, 2 * D:], H, N1, NP, vt2)
     vt3 = torch.zeros(B, H, 64, pad(N), dtype=BF, device=DEV); K.transpose_v(qkvv[:, :, 2 * D:], H, 0, N, vt3)
-    hn = lambda t: t.float().reshape(t.shape[0], t.shape[1], H, 64).norm(dim=-1).max().item()     # largest per-head row norm
-    b1 = hn(qkv[:, :, :D]) * hn(qkv[:, :, D:2 * D]) * 1.01
-    b2 = hn(qkvv[:, :, :D]) * hn(qkvv[:, :, D:2 * D]) * 1.01
-    assert 2 * max(b1, b2) < 96, "test data must sit inside the safe range"
+    retry = K.AttnRetry(N1, NP, H, B, DEV)
 
-    def run(bound1, bound2):
+    def run(fast):
         a = torch.zeros(B, N, D, dtype=BF, device=DEV)
         K.attention_multi(dict(q1=qkv[:, :, :D], k1=qkv[:, :, D:2 * D], vt1=vt1, nk1=N1, out=a[:, :N1], q2=qkvv[:, :N1, :D], k2=qkvv[:, N1:, D:2 * D],
-                               vt2=vt2, nk2=NP, seg2_scale=0.6, bound1=bound1, bound2=bound2),
-                          dict(q1=qkvv[:, N1:, :D], k1=qkvv[:, :, D:2 * D], vt1=vt3, nk1=N, out=a[:, N1:], bound1=bound2), H, 0.125, k_prescaled=True)
+                               vt2=vt2, nk2=NP, seg2_scale=0.6, kmax1=km1 if fast else None, kmax2=km2 if fast else None),
+                          dict(q1=qkvv[:, N1:, :D], k1=qkvv[:, :, D:2 * D], vt1=vt3, nk1=N, out=a[:, N1:], kmax1=km2 if fast else None), H, 0.125,
+                          k_prescaled=True, retry=retry if fast else None)
         return a
-    exact, fixed, toobig = run(0.0, 0.0), run(b1, b2), run(b1, 60.0)
-    assert torch.equal(toobig, exact)                          # 2 B >= 96 on one segment: the whole launch takes the running-max path
-    assert _rel(fixed, exact) < 4e-3                           # bounds < 40: the no-shift kernel (P = 2^s, no seed MFMAs)
-    shifted = run(44.0, 44.0)                                  # a (loose but valid) bound in [40, 48): the constant-shift kernel, P = 2^(s - 44)
-    assert _rel(shifted, exact) < 4e-3
+    exact, fast = run(False), run(True)
+    wgs = retry.ints - 1
+    on_pp = (N1 + 511) // 512 * H * B >= int(os.environ.get("TG_ATTN_PP_MIN_WG", "1024")) and os.environ.get("TG_ATTN_FIXEDM", "1") != "0"
+    assert int(retry.buf[1:].abs().sum().item()) == 0          # every raised flag was consumed by the retry launch
+    if not on_pp:
+        assert retry.count() == 0 and torch.equal(fast, exact)   # short query ranges: the 4-wave running-max kernel, bounds ignored
+    elif gain < 5:
+        assert retry.count() == 0                                # the constant-shift pass stood everywhere
+        assert not torch.equal(fast, exact)                      # ... and it IS a different kernel
+        assert _rel(fast, exact) < 4e-3
+    else:
+        assert retry.count() == wgs                              # verification failed everywhere -> recomputed with the running maximum
+        assert torch.equal(fast, exact)
     rows = torch.cat([torch.arange(0, 40), torch.arange(N1 - 40, N1)]).to(DEV)
     for h in sorted({0, H // 2, H - 1}):
         sl, ks, vs = slice(h * 64, h * 64 + 64), slice(D + h * 64, D + h * 64 + 64), slice(2 * D + h * 64, 2 * D + h * 64 + 64)
         sm = lambda q, k, v: torch.softmax(q.float() @ k.float().transpose(1, 2) * math.log(2.0), -1) @ v.float()
         ref = sm(qkv[:, rows, sl], qkv[:, :, ks], qkv[:, :, vs]) + 0.6 * sm(qkvv[:, rows, sl], qkvv[:, N1:, ks], qkvv[:, N1:, vs])
-        assert _rel(fixed[:, rows, sl], ref) < 8e-3, h
+        assert _rel(fast[:, rows, sl], ref) < 8e-3, h
         refv = sm(qkvv[:, N1:, sl], qkvv[:, :, ks], qkvv[:, :, vs])
-        assert _rel(fixed[:, N1:, sl], refv) < 8e-3, h
+        assert _rel(fast[:, N1:, sl], refv) < 8e-3, h

@@ -35,7 +35,7 @@ struct Seg {
     const bf16_t* k; long k_ld, k_sb;
     const bf16_t* vt; long vt_ld;
     int nk;
-    float bound;        // FIXEDM kernels: the constant subtracted from every score (bf16-representable upper bound on |q . k|)
+    const float* kn2;   // FIXEDM kernels: [batch][heads] upper bound on max_j ||k_j||^2 over this segment's keys (tg_attn_segment.k_norm2_max)
 };
 struct AttnParams {
     Seg s[2];
@@ -53,9 +53,13 @@ struct AttnParams {
     bf16_t* r_out; long r_o_ld, r_o_sb;
     int r_nq;
     int main_wgs;       // workgroups of the main problem (rider workgroups follow); 0 rider workgroups when r_nq == 0
+    int total_wgs;      // main + rider workgroups (the RETRY launch walks this list)
     // training forward only (tg_attention_fwd_lse; single segment, no rider): per query row the log-sum-exp of the scaled scores in the
     // log2 domain, [batch][heads][lse_rows] fp32 — what tg_attention_bwd otherwise recomputes with a pass of its own
     float* lse; long lse_rows;
+    // FIXEDM kernels: retry[0] counts workgroups that were re-run with the running maximum (cumulative), retry[1 + blockIdx.x] is the
+    // "this workgroup's constant-shift result had a row sum below 2^-64" flag the verification raises and the RETRY launch consumes
+    int* retry;
 };
 
 // plain fmaxf nests: clang fuses them to v_max3_f32 (built with -fno-honor-nans so MFMA outputs are not canonicalised by an
@@ -326,21 +330,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #endif
 __device__ long long tg_attn_dbg[16];   // TG_ATTN_TIMING: cycles {X work, X barrier wait, Y work, Y barrier wait} of block 0, waves 0 and 4
 
-// FIXEDM 1: every score has the segment's constant `bound` subtracted instead of a running row maximum (tg_attn_segment.score_bound);
-// FIXEDM 2: bounds below 40 need no shift at all — P = 2^s stays within 2^+-40 — so the four MFMAs that seed the accumulators go too
-template <bool PRESCALED, bool TIMING = false, int FIXEDM = 0, bool LSE = false>
+// FIXEDM 1 — constant-shift softmax, valid for ANY weights.  The softmax is shift invariant, so the running row maximum is only a RANGE
+// device.  Here every query row subtracts a constant c_row fixed before the first tile: with B_row = ||q_row|| * max_j ||k_j|| (Cauchy-
+// Schwarz; ||q_row|| from the Q fragments this lane already holds, max ||k||^2 per (batch, head) from the K-norm kernel,
+// tg_qk_layernorm_rope_pair_kmax) every score lies in [-B_row, B_row], and c_row = max(0, B_row - 64) gives s - c_row <= 64: P <= 2^64 and a
+// row sum <= 2^79 cannot overflow.  Underflow: for B_row <= 64 (c_row = 0, the case of LayerNorm gains around 1) the row maximum is >= -64
+// and nothing can go wrong by construction; for larger B_row a row whose scores ALL sit far below c_row could lose its sum, which the
+// epilogue VERIFIES (row sum >= 2^-64, i.e. the largest weight >= 2^-79: the terms flushed below 2^-126 are then < 2^-32 of the sum) —
+// a workgroup with a failing row raises its flag in p.retry and the RETRY launch (running maximum; a one-workgroup-per-CU grid that walks
+// the flag list) recomputes exactly those workgroups.  The per-tile max chain / vote / rescale (15 % of the launch) is gone from the hot loop.
+// FIXEDM 2: experiment — no shift at all and no seed MFMAs (measured slower than 1).
+template <bool PRESCALED, bool TIMING = false, int FIXEDM = 0, bool LSE = false, bool RETRY = false>
 __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
     // K[2], Vt[2] tiles (32 KiB) + the output staging area: 8 waves x 64 query rows x 128 B (64 KiB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr float RESCALE_THR = 8.0f;
     const int tid = threadIdx.x;
+    // one workgroup's work; `wgid` is its index in the (main + rider) workgroup list.  The ordinary launches run it once with
+    // wgid = blockIdx.x; the RETRY launch is a small persistent grid that walks the flag list (below)
+    auto body = [&](const int wgid) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;
     const int hi = lane >> 5, j = lane & 31;
 
-    const bool rider = p.r_nq > 0 && (int)blockIdx.x >= p.main_wgs;      // workgroup-uniform
-    const int bid = rider ? (int)blockIdx.x - p.main_wgs : (int)blockIdx.x;
+    const bool rider = p.r_nq > 0 && wgid >= p.main_wgs;      // workgroup-uniform
+    const int bid = rider ? wgid - p.main_wgs : wgid;
     const int nq_ = rider ? p.r_nq : p.nq;
     const int nseg_ = rider ? 1 : p.nseg;
     bf16_t* const out_ = rider ? p.r_out : p.out;
@@ -409,8 +424,28 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         bf16x8 ones = {0, 0, 0, 0, 0, 0, 0, 0}, negm[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
         if (hi == 0) {
             ones[0] = (bf16_t)0x3F80;
-            if (FIXEDM == 1) negm[0][0] = negm[1][0] = f32_to_bf16(-S.bound);  // the constant shift (bf16-representable by construction)
-            else if (PRESCALED) negm[0][0] = negm[1][0] = (bf16_t)0x4680; // +2^14 = -m
+            if (FIXEDM != 1 && PRESCALED) negm[0][0] = negm[1][0] = (bf16_t)0x4680; // +2^14 = -m
+        }
+        float cshift[2] = {0.f, 0.f};
+        if (FIXEDM == 1) {
+            const float kn2 = S.kn2[b * p.heads + h];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                float qn2 = 0.f;
+#pragma unroll
+                for (int kd = 0; kd < 4; ++kd)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float v = bf16_to_f32((bf16_t)qf[qb][kd][i]);
+                        qn2 += v * v;
+                    }
+                qn2 += __shfl_xor(qn2, 32, 64);                         // the partner lane holds the other 32 head channels of the row
+                const float B = sqrtf(qn2 * kn2) * 1.01f;              // 1 %: fp32 accumulation order of the dot products and of the norms
+                uint32_t u = __float_as_uint(fmaxf(B - 64.f, 0.f));
+                if (u & 0xffffu) u = (u + 0x10000u) & 0xffff0000u;     // round UP to a bf16-representable value: the MFMA seed is exactly -c
+                cshift[qb] = __uint_as_float(u);
+                if (hi == 0) negm[qb][0] = (bf16_t)((u >> 16) | 0x8000u);
+            }
         }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
@@ -419,7 +454,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             // tile's true row max — upward OR downward, so rows whose scores all sit below -126 do not underflow to l = 0 — with no
             // first-tile test in the hot loop (an explicit `t == 0` there cost 1.5-2 %).  Price: the first tile's 64 scores are
             // formed as s + 2^14 in fp32, i.e. to 2^-9 absolute (0.14 % on their weights, below the bf16 rounding of P).
-            m[qb] = FIXEDM == 2 ? 0.f : FIXEDM == 1 ? S.bound : PRESCALED ? -16384.f : -1e30f;
+            m[qb] = FIXEDM == 2 ? 0.f : FIXEDM == 1 ? cshift[qb] : PRESCALED ? -16384.f : -1e30f;
             l[qb] = 0.f;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
@@ -681,7 +716,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             PP_TICK(2);
             PP_BAR();
         }
-        if (TIMING && blockIdx.x == 0 && sg == 0 && (wave & 3) == 0 && lane == 0)
+        if (TIMING && wgid == 0 && sg == 0 && (wave & 3) == 0 && lane == 0)
             for (int i = 0; i < 4; ++i) tg_attn_dbg[grp * 4 + i] = tc[i];
 #undef PP_TICK
         pv(ntiles - 1);                                                            // X(nt): last P.V
@@ -700,7 +735,10 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
             const float w = (sg == 0 ? 1.f : p.seg2_scale) / lt;
             const int row = qb * 32 + j;
-            if (LSE && FIXEDM == 0 && hi == 0 && q0 + row < nq_) p.lse[((long)b * p.heads + h) * p.lse_rows + q0 + row] = m[qb] + log2f(lt);
+            if (LSE && hi == 0 && q0 + row < nq_) p.lse[((long)b * p.heads + h) * p.lse_rows + q0 + row] = m[qb] + log2f(lt);
+            if (FIXEDM == 1) {       // verification of the constant shift (see the kernel header); also catches a NaN / inf row sum
+                if (__any(!(lt >= 5.421011e-20f && lt < 3.0e38f)) && lane == 0) p.retry[1 + wgid] = 1;
+            }
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -732,6 +770,24 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         }
     }
 #undef PP_BAR
+    };
+    if constexpr (RETRY) {
+        // persistent retry grid (one workgroup per CU): re-run exactly the workgroups whose constant-shift pass raised its flag.  With no flag
+        // up — the normal case — this is a 256-workgroup launch that reads the flag list once and ends.
+        for (int w = blockIdx.x; w < p.total_wgs; w += gridDim.x) {
+            const int flagged = p.retry[1 + w];                // workgroup-uniform
+            if (!flagged) continue;
+            __syncthreads();                                   // every wave has read the flag before it is lowered
+            if (tid == 0) {
+                p.retry[1 + w] = 0;
+                atomicAdd(&p.retry[0], 1);
+            }
+            body(w);
+            __syncthreads();                                   // LDS is reused by the next flagged workgroup
+        }
+    } else {
+        body((int)blockIdx.x);
+    }
 }
 
 }  // namespace
@@ -793,32 +849,25 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
         TG_LAUNCH_CHECK(who);
         return TG_OK;
     }
-    // constant-shift softmax: every segment in the launch carries a usable bound (s - B in [-2B, 0] must stay far from the fp32 / bf16
-    // exponent limits: 2B < 96).  TG_ATTN_FIXEDM=0 forces the running-max path.
-    // 0: always the running max; 1 (default): constant shift through the seed MFMAs; 2: additionally the no-shift kernel for bounds < 40 —
-    // measured SLOWER than 1 (7.51 vs 7.10 ms in the DiT step, 7.59 for the running max): the four seed MFMAs sit under the first fragment
-    // reads' latency, and without them the matrix segment starts with a stall
+    // constant-shift softmax (attn_fwd_pp_kernel<.., FIXEDM = 1>): every segment of a k_prescaled launch carries the key-norm bound and the
+    // caller gave a retry workspace.  TG_ATTN_FIXEDM=0 forces the running-max kernel (bench.py reports both).
     static const int fixedm_on = [] { const char* e = getenv("TG_ATTN_FIXEDM"); return e ? atoi(e) : 1; }();
-    bool fixedm = fixedm_on && p.prescaled && pp && !timing;
-    auto usable = [&](Seg& S) {
-        if (!(S.bound > 0.f) || !(2.f * S.bound < 96.f)) return false;
-        uint32_t u;                                        // round UP to a bf16-representable value: the MFMA seed is then exactly -bound
-        memcpy(&u, &S.bound, 4);
-        if (u & 0xffffu) u = (u + 0x10000u) & 0xffff0000u;
-        memcpy(&S.bound, &u, 4);
-        return true;
-    };
-    for (int sg = 0; sg < p.nseg && fixedm; ++sg) fixedm = usable(p.s[sg]);
-    if (fixedm && p.r_nq > 0) fixedm = usable(p.r_s);
+    bool fixedm = fixedm_on && p.prescaled && pp && !timing && p.retry;
+    for (int sg = 0; sg < p.nseg && fixedm; ++sg) fixedm = p.s[sg].kn2 != nullptr;
+    if (fixedm && p.r_nq > 0) fixedm = p.r_s.kn2 != nullptr;
     p.main_wgs = (int)wg512;
     const long grid512 = wg512 + (p.r_nq > 0 ? (long)((p.r_nq + 511) / 512) * heads * batch : 0);
+    p.total_wgs = (int)grid512;
+    const unsigned retry_grid = (unsigned)(grid512 < n_cu ? grid512 : n_cu);
     constexpr size_t PP_LDS = 4 * TILE_B + 8 * 8192;
     static const bool pp_attr = [] {
         (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         return true;
     }();
     (void)pp_attr;
@@ -829,11 +878,14 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
         fprintf(stderr, "[tg_attention timing] g0: X %lld Xwait %lld Y %lld Ywait %lld | g1: X %lld Xwait %lld Y %lld Ywait %lld (s_memtime ticks, seg 0)\n",
                 h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     } else if (pp && fixedm) {
-        float bmax = p.s[0].bound;
-        if (p.nseg == 2) bmax = fmaxf(bmax, p.s[1].bound);
-        if (p.r_nq > 0) bmax = fmaxf(bmax, p.r_s.bound);
-        if (bmax < 40.f && fixedm_on == 2) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 2>), dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
-        else hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1>), dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
+        // the verified constant-shift pass, then the retry launch: a persistent grid that re-runs the flagged workgroups (normally none)
+        if (p.lse) {
+            hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1, true>), dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
+            hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 0, true, true>), dim3(retry_grid), dim3(512), PP_LDS, stream, p);
+        } else {
+            hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1>), dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
+            hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 0, false, true>), dim3(retry_grid), dim3(512), PP_LDS, stream, p);
+        }
     } else if (pp) {
         if (p.lse) {
             static bool attr_lse = false;
@@ -864,12 +916,16 @@ static int fill_segment(Seg& S, const tg_attn_segment& g, const char* what) {
     TG_REQUIRE(g.q_ld % 8 == 0 && g.k_ld % 8 == 0 && g.vt_ld % 64 == 0 && g.q_strideB % 8 == 0 && g.k_strideB % 8 == 0 && tg_aligned16(g.q) &&
                tg_aligned16(g.k) && tg_aligned16(g.vt), TG_ERR_ALIGN, "tg_attention: %s alignment", what);
     TG_REQUIRE(g.vt_ld >= ((g.nk + 63) / 64) * 64, TG_ERR_SHAPE, "tg_attention: %s: vt_ld must cover nk rounded up to 64", what);
-    S = Seg{(const bf16_t*)g.q, g.q_ld, g.q_strideB, (const bf16_t*)g.k, g.k_ld, g.k_strideB, (const bf16_t*)g.vt, g.vt_ld, g.nk, g.score_bound};
+    S = Seg{(const bf16_t*)g.q, g.q_ld, g.q_strideB, (const bf16_t*)g.k, g.k_ld, g.k_strideB, (const bf16_t*)g.vt, g.vt_ld, g.nk, g.k_norm2_max};
     return TG_OK;
 }
 
+extern "C" long tg_attention_retry_ints(int nq0, int nq1, int heads, int batch) {
+    return 1 + (long)((nq0 + 511) / 512 + (nq1 > 0 ? (nq1 + 511) / 512 : 0)) * heads * batch;
+}
+
 extern "C" int tg_attention_fwd_multi(const tg_attn_problem* problems, int nproblems, int heads, int batch, float scale, int k_prescaled,
-                                      hipStream_t stream) {
+                                      int* retry_ws, long retry_ints, hipStream_t stream) {
     TG_REQUIRE(problems && (nproblems == 1 || nproblems == 2), TG_ERR_ARG, "tg_attention_fwd_multi: 1 or 2 problems");
     TG_REQUIRE(heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_attention_fwd_multi: bad shape");
     const tg_attn_problem& A = problems[0];
@@ -890,6 +946,12 @@ extern "C" int tg_attention_fwd_multi(const tg_attn_problem* problems, int nprob
         if ((rc = fill_segment(p.r_s, B.seg[0], "problem 1"))) return rc;
         p.r_out = (bf16_t*)B.out; p.r_o_ld = B.out_ld; p.r_o_sb = B.out_strideB; p.r_nq = B.nq;
     }
+    if (retry_ws) {
+        TG_REQUIRE(retry_ints >= tg_attention_retry_ints(p.nq, p.r_nq, heads, batch), TG_ERR_SHAPE,
+                   "tg_attention_fwd_multi: retry workspace of %ld ints, need %ld (tg_attention_retry_ints)", retry_ints,
+                   tg_attention_retry_ints(p.nq, p.r_nq, heads, batch));
+        p.retry = retry_ws;
+    }
     return attention_launch(p, scale, k_prescaled, "tg_attention_fwd_multi", stream);
 }
 
@@ -902,16 +964,16 @@ extern "C" int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
     TG_REQUIRE(q1 && k1 && vt1 && out, TG_ERR_ARG, "tg_attention_fwd: null pointer");
     TG_REQUIRE(nq > 0 && nk1 > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_attention_fwd: bad shape nq=%d nk1=%d", nq, nk1);
     tg_attn_problem A{};
-    A.seg[0] = tg_attn_segment{q1, q1_ld, q1_strideB, k1, k1_ld, k1_strideB, vt1, vt1_ld, nk1, 0.f};
+    A.seg[0] = tg_attn_segment{q1, q1_ld, q1_strideB, k1, k1_ld, k1_strideB, vt1, vt1_ld, nk1, nullptr};
     A.nseg = 1;
     if (q2) {
         TG_REQUIRE(k2 && vt2 && nk2 > 0, TG_ERR_ARG, "tg_attention_fwd: segment 2 incomplete");
-        A.seg[1] = tg_attn_segment{q2, q2_ld, q2_strideB, k2, k2_ld, k2_strideB, vt2, vt2_ld, nk2, 0.f};
+        A.seg[1] = tg_attn_segment{q2, q2_ld, q2_strideB, k2, k2_ld, k2_strideB, vt2, vt2_ld, nk2, nullptr};
         A.nseg = 2;
     }
     A.seg2_scale = seg2_scale;
     A.out = out; A.out_ld = out_ld; A.out_strideB = out_strideB; A.nq = nq;
-    return tg_attention_fwd_multi(&A, 1, heads, batch, scale, k_prescaled, stream);
+    return tg_attention_fwd_multi(&A, 1, heads, batch, scale, k_prescaled, nullptr, 0, stream);
 }
 
 extern "C" int tg_attention_fwd_lse(const void* q, long q_ld, long q_strideB, const void* k, long k_ld, long k_strideB, const void* vt, long vt_ld, int nk,
@@ -920,7 +982,7 @@ extern "C" int tg_attention_fwd_lse(const void* q, long q_ld, long q_strideB, co
     TG_REQUIRE(nq > 0 && nk > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_attention_fwd_lse: bad shape nq=%d nk=%d", nq, nk);
     TG_REQUIRE(out_ld % 8 == 0 && out_strideB % 8 == 0 && tg_aligned16(out), TG_ERR_ALIGN, "tg_attention_fwd_lse: output alignment (16 B)");
     AttnParams p{};
-    const tg_attn_segment g{q, q_ld, q_strideB, k, k_ld, k_strideB, vt, vt_ld, nk, 0.f};
+    const tg_attn_segment g{q, q_ld, q_strideB, k, k_ld, k_strideB, vt, vt_ld, nk, nullptr};
     int rc = fill_segment(p.s[0], g, "segment");
     if (rc) return rc;
     p.nseg = 1;

@@ -92,8 +92,9 @@ __global__ __launch_bounds__(256) void adaln_kernel(const bf16_t* __restrict__ x
 // 8 lanes per (token, head) row, 8 elements (16 B) per lane.
 // ------------------------------------------------------------------------------------------------
 // one (token, head) slice of 8 elements per lane: LayerNorm over the 8-lane group, affine, bf16 rounding, RoPE, scale, store
-__device__ __forceinline__ void qk_norm_rope_slice(bf16_t* p, const bf16_t* __restrict__ w, const bf16_t* __restrict__ bvec, int part,
-                                                   float eps, bool rope, const float (&c)[8], const float (&sv)[8], float out_scale, bool live) {
+// returns the sum of squares of the 8 values as STORED (bf16-rounded, scaled): an 8-lane partial of the row's squared norm
+__device__ __forceinline__ float qk_norm_rope_slice(bf16_t* p, const bf16_t* __restrict__ w, const bf16_t* __restrict__ bvec, int part,
+                                                    float eps, bool rope, const float (&c)[8], const float (&sv)[8], float out_scale, bool live) {
     const uint4 raw = *(const uint4*)p;
     const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
     float v[8];
@@ -126,19 +127,30 @@ __device__ __forceinline__ void qk_norm_rope_slice(bf16_t* p, const bf16_t* __re
             v[2 * i + 1] = bb * c[2 * i + 1] + a * sv[2 * i + 1];
         }
     }
-    if (live) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] *= out_scale;    // 1, or softmax_scale*log2(e) folded into K before its single bf16 rounding
-        uint4 o;
-        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-        o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-        *(uint4*)p = o;
+    for (int i = 0; i < 8; ++i) v[i] *= out_scale;    // 1, or softmax_scale*log2(e) folded into K before its single bf16 rounding
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    if (live) *(uint4*)p = o;
+    const uint32_t ou[4] = {o.x, o.y, o.z, o.w};
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = bf16lo_to_f32(ou[i]), bq = bf16hi_to_f32(ou[i]);
+        ss += a * a + bq * bq;
     }
+    return ss;
 }
 
 // x2 != nullptr: the k columns of the same rows get the same treatment in the same launch (their own affine and scale): the
 // rotary table slice (64 B per lane, 4x the size of the data slice) is fetched once for q and k
-template <int HPG>   // heads per 8-lane group: the token's table slice stays in registers while the group walks HPG heads
+// STATS: additionally max_t ||k_t||^2 per (batch, head) of the rows as stored (the constant-shift softmax of tg_attention_fwd_multi needs
+// an upper bound on the key norms, tg_attn_segment.k_norm2_max).  Deterministic two-stage reduction, no global atomics: the grid is
+// (row blocks, batch), a workgroup folds its <= 32 (token, head group) rows into an LDS table of per-head maxima (ds_max_u32 on the
+// float bits — non-negative floats order like unsigned integers) and writes one row of `partial[batch][row block][heads]`;
+// qk_kmax_finalize_kernel takes the column maxima.
+template <int HPG, bool STATS = false>   // heads per 8-lane group: the token's table slice stays in registers while the group walks HPG heads
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ x, bf16_t* __restrict__ x2, long ld, long sb, int tokens,
                                                            int heads, int batch, const bf16_t* __restrict__ w,
                                                            const bf16_t* __restrict__ bvec, const bf16_t* __restrict__ w2,
@@ -146,17 +158,24 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
                                                            int start0, int len0, const float* __restrict__ cos0,
                                                            const float* __restrict__ sin0, int start1, int len1,
                                                            const float* __restrict__ cos1,
-                                                           const float* __restrict__ sin1, float out_scale, float out_scale2) {
+                                                           const float* __restrict__ sin1, float out_scale, float out_scale2,
+                                                           float* __restrict__ partial) {
+    __shared__ unsigned smax[STATS ? 128 : 1];
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const int part = (int)(gid & 7);
-    const long rowid = gid >> 3;                       // (b, t, head group)
     const int hgroups = heads / HPG;
-    const long total = (long)batch * tokens * hgroups;
+    // STATS: blockIdx.y is the batch item and rows are counted inside it; otherwise one flat row index over (b, t, head group)
+    const long rowid = gid >> 3;
+    const long total = STATS ? (long)tokens * hgroups : (long)batch * tokens * hgroups;
     const bool live = rowid < total;
     const long rid = live ? rowid : total - 1;
     const int h0 = (int)(rid % hgroups) * HPG;
     const long bt = rid / hgroups;
-    const int t = (int)(bt % tokens), b = (int)(bt / tokens);
+    const int t = (int)(bt % tokens), b = STATS ? (int)blockIdx.y : (int)(bt / tokens);
+    if (STATS) {
+        if (threadIdx.x < 128) smax[threadIdx.x] = 0u;
+        __syncthreads();
+    }
     const float* cs = nullptr;
     const float* sn = nullptr;
     if (t >= start0 && t < start0 + len0) {
@@ -177,8 +196,33 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
     for (int hh = 0; hh < HPG; ++hh) {
         const long off = (long)b * sb + (long)t * ld + (h0 + hh) * 64 + part * 8;
         qk_norm_rope_slice(x + off, w, bvec, part, eps, cs != nullptr, c, sv, out_scale, live);
-        if (x2) qk_norm_rope_slice(x2 + off, w2, bvec2, part, eps, cs != nullptr, c, sv, out_scale2, live);
+        if (x2) {
+            float ss = qk_norm_rope_slice(x2 + off, w2, bvec2, part, eps, cs != nullptr, c, sv, out_scale2, live);
+            if (STATS) {
+                ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+                if (part == 0 && live) atomicMax(&smax[h0 + hh], __float_as_uint(ss));
+            }
+        }
     }
+    if (STATS) {
+        __syncthreads();
+        if ((int)threadIdx.x < heads)
+            partial[((long)b * gridDim.x + blockIdx.x) * heads + threadIdx.x] = __uint_as_float(smax[threadIdx.x]);
+    }
+}
+
+// kmax[b][h] = max over the row blocks of partial[b][.][h]; one workgroup per (head, batch)
+__global__ __launch_bounds__(256) void qk_kmax_finalize_kernel(const float* __restrict__ partial, int nblocks, int heads, float* __restrict__ kmax) {
+    __shared__ float red[4];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const float* src = partial + (long)b * nblocks * heads + h;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) m = fmaxf(m, src[(long)i * heads]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) kmax[b * heads + h] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -247,7 +291,8 @@ extern "C" int tg_adaln_modulate(const void* x, long ldx, long strideX, void* y,
 
 static int qk_norm_rope_launch(void* xq, void* xk, long ld, long strideB, int tokens, int heads, int batch, const void* wq, const void* bq,
                                const void* wk, const void* bk, float eps, int start0, int len0, const float* cos0, const float* sin0,
-                               int start1, int len1, const float* cos1, const float* sin1, float q_scale, float k_scale, hipStream_t stream) {
+                               int start1, int len1, const float* cos1, const float* sin1, float q_scale, float k_scale, hipStream_t stream,
+                               float* k_norm2_max = nullptr, float* ws = nullptr) {
     TG_REQUIRE(xq && wq && bq && (!xk || (wk && bk)), TG_ERR_ARG, "tg_qk_layernorm_rope: null pointer");
     TG_REQUIRE(tokens > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_qk_layernorm_rope: bad shape");
     TG_REQUIRE(ld % 8 == 0 && strideB % 8 == 0 && tg_aligned16(xq) && (!xk || tg_aligned16(xk)), TG_ERR_ALIGN,
@@ -258,11 +303,28 @@ static int qk_norm_rope_launch(void* xq, void* xk, long ld, long strideB, int to
     TG_REQUIRE(len0 >= 0 && len1 >= 0 && start0 >= 0 && start1 >= 0 && start0 + len0 <= tokens && start1 + len1 <= tokens,
                TG_ERR_SHAPE, "tg_qk_layernorm_rope: rope segment outside the token range");
     const int hpg = heads % 4 == 0 ? 4 : heads % 2 == 0 ? 2 : 1;
+    if (k_norm2_max) {
+        TG_REQUIRE(xk && ws, TG_ERR_ARG, "tg_qk_layernorm_rope_pair_kmax: needs the k columns and a workspace");
+        TG_REQUIRE(heads <= 128, TG_ERR_SHAPE, "tg_qk_layernorm_rope_pair_kmax: heads=%d > 128", heads);
+        const long rows = (long)tokens * (heads / hpg);            // per batch item
+        const unsigned nblk = (unsigned)((rows * 8 + 255) / 256);
+#define TG_QK_LAUNCH_S(H_)                                                                                                                \
+    hipLaunchKernelGGL((qk_norm_rope_kernel<H_, true>), dim3(nblk, (unsigned)batch), dim3(256), 0, stream, (bf16_t*)xq, (bf16_t*)xk, ld,    \
+                       strideB, tokens, heads, batch, (const bf16_t*)wq, (const bf16_t*)bq, (const bf16_t*)wk, (const bf16_t*)bk, eps,     \
+                       start0, len0, cos0, sin0, start1, len1, cos1, sin1, q_scale, k_scale, ws)
+        if (hpg == 4) TG_QK_LAUNCH_S(4); else if (hpg == 2) TG_QK_LAUNCH_S(2); else TG_QK_LAUNCH_S(1);
+#undef TG_QK_LAUNCH_S
+        TG_LAUNCH_CHECK("tg_qk_layernorm_rope_pair_kmax");
+        hipLaunchKernelGGL(qk_kmax_finalize_kernel, dim3((unsigned)heads, (unsigned)batch), dim3(256), 0, stream, (const float*)ws, (int)nblk, heads,
+                           k_norm2_max);
+        TG_LAUNCH_CHECK("tg_qk_layernorm_rope_pair_kmax (finalize)");
+        return TG_OK;
+    }
     const long threads = (long)batch * tokens * (heads / hpg) * 8;
 #define TG_QK_LAUNCH(H_)                                                                                                                 \
     hipLaunchKernelGGL(qk_norm_rope_kernel<H_>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (bf16_t*)xq, (bf16_t*)xk, ld, \
                        strideB, tokens, heads, batch, (const bf16_t*)wq, (const bf16_t*)bq, (const bf16_t*)wk, (const bf16_t*)bk, eps,     \
-                       start0, len0, cos0, sin0, start1, len1, cos1, sin1, q_scale, k_scale)
+                       start0, len0, cos0, sin0, start1, len1, cos1, sin1, q_scale, k_scale, (float*)nullptr)
     if (hpg == 4) TG_QK_LAUNCH(4); else if (hpg == 2) TG_QK_LAUNCH(2); else TG_QK_LAUNCH(1);
 #undef TG_QK_LAUNCH
     TG_LAUNCH_CHECK("tg_qk_layernorm_rope");
@@ -286,6 +348,22 @@ extern "C" int tg_qk_layernorm_rope_pair(void* xq, void* xk, long ld, long strid
     TG_REQUIRE(xk, TG_ERR_ARG, "tg_qk_layernorm_rope_pair: null pointer");
     return qk_norm_rope_launch(xq, xk, ld, strideB, tokens, heads, batch, q_weight, q_bias, k_weight, k_bias, eps, start0, len0, cos0, sin0,
                                start1, len1, cos1, sin1, q_scale, k_scale, stream);
+}
+
+extern "C" long tg_qk_kmax_ws_floats(int tokens, int heads, int batch) {
+    const int hpg = heads % 4 == 0 ? 4 : heads % 2 == 0 ? 2 : 1;
+    const long rows = (long)tokens * (heads / hpg);
+    return ((rows * 8 + 255) / 256) * heads * batch;
+}
+
+extern "C" int tg_qk_layernorm_rope_pair_kmax(void* xq, void* xk, long ld, long strideB, int tokens, int heads, int batch,
+                                              const void* q_weight, const void* q_bias, const void* k_weight, const void* k_bias, float eps,
+                                              int start0, int len0, const float* cos0, const float* sin0,
+                                              int start1, int len1, const float* cos1, const float* sin1, float q_scale, float k_scale,
+                                              float* k_norm2_max, float* ws, hipStream_t stream) {
+    TG_REQUIRE(xk && k_norm2_max && ws, TG_ERR_ARG, "tg_qk_layernorm_rope_pair_kmax: null pointer");
+    return qk_norm_rope_launch(xq, xk, ld, strideB, tokens, heads, batch, q_weight, q_bias, k_weight, k_bias, eps, start0, len0, cos0, sin0,
+                               start1, len1, cos1, sin1, q_scale, k_scale, stream, k_norm2_max, ws);
 }
 
 extern "C" int tg_transpose_v(const void* v, long ld, long strideB, int key_start, int n_keys, int heads, int batch,

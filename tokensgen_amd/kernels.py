@@ -194,8 +194,16 @@ def qk_layernorm_rope(x, heads, ln_weight, ln_bias, eps, seg0=None, seg1=None, o
     return x
 
 
-def qk_layernorm_rope_pair(xq, xk, heads, q_weight, q_bias, k_weight, k_bias, eps, seg0=None, seg1=None, q_scale=1.0, k_scale=1.0):
-    """qk_layernorm_rope on the q and the k column slices of the same fused buffer in one launch (rotary tables read once)."""
+def kmax_workspace(tokens, heads, batch, device):
+    """Scratch for qk_layernorm_rope_pair(kmax=...): fp32 [tg_qk_kmax_ws_floats]."""
+    return torch.empty(L.load().tg_qk_kmax_ws_floats(tokens, heads, batch), dtype=torch.float32, device=device)
+
+
+def qk_layernorm_rope_pair(xq, xk, heads, q_weight, q_bias, k_weight, k_bias, eps, seg0=None, seg1=None, q_scale=1.0, k_scale=1.0,
+                           kmax=None, kmax_ws=None):
+    """qk_layernorm_rope on the q and the k column slices of the same fused buffer in one launch (rotary tables read once).
+    kmax (fp32 [B, heads], with kmax_ws from kmax_workspace): also receives max_t ||k_t||^2 of the stored K rows — the key-side range
+    bound of the constant-shift attention (tg_qk_layernorm_rope_pair_kmax)."""
     _chk(xq, "xq"); _chk(xk, "xk")
     B, T, HD, ld, sb = _bmk(xq)
     assert HD == heads * 64 and _bmk(xk) == (B, T, HD, ld, sb)
@@ -209,6 +217,13 @@ def qk_layernorm_rope_pair(xq, xk, heads, q_weight, q_bias, k_weight, k_bias, ep
         return int(start), int(cos.shape[0]), cos, sin
     s0, l0, c0, n0 = unpack(seg0)
     s1, l1, c1, n1 = unpack(seg1)
+    if kmax is not None:
+        _chk(kmax, "kmax", torch.float32); _chk(kmax_ws, "kmax_ws", torch.float32)
+        assert kmax.is_contiguous() and kmax.shape == (B, heads) and kmax_ws.numel() >= L.load().tg_qk_kmax_ws_floats(T, heads, B)
+        L.check(_launch("qk_layernorm_rope_pair", L.load().tg_qk_layernorm_rope_pair_kmax, _p(xq), _p(xk), ld, sb, T, heads, B, _p(q_weight), _p(q_bias),
+                        _p(k_weight), _p(k_bias), float(eps), s0, l0, _p(c0), _p(n0), s1, l1, _p(c1), _p(n1), float(q_scale), float(k_scale),
+                        _p(kmax), _p(kmax_ws), _stream()), "tg_qk_layernorm_rope_pair_kmax")
+        return xq, xk
     L.check(_launch("qk_layernorm_rope_pair", L.load().tg_qk_layernorm_rope_pair, _p(xq), _p(xk), ld, sb, T, heads, B, _p(q_weight), _p(q_bias),
                     _p(k_weight), _p(k_bias), float(eps), s0, l0, _p(c0), _p(n0), s1, l1, _p(c1), _p(n1), float(q_scale), float(k_scale),
                     _stream()), "tg_qk_layernorm_rope_pair")
@@ -282,39 +297,83 @@ def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, acc
     return dq, dk, dv
 
 
-def _attn_problem(q1, k1, vt1, nk1, out, q2=None, k2=None, vt2=None, nk2=0, seg2_scale=0.0, bound1=0.0, bound2=0.0):
-    import ctypes
+def _attn_problem(q1, k1, vt1, nk1, out, q2=None, k2=None, vt2=None, nk2=0, seg2_scale=0.0, kmax1=None, kmax2=None):
     for n, t in (("q1", q1), ("k1", k1), ("vt1", vt1), ("out", out)):
         _chk(t, n)
     pr = L.AttnProblem()
     B, nq, _, qld, qsb = _bmk(q1)
     _, _, _, kld, ksb = _bmk(k1)
     _, _, _, old, osb = _bmk(out)
-    pr.seg[0] = L.AttnSegment(_p(q1), qld, qsb, _p(k1), kld, ksb, _p(vt1), vt1.stride(2), nk1, float(bound1))
+    for km in (kmax1, kmax2):
+        if km is not None:
+            _chk(km, "kmax", torch.float32)
+            assert km.is_contiguous() and km.shape[0] == B
+    pr.seg[0] = L.AttnSegment(_p(q1), qld, qsb, _p(k1), kld, ksb, _p(vt1), vt1.stride(2), nk1, _p(kmax1) or None)
     pr.nseg = 1
     if q2 is not None:
         _chk(q2, "q2"); _chk(k2, "k2"); _chk(vt2, "vt2")
         _, _, _, q2ld, q2sb = _bmk(q2)
         _, _, _, k2ld, k2sb = _bmk(k2)
-        pr.seg[1] = L.AttnSegment(_p(q2), q2ld, q2sb, _p(k2), k2ld, k2sb, _p(vt2), vt2.stride(2), nk2, float(bound2))
+        pr.seg[1] = L.AttnSegment(_p(q2), q2ld, q2sb, _p(k2), k2ld, k2sb, _p(vt2), vt2.stride(2), nk2, _p(kmax2) or None)
         pr.nseg = 2
     pr.seg2_scale = float(seg2_scale)
     pr.out, pr.out_ld, pr.out_strideB, pr.nq = _p(out), old, osb, nq
     return pr, B
 
 
-def attention_multi(main, rider, heads, scale, k_prescaled=False):
-    """One launch for two attention problems of the same heads/batch (tg_attention_fwd_multi).  main / rider: dicts of the
-    keyword arguments of `attention` (q1, k1, vt1, nk1, out [, q2, k2, vt2, nk2, seg2_scale, bound1, bound2]); the rider has one key segment.
-    bound1 / bound2: optional upper bounds on |q . k| per segment (tg_attn_segment.score_bound): the constant-shift softmax path."""
+class AttnRetry:
+    """Retry workspace of the constant-shift attention path (tg_attention_fwd_multi retry_ws): one int32 buffer per model, sized for its
+    largest launch, zeroed once.  `count()` = workgroups recomputed with the running maximum so far (a device read: diagnostics / tests);
+    `poll()` is the non-blocking form the model uses to notice weights for which the shift estimate keeps failing."""
+
+    def __init__(self, nq0, nq1, heads, batch, device):
+        self.ints = int(L.load().tg_attention_retry_ints(nq0, nq1, heads, batch))
+        self.buf = torch.zeros(self.ints, dtype=torch.int32, device=device)
+        self._host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._event = None
+
+    def fits(self, nq0, nq1, heads, batch):
+        return L.load().tg_attention_retry_ints(nq0, nq1, heads, batch) <= self.ints
+
+    def count(self):
+        return int(self.buf[0].item())
+
+    def poll(self, tag):
+        """Non-blocking read of the counter: returns (value, tag given when that copy was queued) once a queued copy has landed, else
+        None; queues the next copy on the current stream when none is pending."""
+        val = None
+        if self._event is not None and self._event.query():
+            val = (int(self._host[0]), self._tag)
+            self._event = None
+        if self._event is None:
+            self._host.copy_(self.buf[:1], non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+            self._tag = tag
+        return val
+
+
+def attention_multi(main, rider, heads, scale, k_prescaled=False, retry=None):
+    """One launch for one or two attention problems of the same heads/batch (tg_attention_fwd_multi).  main / rider: dicts of the
+    keyword arguments of `attention` (q1, k1, vt1, nk1, out [, q2, k2, vt2, nk2, seg2_scale, kmax1, kmax2]); the rider (may be None) has one
+    key segment.  kmax1 / kmax2 (fp32 [B, heads], from qk_layernorm_rope_pair(kmax=...)) on every segment + retry (AttnRetry): the
+    constant-shift softmax path (tg_attn_segment.k_norm2_max)."""
     import ctypes
     pa, B = _attn_problem(**main)
-    pb, B2 = _attn_problem(**rider)
-    assert B == B2
-    arr = (L.AttnProblem * 2)(pa, pb)
-    L.check(_launch("attention_2seg+rider", L.load().tg_attention_fwd_multi, ctypes.addressof(arr), 2, heads, B, float(scale),
-                    1 if k_prescaled else 0, _stream()), "tg_attention_fwd_multi")
-    return main["out"], rider["out"]
+    n = 1
+    if rider is not None:
+        pb, B2 = _attn_problem(**rider)
+        assert B == B2
+        arr = (L.AttnProblem * 2)(pa, pb)
+        n = 2
+    else:
+        arr = (L.AttnProblem * 1)(pa)
+    if retry is not None:
+        assert retry.fits(main["q1"].shape[1], rider["q1"].shape[1] if rider is not None else 0, heads, B)
+    L.check(_launch("attention_2seg+rider" if n == 2 else f"attention_multi1_nq{pa.nq}", L.load().tg_attention_fwd_multi, ctypes.addressof(arr), n, heads, B,
+                    float(scale), 1 if k_prescaled else 0, _p(retry.buf) if retry is not None else None, retry.ints if retry is not None else 0,
+                    _stream()), "tg_attention_fwd_multi")
+    return main["out"], (rider["out"] if rider is not None else None)
 
 
 def timestep_sinusoid(t, dim, out):

@@ -26,10 +26,11 @@ PROTOTYPES = {
     "tg_adaln_modulate": [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _f, _i, _i, _i, _i, C.POINTER(GroupTable), _vp],
     "tg_qk_layernorm_rope": [_vp, _l, _l, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _vp],
     "tg_qk_layernorm_rope_pair": [_vp, _vp, _l, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _f, _vp],
+    "tg_qk_layernorm_rope_pair_kmax": [_vp, _vp, _l, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp],
     "tg_transpose_v": [_vp, _l, _l, _i, _i, _i, _i, _vp, _l, _vp],
     "tg_attention_fwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _f, _vp, _l, _l,
                          _i, _i, _i, _f, _i, _vp],
-    "tg_attention_fwd_multi": [_vp, _i, _i, _i, _f, _i, _vp],
+    "tg_attention_fwd_multi": [_vp, _i, _i, _i, _f, _i, _vp, _l, _vp],
     "tg_attention_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l,
                          _i, _i, _i, _i, _f, _i, _vp, _vp, _vp],
     "tg_attention_fwd_lse": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp, _l, _l, _i, _i, _i, _f, _vp, _vp],
@@ -69,6 +70,8 @@ QUERIES = {
     "tg_conv3d_gn_partial_floats": [C.c_int, C.c_int, C.c_int],
     "tg_conv3d_splitk_floats": [C.c_int] * 9,
     "tg_attention_bwd_ws_floats": [C.c_int, C.c_int, C.c_int, C.c_int],
+    "tg_attention_retry_ints": [C.c_int, C.c_int, C.c_int, C.c_int],
+    "tg_qk_kmax_ws_floats": [C.c_int, C.c_int, C.c_int],
     "tg_qk_layernorm_rope_bwd_partial_floats": [C.c_int, C.c_int, C.c_int],
     "tg_colsum_partial_floats": [C.c_int, C.c_int],
     "tg_vpred_loss_partial_floats": [C.c_int, C.c_long],
@@ -110,7 +113,7 @@ class AttnSegment(C.Structure):
     """tg_attn_segment (include/tokensgen_hip.h)"""
     _fields_ = [("q", C.c_void_p), ("q_ld", C.c_long), ("q_strideB", C.c_long),
                 ("k", C.c_void_p), ("k_ld", C.c_long), ("k_strideB", C.c_long),
-                ("vt", C.c_void_p), ("vt_ld", C.c_long), ("nk", C.c_int), ("score_bound", C.c_float)]
+                ("vt", C.c_void_p), ("vt_ld", C.c_long), ("nk", C.c_int), ("k_norm2_max", C.c_void_p)]
 
 
 class AttnProblem(C.Structure):

@@ -167,7 +167,9 @@ class CogVideoXTransformer3DModel(nn.Module):
         self._fused = {}          # name -> storage tensor
         self._views = []          # (holder module, attr, fused name, row slice, shape)
         self._ws = {}
-        self._bounds = None
+        # "constant_shift" (default) | "running_max": see _attn_fast; TG_ATTN_FIXEDM=0 in the environment forces the latter inside the library
+        self.attn_path = "constant_shift"
+        self._attn_launches, self._attn_mark = 0, (0, 0)        # fast launches issued; (launches, retries) at the last landed poll
         D = num_attention_heads * attention_head_dim
         self.inner_dim = D
         self.patch_embed = _PatchEmbed()
@@ -284,7 +286,6 @@ class CogVideoXTransformer3DModel(nn.Module):
             raise NotImplementedError("tokensgen_amd kernels are bf16-only")
         self._device = any_t.device
         self._ws = {}
-        self._bounds = None
         return self
 
     @property
@@ -335,7 +336,6 @@ class CogVideoXTransformer3DModel(nn.Module):
             self._fused[p + "vln"][0].fill_(1.0); self._fused[p + "vln"][2].fill_(1.0)
         self._build_mod_storage()
         self._ws = {}
-        self._bounds = None
         if vip_ckpt_dir is not None:
             path = os.path.join(vip_ckpt_dir, "vip.pt")
             if not os.path.exists(path):
@@ -367,32 +367,29 @@ class CogVideoXTransformer3DModel(nn.Module):
             m.load_state_dict(load_file(os.path.join(d, fn)), strict=False)
         return m
 
-    # ------------------------------------------------------------------------------------------ score bounds
-    def _score_bounds(self, kscale):
-        """Per layer, an upper bound on |q . k| in the units the attention kernel exponentiates (K carries kscale = softmax scale * log2 e):
-        q and k leave a per-head LayerNorm(64) — ||x_hat||_2 <= 8 — with affine (g, b) and a rotation that preserves the norm, so
-        ||q|| <= 8 max|g_q| + ||b_q|| and likewise for k (2 % margin for the bf16 roundings).  With such a bound the kernel subtracts a
-        CONSTANT instead of tracking the row maximum (tg_attn_segment.score_bound).  One device->host read per weight load; the softmax
-        is shift invariant, so a bound that has gone stale after an in-place weight update can cost range, never correctness."""
-        if self._bounds is None:
-            L_ = len(self.transformer_blocks)
-
-            def bound(name):
-                if f"l0.{name}" not in self._fused:
-                    return [0.0] * L_
-                w = torch.stack([self._fused[f"l{i}.{name}"] for i in range(L_)]).float()          # [L, 4, 64]: q.w, q.b, k.w, k.b
-                nq = 8.0 * w[:, 0].abs().amax(dim=1) + w[:, 1].norm(dim=1)
-                nk = 8.0 * w[:, 2].abs().amax(dim=1) + w[:, 3].norm(dim=1)
-                return (nq * nk * (1.02 * kscale)).tolist()
-            self._bounds = (bound("qknorm"), bound("vqknorm"))
-        return self._bounds
-
-    def invalidate_score_bounds(self):
-        self._bounds = None
+    # ------------------------------------------------------------------------------------------ attention path
+    def _attn_fast(self, ws):
+        """The constant-shift softmax path of the 512-row attention kernel (tg_attn_segment.k_norm2_max): its range bound comes from the
+        DATA of every launch (key norms from the K-norm kernel, query norms inside the attention kernel), so it holds for any checkpoint,
+        and rows it cannot cover are verified + recomputed on the device.  The host only watches the retry counter without ever waiting
+        for the device: weights for which more than 2 % of the workgroups keep being recomputed are better served by the running
+        maximum, and the model then stays on it until the weights change (`attn_path`)."""
+        if self.attn_path == "running_max" or ws.retry is None:
+            return False
+        got = ws.retry.poll(self._attn_launches)
+        if got is not None:
+            n, mark = got
+            launches, retries = mark - self._attn_mark[0], n - self._attn_mark[1]
+            self._attn_mark = (mark, n)
+            if launches > 0 and retries > 0.02 * launches * (ws.retry.ints - 1):
+                self.attn_path = "running_max"
+                return False
+        self._attn_launches += 1
+        return True
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         r = super().load_state_dict(state_dict, strict=strict, **kw)
-        self._bounds = None
+        self.attn_path = "constant_shift"
         return r
 
     # ------------------------------------------------------------------------------------------ workspace
@@ -410,6 +407,11 @@ class CogVideoXTransformer3DModel(nn.Module):
         ws.QKV = e(B, N1, 3 * D)
         ws.FF = e(B, N, 4 * D)
         ws.Vt1 = e(B, H, 64, _pad_to(N1, 64))
+        # constant-shift attention: key-norm bounds per (batch, head) of the two K projections, their reduction scratch, the retry flags
+        ws.kmax1 = torch.zeros(B, H, dtype=torch.float32, device=dev)
+        ws.kmax2 = torch.zeros(B, H, dtype=torch.float32, device=dev)
+        ws.kmax_ws = K.kmax_workspace(N, H, B, dev)
+        ws.retry = K.AttnRetry(N1, Np, H, B, dev)
         if Np:
             ws.QKVv = e(B, N, 3 * D)
             ws.Vt2 = e(B, H, 64, _pad_to(Np, 64))
@@ -504,7 +506,9 @@ class CogVideoXTransformer3DModel(nn.Module):
             K.gemm_pair(ws.Xn[:, :N1], F[p + "qkv.w"], F[p + "qkv.b"], ws.QKV, ws.Xn, F[p + "vqkv.w"], F[p + "vqkv.b"], ws.QKVv, L.EPI_BIAS)
         else:
             K.gemm(ws.Xn[:, :N1], F[p + "qkv.w"], F[p + "qkv.b"], ws.QKV, L.EPI_BIAS)
-        K.qk_layernorm_rope_pair(ws.QKV[:, :, :D], ws.QKV[:, :, D:2 * D], H, qn[0], qn[1], qn[2], qn[3], 1e-6, (Nt, rope), k_scale=kscale)
+        fast = self._attn_fast(ws) if getattr(ws, "retry", None) is not None else False
+        K.qk_layernorm_rope_pair(ws.QKV[:, :, :D], ws.QKV[:, :, D:2 * D], H, qn[0], qn[1], qn[2], qn[3], 1e-6, (Nt, rope), k_scale=kscale,
+                                 kmax=ws.kmax1 if fast else None, kmax_ws=ws.kmax_ws if fast else None)
         if not fused_vt:
             K.transpose_v(ws.QKV[:, :, 2 * D:], H, 0, N1, ws.Vt1)
         if use_vip:
@@ -512,7 +516,7 @@ class CogVideoXTransformer3DModel(nn.Module):
                 K.gemm(ws.Xn, F[p + "vqkv.w"], F[p + "vqkv.b"], ws.QKVv, L.EPI_BIAS)
             vqn = F[p + "vqknorm"]
             K.qk_layernorm_rope_pair(ws.QKVv[:, :, :D], ws.QKVv[:, :, D:2 * D], H, vqn[0], vqn[1], vqn[2], vqn[3], 1e-6, (Nt, vrope),
-                                     (N1, crope), k_scale=kscale)
+                                     (N1, crope), k_scale=kscale, kmax=ws.kmax2 if fast else None, kmax_ws=ws.kmax_ws if fast else None)
             if not fused_vt:
                 K.transpose_v(ws.QKVv[:, :, 2 * D:], H, 0, N, ws.Vt3)
             if vt2_view_ok and N1 + pad64(Np) <= ws.Vt3.shape[3]:
@@ -532,11 +536,15 @@ class CogVideoXTransformer3DModel(nn.Module):
             s = float(s)
             # text+video rows: softmax(q k^T) v  +  s * softmax(qx kv^T) vv   (attention_processor.py:2066-2069,2117-2134)
             # vip rows: qv against cat(kx, kv) / cat(vx, vv)                  (:2120-2125) — rides in the main launch's last round
-            b1, b2 = self._score_bounds(kscale)
+            # kmax2 is the maximum over ALL rows of the vip-weight K projection: an upper bound for the vip keys of segment 2 as well
+            km1, km2 = (ws.kmax1, ws.kmax2) if fast else (None, None)
             K.attention_multi(dict(q1=ws.QKV[:, :, :D], k1=ws.QKV[:, :, D:2 * D], vt1=ws.Vt1, nk1=N1, out=ws.AO[:, :N1],
-                                   q2=ws.QKVv[:, :N1, :D], k2=ws.QKVv[:, N1:, D:2 * D], vt2=vt2, nk2=Np, seg2_scale=s, bound1=b1[i], bound2=b2[i]),
-                              dict(q1=ws.QKVv[:, N1:, :D], k1=ws.QKVv[:, :, D:2 * D], vt1=ws.Vt3, nk1=N, out=ws.AO[:, N1:], bound1=b2[i]),
-                              H, sm_scale, k_prescaled=True)
+                                   q2=ws.QKVv[:, :N1, :D], k2=ws.QKVv[:, N1:, D:2 * D], vt2=vt2, nk2=Np, seg2_scale=s, kmax1=km1, kmax2=km2),
+                              dict(q1=ws.QKVv[:, N1:, :D], k1=ws.QKVv[:, :, D:2 * D], vt1=ws.Vt3, nk1=N, out=ws.AO[:, N1:], kmax1=km2),
+                              H, sm_scale, k_prescaled=True, retry=ws.retry if fast else None)
+        elif fast:
+            K.attention_multi(dict(q1=ws.QKV[:, :, :D], k1=ws.QKV[:, :, D:2 * D], vt1=ws.Vt1, nk1=N1, out=ws.AO[:, :N1], kmax1=ws.kmax1), None,
+                              H, sm_scale, k_prescaled=True, retry=ws.retry)
         else:
             K.attention(ws.QKV[:, :, :D], ws.QKV[:, :, D:2 * D], ws.Vt1, N1, ws.AO[:, :N1], H, sm_scale, k_prescaled=True)
 
@@ -556,6 +564,9 @@ class CogVideoXTransformer3DModel(nn.Module):
             raise ValueError("rotary tables are required (CogVideoX-5B attention)")
         e = lambda *sh: torch.empty(*sh, dtype=BF16, device=dev)
         ws = SimpleNamespace(Xn=e(B, N, D), QKV=e(B, N1, 3 * D), Vt1=e(B, H, 64, _pad_to(N1, 64)), AO=e(B, N, D))
+        ws.kmax1 = torch.zeros(B, H, dtype=torch.float32, device=dev)
+        ws.kmax2 = torch.zeros(B, H, dtype=torch.float32, device=dev)
+        ws.kmax_ws, ws.retry = K.kmax_workspace(N, H, B, dev), K.AttnRetry(N1, Np, H, B, dev)
         ws.Xn[:, :Nt] = encoder_hidden_states[:, :Nt].to(dev, BF16)
         ws.Xn[:, Nt:N1] = hidden_states.to(dev, BF16)
         f32 = lambda t: tuple(x.to(dev, torch.float32).contiguous() for x in t)

@@ -58,6 +58,42 @@ def bench_attn():
     print(json.dumps({"kernel": "attention_vip", "ms": ms, "tflops": B * 4.0 * NP * N * D / ms / 1e9}))
 
 
+def bench_attn_dit():
+    """The To2V block's attention launch as the model issues it (tg_attention_fwd_multi: SDPA#1+#2 with SDPA#3 riding), q / k from the real
+    K-norm kernel (LayerNorm gains ~ TG_BENCH_GAIN, default 1), on both softmax paths: constant shift (+ its retry launch) and running max."""
+    gain = float(os.environ.get("TG_BENCH_GAIN", "1"))
+    kscale = 0.125 * 1.4426950408889634
+    qkv, qkvv = rnd(B, N1, 3 * D), rnd(B, N, 3 * D)
+    w = lambda: ((1.0 + 0.05 * torch.randn(64, device=DEV)) * gain).to(BF)
+    bb = lambda: (0.05 * torch.randn(64, device=DEV)).to(BF)
+    km1, km2 = (torch.zeros(B, H, dtype=torch.float32, device=DEV) for _ in range(2))
+    kws = K.kmax_workspace(N, H, B, DEV)
+    wq, bq, wk, bk = w(), bb(), w(), bb()
+    K.qk_layernorm_rope_pair(qkv[:, :, :D], qkv[:, :, D:2 * D], H, wq, bq, wk, bk, 1e-6, k_scale=kscale, kmax=km1, kmax_ws=kws)
+    K.qk_layernorm_rope_pair(qkvv[:, :, :D], qkvv[:, :, D:2 * D], H, wq, bq, wk, bk, 1e-6, k_scale=kscale, kmax=km2, kmax_ws=kws)
+    pad = lambda n: (n + 63) // 64 * 64
+    vt1 = torch.zeros(B, H, 64, pad(N1), dtype=BF, device=DEV); K.transpose_v(qkv[:, :, 2 * D:], H, 0, N1, vt1)
+    vt3 = torch.zeros(B, H, 64, pad(N), dtype=BF, device=DEV); K.transpose_v(qkvv[:, :, 2 * D:], H, 0, N, vt3)
+    vt2 = vt3[:, :, :, N1:]
+    ao = torch.empty(B, N, D, dtype=BF, device=DEV)
+    retry = K.AttnRetry(N1, NP, H, B, DEV)
+
+    def run(fast):
+        K.attention_multi(dict(q1=qkv[:, :, :D], k1=qkv[:, :, D:2 * D], vt1=vt1, nk1=N1, out=ao[:, :N1], q2=qkvv[:, :N1, :D], k2=qkvv[:, N1:, D:2 * D],
+                               vt2=vt2, nk2=NP, seg2_scale=0.6, kmax1=km1 if fast else None, kmax2=km2 if fast else None),
+                          dict(q1=qkvv[:, N1:, :D], k1=qkvv[:, :, D:2 * D], vt1=vt3, nk1=N, out=ao[:, N1:], kmax1=km2 if fast else None), H, 0.125,
+                          k_prescaled=True, retry=retry if fast else None)
+    fl = B * (4.0 * N1 * N1 * D + 4.0 * N1 * NP * D + 4.0 * NP * N * D)
+    res = {}
+    for name, fast in (("constant_shift", True), ("running_max", False)):
+        ms = timeit(lambda: run(fast), iters=7)
+        res[name] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}
+    qk_ms = timeit(lambda: K.qk_layernorm_rope_pair(qkv[:, :, :D], qkv[:, :, D:2 * D], H, wq, bq, wk, bk, 1e-6, k_scale=1.0, kmax=km1, kmax_ws=kws))
+    qk0_ms = timeit(lambda: K.qk_layernorm_rope_pair(qkv[:, :, :D], qkv[:, :, D:2 * D], H, wq, bq, wk, bk, 1e-6, k_scale=1.0))
+    print(json.dumps({"kernel": "attention_dit_launch", "gain": gain, **res, "retried": retry.count(), "qk_norm_pair_kmax_ms": round(qk_ms, 4),
+                      "qk_norm_pair_ms": round(qk0_ms, 4)}))
+
+
 def bench_attn_bwd():
     """The training step's main attention call (SDPA #1 of the To2V processor): nq = nk = 17776, 48 heads, batch 2."""
     qkv = rnd(B, N1, 3 * D, scale=0.6)
@@ -105,6 +141,8 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["attn", "gemm", "norm"]
     if "attn" in what:
         bench_attn()
+    if "attn_dit" in what:
+        bench_attn_dit()
     if "attn_bwd" in what:
         bench_attn_bwd()
     if "gemm" in what:
