@@ -368,3 +368,34 @@ def test_vae_batch_of_two_matches_single_items(golden_dir):
             assert torch.equal(d[i], vae.decode(z[i:i + 1]).sample[0]), i
             assert torch.equal(h[i], vae.encode(x[i:i + 1]).latent_dist.parameters[0]), i
     assert not torch.equal(d[0], d[1])
+
+
+def test_vae_weight_reload_invalidates_captured_graphs(golden_dir):
+    """captured tile programs hold raw pointers into the packed weights, so `load_state_dict` must drop them — decode three
+    times (eager, capture, replay), load DIFFERENT weights, decode three more times: every one of them must equal the eager (no-graph) result of
+    the new weights bitwise, and differ from the old weights' output.  Same for a change of the temporal batch size (baked into a program)."""
+    from tokensgen_amd.vae import AutoencoderKLCogVideoX
+    g = torch.load(os.path.join(golden_dir, "vae_tiny.pt"), weights_only=False)
+    cfg = g["cfg"]
+    mk = lambda: AutoencoderKLCogVideoX(block_out_channels=cfg["block_out_channels"], layers_per_block=cfg["layers_per_block"], sample_height=64,
+                                        sample_width=96, device=DEV)
+    sd_a, sd_b = V.make_state_dict(cfg, seed=g["weight_seed"]), V.make_state_dict(cfg, seed=g["weight_seed"] + 1)
+    z = torch.randn(1, 16, 13, 8, 12, generator=torch.Generator().manual_seed(9)).to(DEV, BF)
+    eager = mk(); eager.use_graphs = False; eager.enable_tiling()
+    eager.load_state_dict(sd_a); ref_a = eager.decode(z).sample.clone()
+    eager.load_state_dict(sd_b); ref_b = eager.decode(z).sample.clone()
+    assert not torch.equal(ref_a, ref_b)
+    vae = mk(); vae.enable_tiling()
+    vae.load_state_dict(sd_a)
+    for _ in range(3):
+        assert torch.equal(vae.decode(z).sample, ref_a)
+    assert vae._graphs                                     # the third call really replayed captured programs
+    vae.load_state_dict(sd_b)
+    assert not vae._graphs
+    for _ in range(3):
+        assert torch.equal(vae.decode(z).sample, ref_b)
+    vae.num_latent_frames_batch_size = 3                    # a public attribute the captured program bakes in
+    eager.num_latent_frames_batch_size = 3
+    ref_b3 = eager.decode(z).sample.clone()
+    for _ in range(3):
+        assert torch.equal(vae.decode(z).sample, ref_b3)

@@ -109,6 +109,8 @@ class AutoencoderKLCogVideoX:
             raise RuntimeError(f"AutoencoderKLCogVideoX.load_state_dict: missing {missing[:4]}, unexpected {unexpected[:4]}, shape mismatch {bad[:4]}")
         self._sd = {k: v.detach().to(self.device, BF16).contiguous() for k, v in sd.items()}
         self._packed = {}
+        # captured tile programs hold raw pointers into the old _sd / _packed tensors: a reload must drop them
+        self._graphs, self._seen = {}, {}
         K.zero_page(self.device)          # created on the caller's stream before any tile stream can race for it
         for k, v in self._sd.items():
             if k.endswith(".weight") and v.dim() >= 4:
@@ -306,6 +308,10 @@ class AutoencoderKLCogVideoX:
             tmap = self._tmaps.get(T)
             if tmap is None:                      # cached: a host->device copy cannot sit inside a captured tile program
                 tmap = self._tmaps[T] = torch.tensor(idx, dtype=torch.int32, device=x.device)
+                # created on whichever tile stream needs it first; the other tile streams use it with no dependency on this stream, so the
+                # upload must have LANDED before the host enqueues anything else (once per distinct T; never inside a capture: the eager
+                # first pass of a shape has already created it)
+                torch.cuda.current_stream(x.device).synchronize()
         w = self._sd[name + ".conv.weight"]
         return K.conv3d_cl(x, self._packed[name + ".conv.weight"], self._sd[name + ".conv.bias"], w.shape[0], 1, 3, 3, stride=1, pad=1, up=2,
                            t_map=tmap, out_dims=(To, 2 * H, 2 * W), gn_stats_eps=self.config.norm_eps)
@@ -395,7 +401,9 @@ class AutoencoderKLCogVideoX:
             return self._run_tile(src, i, j, th, tw, decode)
         C, Tt, Ht, Wt = src.shape
         Hc, Wc = min(th, Ht - i), min(tw, Wt - j)
-        key = (decode, src.dtype, C, Tt, Hc, Wc, slot, bool(getattr(self, "_tiled_pass", False)))
+        # everything a captured program bakes in besides the weights (load_state_dict drops the cache): shapes, the temporal batching, eps
+        key = (decode, src.dtype, C, Tt, Hc, Wc, slot, bool(getattr(self, "_tiled_pass", False)), self.num_latent_frames_batch_size,
+               self.num_sample_frames_batch_size, float(self.config.norm_eps))
         g = self._graphs.get(key)
         if g is None:
             if not self._seen.get(key):            # first sight: run eagerly (this is also the warm-up a capture needs)
