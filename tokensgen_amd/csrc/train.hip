@@ -498,9 +498,10 @@ __global__ void clip_coef_kernel(const float* __restrict__ partial, int n_partia
 
 // torch.optim.AdamW (decoupled weight decay, bias correction, eps outside the corrected sqrt) on fp32 moments; parameters are bf16 and are
 // read / written once (fp32 arithmetic in between).  clip: optional device pointer to the coefficient of clip_coef_kernel (coef + 1).
-__global__ __launch_bounds__(OPT_BLOCK) void adamw_kernel(bf16_t* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+// The gradient is read and (zero_grad) zeroed through ONE pointer: two __restrict__ names for the same buffer would be undefined behaviour.
+__global__ __launch_bounds__(OPT_BLOCK) void adamw_kernel(bf16_t* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                                                           float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                          const float* __restrict__ clip, int zero_grad, float* __restrict__ g_rw) {
+                                                          const float* __restrict__ clip, int zero_grad) {
     const float cs = clip ? *clip : 1.f;
     for (long i = (long)blockIdx.x * OPT_BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * OPT_BLOCK) {
         const float gi = g[i] * cs;
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(OPT_BLOCK) void adamw_kernel(bf16_t* __restrict__ p
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         pi -= (lr / bc1) * (mi / denom);
         p[i] = f32_to_bf16(pi);
-        if (zero_grad) g_rw[i] = 0.f;
+        if (zero_grad) g[i] = 0.f;
     }
 }
 
@@ -545,8 +546,8 @@ extern "C" int tg_adamw_step(void* param, float* grad, float* exp_avg, float* ex
     TG_REQUIRE(param && grad && exp_avg && exp_avg_sq, TG_ERR_ARG, "tg_adamw_step: null pointer");
     TG_REQUIRE(n > 0 && step >= 1, TG_ERR_SHAPE, "tg_adamw_step: n and step must be positive");
     const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adamw_kernel, dim3(opt_blocks(n)), dim3(OPT_BLOCK), 0, stream, (bf16_t*)param, (const float*)grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
-                       weight_decay, bc1, bc2s, clip_coef, zero_grad, grad);
+    hipLaunchKernelGGL(adamw_kernel, dim3(opt_blocks(n)), dim3(OPT_BLOCK), 0, stream, (bf16_t*)param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                       weight_decay, bc1, bc2s, clip_coef, zero_grad);
     TG_LAUNCH_CHECK("tg_adamw_step");
     return TG_OK;
 }

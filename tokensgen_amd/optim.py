@@ -96,6 +96,11 @@ class ParamArena:
     def state_dict(self):
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
 
+    def layout(self):
+        """(name, offset, shape) of every parameter in the flat arenas — stored with a checkpoint so that a resume can check it is loading
+        moments of the same geometry."""
+        return [(n, int(self.offsets[n]), tuple(self.shapes[n])) for n in self.names]
+
 
 class AdamW:
     """torch.optim.AdamW semantics (decoupled weight decay) on a ParamArena, with the reference's gradient clipping folded in:
@@ -126,6 +131,34 @@ class AdamW:
                 L.check(lib.tg_adamw_step(a.param.data_ptr() + 2 * lo, a.grad.data_ptr() + 4 * lo, a.exp_avg.data_ptr() + 4 * lo, a.exp_avg_sq.data_ptr() + 4 * lo,
                                           hi - lo, self.t, float(lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), cp,
                                           1 if zero_grad else 0, st), "tg_adamw_step")
+
+
+    # ---- checkpoint / resume (the reference: accelerator.save_state / load_state behind --resume_from_checkpoint, train_cogvideo_to2v.py:1690-1716,
+    # 2030-2047).  Layout of the dict: {"t": optimizer steps taken (bias correction), "exp_avg" / "exp_avg_sq": the flat fp32 moment arenas,
+    # "grad": the flat fp32 gradient arena (non-zero only in the middle of an accumulation window), "layout": ParamArena.layout(),
+    # "hyper": lr / betas / eps / weight_decay / max_grad_norm / clip_elems}.  Parameters are saved separately under the reference's names
+    # (CogVideoXTransformer3DModel.save_vip_layers -> vip.pt, Resampler.save_pretrained).
+    def state_dict(self):
+        a = self.arena
+        return {"t": int(self.t), "exp_avg": a.exp_avg.detach().cpu().clone(), "exp_avg_sq": a.exp_avg_sq.detach().cpu().clone(),
+                "grad": a.grad.detach().cpu().clone(), "layout": a.layout(),
+                "hyper": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "max_grad_norm": self.max_norm,
+                          "clip_elems": self.clip_elems}}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        a = self.arena
+        if [(n, int(o), tuple(sh)) for n, o, sh in sd["layout"]] != a.layout():
+            raise ValueError("AdamW.load_state_dict: the checkpoint's arena layout (names / offsets / shapes) differs from this arena's")
+        for name in ("exp_avg", "exp_avg_sq", "grad"):
+            t = sd[name]
+            if t.numel() != a.numel or t.dtype != torch.float32:
+                raise ValueError(f"AdamW.load_state_dict: {name} has {t.numel()} {t.dtype} elements, arena has {a.numel} fp32")
+            getattr(a, name).copy_(t.to(a.param.device))
+        self.t = int(sd["t"])
+        h = sd.get("hyper", {})
+        self.lr, self.betas, self.eps = h.get("lr", self.lr), tuple(h.get("betas", self.betas)), h.get("eps", self.eps)
+        self.wd, self.max_norm, self.clip_elems = h.get("weight_decay", self.wd), h.get("max_grad_norm", self.max_norm), int(h.get("clip_elems", self.clip_elems))
 
 
 def constant_with_warmup(step, base_lr, warmup_steps):

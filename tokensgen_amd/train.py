@@ -613,12 +613,23 @@ class To2VTrainStep:
     the window: bucketed all-reduce (DDP), clip_grad_norm_ on the transformer's parameters, AdamW, zero_grad.
     `resampler_backward(d_vip_tokens) -> {name: grad}` (optional) chains the Resampler (its parameters sit behind the transformer's in the arena)."""
 
-    def __init__(self, trainer, arena, optimizer, alphas_cumprod, accumulation_steps=9, sync=None, resampler=None):
+    def __init__(self, trainer, arena, optimizer, alphas_cumprod, accumulation_steps=9, sync=None, resampler=None, resampler_params=None):
         self.tr, self.arena, self.opt, self.acp, self.accum, self.sync, self.rs = trainer, arena, optimizer, alphas_cumprod, accumulation_steps, sync, resampler
         self.micro = 0
         self.world = sync.world if sync is not None else 1
-        self.rs_temporal_queries = 4          # resampler_params.num_temporal_queries of the yaml
-        self.latent_frames_per_chunk = 13     # 49 video frames -> 13 latent frames per chunk
+        # resampler_params of the yaml (cogvideo_5b_vaevip_4x8x12_to2v.yaml): 4 temporal queries per chunk of 13 latent frames (49 video frames)
+        rp = resampler_params or {}
+        self.rs_temporal_queries = int(rp.get("num_temporal_queries", 4))
+        self.latent_frames_per_chunk = int(rp.get("max_temporal_seq_len", 13))
+
+    # ---- checkpoint / resume of the loop state (the reference: accelerator.save_state / load_state, train_cogvideo_to2v.py:1690-1716): the
+    # optimizer's dict (optim.AdamW.state_dict: step count, moments, the gradient arena) + the position inside the accumulation window
+    def state_dict(self):
+        return {"optimizer": self.opt.state_dict(), "micro": int(self.micro)}
+
+    def load_state_dict(self, sd):
+        self.opt.load_state_dict(sd["optimizer"])
+        self.micro = int(sd["micro"])
 
     def _frames_per_chunk(self, image_embeddings):
         return min(self.latent_frames_per_chunk, image_embeddings.shape[1])
@@ -635,17 +646,30 @@ class To2VTrainStep:
 
     @torch.no_grad()
     def micro_step(self, model_input, noise, timesteps, text, vip_tokens, rope, vrope, crope, image_embeddings=None, emb_start_idx=None,
-                   resampler_ropes=(None, None), vip_frames=5):
+                   resampler_ropes=(None, None), vip_frames=None, num_chunks=None):
         """One micro-batch.  Either `vip_tokens` [B, f, c, h, w] is given (Resampler outside), or `image_embeddings` [B, chunks * f_lat, n, c]
         (patch-embedded VAE latents, train_cogvideo_to2v.py:1656-1672) with `emb_start_idx[b]`: the Resampler (trainable) runs once per chunk, the
         chunk outputs are concatenated along time and `vip_frames` temporal slots from emb_start_idx[b] on are handed to the transformer
-        (:1931-1968); their gradient flows back through every chunk that contributed.  Returns (loss tensor on the device, stepped: bool)."""
+        (:1931-1968); their gradient flows back through every chunk that contributed.  `num_chunks`: the reference's argument (:1937); derived
+        from max_temporal_seq_len when omitted.  `vip_frames` defaults to the reference's min(num_temporal_queries + 1, max_temporal_seq_len) (:1965).
+        Returns (loss tensor on the device, stepped: bool)."""
         ctxs = None
+        if vip_frames is None:
+            vip_frames = min(self.rs_temporal_queries + 1, self.latent_frames_per_chunk)
         if image_embeddings is not None:
             rs = self.rs
             B = image_embeddings.shape[0]
-            n_chunks = image_embeddings.shape[1] // self._frames_per_chunk(image_embeddings)
+            n_chunks = int(num_chunks) if num_chunks else image_embeddings.shape[1] // self._frames_per_chunk(image_embeddings)
+            if n_chunks < 1 or image_embeddings.shape[1] % n_chunks:
+                raise ValueError(f"image_embeddings has {image_embeddings.shape[1]} frames: not a whole number of {n_chunks} chunk(s)")
             per = image_embeddings.shape[1] // n_chunks
+            total_slots = n_chunks * self.rs_temporal_queries
+            for b in range(B):
+                # the reference slices image_embeddings[[b], start:start+5] (:1964-1966): a window past the last chunk would come back SHORT and
+                # break the fixed vip token count further down — refuse it here with the numbers in the message
+                if not 0 <= int(emb_start_idx[b]) <= total_slots - vip_frames:
+                    raise ValueError(f"emb_start_idx[{b}] = {int(emb_start_idx[b])}: the {vip_frames}-slot window must lie inside the "
+                                     f"{total_slots} temporal slots of {n_chunks} chunk(s) x {self.rs_temporal_queries} queries")
             outs, ctxs = [], []
             for c in range(n_chunks):
                 tok, ctx = rs.forward(image_embeddings[:, c * per:(c + 1) * per], *resampler_ropes)
