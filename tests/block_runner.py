@@ -1,4 +1,4 @@
-"""Run ONE CogVideoXBlock (with the To2V branch) at an arbitrary width through the HIP path — the unit
+"""TEST HELPER (lives under tests/, not in the product package).  Run ONE CogVideoXBlock (with the To2V branch) at an arbitrary width through the HIP path — the unit
 BASELINE config 1 measures (`CogVideoXBlock.forward`, cogvideox_transformer_3d.py:221-332).
 
 The block is executed by a 1-layer CogVideoXTransformer3DModel whose residual stream / temb are injected
@@ -6,10 +6,10 @@ directly, so exactly the same kernels and launch sequence as the full model are 
 import numpy as np
 import torch
 
-from . import kernels as K
-from . import lib as L
-from . import rope as R
-from .transformer import BF16, CogVideoXTransformer3DModel
+from tokensgen_amd import kernels as K
+from tokensgen_amd import lib as L
+from tokensgen_amd import rope as R
+from tokensgen_amd.transformer import BF16, CogVideoXTransformer3DModel
 
 
 def block_forward(model, layer, hidden, enc, temb, rope, vrope=None, crope=None):

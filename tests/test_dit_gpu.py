@@ -140,7 +140,7 @@ def test_dit_42_layers_depth_drift_vs_oracle(parity):
 def test_full_width_block_vs_reference_samples(golden_dir):
     """BASELINE config 1: one CogVideoX-5B block with VIP at the real shape (17550+706 tokens, D=3072) against
     sampled outputs of the REFERENCE block (tests/golden/block_full.pt)."""
-    from tokensgen_amd import block_runner
+    import block_runner
     g = torch.load(os.path.join(golden_dir, "block_full.pt"), weights_only=False)
     cfg = dict(num_attention_heads=48, attention_head_dim=64, num_layers=1, time_embed_dim=512)
     sd = O.make_state_dict(cfg, n_vip_dim=3072, seed=g["weight_seed"])

@@ -48,9 +48,9 @@ def test_attention_bwd_vs_autograd(B, H, nq, nk):
     qd, kd, vd = fd[:, :nq, :H * 64], fd[:, :nk, H * 64:2 * H * 64], fd[:, :nk, 2 * H * 64:]
     dq, dk, dv = K.attention_bwd(qd, kd, vd, o.detach().to(BF).to(DEV), g.to(DEV), H, scale)
     assert dq.shape == (B, nq, H * 64) and dk.shape == dv.shape == (B, nk, H * 64) and dq.dtype == torch.float32
-    assert _rel(dv, vf.grad) < 8e-3
-    assert _rel(dq, qf.grad) < 1.5e-2
-    assert _rel(dk, kf.grad) < 1.5e-2
+    assert _rel(dv, vf.grad) < 4.5e-3          # tolerances = 2x the values measured on MI355X (profiles/r2_parity_report.json: 2.3e-3 / 2.7e-3)
+    assert _rel(dq, qf.grad) < 5.5e-3
+    assert _rel(dk, kf.grad) < 5.5e-3
     # deterministic (no atomics) and accumulate adds
     dq2, dk2, dv2 = K.attention_bwd(qd, kd, vd, o.detach().to(BF).to(DEV), g.to(DEV), H, scale)
     assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
@@ -66,7 +66,7 @@ def test_attention_bwd_vs_autograd(B, H, nq, nk):
     assert (lse.cpu() - want).abs().max().item() < 2e-3
     assert _rel(out, o.detach()) < 8e-3
     dq3, dk3, dv3 = K.attention_bwd(qd, kd, vd, out, g.to(DEV), H, scale, lse=lse)
-    assert _rel(dq3, qf.grad) < 1.5e-2 and _rel(dk3, kf.grad) < 1.5e-2 and _rel(dv3, vf.grad) < 8e-3
+    assert _rel(dq3, qf.grad) < 5.5e-3 and _rel(dk3, kf.grad) < 5.5e-3 and _rel(dv3, vf.grad) < 4.5e-3
 
 
 def test_to2v_processor_attention_gradients():
@@ -104,7 +104,7 @@ def test_to2v_processor_attention_gradients():
                                 dq=torch.zeros(B, Np, H * 64, dtype=f32, device=DEV))
     got = dict(q=dq, k=dk, v=dv, qx=dqx, kx=dkcat[:, :N1], vx=dvcat[:, :N1], qv=dqv, kv=dkcat[:, N1:], vv=dvcat[:, N1:])
     for n in names:
-        assert _rel(got[n], f[n].grad) < 2e-2, n
+        assert _rel(got[n], f[n].grad) < 5e-3, n          # measured 2.4e-3
 
 
 def test_vpred_loss_and_gradient_vs_autograd():
@@ -125,14 +125,14 @@ def test_vpred_loss_and_gradient_vs_autograd():
     assert grad.shape == out.shape and grad.dtype == BF
     assert abs(l2.item() - loss.item()) < 2e-3 * abs(loss.item())
     assert torch.allclose(p2.cpu(), per_item.detach().float(), rtol=2e-3)
-    assert _rel(grad, o.grad) < 1e-2
+    assert _rel(grad, o.grad) < 7.5e-3          # measured 3.7e-3 (the gradient is a bf16 tensor)
     # scalar timestep per batch item
     ts1 = torch.tensor([100, 900])
     o = out.clone().requires_grad_(True)
     loss, _ = T.vpred_loss(ac, o, noisy, x0, ts1)
     loss.backward()
     l3, _, grad3 = train.vpred_loss_and_grad(out.to(DEV), noisy.to(DEV), x0.to(DEV), ts1, ac)
-    assert abs(l3.item() - loss.item()) < 2e-3 * abs(loss.item()) and _rel(grad3, o.grad) < 1e-2
+    assert abs(l3.item() - loss.item()) < 2e-3 * abs(loss.item()) and _rel(grad3, o.grad) < 7.5e-3
 
 
 def _rope_tables(n, seed):
@@ -169,7 +169,7 @@ def test_qk_layernorm_rope_backward_and_linear_backward_vs_autograd():
     assert _rel(dxi, dyo.float() @ w.float()) < 4e-3
 
 
-def test_vip_processor_trainable_parameter_gradients_vs_autograd_of_the_oracle():
+def test_vip_processor_trainable_parameter_gradients_vs_autograd_of_the_oracle(parity):
     """End of the chain for the attention sub-block: from the gradient of the processor's pre-`to_out` output to the gradients of every TRAINABLE
     processor parameter (vip_to_{q,k,v}.{weight,bias}, vip_norm_{q,k}.{weight,bias}; cogvideox_transformer_3d.py:207-218, train_cogvideo_to2v.py:
     1456-1481) — HIP forward pieces (projection GEMM, QK-norm+RoPE, attention) + tg_attention_bwd + tg_qk_layernorm_rope_bwd + GEMM wgrad —
@@ -201,6 +201,11 @@ def test_vip_processor_trainable_parameter_gradients_vs_autograd_of_the_oracle()
     ao_ref = torch.cat([oe[:, :Nt], oh, oe[:, Nt:]], dim=1)                      # text | video | vip rows
     G = _rand(B, N, D, seed=54)
     (ao_ref * G.float()).sum().backward()
+    # noise floor: the same arithmetic in bf16 autograd (what the reference's own bf16 training computes) against the fp32 gradients
+    sd16 = {k: v.detach().to(BF).requires_grad_(k in train_keys) for k, v in sd_no_out.items()}
+    oh16, oe16 = O.vip_attention(sd16, pre, hidden, enc, H, Np, [0.6], rope, vrope, crope)
+    (torch.cat([oe16[:, :Nt], oh16, oe16[:, Nt:]], dim=1) * G).sum().backward()
+    parity(max(float(_rel(sd16[k].grad, sd[k].grad)) for k in train_keys), 1.0, "noise floor: bf16 autograd of the oracle vs fp32 autograd, worst tensor (informative)")
     # ---- HIP: forward pieces with the pre-norm projections kept, then the backward chain ----
     dev = lambda t: t.detach().to(BF).to(DEV).contiguous()
     xn = torch.cat([enc[:, :Nt], hidden, enc[:, Nt:]], dim=1).to(DEV)          # the processor's inputs in residual-stream row order
@@ -225,9 +230,8 @@ def test_vip_processor_trainable_parameter_gradients_vs_autograd_of_the_oracle()
     d_out = torch.cat([Gd[:, :N1], Gd[:, N1:]], dim=1)                          # gradient of cat(O1 + s O2, O3) in row order text|video | vip
     grads = train.to2v_attention_backward(q, k, v, qx, kx, vx, qv, kv, vv, o1, o2, o3, d_out, H, 1.0 / math.sqrt(64), 0.6)
     got = train.vip_projection_backward(xn, qkvv_pre, grads, H, Nt, N1, gq, gk, tab(vrope), tab(crope))
-    for name, g_ in got.items():
-        want = sd[f"{P}.{name}"].grad
-        assert _rel(g_, want) < 3e-2, name
+    parity(max(float(_rel(g_, sd[f"{P}.{name}"].grad)) for name, g_ in got.items()), 3e-2,
+           "worst trainable processor tensor, HIP vs fp32 autograd (r2 measured 2.3e-2; compare the floor above)")
 
 
 def test_adaln_gate_and_activation_backward_kernels_vs_autograd():
@@ -321,7 +325,7 @@ def test_to2v_block_backward_vs_autograd_of_the_oracle_block():
         assert _rel(g_, sd[pre + "." + name].grad) < 2e-2, name
 
 
-def test_to2v_model_training_forward_backward_vs_autograd_of_the_oracle_model():
+def test_to2v_model_training_forward_backward_vs_autograd_of_the_oracle_model(parity):
     """The transformer's share of one training micro-step (train_cogvideo_to2v.py:1930-2010): embeddings -> 2 blocks with per-block checkpointing
     -> final norms / proj_out -> v-prediction loss, then backward to EVERY trainable transformer parameter (all names containing "vip_", incl.
     patch_embed.vip_proj) and to the vip tokens (the Resampler's output).  Against autograd through oracle.dit_ref.dit_forward +
@@ -353,6 +357,15 @@ def test_to2v_model_training_forward_backward_vs_autograd_of_the_oracle_model():
     out_ref = O.dit_forward(sd, cfg, noisy.float(), text.float(), ts, vf, rope, vrope, crope, vip_scale=[0.7])
     loss_ref, _ = T.vpred_loss(ac, out_ref, noisy.float(), x0.float(), ts)
     loss_ref.backward()
+    # the reference's own arithmetic: the same chain with bf16 parameters and activations (torch autograd rounds every op) — its distance to the
+    # fp32 gradients is the noise floor the HIP figures below are read against
+    sd16 = {k: v.detach().to(BF).requires_grad_(k in train_keys) for k, v in sd.items()}
+    v16 = vip.clone().requires_grad_(True)
+    loss16, _ = T.vpred_loss(ac, O.dit_forward(sd16, cfg, noisy, text, ts, v16, rope, vrope, crope, vip_scale=[0.7]), noisy, x0, ts)
+    loss16.backward()
+    floor = max(float(_rel(sd16[k].grad, sd[k].grad)) for k in train_keys)
+    parity(floor, 1.0, "noise floor: bf16 autograd of the oracle vs fp32 autograd, worst trainable tensor (informative)")
+    parity(_rel(v16.grad, vf.grad), 1.0, "noise floor of d(vip tokens) (informative)")
     sd_dev = {k: v.detach().to(BF).to(DEV).contiguous() for k, v in sd.items()}
     tr = train.To2VTrainer(sd_dev, H, 2, patch_size=2, vip_scale=0.7)
     assert tr.trainable == train_keys
@@ -363,9 +376,9 @@ def test_to2v_model_training_forward_backward_vs_autograd_of_the_oracle_model():
     grads, d_vip = tr.backward(d_out)
     assert sorted(grads) == train_keys
     want_vip = vf.grad.permute(0, 1, 3, 4, 2).reshape(B, -1, 128)
-    assert _rel(d_vip, want_vip) < 2e-2
-    for name in train_keys:
-        assert _rel(grads[name], sd[name].grad) < 4e-2, name
+    parity(_rel(d_vip, want_vip), 2e-2, "d(vip tokens), HIP vs fp32 autograd (r2 measured 1.0e-2)")
+    worst = max(float(_rel(grads[name], sd[name].grad)) for name in train_keys)
+    parity(worst, 3.6e-2, "worst trainable tensor, HIP vs fp32 autograd (r2 measured 1.8e-2; compare the floor above)")
     # the two activation schedules are the same computation: blocks that keep their activations (288 GB: the default when memory allows) and blocks
     # that re-run their forward inside the backward (the reference's per-block checkpointing) give bitwise the same gradients
     assert not tr._kept and not tr._ckpt
@@ -474,7 +487,7 @@ def test_training_steps_reduce_the_loss_and_update_only_trainable_parameters(tmp
     assert _rel(y_inf, y_tr) < 1e-2
 
 
-def test_resampler_backward_vs_autograd_of_the_oracle():
+def test_resampler_backward_vs_autograd_of_the_oracle(parity):
     """The Resampler is trainable as a whole (train_cogvideo_to2v.py:1479-1481): train.ResamplerTrainer forward + backward (LayerNorms, to_q / to_kv /
     to_out, per-head QK-norm + the two rotary segments, the 24-query attention over 96 keys, FeedForward, proj_in / proj_out / norm_out, latents) against
     autograd through oracle.resampler_ref.resampler_forward in fp32 on the same bf16-rounded weights — every parameter of a depth-2 module."""
@@ -493,17 +506,19 @@ def test_resampler_backward_vs_autograd_of_the_oracle():
     tok_ref = out_ref.permute(0, 1, 3, 4, 2).reshape(b, 24, 128)
     G = _rand(b, 24, 128, seed=63)
     (tok_ref * G.float()).sum().backward()
+    sd16 = {k: v.detach().to(BF).requires_grad_(True) for k, v in sd.items()}                 # noise floor: the same chain in bf16 autograd
+    (RR.resampler_forward(sd16, cfg, x, img, smp).permute(0, 1, 3, 4, 2).reshape(b, 24, 128) * G).sum().backward()
+    parity(max(float(_rel(sd16[k].grad, sd[k].grad)) for k in sd), 1.0, "noise floor: bf16 autograd of the oracle vs fp32 autograd, worst tensor (informative)")
     sd_dev = {k: v.detach().to(BF).to(DEV).contiguous() for k, v in sd.items()}
     rt = train.ResamplerTrainer(sd_dev, depth=2, heads=2)
     tok, ctx = rt.forward(x.to(DEV), img, smp)
     assert _rel(tok, tok_ref.detach()) < 1e-2
     grads = rt.backward(ctx, G.to(DEV))
     assert sorted(grads) == sorted("resampler." + k for k in sd)
-    for k in sd:
-        assert _rel(grads["resampler." + k], sd[k].grad) < 4e-2, k
+    parity(max(float(_rel(grads["resampler." + k], sd[k].grad)) for k in sd), 4e-2, "worst Resampler tensor, HIP vs fp32 autograd (r2 measured 2.3e-2; compare the floor above)")
 
 
-def test_full_micro_step_with_resampler_gradients_vs_autograd_of_the_oracle_chain():
+def test_full_micro_step_with_resampler_gradients_vs_autograd_of_the_oracle_chain(parity):
     """One whole micro-step of the reference loop body (train_cogvideo_to2v.py:1931-2010) on the HIP path: Resampler over two chunks -> five temporal
     slots per batch item -> add_noise -> transformer (checkpointed) -> v-prediction loss -> backward through the transformer AND both Resampler calls,
     accumulated into the gradient arena.  Every trainable tensor (38 transformer + 38 Resampler) against autograd through the oracle chain
@@ -536,15 +551,24 @@ def test_full_micro_step_with_resampler_gradients_vs_autograd_of_the_oracle_chai
     img = O.rope_3d(64, np.arange(3, dtype=f32), np.arange(4, dtype=f32), np.arange(6, dtype=f32))
     smp = O.rope_3d(64, np.linspace(0, 3, 4, endpoint=False, dtype=f32), np.linspace(0, 4, 2, endpoint=False, dtype=f32), np.linspace(0, 6, 3, endpoint=False, dtype=f32))
     # ---- oracle chain ----
-    toks = torch.cat([RR.resampler_forward(rsd, rcfg, emb[:, c * 3:(c + 1) * 3].float(), img, smp) for c in range(2)], dim=1)      # [B, 8, 128, 2, 3]
-    toks = toks.to(BF).float()                                                        # the Resampler's output is a bf16 tensor (the cast passes gradients through)
-    vip = torch.stack([toks[b, start[b]:start[b] + 5] for b in range(B)])
     acb = ac.to(BF)
     sa, sb = (acb[ts] ** 0.5)[..., None, None, None], ((1 - acb[ts]) ** 0.5)[..., None, None, None]
     noisy = (sa * x0 + sb * noise)                                                    # scheduler.add_noise in bf16
-    out_ref = O.dit_forward(sd, cfg, noisy.float(), text.float(), ts, vip, rope, vrope, crope, vip_scale=[1.0])
-    loss_ref, _ = T.vpred_loss(ac, out_ref, noisy.float(), x0.float(), ts)
+
+    def chain(sd_, rsd_, cast):
+        toks = torch.cat([RR.resampler_forward(rsd_, rcfg, cast(emb[:, c * 3:(c + 1) * 3]), img, smp) for c in range(2)], dim=1)   # [B, 8, 128, 2, 3]
+        toks = cast(toks.to(BF))                                                      # the Resampler's output is a bf16 tensor (the cast passes gradients through)
+        vip = torch.stack([toks[b, start[b]:start[b] + 5] for b in range(B)])
+        out = O.dit_forward(sd_, cfg, cast(noisy), cast(text), ts, vip, rope, vrope, crope, vip_scale=[1.0])
+        return T.vpred_loss(ac, out, cast(noisy), cast(x0), ts)[0]
+    loss_ref = chain(sd, rsd, lambda t: t.float())
     loss_ref.backward()
+    # noise floor: the same chain in bf16 autograd (the reference trains in bf16)
+    sd16 = {k: v.detach().to(BF).requires_grad_(k in tkeys) for k, v in sd.items()}
+    rsd16 = {k: v.detach().to(BF).requires_grad_(True) for k, v in rsd.items()}
+    chain(sd16, rsd16, lambda t: t).backward()
+    parity(max([float(_rel(sd16[k].grad, sd[k].grad)) for k in tkeys] + [float(_rel(rsd16[k].grad, rsd[k].grad)) for k in rsd]), 1.0,
+           "noise floor: bf16 autograd of the oracle chain vs fp32 autograd, worst tensor (informative)")
     # ---- HIP path ----
     sd_dev = {k: v.detach().to(BF).to(DEV).contiguous() for k, v in sd.items()}
     rsd_dev = {k: v.detach().to(BF).to(DEV).contiguous() for k, v in rsd.items()}
@@ -561,10 +585,9 @@ def test_full_micro_step_with_resampler_gradients_vs_autograd_of_the_oracle_chai
     loss, did = step.micro_step(x0.to(DEV), noise.to(DEV), ts, text.to(DEV), None, rope, vrope, crope, image_embeddings=emb.to(DEV), emb_start_idx=start,
                                 resampler_ropes=(img, smp))
     assert not did and abs(loss.item() - loss_ref.item()) < 2e-2 * abs(loss_ref.item())
-    for k in tkeys:
-        assert _rel(arena.grad_view(k) * 2.0, sd[k].grad) < 5e-2, k             # the arena holds grad / accumulation_steps
-    for k in rsd:
-        assert _rel(arena.grad_view("resampler." + k) * 2.0, rsd[k].grad) < 5e-2, k
+    worst = max([float(_rel(arena.grad_view(k) * 2.0, sd[k].grad)) for k in tkeys] +                # the arena holds grad / accumulation_steps
+                [float(_rel(arena.grad_view("resampler." + k) * 2.0, rsd[k].grad)) for k in rsd])
+    parity(worst, 5e-2, "worst of the 76 trainable tensors, HIP micro-step vs fp32 autograd (r2 measured 3.7e-2; compare the floor above)")
     before = arena.param.clone()
     _, did = step.micro_step(x0.to(DEV), noise.to(DEV), ts, text.to(DEV), None, rope, vrope, crope, image_embeddings=emb.to(DEV), emb_start_idx=start,
                              resampler_ropes=(img, smp))
