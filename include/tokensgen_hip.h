@@ -170,6 +170,9 @@ typedef struct tg_attn_problem {
     float seg2_scale;
     void* out; long out_ld, out_strideB;
     int nq;
+    /* Optional (NULL = seg2_scale for every batch item): HOST array of `batch` (<= 16) weights of segment 2, one per batch item — the
+     * reference processor's `scale` list when its length equals the batch size (attention_processor.py:2126-2131). */
+    const float* seg2_scale_batch;
 } tg_attn_problem;
 /* retry_ws (optional, with every segment's k_norm2_max: enables the constant-shift path): >= tg_attention_retry_ints(nq0, nq1, heads,
  * batch) ints, zero-initialised ONCE by the caller and reusable by every later launch on the same stream; retry_ws[0] accumulates the
@@ -221,6 +224,24 @@ int tg_cfg_dpm_step(const void* model_out, const void* x, const void* old_x0, co
 int tg_cfg_dpm_step_f32(const void* model_out, const void* x, const float* old_x0, const void* noise,
                         const float* coef, float guidance, void* x_out, float* x0_out,
                         int frames, long frame_elems, hipStream_t stream);
+
+/* The general form behind the two above — every guidance / prediction branch of the reference's two sampling loops in the same single launch:
+ *   branches = 2: model_out [2][frames][E] = (uncond, cond):                       v = u + g (c - u)            (cogvideo_sampling_mp_fifo.py:531-533)
+ *   branches = 3: model_out [3][frames][E] = (uncond_txt, uncond_img, txt_img):    v = c + (g - 1)(c - ut) + (gi - 1)(c - ui)
+ *                 (`use_separate_guidance`, :528-530 / pipeline_cogvideox_mp_fifo.py:1261-1263; gi = guidance_img)
+ *   guidance_per_frame (optional, fp32 [frames][2] = {g, gi} on the device): `use_dynamic_cfg` in the FIFO worker, where the cosine schedule
+ *                 is evaluated on the window's per-frame timesteps as an fp32 TENSOR (:519-527) — which also promotes the guided
+ *                 prediction to fp32, so pass f32_math = 1 with it; NULL: the two scalars for every frame (the pipelines' dynamic cfg is a
+ *                 Python float per step, pipeline_cogvideox_mp_fifo.py:1252-1259).
+ *   f32_math:     0 = the worker's static path (guidance on bf16 tensors, every op rounded to bf16); 1 = the solver sees an fp32 model output
+ *                 (`noise_pred.float()` in the pipelines; the promoted dynamic-cfg result in the worker) while sample / noise / a bf16 old x0
+ *                 are bf16 tensors scaled by 0-dim coefficients (bf16 products).
+ *   f32_state:    old_x0 / x0_out are fp32 [frames][E] (pipelines; implies f32_math) instead of bf16 (the FIFO queue).
+ *   prediction_type: 0 v_prediction (CogVideoX-5b), 1 epsilon, 2 sample (scheduling_dpm_cogvideox.py:424-436).
+ * tg_cfg_dpm_step = (2, scalars, 0, 0, 0); tg_cfg_dpm_step_f32 = (2, scalars, 1, 1, 0). */
+int tg_cfg_dpm_step_ex(const void* model_out, int branches, const void* x, const void* old_x0, const void* noise, const float* coef,
+                       float guidance, float guidance_img, const float* guidance_per_frame, int f32_math, int f32_state,
+                       int prediction_type, void* x_out, void* x0_out, int frames, long frame_elems, hipStream_t stream);
 
 /* T2To tail (pipeline_cogvideox_t2to.py:890-899 with pca.py:64-66): the sampled latents hold `ncoef` (= 16) normalised PCA
  * coefficients per token; de-normalise and project back to the condensed-token width in fp32:

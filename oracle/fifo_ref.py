@@ -65,20 +65,28 @@ def find_embed_index(cond_t, pos, start_frame_idx):
     return int(np.searchsorted(cond_t, pos + start_frame_idx, side="right") - 1)
 
 
-def window_step(denoise, ac, guidance_scale, latents, old_x0, t, prev_t, next_t, draw, out_dtype):
+def window_step(denoise, ac, guidance_scale, latents, old_x0, t, prev_t, next_t, draw, out_dtype, use_separate_guidance=False,
+                guidance_scale_img=None, use_dynamic_cfg=False, num_inference_steps=None, prediction_type="v_prediction"):
     """Worker body :491-550: CFG-batched denoiser call, CFG combine, 13 per-frame DPM steps.
 
-    denoise(latent_in [2,nf,C,H,W], timesteps [2,nf]) -> [2,nf,C,H,W];
-    draw() -> next gaussian [1,1,C,H,W] (see scheduler_ref.dpm_step).  Returns (latents_out, x0 list)."""
+    denoise(latent_in [nb,nf,C,H,W], timesteps [nb,nf]) -> [nb,nf,C,H,W] with nb = 3 for `use_separate_guidance` (uncond_txt, uncond_img,
+    txt_img; :493-497, 528-530) else 2; `use_dynamic_cfg`: per-frame cosine guidance as an fp32 tensor (:519-527), which promotes the guided
+    prediction to fp32;  draw() -> next gaussian [1,1,C,H,W] (see scheduler_ref.dpm_step).  Returns (latents_out, x0 list)."""
     nf = latents.shape[1]
-    inp = torch.cat([latents] * 2)
-    tt = torch.as_tensor(t)[None].expand(2, -1)
-    pred = S.cfg_combine(denoise(inp, tt), guidance_scale)
+    nb = 3 if use_separate_guidance else 2
+    inp = torch.cat([latents] * nb)
+    tv = torch.as_tensor(t)
+    tt = tv[None].expand(nb, -1)
+    g, gi = guidance_scale, (guidance_scale if guidance_scale_img is None else guidance_scale_img)
+    if use_dynamic_cfg:
+        g, gi = S.dynamic_guidance(g, tv, num_inference_steps), S.dynamic_guidance(gi, tv, num_inference_steps)
+    pred = denoise(inp, tt)
+    pred = S.cfg_combine_separate(pred, g, gi) if use_separate_guidance else S.cfg_combine(pred, g)
     out = latents.clone()
     x0s = []
     for j in range(nf):
         nxt = int(next_t[j]) if next_t[j] > 0 else None
-        x, x0 = S.dpm_step(ac, pred[:, [j]], old_x0[j], int(t[j]), int(prev_t[j]), nxt, latents[:, [j]], draw)
+        x, x0 = S.dpm_step(ac, pred[:, [j]], old_x0[j], int(t[j]), int(prev_t[j]), nxt, latents[:, [j]], draw, prediction_type=prediction_type)
         out[:, [j]] = x.to(out_dtype)
         x0s.append(x0.to(out_dtype))
     return out, x0s
@@ -178,11 +186,18 @@ def run_fifo_prenoise(denoise_window, betas, ac, fifo_latents, fifo_old_x0, time
     return torch.cat(outs[T - nf:], dim=1)
 
 
-def base_stage(denoise, ac, latents, timesteps, guidance_scale, noise_fn, nf=13):
+def base_stage(denoise, ac, latents, timesteps, guidance_scale, noise_fn, nf=13, use_separate_guidance=False, guidance_scale_img=None,
+               use_dynamic_cfg=False):
     """Base stage of the pipeline, pipeline_cogvideox_mp_fifo.py:1186-1307 (chunk 0, scalar timestep, CFG in fp32,
-    whole-chunk scheduler step, latents cast back to the model dtype).  denoise(x[2,nf,...], t[2]) -> [2,nf,...];
-    noise_fn(i) -> [nf,2,C,H,W] (draw 1 of every frame is the one the 2M branch keeps).  Returns
-    (fifo_latents [1,T,C,H,W], fifo_old list, final latents)."""
+    whole-chunk scheduler step, latents cast back to the model dtype).  denoise(x[nb,nf,...], t[nb]) -> [nb,nf,...] (nb = 3 with
+    use_separate_guidance, :1197-1200); noise_fn(i) -> [nf,2,C,H,W] (draw 1 of every frame is the one the 2M branch keeps).  Returns
+    (fifo_latents [1,T,C,H,W], fifo_old list, final latents).  The default branch is pinned bit-exact to a run of the reference pipeline
+    (tests/golden/base_stage_tiny.pt); the separate-guidance / dynamic-cfg lines (:1252-1263) are the worker's expressions with Python-float
+    scales, whose tensor forms ARE pinned (fifo_worker_variants.pt)."""
+    import math
+    nb = 3 if use_separate_guidance else 2
+    gi0 = guidance_scale if guidance_scale_img is None else guidance_scale_img
+    T = len(timesteps)
     dt = latents.dtype
     fifo_lat, fifo_old, old = [], [], None
     ts = [int(t) for t in timesteps]
@@ -190,9 +205,17 @@ def base_stage(denoise, ac, latents, timesteps, guidance_scale, noise_fn, nf=13)
         k = max(0, nf - 1 - i)
         fifo_lat.insert(0, latents[:, [k]])
         fifo_old.insert(0, None if old is None else old[:, [k]])
-        pred = denoise(torch.cat([latents] * 2), torch.tensor([t, t])).float()
-        u, c = pred.chunk(2)
-        pred = u + guidance_scale * (c - u)
+        pred = denoise(torch.cat([latents] * nb), torch.tensor([t] * nb)).float()
+        g, gi = guidance_scale, gi0
+        if use_dynamic_cfg:                                                     # :1252-1259
+            g = 1 + guidance_scale * ((1 - math.cos(math.pi * ((T - t) / T) ** 5.0)) / 2)
+            gi = 1 + gi0 * ((1 - math.cos(math.pi * ((T - t) / T) ** 5.0)) / 2)
+        if use_separate_guidance:                                               # :1261-1263
+            ut, ui, c = pred.chunk(3)
+            pred = c + (g - 1) * (c - ut) + (gi - 1) * (c - ui)
+        else:
+            u, c = pred.chunk(2)
+            pred = u + g * (c - u)
         prev_t = ts[i + 1] if i + 1 < len(ts) else -1
         t_back = ts[i - 1] if i > 0 else None
         nz = noise_fn(i)

@@ -83,3 +83,18 @@ def cfg_combine(noise_pred, guidance_scale):
     """cogvideo_sampling_mp_fifo.py:531-533."""
     u, c = noise_pred.chunk(2)
     return u + guidance_scale * (c - u)
+
+
+def cfg_combine_separate(noise_pred, guidance_scale, guidance_scale_img):
+    """cogvideo_sampling_mp_fifo.py:528-530 (`use_separate_guidance`): batch rows (uncond_txt, uncond_img, txt_img).  The scales are Python floats
+    (static) or fp32 tensors shaped [1, F, 1, 1, 1] (dynamic cfg) — torch's promotion rules then decide the dtype exactly as in the reference."""
+    ut, ui, c = noise_pred.chunk(3)
+    return c + (guidance_scale - 1) * (c - ut) + (guidance_scale_img - 1) * (c - ui)
+
+
+def dynamic_guidance(scale, t, num_inference_steps):
+    """cogvideo_sampling_mp_fifo.py:519-527: the cosine ramp evaluated on the window's integer timestep TENSOR (fp32 tensor arithmetic),
+    shaped for broadcasting over [B, F, C, H, W]."""
+    import math
+    g = 1 + scale * ((1 - torch.cos(math.pi * ((num_inference_steps - t) / num_inference_steps) ** 5.0)) / 2)
+    return g[None, :, None, None, None]

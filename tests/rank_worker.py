@@ -51,6 +51,36 @@ if mode == "gradsync":                  # DDP gradient exchange of the training 
     dist.destroy_process_group()
     sys.exit(0)
 
+if mode == "broadcast":                 # runtime.broadcast_weights: rank 0 owns the weights, rank 1 must end up with them bit for bit
+    init_distributed("gloo", timeout_s=120)
+    from oracle import dit_ref as O
+    from tokensgen_amd.runtime import broadcast_weights
+    from tokensgen_amd.transformer import CogVideoXTransformer3DModel
+    cfg = dict(num_attention_heads=2, attention_head_dim=64, num_layers=2, time_embed_dim=128, text_embed_dim=64)
+    vip = dict(length=30, func_type="1", scale=[0.6], resampler_params=dict(output_dim=128, num_height_queries=2, num_width_queries=3, num_temporal_queries=4))
+    want = {k: v.to(torch.bfloat16) for k, v in O.make_state_dict(dict(cfg, patch_size=2, in_channels=16, out_channels=16), n_vip_dim=128, seed=77).items()}
+
+    def build():
+        m = CogVideoXTransformer3DModel(**cfg, use_rotary_positional_embeddings=True, device="cpu")
+        m.set_vip_layers(None, **vip)
+        return m
+    # (a) explicit call: rank 0 loaded, rank 1 holds its constructor's values
+    m = build()
+    if rank == 0:
+        m.load_state_dict(want, strict=True)
+    m.attn_path = "running_max"
+    nbytes = broadcast_weights(m, src=0)
+    sd = m.state_dict()
+    ok = nbytes > 0 and sorted(sd) == sorted(want) and all(torch.equal(sd[k], want[k]) for k in want) and m.attn_path == "constant_shift"
+    # (b) from_pretrained(broadcast=True): only rank 0's directory holds the safetensors file; rank 1 has config.json alone
+    m2 = CogVideoXTransformer3DModel.from_pretrained(os.path.join(outdir, f"ckpt{rank}"), device="cpu", broadcast=True)
+    sd2 = m2.state_dict()
+    base = {k: v for k, v in want.items() if "vip_" not in k}
+    ok = ok and all(torch.equal(sd2[k], base[k]) for k in base)
+    done("ok" if ok else "mismatch")
+    dist.destroy_process_group()
+    sys.exit(0)
+
 if mode == "raise":                     # rank 1's denoiser raises in FIFO iteration 3: EVERY rank must get RankFailure in that iteration
     init_distributed("gloo", timeout_s=120)
     import test_fifo_cpu as T

@@ -152,3 +152,95 @@ def test_base_stage_vs_reference_pipeline_golden(golden_dir, parity):
     x0 = torch.cat([o for o in out.fifo_old_pred_original_sample if o is not None], dim=1)
     x0r = torch.cat([o for o in c["fifo_old"] if o is not None], dim=1)
     parity(rel(x0, x0r), 2e-2, "base stage x0 seed list vs reference pipeline run")
+
+
+def test_fifo_worker_guidance_variants_vs_reference_runs(golden_dir, parity):
+    """FifoWorker.window_step on the HIP path against RUNS OF THE REFERENCE WORKER BODY (`fifo_onestep_per_gpu`,
+    cogvideo_sampling_mp_fifo.py:408-579; tests/golden/fifo_worker_variants.pt, bf16 cases) for the branches the shipped configs leave off:
+    3-way `use_separate_guidance` with guidance_scale_img (B = 3 forward, tg_cfg_dpm_step_ex branches = 3), `use_dynamic_cfg` (per-frame fp32
+    guidance -> fp32 solver arithmetic), both together, and an epsilon-prediction scheduler — head window (prev_t = -1) and tail window
+    (t = 999 / no back step), with the reference's gaussian draws replayed in order."""
+    from tokensgen_amd.fifo import FifoWorker
+    from tokensgen_amd.scheduler import CogVideoXDPMScheduler
+    from tokensgen_amd.transformer import CogVideoXTransformer3DModel
+    gt = torch.load(os.path.join(golden_dir, "dit_tiny.pt"), weights_only=False)
+    g = torch.load(os.path.join(golden_dir, "fifo_worker_variants.pt"), weights_only=False)
+    cfg, vipcfg, H, W, nf = gt["cfg"], gt["vip"], g["H"], g["W"], 13
+    sd = {k: v.to(BF) for k, v in O.make_state_dict(cfg, 128, seed=g["weight_seed"]).items()}
+    m = CogVideoXTransformer3DModel(num_attention_heads=2, attention_head_dim=64, num_layers=2, time_embed_dim=cfg["time_embed_dim"],
+                                    text_embed_dim=cfg["text_embed_dim"], use_rotary_positional_embeddings=True, device=DEV)
+    m.set_vip_layers(None, **vipcfg)
+    m.load_state_dict(sd, strict=True)
+    rope = O.rope_3d_crop(64, (0, 0, 0), (nf, H // 2, W // 2), (nf, H // 2, W // 2))
+    seen = set()
+    for c in g["cases"]:
+        if "bfloat16" not in c["dtype"]:
+            continue
+        sched = CogVideoXDPMScheduler(prediction_type=c["prediction_type"], rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
+        sched.set_timesteps(52)
+        w = FifoWorker(m, sched, c["prompt"], rope, c["guidance_scale"], c["grid_h"], c["grid_w"], c["cond_h"], c["cond_w"],
+                       use_separate_guidance=c["separate"], guidance_scale_img=c["guidance_scale_img"], use_dynamic_cfg=c["dynamic"],
+                       num_inference_steps=52)
+        t, prev_t, next_t = c["t"].tolist(), c["prev_t"].tolist(), c["next_t"].tolist()
+        has_old = [o is not None for o in c["old"]]
+        old = torch.stack([(o if o is not None else torch.zeros(1, 1, 16, H, W, dtype=BF))[0, 0] for o in c["old"]]).to(DEV)
+        gen = torch.Generator().manual_seed(c["rng_seed"])                     # the reference's draws, in its order: one per frame, a second on the 2M branch
+        noise = torch.zeros(nf, 2, 16, H, W, dtype=BF)
+        for j in range(nf):
+            noise[j, 0] = torch.randn(1, 1, 16, H, W, generator=gen, dtype=BF)[0, 0]
+            if has_old[j] and prev_t[j] >= 0:
+                noise[j, 1] = torch.randn(1, 1, 16, H, W, generator=gen, dtype=BF)[0, 0]
+        x, x0 = w.window_step(c["latents"].to(DEV), old, has_old, t, prev_t, next_t, noise.to(DEV), c["grid_t"], c["cond_t"], c["image_embeddings"].to(DEV))
+        rel = lambda a, b: ((a.float().cpu() - b.float()).norm() / b.float().norm()).item()
+        tag = f"{c['name']} window@{c['start']}"
+        parity(rel(x, c["out_latents"]), 2e-2, f"worker latents, {tag}, HIP vs reference worker run (bf16)")
+        parity(rel(x0, torch.cat(c["out_x0"], dim=1)[0]), 2e-2, f"worker x0, {tag}")
+        seen.add(c["name"])
+    assert seen == {"separate", "dynamic", "separate_dynamic", "epsilon_static"}
+
+
+@pytest.mark.timeout(900)
+def test_base_stage_separate_guidance_and_dynamic_cfg_vs_oracle(golden_dir, parity):
+    """The pipeline base stage with `use_separate_guidance` (3-way batch, guidance_scale_img) + `use_dynamic_cfg`
+    (pipeline_cogvideox_mp_fifo.py:1026-1029, 1197-1200, 1252-1263) on the HIP path (B = 3 forwards, tg_cfg_dpm_step_ex with three branches and
+    the fp32 solver state) against the oracle's base stage with the same keyed noise; the result then seeds a FIFO run in the same mode."""
+    from tokensgen_amd import fifo
+    from tokensgen_amd.pipeline import MPFIFOVideoIPAdapterCogVideoXPipeline
+    from tokensgen_amd.scheduler import CogVideoXDPMScheduler
+    from tokensgen_amd.transformer import CogVideoXTransformer3DModel
+    gt = torch.load(os.path.join(golden_dir, "dit_tiny.pt"), weights_only=False)
+    g = torch.load(os.path.join(golden_dir, "fifo_tiny.pt"), weights_only=False)
+    cfg, vipcfg = gt["cfg"], gt["vip"]
+    sd = {k: v.to(BF) for k, v in O.make_state_dict(cfg, 128, seed=g["weight_seed"]).items()}
+    H, W, nf, T = g["H"], g["W"], 13, 52
+    gen = torch.Generator().manual_seed(78)
+    lat0 = torch.randn(1, nf, 16, H, W, generator=gen).to(BF)
+    prompt = g["prompt"].to(BF)
+    emb1 = g["image_embeddings"].to(BF)[:1, :8]
+    unc = torch.randn(1, 8, 128, 2, 3, generator=gen).to(BF)                    # stands for the tokens of an all-zero video
+    emb3 = torch.cat([emb1, unc, emb1], dim=0)
+    prompt3 = torch.cat([prompt[:1], prompt[1:], prompt[1:]], dim=0)
+    rope = O.rope_3d_crop(64, (0, 0, 0), (nf, H // 2, W // 2), (nf, H // 2, W // 2))
+    _, ac = S.alphas_cumprod()
+    ts = S.trailing_timesteps(T)
+    vr = O.rope_3d(64, g["grid_t"][:13], g["grid_h"], g["grid_w"])
+    cr = O.rope_3d(64, g["cond_t"][:5], g["cond_h"], g["cond_w"])
+    den = lambda x, t: O.dit_forward(sd, cfg, x, prompt3, t, emb3[:, :5], rope, vr, cr, vip_scale=[0.6])
+    ref_lat, ref_old, ref_final = Fq.base_stage(den, ac, lat0, ts, 6.0, lambda i: _noise(i, 5, (nf, 2, 16, H, W)), use_separate_guidance=True,
+                                                guidance_scale_img=4.0, use_dynamic_cfg=True)
+    m = CogVideoXTransformer3DModel(num_attention_heads=2, attention_head_dim=64, num_layers=2, time_embed_dim=cfg["time_embed_dim"],
+                                    text_embed_dim=cfg["text_embed_dim"], use_rotary_positional_embeddings=True, device=DEV)
+    m.set_vip_layers(None, **vipcfg)
+    m.load_state_dict(sd, strict=True)
+    sched = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
+    pipe = MPFIFOVideoIPAdapterCogVideoXPipeline(m, sched, resampler_config=dict(num_temporal_queries=4, num_height_queries=2, num_width_queries=3))
+    out = pipe(prompt_embeds=prompt[1:], negative_prompt_embeds=prompt[:1], image_embeddings=emb3, height=H * 8, width=W * 8, latents=lat0,
+               step_noise=lambda i: _noise(i, 5, (nf, 2, 16, H, W)), use_separate_guidance=True, guidance_scale_img=4.0, use_dynamic_cfg=True)
+    rel = lambda a, b: ((a.float().cpu() - b.float()).norm() / b.float().norm()).item()
+    parity(rel(out.fifo_latents, ref_lat), 2e-2, "3-way + dynamic base stage, FIFO seed latents vs oracle")
+    parity(rel(out.orig_latents, ref_final), 2e-2, "3-way + dynamic base stage, final latents vs oracle")
+    assert out.use_separate_guidance and out.use_dynamic_cfg and out.prompt_embeds.shape[0] == 3 and out.image_embeddings.shape[0] == 3
+    # the FIFO stage accepts that output (3-way windows, per-frame dynamic guidance) and stays finite for a few iterations
+    out.num_frames = 1                                       # 40 iterations: enough to leave the ramp
+    lat = fifo.cogvideo_fifo_mp_v2([pipe], out, noise_seed=3)[1]
+    assert lat.shape[1] == 1 and bool(torch.isfinite(lat).all())

@@ -257,6 +257,43 @@ def test_cfg_dpm_step_matches_oracle(K):
         assert (xo[f].cpu().float() - prev).abs().max().item() <= 2e-2 * prev.abs().max().item() + 1e-3, (t, p)
 
 
+@pytest.mark.parametrize("pred", ["v_prediction", "epsilon", "sample"])
+@pytest.mark.parametrize("branches,dynamic", [(2, False), (3, False), (2, True), (3, True)])
+def test_cfg_dpm_step_ex_variants_match_oracle(K, branches, dynamic, pred):
+    """tg_cfg_dpm_step_ex against the oracle's worker arithmetic run on bf16 tensors (torch's own promotion rules = the reference's): 2-way and
+    3-way (`use_separate_guidance`) guidance, static Python-float scales (bf16 result) and the dynamic per-frame fp32 guidance tensor (promoted
+    fp32 result -> the solver's f32 arithmetic), all three prediction types (cogvideo_sampling_mp_fifo.py:519-550,
+    scheduling_dpm_cogvideox.py:424-463); pinned to reference runs by tests/test_oracle_golden.py::test_fifo_worker_guidance_variants_match_reference."""
+    from oracle import scheduler_ref as S
+    from tokensgen_amd.scheduler import dpm_coef_row
+    _, ac = S.alphas_cumprod()
+    frames, E = 5, 16 * 4 * 6
+    mo, x, old, noise = _rand(branches, frames, E, seed=11), _rand(frames, E, seed=12), _rand(frames, E, seed=13), _rand(frames, 2, E, seed=14)
+    cases = [(980, 961, 999, True), (499, 480, 518, True), (18, -1, 37, True), (37, 18, 57, False), (961, 941, 980, True)]
+    if pred == "v_prediction":
+        cases[0] = (999, 980, None, False)                    # alphas_cumprod = 0: only v-prediction is finite there
+    coef = torch.tensor([dpm_coef_row(ac, t, p, tb, ho) for (t, p, tb, ho) in cases], dtype=torch.float32, device=DEV)
+    tv = torch.tensor([c[0] for c in cases])
+    g, gi = 6.0, 4.0
+    gpf = None
+    if dynamic:
+        gt_, gti = S.dynamic_guidance(g, tv, 52), S.dynamic_guidance(gi, tv, 52)       # [1, F, 1, 1, 1] fp32
+        gpf = torch.stack([gt_.flatten(), gti.flatten()], dim=1).float().contiguous().to(DEV)
+    xo, x0o = torch.empty_like(x), torch.empty_like(x)
+    K.cfg_dpm_step_ex(mo, x, old, noise, coef, g, xo, x0o, guidance_img=gi, guidance_per_frame=gpf, f32_math=dynamic, prediction_type=pred)
+    moc = mo.cpu().view(branches, frames, 1, 1, E)                                       # [B, F, C, H, W]-shaped for the oracle's broadcasting
+    gg, ggi = (gt_, gti) if dynamic else (g, gi)
+    v = S.cfg_combine_separate(moc, gg, ggi) if branches == 3 else S.cfg_combine(moc, gg)
+    assert v.dtype == (torch.float32 if dynamic else torch.bfloat16)
+    for f, (t, p, tb, ho) in enumerate(cases):
+        it = iter([noise[f, 0].cpu().view(1, 1, 1, 1, E), noise[f, 1].cpu().view(1, 1, 1, 1, E)])
+        prev, x0 = S.dpm_step(ac, v[:, [f]], old[f].cpu().view(1, 1, 1, 1, E) if ho else None, t, p, tb, x[f].cpu().view(1, 1, 1, 1, E), lambda: next(it),
+                              prediction_type=pred)
+        prev, x0 = prev.to(torch.bfloat16).flatten(), x0.to(torch.bfloat16).flatten()     # the worker casts both back (:549-550)
+        assert _rel(x0o[f].cpu(), x0) < 6e-3, (t, p, "x0")
+        assert _rel(xo[f].cpu(), prev) < 6e-3, (t, p, "prev")
+
+
 def test_attention_cases_again_on_the_pingpong_kernel():
     """tg_attention_fwd picks the 8-wave ping-pong kernel only for long query ranges (>= 1024 workgroups of 512 rows); the cases above
     are too small for it.  TG_ATTN_PP_MIN_WG is read once per process, so re-run them in a child process with the threshold at 1:

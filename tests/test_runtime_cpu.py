@@ -55,6 +55,29 @@ def test_gradient_all_reduce_buckets_two_ranks(tmp_path):
     assert _read(tmp_path, 0) == "ok" and _read(tmp_path, 1) == "ok"
 
 
+@pytest.mark.timeout(180)
+def test_weight_broadcast_two_ranks(tmp_path):
+    """runtime.broadcast_weights (north_star: "RCCL broadcast of weights"; replaces the reference's whole-pipeline CUDA-IPC pickling,
+    cogvideo_sampling_mp_fifo.py:195-221) on gloo: rank 1 ends up with rank 0's state dict bit for bit — through the explicit call on the fused
+    storages (large tensors one by one, small ones in coalesced buckets) and through from_pretrained(broadcast=True), where rank 1's checkpoint
+    directory holds config.json ONLY (it cannot have read the weights from disk)."""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    from oracle import dit_ref as O
+    from tokensgen_amd.runtime import launch
+    cfg = dict(num_attention_heads=2, attention_head_dim=64, num_layers=2, time_embed_dim=128, text_embed_dim=64, use_rotary_positional_embeddings=True)
+    sd = {k: v.to(torch.bfloat16).contiguous() for k, v in O.make_state_dict(dict(cfg, patch_size=2, in_channels=16, out_channels=16), n_vip_dim=128, seed=77).items()
+          if "vip_" not in k}
+    for r in (0, 1):
+        d = tmp_path / f"ckpt{r}"
+        d.mkdir()
+        (d / "config.json").write_text(json.dumps(dict(cfg, _class_name="CogVideoXTransformer3DModel")))
+    save_file(sd, str(tmp_path / "ckpt0" / "diffusion_pytorch_model.safetensors"))
+    launch(2, [sys.executable, WORKER, "broadcast", str(tmp_path)])
+    assert _read(tmp_path, 0) == "ok" and _read(tmp_path, 1) == "ok"
+
+
 def test_arena_order_is_backward_order_and_keeps_qkv_adjacent():
     from tokensgen_amd.optim import arena_order
     names = [f"transformer_blocks.{i}.{n}" for i in range(3) for n in

@@ -583,14 +583,14 @@ def test_full_micro_step_with_resampler_gradients_vs_autograd_of_the_oracle_chai
     step = train.To2VTrainStep(tr, arena, opt, ac, accumulation_steps=2, resampler=rt)
     step.latent_frames_per_chunk = 3
     loss, did = step.micro_step(x0.to(DEV), noise.to(DEV), ts, text.to(DEV), None, rope, vrope, crope, image_embeddings=emb.to(DEV), emb_start_idx=start,
-                                resampler_ropes=(img, smp))
+                                resampler_ropes=(img, smp), vip_frames=5)
     assert not did and abs(loss.item() - loss_ref.item()) < 2e-2 * abs(loss_ref.item())
     worst = max([float(_rel(arena.grad_view(k) * 2.0, sd[k].grad)) for k in tkeys] +                # the arena holds grad / accumulation_steps
                 [float(_rel(arena.grad_view("resampler." + k) * 2.0, rsd[k].grad)) for k in rsd])
     parity(worst, 5e-2, "worst of the 76 trainable tensors, HIP micro-step vs fp32 autograd (r2 measured 3.7e-2; compare the floor above)")
     before = arena.param.clone()
     _, did = step.micro_step(x0.to(DEV), noise.to(DEV), ts, text.to(DEV), None, rope, vrope, crope, image_embeddings=emb.to(DEV), emb_start_idx=start,
-                             resampler_ropes=(img, smp))
+                             resampler_ropes=(img, smp), vip_frames=5)
     assert did and opt.t == 1 and float(arena.grad.abs().max()) == 0.0
     moved = (arena.param != before)
     assert moved[:n_clip].float().mean().item() > 0.3 and moved[n_clip:].float().mean().item() > 0.3      # transformer and Resampler parameters both stepped

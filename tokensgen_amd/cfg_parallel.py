@@ -30,16 +30,16 @@ def resolve(mode):
     raise ValueError(f"cfg_parallel={mode!r}")
 
 
-def predict(mode, forward_half, forward_both):
-    """forward_half(h) -> prediction [1, ...] of CFG half h (0 = unconditional, 1 = conditional); forward_both() -> [2, ...].
-    Returns the [2, ...] prediction tensor on every rank."""
-    if mode == "batched":
+def predict(mode, forward_half, forward_both, n=2):
+    """forward_half(h) -> prediction [1, ...] of guidance branch h (0 = unconditional, 1 = conditional; with `use_separate_guidance` n = 3:
+    uncond_txt, uncond_img, txt_img); forward_both() -> [n, ...].  Returns the [n, ...] prediction tensor on every rank."""
+    world, me = world_and_rank()
+    if mode == "batched" or (mode == "parallel" and world < n):
         return forward_both()
     if mode == "emulate":
-        return torch.cat([forward_half(0), forward_half(1)], dim=0)
+        return torch.cat([forward_half(h) for h in range(n)], dim=0)
     import torch.distributed as dist
-    world, me = world_and_rank()
-    mine = forward_half(me % 2).contiguous()
+    mine = forward_half(me % n).contiguous()
     allp = torch.empty((world,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
     dist.all_gather_into_tensor(allp, mine)
-    return allp[:2].contiguous()          # rank 0 holds half 0, rank 1 holds half 1
+    return allp[:n].contiguous()          # rank h < n holds branch h

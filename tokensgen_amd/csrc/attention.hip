@@ -40,7 +40,7 @@ struct Seg {
 struct AttnParams {
     Seg s[2];
     int nseg;
-    float seg2_scale;
+    float seg2_scale_b[16];   // weight of segment 2 per batch item (index b & 15): one value for the batch, or the reference's per-item scale list
     bf16_t* out; long o_ld, o_sb;
     int nq, heads, batch;
     float scale_log2;   // softmax scale * log2(e)
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
-            const float w = (sg == 0 ? 1.f : p.seg2_scale) / lt;
+            const float w = (sg == 0 ? 1.f : p.seg2_scale_b[b & 15]) / lt;
             const int q = q0 + qb * 32 + j;
             if (p.lse && hi == 0 && q < p.nq) p.lse[((long)b * p.heads + h) * p.lse_rows + q] = m[qb] + log2f(lt);
             if (q < p.nq) {
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
-            const float w = (sg == 0 ? 1.f : p.seg2_scale) / lt;
+            const float w = (sg == 0 ? 1.f : p.seg2_scale_b[b & 15]) / lt;
             const int row = qb * 32 + j;
             if (LSE && hi == 0 && q0 + row < nq_) p.lse[((long)b * p.heads + h) * p.lse_rows + q0 + row] = m[qb] + log2f(lt);
             if (FIXEDM == 1) {       // verification of the constant shift (see the kernel header); also catches a NaN / inf row sum
@@ -812,7 +812,7 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
     if (p.r_nq > 0 && !pp) {
         // the rider needs the ping-pong kernel: run it as a launch of its own through the ordinary dispatch
         AttnParams r{};
-        r.s[0] = p.r_s; r.nseg = 1; r.seg2_scale = 0.f;
+        r.s[0] = p.r_s; r.nseg = 1;
         r.out = p.r_out; r.o_ld = p.r_o_ld; r.o_sb = p.r_o_sb;
         r.nq = p.r_nq; r.heads = heads; r.batch = batch;
         p.r_nq = 0;
@@ -936,7 +936,8 @@ extern "C" int tg_attention_fwd_multi(const tg_attn_problem* problems, int nprob
     if (rc) return rc;
     p.nseg = A.nseg;
     if (A.nseg == 2 && (rc = fill_segment(p.s[1], A.seg[1], "problem 0 segment 2"))) return rc;
-    p.seg2_scale = A.seg2_scale;
+    TG_REQUIRE(!A.seg2_scale_batch || batch <= 16, TG_ERR_SHAPE, "tg_attention_fwd_multi: per-item segment-2 scales for at most 16 batch items (got %d)", batch);
+    for (int i = 0; i < 16; ++i) p.seg2_scale_b[i] = A.seg2_scale_batch ? A.seg2_scale_batch[i < batch ? i : batch - 1] : A.seg2_scale;
     p.out = (bf16_t*)A.out; p.o_ld = A.out_ld; p.o_sb = A.out_strideB;
     p.nq = A.nq; p.heads = heads; p.batch = batch;
     if (nproblems == 2) {

@@ -74,57 +74,57 @@ __global__ void rope_table_3d_kernel(const float* __restrict__ pos_t, int T, con
     *(float2*)(sin_out + o) = float2{sn, sn};
 }
 
-// coef row: {sa, sb, m1, m2, m3, m4, mn, has_old}
-__global__ void cfg_dpm_step_kernel(const bf16_t* __restrict__ mo, const bf16_t* __restrict__ x,
-                                    const bf16_t* __restrict__ old_x0, const bf16_t* __restrict__ noise,
-                                    const float* __restrict__ coef, float guidance, bf16_t* __restrict__ x_out,
-                                    bf16_t* __restrict__ x0_out, int frames, long fe) {
+// Fused guidance + SDE-DPM-solver++ step for `frames` frames with their own coefficient rows {sa, sb, m1, m2, m3, m4, mn, has_old}.
+//   BR = 2: model_out = (uncond, cond)                      v = u + g (c - u)                               (cogvideo_sampling_mp_fifo.py:531-533)
+//   BR = 3: model_out = (uncond_txt, uncond_img, txt_img)   v = c + (g - 1)(c - ut) + (gi - 1)(c - ui)      (:528-530, use_separate_guidance)
+//   g / gi: per frame from `gpf` [frames][2] when given (use_dynamic_cfg builds an fp32 tensor over the window's timesteps, :519-527), else the
+//   two scalars.
+//   F32MATH = false — the FIFO worker with static guidance: guidance is Python-float arithmetic on bf16 tensors, every op rounds to bf16;
+//                     the solver runs on that bf16 tensor (fp32 inside the kernel, one rounding per output).
+//   F32MATH = true  — the model output reaches the solver as an fp32 tensor: the pipelines call `noise_pred.float()` first
+//                     (pipeline_cogvideox_mp_fifo.py:1236-1276, pipeline_cogvideox_t2to.py:845-870), and in the worker's dynamic-cfg branch the
+//                     fp32 guidance TENSOR promotes the combination.  The sample, the noise and a bf16 old x0 are still bf16 tensors multiplied
+//                     by 0-dim fp64 coefficients, which torch evaluates as bf16(coefficient) x tensor -> bf16 before the fp32 additions.
+//   F32STATE: old_x0 / x0_out are fp32 (pipelines keep the solver history in fp32) or bf16 (the FIFO queue holds model-dtype x0).
+//   pred: 0 v_prediction, 1 epsilon, 2 sample (scheduling_dpm_cogvideox.py:424-436).
+template <int BR, bool F32MATH, bool F32STATE>
+__global__ void cfg_dpm_step_kernel(const bf16_t* __restrict__ mo, const bf16_t* __restrict__ x, const void* __restrict__ old_x0_,
+                                    const bf16_t* __restrict__ noise, const float* __restrict__ coef, float g_s, float gi_s,
+                                    const float* __restrict__ gpf, int pred, bf16_t* __restrict__ x_out, void* __restrict__ x0_out_,
+                                    int frames, long fe) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)frames * fe;
     if (idx >= total) return;
     const int f = (int)(idx / fe);
     const long e = idx - (long)f * fe;
     const float* c = coef + f * 8;
-    const float u = bf16_to_f32(mo[idx]), cd = bf16_to_f32(mo[total + idx]);
-    // CFG result is a bf16 tensor in the reference worker (cogvideo_sampling_mp_fifo.py:531-533)
-    const float v = round_bf16(u + guidance * (cd - u));
+    const float g = gpf ? gpf[2 * f] : g_s, gi = gpf ? gpf[2 * f + 1] : gi_s;
+    float v;
+    if (BR == 2) {
+        const float u = bf16_to_f32(mo[idx]), cd = bf16_to_f32(mo[total + idx]);
+        if (F32MATH) v = gpf ? u + g * round_bf16(cd - u) : u + g * (cd - u);      // fp32 guidance tensor x the bf16 difference | all fp32 after .float()
+        else v = round_bf16(u + round_bf16(g * round_bf16(cd - u)));
+    } else {
+        const float ut = bf16_to_f32(mo[idx]), ui = bf16_to_f32(mo[total + idx]), cd = bf16_to_f32(mo[2 * total + idx]);
+        if (F32MATH) v = gpf ? cd + (g - 1.f) * round_bf16(cd - ut) + (gi - 1.f) * round_bf16(cd - ui) : cd + (g - 1.f) * (cd - ut) + (gi - 1.f) * (cd - ui);
+        else v = round_bf16(round_bf16(cd + round_bf16((g - 1.f) * round_bf16(cd - ut))) + round_bf16((gi - 1.f) * round_bf16(cd - ui)));
+    }
     const float xs = bf16_to_f32(x[idx]);
-    const float x0 = c[0] * xs - c[1] * v;
+    float x0;
+    if (F32MATH) x0 = pred == 0 ? round_bf16(round_bf16(c[0]) * xs) - c[1] * v : pred == 1 ? (xs - c[1] * v) / c[0] : v;
+    else x0 = pred == 0 ? c[0] * xs - c[1] * v : pred == 1 ? (xs - c[1] * v) / c[0] : v;
     const bool has_old = c[7] != 0.f;
     float d = x0;
-    if (has_old) d = c[4] * x0 - c[5] * bf16_to_f32(old_x0[idx]);
+    if (has_old) {
+        if (F32STATE) d = c[4] * x0 - c[5] * ((const float*)old_x0_)[idx];
+        else if (F32MATH) d = c[4] * x0 - round_bf16(round_bf16(c[5]) * bf16_to_f32(((const bf16_t*)old_x0_)[idx]));
+        else d = c[4] * x0 - c[5] * bf16_to_f32(((const bf16_t*)old_x0_)[idx]);
+    }
     const float nz = bf16_to_f32(noise[((long)f * 2 + (has_old ? 1 : 0)) * fe + e]);
-    x_out[idx] = f32_to_bf16(c[2] * xs - c[3] * d + c[6] * nz);
-    x0_out[idx] = f32_to_bf16(x0);
-}
-
-
-// Pipeline-loop variant (pipeline_cogvideox_t2to.py:845-870, pipeline_cogvideox_mp_fifo.py:1236-1276): the pipelines take
-// `noise_pred.float()` before guidance, so CFG, x0 and the solver history stay fp32; the gaussian draws take the SAMPLE's
-// dtype (bf16, scheduling_dpm_cogvideox.py:452,460) and the new sample is cast back to the model dtype after the step.
-__global__ void cfg_dpm_step_f32_kernel(const bf16_t* __restrict__ mo, const bf16_t* __restrict__ x,
-                                        const float* __restrict__ old_x0, const bf16_t* __restrict__ noise,
-                                        const float* __restrict__ coef, float guidance, bf16_t* __restrict__ x_out,
-                                        float* __restrict__ x0_out, int frames, long fe) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)frames * fe;
-    if (idx >= total) return;
-    const int f = (int)(idx / fe);
-    const long e = idx - (long)f * fe;
-    const float* c = coef + f * 8;
-    const float u = bf16_to_f32(mo[idx]), cd = bf16_to_f32(mo[total + idx]);
-    const float v = u + guidance * (cd - u);
-    const float xs = bf16_to_f32(x[idx]);
-    // the sample and the noise are bf16 tensors and the coefficients are 0-dim fp64 tensors, which do not widen them: in
-    // `sa * sample`, `m1 * sample` and `mn * noise` torch first casts the coefficient to bf16, then rounds the product to bf16
-    // (scheduling_dpm_cogvideox.py:437,457-463); everything after is fp32
-    const float x0 = round_bf16(round_bf16(c[0]) * xs) - c[1] * v;
-    const bool has_old = c[7] != 0.f;
-    float d = x0;
-    if (has_old) d = c[4] * x0 - c[5] * old_x0[idx];
-    const float nz = bf16_to_f32(noise[((long)f * 2 + (has_old ? 1 : 0)) * fe + e]);
-    x_out[idx] = f32_to_bf16(round_bf16(round_bf16(c[2]) * xs) - c[3] * d + round_bf16(round_bf16(c[6]) * nz));
-    x0_out[idx] = x0;
+    if (F32MATH) x_out[idx] = f32_to_bf16(round_bf16(round_bf16(c[2]) * xs) - c[3] * d + round_bf16(round_bf16(c[6]) * nz));
+    else x_out[idx] = f32_to_bf16(c[2] * xs - c[3] * d + c[6] * nz);
+    if (F32STATE) ((float*)x0_out_)[idx] = x0;
+    else ((bf16_t*)x0_out_)[idx] = f32_to_bf16(x0);
 }
 
 // T2To tail (pipeline_cogvideox_t2to.py:890-899, pca.py:64-66): de-normalise the 16 sampled coefficients and take them back
@@ -246,29 +246,47 @@ extern "C" int tg_unpatchify(const void* x, long ldx, void* lat, int bf, int C, 
     return TG_OK;
 }
 
+static int cfg_dpm_launch(const char* who, const void* model_out, int branches, const void* x, const void* old_x0, const void* noise, const float* coef,
+                          float guidance, float guidance_img, const float* guidance_per_frame, int f32_math, int f32_state, int prediction_type,
+                          void* x_out, void* x0_out, int frames, long frame_elems, hipStream_t stream) {
+    TG_REQUIRE(model_out && x && old_x0 && noise && coef && x_out && x0_out, TG_ERR_ARG, "%s: null pointer", who);
+    TG_REQUIRE(frames > 0 && frame_elems > 0, TG_ERR_SHAPE, "%s: bad shape", who);
+    TG_REQUIRE(branches == 2 || branches == 3, TG_ERR_ARG, "%s: branches must be 2 (uncond, cond) or 3 (uncond_txt, uncond_img, txt_img)", who);
+    TG_REQUIRE(prediction_type >= 0 && prediction_type <= 2, TG_ERR_ARG, "%s: prediction_type %d", who, prediction_type);
+    TG_REQUIRE(f32_math || !f32_state, TG_ERR_ARG, "%s: an fp32 solver state implies fp32 model-output arithmetic", who);
+    const long total = (long)frames * frame_elems;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+#define TG_DPM(BR_, FM_, FS_)                                                                                                                  \
+    hipLaunchKernelGGL((cfg_dpm_step_kernel<BR_, FM_, FS_>), grid, block, 0, stream, (const bf16_t*)model_out, (const bf16_t*)x, old_x0,        \
+                       (const bf16_t*)noise, coef, guidance, guidance_img, guidance_per_frame, prediction_type, (bf16_t*)x_out, x0_out, frames, \
+                       frame_elems)
+    if (branches == 2) {
+        if (f32_state) TG_DPM(2, true, true); else if (f32_math) TG_DPM(2, true, false); else TG_DPM(2, false, false);
+    } else {
+        if (f32_state) TG_DPM(3, true, true); else if (f32_math) TG_DPM(3, true, false); else TG_DPM(3, false, false);
+    }
+#undef TG_DPM
+    TG_LAUNCH_CHECK(who);
+    return TG_OK;
+}
+
 extern "C" int tg_cfg_dpm_step(const void* model_out, const void* x, const void* old_x0, const void* noise,
                                const float* coef, float guidance, void* x_out, void* x0_out, int frames,
                                long frame_elems, hipStream_t stream) {
-    TG_REQUIRE(model_out && x && old_x0 && noise && coef && x_out && x0_out, TG_ERR_ARG, "tg_cfg_dpm_step: null pointer");
-    TG_REQUIRE(frames > 0 && frame_elems > 0, TG_ERR_SHAPE, "tg_cfg_dpm_step: bad shape");
-    const long total = (long)frames * frame_elems;
-    hipLaunchKernelGGL(cfg_dpm_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)model_out,
-                       (const bf16_t*)x, (const bf16_t*)old_x0, (const bf16_t*)noise, coef, guidance, (bf16_t*)x_out, (bf16_t*)x0_out,
-                       frames, frame_elems);
-    TG_LAUNCH_CHECK("tg_cfg_dpm_step");
-    return TG_OK;
+    return cfg_dpm_launch("tg_cfg_dpm_step", model_out, 2, x, old_x0, noise, coef, guidance, 0.f, nullptr, 0, 0, 0, x_out, x0_out, frames, frame_elems, stream);
 }
 
 extern "C" int tg_cfg_dpm_step_f32(const void* model_out, const void* x, const float* old_x0, const void* noise,
                                    const float* coef, float guidance, void* x_out, float* x0_out, int frames,
                                    long frame_elems, hipStream_t stream) {
-    TG_REQUIRE(model_out && x && old_x0 && noise && coef && x_out && x0_out, TG_ERR_ARG, "tg_cfg_dpm_step_f32: null pointer");
-    TG_REQUIRE(frames > 0 && frame_elems > 0, TG_ERR_SHAPE, "tg_cfg_dpm_step_f32: bad shape");
-    const long total = (long)frames * frame_elems;
-    hipLaunchKernelGGL(cfg_dpm_step_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)model_out,
-                       (const bf16_t*)x, old_x0, (const bf16_t*)noise, coef, guidance, (bf16_t*)x_out, x0_out, frames, frame_elems);
-    TG_LAUNCH_CHECK("tg_cfg_dpm_step_f32");
-    return TG_OK;
+    return cfg_dpm_launch("tg_cfg_dpm_step_f32", model_out, 2, x, old_x0, noise, coef, guidance, 0.f, nullptr, 1, 1, 0, x_out, x0_out, frames, frame_elems, stream);
+}
+
+extern "C" int tg_cfg_dpm_step_ex(const void* model_out, int branches, const void* x, const void* old_x0, const void* noise, const float* coef,
+                                  float guidance, float guidance_img, const float* guidance_per_frame, int f32_math, int f32_state,
+                                  int prediction_type, void* x_out, void* x0_out, int frames, long frame_elems, hipStream_t stream) {
+    return cfg_dpm_launch("tg_cfg_dpm_step_ex", model_out, branches, x, old_x0, noise, coef, guidance, guidance_img, guidance_per_frame, f32_math,
+                          f32_state, prediction_type, x_out, x0_out, frames, frame_elems, stream);
 }
 
 extern "C" int tg_pca_inverse(const void* lat, const float* std16, const float* mean16, const float* comp, const float* pmean,

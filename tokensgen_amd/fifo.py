@@ -23,13 +23,25 @@ class FifoWorker:
     """Per-GPU state that the reference ships to each spawned worker (pipe, prompt_embeds, image_rotary_emb, ...)."""
 
     def __init__(self, transformer, scheduler, prompt_embeds, image_rotary_emb, guidance_scale,
-                 vip_grid_h=None, vip_grid_w=None, cond_grid_h=None, cond_grid_w=None):
+                 vip_grid_h=None, vip_grid_w=None, cond_grid_h=None, cond_grid_w=None, use_separate_guidance=False, guidance_scale_img=None,
+                 use_dynamic_cfg=False, num_inference_steps=None):
         self.transformer = transformer
         self.scheduler = scheduler
         self.device = transformer.device
         self.prompt_embeds = prompt_embeds.to(self.device, BF16)
         self.image_rotary_emb = tuple(t.to(self.device, torch.float32).contiguous() for t in image_rotary_emb)
         self.guidance_scale = float(guidance_scale)
+        # cogvideo_sampling_mp_fifo.py:493-533: 3-way batch (uncond_txt, uncond_img, txt_img) with its own image guidance weight, and the
+        # per-frame cosine guidance schedule
+        self.use_separate_guidance = bool(use_separate_guidance)
+        self.guidance_scale_img = float(guidance_scale if guidance_scale_img is None else guidance_scale_img)
+        self.use_dynamic_cfg = bool(use_dynamic_cfg)
+        self.num_inference_steps = num_inference_steps
+        nb = 3 if self.use_separate_guidance else 2
+        if self.prompt_embeds.shape[0] != nb:
+            raise ValueError(f"prompt_embeds must hold {nb} rows ({'uncond, cond, cond' if nb == 3 else 'uncond, cond'}); got {self.prompt_embeds.shape[0]}")
+        if self.use_dynamic_cfg and not num_inference_steps:
+            raise ValueError("use_dynamic_cfg needs num_inference_steps")
         self.vip_grid_h, self.vip_grid_w = vip_grid_h, vip_grid_w
         self.cond_grid_h, self.cond_grid_w = cond_grid_h, cond_grid_w
         self.head_dim = transformer.config.attention_head_dim
@@ -52,8 +64,11 @@ class FifoWorker:
         if use_vip:
             vr, cr = self.ropes_for(grid_t, cond_grid_t)
         x = latents.to(self.device, BF16)
-        inp = torch.cat([x, x], dim=0)                                        # :492-497 (CFG batch: uncond, cond)
-        tt = torch.as_tensor(np.asarray(t, dtype=np.int64), device=self.device)[None].expand(2, -1)
+        nb = 3 if self.use_separate_guidance else 2
+        if use_vip and image_embeddings.shape[0] != nb:
+            raise ValueError(f"image_embeddings must hold {nb} batch rows for this guidance mode; got {image_embeddings.shape[0]}")
+        inp = torch.cat([x] * nb, dim=0)                                      # :492-497 (CFG batch: uncond, cond | uncond_txt, uncond_img, txt_img)
+        tt = torch.as_tensor(np.asarray(t, dtype=np.int64), device=self.device)[None].expand(nb, -1)
         pred = self.transformer(hidden_states=inp, encoder_hidden_states=self.prompt_embeds, timestep=tt,
                                 image_rotary_emb=self.image_rotary_emb, vip_image_rotary_emb=vr,
                                 vip_condition_rotary_emb=cr, vip_encoder_hidden_states=image_embeddings,
@@ -63,9 +78,16 @@ class FifoWorker:
         for j in range(nf):
             if t_back[j] is None and has_old[j] and int(prev_t[j]) >= 0:
                 raise IndexError("frame without timestep_back must not carry an old x0 (scheduling_dpm_cogvideox.py:459)")
+        gpf = None
+        if self.use_dynamic_cfg:
+            # :519-527, evaluated like the reference: fp32 tensor arithmetic on the window's integer timesteps (the expression uses the timestep
+            # VALUE against num_inference_steps, as the reference does); one small H2D copy per window
+            tv = torch.as_tensor(np.asarray(t, dtype=np.int64))
+            ramp = (1 - torch.cos(math.pi * ((self.num_inference_steps - tv) / self.num_inference_steps) ** 5.0)) / 2
+            gpf = torch.stack([1 + self.guidance_scale * ramp, 1 + self.guidance_scale_img * ramp], dim=1).to(torch.float32).contiguous().to(self.device)
         x_out, x0 = self.scheduler.window_step(pred, x[0].contiguous(), old_x0.contiguous(), noise.contiguous(),
                                                list(map(int, t)), list(map(int, prev_t)), t_back, list(has_old),
-                                               self.guidance_scale)
+                                               self.guidance_scale, self.guidance_scale_img, gpf)
         return x_out[None], x0
 
 
@@ -162,8 +184,8 @@ def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None
     sp = bo.sampling_params
     if sp.get("use_sliding_window_embedding"):
         raise NotImplementedError("use_sliding_window_embedding is not used by the shipped configs")
-    if getattr(bo, "use_separate_guidance", False) or getattr(bo, "use_dynamic_cfg", False) or not bo.do_classifier_free_guidance:
-        raise NotImplementedError("only static 2-way classifier-free guidance (the CLI's setting, infer:310) is on the hot path")
+    if not bo.do_classifier_free_guidance:
+        raise NotImplementedError("the FIFO stage runs with classifier-free guidance (every shipped config; infer_cogvideo_mp_fifo.py:300-340)")
     if len(getattr(bo, "cache_idx", []) or []):
         raise NotImplementedError("cache_idx capture is a debugging feature of the reference and is not mirrored")
     num_partitions = sp.get("num_partitions", 4)
@@ -207,7 +229,9 @@ def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None
         n_c = min(vnf + 1, nf)
     if window_fn is None:
         worker = FifoWorker(pipe.transformer, pipe.scheduler, bo.prompt_embeds, bo.image_rotary_emb, bo.guidance_scale,
-                            *( (g_h, g_w, c_h, c_w) if use_vip else (None,) * 4))
+                            *((g_h, g_w, c_h, c_w) if use_vip else (None,) * 4), use_separate_guidance=getattr(bo, "use_separate_guidance", False),
+                            guidance_scale_img=getattr(bo, "guidance_scale_img", None), use_dynamic_cfg=getattr(bo, "use_dynamic_cfg", False),
+                            num_inference_steps=T)
         window_fn = lambda **kw: worker.window_step(**kw)
     noise = _SeededNoise(noise_seed, dev)
     step_noise_fn = step_noise_fn or noise.step

@@ -297,7 +297,7 @@ def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, acc
     return dq, dk, dv
 
 
-def _attn_problem(q1, k1, vt1, nk1, out, q2=None, k2=None, vt2=None, nk2=0, seg2_scale=0.0, kmax1=None, kmax2=None):
+def _attn_problem(q1, k1, vt1, nk1, out, q2=None, k2=None, vt2=None, nk2=0, seg2_scale=0.0, kmax1=None, kmax2=None, seg2_scale_batch=None):
     for n, t in (("q1", q1), ("k1", k1), ("vt1", vt1), ("out", out)):
         _chk(t, n)
     pr = L.AttnProblem()
@@ -318,6 +318,10 @@ def _attn_problem(q1, k1, vt1, nk1, out, q2=None, k2=None, vt2=None, nk2=0, seg2
         pr.nseg = 2
     pr.seg2_scale = float(seg2_scale)
     pr.out, pr.out_ld, pr.out_strideB, pr.nq = _p(out), old, osb, nq
+    if seg2_scale_batch is not None:            # host list of per-batch-item weights; the ctypes array must outlive the call: kept on the struct
+        assert len(seg2_scale_batch) == B
+        pr._scales = (C.c_float * B)(*[float(v) for v in seg2_scale_batch])
+        pr.seg2_scale_batch = C.cast(pr._scales, C.POINTER(C.c_float))
     return pr, B
 
 
@@ -423,6 +427,33 @@ def cfg_dpm_step_f32(model_out, x, old_x0, noise, coef, guidance, x_out, x0_out)
     F_, E = x.shape[0], x[0].numel()
     L.check(L.load().tg_cfg_dpm_step_f32(_p(model_out), _p(x), _p(old_x0), _p(noise), _p(coef), float(guidance), _p(x_out),
                                          _p(x0_out), F_, E, _stream()), "tg_cfg_dpm_step_f32")
+    return x_out, x0_out
+
+
+PRED_TYPES = {"v_prediction": 0, "epsilon": 1, "sample": 2}
+
+
+def cfg_dpm_step_ex(model_out, x, old_x0, noise, coef, guidance, x_out, x0_out, guidance_img=0.0, guidance_per_frame=None, f32_math=False,
+                    prediction_type="v_prediction"):
+    """tg_cfg_dpm_step_ex: model_out [2 or 3, F, E] bf16; x / x_out / noise [F,2,E] bf16; old_x0 / x0_out [F,E] bf16 or fp32 (fp32: the pipelines'
+    solver state, implies f32_math); guidance_per_frame: fp32 [F, 2] device tensor {g, g_img} (the worker's dynamic cfg) or None."""
+    for n, t in (("model_out", model_out), ("x", x), ("x_out", x_out), ("noise", noise)):
+        _chk(t, n)
+        assert t.is_contiguous()
+    f32_state = old_x0.dtype == torch.float32
+    for n, t in (("old_x0", old_x0), ("x0_out", x0_out)):
+        _chk(t, n, torch.float32 if f32_state else BF16)
+        assert t.is_contiguous()
+    _chk(coef, "coef", torch.float32)
+    F_, E = x.shape[0], x[0].numel()
+    br = model_out.shape[0]
+    assert br in (2, 3) and model_out.numel() == br * F_ * E and coef.shape == (F_, 8) and coef.is_contiguous()
+    if guidance_per_frame is not None:
+        _chk(guidance_per_frame, "guidance_per_frame", torch.float32)
+        assert guidance_per_frame.is_contiguous() and guidance_per_frame.shape == (F_, 2)
+    L.check(L.load().tg_cfg_dpm_step_ex(_p(model_out), br, _p(x), _p(old_x0), _p(noise), _p(coef), float(guidance), float(guidance_img),
+                                        _p(guidance_per_frame) or None, 1 if (f32_math or f32_state) else 0, 1 if f32_state else 0,
+                                        PRED_TYPES[prediction_type], _p(x_out), _p(x0_out), F_, E, _stream()), "tg_cfg_dpm_step_ex")
     return x_out, x0_out
 
 

@@ -51,6 +51,7 @@ PROTOTYPES = {
     "tg_unpatchify": [_vp, _l, _vp, _i, _i, _i, _i, _i, _vp],
     "tg_cfg_dpm_step": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _l, _vp],
     "tg_cfg_dpm_step_f32": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _l, _vp],
+    "tg_cfg_dpm_step_ex": [_vp, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _i, _i, _vp, _vp, _i, _l, _vp],
     "tg_pca_inverse": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "tg_pca_lowrank_filter": [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _vp],
     "tg_conv3d_cl": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp],
@@ -119,4 +120,5 @@ class AttnSegment(C.Structure):
 class AttnProblem(C.Structure):
     """tg_attn_problem (include/tokensgen_hip.h)"""
     _fields_ = [("seg", AttnSegment * 2), ("nseg", C.c_int), ("seg2_scale", C.c_float),
-                ("out", C.c_void_p), ("out_ld", C.c_long), ("out_strideB", C.c_long), ("nq", C.c_int)]
+                ("out", C.c_void_p), ("out_ld", C.c_long), ("out_strideB", C.c_long), ("nq", C.c_int),
+                ("seg2_scale_batch", C.POINTER(C.c_float))]

@@ -8,6 +8,8 @@ None` branch does, :611-616); passing raw prompts or frames raises NotImplemente
 import os
 from types import SimpleNamespace
 
+import math
+
 import numpy as np
 import torch
 
@@ -96,24 +98,16 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
 
     @torch.no_grad()
     def vae_encode_image(self, frames, nf_per_chunk=49, compressed_nf_per_chunk=13, video_ipadapter_start_frame_idx=1000, generator=None,
-                         sample_posterior=True, do_classifier_free_guidance=True):
+                         sample_posterior=True, do_classifier_free_guidance=True, use_separate_guidance=False):
         """Condensed-token encoding of the source video (pipeline_cogvideox_mp_fifo.py:562-648, `use_vae_as_encoder`):
         frames [b, F, 3, H, W] in [-1, 1] -> pad one chunk with the last frame -> per 49-frame chunk: vae.encode, sample, x scaling
         -> `transformer.patch_embed.proj` -> per chunk Resampler -> [2b, 4*(chunks+1), D, 8, 12] (the same tokens in both CFG halves,
-        :646; the zero-video "uncond" branch of the reference is computed but unused when use_separate_guidance is off and is skipped)."""
+        :646; the zero-video "uncond" tokens of the reference are only USED by `use_separate_guidance`, which returns
+        [tokens, tokens of an all-zero video, tokens] = [3b, ...], :620-644)."""
         if self._resampler is None or self.vae is None:
             raise RuntimeError("vae_encode_image needs a VAE and a Resampler")
         rq = self.resampler.config
         dev = self.device
-        video = frames.to(dev, BF16).permute(0, 2, 1, 3, 4)
-        video = torch.cat([video] + [video[:, :, [-1]]] * nf_per_chunk, dim=2)                      # :581 pad one chunk
-        lat = []
-        for c in range(video.shape[2] // nf_per_chunk):
-            post = self.vae.encode(video[:, :, c * nf_per_chunk:(c + 1) * nf_per_chunk].contiguous()).latent_dist
-            z = post.sample(generator=generator) if sample_posterior else post.mode()
-            lat.append((z.float() * self.vae.config.scaling_factor).to(BF16))
-        lat = torch.cat(lat, dim=2).permute(0, 2, 1, 3, 4).contiguous()                             # b f c h w
-        tokens = self.transformer.patch_embed_proj(lat)                                              # b f (h w) D
         f32 = np.float32
         img = R.rope_3d(rq.dim_head, np.linspace(0, rq.max_temporal_seq_len, rq.max_temporal_seq_len, endpoint=False, dtype=f32),
                         np.linspace(0, rq.max_height_seq_len, rq.max_height_seq_len, endpoint=False, dtype=f32),
@@ -122,10 +116,30 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
                                                  rq.num_temporal_queries, endpoint=False, dtype=f32),
                         np.linspace(0, rq.max_height_seq_len, rq.num_height_queries, endpoint=False, dtype=f32),
                         np.linspace(0, rq.max_width_seq_len, rq.num_width_queries, endpoint=False, dtype=f32))             # :1127-1149
-        out = [self._resampler(tokens[:, c * compressed_nf_per_chunk:(c + 1) * compressed_nf_per_chunk].contiguous(), image_rotary_emb=img,
-                               sampling_rotary_emb=smp) for c in range(tokens.shape[1] // compressed_nf_per_chunk)]
-        emb = torch.cat(out, dim=1)
-        return torch.cat([emb, emb], dim=0) if do_classifier_free_guidance else emb
+
+        def encode(video_bfchw):
+            video = video_bfchw.to(dev, BF16).permute(0, 2, 1, 3, 4)
+            video = torch.cat([video] + [video[:, :, [-1]]] * nf_per_chunk, dim=2)                      # :581 pad one chunk
+            lat = []
+            for c in range(video.shape[2] // nf_per_chunk):
+                post = self.vae.encode(video[:, :, c * nf_per_chunk:(c + 1) * nf_per_chunk].contiguous()).latent_dist
+                z = post.sample(generator=generator) if sample_posterior else post.mode()
+                lat.append((z.float() * self.vae.config.scaling_factor).to(BF16))
+            lat = torch.cat(lat, dim=2).permute(0, 2, 1, 3, 4).contiguous()                             # b f c h w
+            tokens = self.transformer.patch_embed_proj(lat)                                              # b f (h w) D
+            out = [self._resampler(tokens[:, c * compressed_nf_per_chunk:(c + 1) * compressed_nf_per_chunk].contiguous(), image_rotary_emb=img,
+                                   sampling_rotary_emb=smp) for c in range(tokens.shape[1] // compressed_nf_per_chunk)]
+            return torch.cat(out, dim=1)
+        emb = encode(frames)
+        if not do_classifier_free_guidance:
+            return emb
+        if use_separate_guidance:
+            # :620-644 — the unconditional-image branch: the same chain on an all-zero video of the same length
+            unc = encode(torch.zeros_like(frames))
+            if unc.shape[1] != emb.shape[1]:
+                emb = torch.cat([emb] + [emb[:, [-1]]] * (unc.shape[1] - emb.shape[1]), dim=1)
+            return torch.cat([emb, unc, emb], dim=0)
+        return torch.cat([emb, emb], dim=0)
 
     def preprare_for_fifo(self, num_inference_steps=52, guidance_scale=6.0, video_ipadapter_scale=None, **unused):
         """:1491-1514 — what the non-zero ranks run instead of the base stage: set vip scale + timesteps."""
@@ -145,11 +159,16 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
     def __call__(self, prompt=None, frames=None, prompt_embeds=None, negative_prompt_embeds=None, image_embeddings=None,
                  height=480, width=720, num_frames_per_chunk=49, num_chunks=1, num_inference_steps=52, guidance_scale=6.0,
                  video_ipadapter_scale=None, video_ipadapter_start_frame_idx=1000, latents=None, generator=None, step_noise=None,
-                 sampling_params=None, output_type="latent", return_dict=False, cfg_parallel=None, **unused):
+                 sampling_params=None, output_type="latent", return_dict=False, cfg_parallel=None, use_separate_guidance=False,
+                 guidance_scale_img=None, use_dynamic_cfg=False, uncond_image_embeddings=None, **unused):
         """Base stage (:837-1344): `num_inference_steps` scalar-timestep CFG steps on chunk 0, harvesting
         `latents[:, max(0, 12-i)]` (and the matching x0) into the FIFO seed lists before every step (:1190-1194).
         step_noise: optional callable i -> [nf,2,C,h,w] bf16 (default: seeded device generator).
-        cfg_parallel: see tokensgen_amd/cfg_parallel.py (default: split the two CFG halves over ranks 0/1 when >= 2 ranks run)."""
+        cfg_parallel: see tokensgen_amd/cfg_parallel.py (default: split the two CFG halves over ranks 0/1 when >= 2 ranks run).
+        use_separate_guidance / guidance_scale_img (:1026-1029, 1197-1200, 1261-1263): 3-way batch (negative prompt + image tokens | prompt +
+        zero-video tokens | prompt + image tokens); image_embeddings then has 3 batch rows (vae_encode_image(use_separate_guidance=True)), or
+        1 row plus `uncond_image_embeddings` [1, 4*(num_chunks+1), C, h, w].  use_dynamic_cfg (:1252-1259): the cosine guidance ramp, a
+        Python float per step."""
         if prompt is not None or frames is not None:
             raise NotImplementedError("T5 prompt encoding and the Resampler are upstream of the hot path: pass prompt_embeds / image_embeddings")
         if prompt_embeds is None or negative_prompt_embeds is None:
@@ -158,7 +177,9 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
         self._guidance_scale = guidance_scale
         self._set_vip_scale(video_ipadapter_scale)
         use_vip = image_embeddings is not None
-        embeds = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0).to(dev, BF16)            # :1028 (uncond, cond)
+        nb = 3 if use_separate_guidance else 2
+        g_img0 = guidance_scale if guidance_scale_img is None else guidance_scale_img                # infer_cogvideo_mp_fifo.py:313
+        embeds = torch.cat([negative_prompt_embeds] + [prompt_embeds] * (nb - 1), dim=0).to(dev, BF16)   # :1026-1029 (uncond, cond[, cond])
         self.scheduler.set_timesteps(num_inference_steps, device=None)
         ts = self.scheduler.timesteps.tolist()
         nf = (num_frames_per_chunk - 1) // self.vae_scale_factor_temporal + 1
@@ -190,9 +211,18 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
                 # (pipeline_cogvideox_mp_fifo.py:611-646; the zero-video "uncond" tokens are computed there but not used)
                 per_chunk = image_embeddings.shape[1] // num_chunks
                 image_embeddings = torch.cat([image_embeddings] + [image_embeddings[:, [-1]]] * per_chunk, dim=1)
-                image_embeddings = torch.cat([image_embeddings, image_embeddings], dim=0)
-            if image_embeddings.shape[0] != 2 or image_embeddings.shape[1] < n_c:
-                raise ValueError(f"image_embeddings must be [1, 4*num_chunks, C, h, w] (reference input) or the prepared [2, 4*(num_chunks+1), "
+                if use_separate_guidance:
+                    if uncond_image_embeddings is None:
+                        raise ValueError("use_separate_guidance with single-row image_embeddings needs uncond_image_embeddings (the tokens of an "
+                                         "all-zero video: vae_encode_image(zeros, do_classifier_free_guidance=False))")
+                    unc = uncond_image_embeddings.to(dev, BF16)
+                    if unc.shape[1] != image_embeddings.shape[1]:                                    # :636-640
+                        image_embeddings = torch.cat([image_embeddings] + [image_embeddings[:, [-1]]] * (unc.shape[1] - image_embeddings.shape[1]), dim=1)
+                    image_embeddings = torch.cat([image_embeddings, unc, image_embeddings], dim=0)
+                else:
+                    image_embeddings = torch.cat([image_embeddings, image_embeddings], dim=0)
+            if image_embeddings.shape[0] != nb or image_embeddings.shape[1] < n_c:
+                raise ValueError(f"image_embeddings must be [1, 4*num_chunks, C, h, w] (reference input) or the prepared [{nb}, 4*(num_chunks+1), "
                                  f"C, h, w]; got {tuple(image_embeddings.shape)}")
             emb0 = image_embeddings[:, :n_c].contiguous()
         rope_d = tuple(t.to(dev) for t in rope)
@@ -210,7 +240,11 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
                                         timestep=torch.full((n,), t, dtype=torch.int64, device=dev), image_rotary_emb=rope_d,
                                         vip_image_rotary_emb=vr, vip_condition_rotary_emb=cr,
                                         vip_encoder_hidden_states=None if emb0 is None else emb0[lo:hi].contiguous(), return_dict=False)[0]
-            pred = CP.predict(cfg_mode, lambda h: fwd(h, h + 1), lambda: fwd(0, 2))
+            pred = CP.predict(cfg_mode, lambda h: fwd(h, h + 1), lambda: fwd(0, nb), n=nb)
+            g_txt, g_img = guidance_scale, g_img0
+            if use_dynamic_cfg:                                  # :1252-1259 — Python floats, the timestep VALUE against num_inference_steps as written there
+                ramp = (1 - math.cos(math.pi * ((num_inference_steps - t) / num_inference_steps) ** 5.0)) / 2
+                g_txt, g_img = 1 + guidance_scale * ramp, 1 + g_img0 * ramp
             prev_t = ts[i + 1] if i + 1 < len(ts) else -1
             t_back = ts[i - 1] if i > 0 else None
             nz = step_noise(i) if step_noise is not None else torch.randn((nf, 2) + tuple(latents.shape[2:]), generator=gen, device=dev,
@@ -221,17 +255,18 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
             coef = self.scheduler.coef_table([t] * nf, [prev_t] * nf, [t_back] * nf, [second] * nf, dev)
             x = torch.empty_like(latents[0])
             x0 = torch.empty(latents.shape[1:], dtype=torch.float32, device=dev)
-            K.cfg_dpm_step_f32(pred.reshape(2, nf, -1), latents[0].reshape(nf, -1),
-                               (old_x0 if has else torch.zeros_like(x0)).reshape(nf, -1), nz.to(dev, BF16).contiguous().reshape(nf, 2, -1),
-                               coef, guidance_scale, x.view(nf, -1), x0.view(nf, -1))
+            K.cfg_dpm_step_ex(pred.reshape(nb, nf, -1), latents[0].reshape(nf, -1),
+                              (old_x0 if has else torch.zeros_like(x0)).reshape(nf, -1), nz.to(dev, BF16).contiguous().reshape(nf, 2, -1),
+                              coef, g_txt, x.view(nf, -1), x0.view(nf, -1), guidance_img=g_img, prediction_type=self.scheduler.config.prediction_type)
             latents, old_x0 = x[None], x0
         return SimpleNamespace(
             fifo_latents=torch.cat(fifo_latents, dim=1), fifo_old_pred_original_sample=fifo_old, orig_latents=latents.clone(),
             nf_per_chunk=nf, vip_nf_per_chunk=self.resampler.config.num_temporal_queries if use_vip else None,
             num_frames=num_chunks * nf, image_embeddings=image_embeddings, timesteps=self.scheduler.timesteps,
-            num_inference_steps=num_inference_steps, do_classifier_free_guidance=True, use_separate_guidance=False, use_dynamic_cfg=False,
+            num_inference_steps=num_inference_steps, do_classifier_free_guidance=True, use_separate_guidance=bool(use_separate_guidance),
+            use_dynamic_cfg=bool(use_dynamic_cfg),
             prompt_embeds=embeds, image_rotary_emb=rope, vip_image_rotary_grid=grids[0] if use_vip else None,
             vip_condition_rotary_grid=grids[1] if use_vip else None, attention_kwargs=None, guidance_scale=guidance_scale,
-            guidance_scale_img=None, extra_step_kwargs={}, cache_idx=[], condition_frames=None,
+            guidance_scale_img=g_img0, extra_step_kwargs={}, cache_idx=[], condition_frames=None,
             video_ipadapter_start_frame_idx=video_ipadapter_start_frame_idx, sampling_params=sampling_params or dict(use_adaptive_padding=True, num_partitions=4),
             output_type=output_type, return_dict=return_dict)

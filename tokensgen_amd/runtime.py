@@ -7,6 +7,8 @@ pipeline pickled as CUDA-IPC handles (cogvideo_sampling_mp_fifo.py:195-221) and 
   parent.  The reference's parent blocks forever in `output_queue.get()` when a worker dies (:308-311).
 * `init_distributed(...)`: `init_process_group` with an explicit timeout (backend nccl = RCCL on the GPU, gloo on CPU), so that a
   rank that died WITHOUT raising (killed, device lost) makes its peers' next collective fail after `timeout_s` instead of hanging.
+* `broadcast_weights(model, src)`: ONE rank reads the checkpoint, the others receive the weights over RCCL / xGMI — the collective that
+  replaces the reference's whole-pipeline CUDA-IPC pickling (:195-221); a few large broadcasts over the models' fused storages.
 * `RankGuard`: exception propagation between live ranks.  A rank that raised inside its part of an iteration still takes part in the
   iteration's exchange and flags it; every rank then raises `RankFailure` naming the rank and its message — within one iteration, not after
   a timeout.
@@ -45,6 +47,65 @@ def init_distributed(backend=None, timeout_s=None, device=None):
         kw["device_id"] = device
     dist.init_process_group(backend, **kw)
     return rank, world
+
+
+def _weight_storages(model):
+    """The tensors that ARE a model's weights, in a deterministic order: the fused storages of CogVideoXTransformer3DModel (its nn.Parameters
+    are views of them), the state-dict tensors of the VAE / Resampler mirrors, or a plain nn.Module's parameters + buffers."""
+    if hasattr(model, "_fused"):
+        return [model._fused[k] for k in sorted(model._fused)]
+    if hasattr(model, "_sd") and isinstance(model._sd, dict):
+        return [model._sd[k] for k in sorted(model._sd)]
+    if isinstance(model, torch.nn.Module):
+        return [t for _, t in sorted(list(model.named_parameters()) + list(model.named_buffers()), key=lambda kv: kv[0])]
+    raise TypeError(f"broadcast_weights: do not know the weight storages of {type(model).__name__}")
+
+
+@torch.no_grad()
+def broadcast_weights(model, src=0, group=None, bucket_bytes=1 << 30):
+    """Every rank ends up with rank `src`'s weights (north_star: "RCCL broadcast of weights").  Large storages (the per-layer [3D, D] / [4D, D]
+    GEMM weights, the fused modulation matrix) go as one broadcast each; the many small ones (biases, LayerNorm affines) are coalesced into flat
+    buckets of at most `bucket_bytes` so that the 42-layer model is ~260 collectives instead of ~1 300 — xGMI rings are per-link bound, few large
+    messages.  bf16 travels as raw bytes (gloo knows neither bf16 nor int16, and a broadcast does not care).  Shapes / dtypes must already
+    agree on every rank (construct the model from the same config; `from_pretrained(..., broadcast=True)` does).  Afterwards the receiver's
+    derived state is refreshed (`_after_weight_update` when the model has one).  Returns the number of bytes received / sent."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    tensors = _weight_storages(model)
+    total = 0
+
+    def raw(t):
+        return t.view(torch.uint8) if t.dtype == torch.bfloat16 else t
+    small = []
+    for t in tensors:
+        if not t.is_contiguous():
+            raise ValueError("broadcast_weights: weight storages must be contiguous")
+        nbytes = t.numel() * t.element_size()
+        total += nbytes
+        if nbytes >= (4 << 20):
+            dist.broadcast(raw(t), src=src, group=group)
+        else:
+            small.append(t)
+    by_dtype = {}
+    for t in small:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for dt, ts in by_dtype.items():
+        i = 0
+        while i < len(ts):
+            chunk, nb = [], 0
+            while i < len(ts) and (not chunk or nb + ts[i].numel() * ts[i].element_size() <= bucket_bytes):
+                chunk.append(ts[i]); nb += ts[i].numel() * ts[i].element_size(); i += 1
+            flat = torch.cat([c.reshape(-1) for c in chunk])
+            dist.broadcast(raw(flat), src=src, group=group)
+            off = 0
+            for c in chunk:
+                c.copy_(flat[off:off + c.numel()].view(c.shape))
+                off += c.numel()
+    hook = getattr(model, "_after_weight_update", None)
+    if hook is not None:
+        hook()
+    return total
 
 
 class RankGuard:

@@ -354,18 +354,33 @@ class CogVideoXTransformer3DModel(nn.Module):
         torch.save(sd, os.path.join(vip_ckpt_dir, "vip.pt"))
 
     @classmethod
-    def from_pretrained(cls, path, subfolder=None, torch_dtype=BF16, device="cuda", **kw):
-        """from_pretrained-lite: <dir>/config.json + diffusion_pytorch_model*.safetensors."""
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=BF16, device="cuda", broadcast=False, **kw):
+        """from_pretrained-lite: <dir>/config.json + diffusion_pytorch_model*.safetensors.
+        broadcast=True (with torch.distributed initialised): only rank 0 reads the safetensors files, the other ranks build the empty model from
+        config.json and receive the weights with `runtime.broadcast_weights` (RCCL over xGMI) — 14.3 GB from one disk read instead of N.  Call
+        `runtime.broadcast_weights(model)` again after `set_vip_layers(vip_ckpt_dir)` if only rank 0 loaded vip.pt."""
         from safetensors.torch import load_file
         d = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(d, "config.json")) as f:
             cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
         m = cls(**cfg, device=device, dtype=torch_dtype)
-        idx = os.path.join(d, "diffusion_pytorch_model.safetensors.index.json")
-        files = sorted(set(json.load(open(idx))["weight_map"].values())) if os.path.exists(idx) else ["diffusion_pytorch_model.safetensors"]
-        for fn in files:
-            m.load_state_dict(load_file(os.path.join(d, fn)), strict=False)
+        rank = 0
+        if broadcast:
+            import torch.distributed as dist
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        if rank == 0:
+            idx = os.path.join(d, "diffusion_pytorch_model.safetensors.index.json")
+            files = sorted(set(json.load(open(idx))["weight_map"].values())) if os.path.exists(idx) else ["diffusion_pytorch_model.safetensors"]
+            for fn in files:
+                m.load_state_dict(load_file(os.path.join(d, fn)), strict=False)
+        if broadcast:
+            from .runtime import broadcast_weights
+            broadcast_weights(m, src=0)
         return m
+
+    def _after_weight_update(self):
+        """Weights changed underneath the parameter views (runtime.broadcast_weights, an in-place optimizer step): forget what was derived."""
+        self.attn_path = "constant_shift"
 
     # ------------------------------------------------------------------------------------------ attention path
     def _attn_fast(self, ws):
@@ -526,20 +541,19 @@ class CogVideoXTransformer3DModel(nn.Module):
                 vt2 = ws.Vt3[:, :, :, N1:]
             else:
                 vt2 = K.transpose_v(ws.QKVv[:, :, 2 * D:], H, N1, Np, ws.Vt2)
+            # attention_processor.py:2126-2131: `scale` becomes a tensor of the activations' dtype (0.6 -> bf16 0.6015625); a list as long as
+            # the batch weighs every batch item with its own entry, any other list uses entry 0
             s = blk.attn1.processor.scale
-            if isinstance(s, (list, tuple)):
-                # the reference applies a per-batch-element scale when len(scale) == batch (attention_processor.py:2126-2131); the shipped
-                # configs pass one value ([0.6] / [1.0]) and the fused launch takes one
-                if len(set(float(v) for v in s)) != 1:
-                    raise NotImplementedError(f"per-batch-element vip scale {s}: the fused attention launch takes one scale for the batch")
-                s = s[0]
-            s = float(s)
+            sl = [float(v) for v in s] if isinstance(s, (list, tuple)) else [float(s)]
+            sl = [float(torch.tensor(v, dtype=torch.float32).to(BF16)) for v in sl]
+            s_batch = sl if (len(sl) == B and len(set(sl)) > 1) else None
+            s = sl[0]
             # text+video rows: softmax(q k^T) v  +  s * softmax(qx kv^T) vv   (attention_processor.py:2066-2069,2117-2134)
             # vip rows: qv against cat(kx, kv) / cat(vx, vv)                  (:2120-2125) — rides in the main launch's last round
             # kmax2 is the maximum over ALL rows of the vip-weight K projection: an upper bound for the vip keys of segment 2 as well
             km1, km2 = (ws.kmax1, ws.kmax2) if fast else (None, None)
             K.attention_multi(dict(q1=ws.QKV[:, :, :D], k1=ws.QKV[:, :, D:2 * D], vt1=ws.Vt1, nk1=N1, out=ws.AO[:, :N1],
-                                   q2=ws.QKVv[:, :N1, :D], k2=ws.QKVv[:, N1:, D:2 * D], vt2=vt2, nk2=Np, seg2_scale=s, kmax1=km1, kmax2=km2),
+                                   q2=ws.QKVv[:, :N1, :D], k2=ws.QKVv[:, N1:, D:2 * D], vt2=vt2, nk2=Np, seg2_scale=s, kmax1=km1, kmax2=km2, seg2_scale_batch=s_batch),
                               dict(q1=ws.QKVv[:, N1:, :D], k1=ws.QKVv[:, :, D:2 * D], vt1=ws.Vt3, nk1=N, out=ws.AO[:, N1:], kmax1=km2),
                               H, sm_scale, k_prescaled=True, retry=ws.retry if fast else None)
         elif fast:

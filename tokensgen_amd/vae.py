@@ -148,9 +148,14 @@ class AutoencoderKLCogVideoX:
         return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
 
 
+    def _after_weight_update(self):
+        """runtime.broadcast_weights wrote into the `_sd` tensors: rebuild the packed GEMM operands (and drop captured graphs) from them."""
+        self.load_state_dict(self._sd)
+
     @classmethod
-    def from_pretrained(cls, path, subfolder=None, torch_dtype=BF16, device="cuda", **unused):
-        """diffusers' ModelMixin.from_pretrained for `<CogVideoX-5b>/vae`: config.json + diffusion_pytorch_model.safetensors."""
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=BF16, device="cuda", broadcast=False, **unused):
+        """diffusers' ModelMixin.from_pretrained for `<CogVideoX-5b>/vae`: config.json + diffusion_pytorch_model.safetensors.
+        broadcast=True: rank 0 reads the file, the others receive the weights over RCCL (runtime.broadcast_weights)."""
         import json
         from safetensors.torch import load_file
         d = os.path.join(path, subfolder) if subfolder else path
@@ -159,7 +164,17 @@ class AutoencoderKLCogVideoX:
         if "down_block_types" in cfg:          # diffusers lists block types; CogVideoX has exactly one kind of each
             cfg.pop("down_block_types"), cfg.pop("up_block_types", None)
         vae = cls(**cfg, device=device)
-        vae.load_state_dict(load_file(os.path.join(d, "diffusion_pytorch_model.safetensors")))
+        rank = 0
+        if broadcast:
+            import torch.distributed as dist
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        if rank == 0:
+            vae.load_state_dict(load_file(os.path.join(d, "diffusion_pytorch_model.safetensors")))
+        else:
+            vae.load_state_dict({k: torch.zeros(sh, dtype=BF16) for k, sh in vae.param_shapes().items()})      # storages to receive into
+        if broadcast:
+            from .runtime import broadcast_weights
+            broadcast_weights(vae, src=0)
         return vae
 
     def save_pretrained(self, path):

@@ -631,6 +631,72 @@ def gen_vae_geometry():
 
 
 @torch.no_grad()
+def gen_fifo_worker():
+    """The reference worker body `fifo_onestep_per_gpu` (cogvideo_sampling_mp_fifo.py:408-579) run IN PROCESS (plain queue.Queue: one work item,
+    then None) for the guidance / prediction branches the shipped configs do not select but the yaml can (VERDICT r2 missing #4):
+    `use_separate_guidance` (3-way batch + guidance_scale_img, :493-497, 528-530), `use_dynamic_cfg` (:519-527), both together, and an
+    epsilon-prediction scheduler — on a head window (prev_t = -1 frames) and a tail window (t = 999, next_t -> None), fp32 and bf16."""
+    fifo = load_ref_module("longvgen/fifo_sampling/cogvideo_sampling_mp_fifo.py", "ref_fifo_worker")
+    H, W, nf, T = 4, 6, 13, 52
+    f32 = np.float32
+    g = torch.Generator().manual_seed(811)
+    ts = make_sched().timesteps.tolist()
+    lvl = [ts[-1]] * 6 + ts[::-1]                       # per queue position, ascending noise (SURVEY App. A)
+    cases = []
+
+    class Pipe:                                          # the attributes the worker touches; guidance_scale is a property on the real pipeline
+        def __init__(self, m, sched, gs):
+            self.transformer, self.scheduler, self._guidance_scale = m, sched, gs
+
+        @property
+        def guidance_scale(self):
+            return self._guidance_scale
+
+        def _prepare_vip_rotary_positional_embeddings(self, grid_t, grid_h, grid_w, device):
+            return get_3d_rotary_pos_embed_v2(64, grid_t, grid_h, grid_w)
+
+    variants = [("separate", True, False, "v_prediction"), ("dynamic", False, True, "v_prediction"), ("separate_dynamic", True, True, "v_prediction"),
+                ("epsilon_static", False, False, "epsilon")]
+    for name, sep, dyn, ptype in variants:
+        for dt in (torch.float32, torch.bfloat16):
+            # alphas_cumprod[999] = 0 under zero terminal SNR and epsilon prediction divides by sqrt(alpha) (inf in the reference too): the epsilon
+            # tail window stops one position short of t = 999 (its last frame then has t_back = 999: r = inf, d = x0)
+            for start in ((0, 44) if ptype == "epsilon" else (0, 45)):
+                m, sd = tiny_model(820)
+                m = m.to(dt)
+                sched = CogVideoXDPMScheduler(prediction_type=ptype, rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
+                sched.set_timesteps(T)
+                nb = 3 if sep else 2
+                pipe = Pipe(m, sched, 6.0)
+                t = torch.tensor(lvl[start:start + nf])
+                prev_t = torch.tensor([(-1 if q <= 6 else lvl[q - 1]) for q in range(start, start + nf)])
+                next_t = torch.tensor([(lvl[q + 1] if q + 1 < len(lvl) else -1) for q in range(start, start + nf)])
+                lat = torch.randn(1, nf, 16, H, W, generator=g).to(dt)
+                old = [torch.randn(1, 1, 16, H, W, generator=g).to(dt) if int(next_t[j]) > 0 else None for j in range(nf)]
+                prompt = torch.randn(nb, 8, TINY["text_embed_dim"], generator=g).to(dt)
+                emb = torch.randn(nb, 5, 128, 2, 3, generator=g).to(dt)
+                grid_t = np.arange(nf, dtype=f32) + f32(start)
+                grid_h, grid_w = np.arange(H // 2, dtype=f32), np.arange(W // 2, dtype=f32)
+                cond_t = np.linspace(1000, 1016.25, 5, dtype=f32)
+                cond_h, cond_w = np.linspace(0, H // 2, 2, endpoint=False, dtype=f32), np.linspace(0, W // 2, 3, endpoint=False, dtype=f32)
+                rope = get_3d_rotary_pos_embed(64, ((0, 0, 0), (nf, H // 2, W // 2)), (nf, H // 2, W // 2))
+                qin, qout = queue.Queue(), queue.Queue()
+                qin.put((0, 0, 0, start, start + 6, start + nf, start + nf, t.clone(), prev_t.clone(), next_t.clone(), lat.clone(), list(old),
+                         grid_t, grid_h, grid_w, cond_t, cond_h, cond_w, emb.clone(), []))
+                qin.put(None)
+                seed = 9000 + len(cases)
+                torch.manual_seed(seed)
+                fifo.fifo_onestep_per_gpu(0, qin, qout, pipe, prompt, rope, T, True, sep, 6.0, 4.0, dyn, None)
+                (_, _, _, _, _, out_lat, out_x0, _) = qout.get()
+                cases.append(dict(name=name, separate=sep, dynamic=dyn, prediction_type=ptype, dtype=str(dt), start=start, t=t, prev_t=prev_t, next_t=next_t,
+                                  latents=lat, old=old, prompt=prompt, image_embeddings=emb, grid_t=grid_t, grid_h=grid_h, grid_w=grid_w, cond_t=cond_t,
+                                  cond_h=cond_h, cond_w=cond_w, rng_seed=seed, guidance_scale=6.0, guidance_scale_img=4.0, out_latents=out_lat.clone(),
+                                  out_x0=[x.clone() for x in out_x0]))
+    torch.save(dict(weight_seed=820, H=H, W=W, cases=cases), os.path.join(GOLD, "fifo_worker_variants.pt"))
+    print("fifo_worker_variants.pt", len(cases), "cases", {c["name"]: str(c["out_latents"].dtype) for c in cases})
+
+
+@torch.no_grad()
 def gen_train():
     """Training-loss arithmetic of the reference (VERDICT r2 missing #1): the scheduler's `add_noise` and `get_velocity`
     (scheduling_dpm_cogvideox.py:470-495, 521-538) on the REFERENCE class, and the weighted loss evaluated exactly as the training script does
@@ -681,7 +747,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    jobs = dict(dit=gen_dit_tiny, vip=gen_vip_processor, sched=gen_scheduler, fifo=gen_fifo, vae=gen_vae, resampler=gen_resampler, t2to=gen_t2to, base=gen_base_stage, vae_geom=gen_vae_geometry, vae_t26=gen_vae_t26, train=gen_train)
+    jobs = dict(dit=gen_dit_tiny, vip=gen_vip_processor, sched=gen_scheduler, fifo=gen_fifo, vae=gen_vae, resampler=gen_resampler, t2to=gen_t2to, base=gen_base_stage, vae_geom=gen_vae_geometry, vae_t26=gen_vae_t26, train=gen_train, fifo_worker=gen_fifo_worker)
     if a.only:
         jobs = {a.only: jobs.get(a.only, gen_full_block)}
     for k, fn in jobs.items():
