@@ -174,13 +174,23 @@ typedef struct tg_attn_problem {
      * reference processor's `scale` list when its length equals the batch size (attention_processor.py:2126-2131). */
     const float* seg2_scale_batch;
 } tg_attn_problem;
-/* retry_ws (optional, with every segment's k_norm2_max: enables the constant-shift path): >= tg_attention_retry_ints(nq0, nq1, heads,
- * batch) ints, zero-initialised ONCE by the caller and reusable by every later launch on the same stream; retry_ws[0] accumulates the
- * number of workgroups that failed the verification and were recomputed (a host that sees it grow should stop passing retry_ws: the
- * Cauchy-Schwarz shift is a poor range estimate for those weights and the running maximum is the right tool). */
+/* Caller-allocated scratch of tg_attention_fwd_multi (both optional; NULL / a NULL struct = feature off):
+ *  retry (with every segment's k_norm2_max: enables the constant-shift path): >= tg_attention_retry_ints(nq0, nq1, heads, batch) ints,
+ *    zero-initialised ONCE by the caller and reusable by every later launch on the same stream; retry[0] accumulates the number of
+ *    workgroups that failed the verification and were recomputed (a host that sees it grow should stop passing it: the Cauchy-Schwarz
+ *    shift is a poor range estimate for those weights and the running maximum is the right tool).
+ *  split (>= tg_attention_split_floats(...) floats, 16-B aligned, contents irrelevant): lets a launch whose workgroup count leaves at most
+ *    half a round of the device's CUs over (the To2V block: 3360 + 96 = 13.5 x 256) split those last workgroups over the KEY axis into
+ *    half-length workgroups joined by a small combine launch — 13.5 rounds instead of 14.  Results are independent of the workspace
+ *    contents; a launch shape that does not qualify ignores it. */
+typedef struct tg_attn_workspace {
+    int* retry; long retry_ints;
+    float* split; long split_floats;
+} tg_attn_workspace;
 long tg_attention_retry_ints(int nq0, int nq1, int heads, int batch);
+long tg_attention_split_floats(int nq0, int nq1, int heads, int batch);
 int tg_attention_fwd_multi(const tg_attn_problem* problems, int nproblems, int heads, int batch, float scale, int k_prescaled,
-                           int* retry_ws, long retry_ints, hipStream_t stream);
+                           const tg_attn_workspace* ws, hipStream_t stream);
 
 /* emb[i][:] = bf16( [cos(t_i w_k) | sin(t_i w_k)] ), w_k = exp(-ln(1e4) k / (dim/2)), k < dim/2
  * (flip_sin_to_cos=True, freq_shift=0).  Replaces embeddings.py:28-79 + dit:678.  t: int64[n]. */

@@ -549,7 +549,7 @@ def test_attention_ragged_tile_split_at_launch_scale(K):
 
 
 @pytest.mark.parametrize("gain", [1.0, 3.0, 8.0])
-@pytest.mark.parametrize("B,H,N1,NP", [(2, 2, 700, 70), (2, 48, 7 * 512 + 150, 480)])
+@pytest.mark.parametrize("B,H,N1,NP", [(2, 2, 700, 70), (2, 48, 7 * 512 + 150, 480), (2, 48, 2 * 512 + 150, 480)])
 def test_attention_constant_shift_softmax(K, B, H, N1, NP, gain):
     """tg_attn_segment.k_norm2_max + retry workspace: the 512-row kernel subtracts a per-row CONSTANT c = max(0, ||q|| max||k|| - 64) instead of
     a running row maximum, for ANY LayerNorm weights (the round-2 bound came from the weights and silently fell back for
@@ -558,7 +558,8 @@ def test_attention_constant_shift_softmax(K, B, H, N1, NP, gain):
       gain 8: B ~ 740 — every row's scores sit hundreds of units below c, the verification fails everywhere and the retry launch recomputes
       every workgroup with the running maximum: bitwise the running-max result.
     Main problem with two key segments + the rider.  The second shape is at launch scale (>= 1024 workgroups of 512 rows: the kernel really
-    runs); the first reaches it in the forced child run of test_attention_cases_again_on_the_pingpong_kernel."""
+    runs); the first and the third reach it in the forced child run of test_attention_cases_again_on_the_pingpong_kernel.  The third shape
+    (288 + 96 = 256 + 128 workgroups) has 32 TWO-SEGMENT main workgroups in its split tail (see the end of the test)."""
     BF = torch.bfloat16
     D, N = H * 64, N1 + NP
     kscale = 0.125 * 1.4426950408889634
@@ -580,12 +581,12 @@ def test_attention_constant_shift_softmax(K, B, H, N1, NP, gain):
     vt3 = torch.zeros(B, H, 64, pad(N), dtype=BF, device=DEV); K.transpose_v(qkvv[:, :, 2 * D:], H, 0, N, vt3)
     retry = K.AttnRetry(N1, NP, H, B, DEV)
 
-    def run(fast):
+    def run(fast, split=None):
         a = torch.zeros(B, N, D, dtype=BF, device=DEV)
         K.attention_multi(dict(q1=qkv[:, :, :D], k1=qkv[:, :, D:2 * D], vt1=vt1, nk1=N1, out=a[:, :N1], q2=qkvv[:, :N1, :D], k2=qkvv[:, N1:, D:2 * D],
                                vt2=vt2, nk2=NP, seg2_scale=0.6, kmax1=km1 if fast else None, kmax2=km2 if fast else None),
                           dict(q1=qkvv[:, N1:, :D], k1=qkvv[:, :, D:2 * D], vt1=vt3, nk1=N, out=a[:, N1:], kmax1=km2 if fast else None), H, 0.125,
-                          k_prescaled=True, retry=retry if fast else None)
+                          k_prescaled=True, retry=retry if fast else None, split=split)
         return a
     exact, fast = run(False), run(True)
     wgs = retry.ints - 1
@@ -608,3 +609,17 @@ def test_attention_constant_shift_softmax(K, B, H, N1, NP, gain):
         assert _rel(fast[:, rows, sl], ref) < 8e-3, h
         refv = sm(qkvv[:, N1:, sl], qkvv[:, :, ks], qkvv[:, :, vs])
         assert _rel(fast[:, N1:, sl], refv) < 8e-3, h
+    # key-axis split of the launch's half-round tail (tg_attn_workspace.split): at the launch-scale shape 768 + 96 = 864 = 3 x 256 + 96
+    # workgroups -> the last 96 workgroups of the MAIN problem (two key segments each) run as 192 half-length workgroups + the combine launch.
+    # Same function: equal to the unsplit launch up to the rounding of the fp32 partial sums; the riders are never split (bitwise unchanged).
+    if retry.split is not None and on_pp:
+        n0 = retry.count()
+        for fastpath, base in ((True, fast), (False, exact)):
+            sp = run(fastpath, split=retry.split)
+            assert torch.equal(sp[:, N1:], base[:, N1:])                     # riders: whole workgroups
+            assert not torch.equal(sp[:, :N1], base[:, :N1]) or (gain >= 5 and fastpath)   # main tail: two halves (gain 8, fast path: recomputed unsplit by the retry)
+            assert _rel(sp, base) < 2e-3
+        assert int(retry.buf[1:].abs().sum().item()) == 0
+        assert retry.count() - n0 == (wgs if gain >= 5 else 0)
+    else:
+        assert retry.split is None or torch.equal(run(True, split=retry.split), fast)      # a launch that does not qualify ignores the workspace

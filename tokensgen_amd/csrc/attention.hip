@@ -60,7 +60,13 @@ struct AttnParams {
     // FIXEDM kernels: retry[0] counts workgroups that were re-run with the running maximum (cumulative), retry[1 + blockIdx.x] is the
     // "this workgroup's constant-shift result had a row sum below 2^-64" flag the verification raises and the RETRY launch consumes
     int* retry;
+    // key-axis split of the launch's LAST `nsplit` workgroups (wgids split_first .. total_wgs - 1): each runs as two half-length workgroups
+    // that leave (unnormalised O, m, l) partials in split_ws, joined by attn_split_combine_kernel — see attention_launch
+    int split_first, nsplit;
+    float* split_ws;
+    long split_ws_floats;
 };
+constexpr long SPLIT_HALF_FLOATS = 512L * (64 + 2 + 64);     // per half: O [512][64], m [512], l [512], O2 [512][64] (second half of a 2-segment parent)
 
 // plain fmaxf nests: clang fuses them to v_max3_f32 (built with -fno-honor-nans so MFMA outputs are not canonicalised by an
 // extra v_max first); inline-asm versions get an s_nop after every dependent op and measured ~1.5 % slower
@@ -340,7 +346,9 @@ __device__ long long tg_attn_dbg[16];   // TG_ATTN_TIMING: cycles {X work, X bar
 // a workgroup with a failing row raises its flag in p.retry and the RETRY launch (running maximum; a one-workgroup-per-CU grid that walks
 // the flag list) recomputes exactly those workgroups.  The per-tile max chain / vote / rescale (15 % of the launch) is gone from the hot loop.
 // FIXEDM 2: experiment — no shift at all and no seed MFMAs (measured slower than 1).
-template <bool PRESCALED, bool TIMING = false, int FIXEDM = 0, bool LSE = false, bool RETRY = false>
+// SPLIT: the launch of the half-length workgroups of the split tail (see attention_launch) — its own instantiation so that the partial-result
+// epilogue and the runtime tile range stay out of the ordinary kernel's register allocation (as one kernel they cost it ~45 spilled VGPRs)
+template <bool PRESCALED, bool TIMING = false, int FIXEDM = 0, bool LSE = false, bool RETRY = false, bool SPLIT = false>
 __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
     // K[2], Vt[2] tiles (32 KiB) + the output staging area: 8 waves x 64 query rows x 128 B (64 KiB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -348,7 +356,9 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
     const int tid = threadIdx.x;
     // one workgroup's work; `wgid` is its index in the (main + rider) workgroup list.  The ordinary launches run it once with
     // wgid = blockIdx.x; the RETRY launch is a small persistent grid that walks the flag list (below)
-    auto body = [&](const int wgid) {
+    // half: -1 = the whole workgroup; 0 / 1 = first / second part of the key range of a split parent (partials go to p.split_ws)
+    auto body = [&](const int wgid, const int half_) {
+    const int half = SPLIT ? half_ : -1;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;
@@ -390,6 +400,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
     } while (0)
 
     for (int sg = 0; sg < nseg_; ++sg) {
+        if (SPLIT && half == 0 && sg > 0) break;              // the first half covers segment-1 keys only
         const Seg& S = rider ? p.r_s : p.s[sg];
         bf16x8 qf[2][4];
 #pragma unroll
@@ -402,6 +413,14 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         const bf16_t* kbase = S.k + (long)b * S.k_sb + h * 64 + dslot;
         const bf16_t* vsrc = S.vt + ((long)(b * p.heads + h) * 64 + drow) * S.vt_ld + dslot;
         const int ntiles = (S.nk + KVBLK - 1) / KVBLK;
+        // tile range of this workgroup: all of the segment, or — split parents, segment 1 — the part that balances the two halves
+        // (the second half also owns segment 2)
+        int tb = 0, te = ntiles;
+        if (SPLIT && half >= 0 && sg == 0) {
+            const int nt2 = nseg_ == 2 ? (p.s[1].nk + KVBLK - 1) / KVBLK : 0;
+            const int na = max(1, min(ntiles - 1, (ntiles + nt2 + 1) >> 1));
+            if (half == 0) te = na; else tb = na;
+        }
         auto dmaK = [&](int t) {      // K(t) -> K buffer t&1
             const int key = min(t * KVBLK + drow, S.nk - 1);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (long)key * S.k_ld),
@@ -412,8 +431,8 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
                                              (__attribute__((address_space(3))) void*)(smem + (2 + (t & 1)) * TILE_B + wave * 1024), 16, 0, 0);
         };
         auto dma_pair = [&](int u) {  // (K(u+1), V(u))
-            if (u + 1 < ntiles) dmaK(u + 1);
-            if (u < ntiles) dmaV(u);
+            if (u + 1 < te) dmaK(u + 1);
+            if (u < te) dmaV(u);
         };
 
         f32x16 acc_o[2][2], sc[2][2];
@@ -676,12 +695,12 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) pf[qb][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        *(uint4*)(smem + 3 * TILE_B + tid * 16) = uint4{0, 0, 0, 0};
-        dmaK(0);
+        *(uint4*)(smem + (2 + ((tb & 1) ^ 1)) * TILE_B + tid * 16) = uint4{0, 0, 0, 0};
+        dmaK(tb);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         PP_BAR();
         if (grp == 1) {
-            dma_pair(0);
+            dma_pair(tb);
             if (!(p.knob & 2)) PP_BAR();          // knob bit 1 (experiment): both groups IN phase (X together, then Y together)
             if (p.knob & 1) __builtin_amdgcn_s_setprio(1);
         }
@@ -695,7 +714,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         __builtin_amdgcn_sched_barrier(0);                            \
     }
         if (TIMING) c0 = __builtin_amdgcn_s_memtime();
-        for (int t = 0; t < ntiles; ++t) {
+        for (int t = tb; t < te; ++t) {
             // X(t): matrix segment
             PP_TICK(3);
             if (grp == 0) dma_pair(t);
@@ -719,7 +738,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         if (TIMING && wgid == 0 && sg == 0 && (wave & 3) == 0 && lane == 0)
             for (int i = 0; i < 4; ++i) tg_attn_dbg[grp * 4 + i] = tc[i];
 #undef PP_TICK
-        pv(ntiles - 1);                                                            // X(nt): last P.V
+        pv(te - 1);                                                                // X(nt): last P.V
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (grp == 0 && !(p.knob & 2)) PP_BAR();                                   // barrier counts of the two groups meet again
         PP_BAR();                                                                  // all LDS reads of this segment done
@@ -729,6 +748,36 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         // the wave's staging area [64 rows][128 B] (16-B slots XOR-swizzled by row&7) is written in that shape and read back as
         // 8 lanes x 16 B per row.  With two key segments the normalised result of segment 1 simply WAITS there (no global write +
         // read-modify-write as before): segment 2 adds its `seg2_scale * O2` on top (each lane re-reads exactly what it wrote).
+        if (SPLIT && half >= 0) {
+            // split parent: leave this half's partial result in the workspace (attn_split_combine_kernel joins the halves).  Segment 1:
+            // unnormalised O + (m, l) per row; segment 2 (second half only): the finished bf16(seg2_scale * O2) as floats.
+            float* wsb = p.split_ws + (long)(2 * (wgid - p.split_first) + half) * SPLIT_HALF_FLOATS;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const float lt = l[qb] + __shfl_xor(l[qb], 32, 64);
+                const int row = wave * 64 + qb * 32 + j;
+                float w = 1.f;
+                float* dst = wsb + (long)row * 64;
+                if (sg == 0) {
+                    if (hi == 0) { wsb[512 * 64 + row] = m[qb]; wsb[512 * 65 + row] = lt; }
+                } else {
+                    w = p.seg2_scale_b[b & 15] / lt;
+                    dst += 512 * 66;
+                    if (FIXEDM == 1) {
+                        if (__any(!(lt >= 5.421011e-20f && lt < 3.0e38f)) && lane == 0) p.retry[1 + wgid] = 1;
+                    }
+                }
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        f32x4 v = {acc_o[qb][db][g4 * 4 + 0] * w, acc_o[qb][db][g4 * 4 + 1] * w, acc_o[qb][db][g4 * 4 + 2] * w, acc_o[qb][db][g4 * 4 + 3] * w};
+                        if (sg > 0) v = f32x4{round_bf16(v[0]), round_bf16(v[1]), round_bf16(v[2]), round_bf16(v[3])};
+                        *(f32x4*)(dst + db * 32 + g4 * 8 + hi * 4) = v;
+                    }
+            }
+            continue;
+        }
         char* stg = smem + 4 * TILE_B + wave * 8192;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
@@ -782,12 +831,75 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
                 p.retry[1 + w] = 0;
                 atomicAdd(&p.retry[0], 1);
             }
-            body(w);
+            body(w, -1);
             __syncthreads();                                   // LDS is reused by the next flagged workgroup
         }
+    } else if constexpr (SPLIT) {
+        // two half workgroups per split parent, both on the XCD the parent's (batch, head) lives on (workgroup b runs on XCD b % 8, and the
+        // parents' wgid % 8 selects their head's XCD when split_first is a multiple of 8): the halves of one head share its K / V in that L2
+        const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        const int i = 8 * (slot >> 1) + xcd;
+        if (i < p.nsplit) body(p.split_first + i, slot & 1);
     } else {
-        body((int)blockIdx.x);
+        // whole workgroups: the launch skips the split parents [split_first, split_first + nsplit)
+        const int w = (int)blockIdx.x;
+        body(w < p.split_first ? w : w + p.nsplit, -1);
     }
+}
+
+// Joins the two halves of every split parent: O = (Oa 2^(ma-M) + Ob 2^(mb-M)) / (la 2^(ma-M) + lb 2^(mb-M)), M = max(ma, mb) — with the
+// constant shift ma == mb and this is a plain sum — rounds to bf16, adds the second segment's bf16(seg2_scale * O2) like the unsplit epilogue,
+// and writes the parent's output rows.  The constant-shift verification of a split parent's segment 1 happens here, on the JOINED row sum.
+__global__ __launch_bounds__(256) void attn_split_combine_kernel(AttnParams p, int fixedm) {
+    const int wgid = p.split_first + blockIdx.x;
+    const bool rider = p.r_nq > 0 && wgid >= p.main_wgs;
+    const int bid = rider ? wgid - p.main_wgs : wgid;
+    const int nq_ = rider ? p.r_nq : p.nq;
+    const int nseg_ = rider ? 1 : p.nseg;
+    bf16_t* const out_ = rider ? p.r_out : p.out;
+    const long o_ld_ = rider ? p.r_o_ld : p.o_ld, o_sb_ = rider ? p.r_o_sb : p.o_sb;
+    const int nqt = (nq_ + 511) / 512;
+    const int nhb = p.heads * p.batch;
+    int hb, qt;
+    if ((nhb & 7) == 0) {
+        const int xcd = bid & 7, slot = bid >> 3;
+        hb = xcd + 8 * (slot / nqt);
+        qt = slot % nqt;
+    } else {
+        hb = bid / nqt;
+        qt = bid % nqt;
+    }
+    const int h = hb % p.heads, b = hb / p.heads;
+    const float* wa = p.split_ws + (long)(2 * blockIdx.x) * SPLIT_HALF_FLOATS;
+    const float* wb = wa + SPLIT_HALF_FLOATS;
+    bool bad = false;
+    for (int item = threadIdx.x; item < 512 * 4; item += 256) {
+        const int row = item >> 2, d0 = (item & 3) * 16;
+        const int q = qt * 512 + row;
+        if (q >= nq_) continue;
+        const float ma = wa[512 * 64 + row], la = wa[512 * 65 + row], mb = wb[512 * 64 + row], lb = wb[512 * 65 + row];
+        const float M = fmaxf(ma, mb);
+        const float fa = __builtin_amdgcn_exp2f(ma - M), fb = __builtin_amdgcn_exp2f(mb - M);
+        const float L = la * fa + lb * fb;
+        if (fixedm && !(L >= 5.421011e-20f && L < 3.0e38f)) bad = true;
+        const float ia = fa / L, ib = fb / L;
+        uint32_t o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int d = d0 + 2 * i;
+            float v0 = wa[(long)row * 64 + d] * ia + wb[(long)row * 64 + d] * ib;
+            float v1 = wa[(long)row * 64 + d + 1] * ia + wb[(long)row * 64 + d + 1] * ib;
+            if (nseg_ == 2) {
+                v0 = round_bf16(v0) + wb[512 * 66 + (long)row * 64 + d];
+                v1 = round_bf16(v1) + wb[512 * 66 + (long)row * 64 + d + 1];
+            }
+            o[i] = pack_bf16x2(v0, v1);
+        }
+        bf16_t* dst = out_ + (long)b * o_sb_ + (long)q * o_ld_ + h * 64 + d0;
+        *(uint4*)dst = uint4{o[0], o[1], o[2], o[3]};
+        *(uint4*)(dst + 8) = uint4{o[4], o[5], o[6], o[7]};
+    }
+    if (bad) p.retry[1 + wgid] = 1;
 }
 
 }  // namespace
@@ -859,6 +971,27 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
     const long grid512 = wg512 + (p.r_nq > 0 ? (long)((p.r_nq + 511) / 512) * heads * batch : 0);
     p.total_wgs = (int)grid512;
     const unsigned retry_grid = (unsigned)(grid512 < n_cu ? grid512 : n_cu);
+    // ---- last-round quantisation: every 512-row workgroup of a launch takes the same time (same key length), so G workgroups cost
+    // ceil(G / CUs) rounds — the DiT's 3360 + 96 = 13.5 x 256 pay for 14.  When the remainder R = G mod CUs is at most half a round, R
+    // workgroups are split over the KEY axis into 2 R half-length workgroups (their own launch behind the G - R whole ones, partials joined by
+    // attn_split_combine_kernel): the tail then costs half a round, 13.5 instead of 14.  Splitting over the queries cannot do that (DESIGN §8:
+    // 128-row workgroups are themselves badly quantised).  The split parents are the last R workgroups of the MAIN problem, not the riders:
+    // the halves of one head's query tiles share that head's K / V in their XCD's L2, whereas every rider has a (batch, head) of its own and
+    // 256 of those streaming at once are HBM-bound.  TG_ATTN_SPLIT=0 disables; needs the caller's split workspace.
+    static const int split_on = [] { const char* e = getenv("TG_ATTN_SPLIT"); return e ? atoi(e) : 1; }();
+    p.nsplit = 0;
+    p.split_first = (int)grid512;
+    if (pp && split_on && p.split_ws && !p.lse && !timing && grid512 > n_cu) {
+        const long R = grid512 % n_cu;
+        const int nt_main = (p.s[0].nk + KVBLK - 1) / KVBLK, nt_rider = p.r_nq > 0 ? (p.r_s.nk + KVBLK - 1) / KVBLK : 2;
+        (void)nt_rider;
+        if (R > 0 && 2 * R <= n_cu && R <= wg512 && nt_main >= 2 && p.split_ws_floats >= 2 * R * SPLIT_HALF_FLOATS) {
+            p.nsplit = (int)R;
+            p.split_first = (int)(wg512 - R);
+        }
+    }
+    // whole workgroups | halves of the split parents (rounded up to whole groups of 16 = 8 XCDs x 2 halves)
+    const unsigned main_grid = (unsigned)(grid512 - p.nsplit), split_grid = (unsigned)(16 * ((p.nsplit + 7) / 8));
     constexpr size_t PP_LDS = 4 * TILE_B + 8 * 8192;
     static const bool pp_attr = [] {
         (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
@@ -868,6 +1001,9 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
         (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 1, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         return true;
     }();
     (void)pp_attr;
@@ -878,12 +1014,17 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
         fprintf(stderr, "[tg_attention timing] g0: X %lld Xwait %lld Y %lld Ywait %lld | g1: X %lld Xwait %lld Y %lld Ywait %lld (s_memtime ticks, seg 0)\n",
                 h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     } else if (pp && fixedm) {
-        // the verified constant-shift pass, then the retry launch: a persistent grid that re-runs the flagged workgroups (normally none)
+        // the verified constant-shift pass, [the split tail and its join,] then the retry launch: a persistent grid that re-runs the flagged
+        // workgroups (normally none)
         if (p.lse) {
-            hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1, true>), dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
+            hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1, true>), dim3(main_grid), dim3(512), PP_LDS, stream, p);
             hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 0, true, true>), dim3(retry_grid), dim3(512), PP_LDS, stream, p);
         } else {
-            hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1>), dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
+            hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1>), dim3(main_grid), dim3(512), PP_LDS, stream, p);
+            if (p.nsplit) {
+                hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1, false, false, true>), dim3(split_grid), dim3(512), PP_LDS, stream, p);
+                hipLaunchKernelGGL(attn_split_combine_kernel, dim3((unsigned)p.nsplit), dim3(256), 0, stream, p, 1);
+            }
             hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 0, false, true>), dim3(retry_grid), dim3(512), PP_LDS, stream, p);
         }
     } else if (pp) {
@@ -893,9 +1034,15 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
                 (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
                 attr_lse = true;
             }
-            hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 0, true>), dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
-        } else if (p.prescaled) hipLaunchKernelGGL(attn_fwd_pp_kernel<true>, dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
-        else hipLaunchKernelGGL(attn_fwd_pp_kernel<false>, dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
+            hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 0, true>), dim3(main_grid), dim3(512), PP_LDS, stream, p);
+        } else if (p.prescaled) {
+            hipLaunchKernelGGL(attn_fwd_pp_kernel<true>, dim3(main_grid), dim3(512), PP_LDS, stream, p);
+            if (p.nsplit) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 0, false, false, true>), dim3(split_grid), dim3(512), PP_LDS, stream, p);
+        } else {
+            hipLaunchKernelGGL(attn_fwd_pp_kernel<false>, dim3(main_grid), dim3(512), PP_LDS, stream, p);
+            if (p.nsplit) hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 0, false, false, true>), dim3(split_grid), dim3(512), PP_LDS, stream, p);
+        }
+        if (p.nsplit) hipLaunchKernelGGL(attn_split_combine_kernel, dim3((unsigned)p.nsplit), dim3(256), 0, stream, p, 0);
     } else if (wg256 >= 1024 && abl) {
         if (abl == 1) hipLaunchKernelGGL((attn_fwd_kernel<2, 1>), dim3((unsigned)wg256), dim3(256), 0, stream, p);
         else if (abl == 2) hipLaunchKernelGGL((attn_fwd_kernel<2, 2>), dim3((unsigned)wg256), dim3(256), 0, stream, p);
@@ -924,8 +1071,17 @@ extern "C" long tg_attention_retry_ints(int nq0, int nq1, int heads, int batch) 
     return 1 + (long)((nq0 + 511) / 512 + (nq1 > 0 ? (nq1 + 511) / 512 : 0)) * heads * batch;
 }
 
+extern "C" long tg_attention_split_floats(int nq0, int nq1, int heads, int batch) {
+    int dev = 0, n_cu = 256;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    const long g = (long)((nq0 + 511) / 512 + (nq1 > 0 ? (nq1 + 511) / 512 : 0)) * heads * batch;
+    const long R = g % n_cu;
+    return (g > n_cu && R > 0 && 2 * R <= n_cu) ? 2 * R * SPLIT_HALF_FLOATS : 0;
+}
+
 extern "C" int tg_attention_fwd_multi(const tg_attn_problem* problems, int nproblems, int heads, int batch, float scale, int k_prescaled,
-                                      int* retry_ws, long retry_ints, hipStream_t stream) {
+                                      const tg_attn_workspace* ws, hipStream_t stream) {
     TG_REQUIRE(problems && (nproblems == 1 || nproblems == 2), TG_ERR_ARG, "tg_attention_fwd_multi: 1 or 2 problems");
     TG_REQUIRE(heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_attention_fwd_multi: bad shape");
     const tg_attn_problem& A = problems[0];
@@ -947,11 +1103,16 @@ extern "C" int tg_attention_fwd_multi(const tg_attn_problem* problems, int nprob
         if ((rc = fill_segment(p.r_s, B.seg[0], "problem 1"))) return rc;
         p.r_out = (bf16_t*)B.out; p.r_o_ld = B.out_ld; p.r_o_sb = B.out_strideB; p.r_nq = B.nq;
     }
-    if (retry_ws) {
-        TG_REQUIRE(retry_ints >= tg_attention_retry_ints(p.nq, p.r_nq, heads, batch), TG_ERR_SHAPE,
-                   "tg_attention_fwd_multi: retry workspace of %ld ints, need %ld (tg_attention_retry_ints)", retry_ints,
+    if (ws && ws->retry) {
+        TG_REQUIRE(ws->retry_ints >= tg_attention_retry_ints(p.nq, p.r_nq, heads, batch), TG_ERR_SHAPE,
+                   "tg_attention_fwd_multi: retry workspace of %ld ints, need %ld (tg_attention_retry_ints)", ws->retry_ints,
                    tg_attention_retry_ints(p.nq, p.r_nq, heads, batch));
-        p.retry = retry_ws;
+        p.retry = ws->retry;
+    }
+    if (ws && ws->split) {
+        TG_REQUIRE(tg_aligned16(ws->split), TG_ERR_ALIGN, "tg_attention_fwd_multi: split workspace alignment (16 B)");
+        p.split_ws = ws->split;
+        p.split_ws_floats = ws->split_floats;
     }
     return attention_launch(p, scale, k_prescaled, "tg_attention_fwd_multi", stream);
 }
@@ -974,7 +1135,7 @@ extern "C" int tg_attention_fwd(const void* q1, long q1_ld, long q1_strideB,
     }
     A.seg2_scale = seg2_scale;
     A.out = out; A.out_ld = out_ld; A.out_strideB = out_strideB; A.nq = nq;
-    return tg_attention_fwd_multi(&A, 1, heads, batch, scale, k_prescaled, nullptr, 0, stream);
+    return tg_attention_fwd_multi(&A, 1, heads, batch, scale, k_prescaled, nullptr, stream);
 }
 
 extern "C" int tg_attention_fwd_lse(const void* q, long q_ld, long q_strideB, const void* k, long k_ld, long k_strideB, const void* vt, long vt_ld, int nk,

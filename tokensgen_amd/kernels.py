@@ -335,6 +335,9 @@ class AttnRetry:
         self.buf = torch.zeros(self.ints, dtype=torch.int32, device=device)
         self._host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self._event = None
+        # the key-split scratch of the same launch shape (tg_attn_workspace.split; 0 floats when the shape leaves no half-round tail)
+        nsf = int(L.load().tg_attention_split_floats(nq0, nq1, heads, batch))
+        self.split = torch.empty(nsf, dtype=torch.float32, device=device) if nsf else None
 
     def fits(self, nq0, nq1, heads, batch):
         return L.load().tg_attention_retry_ints(nq0, nq1, heads, batch) <= self.ints
@@ -357,11 +360,12 @@ class AttnRetry:
         return val
 
 
-def attention_multi(main, rider, heads, scale, k_prescaled=False, retry=None):
+def attention_multi(main, rider, heads, scale, k_prescaled=False, retry=None, split=None):
     """One launch for one or two attention problems of the same heads/batch (tg_attention_fwd_multi).  main / rider: dicts of the
     keyword arguments of `attention` (q1, k1, vt1, nk1, out [, q2, k2, vt2, nk2, seg2_scale, kmax1, kmax2]); the rider (may be None) has one
     key segment.  kmax1 / kmax2 (fp32 [B, heads], from qk_layernorm_rope_pair(kmax=...)) on every segment + retry (AttnRetry): the
-    constant-shift softmax path (tg_attn_segment.k_norm2_max)."""
+    constant-shift softmax path (tg_attn_segment.k_norm2_max).  split (fp32 scratch tensor, e.g. AttnRetry.split): lets the launch split its
+    half-round tail over the key axis (tg_attn_workspace.split)."""
     import ctypes
     pa, B = _attn_problem(**main)
     n = 1
@@ -374,9 +378,10 @@ def attention_multi(main, rider, heads, scale, k_prescaled=False, retry=None):
         arr = (L.AttnProblem * 1)(pa)
     if retry is not None:
         assert retry.fits(main["q1"].shape[1], rider["q1"].shape[1] if rider is not None else 0, heads, B)
+    ws = L.AttnWorkspace(_p(retry.buf) if retry is not None else None, retry.ints if retry is not None else 0,
+                         _p(split) if split is not None else None, split.numel() if split is not None else 0)
     L.check(_launch("attention_2seg+rider" if n == 2 else f"attention_multi1_nq{pa.nq}", L.load().tg_attention_fwd_multi, ctypes.addressof(arr), n, heads, B,
-                    float(scale), 1 if k_prescaled else 0, _p(retry.buf) if retry is not None else None, retry.ints if retry is not None else 0,
-                    _stream()), "tg_attention_fwd_multi")
+                    float(scale), 1 if k_prescaled else 0, ctypes.addressof(ws), _stream()), "tg_attention_fwd_multi")
     return main["out"], (rider["out"] if rider is not None else None)
 
 

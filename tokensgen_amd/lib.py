@@ -30,7 +30,7 @@ PROTOTYPES = {
     "tg_transpose_v": [_vp, _l, _l, _i, _i, _i, _i, _vp, _l, _vp],
     "tg_attention_fwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _f, _vp, _l, _l,
                          _i, _i, _i, _f, _i, _vp],
-    "tg_attention_fwd_multi": [_vp, _i, _i, _i, _f, _i, _vp, _l, _vp],
+    "tg_attention_fwd_multi": [_vp, _i, _i, _i, _f, _i, _vp, _vp],
     "tg_attention_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l,
                          _i, _i, _i, _i, _f, _i, _vp, _vp, _vp],
     "tg_attention_fwd_lse": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp, _l, _l, _i, _i, _i, _f, _vp, _vp],
@@ -72,6 +72,7 @@ QUERIES = {
     "tg_conv3d_splitk_floats": [C.c_int] * 9,
     "tg_attention_bwd_ws_floats": [C.c_int, C.c_int, C.c_int, C.c_int],
     "tg_attention_retry_ints": [C.c_int, C.c_int, C.c_int, C.c_int],
+    "tg_attention_split_floats": [C.c_int, C.c_int, C.c_int, C.c_int],
     "tg_qk_kmax_ws_floats": [C.c_int, C.c_int, C.c_int],
     "tg_qk_layernorm_rope_bwd_partial_floats": [C.c_int, C.c_int, C.c_int],
     "tg_colsum_partial_floats": [C.c_int, C.c_int],
@@ -122,3 +123,8 @@ class AttnProblem(C.Structure):
     _fields_ = [("seg", AttnSegment * 2), ("nseg", C.c_int), ("seg2_scale", C.c_float),
                 ("out", C.c_void_p), ("out_ld", C.c_long), ("out_strideB", C.c_long), ("nq", C.c_int),
                 ("seg2_scale_batch", C.POINTER(C.c_float))]
+
+
+class AttnWorkspace(C.Structure):
+    """tg_attn_workspace (include/tokensgen_hip.h)"""
+    _fields_ = [("retry", C.c_void_p), ("retry_ints", C.c_long), ("split", C.c_void_p), ("split_floats", C.c_long)]

@@ -555,7 +555,7 @@ class CogVideoXTransformer3DModel(nn.Module):
             K.attention_multi(dict(q1=ws.QKV[:, :, :D], k1=ws.QKV[:, :, D:2 * D], vt1=ws.Vt1, nk1=N1, out=ws.AO[:, :N1],
                                    q2=ws.QKVv[:, :N1, :D], k2=ws.QKVv[:, N1:, D:2 * D], vt2=vt2, nk2=Np, seg2_scale=s, kmax1=km1, kmax2=km2, seg2_scale_batch=s_batch),
                               dict(q1=ws.QKVv[:, N1:, :D], k1=ws.QKVv[:, :, D:2 * D], vt1=ws.Vt3, nk1=N, out=ws.AO[:, N1:], kmax1=km2),
-                              H, sm_scale, k_prescaled=True, retry=ws.retry if fast else None)
+                              H, sm_scale, k_prescaled=True, retry=ws.retry if fast else None, split=getattr(ws.retry, "split", None))
         elif fast:
             K.attention_multi(dict(q1=ws.QKV[:, :, :D], k1=ws.QKV[:, :, D:2 * D], vt1=ws.Vt1, nk1=N1, out=ws.AO[:, :N1], kmax1=ws.kmax1), None,
                               H, sm_scale, k_prescaled=True, retry=ws.retry)

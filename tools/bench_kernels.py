@@ -82,7 +82,7 @@ def bench_attn_dit():
         K.attention_multi(dict(q1=qkv[:, :, :D], k1=qkv[:, :, D:2 * D], vt1=vt1, nk1=N1, out=ao[:, :N1], q2=qkvv[:, :N1, :D], k2=qkvv[:, N1:, D:2 * D],
                                vt2=vt2, nk2=NP, seg2_scale=0.6, kmax1=km1 if fast else None, kmax2=km2 if fast else None),
                           dict(q1=qkvv[:, N1:, :D], k1=qkvv[:, :, D:2 * D], vt1=vt3, nk1=N, out=ao[:, N1:], kmax1=km2 if fast else None), H, 0.125,
-                          k_prescaled=True, retry=retry if fast else None)
+                          k_prescaled=True, retry=retry if fast else None, split=retry.split if os.environ.get("TG_BENCH_SPLIT", "1") == "1" else None)
     fl = B * (4.0 * N1 * N1 * D + 4.0 * N1 * NP * D + 4.0 * NP * N * D)
     res = {}
     for name, fast in (("constant_shift", True), ("running_max", False)):
