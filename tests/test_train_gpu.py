@@ -69,6 +69,21 @@ def test_attention_bwd_vs_autograd(B, H, nq, nk):
     assert _rel(dq3, qf.grad) < 5.5e-3 and _rel(dk3, kf.grad) < 5.5e-3 and _rel(dv3, vf.grad) < 4.5e-3
 
 
+def test_attention_bwd_cross_check_kernels_in_a_child_process():
+    """TG_ATTN_BWD_V1=1 selects the correct-first backward kernels (LDS-staged 64 x 64 tiles, explicit transposes) kept as the cross-check of the
+    register-resident ones: the same autograd comparison must hold for them (the switch is read once per process, hence the child)."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("TG_ATTN_BWD_V1") == "1":
+        pytest.skip("already inside the cross-check run")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "test_attention_bwd_vs_autograd", "-x"],
+                       env=dict(os.environ, TG_ATTN_BWD_V1="1"), capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def test_to2v_processor_attention_gradients():
     """The three SDPA calls of VideoIPAdapterCogVideoXAttnProcessor2_0 (func_type "1") composed from tg_attention_bwd calls: gradients of
     every q / k / v tensor of the base and the vip projections (the vip ones are the TRAINABLE path, cogvideox_transformer_3d.py:207-218)

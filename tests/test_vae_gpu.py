@@ -240,7 +240,7 @@ def test_conv_epilogue_groupnorm_sums(ci, co, T, H, W):
 
 def test_conv_4wave_kernel_bitwise_equals_128_kernel(tmp_path):
     """The 4-wave convolution kernels (256x256 tiles for Cout % 256 == 0, 512x128 for Cout = 128; default when there are >= 2 tiles per
-    CU, TG_CONV_W4 / TG_CONV_W4N = 2 force them whenever legal) adds the same products in the same order as the 128x128 kernel (TG_CONV_W4=0): bitwise equal tensors — causal
+    CU, TG_CONV_W4 = 2 forces them whenever legal) adds the same products in the same order as the 128x128 kernel (TG_CONV_W4=0): bitwise equal tensors — causal
     cache frames, replicated first frame, zero padding, spatial upsampling, residual add, ragged last tile, Cin 64..256, Cout 256/512 —
     and GroupNorm statistics from the epilogue equal to fp32 rounding.  The knob is read once per process: tools/conv_w4_check.py runs
     once per mode and the second run compares with the first run's outputs."""
@@ -248,7 +248,7 @@ def test_conv_4wave_kernel_bitwise_equals_128_kernel(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for mode in ("0", "2"):
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_w4_check.py"), str(tmp_path)], env=dict(os.environ, TG_CONV_W4=mode, TG_CONV_W4N=mode, TG_CONV_SPLITK="0", TG_CONV_HALO="0"),
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_w4_check.py"), str(tmp_path)], env=dict(os.environ, TG_CONV_W4=mode, TG_CONV_SPLITK="0", TG_CONV_HALO="0"),
                            capture_output=True, text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "vs mode 0" in r.stdout and "bitwise False" not in r.stdout

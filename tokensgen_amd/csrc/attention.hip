@@ -45,7 +45,6 @@ struct AttnParams {
     int nq, heads, batch;
     float scale_log2;   // softmax scale * log2(e)
     int prescaled;      // 1: K already carries scale*log2(e) (tg_qk_layernorm_rope out_scale): scores are log2-domain as produced
-    int knob;           // TG_ATTN_KNOB experiment bits (1: static s_setprio 1 for the second-dispatched wave group; 2: wave groups in phase)
     // "rider": a second, single-segment problem of the same heads/batch whose workgroups are appended to the launch (ping-pong
     // kernel only).  The main attention leaves 3360 - 13*256 = 32 workgroups for its last round of 256 CUs; the To2V block's
     // vip-query attention (96 workgroups of the same length) rides in that round instead of costing a launch of its own.
@@ -79,7 +78,7 @@ __device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slo
 
 // QB = 32-row query blocks per wave (1 or 2).  QB=2 shares every K / V^T fragment read between two query
 // blocks (half the LDS and L2 traffic per MFMA); QB=1 gives 2x the workgroups for short query ranges.
-template <int QB, int ABL = 0>   // ABL: profiling ablations (1 = no K/V staging after tile 0, 2 = no softmax math, 3 = no MFMA); 0 ships
+template <int QB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // K[2], Vt[2]
     constexpr int QT = 128 * QB;
@@ -165,7 +164,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 
         for (int t = 0; t < ntiles; ++t) {
             const int cur = t & 1;
-            if (ABL != 1 && t + 1 < ntiles) gload(t + 1);
+            if (t + 1 < ntiles) gload(t + 1);
             const char* tK = smem + cur * TILE_B;
             const char* tV = smem + (2 + cur) * TILE_B;
 
@@ -184,7 +183,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
                     const bf16x8 kf = *(const bf16x8*)(tK + offK[kb][kd]);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb)
-                        if (ABL != 3) sc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][kd], sc[qb][kb], 0, 0, 0);
+                        sc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][kd], sc[qb][kb], 0, 0, 0);
                 }
             }
             // ---- mask the ragged last tile: reg r of block kb is key t*64 + kb*32 + 16*(r>>3) + 8*hi + (r&7)
@@ -201,17 +200,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
             }
             // ---- online softmax (log2 domain), lane-local row; P packed to bf16 MFMA operands in place ----
             bf16x8 pf[QB][4];
-            if (ABL == 2) {
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        union { bf16x8 v; float f[4]; } pk;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) pk.f[i] = sc[qb][ks >> 1][(ks & 1) * 8 + i] + sc[qb][ks >> 1][(ks & 1) * 8 + 4 + i];
-                        pf[qb][ks] = pk.v;
-                    }
-            } else
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 float mx = sc[qb][0][0];
@@ -257,10 +245,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
                     const bf16x8 vf = *(const bf16x8*)(tV + offV[db][ks]);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb)
-                        if (ABL != 3) acc_o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][ks], acc_o[qb][db], 0, 0, 0);
+                        acc_o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][ks], acc_o[qb][db], 0, 0, 0);
                 }
             }
-            if (ABL != 1 && t + 1 < ntiles) lwrite(cur ^ 1);
+            if (t + 1 < ntiles) lwrite(cur ^ 1);
             __syncthreads();
         }
         // ---- segment epilogue: normalise and write (segment 2 accumulates onto segment 1's bf16 result, like the
@@ -299,7 +287,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------------
 // 8-wave "ping-pong" kernel for long query ranges (512 query rows per workgroup, 64 per wave).
 //
-// Ablation of the 4-wave kernel on MI355X (TG_ATTN_ABLATE): full 9.15 ms = no-MFMA 4.3 ms + MFMA-only ~4 ms — the two
+// Timing ablations of the 4-wave kernel on MI355X: full 9.15 ms = no-MFMA 4.3 ms + MFMA-only ~4 ms — the two
 // co-resident waves of a SIMD run the same instruction stream in phase, so their MFMA segments collide and their softmax
 // (VALU) segments collide: matrix and vector pipes are used one after the other, not together.  Here the two waves that
 // share a SIMD (wave w of group 0, wave w+4 of group 1) are put in ANTI-PHASE by construction: group 1 runs one barrier
@@ -313,28 +301,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 //     wave before the barrier that ends interval 2u+1, first read in interval 2u+2; the buffers it overwrites were last read
 //     in interval 2u-1.
 //
-// Measured on MI355X, N = 17776 (same-box A/B, tools/ab_run.sh; box-to-box spread is ~4 %):
-//   in-kernel s_memtime per tile: X ~1600 cycles (1152 of MFMA), Y ~2000 cycles for ~190 VALU — a lone wave issues one VALU
-//   per ~6.6 cycles (tools/ubench/valu_rate.hip: 6.64 plain / 10.6 v_exp_f32 with 1 wave per SIMD, half that per SIMD with 2).
-//   Helped: fragment-granular ds_read pipelining in X, -m seeding through the matrix pipe, two v_max3 chains +
-//   v_permlane32_swap, four row-sum chains (8.63 -> 7.8 ms), s_setprio 2 around the matrix segment (-> 7.5 ms; raising
-//   the VECTOR segment instead: +6 %).  Did not help: plain v_add_f32 row sums; s_setprio 1 for the
-//   second-dispatched half; exponentiating the last 1 or 2 k-steps of P(t) inside X(t+1) as MFMA fillers (9.1 / 11.4 ms:
-//   VALU between the MFMAs of the matrix segment costs more than it frees in the vector segment); rescale triggered by the
-//   tile's row SUM instead of a row max (30 fewer VALU per tile, yet 8.3 vs 7.9 ms); ONE barrier per tile with 3-deep K/V rings
-//   (group 0: X|B|Y, group 1: B|X|Y — nobody waits for the partner's longer segment): 8.54 vs 8.12 ms, the per-wave X+Y issue
-//   time (~3600 cycles per tile) did not change, only where the waiting happens; fragment prefetch depth 2/3/4: 7.95/7.89/7.92.
-//   Both groups IN phase (TG_ATTN_KNOB bit 1: X together, then Y together — two vector segments would share the VALU at the
-//   two-wave issue rate while the matrix segments queue on the MFMA pipe): 9.16 vs 7.69 ms, the anti-phase pairing stays.
-//   Code generation is fragile here: a workgroup-uniform `if (knob) xseg(t)` around the matrix segment (for an ablation) made the
-//   whole kernel 60 % slower, fencing the closing s_setprio with sched_barrier(0) 2.5 % — so the TG_ATTN_TIMING build (which adds
-//   s_memtime reads and fences) is good for the RATIO of the segments, not for absolute cycles; one copy of the tile loop per wave
-//   group (no `if (grp == ..)` inside the loop) measured 6 % slower.
+// Measured on MI355X, N = 17776 (the experiments behind this schedule are written up in DESIGN.md §8): per tile X ~1600 cycles (1152 of
+// MFMA), Y ~2000 cycles for ~190 VALU with the running maximum.  What moved it: fragment-granular ds_read pipelining in X, -m seeding
+// through the matrix pipe, two v_max3 chains + v_permlane32_swap, four row-sum chains, s_setprio 2 around the matrix segment, and finally
+// dropping the maximum altogether (FIXEDM).  Code generation is fragile here: a workgroup-uniform branch around the matrix segment made the
+// whole kernel 60 % slower, one copy of the tile loop per wave group 6 % — measure every edit (tools/ab_build.sh, tools/ab_run.sh).
 // ------------------------------------------------------------------------------------------------
-#ifndef TG_ATTN_NFR
-#define TG_ATTN_NFR 3
-#endif
-__device__ long long tg_attn_dbg[16];   // TG_ATTN_TIMING: cycles {X work, X barrier wait, Y work, Y barrier wait} of block 0, waves 0 and 4
 
 // FIXEDM 1 — constant-shift softmax, valid for ANY weights.  The softmax is shift invariant, so the running row maximum is only a RANGE
 // device.  Here every query row subtracts a constant c_row fixed before the first tile: with B_row = ||q_row|| * max_j ||k_j|| (Cauchy-
@@ -345,10 +317,9 @@ __device__ long long tg_attn_dbg[16];   // TG_ATTN_TIMING: cycles {X work, X bar
 // epilogue VERIFIES (row sum >= 2^-64, i.e. the largest weight >= 2^-79: the terms flushed below 2^-126 are then < 2^-32 of the sum) —
 // a workgroup with a failing row raises its flag in p.retry and the RETRY launch (running maximum; a one-workgroup-per-CU grid that walks
 // the flag list) recomputes exactly those workgroups.  The per-tile max chain / vote / rescale (15 % of the launch) is gone from the hot loop.
-// FIXEDM 2: experiment — no shift at all and no seed MFMAs (measured slower than 1).
 // SPLIT: the launch of the half-length workgroups of the split tail (see attention_launch) — its own instantiation so that the partial-result
 // epilogue and the runtime tile range stay out of the ordinary kernel's register allocation (as one kernel they cost it ~45 spilled VGPRs)
-template <bool PRESCALED, bool TIMING = false, int FIXEDM = 0, bool LSE = false, bool RETRY = false, bool SPLIT = false>
+template <bool PRESCALED, int FIXEDM = 0, bool LSE = false, bool RETRY = false, bool SPLIT = false>
 __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
     // K[2], Vt[2] tiles (32 KiB) + the output staging area: 8 waves x 64 query rows x 128 B (64 KiB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -473,7 +444,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             // tile's true row max — upward OR downward, so rows whose scores all sit below -126 do not underflow to l = 0 — with no
             // first-tile test in the hot loop (an explicit `t == 0` there cost 1.5-2 %).  Price: the first tile's 64 scores are
             // formed as s + 2^14 in fp32, i.e. to 2^-9 absolute (0.14 % on their weights, below the bf16 rounding of P).
-            m[qb] = FIXEDM == 2 ? 0.f : FIXEDM == 1 ? cshift[qb] : PRESCALED ? -16384.f : -1e30f;
+            m[qb] = FIXEDM == 1 ? cshift[qb] : PRESCALED ? -16384.f : -1e30f;
             l[qb] = 0.f;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
@@ -493,46 +464,14 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
                         acc_o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][ks], acc_o[qb][db], 0, 0, 0);
                 }
         };
-        // S(t) = K(t).Q^T (+ ragged-tile mask)
-        auto scores = [&](int t) {
-            const char* tK = smem + (t & 1) * TILE_B;
-            // PRESCALED: the accumulator starts at -m (a lane owns ONE query row, so all 16 registers of a block take the same
-            // value) and the MFMA output is already s - m in log2 units: no per-element scale/subtract in the vector segment
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sc[qb][kb][r] = PRESCALED ? -m[qb] : 0.f;
-#pragma unroll
-            for (int kd = 0; kd < 4; ++kd)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    const bf16x8 kf = *(const bf16x8*)(tK + ((offK0 + kb * 4096) ^ (kd << 5)));
-#pragma unroll
-                    for (int qb = 0; qb < 2; ++qb)
-                        sc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][kd], sc[qb][kb], 0, 0, 0);
-                }
-            if ((t + 1) * KVBLK > S.nk) {
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int key = t * KVBLK + kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
-                            if (key >= S.nk) sc[qb][kb][r] = -1e30f;
-                        }
-            }
-        };
-        // X(t) for t > 0: the 8 fragment groups {V^T(t-1) ks=0..3, K(t) kd=0..3} software-pipelined one group ahead, so the
+        // X(t): the 8 fragment groups {V^T(t-1) ks=0..3, K(t) kd=0..3} software-pipelined one group ahead, so the
         // ds_read_b128 latency of group g+1 runs under the 4 MFMAs (128 cycles) of group g instead of after them
         auto xseg = [&](int t) {
             const char* tV = smem + (2 + ((t - 1) & 1)) * TILE_B;
             const char* tK = smem + (t & 1) * TILE_B;
             // fragment i = 2g + xb (g: k-step group, xb: 32-row block of V^T / K); NFR 4-register buffers, fragment i+NFR is
             // fetched into the buffer fragment i just left, so every ds_read_b128 has NFR-1 MFMA pairs (64 cycles each) of cover
-            constexpr int NFR = TG_ATTN_NFR;
+            constexpr int NFR = 3;               // fragment buffers in flight (2 / 3 / 4 measured 7.95 / 7.89 / 7.92 ms)
             bf16x8 fr[NFR];
             // The fragment reads are inline asm with hand-counted lgkmcnt waits: for a C++ LDS load the compiler (a) waits vmcnt(0)
             // first whenever an LDS-DMA piece is in flight (it cannot prove the DMA target is another buffer) — group 0 issues its
@@ -556,7 +495,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
 #pragma unroll
             for (int i = 0; i < NFR; ++i) ld(i);
             const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (PRESCALED && FIXEDM != 2) {
+            if (PRESCALED) {
                 // seed S with -m through the matrix pipe: ones[key][k=0] x negm[k=0][query] = -m[query] in every register of
                 // the lane's row, 4 MFMAs that run under the first fragments' ds_read latency (no 64 v_mov per tile)
 #pragma unroll
@@ -580,7 +519,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
                     if (g < 4) acc_o[qb][xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % NFR], pf[qb][g], acc_o[qb][xb], 0, 0, 0);
-                    else sc[qb][xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % NFR], qf[qb][g - 4], (FIXEDM == 2 && g == 4) ? z : sc[qb][xb], 0, 0, 0);
+                    else sc[qb][xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % NFR], qf[qb][g - 4], sc[qb][xb], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (i + NFR < 16) ld(i + NFR);
@@ -618,9 +557,6 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
                     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
                     mx = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
                 }
-#ifdef TG_ABL_NOMAX          // timing-only ablation (wrong results): no row max
-                mx = 0.f;
-#endif
                 if (PRESCALED) {
                     if (__any(mx > RESCALE_THR)) {                       // rare: the row max grew by more than 2^THR
                         const float m_new = round_bf16(m[qb] + fmaxf(mx, 0.f));
@@ -661,11 +597,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
                     const int kb = ks >> 1, rb = (ks & 1) * 8;
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-#ifdef TG_ABL_NOEXP          // timing-only ablation (wrong results): a full-rate VALU op in place of the transcendental
-                        e[ks][i] = sc[qb][kb][rb + i] * 0.25f;
-#else
                         e[ks][i] = PRESCALED ? __builtin_amdgcn_exp2f(sc[qb][kb][rb + i]) : __builtin_amdgcn_exp2f(sc[qb][kb][rb + i] * p.scale_log2 - mq);
-#endif
                 }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
@@ -674,9 +606,6 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
                     for (int i = 0; i < 4; ++i) pk.u[i] = pack_bf16x2(e[ks][2 * i], e[ks][2 * i + 1]);
                     pf[qb][ks] = pk.v;
                 }
-#ifdef TG_ABL_NOSUM          // timing-only ablation (wrong results): no row sums
-                l[qb] += e[0][0];
-#else
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) ls2[ks] = f32x2{e[ks][0], e[ks][1]};
 #pragma unroll
@@ -685,7 +614,6 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
                     for (int ks = 0; ks < 4; ++ks) ls2[ks] += f32x2{e[ks][2 * i], e[ks][2 * i + 1]};
                 const f32x2 lsum = (ls2[0] + ls2[1]) + (ls2[2] + ls2[3]);
                 l[qb] += lsum[0] + lsum[1];
-#endif
             }
         };
 
@@ -701,22 +629,10 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         PP_BAR();
         if (grp == 1) {
             dma_pair(tb);
-            if (!(p.knob & 2)) PP_BAR();          // knob bit 1 (experiment): both groups IN phase (X together, then Y together)
-            if (p.knob & 1) __builtin_amdgcn_s_setprio(1);
+            PP_BAR();
         }
-        long long tc[4] = {0, 0, 0, 0}, c0 = 0, c1;
-#define PP_TICK(i)                                                    \
-    if (TIMING) {                                                     \
-        __builtin_amdgcn_sched_barrier(0);                            \
-        c1 = __builtin_amdgcn_s_memtime();                            \
-        tc[i] += c1 - c0;                                             \
-        c0 = c1;                                                      \
-        __builtin_amdgcn_sched_barrier(0);                            \
-    }
-        if (TIMING) c0 = __builtin_amdgcn_s_memtime();
         for (int t = tb; t < te; ++t) {
             // X(t): matrix segment
-            PP_TICK(3);
             if (grp == 0) dma_pair(t);
             // the matrix segment runs at raised priority: its MFMA / ds_read issue slots are few (one per ~32 cycles) but each one the
             // partner's VALU stream delays idles the matrix pipe; measured -4..6 % (7.52 vs 7.94 ms same box); prio 1: -2 %, prio 3 = 2
@@ -725,22 +641,16 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             __builtin_amdgcn_s_setprio(0);                         // (fencing this with sched_barrier(0) measured 2.5 % slower)
             if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t (issued one segment ago) has landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            PP_TICK(0);
             PP_BAR();
-            PP_TICK(1);
             // Y(t): vector segment
             if (grp == 1) dma_pair(t + 1);
             softmax();
             if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t has landed
-            PP_TICK(2);
             PP_BAR();
         }
-        if (TIMING && wgid == 0 && sg == 0 && (wave & 3) == 0 && lane == 0)
-            for (int i = 0; i < 4; ++i) tg_attn_dbg[grp * 4 + i] = tc[i];
-#undef PP_TICK
         pv(te - 1);                                                                // X(nt): last P.V
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (grp == 0 && !(p.knob & 2)) PP_BAR();                                   // barrier counts of the two groups meet again
+        if (grp == 0) PP_BAR();                                                    // barrier counts of the two groups meet again
         PP_BAR();                                                                  // all LDS reads of this segment done
 
         // ---- segment epilogue: O through LDS so that every global access is a whole 128-byte row of this head.  A lane owns ONE query
@@ -909,18 +819,13 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
     // k_prescaled: K rows already carry scale*log2(e) (written by tg_qk_layernorm_rope with out_scale), `scale` is then ignored
     p.prescaled = k_prescaled ? 1 : 0;
     p.scale_log2 = k_prescaled ? 1.0f : scale * 1.4426950408889634f;
-    static const int knob = [] { const char* e = getenv("TG_ATTN_KNOB"); return e ? atoi(e) : 0; }();
-    p.knob = knob;
-    // 256-row query tiles (2 query blocks per wave) once they still give >= 4 workgroups per CU, else 128-row tiles
+    // kernel choice by query-range length: the 8-wave ping-pong kernel from `pp_min` workgroups of 512 rows (4 per CU) on; below that the
+    // 4-wave kernel with 256-row tiles (2 query blocks per wave) while those still give >= 4 workgroups per CU, else 128-row tiles.
+    // Measured on MI355X at N = 17776: ping-pong 1.12-1.18 PFLOP/s, 256-row tiles 0.90, 128-row tiles 0.85.
     const long wg256 = (long)((nq + 255) / 256) * heads * batch;
-    // measured on MI355X at N=17776: 256-row tiles 900 TFLOP/s vs 128-row tiles 845; s_setprio around the MFMA clusters and an
-    // intra-wave S(t+1)/softmax(t) software pipeline both measured slower (885 / 781) and were dropped
-    static const int abl = [] { const char* e = getenv("TG_ATTN_ABLATE"); return e ? atoi(e) : 0; }();
-    static const int no_pp = [] { const char* e = getenv("TG_ATTN_NO_PP"); return e ? atoi(e) : 0; }();
-    static const long pp_min = [] { const char* e = getenv("TG_ATTN_PP_MIN_WG"); return e ? atol(e) : 1024L; }();   // tests lower it
+    static const long pp_min = [] { const char* e = getenv("TG_ATTN_PP_MIN_WG"); return e ? atol(e) : 1024L; }();   // the tests lower it
     const long wg512 = (long)((nq + 511) / 512) * heads * batch;
-    static const int timing = [] { const char* e = getenv("TG_ATTN_TIMING"); return e ? atoi(e) : 0; }();
-    const bool pp = wg512 >= pp_min && !abl && !no_pp;
+    const bool pp = wg512 >= pp_min;
     if (p.r_nq > 0 && !pp) {
         // the rider needs the ping-pong kernel: run it as a launch of its own through the ordinary dispatch
         AttnParams r{};
@@ -931,22 +836,19 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
         const int rc = attention_launch(p, scale, k_prescaled, who, stream);
         return rc ? rc : attention_launch(r, scale, k_prescaled, who, stream);
     }
-    // ---- ragged last query tile: every ping-pong workgroup takes the same time, so a launch of G workgroups costs ceil(G / CUs) rounds.
-    // When dropping the ragged last tile of every (head, batch) saves a round, those rows go to the 4-wave kernel in 128-row workgroups
-    // right behind the ping-pong launch (same stream): N = 17776 without a rider 7.69 -> 7.53 ms, the T2To stage's N = 9442 (19 -> 18
-    // tiles: 8 -> 7 rounds).  With a rider problem the riders already fill the last round, and the split loses (measured 8.0 vs 7.75 ms).
-    // Putting the small launch on a second (lower- or equal-priority) stream to pack the last round's idle CUs did NOT overlap here:
-    // two streams 7.62 ms vs 7.53 back to back.
-    static const int tail_split = [] { const char* e = getenv("TG_ATTN_TAIL"); return e ? atoi(e) : 1; }();
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
     }
+    // ---- ragged last query tile: every ping-pong workgroup takes the same time, so a launch of G workgroups costs ceil(G / CUs) rounds.
+    // When dropping the ragged last tile of every (head, batch) saves a round, those rows go to the 4-wave kernel in 128-row workgroups
+    // right behind the ping-pong launch (same stream): N = 17776 without a rider 7.69 -> 7.53 ms, the T2To stage's N = 9442 (19 -> 18
+    // tiles: 8 -> 7 rounds).  With a rider problem the riders already fill the last round, and the split loses (measured 8.0 vs 7.75 ms).
     const int full_rows = (nq / 512) * 512;
     const long wg_full = (long)(nq / 512) * heads * batch;
-    if (pp && tail_split && !timing && p.r_nq == 0 && full_rows < nq && wg_full >= pp_min && (wg_full + n_cu - 1) / n_cu < (wg512 + n_cu - 1) / n_cu) {
+    if (pp && p.r_nq == 0 && full_rows < nq && wg_full >= pp_min && (wg_full + n_cu - 1) / n_cu < (wg512 + n_cu - 1) / n_cu) {
         AttnParams m = p;                                   // the full 512-row tiles: ping-pong kernel
         m.nq = full_rows;
         const int rc = attention_launch(m, scale, k_prescaled, who, stream);
@@ -962,9 +864,9 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
         return TG_OK;
     }
     // constant-shift softmax (attn_fwd_pp_kernel<.., FIXEDM = 1>): every segment of a k_prescaled launch carries the key-norm bound and the
-    // caller gave a retry workspace.  TG_ATTN_FIXEDM=0 forces the running-max kernel (bench.py reports both).
+    // caller gave a retry workspace.  TG_ATTN_FIXEDM=0 forces the running-max kernel.
     static const int fixedm_on = [] { const char* e = getenv("TG_ATTN_FIXEDM"); return e ? atoi(e) : 1; }();
-    bool fixedm = fixedm_on && p.prescaled && pp && !timing && p.retry;
+    bool fixedm = fixedm_on && p.prescaled && pp && p.retry;
     for (int sg = 0; sg < p.nseg && fixedm; ++sg) fixedm = p.s[sg].kn2 != nullptr;
     if (fixedm && p.r_nq > 0) fixedm = p.r_s.kn2 != nullptr;
     p.main_wgs = (int)wg512;
@@ -981,10 +883,9 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
     static const int split_on = [] { const char* e = getenv("TG_ATTN_SPLIT"); return e ? atoi(e) : 1; }();
     p.nsplit = 0;
     p.split_first = (int)grid512;
-    if (pp && split_on && p.split_ws && !p.lse && !timing && grid512 > n_cu) {
+    if (pp && split_on && p.split_ws && !p.lse && grid512 > n_cu) {
         const long R = grid512 % n_cu;
-        const int nt_main = (p.s[0].nk + KVBLK - 1) / KVBLK, nt_rider = p.r_nq > 0 ? (p.r_s.nk + KVBLK - 1) / KVBLK : 2;
-        (void)nt_rider;
+        const int nt_main = (p.s[0].nk + KVBLK - 1) / KVBLK;
         if (R > 0 && 2 * R <= n_cu && R <= wg512 && nt_main >= 2 && p.split_ws_floats >= 2 * R * SPLIT_HALF_FLOATS) {
             p.nsplit = (int)R;
             p.split_first = (int)(wg512 - R);
@@ -993,66 +894,49 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
     // whole workgroups | halves of the split parents (rounded up to whole groups of 16 = 8 XCDs x 2 halves)
     const unsigned main_grid = (unsigned)(grid512 - p.nsplit), split_grid = (unsigned)(16 * ((p.nsplit + 7) / 8));
     constexpr size_t PP_LDS = 4 * TILE_B + 8 * 8192;
-    static const bool pp_attr = [] {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 1, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<true, false, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-        return true;
-    }();
-    (void)pp_attr;
-    if (timing && p.prescaled && wg512 >= pp_min) {
-        hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true>), dim3((unsigned)grid512), dim3(512), PP_LDS, stream, p);
-        long long h[8];
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(tg_attn_dbg), sizeof(h));
-        fprintf(stderr, "[tg_attention timing] g0: X %lld Xwait %lld Y %lld Ywait %lld | g1: X %lld Xwait %lld Y %lld Ywait %lld (s_memtime ticks, seg 0)\n",
-                h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
-    } else if (pp && fixedm) {
+    // launch one instantiation of the ping-pong kernel (96 KiB of dynamic LDS: the attribute is set once per instantiation)
+#define TG_PP(GRID, ...)                                                                                                            \
+    do {                                                                                                                            \
+        static const bool attr_ = [] {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                      4 * TILE_B + 8 * 8192);                                                                       \
+            return true;                                                                                                            \
+        }();                                                                                                                        \
+        (void)attr_;                                                                                                                \
+        hipLaunchKernelGGL((attn_fwd_pp_kernel<__VA_ARGS__>), dim3(GRID), dim3(512), PP_LDS, stream, p);                            \
+    } while (0)
+    if (pp && fixedm) {
         // the verified constant-shift pass, [the split tail and its join,] then the retry launch: a persistent grid that re-runs the flagged
         // workgroups (normally none)
         if (p.lse) {
-            hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1, true>), dim3(main_grid), dim3(512), PP_LDS, stream, p);
-            hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 0, true, true>), dim3(retry_grid), dim3(512), PP_LDS, stream, p);
+            TG_PP(main_grid, true, 1, true);
+            TG_PP(retry_grid, true, 0, true, true);
         } else {
-            hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1>), dim3(main_grid), dim3(512), PP_LDS, stream, p);
+            TG_PP(main_grid, true, 1);
             if (p.nsplit) {
-                hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 1, false, false, true>), dim3(split_grid), dim3(512), PP_LDS, stream, p);
+                TG_PP(split_grid, true, 1, false, false, true);
                 hipLaunchKernelGGL(attn_split_combine_kernel, dim3((unsigned)p.nsplit), dim3(256), 0, stream, p, 1);
             }
-            hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 0, false, true>), dim3(retry_grid), dim3(512), PP_LDS, stream, p);
+            TG_PP(retry_grid, true, 0, false, true);
         }
     } else if (pp) {
         if (p.lse) {
-            static bool attr_lse = false;
-            if (!attr_lse) {
-                (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-                attr_lse = true;
-            }
-            hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 0, true>), dim3(main_grid), dim3(512), PP_LDS, stream, p);
+            TG_PP(main_grid, false, 0, true);
         } else if (p.prescaled) {
-            hipLaunchKernelGGL(attn_fwd_pp_kernel<true>, dim3(main_grid), dim3(512), PP_LDS, stream, p);
-            if (p.nsplit) hipLaunchKernelGGL((attn_fwd_pp_kernel<true, false, 0, false, false, true>), dim3(split_grid), dim3(512), PP_LDS, stream, p);
+            TG_PP(main_grid, true);
+            if (p.nsplit) TG_PP(split_grid, true, 0, false, false, true);
         } else {
-            hipLaunchKernelGGL(attn_fwd_pp_kernel<false>, dim3(main_grid), dim3(512), PP_LDS, stream, p);
-            if (p.nsplit) hipLaunchKernelGGL((attn_fwd_pp_kernel<false, false, 0, false, false, true>), dim3(split_grid), dim3(512), PP_LDS, stream, p);
+            TG_PP(main_grid, false);
+            if (p.nsplit) TG_PP(split_grid, false, 0, false, false, true);
         }
         if (p.nsplit) hipLaunchKernelGGL(attn_split_combine_kernel, dim3((unsigned)p.nsplit), dim3(256), 0, stream, p, 0);
-    } else if (wg256 >= 1024 && abl) {
-        if (abl == 1) hipLaunchKernelGGL((attn_fwd_kernel<2, 1>), dim3((unsigned)wg256), dim3(256), 0, stream, p);
-        else if (abl == 2) hipLaunchKernelGGL((attn_fwd_kernel<2, 2>), dim3((unsigned)wg256), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((attn_fwd_kernel<2, 3>), dim3((unsigned)wg256), dim3(256), 0, stream, p);
     } else if (wg256 >= 1024) {
         hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)wg256), dim3(256), 0, stream, p);
     } else {
         const int nqt = (nq + 127) / 128;
         hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3((unsigned)(nqt * heads * batch)), dim3(256), 0, stream, p);
     }
+#undef TG_PP
     TG_LAUNCH_CHECK(who);
     return TG_OK;
 }

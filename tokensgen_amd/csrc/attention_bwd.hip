@@ -82,69 +82,6 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// (1) statistics: lse2[i] = log2(sum_j 2^(scale_log2 * q_i.k_j)),  D[i] = sum_d dO[i][d] * O[i][d]
-// ---------------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_stats_kernel(BwdParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    bf16_t* sQ = (bf16_t*)smem_raw;
-    bf16_t* sK = sQ + TILE_EL;
-    float* sM = (float*)(sK + TILE_EL);                 // [64 queries][4 partials] running max
-    float* sL = sM + 256;                               // ... and sum
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, hi = lane >> 5;
-    const int qb = wave >> 1, kb = wave & 1;
-    const int h = blockIdx.y % p.heads, b = blockIdx.y / p.heads;
-    const int q0 = blockIdx.x * TQ;
-    const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
-    const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
-    // D: 4 threads per query row, 16 head columns each
-    {
-        const int r = tid >> 2, c = (tid & 3) * 16;
-        float d = 0.f;
-        if (q0 + r < p.nq) {
-            const bf16_t* o = p.o + (long)b * p.o_sb + (long)(q0 + r) * p.o_ld + h * HD + c;
-            const bf16_t* g = p.dout + (long)b * p.do_sb + (long)(q0 + r) * p.do_ld + h * HD + c;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) d += bf16_to_f32(o[i]) * bf16_to_f32(g[i]);
-        }
-        d += __shfl_xor(d, 1, 64);
-        d += __shfl_xor(d, 2, 64);
-        if ((tid & 3) == 0 && q0 + r < p.nq) p.dsum[((long)b * p.heads + h) * p.nq + q0 + r] = d;
-    }
-    stage_tile(Q, p.q_ld, q0, p.nq, sQ);
-    float m = -1e30f, l = 0.f;                            // this lane's query (column j of block qb) over its share of the keys
-    for (int k0 = 0; k0 < p.nk; k0 += TK) {
-        __syncthreads();
-        stage_tile(Kp, p.k_ld, k0, p.nk, sK);
-        __syncthreads();
-        const f32x16 st = mma_nt(sK, kb * 32, sQ, qb * 32, zero16(), lane);        // S^T block: rows = keys, column = query j
-        float s[16], mx = -1e30f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = k0 + kb * 32 + acc_row(r, hi);
-            s[r] = key < p.nk ? st[r] * p.scale_log2 : -1e30f;
-            mx = fmaxf(mx, s[r]);
-        }
-        const float mn = fmaxf(m, mx);
-        float add = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) add += exp2f(s[r] - mn);
-        l = l * exp2f(m - mn) + add;
-        m = mn;
-    }
-    sM[(qb * 32 + j) * 4 + kb * 2 + hi] = m;
-    sL[(qb * 32 + j) * 4 + kb * 2 + hi] = l;
-    __syncthreads();
-    if (tid < TQ && q0 + tid < p.nq) {
-        const float* mm = sM + tid * 4;
-        const float* ll = sL + tid * 4;
-        const float M = fmaxf(fmaxf(mm[0], mm[1]), fmaxf(mm[2], mm[3]));
-        const float L = ll[0] * exp2f(mm[0] - M) + ll[1] * exp2f(mm[1] - M) + ll[2] * exp2f(mm[2] - M) + ll[3] * exp2f(mm[3] - M);
-        p.lse[((long)b * p.heads + h) * p.nq + q0 + tid] = M + log2f(L);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------
 // (2) dK, dV: one workgroup per 64-key tile
 // ---------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(BwdParams p) {
@@ -352,18 +289,23 @@ __device__ __forceinline__ uint32_t pack_bf16x2_trans(float lo, float hi) {
     asm("s_nop 1\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
-#ifndef TG_BWD_PK
-#define TG_BWD_PK 0   // packed fp32 arithmetic (v_pk_fma / add / mul) measured 3.5 % SLOWER beside the MFMAs than scalar fp32 (18.7 vs 19.3 ms)
-#endif
-#ifndef TG_BWD_PRIO
-#define TG_BWD_PRIO 0   // s_setprio 3 around the MFMA blocks: measured no gain (18.8 vs 18.6 ms)
-#endif
-#ifndef TG_BWD_ABL
-#define TG_BWD_ABL 0   // timing-only ablations of the dK/dV kernel (wrong results): 1 no softmax arithmetic, 2 no lse / D reads, 3 no dV / dK MFMAs,
-#endif                 // 4 no global fetch + LDS stage writes (tile 0 re-read), 5 no S | dP MFMAs
-#ifndef TG_BWD_INTERLEAVE
-#define TG_BWD_INTERLEAVE 1
-#endif
+// One (batch, head) per XCD at a time, as in the forward: a 1-D grid of nx * heads * batch workgroups, workgroup w runs on XCD w % 8 and takes
+// (head-batch index xcd + 8 * (slot / nx), block slot % nx) — the ~32 co-resident workgroups of an XCD then walk the SAME streamed tensor
+// (Q | dO for dK/dV, K | V for dQ) nearly in step and share it in that XCD's L2.  With the plain (block, head-batch) grid the 70 key blocks of a
+// head were dealt round-robin to all 8 XCDs and each XCD streamed the head's Q / dO on its own: 14.7 GB of L2 misses per dK/dV launch against
+// ~1.5 GB algorithmic (profiles/r2_attention_bwd_pmc.json).
+__device__ __forceinline__ void xcd_block(int nx, int nhb, int& blk, int& hb) {
+    const int w = blockIdx.x;
+    if ((nhb & 7) == 0) {
+        const int xcd = w & 7, slot = w >> 3;
+        hb = xcd + 8 * (slot / nx);
+        blk = slot % nx;
+    } else {
+        hb = w / nx;
+        blk = w % nx;
+    }
+}
+
 constexpr int BT = 32;                     // rows of the streamed tile
 constexpr int LQ2 = 72;                    // [row][d] tile: row stride in elements (144 B)
 constexpr int LT2 = 36;                    // [d][row] tile: row stride in elements (72 B = 18 banks: the 32 lanes of an 8-byte read — 32 head columns,
@@ -472,468 +414,21 @@ __global__ __launch_bounds__(256) void attn_bwd_stats2_kernel(BwdParams p) {
     }
 }
 
-// ---- (2') dK, dV: workgroup = 256 keys (64 per wave), queries streamed in tiles of 32 ----
-__global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(Bwd2Params pp) {
-    const BwdParams& p = pp.p;
-    __shared__ __attribute__((aligned(16))) bf16_t sQ[2][ROWT_EL], sdO[2][ROWT_EL], sQt[2][COLT_EL], sdOt[2][COLT_EL];
-    __shared__ __attribute__((aligned(16))) float sLse[2][BT], sD[2][BT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, hi = lane >> 5;
-    const int h = blockIdx.y % p.heads, b = blockIdx.y / p.heads;
-    const int kw0 = blockIdx.x * 256 + wave * 64;
-    const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
-    const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
-    const bf16_t* qT = pp.qT + ((long)(b * p.heads + h) * 64) * pp.ldq;
-    const bf16_t* doT = pp.doT + ((long)(b * p.heads + h) * 64) * pp.ldq;
-    const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
-    const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
-    const long stat0 = ((long)b * p.heads + h) * p.nq;
-    bf16x8 kf[2][4], vf[2][4];                             // B operands: this wave's keys, resident in AGPRs (rows past the end: clamped, never stored)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const long r = min(kw0 + kb * 32 + j, p.nk - 1);
-            load_frag_agpr(kf[kb][ks], Kp + r * p.k_ld + ks * 16 + hi * 8);
-            load_frag_agpr(vf[kb][ks], Vp + r * p.v_ld + ks * 16 + hi * 8);
-        }
-    TG_WAIT_FRAGS(kf);
-    TG_WAIT_FRAGS(vf);
-    f32x16 dk[2][2], dv[2][2];                             // [key block][d block]: rows = keys, column = head dim j
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) { dk[a][c] = zero16(); dv[a][c] = zero16(); }
-    const int row = tid >> 3, chunk = (tid & 7) * 8;       // [q][d] tiles: one 16-byte piece per thread
-    const int drow = tid >> 2, part = (tid & 3) * 8;       // [d][q] tiles
-    const int ntile = (p.nq + BT - 1) / BT;
-    uint4 g0, g1, g2, g3;
-    float gs = 0.f;
-    bool okr = false, oks = false;
-    const float* statp = (tid < BT ? p.lse : p.dsum) + stat0;      // threads 0..31 carry the tile's log-sum-exp, 32..63 its D (others: a harmless copy)
-    auto fetch = [&](int q0) {
-        okr = q0 + row < p.nq; oks = q0 + (tid & 31) < p.nq;
-        g0 = ld_row16_clamped(Q, p.q_ld, q0 + row, p.nq, chunk);
-        g1 = ld_row16_clamped(dO, p.do_ld, q0 + row, p.nq, chunk);
-        g2 = *(const uint4*)(qT + (long)drow * pp.ldq + q0 + part);
-        g3 = *(const uint4*)(doT + (long)drow * pp.ldq + q0 + part);
-        gs = statp[min(q0 + (tid & 31), p.nq - 1)];
-    };
-    float* const statdst = tid < BT ? &sLse[0][tid] : &sD[0][tid & 31];     // threads >= 64 write D[tid & 31] again with the same value
-    const float statmask = tid < BT ? 1e30f : 0.f;                          // masked query rows: P = exp2(s - 1e30) = 0, D = 0
-    auto stash_part = [&](int k, int buf) {                                 // branch-free pieces, placed between the last MFMAs of a tile
-        if (k == 0) *(uint4*)(sQ[buf] + row * LQ2 + chunk) = mask16(g0, okr);
-        if (k == 1) *(uint4*)(sdO[buf] + row * LQ2 + chunk) = mask16(g1, okr);
-        if (k == 2) st_2x8(sQt[buf] + drow * LT2 + part, g2);
-        if (k == 3) { st_2x8(sdOt[buf] + drow * LT2 + part, g3); statdst[buf * BT] = oks ? gs : statmask; }
-    };
-    auto stash = [&](int buf) { for (int k = 0; k < 4; ++k) stash_part(k, buf); };
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int it = 0; it < ntile; ++it) {
-        const int buf = TG_BWD_ABL == 4 ? 0 : it & 1;
-        if (TG_BWD_ABL != 4) fetch(min(it + 1, ntile - 1) * BT);      // unconditional (the last tile is fetched twice): no branch in the pinned schedule
-        bf16x8 aQ[4], aO[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            aQ[ks] = *(const bf16x8*)(sQ[buf] + j * LQ2 + ks * 16 + hi * 8);
-            aO[ks] = *(const bf16x8*)(sdO[buf] + j * LQ2 + ks * 16 + hi * 8);
-        }
-        TG_SB();                                           // these eight reads first: the S | dP MFMAs wait for them only (counted lgkmcnt)
-        f32x4 l4[4], d4[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (TG_BWD_ABL == 2) { l4[g] = f32x4{1.f, 2.f, 3.f, 4.f}; d4[g] = f32x4{.1f, .2f, .3f, .4f}; continue; }
-            l4[g] = *(const f32x4*)(sLse[buf] + 8 * g + 4 * hi);
-            d4[g] = *(const f32x4*)(sD[buf] + 8 * g + 4 * hi);
-        }
-        Frag bO[2][2], bQ[2][2];                           // [k-step t][d block]: B operands of the transposed products
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const int o = (db * 32 + j) * LT2 + 16 * t + 4 * hi;
-                bO[t][db].u[0] = *(const uint2*)(sdOt[buf] + o); bO[t][db].u[1] = *(const uint2*)(sdOt[buf] + o + 8);
-                bQ[t][db].u[0] = *(const uint2*)(sQt[buf] + o);  bQ[t][db].u[1] = *(const uint2*)(sQt[buf] + o + 8);
-            }
-        TG_SB();
-        // One wave per SIMD: the matrix pipe and the VALU only overlap if their instructions alternate in program order.  Schedule (pinned
-        // with sched_barrier): S|dP of key block 0;  softmax(0) chunk by chunk between the k-steps of S|dP of key block 1;  softmax(1) chunk by
-        // chunk between the dV / dK MFMAs of key block 0;  dV / dK of key block 1.
-        const f32x2 sc2 = {p.scale_log2, p.scale_log2};
-        auto softmax_chunk = [&](int g, const f32x16& sx, const f32x16& dx, Frag (&pA)[2], Frag (&dA)[2]) {
-            if (TG_BWD_ABL == 1) {
-                pA[g >> 1].w[(g & 1) * 2] = __float_as_uint(sx[4 * g]); pA[g >> 1].w[(g & 1) * 2 + 1] = __float_as_uint(sx[4 * g + 2]);
-                dA[g >> 1].w[(g & 1) * 2] = __float_as_uint(dx[4 * g]); dA[g >> 1].w[(g & 1) * 2 + 1] = __float_as_uint(dx[4 * g + 2]);
-                return;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {               // two elements per VALU instruction (v_pk_fma / v_pk_add / v_pk_mul)
-                const f32x2 sv = {sx[4 * g + e], sx[4 * g + e + 1]}, dpv = {dx[4 * g + e], dx[4 * g + e + 1]};
-                const f32x2 lv = {l4[g][e], l4[g][e + 1]}, dv2 = {d4[g][e], d4[g][e + 1]};
-#if TG_BWD_PK
-                const f32x2 arg = sv * sc2 - lv;
-                const f32x2 pv = {fast_exp2(arg[0]), fast_exp2(arg[1])};
-                const f32x2 ds = pv * (dpv - dv2);
-#else
-                const f32x2 pv = {fast_exp2(sv[0] * p.scale_log2 - lv[0]), fast_exp2(sv[1] * p.scale_log2 - lv[1])};
-                const f32x2 ds = {pv[0] * (dpv[0] - dv2[0]), pv[1] * (dpv[1] - dv2[1])};
-#endif
-                pA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2_trans(pv[0], pv[1]);
-                dA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2(ds[0], ds[1]);
-            }
-        };
-        f32x16 s0, dp0, s1, dp1;
-        Frag pA0[2], dA0[2], pA1[2], dA1[2];
-#if !TG_BWD_INTERLEAVE
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            mfma_pair(s0, dp0, aQ, aO, kf[kb], vf[kb]);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) softmax_chunk(g, s0, dp0, pA0, dA0);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    mfma_acc(dv[kb][db], pA0[t].v, bO[t][db].v);
-                    mfma_acc(dk[kb][db], dA0[t].v, bQ[t][db].v);
-                }
-        }
-        if (TG_BWD_ABL != 4) stash(buf ^ 1);
-#else
-        mfma_pair(s0, dp0, aQ, aO, kf[0], vf[0]);
-        TG_SB();
-        softmax_chunk(0, s0, dp0, pA0, dA0); TG_SB();
-        mfma_pair_step<true, false>(s1, dp1, aQ[0], aO[0], kf[1][0], vf[1][0]); TG_SB();
-        softmax_chunk(1, s0, dp0, pA0, dA0); TG_SB();
-        mfma_pair_step<false, false>(s1, dp1, aQ[1], aO[1], kf[1][1], vf[1][1]); TG_SB();
-        softmax_chunk(2, s0, dp0, pA0, dA0); TG_SB();
-        mfma_pair_step<false, false>(s1, dp1, aQ[2], aO[2], kf[1][2], vf[1][2]); TG_SB();
-        softmax_chunk(3, s0, dp0, pA0, dA0); TG_SB();
-        mfma_pair_step<false, true>(s1, dp1, aQ[3], aO[3], kf[1][3], vf[1][3]); TG_SB();
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {                       // chunk g of key block 1, then the (k-step g/2, d block g%2) products of key block 0
-            softmax_chunk(g, s1, dp1, pA1, dA1); TG_SB();
-            if (TG_BWD_ABL != 3) {
-                mfma_acc(dv[0][g & 1], pA0[g >> 1].v, bO[g >> 1][g & 1].v);
-                mfma_acc(dk[0][g & 1], dA0[g >> 1].v, bQ[g >> 1][g & 1].v);
-            } else asm volatile("" :: "v"(pA0[g >> 1].v), "v"(dA0[g >> 1].v), "v"(bO[g >> 1][g & 1].v), "v"(bQ[g >> 1][g & 1].v));
-            TG_SB();
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {                // the next tile's LDS stage is written under these last eight MFMAs (buffer buf^1 has had
-                if (TG_BWD_ABL != 3) {                      // no reader since the barrier that ended the previous tile)
-                    mfma_acc(dv[1][db], pA1[t].v, bO[t][db].v);
-                    mfma_acc(dk[1][db], dA1[t].v, bQ[t][db].v);
-                } else asm volatile("" :: "v"(pA1[t].v), "v"(dA1[t].v), "v"(bO[t][db].v), "v"(bQ[t][db].v));
-                TG_SB();
-                if (TG_BWD_ABL != 4) stash_part(t * 2 + db, buf ^ 1);
-                TG_SB();
-            }
-#endif
-        __syncthreads();
-    }
-    asm volatile("s_nop 15" ::: "memory");             // last asm MFMA's D -> the reads below (8-pass XDL: 12 wait states)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-            float* DK = p.dk + (long)b * p.dk_sb + h * HD + db * 32 + j;
-            float* DV = p.dv + (long)b * p.dv_sb + h * HD + db * 32 + j;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kw0 + kb * 32 + acc_row(r, hi);
-                if (key >= p.nk) continue;
-                float* a = DK + (long)key * p.dk_ld;
-                float* c = DV + (long)key * p.dv_ld;
-                const float vk = dk[kb][db][r] * p.scale, vv = dv[kb][db][r];
-                *a = (p.accumulate & 2) ? *a + vk : vk;
-                *c = (p.accumulate & 2) ? *c + vv : vv;
-            }
-        }
-}
-
-// ---- (2'') dK, dV with TWO waves per SIMD: workgroup = 128 keys (32 per wave), two workgroups per CU ----
-// Same data path as (2'), half the keys per wave: 96 AGPRs (K | V fragments + the 64 accumulators) + ~150 VGPRs fit the 256 registers two
-// co-resident waves may use, so one wave's softmax runs under the other's MFMAs without any hand-placed interleaving.  The price is LDS
-// traffic: every wave still reads the whole Q / dO tile pair, now for 16 MFMAs instead of 32.
 #define TG_WAIT_FRAGS1(f) asm volatile("s_waitcnt vmcnt(0)" : "+a"(f[0]), "+a"(f[1]), "+a"(f[2]), "+a"(f[3]))
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv3_kernel(Bwd2Params pp) {
-    const BwdParams& p = pp.p;
-    __shared__ __attribute__((aligned(16))) bf16_t sQ[2][ROWT_EL], sdO[2][ROWT_EL], sQt[2][COLT_EL], sdOt[2][COLT_EL];
-    __shared__ __attribute__((aligned(16))) float sLse[2][BT], sD[2][BT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, hi = lane >> 5;
-    const int h = blockIdx.y % p.heads, b = blockIdx.y / p.heads;
-    const int kw0 = blockIdx.x * 128 + wave * 32;
-    const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
-    const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
-    const bf16_t* qT = pp.qT + ((long)(b * p.heads + h) * 64) * pp.ldq;
-    const bf16_t* doT = pp.doT + ((long)(b * p.heads + h) * 64) * pp.ldq;
-    const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
-    const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
-    const long stat0 = ((long)b * p.heads + h) * p.nq;
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const long r = min(kw0 + j, p.nk - 1);
-        load_frag_agpr(kf[ks], Kp + r * p.k_ld + ks * 16 + hi * 8);
-        load_frag_agpr(vf[ks], Vp + r * p.v_ld + ks * 16 + hi * 8);
-    }
-    TG_WAIT_FRAGS1(kf);
-    TG_WAIT_FRAGS1(vf);
-    f32x16 dk[2], dv[2];                                   // [d block]: rows = keys, column = head dim j
-#pragma unroll
-    for (int c = 0; c < 2; ++c) { dk[c] = zero16(); dv[c] = zero16(); }
-    const int row = tid >> 3, chunk = (tid & 7) * 8;
-    const int drow = tid >> 2, part = (tid & 3) * 8;
-    const int ntile = (p.nq + BT - 1) / BT;
-    uint4 g0, g1, g2, g3;
-    float gs = 0.f;
-    bool okr = false, oks = false;
-    const float* statp = (tid < BT ? p.lse : p.dsum) + stat0;
-    float* const statdst = tid < BT ? &sLse[0][tid] : &sD[0][tid & 31];
-    const float statmask = tid < BT ? 1e30f : 0.f;
-    auto fetch = [&](int q0) {
-        okr = q0 + row < p.nq; oks = q0 + (tid & 31) < p.nq;
-        g0 = ld_row16_clamped(Q, p.q_ld, q0 + row, p.nq, chunk);
-        g1 = ld_row16_clamped(dO, p.do_ld, q0 + row, p.nq, chunk);
-        g2 = *(const uint4*)(qT + (long)drow * pp.ldq + q0 + part);
-        g3 = *(const uint4*)(doT + (long)drow * pp.ldq + q0 + part);
-        gs = statp[min(q0 + (tid & 31), p.nq - 1)];
-    };
-    auto stash = [&](int buf) {
-        *(uint4*)(sQ[buf] + row * LQ2 + chunk) = mask16(g0, okr);
-        *(uint4*)(sdO[buf] + row * LQ2 + chunk) = mask16(g1, okr);
-        st_2x8(sQt[buf] + drow * LT2 + part, g2);
-        st_2x8(sdOt[buf] + drow * LT2 + part, g3);
-        statdst[buf * BT] = oks ? gs : statmask;
-    };
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    const f32x2 sc2 = {p.scale_log2, p.scale_log2};
-    for (int it = 0; it < ntile; ++it) {
-        const int buf = it & 1;
-        fetch(min(it + 1, ntile - 1) * BT);
-        bf16x8 aQ[4], aO[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            aQ[ks] = *(const bf16x8*)(sQ[buf] + j * LQ2 + ks * 16 + hi * 8);
-            aO[ks] = *(const bf16x8*)(sdO[buf] + j * LQ2 + ks * 16 + hi * 8);
-        }
-        TG_SB();
-        f32x16 s, dp;                                      // rows = queries, column = key j
-        mfma_pair(s, dp, aQ, aO, kf, vf);
-        Frag pA[2], dA[2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 l4 = *(const f32x4*)(sLse[buf] + 8 * g + 4 * hi), d4 = *(const f32x4*)(sD[buf] + 8 * g + 4 * hi);
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-                const f32x2 sv = {s[4 * g + e], s[4 * g + e + 1]}, dpv = {dp[4 * g + e], dp[4 * g + e + 1]};
-                const f32x2 lv = {l4[e], l4[e + 1]}, dv2 = {d4[e], d4[e + 1]};
-#if TG_BWD_PK
-                const f32x2 arg = sv * sc2 - lv;
-                const f32x2 pv = {fast_exp2(arg[0]), fast_exp2(arg[1])};
-                const f32x2 ds = pv * (dpv - dv2);
-#else
-                const f32x2 pv = {fast_exp2(sv[0] * p.scale_log2 - lv[0]), fast_exp2(sv[1] * p.scale_log2 - lv[1])};
-                const f32x2 ds = {pv[0] * (dpv[0] - dv2[0]), pv[1] * (dpv[1] - dv2[1])};
-#endif
-                pA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2_trans(pv[0], pv[1]);
-                dA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2(ds[0], ds[1]);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const int o = (db * 32 + j) * LT2 + 16 * t + 4 * hi;
-                Frag bO, bQ;
-                bO.u[0] = *(const uint2*)(sdOt[buf] + o); bO.u[1] = *(const uint2*)(sdOt[buf] + o + 8);
-                bQ.u[0] = *(const uint2*)(sQt[buf] + o);  bQ.u[1] = *(const uint2*)(sQt[buf] + o + 8);
-                mfma_acc(dv[db], pA[t].v, bO.v);
-                mfma_acc(dk[db], dA[t].v, bQ.v);
-            }
-        stash(buf ^ 1);
-        __syncthreads();
-    }
-    asm volatile("s_nop 15" ::: "memory");
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-        float* DK = p.dk + (long)b * p.dk_sb + h * HD + db * 32 + j;
-        float* DV = p.dv + (long)b * p.dv_sb + h * HD + db * 32 + j;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kw0 + acc_row(r, hi);
-            if (key >= p.nk) continue;
-            float* a = DK + (long)key * p.dk_ld;
-            float* c = DV + (long)key * p.dv_ld;
-            const float vk = dk[db][r] * p.scale, vv = dv[db][r];
-            *a = (p.accumulate & 2) ? *a + vk : vk;
-            *c = (p.accumulate & 2) ? *c + vv : vv;
-        }
-    }
-}
-
-// ---- (2''') as (2''), with a three-deep LDS ring: tile i+2 is staged while tile i is consumed, so tile i+1's A operands can be read into
-// registers DURING tile i (their latency used to sit exposed behind every barrier: all four waves read 32 KB at once and wait) ----
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv4_kernel(Bwd2Params pp) {
-    const BwdParams& p = pp.p;
-    __shared__ __attribute__((aligned(16))) bf16_t sQ[3][ROWT_EL], sdO[3][ROWT_EL], sQt[3][COLT_EL], sdOt[3][COLT_EL];
-    __shared__ __attribute__((aligned(16))) float sLse[3][BT], sD[3][BT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, hi = lane >> 5;
-    const int h = blockIdx.y % p.heads, b = blockIdx.y / p.heads;
-    const int kw0 = blockIdx.x * 128 + wave * 32;
-    const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
-    const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
-    const bf16_t* qT = pp.qT + ((long)(b * p.heads + h) * 64) * pp.ldq;
-    const bf16_t* doT = pp.doT + ((long)(b * p.heads + h) * 64) * pp.ldq;
-    const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
-    const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
-    const long stat0 = ((long)b * p.heads + h) * p.nq;
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const long r = min(kw0 + j, p.nk - 1);
-        load_frag_agpr(kf[ks], Kp + r * p.k_ld + ks * 16 + hi * 8);
-        load_frag_agpr(vf[ks], Vp + r * p.v_ld + ks * 16 + hi * 8);
-    }
-    TG_WAIT_FRAGS1(kf);
-    TG_WAIT_FRAGS1(vf);
-    f32x16 dk[2], dv[2];                                   // [d block]: rows = keys, column = head dim j
-#pragma unroll
-    for (int c = 0; c < 2; ++c) { dk[c] = zero16(); dv[c] = zero16(); }
-    const int row = tid >> 3, chunk = (tid & 7) * 8;
-    const int drow = tid >> 2, part = (tid & 3) * 8;
-    const int ntile = (p.nq + BT - 1) / BT;
-    uint4 g0, g1, g2, g3;
-    float gs = 0.f;
-    bool okr = false, oks = false;
-    const float* statp = (tid < BT ? p.lse : p.dsum) + stat0;
-    float* const statdst = tid < BT ? &sLse[0][tid] : &sD[0][tid & 31];
-    const float statmask = tid < BT ? 1e30f : 0.f;
-    auto fetch = [&](int q0) {
-        okr = q0 + row < p.nq; oks = q0 + (tid & 31) < p.nq;
-        g0 = ld_row16_clamped(Q, p.q_ld, q0 + row, p.nq, chunk);
-        g1 = ld_row16_clamped(dO, p.do_ld, q0 + row, p.nq, chunk);
-        g2 = *(const uint4*)(qT + (long)drow * pp.ldq + q0 + part);
-        g3 = *(const uint4*)(doT + (long)drow * pp.ldq + q0 + part);
-        gs = statp[min(q0 + (tid & 31), p.nq - 1)];
-    };
-    auto stash = [&](int buf) {
-        *(uint4*)(sQ[buf] + row * LQ2 + chunk) = mask16(g0, okr);
-        *(uint4*)(sdO[buf] + row * LQ2 + chunk) = mask16(g1, okr);
-        st_2x8(sQt[buf] + drow * LT2 + part, g2);
-        st_2x8(sdOt[buf] + drow * LT2 + part, g3);
-        statdst[buf * BT] = oks ? gs : statmask;
-    };
-    fetch(0);
-    stash(0);
-    fetch(min(1, ntile - 1) * BT);
-    stash(1);
-    __syncthreads();
-    const f32x2 sc2 = {p.scale_log2, p.scale_log2};
-    (void)sc2;
-    bf16x8 aQ[4], aO[4];                                   // A operands of the CURRENT tile: read from LDS one tile ahead (below)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        aQ[ks] = *(const bf16x8*)(sQ[0] + j * LQ2 + ks * 16 + hi * 8);
-        aO[ks] = *(const bf16x8*)(sdO[0] + j * LQ2 + ks * 16 + hi * 8);
-    }
-    int buf = 0;
-    for (int it = 0; it < ntile; ++it) {
-        const int nbuf = buf == 2 ? 0 : buf + 1, sbuf = nbuf == 2 ? 0 : nbuf + 1;     // tile it+1 (staged last iteration), tile it+2 (staged now)
-        fetch(min(it + 2, ntile - 1) * BT);
-        f32x16 s, dp;                                      // rows = queries, column = key j
-        if (TG_BWD_PRIO) __builtin_amdgcn_s_setprio(3);    // a wave in an MFMA block wins the issue port: the partner's softmax fills what is left
-        mfma_pair(s, dp, aQ, aO, kf, vf);
-        if (TG_BWD_PRIO) __builtin_amdgcn_s_setprio(0);
-        TG_SB();
-        bf16x8 nQ[4], nO[4];                               // next tile's A operands: their LDS latency hides under this tile's softmax + MFMAs
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            nQ[ks] = *(const bf16x8*)(sQ[nbuf] + j * LQ2 + ks * 16 + hi * 8);
-            nO[ks] = *(const bf16x8*)(sdO[nbuf] + j * LQ2 + ks * 16 + hi * 8);
-        }
-        TG_SB();
-        Frag pA[2], dA[2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 l4 = *(const f32x4*)(sLse[buf] + 8 * g + 4 * hi), d4 = *(const f32x4*)(sD[buf] + 8 * g + 4 * hi);
-            if (TG_BWD_ABL == 1) {
-                pA[g >> 1].w[(g & 1) * 2] = __float_as_uint(s[4 * g] + l4[0]); pA[g >> 1].w[(g & 1) * 2 + 1] = __float_as_uint(s[4 * g + 2]);
-                dA[g >> 1].w[(g & 1) * 2] = __float_as_uint(dp[4 * g] + d4[0]); dA[g >> 1].w[(g & 1) * 2 + 1] = __float_as_uint(dp[4 * g + 2]);
-                continue;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-                const f32x2 pv = {fast_exp2(s[4 * g + e] * p.scale_log2 - l4[e]), fast_exp2(s[4 * g + e + 1] * p.scale_log2 - l4[e + 1])};
-                const f32x2 ds = {pv[0] * (dp[4 * g + e] - d4[e]), pv[1] * (dp[4 * g + e + 1] - d4[e + 1])};
-                pA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2_trans(pv[0], pv[1]);
-                dA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2(ds[0], ds[1]);
-            }
-        }
-        Frag bO[2][2], bQ[2][2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const int o = (db * 32 + j) * LT2 + 16 * t + 4 * hi;
-                bO[t][db].u[0] = *(const uint2*)(sdOt[buf] + o); bO[t][db].u[1] = *(const uint2*)(sdOt[buf] + o + 8);
-                bQ[t][db].u[0] = *(const uint2*)(sQt[buf] + o);  bQ[t][db].u[1] = *(const uint2*)(sQt[buf] + o + 8);
-            }
-        TG_SB();
-        if (TG_BWD_PRIO) __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                if (TG_BWD_ABL == 3) { asm volatile("" :: "v"(pA[t].v), "v"(dA[t].v), "v"(bO[t][db].v), "v"(bQ[t][db].v)); continue; }
-                mfma_acc(dv[db], pA[t].v, bO[t][db].v);
-                mfma_acc(dk[db], dA[t].v, bQ[t][db].v);
-            }
-        if (TG_BWD_PRIO) __builtin_amdgcn_s_setprio(0);
-        TG_SB();
-        stash(sbuf);                                       // buffer of tile it-1: no reader since the barrier that ended the previous iteration
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { aQ[ks] = nQ[ks]; aO[ks] = nO[ks]; }
-        buf = nbuf;
-    }
-    asm volatile("s_nop 15" ::: "memory");
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-        float* DK = p.dk + (long)b * p.dk_sb + h * HD + db * 32 + j;
-        float* DV = p.dv + (long)b * p.dv_sb + h * HD + db * 32 + j;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kw0 + acc_row(r, hi);
-            if (key >= p.nk) continue;
-            float* a = DK + (long)key * p.dk_ld;
-            float* c = DV + (long)key * p.dv_ld;
-            const float vk = dk[db][r] * p.scale, vv = dv[db][r];
-            *a = (p.accumulate & 2) ? *a + vk : vk;
-            *c = (p.accumulate & 2) ? *c + vv : vv;
-        }
-    }
-}
-
-// ---- (2'''') the same with ONE 512-thread workgroup per CU (8 waves x 32 keys = 256 keys): the two waves of a SIMD now share one tile stage, which
-// halves the global bytes per MFMA — with two 4-wave workgroups per CU the kernel sat at the ~11 B/clk/CU every CU gets when all 256 stream at once ----
+// ---- (2') dK, dV: ONE 512-thread workgroup per CU (8 waves x 32 keys = 256 keys), queries streamed in tiles of 32 through a three-deep LDS ring
+// (tile i+2 is staged while tile i is consumed; tile i+1's A operands are read one tile ahead).  The two waves of a SIMD share one tile stage, which
+// halves the global bytes per MFMA against two 4-wave workgroups per CU.  Structures tried and measured within 3 % of this one: 64 keys
+// per wave with one wave per SIMD and a hand-interleaved schedule, two 4-wave workgroups per CU, a two-deep ring, a two-group ping-pong (5 % slower). ----
 __global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
     const BwdParams& p = pp.p;
     __shared__ __attribute__((aligned(16))) bf16_t sQ[3][ROWT_EL], sdO[3][ROWT_EL], sQt[3][COLT_EL], sdOt[3][COLT_EL];
     __shared__ __attribute__((aligned(16))) float sLse[3][BT], sD[3][BT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hi = lane >> 5;
-    const int h = blockIdx.y % p.heads, b = blockIdx.y / p.heads;
-    const int kw0 = blockIdx.x * 256 + wave * 32;
+    int blk, hb;
+    xcd_block((p.nk + 255) / 256, p.heads * p.batch, blk, hb);
+    const int h = hb % p.heads, b = hb / p.heads;
+    const int kw0 = blk * 256 + wave * 32;
     const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
     const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
     const bf16_t* qT = pp.qT + ((long)(b * p.heads + h) * 64) * pp.ldq;
@@ -982,8 +477,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
     fetch(min(1, ntile - 1) * BT);
     stash(1);
     __syncthreads();
-    const f32x2 sc2 = {p.scale_log2, p.scale_log2};
-    (void)sc2;
     bf16x8 aQ[4], aO[4];                                   // A operands of the CURRENT tile: read from LDS one tile ahead (below)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -993,19 +486,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
     int buf = 0;
     for (int it = 0; it < ntile; ++it) {
         const int nbuf = buf == 2 ? 0 : buf + 1, sbuf = nbuf == 2 ? 0 : nbuf + 1;     // tile it+1 (staged last iteration), tile it+2 (staged now)
-        if (TG_BWD_ABL != 7) fetch(min(it + 2, ntile - 1) * BT);
+        fetch(min(it + 2, ntile - 1) * BT);
         f32x16 s, dp;                                      // rows = queries, column = key j
-        if (TG_BWD_PRIO) __builtin_amdgcn_s_setprio(3);    // a wave in an MFMA block wins the issue port: the partner's softmax fills what is left
-        if (TG_BWD_ABL == 8) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = __uint_as_float(((const uint32_t*)&aQ[r & 3])[r >> 2]); dp[r] = __uint_as_float(((const uint32_t*)&aO[r & 3])[r >> 2]); }
-        } else mfma_pair(s, dp, aQ, aO, kf, vf);
-        if (TG_BWD_PRIO) __builtin_amdgcn_s_setprio(0);
+        mfma_pair(s, dp, aQ, aO, kf, vf);
         TG_SB();
         bf16x8 nQ[4], nO[4];                               // next tile's A operands: their LDS latency hides under this tile's softmax + MFMAs
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (TG_BWD_ABL == 6) { nQ[ks] = aQ[ks]; nO[ks] = aO[ks]; continue; }
             nQ[ks] = *(const bf16x8*)(sQ[nbuf] + j * LQ2 + ks * 16 + hi * 8);
             nO[ks] = *(const bf16x8*)(sdO[nbuf] + j * LQ2 + ks * 16 + hi * 8);
         }
@@ -1013,13 +500,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
         Frag pA[2], dA[2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 l4 = TG_BWD_ABL == 6 ? f32x4{1.f, 2.f, 3.f, 4.f} : *(const f32x4*)(sLse[buf] + 8 * g + 4 * hi);
-            const f32x4 d4 = TG_BWD_ABL == 6 ? f32x4{.1f, .2f, .3f, .4f} : *(const f32x4*)(sD[buf] + 8 * g + 4 * hi);
-            if (TG_BWD_ABL == 1) {
-                pA[g >> 1].w[(g & 1) * 2] = __float_as_uint(s[4 * g] + l4[0]); pA[g >> 1].w[(g & 1) * 2 + 1] = __float_as_uint(s[4 * g + 2]);
-                dA[g >> 1].w[(g & 1) * 2] = __float_as_uint(dp[4 * g] + d4[0]); dA[g >> 1].w[(g & 1) * 2 + 1] = __float_as_uint(dp[4 * g + 2]);
-                continue;
-            }
+            const f32x4 l4 = *(const f32x4*)(sLse[buf] + 8 * g + 4 * hi);
+            const f32x4 d4 = *(const f32x4*)(sD[buf] + 8 * g + 4 * hi);
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {
                 const f32x2 pv = {fast_exp2(s[4 * g + e] * p.scale_log2 - l4[e]), fast_exp2(s[4 * g + e + 1] * p.scale_log2 - l4[e + 1])};
@@ -1034,178 +516,24 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 const int o = (db * 32 + j) * LT2 + 16 * t + 4 * hi;
-                if (TG_BWD_ABL == 6) { bO[t][db].v = aQ[t * 2 + db]; bQ[t][db].v = aO[t * 2 + db]; continue; }
                 bO[t][db].u[0] = *(const uint2*)(sdOt[buf] + o); bO[t][db].u[1] = *(const uint2*)(sdOt[buf] + o + 8);
                 bQ[t][db].u[0] = *(const uint2*)(sQt[buf] + o);  bQ[t][db].u[1] = *(const uint2*)(sQt[buf] + o + 8);
             }
         TG_SB();
-        if (TG_BWD_PRIO) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                if (TG_BWD_ABL == 3 || TG_BWD_ABL == 8) { asm volatile("" :: "v"(pA[t].v), "v"(dA[t].v), "v"(bO[t][db].v), "v"(bQ[t][db].v)); continue; }
                 mfma_acc(dv[db], pA[t].v, bO[t][db].v);
                 mfma_acc(dk[db], dA[t].v, bQ[t][db].v);
             }
-        if (TG_BWD_PRIO) __builtin_amdgcn_s_setprio(0);
         TG_SB();
-        if (TG_BWD_ABL != 7) stash(sbuf);                  // buffer of tile it-1: no reader since the barrier that ended the previous iteration
+        stash(sbuf);                  // buffer of tile it-1: no reader since the barrier that ended the previous iteration
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) { aQ[ks] = nQ[ks]; aO[ks] = nO[ks]; }
         buf = nbuf;
     }
-    asm volatile("s_nop 15" ::: "memory");
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-        float* DK = p.dk + (long)b * p.dk_sb + h * HD + db * 32 + j;
-        float* DV = p.dv + (long)b * p.dv_sb + h * HD + db * 32 + j;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kw0 + acc_row(r, hi);
-            if (key >= p.nk) continue;
-            float* a = DK + (long)key * p.dk_ld;
-            float* c = DV + (long)key * p.dv_ld;
-            const float vk = dk[db][r] * p.scale, vv = dv[db][r];
-            *a = (p.accumulate & 2) ? *a + vk : vk;
-            *c = (p.accumulate & 2) ? *c + vv : vv;
-        }
-    }
-}
-
-// ---- (2-pp) ping-pong: the two waves of a SIMD in ANTI-phase (TG_ATTN_BWD_DKDV=6; measured 5 % SLOWER than the in-phase kernel: 19.7 vs 18.6 ms) ----
-// The 8-wave kernel above runs its two waves per SIMD through the same instruction stream behind the same barrier: both are in their MFMA block,
-// then both in their softmax, and the counters show the matrix and the vector pipe taking turns (MFMA busy 37 %).  Here the waves form two groups
-// (waves 0-3 / 4-7: one of each per SIMD) whose tile is cut into a matrix segment X(i) = dV/dK products of tile i-1 + S|dP of tile i, and a vector
-// segment Y(i) = softmax of tile i + every LDS read (B operands of tile i, A operands of tile i+1) + the stage writes of tile i+2, with a barrier
-// after each; group 1 runs one barrier behind, so X of one group always lies beside Y of the other (the structure of attn_fwd_pp_kernel).
-// Three-deep LDS ring: tile i is read in the Y segments of steps i-1 and i of both groups (four half-steps), tile i+2 is written in Y(i).
-// The barrier is a bare s_barrier behind lgkmcnt(0): __syncthreads() also waits for the global prefetch issued just before it.
-#define TG_BAR_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-__global__ __launch_bounds__(512) void attn_bwd_dkdv6_kernel(Bwd2Params pp) {
-    const BwdParams& p = pp.p;
-    __shared__ __attribute__((aligned(16))) bf16_t sQ[3][ROWT_EL], sdO[3][ROWT_EL], sQt[3][COLT_EL], sdOt[3][COLT_EL];
-    __shared__ __attribute__((aligned(16))) float sLse[3][BT], sD[3][BT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;
-    const int j = lane & 31, hi = lane >> 5;
-    const int h = blockIdx.y % p.heads, b = blockIdx.y / p.heads;
-    const int kw0 = blockIdx.x * 256 + wave * 32;
-    const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
-    const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
-    const bf16_t* qT = pp.qT + ((long)(b * p.heads + h) * 64) * pp.ldq;
-    const bf16_t* doT = pp.doT + ((long)(b * p.heads + h) * 64) * pp.ldq;
-    const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
-    const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
-    const long stat0 = ((long)b * p.heads + h) * p.nq;
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const long r = min(kw0 + j, p.nk - 1);
-        load_frag_agpr(kf[ks], Kp + r * p.k_ld + ks * 16 + hi * 8);
-        load_frag_agpr(vf[ks], Vp + r * p.v_ld + ks * 16 + hi * 8);
-    }
-    TG_WAIT_FRAGS1(kf);
-    TG_WAIT_FRAGS1(vf);
-    f32x16 dk[2], dv[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) { dk[c] = zero16(); dv[c] = zero16(); }
-    const int half = tid >> 8, t8 = tid & 255;              // group 0's threads stage Q and Q^T, group 1's dO and dO^T
-    const int row = t8 >> 3, chunk = (t8 & 7) * 8;
-    const int drow = t8 >> 2, part = (t8 & 3) * 8;
-    const bf16_t* const srcR = half ? dO : Q;
-    const bf16_t* const srcT = half ? doT : qT;
-    const long ldR = half ? p.do_ld : p.q_ld;
-    const int ntile = (p.nq + BT - 1) / BT;
-    uint4 g0, g2;
-    float gs = 0.f;
-    bool okr = false, oks = false;
-    const float* statp = (tid < BT ? p.lse : p.dsum) + stat0;
-    float* const statdst = tid < BT ? &sLse[0][tid] : &sD[0][tid & 31];
-    const float statmask = tid < BT ? 1e30f : 0.f;
-    auto fetch = [&](int q0) {
-        okr = q0 + row < p.nq; oks = q0 + (tid & 31) < p.nq;
-        g0 = ld_row16_clamped(srcR, ldR, q0 + row, p.nq, chunk);
-        g2 = *(const uint4*)(srcT + (long)drow * pp.ldq + q0 + part);
-        gs = statp[min(q0 + (tid & 31), p.nq - 1)];
-    };
-    auto stash = [&](int buf) {
-        *(uint4*)((half ? sdO[buf] : sQ[buf]) + row * LQ2 + chunk) = mask16(g0, okr);
-        st_2x8((half ? sdOt[buf] : sQt[buf]) + drow * LT2 + part, g2);
-        if (tid < 2 * BT) statdst[buf * BT] = oks ? gs : statmask;
-    };
-    fetch(0);
-    stash(0);
-    fetch(min(1, ntile - 1) * BT);
-    stash(1);
-    __syncthreads();
-    bf16x8 aQ[4], aO[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        aQ[ks] = *(const bf16x8*)(sQ[0] + j * LQ2 + ks * 16 + hi * 8);
-        aO[ks] = *(const bf16x8*)(sdO[0] + j * LQ2 + ks * 16 + hi * 8);
-    }
-    fetch(min(2, ntile - 1) * BT);                          // in flight across X(0): stored to the ring in Y(0)
-    Frag pA[2], dA[2], bO[2][2], bQ[2][2];                  // carried from Y(i) to X(i+1); zero: X(0) multiplies them harmlessly
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { pA[t].w[w] = 0; dA[t].w[w] = 0; bO[t][0].w[w] = 0; bO[t][1].w[w] = 0; bQ[t][0].w[w] = 0; bQ[t][1].w[w] = 0; }
-    }
-    if (grp == 1) TG_BAR_LDS();                             // group 1 falls one barrier (= one segment) behind group 0
-    int buf = 0;
-    for (int it = 0; it < ntile; ++it) {
-        const int nbuf = buf == 2 ? 0 : buf + 1, sbuf = nbuf == 2 ? 0 : nbuf + 1;
-        // ---------------- X(it): matrix segment ----------------
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                mfma_acc(dv[db], pA[t].v, bO[t][db].v);
-                mfma_acc(dk[db], dA[t].v, bQ[t][db].v);
-            }
-        f32x16 s, dp;                                      // rows = queries, column = key j
-        mfma_pair(s, dp, aQ, aO, kf, vf);
-        TG_SB(); TG_BAR_LDS(); TG_SB();                     // pinned: register-only asm MFMAs may otherwise drift across the barrier
-        // ---------------- Y(it): vector segment ----------------
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 l4 = *(const f32x4*)(sLse[buf] + 8 * g + 4 * hi), d4 = *(const f32x4*)(sD[buf] + 8 * g + 4 * hi);
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-                const f32x2 pv = {fast_exp2(s[4 * g + e] * p.scale_log2 - l4[e]), fast_exp2(s[4 * g + e + 1] * p.scale_log2 - l4[e + 1])};
-                const f32x2 ds = {pv[0] * (dp[4 * g + e] - d4[e]), pv[1] * (dp[4 * g + e + 1] - d4[e + 1])};
-                pA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2_trans(pv[0], pv[1]);
-                dA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2(ds[0], ds[1]);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const int o = (db * 32 + j) * LT2 + 16 * t + 4 * hi;
-                bO[t][db].u[0] = *(const uint2*)(sdOt[buf] + o); bO[t][db].u[1] = *(const uint2*)(sdOt[buf] + o + 8);
-                bQ[t][db].u[0] = *(const uint2*)(sQt[buf] + o);  bQ[t][db].u[1] = *(const uint2*)(sQt[buf] + o + 8);
-            }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {                    // A operands of tile it+1 (staged during step it-1 by both groups)
-            aQ[ks] = *(const bf16x8*)(sQ[nbuf] + j * LQ2 + ks * 16 + hi * 8);
-            aO[ks] = *(const bf16x8*)(sdO[nbuf] + j * LQ2 + ks * 16 + hi * 8);
-        }
-        stash(sbuf);                                       // tile it+2 -> the buffer tile it-1 left (its last reader: group 1's Y(it-1), two barriers ago)
-        fetch(min(it + 3, ntile - 1) * BT);                 // for Y(it+1)
-        TG_SB(); TG_BAR_LDS(); TG_SB();
-        buf = nbuf;
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t)                             // X tail: the last tile's dV / dK products
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-            mfma_acc(dv[db], pA[t].v, bO[t][db].v);
-            mfma_acc(dk[db], dA[t].v, bQ[t][db].v);
-        }
-    if (grp == 0) TG_BAR_LDS();                             // pairs with group 1's extra barrier
     asm volatile("s_nop 15" ::: "memory");
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
@@ -1230,8 +558,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
     __shared__ __attribute__((aligned(16))) bf16_t sK[2][ROWT_EL], sV[2][ROWT_EL], sKt[2][COLT_EL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hi = lane >> 5;
-    const int h = blockIdx.y % p.heads, b = blockIdx.y / p.heads;
-    const int qw0 = blockIdx.x * 256 + wave * 64;
+    int blk, hb;
+    xcd_block((p.nq + 255) / 256, p.heads * p.batch, blk, hb);
+    const int h = hb % p.heads, b = hb / p.heads;
+    const int qw0 = blk * 256 + wave * 64;
     const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
     const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
     const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
@@ -1314,20 +644,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
             f32x16 st, dpt;                                // rows = keys, column = query j
             mfma_pair(st, dpt, aK, aV, qf[qb], of[qb]);
             Frag dA[2];
-            const f32x2 sc2 = {p.scale_log2, p.scale_log2}, lv = {lse[qb], lse[qb]}, dv2 = {dsum[qb], dsum[qb]};
+            const f32x2 lv = {lse[qb], lse[qb]}, dv2 = {dsum[qb], dsum[qb]};
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {
                     const f32x2 sv = {st[4 * g + e], st[4 * g + e + 1]}, dpv = {dpt[4 * g + e], dpt[4 * g + e + 1]};
-#if TG_BWD_PK
-                    const f32x2 arg = sv * sc2 - lv;
-                    const f32x2 pv = {fast_exp2(arg[0]), fast_exp2(arg[1])};
-                    const f32x2 ds = pv * (dpv - dv2);
-#else
+                    // scalar fp32 arithmetic: the packed forms (v_pk_fma / add / mul) measured 3.5 % slower beside the MFMAs
                     const f32x2 pv = {fast_exp2(sv[0] * p.scale_log2 - lv[0]), fast_exp2(sv[1] * p.scale_log2 - lv[1])};
                     const f32x2 ds = {pv[0] * (dpv[0] - dv2[0]), pv[1] * (dpv[1] - dv2[1])};
-#endif
                     dA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2(ds[0], ds[1]);
                 }
 #pragma unroll
@@ -1377,7 +702,7 @@ static int attention_bwd_v1(const void* q, long q_ld, long q_sb, const void* k, 
     BwdParams p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, q_ld, q_sb, k_ld, k_sb, v_ld, v_sb,
                 o_ld, o_sb, do_ld, do_sb, dq, dk, dv, dq_ld, dq_sb, dk_ld, dk_sb, dv_ld, dv_sb, ws, ws + (long)batch * heads * nq, nq, nk, heads, batch,
                 scale * 1.4426950408889634f, scale, accumulate};
-    constexpr int LDS_STATS = 2 * TILE_EL * 2 + 512 * 4, LDS_KV = 8 * TILE_EL * 2 + 128 * 4, LDS_Q = 6 * TILE_EL * 2;
+    constexpr int LDS_KV = 8 * TILE_EL * 2 + 128 * 4, LDS_Q = 6 * TILE_EL * 2;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
@@ -1385,7 +710,7 @@ static int attention_bwd_v1(const void* q, long q_ld, long q_sb, const void* k, 
         attr = true;
     }
     const dim3 gq((unsigned)((nq + TQ - 1) / TQ), (unsigned)(batch * heads)), gk((unsigned)((nk + TK - 1) / TK), (unsigned)(batch * heads));
-    hipLaunchKernelGGL(attn_bwd_stats_kernel, gq, dim3(256), LDS_STATS, stream, p);
+    hipLaunchKernelGGL(attn_bwd_stats2_kernel, dim3((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), dim3(256), 0, stream, p);   // shared with the fast path
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, gk, dim3(256), LDS_KV, stream, p);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(256), LDS_Q, stream, p);
     TG_LAUNCH_CHECK("tg_attention_bwd");
@@ -1422,13 +747,8 @@ extern "C" int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void*
     pp.qT = qT; pp.doT = doT; pp.kT = kT; pp.ldq = ldq; pp.ldk = ldk;
     const dim3 gq((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), gk((unsigned)((nk + 255) / 256), (unsigned)(batch * heads));
     hipLaunchKernelGGL(attn_bwd_stats2_kernel, gq, dim3(256), 0, stream, pp.p);
-    static const int dkdv_sel = [] { const char* e = getenv("TG_ATTN_BWD_DKDV"); return e ? atoi(e) : 5; }();   // 2: 64 keys per wave, 1 wave/SIMD; 3: 32 keys, 2 waves/SIMD; 4: 3 + three-deep LDS ring; 5: 4 as one 8-wave workgroup
-    if (dkdv_sel == 6) hipLaunchKernelGGL(attn_bwd_dkdv6_kernel, gk, dim3(512), 0, stream, pp);      // 6: 5 as a two-group ping-pong
-    else if (dkdv_sel == 5) hipLaunchKernelGGL(attn_bwd_dkdv5_kernel, gk, dim3(512), 0, stream, pp);
-    else if (dkdv_sel == 4) hipLaunchKernelGGL(attn_bwd_dkdv4_kernel, dim3((unsigned)((nk + 127) / 128), (unsigned)(batch * heads)), dim3(256), 0, stream, pp);
-    else if (dkdv_sel == 3) hipLaunchKernelGGL(attn_bwd_dkdv3_kernel, dim3((unsigned)((nk + 127) / 128), (unsigned)(batch * heads)), dim3(256), 0, stream, pp);
-    else hipLaunchKernelGGL(attn_bwd_dkdv2_kernel, gk, dim3(256), 0, stream, pp);
-    hipLaunchKernelGGL(attn_bwd_dq2_kernel, gq, dim3(256), 0, stream, pp);
+    hipLaunchKernelGGL(attn_bwd_dkdv5_kernel, dim3(gk.x * gk.y), dim3(512), 0, stream, pp);
+    hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(gq.x * gq.y), dim3(256), 0, stream, pp);
     TG_LAUNCH_CHECK("tg_attention_bwd");
     return TG_OK;
 }

@@ -30,7 +30,6 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + W
 #define TG_GROUP_M 8
 #endif
 constexpr int GROUP_M = TG_GROUP_M;
-bool g_force_128 = false;   // debugging knob (TG_GEMM_FORCE_128=1): route everything through the 128^2 kernel
 
 struct GemmParams {
     const bf16_t* A; long lda; long sAb;
@@ -217,7 +216,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 // (v_mfma_f32_32x32x16_bf16, 4 independent accumulators), the other does its ds_read_b128 fragment loads.  Group 1 simply
 // runs one barrier behind group 0, so per SIMD one wave is always in its MFMA phase.
 //
-// Why a 4-deep ring of K=32 stages (and not 2 x K=64): ablation on MI355X (TG_GEMM_ABLATE) showed the schedule without
+// Why a 4-deep ring of K=32 stages (and not 2 x K=64): timing ablations on MI355X showed the schedule without
 // its LDS-DMA runs at 1.87 PFLOP/s-equivalent while the DMA path alone takes 72 % of the full kernel's time at only 40 % of
 // L2 bandwidth — the fill is bound by bytes in flight x miss latency (19 % of the pieces are compulsory L2 misses served
 // by MALL/HBM, and vmcnt retires in order).  Four 32-KiB stages keep THREE stages (up to 12 KiB per wave, 96 KiB per CU)
@@ -238,7 +237,7 @@ constexpr int OPER2_BYTES = BM2 * BK2 * 2;       // 16 KiB per operand per stage
 constexpr int STAGE2_BYTES = 2 * OPER2_BYTES;    // 32 KiB
 constexpr int RING2_BYTES = NS2 * STAGE2_BYTES;  // 128 KiB
 
-template <int EPI, int ABL = 0>   // ABL: profiling ablations (1 = no fragment ds_reads, 2 = no MFMA, 3 = no LDS-DMA); 0 ships
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     // PERSISTENT: one workgroup per CU walks the tile list (tile += gridDim.x).  The first three stages of the NEXT output
     // tile are put in flight before the epilogue of the current one, and the epilogue goes through LDS (ring slot 3) so that
@@ -284,7 +283,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         }
     };
     auto stage1 = [&](int st, int ph, int i) {               // piece i of issue phase ph for stage st
-        if (ABL == 3) return;
         char* dstp = smem + (st & (NS2 - 1)) * STAGE2_BYTES + ph * OPER2_BYTES + (wave * 32 + i * 16) * 64;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[ph][i] + (long)st * (BK2 * 2)),
                                          (__attribute__((address_space(3))) void*)dstp, 16, 0, 0);
@@ -302,21 +300,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 
     f32x16 acc[4][2];   // [32-row m block][32-col n block]
     bf16x8 fa[2][2], fw[2][2];   // A: 2 m-blocks x 2 k-steps of the current 64-row half; W: 2 n-blocks x 2 k-steps
-    if (ABL == 1) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) { fw[i][ks] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; fa[i][ks] = fw[i][ks]; }
-    }
     auto loadA = [&](const char* tA, int qm) {
-        if (ABL == 1) return;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) fa[mb][ks] = *(const bf16x8*)(tA + ((offA0 + (qm * 64 + mb * 32) * 64) ^ (ks * 32)));
     };
     auto loadW = [&](const char* tW) {
-        if (ABL == 1) return;
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -329,7 +319,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);               \
     } while (0)
 #define TG_MFMA(QM, KS, MB, NB) \
-    if (ABL != 2) acc[(QM) * 2 + (MB)][NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[NB][KS], fa[MB][KS], acc[(QM) * 2 + (MB)][NB], 0, 0, 0)
+    acc[(QM) * 2 + (MB)][NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[NB][KS], fa[MB][KS], acc[(QM) * 2 + (MB)][NB], 0, 0, 0)
 // 8 MFMAs of one 64x64 half-tile step (4 independent accumulators, each used twice 4 issues apart); the wave's 2 LDS-DMA
 // pieces of issue phase PH for stage st+3 are issued from INSIDE the MFMA stream (the wave idles ~24 of every 32 cycles there)
 #define TG_COMPUTE(QM, PH, MORE)                                                                            \
@@ -498,9 +488,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 //     slot 93       vmcnt(pieces issued so far) + s_barrier: stage s+1 landed everywhere; then (every 2nd slot) reads of set 0 of s+1
 //   The stage stream runs across output tiles (persistent): the last two stages of a tile fetch the first two of the next.
 // ================================================================================================
-#ifndef W4_ABL
-#define W4_ABL 0   // timing-only ablations (wrong results): 1 = no LDS-DMA in the steady stages, 2 = no fragment reads, 3 = no epilogue
-#endif
 constexpr int BK3 = 64;
 constexpr int OPER3_BYTES = 256 * BK3 * 2;       // 32 KiB per operand per stage
 constexpr int STAGE3_BYTES = 2 * OPER3_BYTES;    // 64 KiB
@@ -610,19 +597,12 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
     };
     bf16x8 fa[2][8], fw[2][8];                     // [k-step][16-row block]
     f32x4 acc[8][8];                               // [m block][n block]; lane holds D[n = 4*(lane>>4) + r][m = lane&15]
-    if (W4_ABL == 2) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { fa[i][j] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; fw[i][j] = fa[i][j]; }
-    }
 
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
 #define W4_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
     // fragment read r (0..15) of k-step KS: 0..7 -> W blocks, 8..15 -> A blocks
     auto frag_read = [&](auto ksc, auto rc) {
         constexpr int KS = decltype(ksc)::value, R = decltype(rc)::value;
-        if constexpr (W4_ABL == 2) return;
         if constexpr (R < 8) {
             bf16x8& d = fw[KS][R];
             const int ad = rw[KS];
@@ -686,9 +666,7 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
                 toggle();
             }
             if constexpr (I >= W4_D0 && (I - W4_D0) % W4_DS == 0 && (I - W4_D0) / W4_DS < 16) {
-#if W4_ABL != 1
                 if (dma) dma_piece((I - W4_D0) / W4_DS);
-#endif
             }
             if constexpr (I == W4_B2) {
                 constexpr int ISSUED = (W4_B2 - W4_D0) / W4_DS + 1 > 16 ? 16 : (W4_B2 - W4_D0) / W4_DS + 1;
@@ -770,7 +748,6 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
         // ---- epilogue through LDS (4 KiB per wave behind the stages, 16-B slots XOR-swizzled by row&7): MFMA layout -> full rows ----
         // per 16x16 block a lane holds D[n = 4*(lane>>4) + r][m = lane&15].  The staging accesses are asm so that the compiler's
         // LDS-DMA alias rule (vmcnt(0) before any LDS access while a DMA is in flight) does not serialise them behind the global stores
-        if (W4_ABL == 3 && p.M > 0) continue;
         bf16_t* Cb = ec.sec ? p.C2 + (long)ec.b * p.sCb2 : p.C + (long)ec.b * p.sCb;
         const int eM = ec.sec ? p.M2 : p.M;
         const int stg = W4_STG_OFF + wave * 4096;
@@ -915,14 +892,13 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
 
 template <int EPI>
 int launch(GemmParams p, hipStream_t stream) {
-    if (p.M >= 1024 && p.N % BN2 == 0 && !g_force_128) {   // large-M shapes: 256^2 ping-pong kernel
+    if (p.M >= 1024 && p.N % BN2 == 0) {   // large-M shapes: 256^2 ping-pong kernel
         const int tiles2 = (((p.M + BM2 - 1) / BM2) + (p.A2 ? (p.M2 + BM2 - 1) / BM2 : 0)) * (p.N / BN2) * p.batch;
         // tile order: groups of group_m m-tiles x all n-tiles, m fastest; the 32 tiles resident on one XCD then share group_m A panels and
         // 32/group_m W panels.  A (activations) is the big, XCD-private operand, W (weights) is shared by every XCD through the
         // Infinity Cache, so small groups win: measured sum over the four block GEMMs 7.61 (8) / 7.48 (4) / 7.53 (6) / 7.62 (2) ms,
         // and for K = 12288 (6.3 MB per A panel) a single m-tile per group is another 3 % faster (2.31 vs 2.34 vs 2.40 ms)
-        static const int gm_env = [] { const char* e = getenv("TG_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();
-        p.group_m = gm_env > 0 ? gm_env : (p.K >= 8192 ? 1 : 4);
+        p.group_m = p.K >= 8192 ? 1 : 4;
         static bool attr2 = false;
         if (!attr2) {
             (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2_BYTES);
@@ -934,10 +910,9 @@ int launch(GemmParams p, hipStream_t stream) {
             (void)hipGetDevice(&dev);
             if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
         }
-        static const int abl = [] { const char* e = getenv("TG_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
         const dim3 grid2(tiles2 < n_cu ? tiles2 : n_cu);
         static const int w4 = [] { const char* e = getenv("TG_GEMM_W4"); return e ? atoi(e) : 1; }();   // 0: the 8-wave kernel for every shape
-        if (w4 && p.K >= 4 * BK3 && !abl && p.lda < (1L << 21) && p.ldw < (1L << 21)) {   // 32-bit buffer offsets: 256 rows * ld * 2 B < 2^31
+        if (w4 && p.K >= 4 * BK3 && p.lda < (1L << 21) && p.ldw < (1L << 21)) {   // 32-bit buffer offsets: 256 rows * ld * 2 B < 2^31
             static bool attr4 = false;
             if (!attr4) {
                 (void)hipFuncSetAttribute((const void*)gemm256w4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES);
@@ -947,13 +922,7 @@ int launch(GemmParams p, hipStream_t stream) {
             TG_LAUNCH_CHECK("tg_gemm_bf16(256w4)");
             return TG_OK;
         }
-        if (abl == 1) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2_BYTES);
-                        hipLaunchKernelGGL((gemm256_kernel<EPI, 1>), grid2, dim3(512), RING2_BYTES, stream, p); }
-        else if (abl == 2) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2_BYTES);
-                             hipLaunchKernelGGL((gemm256_kernel<EPI, 2>), grid2, dim3(512), RING2_BYTES, stream, p); }
-        else if (abl == 3) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2_BYTES);
-                             hipLaunchKernelGGL((gemm256_kernel<EPI, 3>), grid2, dim3(512), RING2_BYTES, stream, p); }
-        else hipLaunchKernelGGL(gemm256_kernel<EPI>, grid2, dim3(512), RING2_BYTES, stream, p);
+        hipLaunchKernelGGL(gemm256_kernel<EPI>, grid2, dim3(512), RING2_BYTES, stream, p);
         TG_LAUNCH_CHECK("tg_gemm_bf16(256)");
         return TG_OK;
     }
@@ -979,8 +948,6 @@ extern "C" int tg_gemm_bf16(const void* A, long lda, long strideA, const void* W
     TG_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && strideA % 8 == 0 && strideC % 8 == 0, TG_ERR_ALIGN,
                "tg_gemm_bf16: leading dimensions must keep 16-byte (A, W) / 8-byte (C) alignment");
     TG_REQUIRE(tg_aligned16(A) && tg_aligned16(W) && tg_aligned16(C), TG_ERR_ALIGN, "tg_gemm_bf16: unaligned base pointer");
-    static const bool env_init = [] { const char* e = getenv("TG_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; return true; }();
-    (void)env_init;
     GemmParams p{};
     p.A = (const bf16_t*)A; p.lda = lda; p.sAb = strideA;
     p.W = (const bf16_t*)W; p.ldw = ldw;
@@ -1021,19 +988,6 @@ extern "C" int tg_gemm_bf16_pair(const void* A1, long strideA1, const void* W1, 
     p.M = M1; p.N = N; p.K = K; p.batch = batch;
     p.A2 = (const bf16_t*)A2; p.W2 = (const bf16_t*)W2; p.bias2 = (const bf16_t*)bias2; p.C2 = (bf16_t*)C2; p.sAb2 = strideA2; p.sCb2 = strideC2;
     p.M2 = M2;
-    static const bool env_init = [] { const char* e = getenv("TG_GEMM_FORCE_128"); g_force_128 = e && e[0] == '1'; return true; }();
-    (void)env_init;
-    if (g_force_128) {          // the 128^2 kernel has no second problem: run the two one after the other
-        GemmParams q = p;
-        q.A = p.A2; q.sAb = p.sAb2; q.W = p.W2; q.bias = p.bias2; q.C = p.C2; q.sCb = p.sCb2; q.M = p.M2;
-        p.A2 = q.A2 = nullptr;
-        int rc;
-        switch (epilogue) {
-            case TG_EPI_BIAS: rc = launch<TG_EPI_BIAS>(p, stream); return rc ? rc : launch<TG_EPI_BIAS>(q, stream);
-            case TG_EPI_BIAS_GELU: rc = launch<TG_EPI_BIAS_GELU>(p, stream); return rc ? rc : launch<TG_EPI_BIAS_GELU>(q, stream);
-            default: rc = launch<TG_EPI_BIAS_SILU>(p, stream); return rc ? rc : launch<TG_EPI_BIAS_SILU>(q, stream);
-        }
-    }
     switch (epilogue) {
         case TG_EPI_BIAS: return launch<TG_EPI_BIAS>(p, stream);
         case TG_EPI_BIAS_GELU: return launch<TG_EPI_BIAS_GELU>(p, stream);
@@ -1055,9 +1009,8 @@ extern "C" int tg_gemm_bf16_qkv(const void* A1, long strideA1, const void* W1, c
                tg_aligned16(A1) && tg_aligned16(W1) && tg_aligned16(C1) && tg_aligned16(Vt1) && tg_aligned16(A2) && tg_aligned16(W2) &&
                tg_aligned16(C2) && tg_aligned16(Vt2), TG_ERR_ALIGN, "tg_gemm_bf16_qkv: alignment");
     static const bool w4_off = [] { const char* e = getenv("TG_GEMM_W4"); return e && atoi(e) == 0; }();
-    static const bool f128 = [] { const char* e = getenv("TG_GEMM_FORCE_128"); return e && e[0] == '1'; }();
     TG_REQUIRE(lda < (1L << 21) && ldw < (1L << 21), TG_ERR_SHAPE, "tg_gemm_bf16_qkv: leading dimensions must be < 2^21 elements");
-    TG_REQUIRE(!w4_off && !f128 && !getenv("TG_GEMM_ABLATE"), TG_ERR_ARG, "tg_gemm_bf16_qkv: only the 4-wave GEMM kernel has the V^T epilogue (TG_GEMM_W4=0 / FORCE_128 / ABLATE set)");
+    TG_REQUIRE(!w4_off, TG_ERR_ARG, "tg_gemm_bf16_qkv: only the 4-wave GEMM kernel has the V^T epilogue (TG_GEMM_W4=0 is set)");
     GemmParams p{};
     p.A = (const bf16_t*)A1; p.lda = lda; p.sAb = strideA1;
     p.W = (const bf16_t*)W1; p.ldw = ldw;

@@ -40,7 +40,6 @@ struct ConvParams {
     int To, Ho, Wo;
     const bf16_t* zeros;
     float* gn_partial;    // optional [tiles_m][2][32]: per-tile GroupNorm(32) sums / sums of squares of the STORED bf16 values
-    int order;            // 4-wave kernels: 1 = temporal-locality tile order (see conv3d_w4_kernel)
     int ksplit;           // > 1: the (tap, channel) reduction is cut into ksplit ranges, one workgroup each; raw fp32 sums go to kpart
     float* kpart;         // [ksplit][M][cout_pad] fp32 (conv_splitk_reduce_kernel adds them in a fixed order and runs the epilogue)
 };
@@ -304,10 +303,6 @@ constexpr int H2_W_BYTES = 128 * 64;                  // ring slot: 128 output c
 constexpr int H2_RING = 4;                            // weight stages in flight: the DMA of stage s+3 is issued at the top of stage s
 constexpr int H2_LDS = 2 * H2_HALO_BYTES + H2_RING * H2_W_BYTES;                               // 147456
 
-// TG_CONV_TIMING=1 (a -DTG_CONV_TIMING build, tools/ab_build.sh): s_memtime totals of workgroup 0 / wave 0 per stage segment
-#ifdef TG_CONV_TIMING
-__device__ long long tg_conv_dbg[8];
-#endif
 
 __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -413,10 +408,6 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
     static_for<0, WD>([&](auto ic) { read_w(ic, H2_WIMM(0), decltype(ic)::value); });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-#ifdef TG_CONV_TIMING
-    long long tacc[4] = {0, 0, 0, 0};
-    const long long t_begin = __builtin_amdgcn_s_memtime();
-#endif
     // Four groups = 36 stages per loop iteration: the fragment-set parity (36 % 2), the halo buffer (group parity) and the weight ring slot
     // (36 % 4) of every stage are compile-time constants; stages past the end (ngroups % 4 != 0) are skipped by a uniform test.
     // DMA budget: everything issued in stage s-1 or earlier has landed when stage s ends (counted vmcnt: only the pieces of stage s itself may
@@ -431,13 +422,10 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
             const int st = g0 * 9 + k;
             if (st >= nst) return;                          // workgroup-uniform
             __builtin_amdgcn_sched_barrier(0);
-#ifdef TG_CONV_TIMING
-            long long tc0 = __builtin_amdgcn_s_memtime();
-#endif
             const bool w_iss = st + 3 < nst, h_iss = tap < 7 && g + 1 < ngroups;
             constexpr int hfirst = tap < 5 ? 2 * tap : tap + 5, hcnt = tap < 5 ? 2 : (tap < 7 ? 1 : 0);     // 12 halo pieces over taps 0..6: 2,2,2,2,2,1,1
             // The stage's DMA pieces (2 weight pieces of stage s+3, up to 2 halo pieces of the next group) go out together at the top of the stage.
-            // In-kernel timers (TG_CONV_TIMING builds): a pure MFMA stage is 1021 cycles (= 64 x 16); the fragment reads add ~250; each LDS-DMA
+            // In-kernel timers (instrumented lab builds): a pure MFMA stage is 1021 cycles (= 64 x 16); the fragment reads add ~250; each LDS-DMA
             // piece blocks its wave's issue for ~128 cycles when all four waves issue together — and ~300 when a wave issues alone between its
             // MFMAs (a staggered one-wave-at-a-time schedule was 20 % SLOWER).  On this part the L2 -> LDS fill of a wave does not overlap with that
             // wave's MFMAs, and with one wave per SIMD nobody else fills the gap: stage time = MFMA + fill / (~32 B/clk/CU) + LDS.  That one
@@ -489,10 +477,6 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
                 if (more) read_a(std::integral_constant<int, nxt>{}, H2_AIMM(k + 1), ni);
             });
             __builtin_amdgcn_sched_barrier(0);
-#ifdef TG_CONV_TIMING
-            long long tc1 = __builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_sched_barrier(0);
-#endif
             {
                 bf16x8 &a0 = fa[nxt][0], &a1 = fa[nxt][1], &a2 = fa[nxt][2], &a3 = fa[nxt][3], &a4 = fa[nxt][4], &a5 = fa[nxt][5], &a6 = fa[nxt][6],
                        &a7 = fa[nxt][7], &w0 = fwr[0], &w1 = fwr[1], &w2 = fwr[2], &w3 = fwr[3], &w4 = fwr[4], &w5 = fwr[5];
@@ -508,23 +492,10 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
             else if (h_iss) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(hcnt) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-#ifdef TG_CONV_TIMING
-            __builtin_amdgcn_sched_barrier(0);
-            long long tc2 = __builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_sched_barrier(0);
-#endif
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-#ifdef TG_CONV_TIMING
-            long long tc3 = __builtin_amdgcn_s_memtime();
-            tacc[0] += tc1 - tc0; tacc[1] += tc2 - tc1; tacc[2] += tc3 - tc2; tacc[3] += 1;
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         });
     }
-#ifdef TG_CONV_TIMING
-    if (blockIdx.x == 0 && tid == 0) { for (int i = 0; i < 4; ++i) tg_conv_dbg[i] = tacc[i]; tg_conv_dbg[4] = __builtin_amdgcn_s_memtime() - t_begin; }
-#endif
 
     // ---- epilogue: bias, bf16 rounding before the residual add, bf16 store, GroupNorm sums (Cout = 128: a lane's channel quad is one group) ----
     float gs[8], gq[8];
@@ -681,30 +652,11 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
 
     const long M = (long)p.To * p.Ho * p.Wo;
     const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = p.cout_pad / NT;
-    int tn, tm;
-    if (p.order) {
-        // Temporal-locality tile order.  The linear voxel index is frame-major, so "contiguous chunk of tiles per XCD" gave every XCD ONE
-        // frame: the causal taps (frames t-2, t-1, t) of the same rows were then fetched by three different XCDs' L2s, and PMC showed
-        // 5-6x the algorithmic HBM-side bytes on these launches.  Here an XCD's consecutive workgroups walk (chunk of G tiles ~ 2048 voxels
-        // of a frame) x (all frames) x (tile in chunk): a spatial stripe through all frames stays in one L2.  Frames are the ranges
-        // [b_t, b_t+1) of the linear tile index (b_t = t * tiles_m / F); the grid is padded to F * Jmax and the <= F - 1 empty slots exit.
-        constexpr int G = 2048 / TM;
-        const int F = p.To, Jmax = (tiles_m + F - 1) / F;
-        const int o_all = xcd_remap(blockIdx.x, F * Jmax * tiles_n);
-        tn = o_all % tiles_n;
-        const int o = o_all / tiles_n;
-        const int full = Jmax / G;
-        int c = o / (F * G), rem, gw;
-        if (c < full) { rem = o - c * F * G; gw = G; }
-        else { c = full; rem = o - full * F * G; gw = Jmax - full * G; }
-        const int tf = rem / gw, j = c * G + (rem - tf * gw);
-        const int b0 = (int)((long)tf * tiles_m / F), b1 = (int)((long)(tf + 1) * tiles_m / F);
-        if (j >= b1 - b0) return;                     // padded slot (workgroup-uniform, before any barrier)
-        tm = b0 + j;
-    } else {
-        const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-        tn = t % tiles_n; tm = t / tiles_n;           // n fastest: the tiles_n blocks sharing an A tile run on one XCD
-    }
+    // tile order: contiguous chunk of tiles per XCD, n fastest (the tiles_n blocks sharing an A tile run on one XCD).  A temporal-locality order
+    // (an XCD walks a spatial stripe through all frames) measured neutral — 200.2 vs 199.9 ms on the 256 -> 256 layers: the 5-6x algorithmic
+    // L2-miss bytes PMC shows for these launches are absorbed behind L2 and already hidden.
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tn = t % tiles_n, tm = t / tiles_n;
     const long m0 = (long)tm * TM;
     const int n0 = tn * NT;
     const int Kw = p.kt * p.kh * p.kw * p.Cin;        // row length of the packed weights
@@ -1330,7 +1282,7 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
     TG_REQUIRE(tg_aligned16(x) && tg_aligned16(w) && tg_aligned16(zeros) && (!cache || tg_aligned16(cache)) && (((uintptr_t)y) & 1) == 0 &&
                (cout % 4 != 0 || ((((uintptr_t)y) & 7) == 0 && ldy % 4 == 0)), TG_ERR_ALIGN, "tg_conv3d_cl: alignment");
     ConvParams p{(const bf16_t*)x, T, H, W, Cin, (const bf16_t*)cache, (const bf16_t*)w, (const bf16_t*)bias, cout, cout_pad, kt, kh, kw,
-                 stride, pad, up, t_map, (const bf16_t*)residual, (bf16_t*)y, ldy, To, Ho, Wo, (const bf16_t*)zeros, gn_partial, 0, 1, nullptr};
+                 stride, pad, up, t_map, (const bf16_t*)residual, (bf16_t*)y, ldy, To, Ho, Wo, (const bf16_t*)zeros, gn_partial, 1, nullptr};
     TG_REQUIRE(!gn_partial || (cout == cout_pad && cout % BN == 0 && (cout / GN_GROUPS) % 4 == 0), TG_ERR_SHAPE,
                "tg_conv3d_cl: fused GroupNorm sums need cout in {128, 256, 512, ...} (cout=%d)", cout);
     const long M = (long)To * Ho * Wo;
@@ -1348,10 +1300,6 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
     // 4-wave kernel: 256x256 tiles need enough of them to fill the chip (>= 2 per CU; the 512-channel layers of the VAE have 128 and stay on
     // the 128x128 kernel: measured 161 vs 142 ms there, 226 vs 248 ms on the 256-channel layers).  TG_CONV_W4=0: never, 2: whenever legal
     static const int w4 = [] { const char* e = getenv("TG_CONV_W4"); return e ? atoi(e) : 1; }();
-    // 1: temporal-locality tile order in the 4-wave kernels.  Measured NEUTRAL (256->256 layers 200.2 vs 199.9 ms, 128->128 182.9 vs 182.2 ms per
-    // decode): the 5-6x algorithmic HBM-side bytes PMC shows for these launches are absorbed behind L2 (MALL) and their latency is already
-    // hidden — the Cout = 128 kernel is bound by the L2 -> LDS fill (39 of the ~43 B/clk/CU the path delivers), not by misses.  Off by default.
-    static const int conv_order = [] { const char* e = getenv("TG_CONV_ORDER"); return e ? atoi(e) : 0; }();
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -1362,9 +1310,7 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
         To < 512 && Ho < 2048 && Wo < 2048 && (long)kt * kh * kw * Cin < (1L << 21) && (long)(T + 2) * H * W * Cin < (1L << 31)) {
         static bool attr4 = false;
         if (!attr4) { (void)hipFuncSetAttribute((const void*)conv3d_w4_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS); attr4 = true; }
-        long tiles4 = ((M + 255) / 256) * (cout / 256);
-        p.order = conv_order && To > 1;
-        if (p.order) tiles4 = (long)To * (((M + 255) / 256 + To - 1) / To) * (cout / 256);
+        const long tiles4 = ((M + 255) / 256) * (cout / 256);
         hipLaunchKernelGGL(conv3d_w4_kernel<256>, dim3((unsigned)tiles4), dim3(256), CW_LDS, stream, p);
         TG_LAUNCH_CHECK("tg_conv3d_cl(w4)");
         return TG_OK;
@@ -1383,28 +1329,19 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
             static bool attrh = false;
             if (!attrh) { (void)hipFuncSetAttribute((const void*)conv3d_halo2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS); attrh = true; }
             hipLaunchKernelGGL(conv3d_halo2_kernel, dim3((unsigned)h2tiles), dim3(256), H2_LDS, stream, p);
-#ifdef TG_CONV_TIMING
-            {
-                long long h[8];
-                (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(tg_conv_dbg), sizeof(h));
-                fprintf(stderr, "[tg_conv halo timing] stages %lld: issue+MFMA %lld  lgkm+vmcnt wait %lld  barrier %lld  | kernel total %lld (s_memtime ticks, 100 MHz)\n",
-                        h[3], h[0], h[1], h[2], h[4]);
-            }
-#endif
             TG_LAUNCH_CHECK("tg_conv3d_cl(halo)");
             return TG_OK;
         }
     }
     // Cout = 128: the 512x128 variant (plain 3x3x3 / 1x3x3 convolutions only: 16 A pieces per wave are too many for the general address path)
-    static const int w4n = [] { const char* e = getenv("TG_CONV_W4N"); return e ? atoi(e) : 1; }();    // measured: 128->128 layers 203 -> 187 ms (decode), 181 -> 162 ms (encode)
-    if (w4n && (w4n == 2 || (M + 511) / 512 >= 2L * n_cu) && cout == 128 && cout_pad == 128 && !t_map && stride == 1 && up == 1 && M >= 2048 &&
+    // (TG_CONV_W4 governs this variant too; measured: 128->128 layers 203 -> 187 ms per decode, 181 -> 162 ms per encode)
+    if (w4 && (w4 == 2 || (M + 511) / 512 >= 2L * n_cu) && cout == 128 && cout_pad == 128 && !t_map && stride == 1 && up == 1 && M >= 2048 &&
         (long)kt * kh * kw * (Cin / 64) >= 4 && H < 2048 && W < 2048 && To < 512 && Ho < 2048 && Wo < 2048 && (long)kt * kh * kw * Cin < (1L << 21) &&
         (long)(T + 2) * H * W * Cin < (1L << 31)) {
         constexpr int LDS_N = 2 * (512 * 128 + 128 * 128);
         static bool attrn = false;
         if (!attrn) { (void)hipFuncSetAttribute((const void*)conv3d_w4_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_N); attrn = true; }
-        p.order = conv_order && To > 1;
-        const long tiles5 = p.order ? (long)To * (((M + 511) / 512 + To - 1) / To) : (M + 511) / 512;
+        const long tiles5 = (M + 511) / 512;
         hipLaunchKernelGGL(conv3d_w4_kernel<128>, dim3((unsigned)tiles5), dim3(256), LDS_N, stream, p);
         TG_LAUNCH_CHECK("tg_conv3d_cl(w4n)");
         return TG_OK;

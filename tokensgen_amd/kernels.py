@@ -128,10 +128,9 @@ def gemm_pair(a1, w1, bias1, out1, a2, w2, bias2, out2, epilogue=L.EPI_BIAS):
 
 
 def gemm_qkv_supported(M, N, K, v_col0):
-    """Shapes the fused QKV + V^T launch (tg_gemm_bf16_qkv) takes; the debugging knobs that disable the 4-wave GEMM disable it too."""
+    """Shapes the fused QKV + V^T launch (tg_gemm_bf16_qkv) takes; TG_GEMM_W4=0 (the cross-check tests' switch to the 8-wave GEMM) disables it too."""
     import os
-    return (M >= 1024 and N % 256 == 0 and K % 64 == 0 and K >= 256 and v_col0 % 256 == 0 and os.environ.get("TG_GEMM_W4", "1") != "0"
-            and os.environ.get("TG_GEMM_FORCE_128") != "1" and not os.environ.get("TG_GEMM_ABLATE"))
+    return M >= 1024 and N % 256 == 0 and K % 64 == 0 and K >= 256 and v_col0 % 256 == 0 and os.environ.get("TG_GEMM_W4", "1") != "0"
 
 
 def gemm_qkv(a1, w1, bias1, out1, vt1, a2=None, w2=None, bias2=None, out2=None, vt2=None, v_col0=None):

@@ -454,17 +454,10 @@ class AutoencoderKLCogVideoX:
             self._streams += [torch.cuda.Stream(device=self.device) for _ in range(n - len(self._streams))]
         # stream assignment: round-robin in the reference's row-major tile order (measured best at 480 x 720 on 3 streams: the two streams
         # that carry the full-size tiles and the one that carries the edge tiles drift out of phase, so small-kernel phases of one tile meet
-        # large convolutions of another; longest-processing-time-first balancing measured 3 % slower).  TG_VAE_ASSIGN / TG_VAE_ENQ
-        # ("0,1,2,..." stream per tile / enqueue order of the tiles) are experiment knobs.
+        # large convolutions of another; longest-processing-time-first balancing measured 3 % slower)
         flat = [(i, j) for row in origins for (i, j) in row]
         assign = [k % n for k in range(len(flat))]
         order = list(range(len(flat)))
-        if os.environ.get("TG_VAE_ASSIGN"):
-            a_ = [int(v) % n for v in os.environ["TG_VAE_ASSIGN"].split(",")]
-            assign = a_ if len(a_) == len(flat) else assign
-        if os.environ.get("TG_VAE_ENQ"):
-            o_ = [int(v) for v in os.environ["TG_VAE_ENQ"].split(",")]
-            order = o_ if sorted(o_) == order else order
         res = [None] * len(flat)
         for k in order:
             i, j = flat[k]
