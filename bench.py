@@ -32,7 +32,7 @@ PEAK_BF16 = 2.5e15                # MI355X dense bf16 MFMA peak (MI355X_MICROARC
 # dominant kernel = fused main attention (SDPA#1 + SDPA#2 of the To2V processor), per launch (B=2):
 N1, NP, D_MODEL = 17776, 480, 3072
 # + the vip-query attention (SDPA#3), whose workgroups ride in the same launch (tg_attention_fwd_multi)
-PMC_SUMMARY = "r2_pmc_summary.json"     # committed rocprofv3 PMC passes the `traffic` figure is read from
+PMC_SUMMARY = "r3_pmc_summary.json"     # committed rocprofv3 PMC passes the `traffic` figure is read from
 ATTN_FLOP_PER_LAUNCH = 2 * (4.0 * N1 * N1 * D_MODEL + 4.0 * N1 * NP * D_MODEL + 4.0 * NP * (N1 + NP) * D_MODEL)
 
 
@@ -526,7 +526,7 @@ def main():
                                    "window = 226 text + 17550 video + 480 condensed tokens, CFG batch 2, DPM-solver++ (52 trailing steps)",
                        "layers": a.layers, "exchange": "RCCL all_gather of kept half-windows per step" if use_dist else "none"},
             "step_mfma_frac": FLOP_PER_STEP * (a.layers / 42.0) * (a.steps / dt) / PEAK_BF16,
-            "roofline": {"bound": "mfma", "kernel": "attn_fwd_pp_kernel (SDPA#1+#2 fused, SDPA#3 riding in the last round)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "attn_fwd_pp_kernel (SDPA#1+#2 fused + SDPA#3 riding; whole workgroups, key-split tail + combine, retry grid: one tg_attention_fwd_multi call)", "achieved": achieved,
                          "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16 / 1e12), "traffic": traffic,
                          "launch_ms": attn["ms"], "launches_timed": attn["n"], "attn_path": attn_path},
             "attn_path": attn_path, "attn_retried_workgroups": retried, "finite": finite,
