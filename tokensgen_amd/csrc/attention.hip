@@ -760,8 +760,8 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
 // Joins the two halves of every split parent: O = (Oa 2^(ma-M) + Ob 2^(mb-M)) / (la 2^(ma-M) + lb 2^(mb-M)), M = max(ma, mb) — with the
 // constant shift ma == mb and this is a plain sum — rounds to bf16, adds the second segment's bf16(seg2_scale * O2) like the unsplit epilogue,
 // and writes the parent's output rows.  The constant-shift verification of a split parent's segment 1 happens here, on the JOINED row sum.
-__global__ __launch_bounds__(256) void attn_split_combine_kernel(AttnParams p, int fixedm) {
-    const int wgid = p.split_first + blockIdx.x;
+__global__ __launch_bounds__(256) void attn_split_combine_kernel(AttnParams p, int fixedm) {      // grid: 4 workgroups (128 rows each) per parent
+    const int wgid = p.split_first + ((int)blockIdx.x >> 2);
     const bool rider = p.r_nq > 0 && wgid >= p.main_wgs;
     const int bid = rider ? wgid - p.main_wgs : wgid;
     const int nq_ = rider ? p.r_nq : p.nq;
@@ -780,11 +780,11 @@ __global__ __launch_bounds__(256) void attn_split_combine_kernel(AttnParams p, i
         qt = bid % nqt;
     }
     const int h = hb % p.heads, b = hb / p.heads;
-    const float* wa = p.split_ws + (long)(2 * blockIdx.x) * SPLIT_HALF_FLOATS;
+    const float* wa = p.split_ws + (long)(2 * ((int)blockIdx.x >> 2)) * SPLIT_HALF_FLOATS;
     const float* wb = wa + SPLIT_HALF_FLOATS;
     bool bad = false;
-    for (int item = threadIdx.x; item < 512 * 4; item += 256) {
-        const int row = item >> 2, d0 = (item & 3) * 16;
+    for (int item = threadIdx.x; item < 128 * 4; item += 256) {
+        const int row = ((int)blockIdx.x & 3) * 128 + (item >> 2), d0 = (item & 3) * 16;
         const int q = qt * 512 + row;
         if (q >= nq_) continue;
         const float ma = wa[512 * 64 + row], la = wa[512 * 65 + row], mb = wb[512 * 64 + row], lb = wb[512 * 65 + row];
@@ -915,7 +915,7 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
             TG_PP(main_grid, true, 1);
             if (p.nsplit) {
                 TG_PP(split_grid, true, 1, false, false, true);
-                hipLaunchKernelGGL(attn_split_combine_kernel, dim3((unsigned)p.nsplit), dim3(256), 0, stream, p, 1);
+                hipLaunchKernelGGL(attn_split_combine_kernel, dim3((unsigned)(4 * p.nsplit)), dim3(256), 0, stream, p, 1);
             }
             TG_PP(retry_grid, true, 0, false, true);
         }
@@ -929,7 +929,7 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
             TG_PP(main_grid, false);
             if (p.nsplit) TG_PP(split_grid, false, 0, false, false, true);
         }
-        if (p.nsplit) hipLaunchKernelGGL(attn_split_combine_kernel, dim3((unsigned)p.nsplit), dim3(256), 0, stream, p, 0);
+        if (p.nsplit) hipLaunchKernelGGL(attn_split_combine_kernel, dim3((unsigned)(4 * p.nsplit)), dim3(256), 0, stream, p, 0);
     } else if (wg256 >= 1024) {
         hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)wg256), dim3(256), 0, stream, p);
     } else {
