@@ -525,7 +525,7 @@ def test_gemm_4wave_random_shapes(K):
 
 def test_attention_ragged_tile_split_at_launch_scale(K):
     """At launch scale (>= 1024 ping-pong workgroups) a single-problem call whose ragged last query tile would cost a whole extra round
-    of workgroups hands that tile to the 4-wave kernel behind the ping-pong launch (attention.hip, TG_ATTN_TAIL): 48 heads x 2, nq =
+    of workgroups hands that tile to the 4-wave kernel behind the ping-pong launch (attention.hip, attention_launch): 48 heads x 2, nq =
     13 x 512 + 150 (1248 -> 5 rounds instead of 1344 -> 6).  Both parts against fp32 torch on a few heads: rows of full tiles, the
     ragged rows, two key segments."""
     B, H, nq, nk2 = 2, 48, 13 * 512 + 150, 200
