@@ -275,8 +275,8 @@ int tg_attention_fwd_lse(const void* q, long q_ld, long q_strideB, const void* k
  * k, v: likewise with nk rows (v row-major here, not the transposed image of the forward).  dq / dk / dv: fp32, same indexing;
  * accumulate: 0 overwrite; 1 (= 3) add to what is there in all three; 2 add into dk / dv only, overwrite dq (the To2V processor's three attention
  * calls share K / V tensors — their gradients sum — but not queries).
- * ws: 16-byte aligned fp32 workspace of tg_attention_bwd_ws_floats(nq, nk, heads, batch) floats (row log-sum-exp, rowsum(dO o O), and the
- * transposed bf16 copies Q^T, dO^T, K^T the kernels' [d][row] tiles are loaded from).
+ * ws: 16-byte aligned fp32 workspace of tg_attention_bwd_ws_floats(nq, nk, heads, batch) floats (row log-sum-exp and rowsum(dO o O); the
+ * [d][row] operands are read from the row-major tiles with the LDS transpose read, no transposed copies).
  * P is recomputed from the log-sum-exp tile by tile; three launches (statistics, dK/dV per 256-key workgroup, dQ per 256-query workgroup) behind
  * three tg_transpose_v passes, no atomics: run-to-run deterministic.  lse: optional [batch][heads][nq] fp32 row log-sum-exp (log2 domain) written by
  * tg_attention_fwd_lse for the same q / k / scale — the statistics launch then only forms rowsum(dO o O); NULL: recomputed here.

@@ -99,17 +99,23 @@ __device__ __forceinline__ void xcd_block(int nx, int nhb, int& blk, int& hb) {
     }
 }
 
+// B operand of dV += P^T dO / dK += dS^T Q / dQ += dS K straight from the ROW-major [row][d] tile (gfx950 LDS transpose read): a 16-lane group hands
+// the hardware the sixteen 8-byte chunks of a [4 rows][16 columns] block and every lane receives ITS column's four row values — lane (j = lane & 31,
+// hi) ends up with rows r0 + 4 hi + {0..3} of head column j, exactly the half k-step the P / dS accumulator fragments pair with (measured with
+// tools/ubench/tr_probe.hip).  No [d][row] copies of Q / dO / K any more: half the stage writes and global fetches of the streamed side, and the three
+// tg_transpose_v passes per call are gone.  The asm result is consumed after an explicit s_waitcnt (the compiler cannot see the pending LDS read).
+__device__ __forceinline__ uint2 lds_tr_b64(const bf16_t* p) {
+    uint2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"((uint32_t)(uintptr_t)p) : "memory");
+    return r;
+}
+
 constexpr int BT = 32;                     // rows of the streamed tile
 constexpr int LQ2 = 72;                    // [row][d] tile: row stride in elements (144 B)
-constexpr int LT2 = 36;                    // [d][row] tile: row stride in elements (72 B = 18 banks: the 32 lanes of an 8-byte read — 32 head columns,
-                                           // one row each — land on 32 distinct bank pairs; 80 B put columns j and j+16 on the same banks: 2-way conflict
-                                           // on every B-operand read).  Rows are 8-byte aligned only: the stage writes them as two 8-byte halves
-constexpr int ROWT_EL = BT * LQ2, COLT_EL = 64 * LT2;
+constexpr int ROWT_EL = BT * LQ2;
 
 struct Bwd2Params {
     BwdParams p;
-    const bf16_t *qT, *doT, *kT;           // [batch][heads][64][ldq / ldq / ldk] (zero padded)
-    long ldq, ldk;
 };
 
 union Frag { bf16x8 v; uint2 u[2]; uint32_t w[4]; };
@@ -124,7 +130,6 @@ __device__ __forceinline__ uint4 ld_row16_clamped(const bf16_t* base, long ld, i
     return *(const uint4*)(base + (long)min(row, n - 1) * ld + col);
 }
 __device__ __forceinline__ uint4 mask16(uint4 v, bool ok) { return ok ? v : uint4{0, 0, 0, 0}; }
-__device__ __forceinline__ void st_2x8(bf16_t* dst, uint4 v) { ((uint2*)dst)[0] = uint2{v.x, v.y}; ((uint2*)dst)[1] = uint2{v.z, v.w}; }
 
 // ---- (1') statistics: one wave per 64 queries, keys streamed in tiles of 32 ----
 __global__ __launch_bounds__(256) void attn_bwd_stats2_kernel(BwdParams p) {
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) void attn_bwd_stats2_kernel(BwdParams p) {
 // per wave with one wave per SIMD and a hand-interleaved schedule, two 4-wave workgroups per CU, a two-deep ring, a two-group ping-pong (5 % slower). ----
 __global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
     const BwdParams& p = pp.p;
-    __shared__ __attribute__((aligned(16))) bf16_t sQ[3][ROWT_EL], sdO[3][ROWT_EL], sQt[3][COLT_EL], sdOt[3][COLT_EL];
+    __shared__ __attribute__((aligned(16))) bf16_t sQ[3][ROWT_EL], sdO[3][ROWT_EL];
     __shared__ __attribute__((aligned(16))) float sLse[3][BT], sD[3][BT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hi = lane >> 5;
@@ -224,8 +229,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
     const int kw0 = blk * 256 + wave * 32;
     const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
     const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
-    const bf16_t* qT = pp.qT + ((long)(b * p.heads + h) * 64) * pp.ldq;
-    const bf16_t* doT = pp.doT + ((long)(b * p.heads + h) * 64) * pp.ldq;
     const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
     const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
     const long stat0 = ((long)b * p.heads + h) * p.nq;
@@ -241,14 +244,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
     f32x16 dk[2], dv[2];                                   // [d block]: rows = keys, column = head dim j
 #pragma unroll
     for (int c = 0; c < 2; ++c) { dk[c] = zero16(); dv[c] = zero16(); }
-    const int half = tid >> 8, t8 = tid & 255;              // threads 0..255 stage Q and Q^T, 256..511 dO and dO^T
+    const int half = tid >> 8, t8 = tid & 255;              // threads 0..255 stage Q, 256..511 dO
     const int row = t8 >> 3, chunk = (t8 & 7) * 8;
-    const int drow = t8 >> 2, part = (t8 & 3) * 8;
     const bf16_t* const srcR = half ? dO : Q;
-    const bf16_t* const srcT = half ? doT : qT;
     const long ldR = half ? p.do_ld : p.q_ld;
+    // transpose-read base of this lane inside a [32][LQ2] tile: row 4 hi + (a >> 2), 4-element chunk (a & 3) of the 16 columns of its lane group
+    const int trb = (4 * hi + ((lane & 15) >> 2)) * LQ2 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
     const int ntile = (p.nq + BT - 1) / BT;
-    uint4 g0, g2;
+    uint4 g0;
     float gs = 0.f;
     bool okr = false, oks = false;
     const float* statp = (tid < BT ? p.lse : p.dsum) + stat0;
@@ -257,12 +260,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
     auto fetch = [&](int q0) {
         okr = q0 + row < p.nq; oks = q0 + (tid & 31) < p.nq;
         g0 = ld_row16_clamped(srcR, ldR, q0 + row, p.nq, chunk);
-        g2 = *(const uint4*)(srcT + (long)drow * pp.ldq + q0 + part);
         gs = statp[min(q0 + (tid & 31), p.nq - 1)];
     };
     auto stash = [&](int buf) {
         *(uint4*)((half ? sdO[buf] : sQ[buf]) + row * LQ2 + chunk) = mask16(g0, okr);
-        st_2x8((half ? sdOt[buf] : sQt[buf]) + drow * LT2 + part, g2);
         if (tid < 2 * BT) statdst[buf * BT] = oks ? gs : statmask;
     };
     fetch(0);
@@ -308,10 +309,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const int o = (db * 32 + j) * LT2 + 16 * t + 4 * hi;
-                bO[t][db].u[0] = *(const uint2*)(sdOt[buf] + o); bO[t][db].u[1] = *(const uint2*)(sdOt[buf] + o + 8);
-                bQ[t][db].u[0] = *(const uint2*)(sQt[buf] + o);  bQ[t][db].u[1] = *(const uint2*)(sQt[buf] + o + 8);
+                const int o = trb + 16 * t * LQ2 + db * 32;              // rows 16 t + 4 hi + {0..3}, then + 8
+                bO[t][db].u[0] = lds_tr_b64(sdO[buf] + o); bO[t][db].u[1] = lds_tr_b64(sdO[buf] + o + 8 * LQ2);
+                bQ[t][db].u[0] = lds_tr_b64(sQ[buf] + o);  bQ[t][db].u[1] = lds_tr_b64(sQ[buf] + o + 8 * LQ2);
             }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bO[0][0].v), "+v"(bO[0][1].v), "+v"(bO[1][0].v), "+v"(bO[1][1].v), "+v"(bQ[0][0].v), "+v"(bQ[0][1].v),
+                     "+v"(bQ[1][0].v), "+v"(bQ[1][1].v));
         TG_SB();
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
 // ---- (3') dQ: workgroup = 256 queries (64 per wave), keys streamed in tiles of 32 ----
 __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
     const BwdParams& p = pp.p;
-    __shared__ __attribute__((aligned(16))) bf16_t sK[2][ROWT_EL], sV[2][ROWT_EL], sKt[2][COLT_EL];
+    __shared__ __attribute__((aligned(16))) bf16_t sK[2][ROWT_EL], sV[2][ROWT_EL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hi = lane >> 5;
     int blk, hb;
@@ -359,7 +362,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
     const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
     const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
     const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
-    const bf16_t* kT = pp.kT + ((long)(b * p.heads + h) * 64) * pp.ldk;
     const long stat0 = ((long)b * p.heads + h) * p.nq;
     bf16x8 qf[2][4], of[2][4];                             // B operands: this wave's queries, resident in AGPRs
     float lse[2], dsum[2];
@@ -383,15 +385,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) dq[a][c] = zero16();
     const int row = tid >> 3, chunk = (tid & 7) * 8;
-    const int drow = tid >> 2, part = (tid & 3) * 8;
+    const int trb = (4 * hi + ((lane & 15) >> 2)) * LQ2 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;     // see attn_bwd_dkdv5_kernel
     const int ntile = (p.nk + BT - 1) / BT;
-    uint4 g0, g1, g2;
+    uint4 g0, g1;
     bool okr = false;
     // running pointers: tiles are fetched in order, so a tile that lies wholly inside the key range costs three loads and three pointer adds — the
     // clamped 64-bit index arithmetic is kept for the ragged last tile only (this kernel is VALU-bound: 61 % VALU busy against 51 % MFMA busy)
     const bf16_t* pK = Kp + (long)row * p.k_ld + chunk;
     const bf16_t* pV = Vp + (long)row * p.v_ld + chunk;
-    const bf16_t* pT = kT + (long)drow * pp.ldk + part;
     const long stepK = (long)BT * p.k_ld, stepV = (long)BT * p.v_ld;
     auto fetch = [&](int k0) {
         if (k0 + BT <= p.nk) {
@@ -403,13 +404,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
             g0 = ld_row16_clamped(Kp, p.k_ld, k0 + row, p.nk, chunk);
             g1 = ld_row16_clamped(Vp, p.v_ld, k0 + row, p.nk, chunk);
         }
-        g2 = *(const uint4*)pT;
-        pK += stepK; pV += stepV; pT += BT;
+        pK += stepK; pV += stepV;
     };
     auto stash = [&](int buf) {
         *(uint4*)(sK[buf] + row * LQ2 + chunk) = mask16(g0, okr);
         *(uint4*)(sV[buf] + row * LQ2 + chunk) = mask16(g1, okr);
-        st_2x8(sKt[buf] + drow * LT2 + part, g2);
     };
     fetch(0);
     stash(0);
@@ -429,9 +428,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const int o = (db * 32 + j) * LT2 + 16 * t + 4 * hi;
-                bK[t][db].u[0] = *(const uint2*)(sKt[buf] + o); bK[t][db].u[1] = *(const uint2*)(sKt[buf] + o + 8);
+                const int o = trb + 16 * t * LQ2 + db * 32;
+                bK[t][db].u[0] = lds_tr_b64(sK[buf] + o); bK[t][db].u[1] = lds_tr_b64(sK[buf] + o + 8 * LQ2);
             }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bK[0][0].v), "+v"(bK[0][1].v), "+v"(bK[1][0].v), "+v"(bK[1][1].v));
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 st, dpt;                                // rows = keys, column = query j
@@ -476,10 +476,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
 
 }  // namespace
 
-static inline long pad64(long n) { return (n + 63) / 64 * 64; }
-// statistics (2 floats per query row) + the transposed copies Q^T, dO^T, K^T (bf16 [batch][heads][64][padded length])
+// statistics: 2 floats per query row (log-sum-exp unless the forward kept it, and D)
 extern "C" long tg_attention_bwd_ws_floats(int nq, int nk, int heads, int batch) {
-    return 2L * batch * heads * nq + 8 + (long)batch * heads * 64 * (2 * pad64(nq) + pad64(nk)) / 2;
+    (void)nk;
+    return 2L * batch * heads * nq + 8;
 }
 
 
@@ -501,21 +501,11 @@ extern "C" int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void*
         hipLaunchKernelGGL(attn_bwd_stats2_kernel, dim3((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), dim3(256), 0, stream, p);
         return tg_attention_bwd_ref_launch(p, stream);
     }
-    const long nstat = ((2L * batch * heads * nq + 7) / 8) * 8;                    // keeps the bf16 arrays behind it 16-byte aligned
-    const long ldq = pad64(nq), ldk = pad64(nk);
-    bf16_t* qT = (bf16_t*)(ws + nstat);
-    bf16_t* doT = qT + (long)batch * heads * 64 * ldq;
-    bf16_t* kT = doT + (long)batch * heads * 64 * ldq;
-    int rc;
-    if ((rc = tg_transpose_v(q, q_ld, q_sb, 0, nq, heads, batch, qT, ldq, stream)) != TG_OK) return rc;
-    if ((rc = tg_transpose_v(dout, do_ld, do_sb, 0, nq, heads, batch, doT, ldq, stream)) != TG_OK) return rc;
-    if ((rc = tg_transpose_v(k, k_ld, k_sb, 0, nk, heads, batch, kT, ldk, stream)) != TG_OK) return rc;
     Bwd2Params pp{};
     pp.p = BwdParams{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, q_ld, q_sb, k_ld, k_sb, v_ld, v_sb,
                      o_ld, o_sb, do_ld, do_sb, dq, dk, dv, dq_ld, dq_sb, dk_ld, dk_sb, dv_ld, dv_sb, ws, ws + (long)batch * heads * nq, nq, nk, heads, batch,
                      scale * 1.4426950408889634f, scale, accumulate, lse ? 1 : 0};
     if (lse) pp.p.lse = const_cast<float*>(lse);
-    pp.qT = qT; pp.doT = doT; pp.kT = kT; pp.ldq = ldq; pp.ldk = ldk;
     const dim3 gq((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), gk((unsigned)((nk + 255) / 256), (unsigned)(batch * heads));
     hipLaunchKernelGGL(attn_bwd_stats2_kernel, gq, dim3(256), 0, stream, pp.p);
     hipLaunchKernelGGL(attn_bwd_dkdv5_kernel, dim3(gk.x * gk.y), dim3(512), 0, stream, pp);
