@@ -61,24 +61,38 @@ class Resampler:
         print(f"Successfully set pca: {pca_path}")
 
     @classmethod
-    def from_pretrained(cls, path, subfolder=None, torch_dtype=BF16, device="cuda", **unused):
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=BF16, device="cuda", broadcast=False, **unused):
         """diffusers' ModelMixin.from_pretrained as the entry script uses it (infer_cogvideo_mp_fifo.py:113-117, 162-166):
-        <path>/<subfolder>/config.json + diffusion_pytorch_model.safetensors (or the sharded index)."""
+        <path>/<subfolder>/config.json + diffusion_pytorch_model.safetensors (or the sharded index).
+        broadcast=True (torch.distributed initialised): rank 0 reads the weights, the other ranks receive them (runtime.broadcast_weights)."""
         from safetensors.torch import load_file
         d = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(d, "config.json")) as f:
             cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
         m = cls(**cfg, device=device)
-        idx = os.path.join(d, "diffusion_pytorch_model.safetensors.index.json")
-        if os.path.exists(idx):
-            with open(idx) as f:
-                files = sorted(set(json.load(f)["weight_map"].values()))
-        else:
-            files = ["diffusion_pytorch_model.safetensors"]
-        sd = {}
-        for fn in files:
-            sd.update(load_file(os.path.join(d, fn)))
-        m.load_state_dict(sd)
+        rank = 0
+        if broadcast:
+            import torch.distributed as dist
+            broadcast = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            rank = dist.get_rank() if broadcast else 0
+        if rank == 0:
+            idx = os.path.join(d, "diffusion_pytorch_model.safetensors.index.json")
+            if os.path.exists(idx):
+                with open(idx) as f:
+                    files = sorted(set(json.load(f)["weight_map"].values()))
+            else:
+                files = ["diffusion_pytorch_model.safetensors"]
+            sd = {}
+            for fn in files:
+                sd.update(load_file(os.path.join(d, fn)))
+            m.load_state_dict(sd)
+        if broadcast:
+            from .runtime import broadcast_weights
+            meta = [[(k, tuple(v.shape)) for k, v in sorted(m._sd.items())] if rank == 0 else None]
+            dist.broadcast_object_list(meta, src=0)              # the Resampler has no static shape table: names and shapes travel first
+            if rank != 0:
+                m.load_state_dict({k: torch.zeros(sh, dtype=BF16) for k, sh in meta[0]})
+            broadcast_weights(m, src=0)
         return m
 
     def save_pretrained(self, path):
