@@ -77,6 +77,14 @@ if mode == "broadcast":                 # runtime.broadcast_weights: rank 0 owns
     sd2 = m2.state_dict()
     base = {k: v for k, v in want.items() if "vip_" not in k}
     ok = ok and all(torch.equal(sd2[k], base[k]) for k in base)
+    # (c) the Resampler: no static shape table, names and shapes travel first
+    from oracle import resampler_ref as RR
+    from tokensgen_amd.resampler import Resampler
+    rcfg = dict(dim=128, depth=2, dim_head=64, heads=2, num_height_queries=2, num_width_queries=3, num_temporal_queries=4, embedding_dim=128, output_dim=128, ff_mult=4)
+    rwant = {k: v.to(torch.bfloat16) for k, v in RR.make_state_dict(rcfg, seed=78).items()}
+    rs = Resampler.from_pretrained(os.path.join(outdir, f"rs{rank}"), device="cpu", broadcast=True)
+    rsd = rs.state_dict()
+    ok = ok and sorted(rsd) == sorted(rwant) and all(torch.equal(rsd[k], rwant[k]) for k in rwant)
     done("ok" if ok else "mismatch")
     dist.destroy_process_group()
     sys.exit(0)

@@ -74,6 +74,13 @@ def test_weight_broadcast_two_ranks(tmp_path):
         d.mkdir()
         (d / "config.json").write_text(json.dumps(dict(cfg, _class_name="CogVideoXTransformer3DModel")))
     save_file(sd, str(tmp_path / "ckpt0" / "diffusion_pytorch_model.safetensors"))
+    from oracle import resampler_ref as RR
+    rcfg = dict(dim=128, depth=2, dim_head=64, heads=2, num_height_queries=2, num_width_queries=3, num_temporal_queries=4, embedding_dim=128, output_dim=128, ff_mult=4)
+    for r in (0, 1):
+        d = tmp_path / f"rs{r}"
+        d.mkdir()
+        (d / "config.json").write_text(json.dumps(dict(rcfg, _class_name="Resampler")))
+    save_file({k: v.to(torch.bfloat16).contiguous() for k, v in RR.make_state_dict(rcfg, seed=78).items()}, str(tmp_path / "rs0" / "diffusion_pytorch_model.safetensors"))
     launch(2, [sys.executable, WORKER, "broadcast", str(tmp_path)])
     assert _read(tmp_path, 0) == "ok" and _read(tmp_path, 1) == "ok"
 
