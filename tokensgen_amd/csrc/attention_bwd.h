@@ -14,6 +14,7 @@ struct BwdParams {
     float *dq, *dk, *dv;
     long dq_ld, dq_sb, dk_ld, dk_sb, dv_ld, dv_sb;
     float *lse, *dsum;                     // [batch][heads][nq] fp32 workspaces
+    uint4* seed;                           // [batch][heads][nq] 16-byte seed rows of the dK/dV kernel (attn_bwd_stats2_kernel writes them)
     int nq, nk, heads, batch;
     float scale_log2, scale;
     int accumulate;

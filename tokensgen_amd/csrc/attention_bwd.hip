@@ -130,10 +130,29 @@ __device__ __forceinline__ uint4 ld_row16_clamped(const bf16_t* base, long ld, i
     return *(const uint4*)(base + (long)min(row, n - 1) * ld + col);
 }
 __device__ __forceinline__ uint4 mask16(uint4 v, bool ok) { return ok ? v : uint4{0, 0, 0, 0}; }
+// component-wise: `c ? a : b` on two uint4 lvalues becomes a pointer select and sends both to scratch memory
+__device__ __forceinline__ uint4 sel16(bool c, uint4 a, uint4 b) { return uint4{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w}; }
 
-// ---- (1') statistics: one wave per 64 queries, keys streamed in tiles of 32 ----
+// x = a + b + c to 2^-24 of x, each term the upper half of an fp32 word (= a bf16 value): the pieces of a statistic that travels through the matrix pipe
+__device__ __forceinline__ void split_bf16x3(float x, uint32_t& a, uint32_t& b, uint32_t& c) {
+    a = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(a);
+    b = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(b);
+    c = __float_as_uint(r2) & 0xffff0000u;
+}
+// the dK/dV kernel's per-query seed row: bf16 k-slots [l1 l2 l3 d1 d2 d3 0 0] with l = -lse / scale_log2 and d = -D in three pieces each
+__device__ __forceinline__ uint4 seed_row(float lse, float dsum, float scale_log2) {
+    uint32_t l1, l2, l3, d1, d2, d3;
+    split_bf16x3(-lse / scale_log2, l1, l2, l3);
+    split_bf16x3(-dsum, d1, d2, d3);
+    return uint4{(l1 >> 16) | l2, (l3 >> 16) | d1, (d2 >> 16) | d3, 0u};
+}
+
+// ---- (1') statistics: one wave per 64 queries, keys streamed in tiles of 32; also packs the dK/dV kernel's seed rows ----
 __global__ __launch_bounds__(256) void attn_bwd_stats2_kernel(BwdParams p) {
     __shared__ __attribute__((aligned(16))) bf16_t sK[2][ROWT_EL];
+    __shared__ float sDs[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hi = lane >> 5;
     const int h = blockIdx.y % p.heads, b = blockIdx.y / p.heads;
@@ -155,6 +174,8 @@ __global__ __launch_bounds__(256) void attn_bwd_stats2_kernel(BwdParams p) {
                 for (int e = 0; e < 4; ++e) d += bf16lo_to_f32(au[e]) * bf16lo_to_f32(cu[e]) + bf16hi_to_f32(au[e]) * bf16hi_to_f32(cu[e]);
             }
             p.dsum[stat0 + r] = d;
+            sDs[tid] = d;
+            if (p.have_lse) p.seed[stat0 + r] = seed_row(p.lse[stat0 + r], d, p.scale_log2);
         }
     }
     if (p.have_lse) return;
@@ -208,7 +229,11 @@ __global__ __launch_bounds__(256) void attn_bwd_stats2_kernel(BwdParams p) {
         const float M = fmaxf(m[qb], mo);
         const float Lsum = l[qb] * fast_exp2(m[qb] - M) + lo * fast_exp2(mo - M);
         const int q = q0 + qb * 32 + j;
-        if (hi == 0 && q < p.nq) p.lse[stat0 + q] = M + log2f(Lsum);
+        if (hi == 0 && q < p.nq) {
+            const float lse = M + log2f(Lsum);
+            p.lse[stat0 + q] = lse;
+            p.seed[stat0 + q] = seed_row(lse, sDs[wave * 64 + qb * 32 + j], p.scale_log2);      // sDs: written before the tile loop's barriers
+        }
     }
 }
 
@@ -331,6 +356,250 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
         buf = nbuf;
     }
     asm volatile("s_nop 15" ::: "memory");
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        float* DK = p.dk + (long)b * p.dk_sb + h * HD + db * 32 + j;
+        float* DV = p.dv + (long)b * p.dv_sb + h * HD + db * 32 + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kw0 + acc_row(r, hi);
+            if (key >= p.nk) continue;
+            float* a = DK + (long)key * p.dk_ld;
+            float* c = DV + (long)key * p.dv_ld;
+            const float vk = dk[db][r] * p.scale, vv = dv[db][r];
+            *a = (p.accumulate & 2) ? *a + vk : vk;
+            *c = (p.accumulate & 2) ? *c + vv : vv;
+        }
+    }
+}
+
+#define BWD_BAR() do { TG_SB(); __builtin_amdgcn_s_barrier(); TG_SB(); } while (0)
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }      // the low 32 bits of a flat LDS address are the LDS offset
+
+// ---- (2'') dK, dV as a two-group ping-pong (the forward's structure): 8 waves x 32 keys, queries in tiles of 32 through a three-deep LDS ring.
+// The in-phase kernel (attn_bwd_dkdv5_kernel) measured per tile and wave: S/dP MFMAs 560-860 cycles, softmax 820-1030, transposed reads 370, dV/dK
+// MFMAs 250, stage 200, barrier 130-600 — the two waves of a SIMD run the same phase at the same time, so their MFMA blocks collide and their VALU
+// blocks collide, and every LDS read is waited for where it is used.  Here every wave alternates
+//     X(t) = { dV += P(t-1)^T dO(t-1), dK += dS(t-1)^T Q(t-1) ; S(t) = Q(t) K^T, dP(t) = dO(t) V^T }    18 MFMAs, ALL LDS reads (16 transposed b64 + 9 b128),
+//                                                                                                     each read issued two MFMA pairs ahead of its use
+//     Y(t) = { P = exp2(c S), dS = P o dP -> bf16 A operands ; stage write of a later tile ; next global fetch }      VALU only
+// with one s_barrier after each segment and group 1 (waves 4-7) one segment behind group 0.
+// The row statistics ride on the matrix pipe: S must become scale_log2 * (q.k) - lse and dP must become dP - D, both per QUERY ROW, which in this
+// accumulator layout (rows = queries) costs every lane 8 ds_read_b128 and 32 VALU operations per tile.  Instead the stager splits -lse / scale_log2 and -D
+// into three bf16 pieces each (exact to 2^-24) and leaves them as one 16-byte A-operand row per query: [l1 l2 l3 d1 d2 d3 0 0]; one extra k-step against the
+// constant B operands [1 1 1 0 0 0 0 0] / [0 0 0 1 1 1 0 0] seeds both accumulators (2 MFMAs, 1 ds_read_b128 per wave and tile).
+// Ring: tile u lives in buffer u % 4, is read in X(u) (A operands) and X(u+1) (transposed operands) of both groups = intervals 2u .. 2u+3, and is
+// written by group 0 (Q + statistics) in its Y(u-2) = interval 2u-3 and by group 1 (dO) in its Y(u-3) = interval 2u-4, complete (the writer's next X ends
+// with lgkmcnt(0)) one barrier before interval 2u; the tile it replaces (u-4) was last read in interval 2u-5. ----
+__global__ __launch_bounds__(512) void attn_bwd_dkdv7_kernel(Bwd2Params pp) {
+    const BwdParams& p = pp.p;
+    constexpr int RING = 4;
+    constexpr int DO_OFF = RING * ROWT_EL * 2;              // byte distance sT[0][b] -> sT[1][b]
+    __shared__ __attribute__((aligned(16))) bf16_t sT[2][RING][ROWT_EL];    // [0] Q tiles, [1] dO tiles
+    __shared__ __attribute__((aligned(16))) uint4 sSt[RING][64];               // seed operand rows (entries 32..63 stay zero: the hi lanes' k-slots)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int j = lane & 31, hi = lane >> 5;
+    int blk, hb;
+    xcd_block((p.nk + 255) / 256, p.heads * p.batch, blk, hb);
+    const int h = hb % p.heads, b = hb / p.heads;
+    const int kw0 = blk * 256 + wave * 32;
+    const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
+    const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
+    const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
+    const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
+    const long stat0 = ((long)b * p.heads + h) * p.nq;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const long r = min(kw0 + j, p.nk - 1);
+        load_frag_agpr(kf[ks], Kp + r * p.k_ld + ks * 16 + hi * 8);
+        load_frag_agpr(vf[ks], Vp + r * p.v_ld + ks * 16 + hi * 8);
+    }
+    TG_WAIT_FRAGS1(kf);
+    TG_WAIT_FRAGS1(vf);
+    Frag oS, oD;                                            // B operands of the seed k-step (k-slots 0..2 -> S, 3..5 -> dP; lanes hi = 0 only)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { oS.w[w] = 0; oD.w[w] = 0; }
+    if (hi == 0) { oS.w[0] = 0x3F803F80u; oS.w[1] = 0x00003F80u; oD.w[1] = 0x3F800000u; oD.w[2] = 0x3F803F80u; }
+    f32x16 dk[2], dv[2];                                   // [d block]: rows = keys, column = head dim j
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { dk[c] = zero16(); dv[c] = zero16(); }
+    // staging: group 0's threads own Q (+ wave 0, lanes 0..31: the statistics), group 1's dO; one 16-byte chunk per thread and tile
+    const int t8 = tid & 255, row = t8 >> 3, chunk = (t8 & 7) * 8;
+    const bf16_t* const srcR = grp ? dO : Q;
+    const long ldR = grp ? p.do_ld : p.q_ld;
+    bf16_t* const dstR = &sT[grp][0][0] + row * LQ2 + chunk;
+    const int ntile = (p.nq + BT - 1) / BT;
+    // running pointers: a tile that lies wholly inside the query range costs one load and one pointer add (and one more of each for the seed rows in
+    // wave 0); clamped rows + masking for the ragged last tile only.  VALU work in Y is expensive: the partner wave's MFMA stream owns the issue port
+    // (measured ~13 cycles per VALU instruction there), the address arithmetic of the first version cost 270-370 cycles per tile
+    const bf16_t* pR = srcR + (long)row * ldR + chunk;
+    const long stepR = (long)BT * ldR;
+    const uint4* pS = p.seed + stat0 + j;
+    // the last tile (and the never-read ones behind it) comes from clamped rows and is masked at the LDS write.  Loads stay unconditional and
+    // branch-free (a load under a branch made hipcc wait for it on the spot: 2000 cycles per tile)
+    const int qlast = (ntile - 1) * BT;
+    const bf16_t* const pLast = srcR + (long)min(qlast + row, p.nq - 1) * ldR + chunk;
+    const uint4* const pSLast = p.seed + stat0 + min(qlast + j, p.nq - 1);
+    const bool okLast = qlast + row < p.nq, okSLast = qlast + j < p.nq;
+    uint4 maskrow;                                          // seed row of a masked query: l = -1e30 (P = exp2(c (s - 1e30)) = 0), d = 0
+    {
+        uint32_t l1, l2, l3;
+        split_bf16x3(-1e30f, l1, l2, l3);
+        maskrow = uint4{(l1 >> 16) | l2, l3 >> 16, 0u, 0u};
+    }
+    uint4 g0, gseed = maskrow;
+    bool inner = true;                                      // the fetched tile lies wholly inside the query range
+    int tf = 0;                                             // tile the next fetch() loads
+    auto fetch = [&]() {
+        inner = tf < ntile - 1;
+        g0 = *(const uint4*)(inner ? pR : pLast);
+        if (wave == 0) gseed = *(inner ? pS : pSLast);
+        pR += stepR; pS += BT;
+        ++tf;
+    };
+    auto stash = [&](int buf) {
+        if (inner) {
+            *(uint4*)(dstR + buf * ROWT_EL) = g0;
+            if (wave == 0 && hi == 0) sSt[buf][j] = gseed;
+        } else {
+            *(uint4*)(dstR + buf * ROWT_EL) = mask16(g0, okLast);
+            if (wave == 0 && hi == 0) sSt[buf][j] = sel16(okSLast, gseed, maskrow);
+        }
+    };
+    // prologue: Q(0), Q(1) + their statistics, dO(0..2); the buffers of "tile -1" (index RING - 1) zeroed — X(0) multiplies them by P = dS = 0
+    *(uint4*)(dstR + (RING - 1) * ROWT_EL) = uint4{0, 0, 0, 0};
+    if (wave == 0 && hi == 1) {
+#pragma unroll
+        for (int bb = 0; bb < RING; ++bb) sSt[bb][lane] = uint4{0, 0, 0, 0};
+    }
+    fetch();
+    stash(0);
+    fetch();
+    stash(1);
+    fetch();
+    if (grp == 1) {
+        stash(2);
+        fetch();
+    }
+    Frag pA[2], dA[2];                                      // P^T / dS^T A operands, carried from Y(t) to X(t+1)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { pA[t].w[w] = 0; dA[t].w[w] = 0; }
+    f32x16 s, dp;                                           // rows = queries, column = key j
+    // lane bases inside a tile: A rows (row j, 16-byte slot hi of every k-step), transposed 4 x 16 blocks (see lds_tr_b64), seed rows
+    const uint32_t offA = (uint32_t)((j * LQ2 + hi * 8) * 2);
+    const uint32_t offB = (uint32_t)(((4 * hi + ((lane & 15) >> 2)) * LQ2 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2);
+    const uint32_t ldsT = lds_addr(&sT[0][0][0]), ldsS = lds_addr(&sSt[0][0]) + (uint32_t)lane * 16;
+    Frag fr[4][2];
+    // dV / dK products of the tile in buffer pb: fragment group i (t2 = i >> 1, db = i & 1) = 4 transposed reads
+#define BWD_RD_T(dst, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(vB), "i"(off))
+#define BWD_RD_A(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "i"(off))
+#define BWD_WAIT(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0].v), "+v"(f[1].v))
+    auto xseg = [&](const int cb, const int pb, const bool tail) {
+        const uint32_t vB = ldsT + (uint32_t)(pb * ROWT_EL * 2) + offB;
+        const uint32_t vA = ldsT + (uint32_t)(cb * ROWT_EL * 2) + offA;
+        const uint32_t vS = ldsS + (uint32_t)(cb * 1024);
+        // (every MFMA statement starts with s_nop 1: hipcc pads VALU -> MFMA-operand hazards only for instructions it knows, and it does move
+        //  accumulator blocks between AGPR ranges with v_accvgpr_mov right in front of these statements — without the wait states the products
+        //  read the accumulator's old contents)
+        // fragment group i: 0..3 = transposed dO | Q blocks (t2 = i >> 1, db = i & 1) of tile pb, 4 = seed row, 5..8 = Q | dO rows of k-step i - 5 of tile cb
+#define BWD_ISSUE(i)                                                                                                              \
+        do {                                                                                                                      \
+            Frag(&f)[2] = fr[(i) & 3];                                                                                            \
+            if ((i) < 4) {                                                                                                        \
+                constexpr int o = ((i) >> 1) * (16 * LQ2 * 2) + ((i) & 1) * 64;                                                   \
+                BWD_RD_T(f[0].u[0], DO_OFF + o); BWD_RD_T(f[0].u[1], DO_OFF + o + 8 * LQ2 * 2);                                   \
+                BWD_RD_T(f[1].u[0], o);          BWD_RD_T(f[1].u[1], o + 8 * LQ2 * 2);                                            \
+            } else if ((i) == 4) {                                                                                                \
+                BWD_RD_A(f[0].v, vS, 0);                                                                                          \
+            } else {                                                                                                              \
+                constexpr int ks = (i) >= 5 ? (i) - 5 : 0;                                                                        \
+                BWD_RD_A(f[0].v, vA, ks * 32); BWD_RD_A(f[1].v, vA, DO_OFF + ks * 32);                                            \
+            }                                                                                                                     \
+        } while (0)
+#define BWD_CONSUME(i)                                                                                                            \
+        do {                                                                                                                      \
+            Frag(&f)[2] = fr[(i) & 3];                                                                                            \
+            if ((i) < 4) {                                                                                                        \
+                constexpr int t2 = ((i) >> 1) & 1, db = (i) & 1;                                                                  \
+                asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dv[db]) : "v"(pA[t2].v), "v"(f[0].v));              \
+                asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dk[db]) : "v"(dA[t2].v), "v"(f[1].v));              \
+            } else if ((i) == 4) {                                                                                                \
+                asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %3, 0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, 0"                   \
+                    : "=&v"(s), "=&v"(dp) : "v"(f[0].v), "a"(oS.v), "a"(oD.v));                                                   \
+            } else {                                                                                                              \
+                constexpr int ks = (i) >= 5 ? (i) - 5 : 0;                                                                        \
+                asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %5, %1"                 \
+                    : "+v"(s), "+v"(dp) : "v"(f[0].v), "v"(f[1].v), "a"(kf[ks]), "a"(vf[ks]));                                    \
+            }                                                                                                                     \
+        } while (0)
+        // reads run three groups ahead of their MFMAs (at most 13 LDS operations in flight: lgkmcnt has 4 bits); lgkmcnt(n) = the reads of the
+        // younger groups that may still be in flight (LDS returns in order).  Groups 0..2 were issued by xprefetch() BEFORE the barrier that
+        // opens this segment (the tile they read was complete long ago), so the segment starts on landed data
+        if (tail) {
+            TG_SB(); BWD_WAIT(8, fr[0]); BWD_ISSUE(3); TG_SB(); BWD_CONSUME(0);
+            TG_SB(); BWD_WAIT(8, fr[1]); BWD_CONSUME(1);
+            TG_SB(); BWD_WAIT(4, fr[2]); BWD_CONSUME(2);
+            TG_SB(); BWD_WAIT(0, fr[3]); BWD_CONSUME(3);
+            TG_SB();
+            return;
+        }
+        TG_SB(); BWD_WAIT(8, fr[0]); BWD_ISSUE(3); TG_SB(); BWD_CONSUME(0); TG_SB(); BWD_ISSUE(4);
+        TG_SB(); BWD_WAIT(9, fr[1]); BWD_CONSUME(1); TG_SB(); BWD_ISSUE(5);
+        TG_SB(); BWD_WAIT(7, fr[2]); BWD_CONSUME(2); TG_SB(); BWD_ISSUE(6);
+        TG_SB(); BWD_WAIT(5, fr[3]); BWD_CONSUME(3); TG_SB(); BWD_ISSUE(7);
+        TG_SB(); BWD_WAIT(6, fr[0]); BWD_CONSUME(4); TG_SB(); BWD_ISSUE(8);
+        TG_SB(); BWD_WAIT(6, fr[1]); BWD_CONSUME(5);
+        TG_SB(); BWD_WAIT(4, fr[2]); BWD_CONSUME(6);
+        TG_SB(); BWD_WAIT(2, fr[3]); BWD_CONSUME(7);
+        TG_SB(); BWD_WAIT(0, fr[0]); BWD_CONSUME(8);
+        TG_SB();
+        asm volatile("s_nop 11" : "+v"(s), "+v"(dp));      // an 8-pass MFMA result needs 12 wait states before VALU reads it (the barrier may be short)
+    };
+    auto xprefetch = [&](const int pb) {                    // fragment groups 0..2 of the next X: transposed blocks of the tile in buffer pb
+        const uint32_t vB = ldsT + (uint32_t)(pb * ROWT_EL * 2) + offB, vA = 0, vS = 0;     // (vA, vS: dead branches of the macro)
+        BWD_ISSUE(0); BWD_ISSUE(1); BWD_ISSUE(2);
+    };
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    xprefetch(RING - 1);
+    if (grp == 1) BWD_BAR();                                // group 1 falls one segment behind group 0
+    int cb = 0, pb = RING - 1, wb = 2 + grp;                // current / previous tile buffer; buffer this thread stages next
+    for (int it = 0; it < ntile; ++it) {
+        // ---------------- X(it): matrix segment ----------------
+        __builtin_amdgcn_s_setprio(2);
+        xseg(cb, pb, false);
+        __builtin_amdgcn_s_setprio(0);
+        BWD_BAR();
+        // ---------------- Y(it): vector segment ----------------
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const float p0 = fast_exp2(s[4 * g + e] * p.scale_log2), p1 = fast_exp2(s[4 * g + e + 1] * p.scale_log2);
+                const float ds0 = p0 * dp[4 * g + e], ds1 = p1 * dp[4 * g + e + 1];
+                pA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2_trans(p0, p1);
+                dA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2(ds0, ds1);
+            }
+        stash(wb);                                          // tile it + 2 + grp (fetched one tile period ago); its LDS write is not waited for here: the
+                                                            // partner group's X keeps the LDS queue full (measured 450-700 cycles), and the tile is first read two
+                                                            // barriers from now — this wave's own reads in X(it + 1) return behind the write
+        fetch();
+        wb = (wb + 1) & (RING - 1);
+        pb = cb;
+        cb = (cb + 1) & (RING - 1);
+        TG_SB();
+        xprefetch(pb);
+        BWD_BAR();
+    }
+    __builtin_amdgcn_s_setprio(2);
+    xseg(cb, pb, true);                                     // X(ntile): the last tile's dV / dK products
+    __builtin_amdgcn_s_setprio(0);
+    if (grp == 0) BWD_BAR();                                // pairs with group 1's extra barrier
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
         float* DK = p.dk + (long)b * p.dk_sb + h * HD + db * 32 + j;
@@ -476,10 +745,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
 
 }  // namespace
 
-// statistics: 2 floats per query row (log-sum-exp unless the forward kept it, and D)
+// statistics: 2 floats per query row (log-sum-exp unless the forward kept it, and D) + the 16-byte seed row of the dK/dV kernel
 extern "C" long tg_attention_bwd_ws_floats(int nq, int nk, int heads, int batch) {
     (void)nk;
-    return 2L * batch * heads * nq + 8;
+    return 6L * batch * heads * nq + 8;
 }
 
 
@@ -494,21 +763,24 @@ extern "C" int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void*
     TG_REQUIRE(tg_aligned16(q) && tg_aligned16(k) && tg_aligned16(v) && tg_aligned16(o) && tg_aligned16(dout) && tg_aligned16(ws) && q_ld % 8 == 0 &&
                k_ld % 8 == 0 && v_ld % 8 == 0 && o_ld % 8 == 0 && do_ld % 8 == 0 && q_sb % 8 == 0 && k_sb % 8 == 0 && v_sb % 8 == 0 && o_sb % 8 == 0 &&
                do_sb % 8 == 0, TG_ERR_ALIGN, "tg_attention_bwd: q/k/v/o/dO need 16-byte aligned rows");
+    const long nrow = (long)batch * heads * nq;               // workspace: seed rows (16 B each, first: alignment) | log-sum-exp | D
     if (v1) {
         const BwdParams p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, q_ld, q_sb, k_ld, k_sb, v_ld, v_sb,
-                          o_ld, o_sb, do_ld, do_sb, dq, dk, dv, dq_ld, dq_sb, dk_ld, dk_sb, dv_ld, dv_sb, ws, ws + (long)batch * heads * nq, nq, nk, heads,
+                          o_ld, o_sb, do_ld, do_sb, dq, dk, dv, dq_ld, dq_sb, dk_ld, dk_sb, dv_ld, dv_sb, ws + 4 * nrow, ws + 5 * nrow, (uint4*)ws, nq, nk, heads,
                           batch, scale * 1.4426950408889634f, scale, accumulate, 0};
         hipLaunchKernelGGL(attn_bwd_stats2_kernel, dim3((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), dim3(256), 0, stream, p);
         return tg_attention_bwd_ref_launch(p, stream);
     }
     Bwd2Params pp{};
     pp.p = BwdParams{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, q_ld, q_sb, k_ld, k_sb, v_ld, v_sb,
-                     o_ld, o_sb, do_ld, do_sb, dq, dk, dv, dq_ld, dq_sb, dk_ld, dk_sb, dv_ld, dv_sb, ws, ws + (long)batch * heads * nq, nq, nk, heads, batch,
+                     o_ld, o_sb, do_ld, do_sb, dq, dk, dv, dq_ld, dq_sb, dk_ld, dk_sb, dv_ld, dv_sb, ws + 4 * nrow, ws + 5 * nrow, (uint4*)ws, nq, nk, heads, batch,
                      scale * 1.4426950408889634f, scale, accumulate, lse ? 1 : 0};
     if (lse) pp.p.lse = const_cast<float*>(lse);
     const dim3 gq((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), gk((unsigned)((nk + 255) / 256), (unsigned)(batch * heads));
     hipLaunchKernelGGL(attn_bwd_stats2_kernel, gq, dim3(256), 0, stream, pp.p);
-    hipLaunchKernelGGL(attn_bwd_dkdv5_kernel, dim3(gk.x * gk.y), dim3(512), 0, stream, pp);
+    static const bool old5 = [] { const char* e = getenv("TG_ATTN_BWD_DKDV"); return e && e[0] == '5'; }();
+    if (old5) hipLaunchKernelGGL(attn_bwd_dkdv5_kernel, dim3(gk.x * gk.y), dim3(512), 0, stream, pp);
+    else hipLaunchKernelGGL(attn_bwd_dkdv7_kernel, dim3(gk.x * gk.y), dim3(512), 0, stream, pp);
     hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(gq.x * gq.y), dim3(256), 0, stream, pp);
     TG_LAUNCH_CHECK("tg_attention_bwd");
     return TG_OK;
