@@ -66,3 +66,11 @@ def pytest_sessionfinish(session, exitstatus):
             json.dump(old, f, indent=1, sort_keys=True)
     except OSError:
         pass
+
+
+def free_port():
+    """A TCP port nobody listens on right now (bound on 127.0.0.1 and released): rendezvous port of the multi-process gloo tests."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

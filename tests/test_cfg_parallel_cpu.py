@@ -29,7 +29,7 @@ def _worker(rank, world, port, q):
             calls.append(h)
             return _half(h)
         out = CP.predict(mode, fh, lambda: (_ for _ in ()).throw(AssertionError("batched forward must not run")))
-        q.put((rank, mode, calls, out))
+        q.put((rank, mode, calls, out.numpy()))      # by value: a tensor travels as a shared-memory handle that dies with this process
     finally:
         dist.destroy_process_group()
 
@@ -39,7 +39,8 @@ def test_cfg_parallel_three_ranks_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31000 + os.getpid() % 2000
+    from conftest import free_port
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, 3, port, q)) for r in range(3)]
     for p in procs:
         p.start()
@@ -49,7 +50,7 @@ def test_cfg_parallel_three_ranks_gloo():
     want = torch.cat([_half(0), _half(1)])
     for r in range(3):
         mode, calls, out = got[r]
-        assert mode == "parallel" and calls == [r % 2] and torch.equal(out, want)
+        assert mode == "parallel" and calls == [r % 2] and torch.equal(torch.from_numpy(out), want)
 
 
 def test_cfg_parallel_modes_single_process():

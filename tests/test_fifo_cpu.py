@@ -132,7 +132,7 @@ def _worker(rank, world, port, q):
     try:
         out = _product_run(_inputs())
         dec = _product_run(_inputs(2), output_type="pt")
-        q.put((rank, out.float(), dec.float()))
+        q.put((rank, out.float().numpy(), dec.float().numpy()))      # by value: a tensor travels as a shared-memory handle that dies with this process
     finally:
         dist.destroy_process_group()
 
@@ -143,13 +143,14 @@ def test_driver_two_ranks_gloo_matches_single():
     ref = _product_run(_inputs())          # single-process product result (itself checked against the oracle above)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    from conftest import free_port
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     ref_dec = _product_run(_inputs(2), output_type="pt")      # 2 chunks: one per rank in the sharded decode, + the 1-chunk orig video
     assert ref_dec.shape == (1, 3, 3 * 49, 2 * H, 2 * W)
-    got = {r: (o, dcd) for r, o, dcd in (q.get(timeout=280) for _ in range(2))}
+    got = {r: (torch.from_numpy(o), torch.from_numpy(dcd)) for r, o, dcd in (q.get(timeout=280) for _ in range(2))}
     for p in procs:
         p.join(timeout=60)
     assert torch.equal(got[0][0], ref.float()) and torch.equal(got[1][0], ref.float())
