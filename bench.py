@@ -331,7 +331,7 @@ def run_train(a, rank, world, device, dist):
         micro()
     step.micro = 0                                    # the timed region starts at the beginning of an accumulation window
     K.PROFILE_ON[0] = True
-    K.PROFILE_FILTER[0] = {"attention_bwd"}
+    K.PROFILE_FILTER[0] = None if os.environ.get("TG_BENCH_PROFILE_ALL") == "1" else {"attention_bwd"}     # 1: every launch timed (per-shape table, slower step)
     fence()
     t0 = time.perf_counter()
     n_opt = 0
@@ -366,6 +366,8 @@ def run_train(a, rank, world, device, dist):
                          "achieved": alg / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else None, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": (alg / (tot_ms * 1e-3) / 1e12 / 2500.0) if tot_ms > 0 else None, "traffic": None,
                          "ms_per_micro_step_in_this_kernel": tot_ms, "launches_per_micro_step": prof["n"] / max(1, a.steps)},
+            **({"kernel_ms_per_micro_step": {k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(K.profile_summary().items(), key=lambda kv: -kv[1]["total_ms"])},
+                "launches_per_micro_step": {k: v["n"] / a.steps for k, v in K.profile_summary().items()}} if K.PROFILE_FILTER[0] is None else {}),
             "loss": float(loss), "grad_norm_last_step": float(opt.coef[0]) if n_opt else None,
             "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))
 

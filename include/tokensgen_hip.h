@@ -302,7 +302,8 @@ long tg_qk_layernorm_rope_bwd_partial_floats(int tokens, int heads, int batch);
  * padded to the GEMM's K granule; input gradients dX = dY W = tg_gemm(A = dY, W = W^T). */
 int tg_transpose_2d(const void* src, long ld, int rows, int cols, void* dst, long ld_dst, int rows_pad, hipStream_t stream);
 
-/* Bias gradients: partial[blk][c] = sum of src[r][c] over the block's 256 rows (bf16 in, fp32 out; tg_colsum_partial_floats floats). */
+/* Bias gradients: partial[blk][c] = sum of src[r][c] over the block's rows (bf16 in, fp32 out; tg_colsum_partial_floats floats = blocks * cols:
+ * 256 rows per block for tall matrices, fewer for short ones — a function of (rows, cols) only, so the summation order is fixed). */
 int tg_colsum(const void* src, long ld, int rows, int cols, float* partial, hipStream_t stream);
 long tg_colsum_partial_floats(int rows, int cols);
 
@@ -318,11 +319,13 @@ int tg_adaln_modulate_bwd(const void* x, long ldx, long strideX, const void* dy,
 
 /* Backward of the gated residual out = res + gate[g] y (cogvideox_transformer_3d.py:290-293, 318-324): dy = gate[g] dout (bf16), t_dgate = dout y (fp32
  * [batch][tokens - t_row0][dim], written for the token rows >= t_row0 only — the group whose gate trains; column sums over a group's rows =
- * d gate[g]); d res = dout. */
+ * d gate[g]); d res = dout.  y is read for the token rows >= t_row0 only: a caller that kept just those rows passes the address row 0 WOULD have
+ * (first kept row - t_row0 * ldy elements). */
 int tg_gate_residual_bwd(const void* dout, long ld_dout, long stride_dout, const void* y, long ldy, long strideY, void* dy, long ld_dy, long stride_dy,
                          int tokens, int dim, int batch, const tg_group_table* gate, float* t_dgate, int t_row0, hipStream_t stream);
 
-/* Elementwise: mode 0 out = silu(x); mode 1 out = dy * gelu_tanh'(x) (the FeedForward activation's derivative). bf16, n elements. */
+/* Elementwise: mode 0 out = silu(x); mode 1 out = dy * gelu_tanh'(x) (the FeedForward activation's derivative); mode 2 out = gelu_tanh(x), bit for
+ * bit the TG_EPI_BIAS_GELU epilogue applied to a stored TG_EPI_BIAS output (the training forward keeps the pre-activation). bf16, n elements. */
 int tg_act(const void* x, const void* dy, void* out, long n, int mode, hipStream_t stream);
 
 /* tg_colsum for an fp32 matrix (same partial layout). */

@@ -254,6 +254,7 @@ def test_adaln_gate_and_activation_backward_kernels_vs_autograd():
     (normalization.py:441-488, cogvideox_transformer_3d.py:290-324, FeedForward gelu-approximate)."""
     import torch.nn.functional as F
     from tokensgen_amd import kernels as K
+    from tokensgen_amd import lib as L
     from tokensgen_amd import train
     B, T, D, Fr = 2, 40, 128, 4
     x, dy = _rand(B, T, D, seed=71), _rand(B, T, D, seed=72)
@@ -287,6 +288,14 @@ def test_adaln_gate_and_activation_backward_kernels_vs_autograd():
     assert _rel(train._colsum_f32(tgate.view(B, T, D)[0, :8]), mg.grad[0, 0, 5 * D:6 * D]) < 1e-5
     dyk2, tg_tail = train._gate_res_bwd(dout.to(DEV), yv.to(DEV), table, row0=24)        # products only for the trailing rows (the vip group in the block)
     assert torch.equal(dyk2, dyk) and tg_tail.shape == (B, T - 24, D) and torch.equal(tg_tail, tgate.view(B, T, D)[:, 24:])
+    dyk3, tg_tail3 = train._gate_res_bwd(dout.to(DEV), yv[:, 24:].contiguous().to(DEV), table, row0=24)   # the caller kept only the rows that are read
+    assert torch.equal(dyk3, dyk) and torch.equal(tg_tail3, tg_tail)
+    # column sums with few rows per block (short matrices) and with 256 (tall ones): same sums as torch, fixed order run to run
+    for R_, C_ in ((480, 3072), (40, 128), (5000, 640)):
+        m = torch.randn(R_, C_, generator=torch.Generator().manual_seed(R_), dtype=torch.float32)
+        got = train._colsum_f32(m.to(DEV))
+        assert _rel(got, m.double().sum(0).float()) < 1e-6 and torch.equal(got, train._colsum_f32(m.to(DEV)))
+        assert _rel(train.colsum(m.to(BF).to(DEV)), m.to(BF).double().sum(0).float()) < 1e-6
     # the frozen-norm form: no products, the residual gradient summed in the same pass (bf16 + bf16 like autograd on bf16 tensors)
     res = _rand(B, T, D, seed=80)
     dx2 = torch.empty(B, T, D, dtype=BF, device=DEV)
@@ -299,6 +308,14 @@ def test_adaln_gate_and_activation_backward_kernels_vs_autograd():
     (F.gelu(vf, approximate="tanh") * g_.float()).sum().backward()
     assert _rel(train._act(v.to(DEV), g_.to(DEV)), vf.grad) < 4e-3
     assert _rel(train._act(v.to(DEV)), F.silu(v.float())) < 4e-3
+    # gelu forward as a pass of its own == the GEMM's GELU epilogue on the stored pre-activation, bit for bit (the training forward relies on it)
+    a_, w_, b_ = _rand(2, 300, 256, seed=81), _rand(384, 256, seed=82, scale=0.1), _rand(384, seed=83)
+    pre_, fused = torch.empty(2, 300, 384, dtype=BF, device=DEV), torch.empty(2, 300, 384, dtype=BF, device=DEV)
+    K.gemm(a_.to(DEV), w_.to(DEV), b_.to(DEV), pre_, L.EPI_BIAS)
+    K.gemm(a_.to(DEV), w_.to(DEV), b_.to(DEV), fused, L.EPI_BIAS_GELU)
+    assert torch.equal(train._act(pre_, gelu=True), fused)
+    assert _rel(train._act(v.to(DEV), gelu=True), F.gelu(v.float(), approximate="tanh")) < 4e-3
+    assert torch.equal(train._act(v[:2995].contiguous().to(DEV), gelu=True), train._act(v.to(DEV), gelu=True)[:2995])
     # element counts that are not a multiple of 8 take the scalar form of the kernel: same values
     assert torch.equal(train._act(v[:2995].contiguous().to(DEV), g_[:2995].contiguous().to(DEV)), train._act(v.to(DEV), g_.to(DEV))[:2995])
 

@@ -53,6 +53,16 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// F.gelu(approximate="tanh"): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3)  ==  x / (1 + exp(-2u)).
+// One v_exp + one v_rcp (1 ulp each; the result is rounded to bf16 right after) instead of a correctly rounded fp32 division:
+// the GELU of the FF1 epilogue is 64 Ki elements per 256x256 tile on VALUs that have nothing to overlap with.  Shared by the GEMM epilogue
+// (gemm.hip) and the stand-alone activation pass of the training forward (train.hip: tg_act mode 2) so that both give the same bits.
+__device__ __forceinline__ float gelu_tanh(float x) {
+    const float x2 = x * x;
+    const float t = x * (-2.f * 0.7978845608028654f * 1.4426950408889634f) * (1.f + 0.044715f * x2);   // -2u log2(e)
+    return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(t));   // t -> +inf: x * 0; t -> -inf: x
+}
+
 // XCD-aware block remap (8 XCDs, block b lands on XCD b%8): give each XCD a contiguous chunk.
 // Bijective for any nwg (cdna guide T1).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -50,14 +50,7 @@ struct GemmParams {
     int group_m;                                  // m-tiles per n sweep of the 256^2 kernel's tile order (see launch())
 };
 
-__device__ __forceinline__ float gelu_tanh(float x) {
-    // F.gelu(approximate="tanh"): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3)  ==  x / (1 + exp(-2u)).
-    // One v_exp + one v_rcp (1 ulp each; the result is rounded to bf16 right after) instead of a correctly rounded fp32 division:
-    // the GELU of the FF1 epilogue is 64 Ki elements per 256x256 tile on VALUs that have nothing to overlap with.
-    const float x2 = x * x;
-    const float t = x * (-2.f * 0.7978845608028654f * 1.4426950408889634f) * (1.f + 0.044715f * x2);   // -2u log2(e)
-    return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(t));   // t -> +inf: x * 0; t -> -inf: x
-}
+// gelu_tanh(): common.h
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 // two elements at a time: the polynomial part maps onto v_pk_mul_f32 / v_pk_fma_f32 (same operations, same results as gelu_tanh)
 __device__ __forceinline__ f32x2v gelu_tanh2(f32x2v x) {

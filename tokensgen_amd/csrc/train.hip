@@ -122,8 +122,16 @@ __global__ __launch_bounds__(256) void transpose_2d_kernel(const bf16_t* __restr
 }
 
 // partial[blk][c] = sum over the block's rows of src[r][c]  (fp32; summed over blk on the host side in a fixed order)
-constexpr int CS_ROWS = 256;
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ src, long ld, int rows, int cols, float* __restrict__ partial) {
+// Rows per block: 256 for the big matrices; fewer for short ones so that the launch still has ~2000 workgroups (a [480 x 3072] product tensor of
+// the vip rows was 24 workgroups walking 256 rows each: 75 us per call, 16 calls per layer).  A function of the shape only: the summation order
+// stays fixed, and tg_colsum_partial_floats() uses the same value.
+static inline int cs_rows(int rows, int cols) {
+    const long cb = (cols + 255) / 256;
+    long r = ((long)rows * cb + 2047) / 2048;
+    r = r < 8 ? 8 : (r > 256 ? 256 : r);
+    return (int)r;
+}
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ src, long ld, int rows, int cols, float* __restrict__ partial, int CS_ROWS) {
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c >= cols) return;
     const int r0 = blockIdx.x * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
@@ -309,12 +317,15 @@ __global__ __launch_bounds__(256) void gate_res_bwd_kernel(const bf16_t* __restr
     }
 }
 
-// mode 0: y = silu(x);  mode 1: dx = dy * gelu_tanh'(x)  (F.gelu(approximate="tanh"), diffusers FeedForward)
+// mode 0: y = silu(x);  mode 1: dx = dy * gelu_tanh'(x)  (F.gelu(approximate="tanh"), diffusers FeedForward);  mode 2: y = gelu_tanh(x), the
+// same function as the GEMM's GELU epilogue (the training forward keeps the pre-activation for mode 1 and applies the activation in this pass
+// instead of running the FF1 GEMM a second time)
 __global__ __launch_bounds__(256) void act_scalar_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ out, long n, int mode) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float v = bf16_to_f32(x[i]);
     if (mode == 0) { out[i] = f32_to_bf16(v / (1.f + __expf(-v))); return; }
+    if (mode == 2) { out[i] = f32_to_bf16(gelu_tanh(v)); return; }
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
     const float u = k0 * (v + k1 * v * v * v), th = tanhf(u);
     const float dg = 0.5f * (1.f + th) + 0.5f * v * (1.f - th * th) * k0 * (1.f + 3.f * k1 * v * v);
@@ -323,6 +334,7 @@ __global__ __launch_bounds__(256) void act_scalar_kernel(const bf16_t* __restric
 
 __device__ __forceinline__ float act_one(float v, float dyv, int mode) {
     if (mode == 0) return v / (1.f + __expf(-v));
+    if (mode == 2) return gelu_tanh(v);
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
     const float u = k0 * (v + k1 * v * v * v), th = tanhf(u);
     return dyv * (0.5f * (1.f + th) + 0.5f * v * (1.f - th * th) * k0 * (1.f + 3.f * k1 * v * v));
@@ -338,7 +350,7 @@ __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, 
     *(uint4*)(out + i * 8) = uint4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
 }
 
-__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ src, long ld, int rows, int cols, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ src, long ld, int rows, int cols, float* __restrict__ partial, int CS_ROWS) {
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c >= cols) return;
     const int r0 = blockIdx.x * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
@@ -381,13 +393,17 @@ extern "C" int tg_transpose_2d(const void* src, long ld, int rows, int cols, voi
     return TG_OK;
 }
 
-extern "C" long tg_colsum_partial_floats(int rows, int cols) { return (long)((rows + CS_ROWS - 1) / CS_ROWS) * cols; }
+extern "C" long tg_colsum_partial_floats(int rows, int cols) {
+    const int CS_ROWS = cs_rows(rows, cols);
+    return (long)((rows + CS_ROWS - 1) / CS_ROWS) * cols;
+}
 
 extern "C" int tg_colsum(const void* src, long ld, int rows, int cols, float* partial, hipStream_t stream) {
     TG_REQUIRE(src && partial, TG_ERR_ARG, "tg_colsum: null pointer");
     TG_REQUIRE(rows > 0 && cols > 0 && ld >= cols, TG_ERR_SHAPE, "tg_colsum: bad shape");
+    const int CS_ROWS = cs_rows(rows, cols);
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + CS_ROWS - 1) / CS_ROWS), (unsigned)((cols + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)src, ld,
-                       rows, cols, partial);
+                       rows, cols, partial, CS_ROWS);
     TG_LAUNCH_CHECK("tg_colsum");
     return TG_OK;
 }
@@ -442,8 +458,8 @@ extern "C" int tg_gate_residual_bwd(const void* dout, long ld_dout, long stride_
 }
 
 extern "C" int tg_act(const void* x, const void* dy, void* out, long n, int mode, hipStream_t stream) {
-    TG_REQUIRE(x && out && (mode == 0 || dy), TG_ERR_ARG, "tg_act: null pointer");
-    TG_REQUIRE(n > 0 && (mode == 0 || mode == 1), TG_ERR_SHAPE, "tg_act: bad arguments");
+    TG_REQUIRE(x && out && (mode != 1 || dy), TG_ERR_ARG, "tg_act: null pointer");
+    TG_REQUIRE(n > 0 && mode >= 0 && mode <= 2, TG_ERR_SHAPE, "tg_act: bad arguments");
     if (n % 8 == 0 && tg_aligned16(x) && tg_aligned16(out) && (!dy || tg_aligned16(dy)))
         hipLaunchKernelGGL(act_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)out, n / 8, mode);
     else
@@ -455,7 +471,9 @@ extern "C" int tg_act(const void* x, const void* dy, void* out, long n, int mode
 extern "C" int tg_colsum_f32(const float* src, long ld, int rows, int cols, float* partial, hipStream_t stream) {
     TG_REQUIRE(src && partial, TG_ERR_ARG, "tg_colsum_f32: null pointer");
     TG_REQUIRE(rows > 0 && cols > 0 && ld >= cols, TG_ERR_SHAPE, "tg_colsum_f32: bad shape");
-    hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)((rows + CS_ROWS - 1) / CS_ROWS), (unsigned)((cols + 255) / 256)), dim3(256), 0, stream, src, ld, rows, cols, partial);
+    const int CS_ROWS = cs_rows(rows, cols);
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)((rows + CS_ROWS - 1) / CS_ROWS), (unsigned)((cols + 255) / 256)), dim3(256), 0, stream, src, ld, rows, cols, partial,
+                       CS_ROWS);
     TG_LAUNCH_CHECK("tg_colsum_f32");
     return TG_OK;
 }

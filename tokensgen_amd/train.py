@@ -200,10 +200,10 @@ def _colsum_f32(src2d):
     return part.view(-1, C_).sum(dim=0)
 
 
-def _act(x, dy=None):
-    """silu(x) (dy None) or dy * gelu_tanh'(x) (tg_act)."""
+def _act(x, dy=None, gelu=False):
+    """silu(x) (dy None), gelu_tanh(x) (gelu=True: the GEMM's GELU epilogue as a separate pass over a kept pre-activation) or dy * gelu_tanh'(x) (tg_act)."""
     out = torch.empty_like(x)
-    L.check(L.load().tg_act(x.data_ptr(), K._p(dy), out.data_ptr(), x.numel(), 0 if dy is None else 1, K._stream()), "tg_act")
+    L.check(L.load().tg_act(x.data_ptr(), K._p(dy), out.data_ptr(), x.numel(), 2 if gelu else (0 if dy is None else 1), K._stream()), "tg_act")
     return out
 
 
@@ -224,12 +224,15 @@ def _adaln_bwd(x, dy, dx, w, b, eps, table, products=True, add=None):
 
 
 def _gate_res_bwd(dout, y, table, row0=0):
-    """dy = gate[g] * dout (bf16 [B, T, D]) and t_dgate = dout * y for the token rows >= row0 (fp32 [B, T - row0, D])."""
+    """dy = gate[g] * dout (bf16 [B, T, D]) and t_dgate = dout * y for the token rows >= row0 (fp32 [B, T - row0, D]).  y: [B, T, D], or only the
+    rows the kernel reads, [B, T - row0, D]."""
     B, T, D, ldd, sd_ = K._bmk(dout)
-    _, _, _, ldy, sy = K._bmk(y)
+    _, Ty, _, ldy, sy = K._bmk(y)
+    assert Ty in (T, T - row0)
+    y_ptr = y.data_ptr() - ((row0 * ldy * y.element_size()) if Ty != T else 0)      # the address row 0 would have (never read below row0)
     dy = torch.empty(B, T, D, dtype=BF16, device=dout.device)
     tg = torch.empty(B, T - row0, D, dtype=torch.float32, device=dout.device)
-    L.check(L.load().tg_gate_residual_bwd(dout.data_ptr(), ldd, sd_, y.data_ptr(), ldy, sy, dy.data_ptr(), dy.stride(1), dy.stride(0), T, D, B, table.ref(),
+    L.check(L.load().tg_gate_residual_bwd(dout.data_ptr(), ldd, sd_, y_ptr, ldy, sy, dy.data_ptr(), dy.stride(1), dy.stride(0), T, D, B, table.ref(),
                                           tg.data_ptr(), int(row0), K._stream()), "tg_gate_residual_bwd")
     return dy, tg
 
@@ -330,8 +333,10 @@ class To2VBlockTrainer:
         AO = e(B, N, D)
         torch.add(o1, o2 * self.s, out=AO[:, :N1])           # `hidden_states + scale * vip_hidden_states` on bf16 tensors (attention_processor.py:2117-2125)
         AO[:, N1:] = o3
-        y_attn = e(B, N, D)
-        K.gemm(AO, sd[A + "to_out.0.weight"], sd[A + "to_out.0.bias"], y_attn, L.EPI_BIAS)
+        # the un-gated branch outputs are kept for the vip rows only (d gate of the vip group is the one gate gradient that is needed): a 2 x 480-row
+        # GEMM instead of a second full one
+        y_attn = e(B, Np, D)
+        K.gemm(AO[:, N1:], sd[A + "to_out.0.weight"], sd[A + "to_out.0.bias"], y_attn, L.EPI_BIAS)
         X1 = e(B, N, D)
         K.gemm(AO, sd[A + "to_out.0.weight"], sd[A + "to_out.0.bias"], X1, L.EPI_BIAS_GATE_RES, residual=X0, gate=t1)
         mod2, t2 = self._mod(emb, 2)
@@ -339,11 +344,11 @@ class To2VBlockTrainer:
         K.adaln_modulate(X1[:, :N1], Xn2[:, :N1], sd[f"{pre}.norm2.norm.weight"], sd[f"{pre}.norm2.norm.bias"], self.eps, t2)
         K.adaln_modulate(X1[:, N1:], Xn2[:, N1:], sd[f"{pre}.vip_norm2.norm.weight"], sd[f"{pre}.vip_norm2.norm.bias"], self.eps, t2.offset(N1))
         Fw1, Fb1, Fw2, Fb2 = (sd[f"{pre}.ff.net.{n}"] for n in ("0.proj.weight", "0.proj.bias", "2.weight", "2.bias"))
-        ffpre, ffh = e(B, N, Fw1.shape[0]), e(B, N, Fw1.shape[0])
+        ffpre = e(B, N, Fw1.shape[0])
         K.gemm(Xn2, Fw1, Fb1, ffpre, L.EPI_BIAS)
-        K.gemm(Xn2, Fw1, Fb1, ffh, L.EPI_BIAS_GELU)
-        y_ff = e(B, N, D)
-        K.gemm(ffh, Fw2, Fb2, y_ff, L.EPI_BIAS)
+        ffh = _act(ffpre, gelu=True)                          # == the GELU epilogue on the same pre-activation, as one streaming pass (not a second GEMM)
+        y_ff = e(B, Np, D)
+        K.gemm(ffh[:, N1:], Fw2, Fb2, y_ff, L.EPI_BIAS)
         X2 = e(B, N, D)
         K.gemm(ffh, Fw2, Fb2, X2, L.EPI_BIAS_GATE_RES, residual=X1, gate=t2)
         if not self.keep:
@@ -763,9 +768,9 @@ class ResamplerTrainer:
             lat1 = e(b, Nq, dim)
             ones = self._ones(Nq, dim, b, dev)
             K.gemm(ao, sd[p + ".to_out.weight"], None, lat1, L.EPI_BIAS_GATE_RES, residual=lat, gate=ones)
-            ffpre, ffh = e(b, Nq, sd[f + ".net.0.proj.weight"].shape[0]), e(b, Nq, sd[f + ".net.0.proj.weight"].shape[0])
+            ffpre = e(b, Nq, sd[f + ".net.0.proj.weight"].shape[0])
             K.gemm(lat1, sd[f + ".net.0.proj.weight"], sd[f + ".net.0.proj.bias"], ffpre, L.EPI_BIAS)
-            K.gemm(lat1, sd[f + ".net.0.proj.weight"], sd[f + ".net.0.proj.bias"], ffh, L.EPI_BIAS_GELU)
+            ffh = _act(ffpre, gelu=True)
             lat2 = e(b, Nq, dim)
             K.gemm(ffh, sd[f + ".net.2.weight"], sd[f + ".net.2.bias"], lat2, L.EPI_BIAS_GATE_RES, residual=lat1, gate=ones)
             S.update(cat=cat, q_pre=q_pre, kv_pre=kv_pre, q=q, kv=kv, ao=ao, lse=lse, lat1=lat1, ffpre=ffpre, ffh=ffh)
