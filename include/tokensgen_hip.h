@@ -268,6 +268,15 @@ int tg_pca_inverse(const void* lat, const float* std16, const float* mean16, con
 int tg_attention_fwd_lse(const void* q, long q_ld, long q_strideB, const void* k, long k_ld, long k_strideB, const void* vt, long vt_ld, int nk,
                          void* out, long out_ld, long out_strideB, int nq, int heads, int batch, float scale, float* lse, hipStream_t stream);
 
+/* tg_attention_fwd_lse on the inference path's kernels (the training forward of the 17776^2 call): k_prescaled = 1: the K rows already carry
+ * scale * log2(e) (tg_qk_layernorm_rope_pair k_scale; `scale` is then ignored and tg_attention_bwd is called on the same K with scale = ln 2, its
+ * dk being the gradient of the SCALED rows); k_norm2_max ([batch][heads] fp32 from tg_qk_layernorm_rope_pair_kmax) + retry (int32 workspace of
+ * tg_attention_retry_ints(nq, 0, heads, batch) ints, zeroed once): the verified constant-shift softmax with its retry launch, as in
+ * tg_attention_fwd_multi; either NULL: running maximum.  lse as for tg_attention_fwd_lse (log2 domain, of the scores as the kernel sees them). */
+int tg_attention_fwd_lse_ex(const void* q, long q_ld, long q_strideB, const void* k, long k_ld, long k_strideB, const void* vt, long vt_ld, int nk,
+                            void* out, long out_ld, long out_strideB, int nq, int heads, int batch, float scale, int k_prescaled,
+                            const float* k_norm2_max, int* retry, long retry_ints, float* lse, hipStream_t stream);
+
 /* Attention BACKWARD (training step): what autograd runs for F.scaled_dot_product_attention in the reference's training
  * loop (attention_processor.py:2066-2125 under train_cogvideo_to2v.py:1995-2010), head_dim 64, no mask, no dropout.
  *   P = softmax(scale q k^T)   dV = P^T dO   dP = dO v^T   dS = P o (dP - rowsum(dO o O))   dQ = scale dS k   dK = scale dS^T q

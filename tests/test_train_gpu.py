@@ -69,6 +69,47 @@ def test_attention_bwd_vs_autograd(B, H, nq, nk):
     assert _rel(dq3, qf.grad) < 5.5e-3 and _rel(dk3, kf.grad) < 5.5e-3 and _rel(dv3, vf.grad) < 4.5e-3
 
 
+def test_attention_lse_on_the_constant_shift_kernel_and_its_backward():
+    """tg_attention_fwd_lse_ex (the training forward of the 17776^2 call): K rows prescaled by scale * log2(e) in the real norm kernel, the key-norm
+    bound from the same launch, the verified constant-shift 512-row kernel WITH the log-sum-exp store (launch scale: 2 x 48 x 11 = 1056 workgroups
+    + a ragged tail of 68 rows on the 4-wave kernel) against the running-max kernels on the same operands and torch on sampled rows; then
+    tg_attention_bwd on the scaled K with scale = ln 2 against autograd of softmax(ln2 q k'^T) v on sampled heads."""
+    from tokensgen_amd import kernels as K
+    B, H, N = 2, 48, 11 * 512 + 68
+    D = H * 64
+    kscale = 0.125 * 1.4426950408889634
+    qkv = _rand(B, N, 3 * D, seed=91).to(DEV)
+    g = torch.Generator().manual_seed(9)
+    w = lambda: (1.0 + 0.1 * torch.randn(64, generator=g)).to(BF).to(DEV)
+    bb = lambda: (0.1 * torch.randn(64, generator=g)).to(BF).to(DEV)
+    km, kws = torch.zeros(B, H, dtype=torch.float32, device=DEV), K.kmax_workspace(N, H, B, DEV)
+    K.qk_layernorm_rope_pair(qkv[:, :, :D], qkv[:, :, D:2 * D], H, w(), bb(), w(), bb(), 1e-6, k_scale=kscale, kmax=km, kmax_ws=kws)
+    q, k, v = qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
+    vt = K.transpose_v(v, H, 0, N, torch.zeros(B, H, 64, (N + 63) // 64 * 64, dtype=BF, device=DEV))
+    retry = K.AttnRetry(N, 0, H, B, DEV)
+    o_fast, o_run = torch.zeros(B, N, D, dtype=BF, device=DEV), torch.zeros(B, N, D, dtype=BF, device=DEV)
+    _, lse_fast = K.attention_lse(q, k, vt, N, o_fast, H, 0.125, k_prescaled=True, kmax=km, retry=retry)
+    _, lse_run = K.attention_lse(q, k, vt, N, o_run, H, 0.125, k_prescaled=True)
+    assert retry.count() == 0 and int(retry.buf[1:].abs().sum().item()) == 0          # the constant shift stood everywhere
+    assert not torch.equal(o_fast, o_run)                                              # ... and it is a different kernel
+    assert _rel(o_fast, o_run) < 4e-3 and (lse_fast - lse_run).abs().max().item() < 2e-3
+    rows = torch.cat([torch.arange(0, 40), torch.arange(N - 40, N)]).to(DEV)
+    for h in (0, 23, 47):
+        sl = slice(h * 64, h * 64 + 64)
+        sc = q[:, rows, sl].float() @ k[:, :, sl].float().transpose(1, 2)              # log2-domain scores
+        assert (lse_fast[:, h, rows] - torch.logsumexp(sc * math.log(2.0), -1) / math.log(2.0)).abs().max().item() < 2e-3, h
+        assert _rel(o_fast[:, rows, sl], torch.softmax(sc * math.log(2.0), -1) @ v[:, :, sl].float()) < 8e-3, h
+    # backward on the scaled rows: scale = ln 2, dk = gradient of the scaled K
+    do = _rand(B, N, D, seed=92).to(DEV)
+    dq, dk, dv = K.attention_bwd(q, k, v, o_fast, do, H, math.log(2.0), lse=lse_fast)
+    for h in (0, 47):
+        sl = slice(h * 64, h * 64 + 64)
+        qf, kf, vf = (t[:1, :, sl].float().clone().requires_grad_(True) for t in (q, k, v))
+        (((torch.softmax(qf @ kf.transpose(1, 2) * math.log(2.0), -1) @ vf)) * do[:1, :, sl].float()).sum().backward()
+        assert _rel(dq[:1, :, sl], qf.grad) < 5.5e-3 and _rel(dk[:1, :, sl], kf.grad) < 5.5e-3 and _rel(dv[:1, :, sl], vf.grad) < 4.5e-3, h
+
+
+
 def test_attention_bwd_cross_check_kernels_in_a_child_process():
     """TG_ATTN_BWD_V1=1 selects the correct-first backward kernels (LDS-staged 64 x 64 tiles, explicit transposes) kept as the cross-check of the
     register-resident ones: the same autograd comparison must hold for them (the switch is read once per process, hence the child)."""

@@ -1037,3 +1037,27 @@ extern "C" int tg_attention_fwd_lse(const void* q, long q_ld, long q_strideB, co
     p.lse = lse; p.lse_rows = nq;
     return attention_launch(p, scale, 0, "tg_attention_fwd_lse", stream);
 }
+
+// tg_attention_fwd_lse on the inference path's fast kernels: K rows that already carry scale * log2(e) (k_prescaled) and, with the key-norm bound
+// of tg_qk_layernorm_rope_pair_kmax + a retry workspace, the verified constant-shift softmax (attn_fwd_pp_kernel<true, 1, LSE> + its retry launch).
+extern "C" int tg_attention_fwd_lse_ex(const void* q, long q_ld, long q_strideB, const void* k, long k_ld, long k_strideB, const void* vt, long vt_ld, int nk,
+                                       void* out, long out_ld, long out_strideB, int nq, int heads, int batch, float scale, int k_prescaled,
+                                       const float* k_norm2_max, int* retry, long retry_ints, float* lse, hipStream_t stream) {
+    TG_REQUIRE(q && k && vt && out && lse, TG_ERR_ARG, "tg_attention_fwd_lse_ex: null pointer");
+    TG_REQUIRE(nq > 0 && nk > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_attention_fwd_lse_ex: bad shape nq=%d nk=%d", nq, nk);
+    TG_REQUIRE(out_ld % 8 == 0 && out_strideB % 8 == 0 && tg_aligned16(out), TG_ERR_ALIGN, "tg_attention_fwd_lse_ex: output alignment (16 B)");
+    AttnParams p{};
+    const tg_attn_segment g{q, q_ld, q_strideB, k, k_ld, k_strideB, vt, vt_ld, nk, k_norm2_max};
+    int rc = fill_segment(p.s[0], g, "segment");
+    if (rc) return rc;
+    p.nseg = 1;
+    p.out = (bf16_t*)out; p.o_ld = out_ld; p.o_sb = out_strideB;
+    p.nq = nq; p.heads = heads; p.batch = batch;
+    p.lse = lse; p.lse_rows = nq;
+    if (retry) {
+        TG_REQUIRE(retry_ints >= tg_attention_retry_ints(nq, 0, heads, batch), TG_ERR_SHAPE,
+                   "tg_attention_fwd_lse_ex: retry workspace of %ld ints, need %ld (tg_attention_retry_ints)", retry_ints, tg_attention_retry_ints(nq, 0, heads, batch));
+        p.retry = retry;
+    }
+    return attention_launch(p, scale, k_prescaled, "tg_attention_fwd_lse_ex", stream);
+}

@@ -255,14 +255,25 @@ def attention(q1, k1, vt1, nk1, out, heads, scale, q2=None, k2=None, vt2=None, n
     return out
 
 
-def attention_lse(q, k, vt, nk, out, heads, scale):
+def attention_lse(q, k, vt, nk, out, heads, scale, k_prescaled=False, kmax=None, retry=None):
     """Training forward of one attention call: out = softmax(scale q k^T) v AND the per-row log-sum-exp (log2 domain, fp32 [B, heads, nq]) that
-    attention_bwd takes instead of recomputing it (tg_attention_fwd_lse)."""
+    attention_bwd takes instead of recomputing it (tg_attention_fwd_lse).  k_prescaled: k already carries scale * log2(e)
+    (qk_layernorm_rope_pair k_scale) — attention_bwd then takes the same k with scale = ln 2; kmax (from qk_layernorm_rope_pair) + retry
+    (AttnRetry): the verified constant-shift softmax of the inference path (tg_attention_fwd_lse_ex)."""
     _chk(q, "q"); _chk(k, "k"); _chk(vt, "vt"); _chk(out, "out")
     B, nq, _, qld, qsb = _bmk(q)
     _, _, _, kld, ksb = _bmk(k)
     _, _, _, old, osb = _bmk(out)
     lse = torch.empty(B, heads, nq, dtype=torch.float32, device=q.device)
+    if k_prescaled or kmax is not None or retry is not None:
+        if kmax is not None:
+            _chk(kmax, "kmax", torch.float32)
+            assert kmax.is_contiguous() and kmax.shape == (B, heads)
+        assert retry is None or retry.fits(nq, 0, heads, B)
+        L.check(_launch(f"attention_lse_nq{nq}", L.load().tg_attention_fwd_lse_ex, _p(q), qld, qsb, _p(k), kld, ksb, _p(vt), vt.stride(2), nk, _p(out), old, osb,
+                        nq, heads, B, float(scale), 1 if k_prescaled else 0, _p(kmax), _p(retry.buf) if retry is not None else None,
+                        retry.ints if retry is not None else 0, _p(lse), _stream()), "tg_attention_fwd_lse_ex")
+        return out, lse
     L.check(_launch(f"attention_lse_nq{nq}", L.load().tg_attention_fwd_lse, _p(q), qld, qsb, _p(k), kld, ksb, _p(vt), vt.stride(2), nk, _p(out), old, osb, nq, heads, B,
                     float(scale), _p(lse), _stream()), "tg_attention_fwd_lse")
     return out, lse

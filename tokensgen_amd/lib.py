@@ -34,6 +34,7 @@ PROTOTYPES = {
     "tg_attention_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l,
                          _i, _i, _i, _i, _f, _i, _vp, _vp, _vp],
     "tg_attention_fwd_lse": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp, _l, _l, _i, _i, _i, _f, _vp, _vp],
+    "tg_attention_fwd_lse_ex": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp, _l, _l, _i, _i, _i, _f, _i, _vp, _vp, _l, _vp, _vp],
     "tg_qk_layernorm_rope_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _vp, _f, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _vp, _vp],
     "tg_transpose_2d": [_vp, _l, _i, _i, _vp, _l, _i, _vp],
     "tg_colsum": [_vp, _l, _i, _i, _vp, _vp],

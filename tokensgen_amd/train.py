@@ -4,6 +4,8 @@ Built so far: the loss + its gradient w.r.t. the model output (`vpred_loss_and_g
 operator — the three attention calls of the To2V processor (`to2v_attention_backward`, attention_processor.py:2066-2135) on
 tg_attention_bwd.  Not built yet: backward of the projections / norms / RoPE / FeedForward, gradient checkpointing,
 the DDP all-reduce and the optimizer — the forward-only product never routes through this module."""
+import math
+
 import torch
 
 from . import kernels as K
@@ -39,25 +41,27 @@ def vpred_loss_and_grad(model_output, noisy_model_input, model_input, timesteps,
 
 
 @torch.no_grad()
-def to2v_attention_backward(q, k, v, qx, kx, vx, qv, kv, vv, o1, o2, o3, d_out, heads, sm_scale, vip_scale, lse=(None, None, None), kcat=None, vcat=None):
+def to2v_attention_backward(q, k, v, qx, kx, vx, qv, kv, vv, o1, o2, o3, d_out, heads, sm_scale, vip_scale, lse=(None, None, None), kcat=None, vcat=None,
+                            k1_prescaled=False):
     """Backward of `cat(sdpa(q, k, v) + vip_scale * sdpa(qx, kv, vv), sdpa(qv, cat(kx, kv), cat(vx, vv)))` (attention_processor.py:2066-2135):
     q..vv are the post-norm / post-RoPE projections [B, n, heads*64] (bf16), o1/o2/o3 the three attention outputs saved by the forward,
     d_out [B, N1 + Np, heads*64] the gradient of the concatenated result.  Returns fp32 gradients keyed like the inputs (views of three combined
     tensors q_all / k_all / v_all over the rows text+video | vip of the vip-weight projection).  kv / vv receive the sum of two calls' gradients.
     lse: the three calls' log-sum-exps from K.attention_lse (optional); kcat / vcat: cat(kx, kv) / cat(vx, vv) as views when the caller has them
-    (the fused projection buffer), else they are concatenated here."""
+    (the fused projection buffer), else they are concatenated here.  k1_prescaled: `k` of the first call carries sm_scale * log2(e) (the training
+    forward's constant-shift attention): that call's backward runs with scale = ln 2 and its "k" gradient is the gradient of the SCALED rows."""
     N1, Np = q.shape[1], qv.shape[1]
     f32 = torch.float32
     B, HD = q.shape[0], q.shape[2]
     g1 = d_out[:, :N1]
-    dq, dk, dv = K.attention_bwd(q, k, v, o1, g1, heads, sm_scale, lse=lse[0])
+    dq, dk, dv = K.attention_bwd(q, k, v, o1, g1, heads, math.log(2.0) if k1_prescaled else sm_scale, lse=lse[0])
     dq_all = torch.empty(B, N1 + Np, HD, dtype=f32, device=q.device)
     dk_all, dv_all = torch.empty_like(dq_all), torch.empty_like(dq_all)
     kcat = torch.cat([kx, kv], 1) if kcat is None else kcat
     vcat = torch.cat([vx, vv], 1) if vcat is None else vcat
     # call 3 first: it writes EVERY row of dk_all / dv_all; call 2 then adds its share into the vip rows (accumulate = 2: dk / dv only)
     K.attention_bwd(qv, kcat, vcat, o3, d_out[:, N1:], heads, sm_scale, dq=dq_all[:, N1:], dk=dk_all, dv=dv_all, lse=lse[2])
-    g2 = (g1.float() * float(vip_scale)).to(BF16)          # `scale * O2` is a bf16 tensor in the forward
+    g2 = g1 if float(vip_scale) == 1.0 else g1 * float(vip_scale)      # `scale * O2` is a bf16 tensor in the forward (bf16 x scalar: fp32 product, one rounding)
     K.attention_bwd(qx, kv, vv, o2, g2, heads, sm_scale, dq=dq_all[:, :N1], dk=dk_all[:, N1:], dv=dv_all[:, N1:], accumulate=2, lse=lse[1])
     return dict(q=dq, k=dk, v=dv, qx=dq_all[:, :N1], kx=dk_all[:, :N1], vx=dv_all[:, :N1], qv=dq_all[:, N1:], kv=dk_all[:, N1:], vv=dv_all[:, N1:],
                 q_all=dq_all, k_all=dk_all, v_all=dv_all)
@@ -200,6 +204,20 @@ def _colsum_f32(src2d):
     return part.view(-1, C_).sum(dim=0)
 
 
+LOG2E = 1.4426950408889634
+_FAST_WS = {}
+
+
+def _fast_attention_ws(nq, heads, batch, device):
+    """(AttnRetry, key-norm bound [B, heads], its scratch) of the constant-shift attention forward: one set per shape, shared by all blocks (every
+    use is ordered on the launch stream)."""
+    key = (nq, heads, batch, str(device))
+    if key not in _FAST_WS:
+        _FAST_WS[key] = (K.AttnRetry(nq, 0, heads, batch, device), torch.zeros(batch, heads, dtype=torch.float32, device=device),
+                         K.kmax_workspace(nq, heads, batch, device))
+    return _FAST_WS[key]
+
+
 def _act(x, dy=None, gelu=False):
     """silu(x) (dy None), gelu_tanh(x) (gelu=True: the GEMM's GELU epilogue as a separate pass over a kept pre-activation) or dy * gelu_tanh'(x) (tg_act)."""
     out = torch.empty_like(x)
@@ -311,27 +329,33 @@ class To2VBlockTrainer:
         qkv_pre, qkvv_pre = e(B, N1, 3 * D), e(B, N, 3 * D)
         K.gemm(Xn[:, :N1], self.Wqkv, self.bqkv, qkv_pre, L.EPI_BIAS)
         K.gemm(Xn, self.Wv, self.bv, qkvv_pre, L.EPI_BIAS)
-        qkv, qkvv = qkv_pre.clone(), qkvv_pre.clone()
+        # the norm + RoPE kernel works in place and the backward needs the pre-norm Q / K: copy those two thirds; V is read where the projection left it
+        qkv, qkvv = torch.empty_like(qkv_pre), torch.empty_like(qkvv_pre)
+        qkv[:, :, :2 * D] = qkv_pre[:, :, :2 * D]
+        qkvv[:, :, :2 * D] = qkvv_pre[:, :, :2 * D]
         A = f"{pre}.attn1."
         tab = lambda r: tuple(t.to(dev, torch.float32).contiguous() for t in r)
         rope, vrope, crope = tab(rope), tab(vrope), tab(crope)
-        K.qk_layernorm_rope(qkv[:, :, :D], H, sd[A + "norm_q.weight"], sd[A + "norm_q.bias"], 1e-6, (Nt, rope))
-        K.qk_layernorm_rope(qkv[:, :, D:2 * D], H, sd[A + "norm_k.weight"], sd[A + "norm_k.bias"], 1e-6, (Nt, rope))
+        # the 17776^2 call runs on the inference path's constant-shift kernel: its K carries sm_scale * log2(e) (one rounding, in the norm kernel), the
+        # key-norm bound comes out of the same launch, and the backward sees the scaled rows (to2v_attention_backward k1_prescaled)
+        sm = 1.0 / 8.0
+        retry, km1, kws = _fast_attention_ws(N1, H, B, dev)
+        K.qk_layernorm_rope_pair(qkv[:, :, :D], qkv[:, :, D:2 * D], H, sd[A + "norm_q.weight"], sd[A + "norm_q.bias"], sd[A + "norm_k.weight"],
+                                 sd[A + "norm_k.bias"], 1e-6, (Nt, rope), k_scale=sm * LOG2E, kmax=km1, kmax_ws=kws)
         K.qk_layernorm_rope(qkvv[:, :, :D], H, sd[A + "processor.vip_norm_q.weight"], sd[A + "processor.vip_norm_q.bias"], 1e-6, (Nt, vrope), (N1, crope))
         K.qk_layernorm_rope(qkvv[:, :, D:2 * D], H, sd[A + "processor.vip_norm_k.weight"], sd[A + "processor.vip_norm_k.bias"], 1e-6, (Nt, vrope), (N1, crope))
         pad = lambda n: (n + 63) // 64 * 64
         vt = lambda v, n0, n: K.transpose_v(v, H, n0, n, torch.zeros(B, H, 64, pad(n), dtype=BF16, device=dev))
-        sm = 1.0 / 8.0
-        q, k, v = (qkv[:, :, c * D:(c + 1) * D] for c in range(3))
-        qx, kx, vx = (qkvv[:, :N1, c * D:(c + 1) * D] for c in range(3))
-        qv, kv, vv = (qkvv[:, N1:, c * D:(c + 1) * D] for c in range(3))
+        q, k, v = qkv[:, :, :D], qkv[:, :, D:2 * D], qkv_pre[:, :, 2 * D:]
+        qx, kx, vx = qkvv[:, :N1, :D], qkvv[:, :N1, D:2 * D], qkvv_pre[:, :N1, 2 * D:]
+        qv, kv, vv = qkvv[:, N1:, :D], qkvv[:, N1:, D:2 * D], qkvv_pre[:, N1:, 2 * D:]
         o1, o2, o3 = e(B, N1, D), e(B, N1, D), e(B, Np, D)
-        vt1, vt2, vt3 = vt(qkv[:, :, 2 * D:], 0, N1), vt(qkvv[:, :, 2 * D:], N1, Np), vt(qkvv[:, :, 2 * D:], 0, N)
-        _, lse1 = K.attention_lse(q, k, vt1, N1, o1, H, sm)
+        vt1, vt2, vt3 = vt(qkv_pre[:, :, 2 * D:], 0, N1), vt(qkvv_pre[:, :, 2 * D:], N1, Np), vt(qkvv_pre[:, :, 2 * D:], 0, N)
+        _, lse1 = K.attention_lse(q, k, vt1, N1, o1, H, sm, k_prescaled=True, kmax=km1, retry=retry)
         _, lse2 = K.attention_lse(qx, kv, vt2, Np, o2, H, sm)
         _, lse3 = K.attention_lse(qv, qkvv[:, :, D:2 * D], vt3, N, o3, H, sm)
         AO = e(B, N, D)
-        torch.add(o1, o2 * self.s, out=AO[:, :N1])           # `hidden_states + scale * vip_hidden_states` on bf16 tensors (attention_processor.py:2117-2125)
+        torch.add(o1, o2 if self.s == 1.0 else o2 * self.s, out=AO[:, :N1])   # `hidden_states + scale * vip_hidden_states` on bf16 tensors (attention_processor.py:2117-2125)
         AO[:, N1:] = o3
         # the un-gated branch outputs are kept for the vip rows only (d gate of the vip group is the one gate gradient that is needed): a 2 x 480-row
         # GEMM instead of a second full one
@@ -356,7 +380,7 @@ class To2VBlockTrainer:
             return X2
         S.update(X0=X0, X1=X1, Xn=Xn, Xn2=Xn2, emb=emb, t1=t1, t2=t2, mod1=mod1, mod2=mod2, qkv_pre=qkv_pre, qkvv_pre=qkvv_pre, q=q, k=k, v=v, qx=qx, kx=kx,
                  vx=vx, qv=qv, kv=kv, vv=vv, o1=o1, o2=o2, o3=o3, lse=(lse1, lse2, lse3), y_attn=y_attn, y_ff=y_ff, ffpre=ffpre, rope=rope, vrope=vrope, crope=crope, dims=(B, Nv, D, N1, N),
-                 kcat=qkvv[:, :, D:2 * D], vcat=qkvv[:, :, 2 * D:])
+                 kcat=qkvv[:, :, D:2 * D], vcat=qkvv_pre[:, :, 2 * D:])
         return X2
 
     def _vip_norm_grads(self, which, t_dln, t_dlnx, t_dyln, dxn, t_dgate, grads):
@@ -414,14 +438,15 @@ class To2VBlockTrainer:
         dAO = _dgrad(dy_attn.view(B * N, D), sd[A + "to_out.0.weight"]).view(B, N, D)
         # ---- the three attention calls, QK-norm + RoPE, projections ----
         ga = to2v_attention_backward(S["q"], S["k"], S["v"], S["qx"], S["kx"], S["vx"], S["qv"], S["kv"], S["vv"], S["o1"], S["o2"], S["o3"], dAO, H, 1.0 / 8.0, self.s, lse=S["lse"],
-                                     kcat=S["kcat"], vcat=S["vcat"])
+                                     kcat=S["kcat"], vcat=S["vcat"], k1_prescaled=True)
         pg, d_pre_v = vip_projection_backward(S["Xn"], S["qkvv_pre"], ga, H, Nt, N1, sd[A + "processor.vip_norm_q.weight"], sd[A + "processor.vip_norm_k.weight"],
                                               S["vrope"], S["crope"], return_dpre=True)
         for kname, val in pg.items():
             grads["attn1.processor." + kname] = val
         d_pre_b = torch.empty(B, N1, 3 * D, dtype=BF16, device=dX2.device)       # d(fused base projection output), written third by third
         qk_layernorm_rope_backward(S["qkv_pre"][:, :, :D], ga["q"], H, sd[A + "norm_q.weight"], 1e-6, (Nt, S["rope"]), out=d_pre_b[:, :, :D])
-        qk_layernorm_rope_backward(S["qkv_pre"][:, :, D:2 * D], ga["k"], H, sd[A + "norm_k.weight"], 1e-6, (Nt, S["rope"]), out=d_pre_b[:, :, D:2 * D])
+        qk_layernorm_rope_backward(S["qkv_pre"][:, :, D:2 * D], ga["k"], H, sd[A + "norm_k.weight"], 1e-6, (Nt, S["rope"]), out_scale=LOG2E / 8.0,
+                                   out=d_pre_b[:, :, D:2 * D])
         d_pre_b[:, :, 2 * D:] = ga["v"]
         dXn = _dgrad(d_pre_v.view(B * N, 3 * D), self.Wv).view(B, N, D)
         if dXn.is_contiguous() and D % 128 == 0:     # the base projection's share lands on the text + video rows through the GEMM's residual epilogue
