@@ -110,16 +110,14 @@ def test_attention_lse_on_the_constant_shift_kernel_and_its_backward():
 
 
 
-@pytest.mark.parametrize("switch", ["TG_ATTN_BWD_V1=1", "TG_ATTN_BWD_DKDV=5"])
-def test_attention_bwd_cross_check_kernels_in_a_child_process(switch):
+def test_attention_bwd_cross_check_kernels_in_a_child_process():
     """TG_ATTN_BWD_V1=1 selects the correct-first backward kernels (LDS-staged 64 x 64 tiles, explicit transposes) kept as the cross-check of the
-    register-resident ones; TG_ATTN_BWD_DKDV=5 the in-phase dK/dV kernel (row statistics on the vector pipe) instead of the ping-pong one: the same
-    autograd comparison must hold for them (the switches are read once per process, hence the child)."""
+    register-resident ones: the same autograd comparison must hold for them (the switch is read once per process, hence the child)."""
     import os
     import subprocess
     import sys
-    name, val = switch.split("=")
-    if os.environ.get("TG_ATTN_BWD_V1") == "1" or os.environ.get("TG_ATTN_BWD_DKDV") == "5":
+    name, val = "TG_ATTN_BWD_V1", "1"
+    if os.environ.get("TG_ATTN_BWD_V1") == "1":
         pytest.skip("already inside the cross-check run")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "test_attention_bwd_vs_autograd", "-x"],
                        env=dict(os.environ, **{name: val}), capture_output=True, text=True, timeout=600,

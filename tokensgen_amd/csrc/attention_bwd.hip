@@ -238,146 +238,12 @@ __global__ __launch_bounds__(256) void attn_bwd_stats2_kernel(BwdParams p) {
 }
 
 #define TG_WAIT_FRAGS1(f) asm volatile("s_waitcnt vmcnt(0)" : "+a"(f[0]), "+a"(f[1]), "+a"(f[2]), "+a"(f[3]))
-// ---- (2') dK, dV: ONE 512-thread workgroup per CU (8 waves x 32 keys = 256 keys), queries streamed in tiles of 32 through a three-deep LDS ring
-// (tile i+2 is staged while tile i is consumed; tile i+1's A operands are read one tile ahead).  The two waves of a SIMD share one tile stage, which
-// halves the global bytes per MFMA against two 4-wave workgroups per CU.  Structures tried and measured within 3 % of this one: 64 keys
-// per wave with one wave per SIMD and a hand-interleaved schedule, two 4-wave workgroups per CU, a two-deep ring, a two-group ping-pong (5 % slower). ----
-__global__ __launch_bounds__(512) void attn_bwd_dkdv5_kernel(Bwd2Params pp) {
-    const BwdParams& p = pp.p;
-    __shared__ __attribute__((aligned(16))) bf16_t sQ[3][ROWT_EL], sdO[3][ROWT_EL];
-    __shared__ __attribute__((aligned(16))) float sLse[3][BT], sD[3][BT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, hi = lane >> 5;
-    int blk, hb;
-    xcd_block((p.nk + 255) / 256, p.heads * p.batch, blk, hb);
-    const int h = hb % p.heads, b = hb / p.heads;
-    const int kw0 = blk * 256 + wave * 32;
-    const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
-    const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
-    const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
-    const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
-    const long stat0 = ((long)b * p.heads + h) * p.nq;
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const long r = min(kw0 + j, p.nk - 1);
-        load_frag_agpr(kf[ks], Kp + r * p.k_ld + ks * 16 + hi * 8);
-        load_frag_agpr(vf[ks], Vp + r * p.v_ld + ks * 16 + hi * 8);
-    }
-    TG_WAIT_FRAGS1(kf);
-    TG_WAIT_FRAGS1(vf);
-    f32x16 dk[2], dv[2];                                   // [d block]: rows = keys, column = head dim j
-#pragma unroll
-    for (int c = 0; c < 2; ++c) { dk[c] = zero16(); dv[c] = zero16(); }
-    const int half = tid >> 8, t8 = tid & 255;              // threads 0..255 stage Q, 256..511 dO
-    const int row = t8 >> 3, chunk = (t8 & 7) * 8;
-    const bf16_t* const srcR = half ? dO : Q;
-    const long ldR = half ? p.do_ld : p.q_ld;
-    // transpose-read base of this lane inside a [32][LQ2] tile: row 4 hi + (a >> 2), 4-element chunk (a & 3) of the 16 columns of its lane group
-    const int trb = (4 * hi + ((lane & 15) >> 2)) * LQ2 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
-    const int ntile = (p.nq + BT - 1) / BT;
-    uint4 g0;
-    float gs = 0.f;
-    bool okr = false, oks = false;
-    const float* statp = (tid < BT ? p.lse : p.dsum) + stat0;
-    float* const statdst = tid < BT ? &sLse[0][tid] : &sD[0][tid & 31];
-    const float statmask = tid < BT ? 1e30f : 0.f;
-    auto fetch = [&](int q0) {
-        okr = q0 + row < p.nq; oks = q0 + (tid & 31) < p.nq;
-        g0 = ld_row16_clamped(srcR, ldR, q0 + row, p.nq, chunk);
-        gs = statp[min(q0 + (tid & 31), p.nq - 1)];
-    };
-    auto stash = [&](int buf) {
-        *(uint4*)((half ? sdO[buf] : sQ[buf]) + row * LQ2 + chunk) = mask16(g0, okr);
-        if (tid < 2 * BT) statdst[buf * BT] = oks ? gs : statmask;
-    };
-    fetch(0);
-    stash(0);
-    fetch(min(1, ntile - 1) * BT);
-    stash(1);
-    __syncthreads();
-    bf16x8 aQ[4], aO[4];                                   // A operands of the CURRENT tile: read from LDS one tile ahead (below)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        aQ[ks] = *(const bf16x8*)(sQ[0] + j * LQ2 + ks * 16 + hi * 8);
-        aO[ks] = *(const bf16x8*)(sdO[0] + j * LQ2 + ks * 16 + hi * 8);
-    }
-    int buf = 0;
-    for (int it = 0; it < ntile; ++it) {
-        const int nbuf = buf == 2 ? 0 : buf + 1, sbuf = nbuf == 2 ? 0 : nbuf + 1;     // tile it+1 (staged last iteration), tile it+2 (staged now)
-        fetch(min(it + 2, ntile - 1) * BT);
-        f32x16 s, dp;                                      // rows = queries, column = key j
-        mfma_pair(s, dp, aQ, aO, kf, vf);
-        TG_SB();
-        bf16x8 nQ[4], nO[4];                               // next tile's A operands: their LDS latency hides under this tile's softmax + MFMAs
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            nQ[ks] = *(const bf16x8*)(sQ[nbuf] + j * LQ2 + ks * 16 + hi * 8);
-            nO[ks] = *(const bf16x8*)(sdO[nbuf] + j * LQ2 + ks * 16 + hi * 8);
-        }
-        TG_SB();
-        Frag pA[2], dA[2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 l4 = *(const f32x4*)(sLse[buf] + 8 * g + 4 * hi);
-            const f32x4 d4 = *(const f32x4*)(sD[buf] + 8 * g + 4 * hi);
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-                const f32x2 pv = {fast_exp2(s[4 * g + e] * p.scale_log2 - l4[e]), fast_exp2(s[4 * g + e + 1] * p.scale_log2 - l4[e + 1])};
-                const f32x2 ds = {pv[0] * (dp[4 * g + e] - d4[e]), pv[1] * (dp[4 * g + e + 1] - d4[e + 1])};
-                pA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2_trans(pv[0], pv[1]);
-                dA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2(ds[0], ds[1]);
-            }
-        }
-        Frag bO[2][2], bQ[2][2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const int o = trb + 16 * t * LQ2 + db * 32;              // rows 16 t + 4 hi + {0..3}, then + 8
-                bO[t][db].u[0] = lds_tr_b64(sdO[buf] + o); bO[t][db].u[1] = lds_tr_b64(sdO[buf] + o + 8 * LQ2);
-                bQ[t][db].u[0] = lds_tr_b64(sQ[buf] + o);  bQ[t][db].u[1] = lds_tr_b64(sQ[buf] + o + 8 * LQ2);
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bO[0][0].v), "+v"(bO[0][1].v), "+v"(bO[1][0].v), "+v"(bO[1][1].v), "+v"(bQ[0][0].v), "+v"(bQ[0][1].v),
-                     "+v"(bQ[1][0].v), "+v"(bQ[1][1].v));
-        TG_SB();
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                mfma_acc(dv[db], pA[t].v, bO[t][db].v);
-                mfma_acc(dk[db], dA[t].v, bQ[t][db].v);
-            }
-        TG_SB();
-        stash(sbuf);                  // buffer of tile it-1: no reader since the barrier that ended the previous iteration
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { aQ[ks] = nQ[ks]; aO[ks] = nO[ks]; }
-        buf = nbuf;
-    }
-    asm volatile("s_nop 15" ::: "memory");
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-        float* DK = p.dk + (long)b * p.dk_sb + h * HD + db * 32 + j;
-        float* DV = p.dv + (long)b * p.dv_sb + h * HD + db * 32 + j;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kw0 + acc_row(r, hi);
-            if (key >= p.nk) continue;
-            float* a = DK + (long)key * p.dk_ld;
-            float* c = DV + (long)key * p.dv_ld;
-            const float vk = dk[db][r] * p.scale, vv = dv[db][r];
-            *a = (p.accumulate & 2) ? *a + vk : vk;
-            *c = (p.accumulate & 2) ? *c + vv : vv;
-        }
-    }
-}
 
 #define BWD_BAR() do { TG_SB(); __builtin_amdgcn_s_barrier(); TG_SB(); } while (0)
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }      // the low 32 bits of a flat LDS address are the LDS offset
 
-// ---- (2'') dK, dV as a two-group ping-pong (the forward's structure): 8 waves x 32 keys, queries in tiles of 32 through a three-deep LDS ring.
-// The in-phase kernel (attn_bwd_dkdv5_kernel) measured per tile and wave: S/dP MFMAs 560-860 cycles, softmax 820-1030, transposed reads 370, dV/dK
+// ---- (2') dK, dV as a two-group ping-pong (the forward's structure): 8 waves x 32 keys = 256 keys per workgroup, queries in tiles of 32 through a four-deep
+// LDS ring.  The in-phase kernel this replaces (one 512-thread workgroup per CU, every wave in the same phase; round 3's first version) measured per tile and wave: S/dP MFMAs 560-860 cycles, softmax 820-1030, transposed reads 370, dV/dK
 // MFMAs 250, stage 200, barrier 130-600 — the two waves of a SIMD run the same phase at the same time, so their MFMA blocks collide and their VALU
 // blocks collide, and every LDS read is waited for where it is used.  Here every wave alternates
 //     X(t) = { dV += P(t-1)^T dO(t-1), dK += dS(t-1)^T Q(t-1) ; S(t) = Q(t) K^T, dP(t) = dO(t) V^T }    18 MFMAs, ALL LDS reads (16 transposed b64 + 9 b128),
@@ -654,7 +520,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) dq[a][c] = zero16();
     const int row = tid >> 3, chunk = (tid & 7) * 8;
-    const int trb = (4 * hi + ((lane & 15) >> 2)) * LQ2 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;     // see attn_bwd_dkdv5_kernel
+    const int trb = (4 * hi + ((lane & 15) >> 2)) * LQ2 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;     // transpose-read base of this lane inside a [32][LQ2] tile: row 4 hi + (a >> 2), 4-element chunk (a & 3) of its 16-lane group's columns (lds_tr_b64)
     const int ntile = (p.nk + BT - 1) / BT;
     uint4 g0, g1;
     bool okr = false;
@@ -778,9 +644,7 @@ extern "C" int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void*
     if (lse) pp.p.lse = const_cast<float*>(lse);
     const dim3 gq((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), gk((unsigned)((nk + 255) / 256), (unsigned)(batch * heads));
     hipLaunchKernelGGL(attn_bwd_stats2_kernel, gq, dim3(256), 0, stream, pp.p);
-    static const bool old5 = [] { const char* e = getenv("TG_ATTN_BWD_DKDV"); return e && e[0] == '5'; }();
-    if (old5) hipLaunchKernelGGL(attn_bwd_dkdv5_kernel, dim3(gk.x * gk.y), dim3(512), 0, stream, pp);
-    else hipLaunchKernelGGL(attn_bwd_dkdv7_kernel, dim3(gk.x * gk.y), dim3(512), 0, stream, pp);
+    hipLaunchKernelGGL(attn_bwd_dkdv7_kernel, dim3(gk.x * gk.y), dim3(512), 0, stream, pp);
     hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(gq.x * gq.y), dim3(256), 0, stream, pp);
     TG_LAUNCH_CHECK("tg_attention_bwd");
     return TG_OK;
