@@ -1,9 +1,11 @@
-"""Training step pieces on the gfx950 kernels (BASELINE config 5; reference loop train_cogvideo_to2v.py:1721-2021).
+"""Training step on the gfx950 kernels (BASELINE config 5; reference loop train_cogvideo_to2v.py:1721-2021).
 
-Built so far: the loss + its gradient w.r.t. the model output (`vpred_loss_and_grad`, :1995-2010) and the backward of the dominant
-operator — the three attention calls of the To2V processor (`to2v_attention_backward`, attention_processor.py:2066-2135) on
-tg_attention_bwd.  Not built yet: backward of the projections / norms / RoPE / FeedForward, gradient checkpointing,
-the DDP all-reduce and the optimizer — the forward-only product never routes through this module."""
+`vpred_loss_and_grad` (the v-prediction loss and its gradient, :1990-2010), `to2v_attention_backward` (the three attention calls of the To2V processor,
+attention_processor.py:2066-2135, on tg_attention_bwd), the projection / norm / RoPE / FeedForward / AdaLN backward helpers, `To2VBlockTrainer` (one block:
+forward with the intermediates kept, backward to every trainable `vip_` parameter and to the block inputs), `To2VTrainer` (the whole transformer: blocks
+keep their activations while device memory allows, the rest are recomputed in the backward like the reference's per-block checkpointing),
+`ResamplerTrainer`, and `To2VTrainStep` (add_noise -> forward -> loss -> backward -> gradient arena -> accumulate / all-reduce / clip / AdamW through
+tokensgen_amd.optim).  The forward-only product never routes through this module."""
 import math
 
 import torch
