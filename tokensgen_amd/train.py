@@ -344,8 +344,8 @@ class To2VBlockTrainer:
         retry, km1, kws = _fast_attention_ws(N1, H, B, dev)
         K.qk_layernorm_rope_pair(qkv[:, :, :D], qkv[:, :, D:2 * D], H, sd[A + "norm_q.weight"], sd[A + "norm_q.bias"], sd[A + "norm_k.weight"],
                                  sd[A + "norm_k.bias"], 1e-6, (Nt, rope), k_scale=sm * LOG2E, kmax=km1, kmax_ws=kws)
-        K.qk_layernorm_rope(qkvv[:, :, :D], H, sd[A + "processor.vip_norm_q.weight"], sd[A + "processor.vip_norm_q.bias"], 1e-6, (Nt, vrope), (N1, crope))
-        K.qk_layernorm_rope(qkvv[:, :, D:2 * D], H, sd[A + "processor.vip_norm_k.weight"], sd[A + "processor.vip_norm_k.bias"], 1e-6, (Nt, vrope), (N1, crope))
+        K.qk_layernorm_rope_pair(qkvv[:, :, :D], qkvv[:, :, D:2 * D], H, sd[A + "processor.vip_norm_q.weight"], sd[A + "processor.vip_norm_q.bias"],
+                                 sd[A + "processor.vip_norm_k.weight"], sd[A + "processor.vip_norm_k.bias"], 1e-6, (Nt, vrope), (N1, crope))
         pad = lambda n: (n + 63) // 64 * 64
         vt = lambda v, n0, n: K.transpose_v(v, H, n0, n, torch.zeros(B, H, 64, pad(n), dtype=BF16, device=dev))
         q, k, v = qkv[:, :, :D], qkv[:, :, D:2 * D], qkv_pre[:, :, 2 * D:]
