@@ -353,6 +353,13 @@ def run_train(a, rank, world, device, dist):
         n1, nv = 226 + 17550, 480
         alg = 5 * 2.0 * 64 * 48 * B * (n1 * n1 + n1 * nv + nv * (n1 + nv)) * a.layers
         tot_ms = prof["total_ms"] / max(1, a.steps)
+        traffic = None          # L2-miss bytes of one 17776^2 backward call (dK/dV + dQ launches), from the committed rocprofv3 PMC passes (tools/profile_attn_bwd.sh)
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_attention_bwd_pmc.json")) as f:
+                pm = json.load(f)
+            traffic = sum(v["l2_miss_traffic_bytes_per_launch"] for k, v in pm.items() if k.startswith(("attn_bwd_dkdv", "attn_bwd_dq")))
+        except (OSError, KeyError, ValueError):
+            pass
         print(json.dumps({
             "metric": "To2V training samples/sec (micro-steps of per_gpu_batch_size 2, gradient accumulation, clip + AdamW), CogVideoX-5B + Resampler",
             "value": B * world * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -364,7 +371,8 @@ def run_train(a, rank, world, device, dist):
                        "trainable_parameters": int(sum(v.numel() for v in arena.views.values()))},
             "roofline": {"bound": "mfma", "kernel": "tg_attention_bwd (statistics + dK/dV + dQ launches, all transformer layers of one micro-step)",
                          "achieved": alg / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else None, "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": (alg / (tot_ms * 1e-3) / 1e12 / 2500.0) if tot_ms > 0 else None, "traffic": None,
+                         "frac": (alg / (tot_ms * 1e-3) / 1e12 / 2500.0) if tot_ms > 0 else None, "traffic": traffic,
+                         "traffic_note": "bytes past L2 of ONE main (17776 x 17776, 96 heads) call's dK/dV + dQ launches; algorithmic 3.06e9",
                          "ms_per_micro_step_in_this_kernel": tot_ms, "launches_per_micro_step": prof["n"] / max(1, a.steps)},
             **({"kernel_ms_per_micro_step": {k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(K.profile_summary().items(), key=lambda kv: -kv[1]["total_ms"])},
                 "launches_per_micro_step": {k: v["n"] / a.steps for k, v in K.profile_summary().items()}} if K.PROFILE_FILTER[0] is None else {}),
