@@ -332,9 +332,9 @@ class To2VBlockTrainer:
         K.gemm(Xn[:, :N1], self.Wqkv, self.bqkv, qkv_pre, L.EPI_BIAS)
         K.gemm(Xn, self.Wv, self.bv, qkvv_pre, L.EPI_BIAS)
         # the norm + RoPE kernel works in place and the backward needs the pre-norm Q / K: copy those two thirds; V is read where the projection left it
-        qkv, qkvv = torch.empty_like(qkv_pre), torch.empty_like(qkvv_pre)
-        qkv[:, :, :2 * D] = qkv_pre[:, :, :2 * D]
-        qkvv[:, :, :2 * D] = qkvv_pre[:, :, :2 * D]
+        qkv, qkvv = e(B, N1, 2 * D), e(B, N, 2 * D)
+        qkv.copy_(qkv_pre[:, :, :2 * D])
+        qkvv.copy_(qkvv_pre[:, :, :2 * D])
         A = f"{pre}.attn1."
         tab = lambda r: tuple(t.to(dev, torch.float32).contiguous() for t in r)
         rope, vrope, crope = tab(rope), tab(vrope), tab(crope)
