@@ -226,6 +226,19 @@ def test_qk_layernorm_rope_backward_and_linear_backward_vs_autograd():
     assert _rel(dxi, dyo.float() @ w.float()) < 4e-3
 
 
+@pytest.mark.parametrize("R,C,ld,pad", [(200, 128, 128, 256), (36, 64, 192, 64), (1000, 3072, 9216, 1024), (130, 72, 72, 136), (50, 30, 30, 64), (77, 64, 64, 77)])
+def test_transpose_2d_both_forms_are_exact(R, C, ld, pad):
+    """tg_transpose_2d: dst[c][r] = src[r][c], zero columns rows..rows_pad; the 16-byte form (cols / strides / rows_pad multiples of 8) and the scalar
+    form move the same bits (strided sources: a column slice of a fused buffer)."""
+    from tokensgen_amd import train
+    src = _rand(R, ld, seed=R + C).to(DEV)[:, :C]
+    got = train.transpose_2d(src, pad)
+    want = torch.zeros(C, pad, dtype=BF, device=DEV)
+    want[:, :R] = src.t()
+    assert got.shape == (C, pad) and torch.equal(got, want)
+
+
+
 def test_vip_processor_trainable_parameter_gradients_vs_autograd_of_the_oracle(parity):
     """End of the chain for the attention sub-block: from the gradient of the processor's pre-`to_out` output to the gradients of every TRAINABLE
     processor parameter (vip_to_{q,k,v}.{weight,bias}, vip_norm_{q,k}.{weight,bias}; cogvideox_transformer_3d.py:207-218, train_cogvideo_to2v.py:

@@ -121,6 +121,32 @@ __global__ __launch_bounds__(256) void transpose_2d_kernel(const bf16_t* __restr
     }
 }
 
+// 16-byte form of transpose_2d_kernel (cols, row strides and rows_pad multiples of 8, 16-byte aligned bases): 128-byte runs on both the global read and the
+// global write side; the tile's row stride of 66 elements keeps the 4-byte LDS stores and the strided 2-byte LDS loads off each other's banks.
+__global__ __launch_bounds__(256) void transpose_2d_vec_kernel(const bf16_t* __restrict__ src, long ld, int rows, int cols, bf16_t* __restrict__ dst,
+                                                               long ldd, int rows_pad) {
+    __shared__ __attribute__((aligned(4))) bf16_t tile[64 * 66];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = threadIdx.x + k * 256, r = i >> 3, cc = (i & 7) * 8;
+        uint4 v = uint4{0, 0, 0, 0};
+        if (r0 + r < rows && c0 + cc < cols) v = *(const uint4*)(src + (long)(r0 + r) * ld + c0 + cc);
+        uint32_t* d = (uint32_t*)(tile + r * 66 + cc);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = threadIdx.x + k * 256, c = i >> 3, rr = (i & 7) * 8;
+        if (c0 + c >= cols || r0 + rr >= rows_pad) continue;
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (uint32_t)tile[(rr + 2 * e) * 66 + c] | ((uint32_t)tile[(rr + 2 * e + 1) * 66 + c] << 16);
+        *(uint4*)(dst + (long)(c0 + c) * ldd + r0 + rr) = uint4{w[0], w[1], w[2], w[3]};
+    }
+}
+
 // partial[blk][c] = sum over the block's rows of src[r][c]  (fp32; summed over blk on the host side in a fixed order)
 // Rows per block: 256 for the big matrices; fewer for short ones so that the launch still has ~2000 workgroups (a [480 x 3072] product tensor of
 // the vip rows was 24 workgroups walking 256 rows each: 75 us per call, 16 calls per layer).  A function of the shape only: the summation order
@@ -387,8 +413,13 @@ extern "C" int tg_qk_layernorm_rope_bwd(const void* x, long ld, long strideB, co
 extern "C" int tg_transpose_2d(const void* src, long ld, int rows, int cols, void* dst, long ld_dst, int rows_pad, hipStream_t stream) {
     TG_REQUIRE(src && dst, TG_ERR_ARG, "tg_transpose_2d: null pointer");
     TG_REQUIRE(rows > 0 && cols > 0 && rows_pad >= rows && ld >= cols && ld_dst >= rows_pad, TG_ERR_SHAPE, "tg_transpose_2d: bad shape");
-    hipLaunchKernelGGL(transpose_2d_kernel, dim3((unsigned)((rows_pad + 63) / 64), (unsigned)((cols + 63) / 64)), dim3(256), 0, stream, (const bf16_t*)src, ld,
-                       rows, cols, (bf16_t*)dst, ld_dst, rows_pad);
+    const bool vec = cols % 8 == 0 && rows_pad % 8 == 0 && ld % 8 == 0 && ld_dst % 8 == 0 && tg_aligned16(src) && tg_aligned16(dst);
+    if (vec)
+        hipLaunchKernelGGL(transpose_2d_vec_kernel, dim3((unsigned)((rows_pad + 63) / 64), (unsigned)((cols + 63) / 64)), dim3(256), 0, stream, (const bf16_t*)src,
+                           ld, rows, cols, (bf16_t*)dst, ld_dst, rows_pad);
+    else
+        hipLaunchKernelGGL(transpose_2d_kernel, dim3((unsigned)((rows_pad + 63) / 64), (unsigned)((cols + 63) / 64)), dim3(256), 0, stream, (const bf16_t*)src, ld,
+                           rows, cols, (bf16_t*)dst, ld_dst, rows_pad);
     TG_LAUNCH_CHECK("tg_transpose_2d");
     return TG_OK;
 }
