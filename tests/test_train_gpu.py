@@ -346,7 +346,7 @@ def test_adaln_gate_and_activation_backward_kernels_vs_autograd():
     dyk3, tg_tail3 = train._gate_res_bwd(dout.to(DEV), yv[:, 24:].contiguous().to(DEV), table, row0=24)   # the caller kept only the rows that are read
     assert torch.equal(dyk3, dyk) and torch.equal(tg_tail3, tg_tail)
     # column sums with few rows per block (short matrices) and with 256 (tall ones): same sums as torch, fixed order run to run
-    for R_, C_ in ((480, 3072), (40, 128), (5000, 640)):
+    for R_, C_ in ((480, 3072), (40, 128), (5000, 640), (33, 100)):
         m = torch.randn(R_, C_, generator=torch.Generator().manual_seed(R_), dtype=torch.float32)
         got = train._colsum_f32(m.to(DEV))
         assert _rel(got, m.double().sum(0).float()) < 1e-6 and torch.equal(got, train._colsum_f32(m.to(DEV)))
