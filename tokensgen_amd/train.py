@@ -329,8 +329,11 @@ class To2VBlockTrainer:
         K.adaln_modulate(X0[:, :N1], Xn[:, :N1], sd[f"{pre}.norm1.norm.weight"], sd[f"{pre}.norm1.norm.bias"], self.eps, t1)
         K.adaln_modulate(X0[:, N1:], Xn[:, N1:], sd[f"{pre}.vip_norm1.norm.weight"], sd[f"{pre}.vip_norm1.norm.bias"], self.eps, t1.offset(N1))
         qkv_pre, qkvv_pre = e(B, N1, 3 * D), e(B, N, 3 * D)
-        K.gemm(Xn[:, :N1], self.Wqkv, self.bqkv, qkv_pre, L.EPI_BIAS)
-        K.gemm(Xn, self.Wv, self.bv, qkvv_pre, L.EPI_BIAS)
+        if N1 >= 1024 and (3 * D) % 256 == 0 and self.Wqkv.stride(0) == self.Wv.stride(0):     # both projections in one launch of the 256^2 kernel (one tile tail, not two)
+            K.gemm_pair(Xn[:, :N1], self.Wqkv, self.bqkv, qkv_pre, Xn, self.Wv, self.bv, qkvv_pre, L.EPI_BIAS)
+        else:
+            K.gemm(Xn[:, :N1], self.Wqkv, self.bqkv, qkv_pre, L.EPI_BIAS)
+            K.gemm(Xn, self.Wv, self.bv, qkvv_pre, L.EPI_BIAS)
         # the norm + RoPE kernel works in place and the backward needs the pre-norm Q / K: copy those two thirds; V is read where the projection left it
         qkv, qkvv = e(B, N1, 2 * D), e(B, N, 2 * D)
         qkv.copy_(qkv_pre[:, :, :2 * D])
