@@ -286,8 +286,10 @@ int tg_attention_fwd_lse_ex(const void* q, long q_ld, long q_strideB, const void
  * calls share K / V tensors — their gradients sum — but not queries).
  * ws: 16-byte aligned fp32 workspace of tg_attention_bwd_ws_floats(nq, nk, heads, batch) floats (row log-sum-exp and rowsum(dO o O); the
  * [d][row] operands are read from the row-major tiles with the LDS transpose read, no transposed copies).
- * P is recomputed from the log-sum-exp tile by tile; three launches (statistics, dK/dV per 256-key workgroup, dQ per 256-query workgroup) behind
- * three tg_transpose_v passes, no atomics: run-to-run deterministic.  lse: optional [batch][heads][nq] fp32 row log-sum-exp (log2 domain) written by
+ * P is recomputed from the log-sum-exp tile by tile.  Launches: statistics, then EITHER one kernel that forms dK, dV and dQ (5 GEMMs; the key blocks of
+ * a head add their dQ contributions in a fixed order through L2 — used for calls with >= 4 query tiles per key block and a multiple of 8 (batch, head)
+ * pairs, after a one-time device probe of the exchange protocol; TG_ATTN_BWD_FUSED=0 disables) OR dK/dV per 256-key workgroup + dQ per 256-query
+ * workgroup (7 GEMMs).  No atomics on the data either way: run-to-run deterministic.  lse: optional [batch][heads][nq] fp32 row log-sum-exp (log2 domain) written by
  * tg_attention_fwd_lse for the same q / k / scale — the statistics launch then only forms rowsum(dO o O); NULL: recomputed here.
  * TG_ATTN_BWD_V1=1 selects the earlier correct-first kernels (cross-check). */
 int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void* k, long k_ld, long k_sb, const void* v, long v_ld, long v_sb,

@@ -10,6 +10,7 @@
 // tiles.  All products run on v_mfma_f32_32x32x16_bf16; gradients are fp32 (accumulate flag: the To2V processor's three attention calls share
 // K / V tensors, so their gradients add up).
 #include <cstdlib>
+#include <vector>
 
 #include "attention_bwd.h"
 #include "tokensgen_hip.h"
@@ -609,14 +610,337 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
         }
 }
 
+// =================================================================================================================================
+// ONE kernel for dK, dV AND dQ (5 executed GEMMs instead of 7: S and dP are formed once).  DESIGN §10 "one-kernel backward".
+// A workgroup owns 256 keys (8 waves x 32) like the dK/dV kernel and walks the query tiles; per tile it also forms its 256 keys' contribution to the
+// tile's dQ [32 q][64 d]: every wave leaves its dS^T block [32 keys][32 queries] (bf16) in LDS, and behind the tile's barrier wave w computes ONE 16 x 16
+// block of dQ^T (head dims 16 (w >> 1) .., queries 16 (w & 1) ..) over all 256 keys on v_mfma_f32_16x16x32_bf16 — A = the workgroup's K rows of its 16
+// head dims, resident; B = dS through transposed reads of the [key][query] tiles; a lane ends up with 4 consecutive floats of one dQ row.
+// The key blocks of a head add their blocks to the fp32 dQ tile in global memory IN KEY-BLOCK ORDER (bitwise reproducible, no atomics on the data): per
+// (head, tile) a counter says how many key blocks have added; key block kb waits for the counter to reach kb (wave 0, before the tile's barrier), every
+// wave reads its 16 bytes per row, adds, writes, and when every wave's write has been acknowledged by L2 (vmcnt(0) + the next barrier) the counter is
+// set to kb + 1.  All workgroups of a head run on ONE XCD (xcd_block), whose L2 is the coherence point: stores are written through the CU's L1; the CU's
+// L1 is invalidated once per workgroup, after which every dQ line is loaded once and only when complete; the counter is polled with sc1 loads (past the
+// L1).  fused_probe_kernel checks exactly these primitives and the workgroup -> XCD mapping on the device before the launcher uses this kernel.
+// The wait never points at a workgroup that has not started (kb - 1 has the lower index).  The read-add-write of a tile is spread over the next
+// iterations (checked during iteration T, requested at the top of T + 1, written at the top of T + 2, signalled behind the barrier of T + 3), so
+// consecutive key blocks run a few tiles apart — which is why the launcher uses this kernel only for calls with many more query tiles than key blocks.
+// In-phase structure (one barrier per tile), statistics seeded through the matrix pipe as in the ping-pong kernel.  Measured at the training shape: 24.3 ms
+// against 15.9 + 11.4 for the two launches it replaces; without the dQ exchange the same kernel takes 19.1.
+// =================================================================================================================================
+struct FusedParams {
+    BwdParams p;
+    int* cnt;            // [heads * batch][query tiles][32]: key blocks that have added their dQ blocks, one counter per 128-byte line (zeroed by the launcher)
+};
+constexpr int DSLD = 40;                 // dS^T tile row stride in elements (80 B: 8-byte aligned 4-query runs)
+constexpr int FUSED_LDS = 2 * 3 * ROWT_EL * 2 + 3 * 64 * 16 + 2 * 256 * DSLD * 2;
+
+// The counters and the dQ blocks are exchanged between workgroups of ONE XCD, whose L2 is the coherence point — and the only accesses that are certain to
+// be performed AT the L2 are atomics.  So a workgroup ADDS its block with global_atomic_add_f32 (no read-modify-write round trip in the kernel at all; the
+// order of the adds per address is the key-block order the counters enforce, so the sum is still bitwise reproducible), signals with a store (written
+// through the CU's L1 to L2) and reads the counters with a returning atomic OR 0.  Measured on the way: agent-scope atomics compile to sc1 accesses that
+// travel to memory behind the L2 (every iteration waited 600-1400 cycles for its signal store's acknowledgement); the sc0 bit alone is workgroup scope and
+// does not bypass the L1 (stale counters, polls that never end); buffer_inv sc1 before plain loads is correct and 8x slower than the whole kernel.
+__device__ __forceinline__ int cnt_read(int* c) {
+    int v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(c) : "memory");
+    return v;
+}
+__device__ __forceinline__ void cnt_write(int* c, int v) { asm volatile("global_store_dword %0, %1, off" :: "v"(c), "v"(v) : "memory"); }
+
+__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
+    const BwdParams& p = fp.p;
+    extern __shared__ __attribute__((aligned(16))) char fsm[];
+    bf16_t (*sQ)[ROWT_EL] = (bf16_t (*)[ROWT_EL])fsm;                                   // [3]
+    bf16_t (*sdO)[ROWT_EL] = (bf16_t (*)[ROWT_EL])(fsm + 3 * ROWT_EL * 2);              // [3]
+    uint4 (*sSt)[64] = (uint4 (*)[64])(fsm + 6 * ROWT_EL * 2);                            // [3] seed rows (entries 32..63 zero)
+    bf16_t* sDS = (bf16_t*)(fsm + 6 * ROWT_EL * 2 + 3 * 64 * 16);                         // [2][256][DSLD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, hi = lane >> 5, t16 = lane & 15, g4 = lane >> 4;
+    int blk, hb;
+    xcd_block((p.nk + 255) / 256, p.heads * p.batch, blk, hb);
+    const int h = hb % p.heads, b = hb / p.heads;
+    const int kw0 = blk * 256 + wave * 32;
+    const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
+    const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
+    const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
+    const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
+    const long stat0 = ((long)b * p.heads + h) * p.nq;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const long r = min(kw0 + j, p.nk - 1);
+        load_frag_agpr(kf[ks], Kp + r * p.k_ld + ks * 16 + hi * 8);
+        load_frag_agpr(vf[ks], Vp + r * p.v_ld + ks * 16 + hi * 8);
+    }
+    TG_WAIT_FRAGS1(kf);
+    TG_WAIT_FRAGS1(vf);
+    Frag oS, oD;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { oS.w[w] = 0; oD.w[w] = 0; }
+    if (hi == 0) { oS.w[0] = 0x3F803F80u; oS.w[1] = 0x00003F80u; oD.w[1] = 0x3F800000u; oD.w[2] = 0x3F803F80u; }
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { dk[c] = zero16(); dv[c] = zero16(); }
+    // this wave's dQ block and its resident B operand: K rows of the workgroup's 256 keys (zero beyond nk), head dims 16 dblk ..
+    const int qh = wave & 1, dblk = wave >> 1;
+    Frag kb8[8];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2)
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const int k0 = blk * 256 + 32 * s2 + 8 * g4 + e;
+            const uint32_t lo = k0 < p.nk ? Kp[(long)k0 * p.k_ld + 16 * dblk + t16] : 0u;
+            const uint32_t hi16 = k0 + 1 < p.nk ? Kp[(long)(k0 + 1) * p.k_ld + 16 * dblk + t16] : 0u;
+            kb8[s2].w[e >> 1] = lo | (hi16 << 16);
+        }
+    const int half = tid >> 8, t8 = tid & 255, row = t8 >> 3, chunk = (t8 & 7) * 8;
+    const bf16_t* const srcR = half ? dO : Q;
+    const long ldR = half ? p.do_ld : p.q_ld;
+    const int trb = (4 * hi + ((lane & 15) >> 2)) * LQ2 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    const int ntile = (p.nq + BT - 1) / BT;
+    uint4 maskrow;
+    {
+        uint32_t l1, l2, l3;
+        split_bf16x3(-1e30f, l1, l2, l3);
+        maskrow = uint4{(l1 >> 16) | l2, l3 >> 16, 0u, 0u};
+    }
+    uint4 g0 = uint4{0, 0, 0, 0}, gseed = maskrow;
+    bool okr = false, oks = false;
+    auto fetch = [&](int q0) {
+        okr = q0 + row < p.nq; oks = q0 + j < p.nq;
+        g0 = ld_row16_clamped(srcR, ldR, q0 + row, p.nq, chunk);
+        gseed = p.seed[stat0 + min(q0 + j, p.nq - 1)];        // (every wave: a uniform number of loads per iteration; wave 0 stages it)
+    };
+    auto stash = [&](int buf) {
+        *(uint4*)((half ? sdO[buf] : sQ[buf]) + row * LQ2 + chunk) = mask16(g0, okr);
+        if (wave == 0 && hi == 0) sSt[buf][j] = sel16(oks, gseed, maskrow);
+    };
+    if (wave == 0 && hi == 1) {
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) sSt[bb][lane] = uint4{0, 0, 0, 0};
+    }
+    fetch(0);
+    stash(0);
+    fetch(min(1, ntile - 1) * BT);
+    stash(1);
+    __syncthreads();
+    constexpr int CNT_PAD = 32;                               // one counter per 128-byte line
+    int* const cntw = fp.cnt + (long)hb * ntile * CNT_PAD;   // one counter per (head, tile): key blocks that have added
+    // the block is formed TRANSPOSED (rows = head dims 4 g4 + r, column = query t16): a lane then owns 4 consecutive floats of one dQ row — one 16-byte
+    // load and one 16-byte store per tile
+    float* const DQb = p.dq + (long)b * p.dq_sb + h * HD + 16 * dblk + 4 * g4;
+    const bool first = blk == 0 && !(p.accumulate & 1);      // nothing to read: this workgroup's block starts the sum
+    f32x4 accP = f32x4{0.f, 0.f, 0.f, 0.f}, accO = f32x4{0.f, 0.f, 0.f, 0.f};      // blocks of the last two tiles
+    f32x4 ldv = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cval = 0;                                           // wave 0: counter of the next tile to check, sampled one iteration ahead
+    asm volatile("buffer_inv sc1" ::: "memory");            // ONCE per workgroup: whatever earlier workgroups on this CU left in its L1 is gone; from here on
+                                                            // every dQ line is loaded once, and only after the key block before has completed the whole tile
+    auto e_signal = [&](int T) {                             // (wave 0, behind a barrier behind every wave's vmcnt(0)): the stores of tile T are in L2
+        if (tid == 0) cnt_write(cntw + (long)T * CNT_PAD, blk + 1);
+    };
+    auto e_sample = [&](int T) {                             // (wave 0) returning atomic: performed at the L2
+        if (wave == 0) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(cval) : "v"(cntw + (long)min(T, ntile - 1) * CNT_PAD) : "memory");
+    };
+    auto e_check = [&](int T) {                              // (wave 0, before the barrier that lets the others request tile T)
+        if (wave == 0 && blk > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cval));
+            if (lane == 0 && cval != blk) {
+                int spin = 0;
+                while (cnt_read(cntw + (long)T * CNT_PAD) != blk && ++spin < (1 << 16)) __builtin_amdgcn_s_sleep(2);
+            }
+        }
+    };
+    auto e_request = [&](int T) {
+        const int q = T * BT + 16 * qh + t16;
+        const float* src = DQb + (long)min(q, p.nq - 1) * p.dq_ld;
+        if (!first) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ldv) : "v"(src) : "memory");
+    };
+    auto e_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(ldv)); };      // last iteration's request is in, its store has been acknowledged by L2
+    auto e_write = [&](int T, const f32x4& acc) {
+        const int q = T * BT + 16 * qh + t16;
+        if (q < p.nq) {
+            f32x4 v = f32x4{acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale};
+            if (!first) v = f32x4{v[0] + ldv[0], v[1] + ldv[1], v[2] + ldv[2], v[3] + ldv[3]};
+            *(f32x4*)(DQb + (long)q * p.dq_ld) = v;
+        }
+    };
+    e_sample(0);
+    for (int it = 0; it < ntile; ++it) {
+        const int buf = it % 3, sbuf = (it + 2) % 3;
+        // the dQ pipeline, all at the top of the iteration where a whole iteration has passed since the loads / stores it waits for were issued:
+        // tile it - 3 signalled (its store went out one iteration ago), tile it - 2 written (its old values were requested one iteration ago), tile it - 1 requested
+        // the dQ pipeline: tile T is checked (wave 0) during iteration T, requested at the top of T + 1, written at the top of T + 2, signalled behind the
+        // barrier of T + 3 — a whole iteration lies between every wait and what it waits for
+        e_landed();
+        if (it >= 2) e_write(it - 2, accO);
+        fetch(min(it + 2, ntile - 1) * BT);
+        if (it >= 1) e_request(it - 1);                      // (tile it - 1 was checked before the previous barrier)
+        // ---- S, dP of this tile (statistics seeded through the matrix pipe) ----
+        bf16x8 aQ[4], aO[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            aQ[ks] = *(const bf16x8*)(sQ[buf] + j * LQ2 + ks * 16 + hi * 8);
+            aO[ks] = *(const bf16x8*)(sdO[buf] + j * LQ2 + ks * 16 + hi * 8);
+        }
+        Frag sd;
+        {
+            const uint4 t_ = sSt[buf][lane];
+            sd.w[0] = t_.x; sd.w[1] = t_.y; sd.w[2] = t_.z; sd.w[3] = t_.w;
+        }
+        f32x16 s, dp;
+        asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %3, 0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, 0" : "=&v"(s), "=&v"(dp) : "v"(sd.v), "v"(oS.v), "v"(oD.v));
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) mfma_pair_step<false, false>(s, dp, aQ[ks], aO[ks], kf[ks], vf[ks]);
+            else mfma_pair_step<false, true>(s, dp, aQ[ks], aO[ks], kf[ks], vf[ks]);
+        }
+        // ---- P, dS -> A operands; dS^T block -> LDS ----
+        Frag pA[2], dA[2];
+        bf16_t* const dsw = sDS + (it & 1) * 256 * DSLD + (wave * 32 + j) * DSLD + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint32_t w01[2];
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const float p0 = fast_exp2(s[4 * g + e] * p.scale_log2), p1 = fast_exp2(s[4 * g + e + 1] * p.scale_log2);
+                pA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2_trans(p0, p1);
+                w01[e >> 1] = pack_bf16x2(p0 * dp[4 * g + e], p1 * dp[4 * g + e + 1]);
+                dA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = w01[e >> 1];
+            }
+            *(uint2*)(dsw + 8 * g) = uint2{w01[0], w01[1]};
+        }
+        // ---- dV += P^T dO, dK += dS^T Q ----
+        Frag bO[2][2], bQ[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int o = trb + 16 * t * LQ2 + db * 32;
+                bO[t][db].u[0] = lds_tr_b64(sdO[buf] + o); bO[t][db].u[1] = lds_tr_b64(sdO[buf] + o + 8 * LQ2);
+                bQ[t][db].u[0] = lds_tr_b64(sQ[buf] + o);  bQ[t][db].u[1] = lds_tr_b64(sQ[buf] + o + 8 * LQ2);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bO[0][0].v), "+v"(bO[0][1].v), "+v"(bO[1][0].v), "+v"(bO[1][1].v), "+v"(bQ[0][0].v), "+v"(bQ[0][1].v),
+                     "+v"(bQ[1][0].v), "+v"(bQ[1][1].v));
+        TG_SB();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                mfma_acc(dv[db], pA[t].v, bO[t][db].v);
+                mfma_acc(dk[db], dA[t].v, bQ[t][db].v);
+            }
+        TG_SB();
+        stash(sbuf);
+        e_check(it);                                        // wave 0: key block blk - 1 has completed tile it (needed from the top of the next iteration on)
+        __syncthreads();
+        if (it >= 3) e_signal(it - 3);                      // every wave passed its e_landed() of this iteration: the stores of tile it - 3 are in L2
+        e_sample(it + 1);
+        // ---- this tile's dQ block: dS [16 q][256 keys] x K [256 keys][16 d] ----
+        {
+            const bf16_t* dsr = sDS + (it & 1) * 256 * DSLD + (8 * g4 + (t16 >> 2)) * DSLD + 16 * qh + (t16 & 3) * 4;
+            Frag a8[8];
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) {
+                a8[s2].u[0] = lds_tr_b64(dsr + 32 * s2 * DSLD);
+                a8[s2].u[1] = lds_tr_b64(dsr + (32 * s2 + 4) * DSLD);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a8[0].v), "+v"(a8[1].v), "+v"(a8[2].v), "+v"(a8[3].v), "+v"(a8[4].v), "+v"(a8[5].v), "+v"(a8[6].v), "+v"(a8[7].v));
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb8[s2].v, a8[s2].v, acc, 0, 0, 0);     // rows = head dims, column = query
+            accO = accP;
+            accP = acc;
+        }
+    }
+    // drain the dQ pipeline (tiles ntile - 2 and ntile - 1 are still to be written, ntile - 3 .. ntile - 1 to be signalled)
+    e_landed();
+    if (ntile >= 2) e_write(ntile - 2, accO);
+    e_request(ntile - 1);                                   // (checked before the last barrier)
+    e_landed();
+    e_write(ntile - 1, accP);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        for (int T = max(ntile - 3, 0); T < ntile; ++T) cnt_write(cntw + (long)T * CNT_PAD, blk + 1);
+    }
+    asm volatile("s_nop 15" ::: "memory");
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        float* DK = p.dk + (long)b * p.dk_sb + h * HD + db * 32 + j;
+        float* DV = p.dv + (long)b * p.dv_sb + h * HD + db * 32 + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kw0 + acc_row(r, hi);
+            if (key >= p.nk) continue;
+            float* a = DK + (long)key * p.dk_ld;
+            float* c = DV + (long)key * p.dv_ld;
+            const float vk = dk[db][r] * p.scale, vv = dv[db][r];
+            *a = (p.accumulate & 2) ? *a + vk : vk;
+            *c = (p.accumulate & 2) ? *c + vv : vv;
+        }
+    }
+}
+
+// One-time probe of what the one-kernel backward relies on, on THIS device: (1) workgroup w of a 1-D launch runs on XCD w % 8; (2) the exchange protocol
+// itself — a chain of 32 workgroups of XCD 0, each adding its number to 64 tiles of a buffer in chain order with exactly the kernel's primitives (L1
+// invalidated once per workgroup; sc1 poll of a counter; plain 16-byte load; plain store; vmcnt(0); plain-store signal).  Any stale read, lost update or
+// poll that does not end shows up as a wrong sum or a raised flag, and the launcher then keeps the two-kernel form.
+__global__ __launch_bounds__(64) void fused_probe_kernel(int* bad, int* cnt, float* data) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;        // HW_REG_XCC_ID, bits 3:0
+    if (threadIdx.x == 0 && xcc != (blockIdx.x & 7u)) atomicAdd(bad, 1);
+    if ((blockIdx.x & 7u) != 0 || (blockIdx.x >> 3) >= 32u) return;
+    const int kb = (int)(blockIdx.x >> 3), lane = (int)threadIdx.x;
+    asm volatile("buffer_inv sc1" ::: "memory");
+    for (int T = 0; T < 64; ++T) {
+        if (kb > 0 && lane == 0) {
+            int spin = 0;
+            while (cnt_read(cnt + T * 32) != kb && ++spin < (1 << 20)) __builtin_amdgcn_s_sleep(2);
+            if (spin >= (1 << 20)) atomicAdd(bad, 1);
+        }
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        float* ptr = data + (T * 64 + lane) * 4;
+        if (kb > 0) asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(ptr) : "memory");
+        const float add = (float)(kb + 1);
+        *(f32x4*)ptr = f32x4{v[0] + add, v[1] + add, v[2] + add, v[3] + add};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) cnt_write(cnt + T * 32, kb + 1);
+    }
+}
+
 }  // namespace
 
 // statistics: 2 floats per query row (log-sum-exp unless the forward kept it, and D) + the 16-byte seed row of the dK/dV kernel
 extern "C" long tg_attention_bwd_ws_floats(int nq, int nk, int heads, int batch) {
     (void)nk;
-    return 6L * batch * heads * nq + 8;
+    return 6L * batch * heads * nq + 8 + (long)batch * heads * ((nq + BT - 1) / BT) * 32 + 8;      // + the one-kernel form's dQ counters
 }
 
+// one-time check (per process): workgroup -> XCD mapping and the L2 exchange protocol of the one-kernel backward (fused_probe_kernel)
+static bool fused_protocol_ok(hipStream_t stream) {
+    static int state = -1;
+    if (state < 0) {
+        state = 0;
+        const size_t nb = sizeof(int) * (4 + 64 * 32) + sizeof(float) * 64 * 64 * 4;
+        char* buf = nullptr;
+        if (hipMalloc(&buf, nb) == hipSuccess) {
+            int* bad = (int*)buf;
+            int* cnt = bad + 4;
+            float* data = (float*)(cnt + 64 * 32);
+            (void)hipMemsetAsync(buf, 0, nb, stream);
+            hipLaunchKernelGGL(fused_probe_kernel, dim3(4096), dim3(64), 0, stream, bad, cnt, data);
+            std::vector<char> host(nb);
+            if (hipMemcpyAsync(host.data(), buf, nb, hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess) {
+                bool ok = *(const int*)host.data() == 0;
+                const float* hd = (const float*)(host.data() + sizeof(int) * (4 + 64 * 32));
+                for (int i = 0; i < 64 * 64 * 4 && ok; ++i) ok = hd[i] == 528.0f;          // 1 + 2 + ... + 32, every element, exactly
+                state = ok ? 1 : 0;
+            }
+            (void)hipFree(buf);
+        }
+    }
+    return state == 1;
+}
 
 extern "C" int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void* k, long k_ld, long k_sb, const void* v, long v_ld, long v_sb,
                                  const void* o, long o_ld, long o_sb, const void* dout, long do_ld, long do_sb,
@@ -644,6 +968,23 @@ extern "C" int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void*
     if (lse) pp.p.lse = const_cast<float*>(lse);
     const dim3 gq((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), gk((unsigned)((nk + 255) / 256), (unsigned)(batch * heads));
     hipLaunchKernelGGL(attn_bwd_stats2_kernel, gq, dim3(256), 0, stream, pp.p);
+    static const bool fused_on = [] { const char* e = getenv("TG_ATTN_BWD_FUSED"); return !(e && e[0] == '0'); }();       // default on; 0: always the two-kernel form
+    // the ordered dQ accumulation runs the key blocks of a head as a chain a few tiles apart: worth it only when there are many more query tiles than
+    // key blocks (the 17776^2 call: 556 tiles, 70 blocks; the vip queries' call with 15 tiles and 72 blocks would serialise)
+    const bool chain_ok = (long)((nq + BT - 1) / BT) >= 4L * gk.x && dq_ld % 4 == 0 && dq_sb % 4 == 0 && tg_aligned16(dq);
+    if (fused_on && chain_ok && ((heads * batch) & 7) == 0 && fused_protocol_ok(stream)) {
+        FusedParams fp{pp.p, (int*)(ws + ((6 * nrow + 8 + 3) & ~3L))};
+        const long ncnt = (long)batch * heads * ((nq + BT - 1) / BT) * 32;
+        (void)hipMemsetAsync(fp.cnt, 0, ncnt * sizeof(int), stream);
+        static const bool attr = [] {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
+            return true;
+        }();
+        (void)attr;
+        hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(gk.x * gk.y), dim3(512), FUSED_LDS, stream, fp);
+        TG_LAUNCH_CHECK("tg_attention_bwd(one kernel)");
+        return TG_OK;
+    }
     hipLaunchKernelGGL(attn_bwd_dkdv7_kernel, dim3(gk.x * gk.y), dim3(512), 0, stream, pp);
     hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(gq.x * gq.y), dim3(256), 0, stream, pp);
     TG_LAUNCH_CHECK("tg_attention_bwd");

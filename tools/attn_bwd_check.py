@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tokensgen_amd import kernels as K
 BF = torch.bfloat16
 def rel(a, b): return ((a.float().cpu() - b.float()).norm() / b.float().norm()).item()
-for (B, H, nq, nk) in [(1, 2, 50, 70), (2, 3, 513, 1500), (1, 4, 200, 33)]:
+for (B, H, nq, nk) in [(1, 2, 50, 70), (2, 3, 513, 1500), (1, 4, 200, 33), (1, 8, 50, 70), (2, 4, 513, 1500), (1, 8, 200, 33), (2, 8, 1000, 777)]:
     g = torch.Generator().manual_seed(1)
     q, k, v = (torch.randn(B, n, H * 64, generator=g).mul(1.5).to(BF) for n in (nq, nk, nk))
     do = torch.randn(B, nq, H * 64, generator=g).to(BF)

@@ -1,0 +1,15 @@
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from tokensgen_amd import kernels as K
+B, H, D, N1 = 2, 48, 3072, 17776
+rnd = lambda *sh, scale=1.0: (torch.randn(*sh, device="cuda") * scale).to(torch.bfloat16)
+qkv = rnd(B, N1, 3 * D, scale=0.6)
+o, do = rnd(B, N1, D, scale=0.3), rnd(B, N1, D, scale=0.3)
+dq, dk, dv = (torch.empty(B, N1, D, dtype=torch.float32, device="cuda") for _ in range(3))
+for _ in range(2):
+    K.attention_bwd(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], o, do, 48, 0.125, dq=dq, dk=dk, dv=dv)
+torch.cuda.synchronize()
+raw = dv.view(-1)[:64].view(torch.int64).cpu().tolist()
+for i in range(6):
+    c = raw[4 * i: 4 * i + 4]
+    print("wg", [40, 320, 2400][i // 2], "wave", [0, 5][i % 2], "E ticks/tile %.1f  all ticks/tile %.1f  spins %d of %d tiles" % (c[0] / max(c[3], 1), c[1] / max(c[3], 1), c[2], c[3]))
