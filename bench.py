@@ -357,7 +357,7 @@ def run_train(a, rank, world, device, dist):
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_attention_bwd_pmc.json")) as f:
                 pm = json.load(f)
-            traffic = sum(v["l2_miss_traffic_bytes_per_launch"] for k, v in pm.items() if k.startswith(("attn_bwd_dkdv", "attn_bwd_dq")))
+            traffic = sum(v["l2_miss_traffic_bytes_per_launch"] for k, v in pm.items() if k.startswith(("attn_bwd_dkdv", "attn_bwd_dq", "attn_bwd_fused")))
         except (OSError, KeyError, ValueError):
             pass
         print(json.dumps({
@@ -369,10 +369,10 @@ def run_train(a, rank, world, device, dist):
                        "layers": a.layers, "accumulation_steps": a.accum, "optimizer_steps_in_timed_region": n_opt,
                        "blocks_keeping_activations": tr.blocks_kept, "blocks_recomputed_in_backward": a.layers - tr.blocks_kept,
                        "trainable_parameters": int(sum(v.numel() for v in arena.views.values()))},
-            "roofline": {"bound": "mfma", "kernel": "tg_attention_bwd (statistics + dK/dV + dQ launches, all transformer layers of one micro-step)",
+            "roofline": {"bound": "mfma", "kernel": "tg_attention_bwd (statistics + the one-kernel dK/dV/dQ launch for the 17776^2 and the vip-key calls, dK/dV + dQ launches for the vip-query call; all transformer layers of one micro-step)",
                          "achieved": alg / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else None, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": (alg / (tot_ms * 1e-3) / 1e12 / 2500.0) if tot_ms > 0 else None, "traffic": traffic,
-                         "traffic_note": "bytes past L2 of ONE main (17776 x 17776, 96 heads) call's dK/dV + dQ launches; algorithmic 3.06e9",
+                         "traffic_note": "bytes past L2 of ONE main (17776 x 17776, 96 heads) call's backward launch(es) behind the statistics; algorithmic 3.06e9; the one-kernel form's ordered dQ accumulation is 60 GB of L2 read-modify-write, part of which reaches memory",
                          "ms_per_micro_step_in_this_kernel": tot_ms, "launches_per_micro_step": prof["n"] / max(1, a.steps)},
             **({"kernel_ms_per_micro_step": {k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(K.profile_summary().items(), key=lambda kv: -kv[1]["total_ms"])},
                 "launches_per_micro_step": {k: v["n"] / a.steps for k, v in K.profile_summary().items()}} if K.PROFILE_FILTER[0] is None else {}),
