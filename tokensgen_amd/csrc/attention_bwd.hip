@@ -747,7 +747,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(cval));
             if (lane == 0 && cval != blk) {
                 int spin = 0;
-                while (cnt_read(cntw + (long)T * CNT_PAD) != blk && ++spin < (1 << 16)) __builtin_amdgcn_s_sleep(2);
+                // (bounded: a workgroup that never sees its turn — only possible if the predecessor was descheduled for seconds — goes on instead of hanging the GPU)
+                while (cnt_read(cntw + (long)T * CNT_PAD) != blk && ++spin < (1 << 20)) __builtin_amdgcn_s_sleep(2);
             }
         }
     };
