@@ -1,3 +1,4 @@
+"""Reads the counters a `fprobe` library variant (tools/patches/fused_probe.py) leaves in dV: three workgroups, waves 0 and 5, at the training shape."""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from tokensgen_amd import kernels as K
