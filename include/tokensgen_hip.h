@@ -284,7 +284,8 @@ int tg_attention_fwd_lse_ex(const void* q, long q_ld, long q_strideB, const void
  * k, v: likewise with nk rows (v row-major here, not the transposed image of the forward).  dq / dk / dv: fp32, same indexing;
  * accumulate: 0 overwrite; 1 (= 3) add to what is there in all three; 2 add into dk / dv only, overwrite dq (the To2V processor's three attention
  * calls share K / V tensors — their gradients sum — but not queries).
- * ws: 16-byte aligned fp32 workspace of tg_attention_bwd_ws_floats(nq, nk, heads, batch) floats (row log-sum-exp and rowsum(dO o O); the
+ * ws: 16-byte aligned fp32 workspace of tg_attention_bwd_ws_floats(nq, nk, heads, batch) floats (row log-sum-exp, rowsum(dO o O), the statistics' seed
+ * rows and the one-kernel form's per-(head, query tile) counters, which the call zeroes itself; the
  * [d][row] operands are read from the row-major tiles with the LDS transpose read, no transposed copies).
  * P is recomputed from the log-sum-exp tile by tile.  Launches: statistics, then EITHER one kernel that forms dK, dV and dQ (5 GEMMs; the key blocks of
  * a head add their dQ contributions in a fixed order through L2 — used for calls with >= 4 query tiles per key block and a multiple of 8 (batch, head)
