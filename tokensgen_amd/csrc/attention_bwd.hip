@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
 // L1 is invalidated once per workgroup, after which every dQ line is loaded once and only when complete; the counter is polled with sc1 loads (past the
 // L1).  fused_probe_kernel checks exactly these primitives and the workgroup -> XCD mapping on the device before the launcher uses this kernel.
 // The wait never points at a workgroup that has not started (kb - 1 has the lower index).  The read-add-write of a tile is spread over the next
-// iterations (checked during iteration T, requested at the top of T + 1, written at the top of T + 2, signalled behind the barrier of T + 3), so
+// iterations (checked during iteration T, requested at the top of T + 1, written at the top of T + 2, signalled behind the barrier of T + 2), so
 // consecutive key blocks run a few tiles apart — which is why the launcher uses this kernel only for calls with many more query tiles than key blocks.
 // In-phase structure (one barrier per tile), statistics seeded through the matrix pipe as in the ping-pong kernel.  Measured at the training shape: 24.3 ms
 // against 15.9 + 11.4 for the two launches it replaces; without the dQ exchange the same kernel takes 19.1.
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
         // the dQ pipeline, all at the top of the iteration where a whole iteration has passed since the loads / stores it waits for were issued:
         // tile it - 3 signalled (its store went out one iteration ago), tile it - 2 written (its old values were requested one iteration ago), tile it - 1 requested
         // the dQ pipeline: tile T is checked (wave 0) during iteration T, requested at the top of T + 1, written at the top of T + 2, signalled behind the
-        // barrier of T + 3 — a whole iteration lies between every wait and what it waits for
+        // barrier of T + 2 (every wave waits for its store in front of that barrier)
         e_landed();
         if (it >= 2) e_write(it - 2, accO);
         fetch(min(it + 2, ntile - 1) * BT);
@@ -834,8 +834,9 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
         TG_SB();
         stash(sbuf);
         e_check(it);                                        // wave 0: key block blk - 1 has completed tile it (needed from the top of the next iteration on)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ldv));     // the store of tile it - 2 (issued at the top of this iteration) is in L2, the request is in
         __syncthreads();
-        if (it >= 3) e_signal(it - 3);                      // every wave passed its e_landed() of this iteration: the stores of tile it - 3 are in L2
+        if (it >= 2) e_signal(it - 2);
         e_sample(it + 1);
         // ---- this tile's dQ block: dS [16 q][256 keys] x K [256 keys][16 d] ----
         {
@@ -863,7 +864,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        for (int T = max(ntile - 3, 0); T < ntile; ++T) cnt_write(cntw + (long)T * CNT_PAD, blk + 1);
+        for (int T = max(ntile - 2, 0); T < ntile; ++T) cnt_write(cntw + (long)T * CNT_PAD, blk + 1);
     }
     asm volatile("s_nop 15" ::: "memory");
 #pragma unroll
