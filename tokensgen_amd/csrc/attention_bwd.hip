@@ -707,10 +707,24 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
     }
     uint4 g0 = uint4{0, 0, 0, 0}, gseed = maskrow;
     bool okr = false, oks = false;
-    auto fetch = [&](int q0) {
-        okr = q0 + row < p.nq; oks = q0 + j < p.nq;
-        g0 = ld_row16_clamped(srcR, ldR, q0 + row, p.nq, chunk);
-        gseed = p.seed[stat0 + min(q0 + j, p.nq - 1)];        // (every wave: a uniform number of loads per iteration; wave 0 stages it)
+    // running pointers: a tile that lies wholly inside the query range costs one load and one pointer add; clamped rows + masking for the last tile and the
+    // (never consumed) ones behind it.  The address arithmetic of an iteration's top (fetch, request, write: five 64-bit multiplies per lane) was a
+    // measurable part of the tile: ~500 of ~4000 cycles per tile went into that section
+    const bf16_t* pR = srcR + (long)row * ldR + chunk;
+    const long stepR = (long)BT * ldR;
+    const uint4* pS = p.seed + stat0 + j;
+    const int qlast = (ntile - 1) * BT;
+    const bf16_t* const pRLast = srcR + (long)min(qlast + row, p.nq - 1) * ldR + chunk;
+    const uint4* const pSLast = p.seed + stat0 + min(qlast + j, p.nq - 1);
+    const bool okrLast = qlast + row < p.nq, oksLast = qlast + j < p.nq;
+    int tfetch = 0;                                         // tile the next fetch() loads
+    auto fetch = [&](int) {
+        const bool inner = tfetch < ntile - 1;
+        okr = inner || okrLast; oks = inner || oksLast;
+        g0 = *(const uint4*)(inner ? pR : pRLast);
+        if (wave == 0) gseed = *(inner ? pS : pSLast);
+        pR += stepR; pS += BT;
+        ++tfetch;
     };
     auto stash = [&](int buf) {
         *(uint4*)((half ? sdO[buf] : sQ[buf]) + row * LQ2 + chunk) = mask16(g0, okr);
@@ -752,19 +766,25 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
             }
         }
     };
+    // this lane's dQ row of tile 0 and the tile-to-tile step; the last tile's rows may lie beyond nq: its request reads a clamped row, its write is skipped
+    float* pRq = DQb + (long)min(16 * qh + t16, p.nq - 1) * p.dq_ld;        // next request
+    float* pWr = pRq;                                                        // next write
+    const long stepDQ = (long)BT * p.dq_ld;
+    float* const pDQLast = DQb + (long)min(qlast + 16 * qh + t16, p.nq - 1) * p.dq_ld;
+    const bool okDQLast = qlast + 16 * qh + t16 < p.nq;
     auto e_request = [&](int T) {
-        const int q = T * BT + 16 * qh + t16;
-        const float* src = DQb + (long)min(q, p.nq - 1) * p.dq_ld;
+        const float* src = T < ntile - 1 ? pRq : pDQLast;
         if (!first) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ldv) : "v"(src) : "memory");
+        pRq += stepDQ;
     };
     auto e_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(ldv)); };      // last iteration's request is in, its store has been acknowledged by L2
     auto e_write = [&](int T, const f32x4& acc) {
-        const int q = T * BT + 16 * qh + t16;
-        if (q < p.nq) {
+        if (T < ntile - 1 || okDQLast) {
             f32x4 v = f32x4{acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale};
             if (!first) v = f32x4{v[0] + ldv[0], v[1] + ldv[1], v[2] + ldv[2], v[3] + ldv[3]};
-            *(f32x4*)(DQb + (long)q * p.dq_ld) = v;
+            *(f32x4*)(T < ntile - 1 ? pWr : pDQLast) = v;
         }
+        pWr += stepDQ;
     };
     e_sample(0);
     for (int it = 0; it < ntile; ++it) {

@@ -10,7 +10,9 @@ dq, dk, dv = (torch.empty(B, N1, D, dtype=torch.float32, device="cuda") for _ in
 for _ in range(2):
     K.attention_bwd(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], o, do, 48, 0.125, dq=dq, dk=dk, dv=dv)
 torch.cuda.synchronize()
-raw = dv.view(-1)[:64].view(torch.int64).cpu().tolist()
+raw = dv.view(-1)[:128].view(torch.int64).cpu().tolist()
+names = ["exchange at the top", "check (sample wait + polls)", "vmcnt + barrier", "rest of the iteration", "polls"]
 for i in range(6):
-    c = raw[4 * i: 4 * i + 4]
-    print("wg", [40, 320, 2400][i // 2], "wave", [0, 5][i % 2], "E ticks/tile %.1f  all ticks/tile %.1f  spins %d of %d tiles" % (c[0] / max(c[3], 1), c[1] / max(c[3], 1), c[2], c[3]))
+    c = raw[8 * i: 8 * i + 8]
+    nt = max(c[5], 1)
+    print("workgroup", [40, 320, 2400][i // 2], "wave", [0, 5][i % 2], {n: round(c[k] / nt, 1) for k, n in enumerate(names)}, "tiles", c[5])
