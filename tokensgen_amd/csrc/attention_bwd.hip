@@ -618,14 +618,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
 // head dims, resident; B = dS through transposed reads of the [key][query] tiles; a lane ends up with 4 consecutive floats of one dQ row.
 // The key blocks of a head add their blocks to the fp32 dQ tile in global memory IN KEY-BLOCK ORDER (bitwise reproducible, no atomics on the data): per
 // (head, tile) a counter says how many key blocks have added; key block kb waits for the counter to reach kb (wave 0, before the tile's barrier), every
-// wave reads its 16 bytes per row, adds, writes, and when every wave's write has been acknowledged by L2 (vmcnt(0) + the next barrier) the counter is
-// set to kb + 1.  All workgroups of a head run on ONE XCD (xcd_block), whose L2 is the coherence point: stores are written through the CU's L1; the CU's
+// thread reads 16 bytes of the tile (the eight blocks meet in an LDS tile so that 16 lanes cover a whole 256-byte dQ row: full lines), adds, writes,
+// and when every wave's write has been acknowledged by L2 (vmcnt(0) + the next barrier) the counter is set to kb + 1.  All workgroups of a head run on ONE XCD (xcd_block), whose L2 is the coherence point: stores are written through the CU's L1; the CU's
 // L1 is invalidated once per workgroup, after which every dQ line is loaded once and only when complete; the counter is polled with sc1 loads (past the
 // L1).  fused_probe_kernel checks exactly these primitives and the workgroup -> XCD mapping on the device before the launcher uses this kernel.
 // The wait never points at a workgroup that has not started (kb - 1 has the lower index).  The read-add-write of a tile is spread over the next
 // iterations (checked during iteration T, requested at the top of T + 1, written at the top of T + 2, signalled behind the barrier of T + 2), so
 // consecutive key blocks run a few tiles apart — which is why the launcher uses this kernel only for calls with many more query tiles than key blocks.
-// In-phase structure (one barrier per tile), statistics seeded through the matrix pipe as in the ping-pong kernel.  Measured at the training shape: 24.3 ms
+// In-phase structure (one barrier per tile), statistics seeded through the matrix pipe as in the ping-pong kernel.  Measured at the training shape: ~23.8 ms
 // against 15.9 + 11.4 for the two launches it replaces; without the dQ exchange the same kernel takes 19.1.
 // =================================================================================================================================
 struct FusedParams {
@@ -633,7 +633,8 @@ struct FusedParams {
     int* cnt;            // [heads * batch][query tiles][32]: key blocks that have added their dQ blocks, one counter per 128-byte line (zeroed by the launcher)
 };
 constexpr int DSLD = 40;                 // dS^T tile row stride in elements (80 B: 8-byte aligned 4-query runs)
-constexpr int FUSED_LDS = 2 * 3 * ROWT_EL * 2 + 3 * 64 * 16 + 2 * 256 * DSLD * 2;
+constexpr int DQLD = 68;                 // dQ tile row stride in floats (272 B: the 16 lanes of a block column land on different banks)
+constexpr int FUSED_LDS = 2 * 3 * ROWT_EL * 2 + 3 * 64 * 16 + 2 * 256 * DSLD * 2 + 2 * BT * DQLD * 4;
 
 // The counters and the dQ blocks are exchanged between workgroups of ONE XCD, whose L2 is the coherence point — and the only accesses that are certain to
 // be performed AT the L2 are atomics.  So a workgroup ADDS its block with global_atomic_add_f32 (no read-modify-write round trip in the kernel at all; the
@@ -655,6 +656,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
     bf16_t (*sdO)[ROWT_EL] = (bf16_t (*)[ROWT_EL])(fsm + 3 * ROWT_EL * 2);              // [3]
     uint4 (*sSt)[64] = (uint4 (*)[64])(fsm + 6 * ROWT_EL * 2);                            // [3] seed rows (entries 32..63 zero)
     bf16_t* sDS = (bf16_t*)(fsm + 6 * ROWT_EL * 2 + 3 * 64 * 16);                         // [2][256][DSLD]
+    float* sDQ = (float*)(fsm + 6 * ROWT_EL * 2 + 3 * 64 * 16 + 2 * 256 * DSLD * 2);     // [2][32][DQLD]: the tile's dQ contribution, all eight blocks
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, hi = lane >> 5, t16 = lane & 15, g4 = lane >> 4;
     int blk, hb;
@@ -741,11 +743,13 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
     __syncthreads();
     constexpr int CNT_PAD = 32;                               // one counter per 128-byte line
     int* const cntw = fp.cnt + (long)hb * ntile * CNT_PAD;   // one counter per (head, tile): key blocks that have added
-    // the block is formed TRANSPOSED (rows = head dims 4 g4 + r, column = query t16): a lane then owns 4 consecutive floats of one dQ row — one 16-byte
-    // load and one 16-byte store per tile
-    float* const DQb = p.dq + (long)b * p.dq_sb + h * HD + 16 * dblk + 4 * g4;
+    // the blocks are formed TRANSPOSED (rows = head dims 4 g4 + r, column = query t16: a lane owns 4 consecutive floats of one dQ row) and meet in an LDS tile
+    // [32 q][64 d]; the exchange with global memory is done by thread (er = tid >> 4, ec = 4 (tid & 15)): 16 lanes cover one whole 256-byte dQ row — FULL
+    // 128-byte lines.  (With every wave exchanging its own 16 x 16 block, two waves shared a line: half-line stores, 13.9 GB of the 30 GB stored went out past
+    // the L2 and the reads behind them came back late.)
+    const int er = tid >> 4, ec = (tid & 15) * 4;
+    float* const DQb = p.dq + (long)b * p.dq_sb + h * HD + ec;
     const bool first = blk == 0 && !(p.accumulate & 1);      // nothing to read: this workgroup's block starts the sum
-    f32x4 accP = f32x4{0.f, 0.f, 0.f, 0.f}, accO = f32x4{0.f, 0.f, 0.f, 0.f};      // blocks of the last two tiles
     f32x4 ldv = f32x4{0.f, 0.f, 0.f, 0.f};
     int cval = 0;                                           // wave 0: counter of the next tile to check, sampled one iteration ahead
     asm volatile("buffer_inv sc1" ::: "memory");            // ONCE per workgroup: whatever earlier workgroups on this CU left in its L1 is gone; from here on
@@ -767,19 +771,20 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
         }
     };
     // this lane's dQ row of tile 0 and the tile-to-tile step; the last tile's rows may lie beyond nq: its request reads a clamped row, its write is skipped
-    float* pRq = DQb + (long)min(16 * qh + t16, p.nq - 1) * p.dq_ld;        // next request
+    float* pRq = DQb + (long)min(er, p.nq - 1) * p.dq_ld;                    // next request
     float* pWr = pRq;                                                        // next write
     const long stepDQ = (long)BT * p.dq_ld;
-    float* const pDQLast = DQb + (long)min(qlast + 16 * qh + t16, p.nq - 1) * p.dq_ld;
-    const bool okDQLast = qlast + 16 * qh + t16 < p.nq;
+    float* const pDQLast = DQb + (long)min(qlast + er, p.nq - 1) * p.dq_ld;
+    const bool okDQLast = qlast + er < p.nq;
     auto e_request = [&](int T) {
         const float* src = T < ntile - 1 ? pRq : pDQLast;
         if (!first) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ldv) : "v"(src) : "memory");
         pRq += stepDQ;
     };
     auto e_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(ldv)); };      // last iteration's request is in, its store has been acknowledged by L2
-    auto e_write = [&](int T, const f32x4& acc) {
+    auto e_write = [&](int T) {
         if (T < ntile - 1 || okDQLast) {
+            const f32x4 acc = *(const f32x4*)(sDQ + ((T & 1) * BT + er) * DQLD + ec);        // (written behind the barrier of iteration T, one barrier ago at least)
             f32x4 v = f32x4{acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale};
             if (!first) v = f32x4{v[0] + ldv[0], v[1] + ldv[1], v[2] + ldv[2], v[3] + ldv[3]};
             *(f32x4*)(T < ntile - 1 ? pWr : pDQLast) = v;
@@ -794,7 +799,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
         // the dQ pipeline: tile T is checked (wave 0) during iteration T, requested at the top of T + 1, written at the top of T + 2, signalled behind the
         // barrier of T + 2 (every wave waits for its store in front of that barrier)
         e_landed();
-        if (it >= 2) e_write(it - 2, accO);
+        if (it >= 2) e_write(it - 2);
         fetch(min(it + 2, ntile - 1) * BT);
         if (it >= 1) e_request(it - 1);                      // (tile it - 1 was checked before the previous barrier)
         // ---- S, dP of this tile (statistics seeded through the matrix pipe) ----
@@ -871,16 +876,16 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s2 = 0; s2 < 8; ++s2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb8[s2].v, a8[s2].v, acc, 0, 0, 0);     // rows = head dims, column = query
-            accO = accP;
-            accP = acc;
+            *(f32x4*)(sDQ + ((it & 1) * BT + 16 * qh + t16) * DQLD + 16 * dblk + 4 * g4) = acc;
         }
     }
     // drain the dQ pipeline (tiles ntile - 2 and ntile - 1 are still to be written, ntile - 3 .. ntile - 1 to be signalled)
+    __syncthreads();                                        // the last tile's blocks are in the LDS tile
     e_landed();
-    if (ntile >= 2) e_write(ntile - 2, accO);
+    if (ntile >= 2) e_write(ntile - 2);
     e_request(ntile - 1);                                   // (checked before the last barrier)
     e_landed();
-    e_write(ntile - 1, accP);
+    e_write(ntile - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
