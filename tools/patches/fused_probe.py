@@ -19,7 +19,7 @@ rep("            if (lane == 0 && cval != blk) {\n                int spin = 0;"
 rep("        e_check(it);                                        // wave 0: key block blk - 1 has completed tile it (needed from the top of the next iteration on)\n",
     "        " + T % 3 + "\n        e_check(it);\n        " + T % 1 + "\n")
 rep("        if (it >= 2) e_signal(it - 2);\n", "        " + T % 2 + "\n        if (it >= 2) e_signal(it - 2);\n")
-rep("            accO = accP;\n            accP = acc;\n        }\n    }\n", "            accO = accP;\n            accP = acc;\n        }\n        " + T % 3 + "\n    }\n")
+rep("            *(f32x4*)(sDQ + ((it & 1) * BT + 16 * qh + t16) * DQLD + 16 * dblk + 4 * g4) = acc;\n        }\n    }\n", "            *(f32x4*)(sDQ + ((it & 1) * BT + 16 * qh + t16) * DQLD + 16 * dblk + 4 * g4) = acc;\n        }\n        " + T % 3 + "\n    }\n")
 rep("            *c = (p.accumulate & 2) ? *c + vv : vv;\n        }\n    }\n}\n\n// One-time probe",
     "            *c = (p.accumulate & 2) ? *c + vv : vv;\n        }\n    }\n    __syncthreads();\n"
     "    if (lane == 0 && (wave == 0 || wave == 5) && (blockIdx.x == 40 || blockIdx.x == 320 || blockIdx.x == 2400)) { long long* o_ = (long long*)fp.p.dv + ((blockIdx.x == 40 ? 0 : blockIdx.x == 320 ? 1 : 2) * 2 + (wave ? 1 : 0)) * 8; for (int i = 0; i < 5; ++i) o_[i] = tc[i]; o_[5] = ntile; }\n}\n\n// One-time probe")
