@@ -285,18 +285,42 @@ int tg_attention_fwd_lse_ex(const void* q, long q_ld, long q_strideB, const void
  * accumulate: 0 overwrite; 1 (= 3) add to what is there in all three; 2 add into dk / dv only, overwrite dq (the To2V processor's three attention
  * calls share K / V tensors — their gradients sum — but not queries).
  * ws: 16-byte aligned fp32 workspace of tg_attention_bwd_ws_floats(nq, nk, heads, batch) floats (row log-sum-exp, rowsum(dO o O), the statistics' seed
- * rows and the one-kernel form's per-(head, query tile) counters, which the call zeroes itself; the
+ * rows and the one-kernel form's per-(head, query tile) counters, which tg_attention_bwd_ex zeroes itself; the
  * [d][row] operands are read from the row-major tiles with the LDS transpose read, no transposed copies).
- * P is recomputed from the log-sum-exp tile by tile.  Launches: statistics, then EITHER one kernel that forms dK, dV and dQ (5 GEMMs; the key blocks of
- * a head add their dQ contributions in a fixed order through L2 — used for calls with >= 4 query tiles per key block and a multiple of 8 (batch, head)
- * pairs, after a one-time device probe of the exchange protocol; TG_ATTN_BWD_FUSED=0 disables) OR dK/dV per 256-key workgroup + dQ per 256-query
- * workgroup (7 GEMMs).  No atomics on the data either way: run-to-run deterministic.  lse: optional [batch][heads][nq] fp32 row log-sum-exp (log2 domain) written by
+ * P is recomputed from the log-sum-exp tile by tile.  Launches: statistics, then dK/dV per 256-key workgroup + dQ per 256-query workgroup (7 executed
+ * GEMMs).  No atomics on the data: run-to-run deterministic.  lse: optional [batch][heads][nq] fp32 row log-sum-exp (log2 domain) written by
  * tg_attention_fwd_lse for the same q / k / scale — the statistics launch then only forms rowsum(dO o O); NULL: recomputed here.
  * TG_ATTN_BWD_V1=1 selects the earlier correct-first kernels (cross-check). */
 int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void* k, long k_ld, long k_sb, const void* v, long v_ld, long v_sb,
                      const void* o, long o_ld, long o_sb, const void* dout, long do_ld, long do_sb,
                      float* dq, long dq_ld, long dq_sb, float* dk, long dk_ld, long dk_sb, float* dv, long dv_ld, long dv_sb,
                      int nq, int nk, int heads, int batch, float scale, int accumulate, const float* lse, float* ws, hipStream_t stream);
+
+/* tg_attention_bwd with the ONE-KERNEL form available (5 executed GEMMs: S and dP are formed once; the key blocks of a head add their dQ
+ * contributions to the fp32 dQ tile in key-block order through the XCD's L2 — still no atomics on the data, still bitwise reproducible).
+ *   flags & TG_BWD_ONE_KERNEL: the caller has run tg_attention_bwd_probe on THIS device and tg_attention_bwd_probe_verdict returned 1.  The form is
+ *     then used for calls with >= 4 query tiles per key block and a multiple of 8 (batch, head) pairs; every other call takes the two launches above.
+ *   status: caller-owned DEVICE int32[4], zeroed once by the caller (required with TG_BWD_ONE_KERNEL, may be NULL otherwise):
+ *     [0] sticky count of ordered-exchange polls that gave up (a key block never saw its predecessor's signal within the poll limit).  The kernel
+ *         does not hang the GPU in that case, it goes on — and the dq of that launch is INVALID.  The caller reads the word whenever it next
+ *         synchronises (e.g. once per optimizer micro-step) and must discard the step when it is non-zero.  The launch itself returns 0: the
+ *         condition only exists on the device, and the ABI never synchronises.
+ *     [1] poll limit override (0: 2^20 polls of ~100 cycles); tests set 1 to force the path.   [2], [3] reserved (keep zero).
+ * Nothing is allocated, freed or synchronised inside; safe under stream capture; no process-wide state. */
+enum { TG_BWD_ONE_KERNEL = 1 };
+int tg_attention_bwd_ex(const void* q, long q_ld, long q_sb, const void* k, long k_ld, long k_sb, const void* v, long v_ld, long v_sb,
+                        const void* o, long o_ld, long o_sb, const void* dout, long do_ld, long do_sb,
+                        float* dq, long dq_ld, long dq_sb, float* dk, long dk_ld, long dk_sb, float* dv, long dv_ld, long dv_sb,
+                        int nq, int nk, int heads, int batch, float scale, int accumulate, const float* lse, float* ws, int flags, int* status,
+                        hipStream_t stream);
+
+/* Device probe of what the one-kernel form relies on: (1) workgroup w of a 1-D launch runs on XCD w % 8; (2) the exchange protocol itself — a chain
+ * of 32 workgroups on one XCD adds to 64 tiles in chain order with exactly the kernel's primitives.  buf: caller-owned device memory of
+ * tg_attention_bwd_probe_bytes() bytes (16-byte aligned); the call clears it and launches the probe, asynchronously.  The caller copies buf to the
+ * host once the stream has passed it; tg_attention_bwd_probe_verdict(host copy) = 1 when every sum is exact and no poll timed out, else 0. */
+long tg_attention_bwd_probe_bytes(void);
+int tg_attention_bwd_probe(void* buf, long nbytes, hipStream_t stream);
+int tg_attention_bwd_probe_verdict(const void* host_copy, long nbytes);
 long tg_attention_bwd_ws_floats(int nq, int nk, int heads, int batch);
 
 /* Backward of tg_qk_layernorm_rope (y = rope(bf16(LN64(x) g + b)) * out_scale; attention_processor.py:2031-2056) for the trainable vip_norm_q /

@@ -187,16 +187,19 @@ def run_fifo_prenoise(denoise_window, betas, ac, fifo_latents, fifo_old_x0, time
 
 
 def base_stage(denoise, ac, latents, timesteps, guidance_scale, noise_fn, nf=13, use_separate_guidance=False, guidance_scale_img=None,
-               use_dynamic_cfg=False):
+               use_dynamic_cfg=False, export=None):
     """Base stage of the pipeline, pipeline_cogvideox_mp_fifo.py:1186-1307 (chunk 0, scalar timestep, CFG in fp32,
     whole-chunk scheduler step, latents cast back to the model dtype).  denoise(x[nb,nf,...], t[nb]) -> [nb,nf,...] (nb = 3 with
     use_separate_guidance, :1197-1200); noise_fn(i) -> [nf,2,C,H,W] (draw 1 of every frame is the one the 2M branch keeps).  Returns
     (fifo_latents [1,T,C,H,W], fifo_old list, final latents).  The default branch is pinned bit-exact to a run of the reference pipeline
-    (tests/golden/base_stage_tiny.pt); the separate-guidance / dynamic-cfg lines (:1252-1263) are the worker's expressions with Python-float
-    scales, whose tensor forms ARE pinned (fifo_worker_variants.pt)."""
+    (tests/golden/base_stage_tiny.pt); the separate-guidance + dynamic-cfg branch (:1252-1263) to a second run (base_stage_dyn_sep.pt): there the
+    reference re-assigns its LOCAL `guidance_scale_img = 1 + guidance_scale_img * ramp` every step (:1257), so the image weight COMPOUNDS from
+    step to step, while the text weight is recomputed from the unchanged argument (:1254, it goes to self._guidance_scale); `export` (a dict,
+    optional) receives what the stage hands to the FIFO driver: guidance_scale (the argument, :1335) and guidance_scale_img (the compounded
+    local, :1336)."""
     import math
     nb = 3 if use_separate_guidance else 2
-    gi0 = guidance_scale if guidance_scale_img is None else guidance_scale_img
+    gi = guidance_scale if guidance_scale_img is None else guidance_scale_img      # :1026-1029
     T = len(timesteps)
     dt = latents.dtype
     fifo_lat, fifo_old, old = [], [], None
@@ -206,10 +209,10 @@ def base_stage(denoise, ac, latents, timesteps, guidance_scale, noise_fn, nf=13,
         fifo_lat.insert(0, latents[:, [k]])
         fifo_old.insert(0, None if old is None else old[:, [k]])
         pred = denoise(torch.cat([latents] * nb), torch.tensor([t] * nb)).float()
-        g, gi = guidance_scale, gi0
+        g = guidance_scale
         if use_dynamic_cfg:                                                     # :1252-1259
             g = 1 + guidance_scale * ((1 - math.cos(math.pi * ((T - t) / T) ** 5.0)) / 2)
-            gi = 1 + gi0 * ((1 - math.cos(math.pi * ((T - t) / T) ** 5.0)) / 2)
+            gi = 1 + gi * ((1 - math.cos(math.pi * ((T - t) / T) ** 5.0)) / 2)      # (the local is overwritten: compounds)
         if use_separate_guidance:                                               # :1261-1263
             ut, ui, c = pred.chunk(3)
             pred = c + (g - 1) * (c - ut) + (gi - 1) * (c - ui)
@@ -224,4 +227,6 @@ def base_stage(denoise, ac, latents, timesteps, guidance_scale, noise_fn, nf=13,
         seq = iter([n, n])
         latents_f, old = S.dpm_step(ac, pred, old, t, prev_t, t_back, latents, lambda: next(seq))
         latents = latents_f.to(dt)
+    if export is not None:
+        export.update(guidance_scale=guidance_scale, guidance_scale_img=gi)
     return torch.cat(fifo_lat, dim=1), fifo_old, latents

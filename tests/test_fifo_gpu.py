@@ -154,6 +154,42 @@ def test_base_stage_vs_reference_pipeline_golden(golden_dir, parity):
     parity(rel(x0, x0r), 2e-2, "base stage x0 seed list vs reference pipeline run")
 
 
+@pytest.mark.timeout(900)
+def test_base_stage_dynamic_separate_guidance_vs_reference_pipeline_golden(golden_dir, parity):
+    """The base stage with use_dynamic_cfg + use_separate_guidance against the reference's OWN pipeline run in that mode
+    (tests/golden/base_stage_dyn_sep.pt, bf16 case, draws replayed): the image guidance weight is the reference's local variable re-assigned every
+    step (pipeline_cogvideox_mp_fifo.py:1257) — it compounds — and the compounded value is what the stage exports to the FIFO driver (:1336)."""
+    from tokensgen_amd.pipeline import MPFIFOVideoIPAdapterCogVideoXPipeline
+    from tokensgen_amd.scheduler import CogVideoXDPMScheduler
+    from tokensgen_amd.transformer import CogVideoXTransformer3DModel
+    gt = torch.load(os.path.join(golden_dir, "dit_tiny.pt"), weights_only=False)
+    g = torch.load(os.path.join(golden_dir, "base_stage_dyn_sep.pt"), weights_only=False)
+    c = g["cases"]["torch.bfloat16"]
+    cfg, vipcfg, H, W, T, nf = gt["cfg"], gt["vip"], g["H"], g["W"], g["steps"], 13
+    sd = {k: v.to(BF) for k, v in O.make_state_dict(cfg, 128, seed=g["weight_seed"]).items()}
+    m = CogVideoXTransformer3DModel(num_attention_heads=2, attention_head_dim=64, num_layers=2, time_embed_dim=cfg["time_embed_dim"],
+                                    text_embed_dim=cfg["text_embed_dim"], use_rotary_positional_embeddings=True, device=DEV)
+    m.set_vip_layers(None, **vipcfg)
+    m.load_state_dict(sd, strict=True)
+    sched = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
+    pipe = MPFIFOVideoIPAdapterCogVideoXPipeline(m, sched, resampler_config=dict(num_temporal_queries=4, num_height_queries=2, num_width_queries=3))
+    draws, per_step, k = list(c["step_draws"]), [], 0
+    for i in range(T):
+        n = 1 if (i == 0 or i == T - 1) else 2
+        per_step.append(draws[k:k + n]); k += n
+    unc = torch.cat([g["unc_tok"].to(BF)] * (g["chunks"] + 1), dim=1)
+    out = pipe(prompt_embeds=c["prompt"], negative_prompt_embeds=c["negative"], image_embeddings=c["emb_in"], uncond_image_embeddings=unc,
+               height=H * 8, width=W * 8, num_chunks=g["chunks"], num_inference_steps=T, latents=c["init_latents"], video_ipadapter_scale=g["vip_scale"],
+               guidance_scale=g["guidance_scale"], guidance_scale_img=g["guidance_scale_img"], use_separate_guidance=True, use_dynamic_cfg=True,
+               step_noise=lambda i: torch.stack([per_step[i][0][0], per_step[i][-1][0]], dim=1))
+    assert torch.equal(out.image_embeddings.cpu(), c["image_embeddings"]) and torch.equal(out.prompt_embeds.cpu(), c["prompt_embeds"])
+    assert out.guidance_scale == c["guidance_scale_out"]
+    assert out.guidance_scale_img == c["guidance_scale_img_out"] != g["guidance_scale_img"]        # Python-float arithmetic: exact
+    rel = lambda a, b: ((a.float().cpu() - b.float()).norm() / b.float().norm()).item()
+    parity(rel(out.fifo_latents, c["fifo_latents"]), 2e-2, "dynamic + 3-way base stage FIFO seed latents vs reference pipeline run (bf16, 16 SDE steps)")
+    parity(rel(out.orig_latents, c["orig_latents"]), 2e-2, "dynamic + 3-way base stage final latents vs reference pipeline run")
+
+
 def test_fifo_worker_guidance_variants_vs_reference_runs(golden_dir, parity):
     """FifoWorker.window_step on the HIP path against RUNS OF THE REFERENCE WORKER BODY (`fifo_onestep_per_gpu`,
     cogvideo_sampling_mp_fifo.py:408-579; tests/golden/fifo_worker_variants.pt, bf16 cases) for the branches the shipped configs leave off:

@@ -631,17 +631,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
 struct FusedParams {
     BwdParams p;
     int* cnt;            // [heads * batch][query tiles][32]: key blocks that have added their dQ blocks, one counter per 128-byte line (zeroed by the launcher)
+    int* status;         // caller-owned int32[4]: [0] sticky count of exchange polls that timed out (dq of such a launch is INVALID), [1] poll limit (0: 2^20)
 };
 constexpr int DSLD = 40;                 // dS^T tile row stride in elements (80 B: 8-byte aligned 4-query runs)
 constexpr int DQLD = 68;                 // dQ tile row stride in floats (272 B: the 16 lanes of a block column land on different banks)
 constexpr int FUSED_LDS = 2 * 3 * ROWT_EL * 2 + 3 * 64 * 16 + 2 * 256 * DSLD * 2 + 2 * BT * DQLD * 4;
 
-// The counters and the dQ blocks are exchanged between workgroups of ONE XCD, whose L2 is the coherence point — and the only accesses that are certain to
-// be performed AT the L2 are atomics.  So a workgroup ADDS its block with global_atomic_add_f32 (no read-modify-write round trip in the kernel at all; the
-// order of the adds per address is the key-block order the counters enforce, so the sum is still bitwise reproducible), signals with a store (written
-// through the CU's L1 to L2) and reads the counters with a returning atomic OR 0.  Measured on the way: agent-scope atomics compile to sc1 accesses that
-// travel to memory behind the L2 (every iteration waited 600-1400 cycles for its signal store's acknowledgement); the sc0 bit alone is workgroup scope and
-// does not bypass the L1 (stale counters, polls that never end); buffer_inv sc1 before plain loads is correct and 8x slower than the whole kernel.
+// The counters and the dQ blocks are exchanged between workgroups of ONE XCD, whose L2 is the coherence point.  What the kernel uses, and what
+// tg_attention_bwd_probe checks on the device before a caller may select this form: dQ lines are read with PLAIN 16-byte loads behind one
+// `buffer_inv sc1` per workgroup (every line is loaded once, and only after the key block before has signalled the whole tile, so the CU's L1 never holds a
+// stale copy of it); they are written with plain stores, which go through the CU's L1 to the XCD's L2; the counter is written with a plain store behind
+// every wave's vmcnt(0) + a barrier, and polled with sc1 loads (past the L1).  No atomics on the data or on the counters.  Measured on the way:
+// agent-scope atomics compile to sc1 accesses that travel to memory behind the L2 (every iteration waited 600-1400 cycles for its signal store's
+// acknowledgement); the sc0 bit alone is workgroup scope and does not bypass the L1 (stale counters, polls that never end); buffer_inv sc1 before
+// every plain load is correct and 8x slower than the whole kernel.
 __device__ __forceinline__ int cnt_read(int* c) {
     int v;
     asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(c) : "memory");
@@ -757,16 +760,20 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
     auto e_signal = [&](int T) {                             // (wave 0, behind a barrier behind every wave's vmcnt(0)): the stores of tile T are in L2
         if (tid == 0) cnt_write(cntw + (long)T * CNT_PAD, blk + 1);
     };
-    auto e_sample = [&](int T) {                             // (wave 0) returning atomic: performed at the L2
+    auto e_sample = [&](int T) {                             // (wave 0) sc1 load: served by the L2, not by this CU's L1
         if (wave == 0) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(cval) : "v"(cntw + (long)min(T, ntile - 1) * CNT_PAD) : "memory");
     };
     auto e_check = [&](int T) {                              // (wave 0, before the barrier that lets the others request tile T)
         if (wave == 0 && blk > 0) {
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(cval));
             if (lane == 0 && cval != blk) {
+                // bounded: a workgroup that never sees its turn (its predecessor descheduled for seconds) goes on instead of hanging the GPU — and SAYS so:
+                // the sticky word status[0] counts the polls that gave up; the dq this launch leaves is then invalid and the host must not use it
+                // (kernels.attention_bwd_check raises).  status[1] != 0 overrides the limit (tests force the path with 1).
+                const int lim = fp.status[1] > 0 ? fp.status[1] : (1 << 20);
                 int spin = 0;
-                // (bounded: a workgroup that never sees its turn — only possible if the predecessor was descheduled for seconds — goes on instead of hanging the GPU)
-                while (cnt_read(cntw + (long)T * CNT_PAD) != blk && ++spin < (1 << 20)) __builtin_amdgcn_s_sleep(2);
+                while (cnt_read(cntw + (long)T * CNT_PAD) != blk && ++spin < lim) __builtin_amdgcn_s_sleep(2);
+                if (spin >= lim) atomicAdd(fp.status, 1);
             }
         }
     };
@@ -943,36 +950,47 @@ extern "C" long tg_attention_bwd_ws_floats(int nq, int nk, int heads, int batch)
     return 6L * batch * heads * nq + 8 + (long)batch * heads * ((nq + BT - 1) / BT) * 32 + 8;      // + the one-kernel form's dQ counters
 }
 
-// one-time check (per process): workgroup -> XCD mapping and the L2 exchange protocol of the one-kernel backward (fused_probe_kernel)
-static bool fused_protocol_ok(hipStream_t stream) {
-    static int state = -1;
-    if (state < 0) {
-        state = 0;
-        const size_t nb = sizeof(int) * (4 + 64 * 32) + sizeof(float) * 64 * 64 * 4;
-        char* buf = nullptr;
-        if (hipMalloc(&buf, nb) == hipSuccess) {
-            int* bad = (int*)buf;
-            int* cnt = bad + 4;
-            float* data = (float*)(cnt + 64 * 32);
-            (void)hipMemsetAsync(buf, 0, nb, stream);
-            hipLaunchKernelGGL(fused_probe_kernel, dim3(4096), dim3(64), 0, stream, bad, cnt, data);
-            std::vector<char> host(nb);
-            if (hipMemcpyAsync(host.data(), buf, nb, hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess) {
-                bool ok = *(const int*)host.data() == 0;
-                const float* hd = (const float*)(host.data() + sizeof(int) * (4 + 64 * 32));
-                for (int i = 0; i < 64 * 64 * 4 && ok; ++i) ok = hd[i] == 528.0f;          // 1 + 2 + ... + 32, every element, exactly
-                state = ok ? 1 : 0;
-            }
-            (void)hipFree(buf);
-        }
-    }
-    return state == 1;
+// The device probe of the one-kernel form (fused_probe_kernel) as explicit entry points on CALLER-owned memory: nothing is allocated, freed or
+// synchronised inside the ABI.  The caller zero-fills nothing (the call clears the buffer itself, asynchronously), copies the buffer to the host once the
+// stream has passed the launch, and hands the copy to tg_attention_bwd_probe_verdict.
+constexpr long PROBE_INTS = 4 + 64 * 32, PROBE_FLOATS = 64 * 64 * 4;
+extern "C" long tg_attention_bwd_probe_bytes(void) { return (long)sizeof(int) * PROBE_INTS + (long)sizeof(float) * PROBE_FLOATS; }
+
+extern "C" int tg_attention_bwd_probe(void* buf, long nbytes, hipStream_t stream) {
+    TG_REQUIRE(buf && tg_aligned16(buf), TG_ERR_ARG, "tg_attention_bwd_probe: buf must be a 16-byte aligned device pointer");
+    TG_REQUIRE(nbytes >= tg_attention_bwd_probe_bytes(), TG_ERR_SHAPE, "tg_attention_bwd_probe: buffer of %ld bytes, need %ld", nbytes, tg_attention_bwd_probe_bytes());
+    const hipError_t e = hipMemsetAsync(buf, 0, (size_t)tg_attention_bwd_probe_bytes(), stream);
+    if (e != hipSuccess) return tg_set_error(TG_ERR_HIP - (int)e, "tg_attention_bwd_probe: memset failed: %s", hipGetErrorString(e));
+    int* bad = (int*)buf;
+    int* cnt = bad + 4;
+    float* data = (float*)(cnt + 64 * 32);
+    hipLaunchKernelGGL(fused_probe_kernel, dim3(4096), dim3(64), 0, stream, bad, cnt, data);
+    TG_LAUNCH_CHECK("tg_attention_bwd_probe");
+    return TG_OK;
+}
+
+extern "C" int tg_attention_bwd_probe_verdict(const void* host_copy, long nbytes) {
+    if (!host_copy || nbytes < tg_attention_bwd_probe_bytes()) return 0;
+    if (*(const int*)host_copy != 0) return 0;                                          // a workgroup off its XCD, or a poll that did not end
+    const float* hd = (const float*)((const char*)host_copy + sizeof(int) * PROBE_INTS);
+    for (long i = 0; i < PROBE_FLOATS; ++i)
+        if (hd[i] != 528.0f) return 0;                                                  // 1 + 2 + ... + 32, every element, exactly
+    return 1;
 }
 
 extern "C" int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void* k, long k_ld, long k_sb, const void* v, long v_ld, long v_sb,
                                  const void* o, long o_ld, long o_sb, const void* dout, long do_ld, long do_sb,
                                  float* dq, long dq_ld, long dq_sb, float* dk, long dk_ld, long dk_sb, float* dv, long dv_ld, long dv_sb,
                                  int nq, int nk, int heads, int batch, float scale, int accumulate, const float* lse, float* ws, hipStream_t stream) {
+    return tg_attention_bwd_ex(q, q_ld, q_sb, k, k_ld, k_sb, v, v_ld, v_sb, o, o_ld, o_sb, dout, do_ld, do_sb, dq, dq_ld, dq_sb, dk, dk_ld, dk_sb, dv, dv_ld,
+                               dv_sb, nq, nk, heads, batch, scale, accumulate, lse, ws, 0, nullptr, stream);
+}
+
+extern "C" int tg_attention_bwd_ex(const void* q, long q_ld, long q_sb, const void* k, long k_ld, long k_sb, const void* v, long v_ld, long v_sb,
+                                    const void* o, long o_ld, long o_sb, const void* dout, long do_ld, long do_sb,
+                                    float* dq, long dq_ld, long dq_sb, float* dk, long dk_ld, long dk_sb, float* dv, long dv_ld, long dv_sb,
+                                    int nq, int nk, int heads, int batch, float scale, int accumulate, const float* lse, float* ws, int flags, int* status,
+                                    hipStream_t stream) {
     accumulate = accumulate == 1 ? 3 : (accumulate & 3);      // bit 0: dq, bit 1: dk and dv; 1 = all three (the original meaning of the flag)
     static const bool v1 = [] { const char* e = getenv("TG_ATTN_BWD_V1"); return e && e[0] == '1'; }();   // the cross-check kernels (attention_bwd_ref.hip)
     TG_REQUIRE(q && k && v && o && dout && dq && dk && dv && ws, TG_ERR_ARG, "tg_attention_bwd: null pointer");
@@ -995,19 +1013,16 @@ extern "C" int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void*
     if (lse) pp.p.lse = const_cast<float*>(lse);
     const dim3 gq((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), gk((unsigned)((nk + 255) / 256), (unsigned)(batch * heads));
     hipLaunchKernelGGL(attn_bwd_stats2_kernel, gq, dim3(256), 0, stream, pp.p);
-    static const bool fused_on = [] { const char* e = getenv("TG_ATTN_BWD_FUSED"); return !(e && e[0] == '0'); }();       // default on; 0: always the two-kernel form
+    TG_REQUIRE(!(flags & TG_BWD_ONE_KERNEL) || status, TG_ERR_ARG, "tg_attention_bwd_ex: TG_BWD_ONE_KERNEL needs the status words");
     // the ordered dQ accumulation runs the key blocks of a head as a chain a few tiles apart: worth it only when there are many more query tiles than
     // key blocks (the 17776^2 call: 556 tiles, 70 blocks; the vip queries' call with 15 tiles and 72 blocks would serialise)
     const bool chain_ok = (long)((nq + BT - 1) / BT) >= 4L * gk.x && dq_ld % 4 == 0 && dq_sb % 4 == 0 && tg_aligned16(dq);
-    if (fused_on && chain_ok && ((heads * batch) & 7) == 0 && fused_protocol_ok(stream)) {
-        FusedParams fp{pp.p, (int*)(ws + ((6 * nrow + 8 + 3) & ~3L))};
+    if ((flags & TG_BWD_ONE_KERNEL) && chain_ok && ((heads * batch) & 7) == 0) {
+        FusedParams fp{pp.p, (int*)(ws + ((6 * nrow + 8 + 3) & ~3L)), status};
         const long ncnt = (long)batch * heads * ((nq + BT - 1) / BT) * 32;
-        (void)hipMemsetAsync(fp.cnt, 0, ncnt * sizeof(int), stream);
-        static const bool attr = [] {
-            (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
-            return true;
-        }();
-        (void)attr;
+        hipError_t e = hipMemsetAsync(fp.cnt, 0, ncnt * sizeof(int), stream);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);   // (per device: cheap, no state kept here)
+        if (e != hipSuccess) return tg_set_error(TG_ERR_HIP - (int)e, "tg_attention_bwd_ex: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(gk.x * gk.y), dim3(512), FUSED_LDS, stream, fp);
         TG_LAUNCH_CHECK("tg_attention_bwd(one kernel)");
         return TG_OK;

@@ -2,6 +2,7 @@
 torch, launches go on torch's current HIP stream.  Every function requires bf16 CUDA(HIP) tensors; there is
 no CPU path."""
 import ctypes as C
+import os
 
 import torch
 
@@ -279,10 +280,55 @@ def attention_lse(q, k, vt, nk, out, heads, scale, k_prescaled=False, kmax=None,
     return out, lse
 
 
+class BwdDeviceState:
+    """What the one-kernel attention backward needs per DEVICE, owned by the caller of the C ABI (nothing process-wide lives in the library):
+    `status` = the int32[4] words tg_attention_bwd_ex reports through ([0] sticky count of exchange polls that timed out, [1] poll-limit override),
+    `one_kernel` = verdict of the device probe (tg_attention_bwd_probe on a buffer of ours; one synchronisation, here, outside the ABI)."""
+
+    _by_device = {}
+
+    def __init__(self, device):
+        lib = L.load()
+        self.status = torch.zeros(4, dtype=torch.int32, device=device)
+        self.one_kernel = False
+        if os.environ.get("TG_ATTN_BWD_FUSED", "1") != "0":
+            nb = lib.tg_attention_bwd_probe_bytes()
+            buf = torch.empty(nb, dtype=torch.uint8, device=device)
+            L.check(lib.tg_attention_bwd_probe(_p(buf), nb, _stream()), "tg_attention_bwd_probe")
+            host = buf.cpu()                                   # (synchronises this stream, once per device and process)
+            self.one_kernel = bool(lib.tg_attention_bwd_probe_verdict(host.data_ptr(), nb))
+
+    @classmethod
+    def get(cls, device):
+        device = torch.device(device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        st = cls._by_device.get(idx)
+        if st is None:
+            with torch.cuda.device(idx):
+                st = cls._by_device[idx] = cls(torch.device("cuda", idx))
+        return st
+
+
+def attention_bwd_check(device=None):
+    """Read the sticky status word of the one-kernel backward on `device` (synchronises) and raise if any ordered-exchange poll timed out since the
+    last check: the dq of that launch is invalid, the step must not be applied.  Called by the training step once per micro-step."""
+    devs = [torch.device(device).index] if device is not None else list(BwdDeviceState._by_device)
+    for idx in devs:
+        st = BwdDeviceState._by_device.get(idx if idx is not None else torch.cuda.current_device())
+        if st is None:
+            continue
+        n = int(st.status[0].item())
+        if n:
+            st.status[0].zero_()
+            raise RuntimeError(f"tg_attention_bwd_ex: {n} ordered dQ exchange poll(s) timed out on cuda:{idx} — the gradients of this step are "
+                               "invalid (a key block never saw its predecessor's signal); discard the step. TG_ATTN_BWD_FUSED=0 selects the two-launch form.")
+
+
 def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, accumulate=False, lse=None):
-    """Gradients of o = softmax(scale q k^T) v per head (tg_attention_bwd).  q/o/dout [B,nq,heads*64], k/v [B,nk,heads*64] bf16 views;
+    """Gradients of o = softmax(scale q k^T) v per head (tg_attention_bwd_ex).  q/o/dout [B,nq,heads*64], k/v [B,nk,heads*64] bf16 views;
     returns fp32 (dq, dk, dv) shaped like q, k, v (given tensors are written, or added to with accumulate=True).  lse: the forward's
-    log-sum-exp from attention_lse (optional; recomputed when None)."""
+    log-sum-exp from attention_lse (optional; recomputed when None).  The one-kernel form is offered to the library when the device probe
+    passed (BwdDeviceState); a poll time-out inside it is reported by attention_bwd_check(), never silently."""
     for n, t in (("q", q), ("k", k), ("v", v), ("o", o), ("dout", dout)):
         _chk(t, n)
     if lse is not None:
@@ -301,9 +347,10 @@ def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, acc
     dk = new(B, nk, HD, dtype=f32, device=q.device) if dk is None else _chk(dk, "dk", f32)
     dv = new(B, nk, HD, dtype=f32, device=q.device) if dv is None else _chk(dv, "dv", f32)
     ws = torch.empty(L.load().tg_attention_bwd_ws_floats(nq, nk, heads, B), dtype=f32, device=q.device)
-    L.check(_launch("attention_bwd", L.load().tg_attention_bwd, _p(q), qld, qsb, _p(k), kld, ksb, _p(v), vld, vsb, _p(o), old, osb, _p(dout), gld, gsb,
+    st = BwdDeviceState.get(q.device)
+    L.check(_launch("attention_bwd", L.load().tg_attention_bwd_ex, _p(q), qld, qsb, _p(k), kld, ksb, _p(v), vld, vsb, _p(o), old, osb, _p(dout), gld, gsb,
                     _p(dq), dq.stride(1), dq.stride(0), _p(dk), dk.stride(1), dk.stride(0), _p(dv), dv.stride(1), dv.stride(0), nq, nk, heads, B,
-                    float(scale), acc, _p(lse), _p(ws), _stream()), "tg_attention_bwd")
+                    float(scale), acc, _p(lse), _p(ws), L.TG_BWD_ONE_KERNEL if st.one_kernel else 0, _p(st.status), _stream()), "tg_attention_bwd_ex")
     return dq, dk, dv
 
 

@@ -33,6 +33,10 @@ PROTOTYPES = {
     "tg_attention_fwd_multi": [_vp, _i, _i, _i, _f, _i, _vp, _vp],
     "tg_attention_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l,
                          _i, _i, _i, _i, _f, _i, _vp, _vp, _vp],
+    "tg_attention_bwd_ex": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l,
+                            _i, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp],
+    "tg_attention_bwd_probe": [_vp, _l, _vp],
+    "tg_attention_bwd_probe_verdict": [_vp, _l],
     "tg_attention_fwd_lse": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp, _l, _l, _i, _i, _i, _f, _vp, _vp],
     "tg_attention_fwd_lse_ex": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp, _l, _l, _i, _i, _i, _f, _i, _vp, _vp, _l, _vp, _vp],
     "tg_qk_layernorm_rope_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _vp, _f, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _vp, _vp],
@@ -72,6 +76,7 @@ QUERIES = {
     "tg_conv3d_gn_partial_floats": [C.c_int, C.c_int, C.c_int],
     "tg_conv3d_splitk_floats": [C.c_int] * 9,
     "tg_attention_bwd_ws_floats": [C.c_int, C.c_int, C.c_int, C.c_int],
+    "tg_attention_bwd_probe_bytes": [],
     "tg_attention_retry_ints": [C.c_int, C.c_int, C.c_int, C.c_int],
     "tg_attention_split_floats": [C.c_int, C.c_int, C.c_int, C.c_int],
     "tg_qk_kmax_ws_floats": [C.c_int, C.c_int, C.c_int],
@@ -80,6 +85,8 @@ QUERIES = {
     "tg_vpred_loss_partial_floats": [C.c_int, C.c_long],
     "tg_grad_norm_ws_floats": [],
 }
+
+TG_BWD_ONE_KERNEL = 1
 
 _lib = None
 

@@ -178,7 +178,7 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
         self._set_vip_scale(video_ipadapter_scale)
         use_vip = image_embeddings is not None
         nb = 3 if use_separate_guidance else 2
-        g_img0 = guidance_scale if guidance_scale_img is None else guidance_scale_img                # infer_cogvideo_mp_fifo.py:313
+        g_img = guidance_scale if guidance_scale_img is None else guidance_scale_img                 # infer_cogvideo_mp_fifo.py:313
         embeds = torch.cat([negative_prompt_embeds] + [prompt_embeds] * (nb - 1), dim=0).to(dev, BF16)   # :1026-1029 (uncond, cond[, cond])
         self.scheduler.set_timesteps(num_inference_steps, device=None)
         ts = self.scheduler.timesteps.tolist()
@@ -241,10 +241,12 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
                                         vip_image_rotary_emb=vr, vip_condition_rotary_emb=cr,
                                         vip_encoder_hidden_states=None if emb0 is None else emb0[lo:hi].contiguous(), return_dict=False)[0]
             pred = CP.predict(cfg_mode, lambda h: fwd(h, h + 1), lambda: fwd(0, nb), n=nb)
-            g_txt, g_img = guidance_scale, g_img0
+            g_txt = guidance_scale
             if use_dynamic_cfg:                                  # :1252-1259 — Python floats, the timestep VALUE against num_inference_steps as written there
                 ramp = (1 - math.cos(math.pi * ((num_inference_steps - t) / num_inference_steps) ** 5.0)) / 2
-                g_txt, g_img = 1 + guidance_scale * ramp, 1 + g_img0 * ramp
+                # the text weight is recomputed from the argument (it lives in self._guidance_scale, :1254); the image weight is the reference's
+                # LOCAL variable re-assigned in place (:1257): it compounds from step to step, and the compounded value is what is exported (:1336)
+                g_txt, g_img = 1 + guidance_scale * ramp, 1 + g_img * ramp
             prev_t = ts[i + 1] if i + 1 < len(ts) else -1
             t_back = ts[i - 1] if i > 0 else None
             nz = step_noise(i) if step_noise is not None else torch.randn((nf, 2) + tuple(latents.shape[2:]), generator=gen, device=dev,
@@ -267,6 +269,6 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
             use_dynamic_cfg=bool(use_dynamic_cfg),
             prompt_embeds=embeds, image_rotary_emb=rope, vip_image_rotary_grid=grids[0] if use_vip else None,
             vip_condition_rotary_grid=grids[1] if use_vip else None, attention_kwargs=None, guidance_scale=guidance_scale,
-            guidance_scale_img=g_img0, extra_step_kwargs={}, cache_idx=[], condition_frames=None,
+            guidance_scale_img=g_img, extra_step_kwargs={}, cache_idx=[], condition_frames=None,
             video_ipadapter_start_frame_idx=video_ipadapter_start_frame_idx, sampling_params=sampling_params or dict(use_adaptive_padding=True, num_partitions=4),
             output_type=output_type, return_dict=return_dict)

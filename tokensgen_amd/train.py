@@ -279,7 +279,10 @@ class To2VBlockTrainer:
     tensors for the reductions; nothing in the inference path uses this class."""
 
     def __init__(self, sd, pre, heads, n_text, n_vip, frames, vip_scale, eps=1e-5):
-        self.sd, self.pre, self.H, self.Nt, self.Np, self.F, self.s, self.eps = sd, pre, heads, n_text, n_vip, frames, float(vip_scale), eps
+        # attention_processor.py:2126-2134: `scale` becomes a tensor of the activations' dtype before it multiplies (0.6 -> bf16 0.6015625), in the
+        # forward and therefore in autograd's backward: round it once here, as the inference path does (transformer.py)
+        vip_scale = float(torch.tensor(float(vip_scale), dtype=BF16))
+        self.sd, self.pre, self.H, self.Nt, self.Np, self.F, self.s, self.eps = sd, pre, heads, n_text, n_vip, frames, vip_scale, eps
         self.keep = True          # False: forward only (the checkpointed pass of To2VTrainer keeps nothing but the block inputs)
         g = lambda n: sd[f"{pre}.{n}"]
         P = "attn1.processor."
@@ -732,6 +735,9 @@ class To2VTrainStep:
                 d_all[b, int(emb_start_idx[b]) * slot:(int(emb_start_idx[b]) + vip_frames) * slot] = d_vip[b]
             for c, ctx in enumerate(ctxs):
                 self.arena.accumulate(self.rs.backward(ctx, d_all[:, c * Nq:(c + 1) * Nq].contiguous()), scale)
+        # the one-kernel attention backward reports an ordered-exchange poll that gave up through a sticky device word: read it (one
+        # synchronisation per micro-step) BEFORE the optimizer may apply anything — RuntimeError, never silently wrong gradients
+        K.attention_bwd_check(out.device)
         if last:
             if self.sync is not None:
                 self.sync.finish()

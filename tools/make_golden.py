@@ -482,8 +482,12 @@ def gen_t2to():
 
 
 @torch.no_grad()
-def gen_base_stage():
-    """the reference's OWN `MPFIFOVideoIPAdapterCogVideoXPipeline.__call__` (pipeline_cogvideox_mp_fifo.py:837-1344, the
+def gen_base_stage(variant=False):
+    """variant=True -> base_stage_dyn_sep.pt: the same run with use_dynamic_cfg + use_separate_guidance (guidance_scale_img 4.0, 16 steps) — the
+    branch in which the reference re-assigns its LOCAL `guidance_scale_img = 1 + guidance_scale_img * ramp` on every step (:1257), so the image
+    weight compounds from step to step and the compounded value is what the stage exports to the FIFO driver (:1336).  The Resampler stub returns
+    a fixed seeded tensor there (the "tokens of an all-zero video" of the third CFG branch), zeros in the default fixture.
+    SURVEY §8c G11: the reference's OWN `MPFIFOVideoIPAdapterCogVideoXPipeline.__call__` (pipeline_cogvideox_mp_fifo.py:837-1344, the
     52-step base stage that seeds the FIFO queue, :1186-1307) run on CPU with the tiny To2V DiT.  Only the constructor is bypassed
     (DiffusionPipeline.register_modules / T5 / VAE weights): `vae.encode` and the Resampler are touched solely by the zero-video "uncond"
     branch of vae_encode_image (:618-646), whose result the reference discards unless use_separate_guidance — they are stubs returning
@@ -491,7 +495,8 @@ def gen_base_stage():
     fifo_latents, fifo_old_pred_original_sample, orig_latents, the position grids and the RoPE table the pipeline built."""
     import contextlib
     ref = load_ref_module("longvgen/pipeline/pipeline_cogvideox_mp_fifo.py", "ref_pipe_mp_fifo")
-    H, W, nf, T, chunks = 4, 6, 13, 52, 2
+    H, W, nf, T, chunks = 4, 6, 13, (16 if variant else 52), 2
+    unc_tok = torch.randn(1, 4, 128, 2, 3, generator=torch.Generator().manual_seed(903)) if variant else torch.zeros(1, 4, 128, 2, 3)
     rq = types.SimpleNamespace(num_temporal_queries=4, num_height_queries=2, num_width_queries=3, max_temporal_seq_len=13, max_height_seq_len=2,
                                max_width_seq_len=3)
 
@@ -499,7 +504,7 @@ def gen_base_stage():
         config = rq
 
         def __call__(self, x, image_rotary_emb=None, sampling_rotary_emb=None):
-            return torch.zeros(x.shape[0], 4, 128, 2, 3, dtype=x.dtype)
+            return unc_tok.to(x.dtype).expand(x.shape[0], -1, -1, -1, -1).clone()
 
     class _Vae:
         config = types.SimpleNamespace(scaling_factor=1.15258426)
@@ -549,7 +554,8 @@ def gen_base_stage():
         try:
             out = Pipe(m, sched, dt)(prompt_embeds=prompt, negative_prompt_embeds=negative, image_embeddings=emb, height=8 * H, width=8 * W,
                                      num_frames_per_chunk=49, max_num_chunks=chunks, max_num_chunks_wo_fifo=1, num_inference_steps=T,
-                                     guidance_scale=6.0, use_dynamic_cfg=False, generator=torch.Generator().manual_seed(902), vip_scale=[0.6],
+                                     guidance_scale=6.0, use_dynamic_cfg=bool(variant), generator=torch.Generator().manual_seed(902), vip_scale=[0.6],
+                                     **(dict(use_separate_guidance=True, guidance_scale_img=4.0) if variant else {}),
                                      sampling_mode="fifo", sampling_params=dict(use_adaptive_padding=True, num_partitions=4), output_type="latent",
                                      video_ipadapter_start_frame_idx=1000)
         finally:
@@ -558,15 +564,19 @@ def gen_base_stage():
         cases[str(dt)] = dict(prompt=prompt, negative=negative, emb_in=emb, init_latents=draws[0], step_draws=draws[1:],
                               fifo_latents=out.fifo_latents.clone(), fifo_old=[None if o is None else o.clone() for o in out.fifo_old_pred_original_sample],
                               orig_latents=out.orig_latents.clone(), image_embeddings=out.image_embeddings.clone(), prompt_embeds=out.prompt_embeds.clone())
+        if variant:
+            cases[str(dt)].update(guidance_scale_out=float(out.guidance_scale), guidance_scale_img_out=float(out.guidance_scale_img))
         if dt == torch.float32:
             common = dict(timesteps=out.timesteps.clone(), image_rotary_emb=tuple(t.clone() for t in out.image_rotary_emb),
                           vip_image_rotary_grid=[np.asarray(a).copy() for a in out.vip_image_rotary_grid],
                           vip_condition_rotary_grid=[np.asarray(a).copy() for a in out.vip_condition_rotary_grid],
                           vip_nf_per_chunk=out.vip_nf_per_chunk, sd_checksum=sd_checksum(sd))
+    name = "base_stage_dyn_sep.pt" if variant else "base_stage_tiny.pt"
     torch.save(dict(weight_seed=900, input_seed=901, gen_seed=902, H=H, W=W, chunks=chunks, steps=T, guidance_scale=6.0, vip_scale=[0.6],
-                    **common, cases=cases), os.path.join(GOLD, "base_stage_tiny.pt"))
+                    **(dict(guidance_scale_img=4.0, use_dynamic_cfg=True, use_separate_guidance=True, unc_tok=unc_tok) if variant else {}),
+                    **common, cases=cases), os.path.join(GOLD, name))
     c = cases[str(torch.float32)]
-    print("base_stage_tiny.pt", tuple(c["fifo_latents"].shape), len(c["step_draws"]), "step draws", tuple(c["image_embeddings"].shape))
+    print(name, tuple(c["fifo_latents"].shape), len(c["step_draws"]), "step draws", tuple(c["image_embeddings"].shape))
 
 
 @torch.no_grad()
@@ -747,7 +757,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    jobs = dict(dit=gen_dit_tiny, vip=gen_vip_processor, sched=gen_scheduler, fifo=gen_fifo, vae=gen_vae, resampler=gen_resampler, t2to=gen_t2to, base=gen_base_stage, vae_geom=gen_vae_geometry, vae_t26=gen_vae_t26, train=gen_train, fifo_worker=gen_fifo_worker)
+    jobs = dict(dit=gen_dit_tiny, vip=gen_vip_processor, sched=gen_scheduler, fifo=gen_fifo, vae=gen_vae, resampler=gen_resampler, t2to=gen_t2to, base=gen_base_stage, base_dyn_sep=lambda: gen_base_stage(variant=True), vae_geom=gen_vae_geometry, vae_t26=gen_vae_t26, train=gen_train, fifo_worker=gen_fifo_worker)
     if a.only:
         jobs = {a.only: jobs.get(a.only, gen_full_block)}
     for k, fn in jobs.items():
