@@ -33,6 +33,7 @@ PEAK_BF16 = 2.5e15                # MI355X dense bf16 MFMA peak (MI355X_MICROARC
 N1, NP, D_MODEL = 17776, 480, 3072
 # + the vip-query attention (SDPA#3), whose workgroups ride in the same launch (tg_attention_fwd_multi)
 PMC_SUMMARY = "r3_pmc_summary.json"     # committed rocprofv3 PMC passes the `traffic` figure is read from
+BWD_PMC_SUMMARY = "r3_attention_bwd_pmc.json"   # likewise for the training sub-record's dominant kernel (tools/profile_attn_bwd.sh)
 ATTN_FLOP_PER_LAUNCH = 2 * (4.0 * N1 * N1 * D_MODEL + 4.0 * N1 * NP * D_MODEL + 4.0 * NP * (N1 + NP) * D_MODEL)
 
 
@@ -281,7 +282,14 @@ def build_resampler_sd(device):
 
 
 def run_train(a, rank, world, device, dist):
-    """--mode train (BASELINE config 5): To2V training micro-steps at the yaml's shapes — per_gpu_batch_size 2, 13 latent frames of 60 x 90, 226 text
+    """--mode train: prints train_measure()'s record as the one JSON line (rank 0)."""
+    rec = train_measure(a, rank, world, device, dist)
+    if rank == 0:
+        print(json.dumps(rec))
+
+
+def train_measure(a, rank, world, device, dist):
+    """BASELINE config 5 (`--mode train`, and the `train` sub-record of the default run): To2V training micro-steps at the yaml's shapes — per_gpu_batch_size 2, 13 latent frames of 60 x 90, 226 text
     tokens, the Resampler (trainable) over two 13-frame chunks -> 480 vip tokens, transformer forward with per-block checkpointing, v-prediction
     loss, backward with recompute, gradient accumulation over `--accum` micro-steps, then bucketed RCCL all-reduce (N > 1), clip, AdamW.
     A "step" is one micro-step (one micro-batch per rank); the timed region holds exactly `--steps` of them, optimizer steps included when
@@ -355,12 +363,12 @@ def run_train(a, rank, world, device, dist):
         tot_ms = prof["total_ms"] / max(1, a.steps)
         traffic = None          # L2-miss bytes of one 17776^2 backward call (dK/dV + dQ launches), from the committed rocprofv3 PMC passes (tools/profile_attn_bwd.sh)
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_attention_bwd_pmc.json")) as f:
+            with open(os.path.join(ROOT, "profiles", BWD_PMC_SUMMARY)) as f:
                 pm = json.load(f)
             traffic = sum(v["l2_miss_traffic_bytes_per_launch"] for k, v in pm.items() if k.startswith(("attn_bwd_dkdv", "attn_bwd_dq", "attn_bwd_fused")))
         except (OSError, KeyError, ValueError):
             pass
-        print(json.dumps({
+        return ({
             "metric": "To2V training samples/sec (micro-steps of per_gpu_batch_size 2, gradient accumulation, clip + AdamW), CogVideoX-5B + Resampler",
             "value": B * world * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "rank_ms_per_step": rank_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
@@ -377,7 +385,10 @@ def run_train(a, rank, world, device, dist):
             **({"kernel_ms_per_micro_step": {k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(K.profile_summary().items(), key=lambda kv: -kv[1]["total_ms"])},
                 "launches_per_micro_step": {k: v["n"] / a.steps for k, v in K.profile_summary().items()}} if K.PROFILE_FILTER[0] is None else {}),
             "loss": float(loss), "grad_norm_last_step": float(opt.coef[0]) if n_opt else None,
-            "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))
+            "attention_bwd_form": "one kernel (dK, dV, dQ; ordered dQ exchange, status word checked every micro-step)" if K.BwdDeviceState.get(device).one_kernel
+                                  else "two launches (dK/dV + dQ)",
+            "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30})
+    return None
 
 
 def main():
@@ -393,6 +404,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=12, help="--mode e2e: number of 49-frame clips (edit.yaml: 12)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE (BASELINE config 4) sub-record")
+    ap.add_argument("--no-train", action="store_true", help="skip the training (BASELINE config 5) sub-record")
     a = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -529,7 +541,11 @@ def main():
             pass
         out = {
             "metric": "DiT denoising steps/sec (CFG-batched 13-frame window: DiT fwd + CFG + 13 DPM updates), CogVideoX-5B To2V 720x480",
-            "value": world * a.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            # `value` is the WHOLE-JOB aggregate over the N ranks (the bench contract); BASELINE's metric is quoted per GPU: that is value_per_gpu.
+            # At N = 1 the two coincide.  Each rank runs a steady-state window (weak scaling); the end-to-end rate incl. the ramp is `--mode e2e`.
+            "value": world * a.steps / dt, "value_aggregate": world * a.steps / dt, "value_per_gpu": a.steps / dt, "value_is": "aggregate over n_gpus",
+            "leg": "steady_state (one full window per rank per step; end to end incl. ramp / base stage / decode: --mode e2e, strong scaling)",
+            "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic latents/embeddings, random-init weights at CogVideoX-5B shapes",
             "config": {"workload": "To2V FIFO window step, CogVideoX-5B (42 layers, D=3072, 48x64 heads), 13x60x90 latent "
@@ -548,6 +564,13 @@ def main():
         }
         if not a.no_vae and world == 1:
             out["vae"] = vae_record(device)
+        if not a.no_train and world == 1 and a.layers == 42:
+            # BASELINE config 5 on the driver's record (outside the timed region, like `vae`): the inference model is released first
+            worker = model = retry_ws = None          # (the step closure sees the same cells: nothing keeps the 14 GB of weights + workspaces)
+            import gc
+            gc.collect(); torch.cuda.empty_cache()
+            ta = argparse.Namespace(layers=a.layers, steps=3, warmup=1, accum=9)
+            out["train"] = train_measure(ta, 0, 1, device, None)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -129,6 +129,74 @@ def test_attention_bwd_cross_check_kernels_in_a_child_process():
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
+def test_attention_bwd_poll_timeout_is_reported_not_silent():
+    """The one-kernel backward's ordered dQ exchange is bounded (a key block that never sees its predecessor's signal goes on instead of hanging the
+    GPU) — and that MUST be visible: the poll limit is forced to 1 through the caller-owned status words (include/tokensgen_hip.h, tg_attention_bwd_ex
+    status[1]), so key blocks overtake each other; the launch returns 0 (the condition exists on the device only), the sticky word status[0] counts the
+    polls that gave up, and kernels.attention_bwd_check() — what To2VTrainStep.micro_step calls before the optimizer may run — raises.  Afterwards the
+    word is clear and an ordinary call is exact again."""
+    import os
+    from tokensgen_amd import kernels as K
+    if os.environ.get("TG_ATTN_BWD_FUSED") == "0" or os.environ.get("TG_ATTN_BWD_V1") == "1":
+        pytest.skip("the one-kernel form is switched off in this run")
+    st = K.BwdDeviceState.get(DEV)
+    assert st.one_kernel, "tg_attention_bwd_probe failed on this device: the one-kernel backward would never be selected"
+    B, H, nq, nk = 1, 8, 1100, 700
+    scale = 0.125
+    fused = _rand(B, nq, 3 * H * 64, seed=11, scale=1.5).to(DEV)
+    q, k, v = fused[:, :, :H * 64], fused[:, :nk, H * 64:2 * H * 64], fused[:, :nk, 2 * H * 64:]
+    g = _rand(B, nq, H * 64, seed=12).to(DEV)
+    o = _sdpa(q.float(), k.float(), v.float(), H, scale).to(BF)
+    K.attention_bwd_check(DEV)                                       # clean before
+    good = K.attention_bwd(q, k, v, o, g, H, scale)
+    K.attention_bwd_check(DEV)
+    st.status[1] = 1                                                 # poll limit 1: every wait that is not already satisfied gives up
+    try:
+        K.attention_bwd(q, k, v, o, g, H, scale)
+    finally:
+        st.status[1] = 0
+    assert int(st.status[0].item()) > 0
+    with pytest.raises(RuntimeError, match="timed out"):
+        K.attention_bwd_check(DEV)
+    K.attention_bwd_check(DEV)                                       # reported once, then clear
+    again = K.attention_bwd(q, k, v, o, g, H, scale)
+    K.attention_bwd_check(DEV)
+    assert all(torch.equal(a, b) for a, b in zip(good, again))
+
+
+def test_attention_bwd_without_the_probe_flag_takes_two_launches():
+    """The plain entry point tg_attention_bwd (no flags, no status words) never selects the one-kernel form; its results equal tg_attention_bwd_ex's
+    dK / dV bit for bit is not promised (different kernels) — both must match autograd's."""
+    import ctypes as C
+    from tokensgen_amd import kernels as K
+    from tokensgen_amd import lib as L
+    B, H, nq, nk = 1, 8, 1100, 700
+    scale = 0.125
+    fused = _rand(B, nq, 3 * H * 64, seed=21, scale=1.5)
+    q, k, v = fused[:, :, :H * 64], fused[:, :nk, H * 64:2 * H * 64], fused[:, :nk, 2 * H * 64:]
+    g = _rand(B, nq, H * 64, seed=22)
+    qf, kf, vf = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    o = _sdpa(qf, kf, vf, H, scale)
+    (o * g.float()).sum().backward()
+    fd, gd, od = fused.to(DEV), g.to(DEV), o.detach().to(BF).to(DEV)
+    qd, kd, vd = fd[:, :, :H * 64], fd[:, :nk, H * 64:2 * H * 64], fd[:, :nk, 2 * H * 64:]
+    lib = L.load()
+    f32 = torch.float32
+    dq, dk, dv = (torch.empty(B, n, H * 64, dtype=f32, device=DEV) for n in (nq, nk, nk))
+    ws = torch.empty(lib.tg_attention_bwd_ws_floats(nq, nk, H, B), dtype=f32, device=DEV)
+    L.check(lib.tg_attention_bwd(qd.data_ptr(), qd.stride(1), qd.stride(0), kd.data_ptr(), kd.stride(1), kd.stride(0), vd.data_ptr(), vd.stride(1), vd.stride(0),
+                                 od.data_ptr(), od.stride(1), od.stride(0), gd.data_ptr(), gd.stride(1), gd.stride(0), dq.data_ptr(), dq.stride(1), dq.stride(0),
+                                 dk.data_ptr(), dk.stride(1), dk.stride(0), dv.data_ptr(), dv.stride(1), dv.stride(0), nq, nk, H, B, scale, 0, None,
+                                 ws.data_ptr(), K._stream()), "tg_attention_bwd")
+    assert _rel(dq, qf.grad) < 5.5e-3 and _rel(dk, kf.grad) < 5.5e-3 and _rel(dv, vf.grad) < 4.5e-3
+    # TG_BWD_ONE_KERNEL without status words is an argument error, not a crash
+    code = lib.tg_attention_bwd_ex(qd.data_ptr(), qd.stride(1), qd.stride(0), kd.data_ptr(), kd.stride(1), kd.stride(0), vd.data_ptr(), vd.stride(1), vd.stride(0),
+                                   od.data_ptr(), od.stride(1), od.stride(0), gd.data_ptr(), gd.stride(1), gd.stride(0), dq.data_ptr(), dq.stride(1), dq.stride(0),
+                                   dk.data_ptr(), dk.stride(1), dk.stride(0), dv.data_ptr(), dv.stride(1), dv.stride(0), nq, nk, H, B, scale, 0, None,
+                                   ws.data_ptr(), L.TG_BWD_ONE_KERNEL, None, K._stream())
+    assert code == -1 and b"status" in lib.tg_last_error_string()
+
+
 def test_attention_bwd_two_kernel_form_in_a_child_process():
     """TG_ATTN_BWD_FUSED=0: the dK/dV + dQ launches for the shapes the one-kernel form would take (same autograd comparison, same determinism check)."""
     import os

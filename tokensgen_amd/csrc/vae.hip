@@ -431,19 +431,13 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
             // wave's MFMAs, and with one wave per SIMD nobody else fills the gap: stage time = MFMA + fill / (~32 B/clk/CU) + LDS.  That one
             // relation reproduces every kernel here: this one, the GEMM-shaped 512 x 128 convolution (80 KB per 2048 MFMA cycles: 0.83 PFLOP/s)
             // and the DiT's 256 x 256 GEMM (64 KB per 2048: 1.4 PFLOP/s).  Hence: as few fill bytes per MFMA as the tile allows.
-#ifndef TG_H2_NODMA
             if (w_iss) { dma_w((k + 3) % H2_RING, st + 3, 0); dma_w((k + 3) % H2_RING, st + 3, 1); }
             if (h_iss) {
 #pragma unroll
                 for (int i = 0; i < 12; ++i)
                     if (i >= hfirst && i < hfirst + hcnt) dma_halo((g + 1) & 1, g + 1, i);
             }
-#endif
-#ifdef TG_H2_NOLDS         // timing-only ablation (wrong results): no fragment reads inside the stage loop
-            const bool more = false;
-#else
             const bool more = st + 1 < nst;
-#endif
             // 8 blocks of 8 MFMAs (one W fragment x the 8 voxel fragments).  After the first half of block ni: W fragment ni + 2 (of this stage,
             // or 0 / 1 of the next one); after the second half: voxel fragment ni of the NEXT stage.  Reads return in order, so before block ni
             // the W fragment it needs (issued two blocks earlier) is complete once at most 3 younger reads are outstanding.
@@ -463,11 +457,7 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
                 for (int mi = 0; mi < 4; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwr[q % (WD + 1)], fa[cur][mi], acc[ni][mi], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-#ifndef TG_H2_NOLDS
                 if constexpr (ni + WD < 8) read_w(std::integral_constant<int, (q + WD) % (WD + 1)>{}, H2_WIMM(k), ni + WD);
-#else
-                if constexpr (false) {}
-#endif
                 else if (more) read_w(std::integral_constant<int, (q + WD) % (WD + 1)>{}, H2_WIMM(k + 1), ni + WD - 8);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -484,14 +474,10 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
                              "+v"(w3), "+v"(w4), "+v"(w5));
             }
             // allowed in flight: this stage's own pieces (2 weight pieces, hcnt halo pieces) — all wave-uniform, compile-time counts
-#ifdef TG_H2_NODMA
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
             if (w_iss && h_iss) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + hcnt) : "memory");
             else if (w_iss) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else if (h_iss) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(hcnt) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         });

@@ -151,11 +151,12 @@ def decode_chunks_sharded(pipe, latents, nf, decode_chunk_fn=None):
     import torch.distributed as dist
     fn = decode_chunk_fn or (lambda z: pipe.decode_latents(z, nf_per_chunk=nf))
     chunks = latents.shape[1] // nf
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-    me = dist.get_rank() if world > 1 else 0
+    dist_on = dist.is_available() and dist.is_initialized()       # a 1-rank group runs the same collectives (tests/test_rccl_gpu.py)
+    world = dist.get_world_size() if dist_on else 1
+    me = dist.get_rank() if dist_on else 0
     mine = [c for c in range(chunks) if c % world == me]
     dec = [fn(latents[:, c * nf:(c + 1) * nf].contiguous()) for c in mine]
-    if world == 1:
+    if not dist_on:
         return torch.cat(dec, dim=2)
     meta = [None] * world
     dist.all_gather_object(meta, (tuple(dec[0].shape), dec[0].dtype) if dec else None)      # a rank may hold no chunk
@@ -194,8 +195,9 @@ def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None
     dev = pipe.device
     nf, vnf, T = bo.nf_per_chunk, bo.vip_nf_per_chunk, bo.num_inference_steps
     r, l = nf // 2, nf - nf // 2
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-    me = dist.get_rank() if world > 1 else 0
+    dist_on = dist.is_available() and dist.is_initialized()       # with a process group — of ANY size — the exchange below runs (1 rank: RCCL to itself)
+    world = dist.get_world_size() if dist_on else 1
+    me = dist.get_rank() if dist_on else 0
     use_vip = bo.image_embeddings is not None
 
     lat = bo.fifo_latents.to(dev, BF16)
@@ -260,7 +262,7 @@ def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None
                         trace.append((i, w["rank"], s, w["mid"], e, w["real_end"], vs))
                 x_out, x0_out = window_fn(**kw)
                 buf[slot, 0], buf[slot, 1] = x_out[0], x0_out
-        if world > 1:                                   # the path's one exchange: kept windows of every rank (+ the failure flags)
+        if dist_on:                                     # the path's one exchange: kept windows of every rank (+ the failure flags)
             xbuf[n_el:n_el + 1] = guard.flag(dev)
             flat = torch.empty(world * (n_el + 8), dtype=BF16, device=dev)     # rank-major concat
             dist.all_gather_into_tensor(flat, xbuf)

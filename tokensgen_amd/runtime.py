@@ -70,8 +70,8 @@ def broadcast_weights(model, src=0, group=None, bucket_bytes=1 << 30):
     agree on every rank (construct the model from the same config; `from_pretrained(..., broadcast=True)` does).  Afterwards the receiver's
     derived state is refreshed (`_after_weight_update` when the model has one).  Returns the number of bytes received / sent."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return 0
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0                                       # (a 1-rank group still runs the broadcasts: the same calls, RCCL to itself)
     tensors = _weight_storages(model)
     total = 0
 
