@@ -387,6 +387,7 @@ def train_measure(a, rank, world, device, dist):
             "loss": float(loss), "grad_norm_last_step": float(opt.coef[0]) if n_opt else None,
             "attention_bwd_form": "one kernel (dK, dV, dQ; ordered dQ exchange, status word checked every micro-step)" if K.BwdDeviceState.get(device).one_kernel
                                   else "two launches (dK/dV + dQ)",
+            "attention_bwd_probe": K.BwdDeviceState.get(device).probe,
             "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30})
     return None
 

@@ -445,6 +445,20 @@ int tg_spatialnorm_silu(const void* f, int T, int H, int W, int C, const float* 
                         const void* yz, const void* bz, long ldz, int Tz, int Hz, int Wz, void* y, int apply_silu,
                         hipStream_t stream);
 
+/* The same two norm passes WITHOUT a statistics launch in front of them: instead of (mean, rstd) pairs they take the per-tile sums a convolution's
+ * epilogue left (tg_conv3d_cl's gn_partial: rows of [2][32] fp32 — sum and sum of squares per GroupNorm group; sums_f64 = 0) and turn them into
+ * (mean, rstd) in their own prologue: every workgroup adds the rows in the same fixed order in fp64 (deterministic, identical in every workgroup), so
+ * the ~2 000 tg_groupnorm_finalize launches of a clip disappear.  At most 64 rows are read that way; a longer list (nrows = ceil(V / 128) > 64) is first
+ * cut to tg_groupnorm_reduce_rows(nrows) <= 64 rows of fp64 by ONE coalesced pass, tg_groupnorm_reduce (out: that many rows of [2][32] doubles;
+ * sums_f64 = 1).  Exactly one of `stats` / `sums` is given; eps is used with `sums` only.  GroupNorm(32, eps) of autoencoder_kl_cogvideox.py:171-188, 286-303. */
+long tg_groupnorm_reduce_rows(long nrows);
+int tg_groupnorm_reduce(const float* partial, long nrows, double* out, hipStream_t stream);
+int tg_groupnorm_silu_ex(const void* x, long V, int C, const float* stats, const void* sums, long nsum, int sums_f64, float eps,
+                         const void* gamma, const void* beta, void* y, int apply_silu, hipStream_t stream);
+int tg_spatialnorm_silu_ex(const void* f, int T, int H, int W, int C, const float* stats, const void* sums, long nsum, int sums_f64, float eps,
+                           const void* gamma, const void* beta, const void* yz, const void* bz, long ldz, int Tz, int Hz, int Wz, void* y,
+                           int apply_silu, hipStream_t stream);
+
 /* Temporal average pooling of CogVideoXDownsample3D(compress_time): pairs of frames are averaged; when T is odd the first
  * frame is kept.  x [T][HW][C] -> y [To][HW][C]. */
 int tg_avgpool_time(const void* x, int T, long HW, int C, void* y, hipStream_t stream);

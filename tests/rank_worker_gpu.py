@@ -63,7 +63,7 @@ def fake_decode(z):
 def fifo_run(pipe, output_type):
     from tokensgen_amd import fifo
     g = torch.Generator().manual_seed(5)
-    H, W, nf, T, chunks = 4, 6, 13, 16, 2
+    H, W, nf, T, chunks = 4, 6, 13, 52, 2          # (the FIFO window plan needs T = nf * num_partitions: 52 = 13 x 4)
     lat0 = torch.randn(1, nf, 16, H, W, generator=g).to(BF)
     pe, ne = torch.randn(1, 8, 64, generator=g).to(BF), torch.randn(1, 8, 64, generator=g).to(BF)
     emb = torch.randn(1, 4 * chunks, 128, 2, 3, generator=g).to(BF)

@@ -229,13 +229,43 @@ def test_conv_epilogue_groupnorm_sums(ci, co, T, H, W):
     for r in (None, res):
         y0 = K.conv3d_cl(xc, wp, bd, co, 3, 3, 3, residual=r)
         y1 = K.conv3d_cl(xc, wp, bd, co, 3, 3, 3, residual=r, gn_stats_eps=1e-6)
-        assert torch.equal(y0, y1) and not hasattr(y0, "gn_stats")
+        assert torch.equal(y0, y1) and not hasattr(y0, "gn_sums")
         want = K.groupnorm_stats(y1.view(-1, co), 1e-6)
-        got = y1.gn_stats
+        got = y1.gn_sums.stats()
         assert got.shape == (32, 2)
         torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6)
         y2 = K.conv3d_cl(xc, wp, bd, co, 3, 3, 3, residual=r, gn_stats_eps=1e-6)
-        assert torch.equal(y2.gn_stats, got)                      # fixed summation order: bitwise repeatable
+        assert torch.equal(y2.gn_sums.stats(), got)                      # fixed summation order: bitwise repeatable
+
+
+@pytest.mark.parametrize("co,T,H,W", [(128, 2, 30, 45), (256, 4, 60, 90), (128, 3, 96, 128)])
+def test_norm_passes_finalise_the_conv_sums_themselves(co, T, H, W):
+    """tg_groupnorm_silu_ex / tg_spatialnorm_silu_ex with the convolution's per-tile sums instead of ready-made (mean, rstd): <= 64 rows are read by the
+    norm pass itself (22 rows here), longer lists go through ONE tg_groupnorm_reduce launch (169 and 288 rows -> 3 and 5 fp64 rows).  Against the same
+    pass fed by tg_groupnorm_finalize's statistics: the two fp64 summation orders may differ in the last bit of a float mean, i.e. by at most one bf16
+    ulp on isolated outputs; run to run the result is bitwise repeatable (fixed order, no atomics)."""
+    from tokensgen_amd import kernels as K
+    from tokensgen_amd import lib as L
+    ci = 64
+    w, b, x = _r(co, ci, 3, 3, 3, seed=1, scale=0.05), _r(co, seed=2), _r(1, ci, T, H, W, seed=3)
+    y = K.conv3d_cl(_cl(x).to(DEV), _pack(w).to(DEV), b.to(DEV), co, 3, 3, 3, gn_stats_eps=1e-6)
+    rows = (T * H * W + 127) // 128
+    t, n, f64 = y.gn_sums.rows()
+    assert (n, f64) == ((rows, 0) if rows <= 64 else (L.load().tg_groupnorm_reduce_rows(rows), 1)) and 0 < n <= 64
+    gamma, beta = (1 + 0.1 * _r(co, seed=4).float()).to(BF).to(DEV), _r(co, seed=5, scale=0.1).to(DEV)
+    stats = y.gn_sums.stats()
+    a = K.groupnorm_silu(y, y.gn_sums, gamma, beta)
+    b_ = K.groupnorm_silu(y, stats, gamma, beta)
+    assert torch.equal(a, K.groupnorm_silu(y, y.gn_sums, gamma, beta))
+    d = (a.float() - b_.float()).abs()
+    assert (d <= 2.0 ** -7 * b_.float().abs().clamp_min(2.0 ** -6)).all() and (d > 0).float().mean().item() < 0.02
+    Tz, Hz, Wz = max(1, (T + 1) // 2), max(1, H // 2), max(1, W // 2)
+    yz, bz = (1 + 0.1 * _r(Tz * Hz * Wz, co, seed=6).float()).to(BF).to(DEV), _r(Tz * Hz * Wz, co, seed=7, scale=0.1).to(DEV)
+    a = K.spatialnorm_silu(y, y.gn_sums, gamma, beta, yz, bz, (Tz, Hz, Wz))
+    b_ = K.spatialnorm_silu(y, stats, gamma, beta, yz, bz, (Tz, Hz, Wz))
+    assert torch.equal(a, K.spatialnorm_silu(y, y.gn_sums, gamma, beta, yz, bz, (Tz, Hz, Wz)))
+    d = (a.float() - b_.float()).abs()
+    assert (d <= 2.0 ** -6 * b_.float().abs().clamp_min(2.0 ** -5)).all() and (d > 0).float().mean().item() < 0.02
 
 
 def test_conv_4wave_kernel_bitwise_equals_128_kernel(tmp_path):
@@ -324,12 +354,12 @@ def test_splitk_conv_small_m(ci, co, T, H, W):
     res = _r(T, H, W, co, seed=9).to(DEV)
     y = K.conv3d_cl(xc, wp, bd, co, 3, 3, 3, gn_stats_eps=1e-6)
     assert _rel(_ncdhw(y), ref) < 5e-3
-    torch.testing.assert_close(y.gn_stats, K.groupnorm_stats(y.view(-1, co), 1e-6), rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(y.gn_sums.stats(), K.groupnorm_stats(y.view(-1, co), 1e-6), rtol=2e-5, atol=2e-6)
     yr = K.conv3d_cl(xc, wp, bd, co, 3, 3, 3, residual=res, gn_stats_eps=1e-6)
     assert _rel(yr, y.float() + res.float()) < 5e-3
-    torch.testing.assert_close(yr.gn_stats, K.groupnorm_stats(yr.view(-1, co), 1e-6), rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(yr.gn_sums.stats(), K.groupnorm_stats(yr.view(-1, co), 1e-6), rtol=2e-5, atol=2e-6)
     y2 = K.conv3d_cl(xc, wp, bd, co, 3, 3, 3, gn_stats_eps=1e-6)
-    assert torch.equal(y, y2) and torch.equal(y.gn_stats, y2.gn_stats)
+    assert torch.equal(y, y2) and torch.equal(y.gn_sums.stats(), y2.gn_sums.stats())
 
 
 def test_halo_tiled_conv_kernel(tmp_path):

@@ -304,15 +304,28 @@ constexpr int H2_RING = 4;                            // weight stages in flight
 constexpr int H2_LDS = 2 * H2_HALO_BYTES + H2_RING * H2_W_BYTES;                               // 147456
 
 
-__global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
+// NW waves per workgroup: 4 (one per SIMD, 128 voxels x 128 channels each) or 8 (two per SIMD, 64 voxels x 128 channels each: what one wave cannot
+// overlap with its own MFMAs — the blocked issue of its LDS-DMA pieces, its fragment-read waits — is covered by the other wave of the SIMD; twice the
+// weight-fragment reads, 37 % of the LDS pipe at the full matrix rate).  Output channels beyond 128 are further 128-channel SLABS of the same patch:
+// virtual workgroup v = patch * nslab + slab, consecutive on one XCD, so the slabs of a patch find its halo in that XCD's L2.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void conv3d_halo2_kernel(ConvParams p) {
+    constexpr int HP = 48 / NW;                           // halo pieces per wave and (temporal tap, 32-channel chunk) group
+    constexpr int WP = 8 / NW;                            // weight pieces per wave and stage
+    constexpr int RW = H2_PH / NW;                        // patch rows per wave
+    constexpr int MI = 2 * RW;                            // 16-voxel A fragments per wave
+    constexpr int ASTEP = 8 / MI;                         // an A fragment of the next stage is read every ASTEP-th block
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sH = smem;
     char* const sW = smem + 2 * H2_HALO_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = (p.Wo + H2_PW - 1) / H2_PW, tiles_y = (p.Ho + H2_PH - 1) / H2_PH;
-    const int ntiles = p.To * tiles_y * tiles_x;
-    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int npatch = p.To * tiles_y * tiles_x;
+    const int nslab = p.cout / 128;
+    const int vwg = xcd_remap(blockIdx.x, npatch * nslab);
+    const int tile = vwg / nslab, slab = vwg - tile * nslab;
+    const int ntiles = npatch;
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tf = tile / (tiles_x * tiles_y);
     const int x0 = tx * H2_PW, y0 = ty * H2_PH;
     const int Kw = p.kt * 9 * p.Cin;
@@ -321,65 +334,67 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
     const int ngroups = p.kt * nc32, nst = ngroups * 9;
 
     // ---- DMA maps: lane -> (row, slot) of a 1 KiB piece under the 80-byte row stride; slot 4 is the pad ----
-    int hoff[12], woffs[2];
+    int hoff[HP], woffs[WP];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const int o = (wave * 12 + i) * 1024 + lane * 16;
+    for (int i = 0; i < HP; ++i) {
+        const int o = (wave * HP + i) * 1024 + lane * 16;
         const int hr = o / H2_STRIDE, slot = (o - hr * H2_STRIDE) >> 4;
         const int hy = hr / H2_LW, hx = hr - hy * H2_LW;
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
         hoff[i] = (slot < 4 && hr < H2_ROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? (y * p.W + x) * p.Cin + slot * 8 : -1;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {                          // weight pieces 2 * wave + i: 16 rows x 64 B; the lane's physical slot holds logical slot ^ swizzle
-        const int row = (2 * wave + i) * 16 + (lane >> 2);
-        woffs[i] = row * Kw + (((lane & 3) ^ ((row >> 2) & 3)) * 8);
+    for (int i = 0; i < WP; ++i) {                         // weight pieces WP * wave + i: 16 rows x 64 B; the lane's physical slot holds logical slot ^ swizzle
+        const int row = (WP * wave + i) * 16 + (lane >> 2);
+        woffs[i] = (slab * 128 + row) * Kw + (((lane & 3) ^ ((row >> 2) & 3)) * 8);
     }
     auto frame_base = [&](int dt) -> const bf16_t* {
         const int tv = tf + dt - (p.kt - 1);
         if (tv >= 0) return p.x + (long)tv * frame;
         return p.cache ? p.cache + (long)(tv + p.kt - 1) * frame : p.x;
     };
-    auto dma_halo = [&](int buf, int g, int i) {          // piece i (0..11) of this wave for group g = dt * nc32 + c32
+    auto dma_halo = [&](int buf, int g, int i) {          // piece i (0..HP-1) of this wave for group g = dt * nc32 + c32
         const int dt = g / nc32, c32 = g - dt * nc32;
         const bf16_t* src = hoff[i] >= 0 ? frame_base(dt) + hoff[i] + c32 * 32 : p.zeros + (lane & 7) * 8;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(sH + buf * H2_HALO_BYTES + (wave * 12 + i) * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(sH + buf * H2_HALO_BYTES + (wave * HP + i) * 1024), 16, 0, 0);
     };
-    auto dma_w = [&](int slot3, int st_, int i) {         // weight piece i (0, 1) of this wave for stage st_ = g * 9 + tap into ring slot slot3
+    auto dma_w = [&](int slot3, int st_, int i) {         // weight piece i (< WP) of this wave for stage st_ = g * 9 + tap into ring slot slot3
         const int g = st_ / 9, tap = st_ - g * 9;
         const int dt = g / nc32, c32 = g - dt * nc32;
         const long koff = (long)(dt * 9 + tap) * p.Cin + c32 * 32;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.w + woffs[i] + koff),
-                                         (__attribute__((address_space(3))) void*)(sW + slot3 * H2_W_BYTES + (2 * wave + i) * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(sW + slot3 * H2_W_BYTES + (WP * wave + i) * 1024), 16, 0, 0);
     };
     const uint32_t ldsH = (uint32_t)(uintptr_t)sH, ldsW = (uint32_t)(uintptr_t)sW;
-    uint32_t aoff[8], woff[8];
+    uint32_t aoff[MI], woff[8];
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-        aoff[mi] = (uint32_t)(((4 * wave + (mi >> 1)) * H2_LW + (mi & 1) * 16 + (lane & 15)) * H2_STRIDE + (lane >> 4) * 16);
+    for (int mi = 0; mi < MI; ++mi)
+        aoff[mi] = (uint32_t)(((RW * wave + (mi >> 1)) * H2_LW + (mi & 1) * 16 + (lane & 15)) * H2_STRIDE + (lane >> 4) * 16);
 #pragma unroll
     for (int ni = 0; ni < 8; ++ni) {
         const int rw = ni * 16 + (lane & 15);
         woff[ni] = (uint32_t)(rw * 64 + (((lane >> 4) ^ ((rw >> 2) & 3)) << 4));
     }
 
-    f32x4 acc[8][8];
+    f32x4 acc[8][MI];
 #pragma unroll
     for (int ni = 0; ni < 8; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
     // Fragment registers: the voxel (A) fragments are needed by every MFMA block of a stage -> two sets by stage parity, the next set filled
     // during the current stage; the weight (W) fragments are needed one block (8 MFMAs) at a time -> a ring of three, W fragment q = stage * 8 + ni
     // in slot q % 3, read two blocks ahead (the full double set of both spilled: 512 VGPRs + 81 to scratch, 341 vs 182 ms)
     constexpr int WD = 5;                                  // W fragments are read WD blocks (8 MFMAs = 128 cycles each) ahead of their use; ring of WD + 1
-    bf16x8 fa[2][8], fwr[WD + 1];
+    bf16x8 fa[2][MI], fwr[WD + 1];
     // The LDS byte address of a fragment = a per-lane base (runtime, 8 + 8 registers) + a COMPILE-TIME immediate (halo buffer, tap offset /
     // weight ring slot) in the instruction's 16-bit offset field: no address arithmetic per read — and nothing for the optimizer to hoist
     // (with the addresses computed in C++ it pre-computed all 144 (stage, fragment) addresses of the unrolled loop into VGPRs and spilled)
-    uint32_t abase[8], wbase[8];
+    uint32_t abase[MI], wbase[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { abase[i] = ldsH + aoff[i]; wbase[i] = ldsW + woff[i]; }
+    for (int i = 0; i < 8; ++i) wbase[i] = ldsW + woff[i];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) abase[i] = ldsH + aoff[i];
     auto read_a = [&](auto setc, auto immc, int mi) {       // immc: (group parity) * H2_HALO_BYTES + ((tap / 3) * H2_LW + tap % 3) * H2_STRIDE
         constexpr int set = decltype(setc)::value, imm = decltype(immc)::value;
         static_assert(imm >= 0 && imm < 65536, "ds_read offset field");
@@ -398,13 +413,13 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
 
     // ---- prologue: halo of group 0, weights of stages 0 and 1; A fragments of stage 0, W fragments 0 and 1 ----
 #pragma unroll
-    for (int i = 0; i < 12; ++i) dma_halo(0, 0, i);
+    for (int i = 0; i < HP; ++i) dma_halo(0, 0, i);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { dma_w(0, 0, i); dma_w(1, 1, i); dma_w(2, 2, i); }
+    for (int i = 0; i < WP; ++i) { dma_w(0, 0, i); dma_w(1, 1, i); dma_w(2, 2, i); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) read_a(std::integral_constant<int, 0>{}, H2_AIMM(0), i);
+    for (int i = 0; i < MI; ++i) read_a(std::integral_constant<int, 0>{}, H2_AIMM(0), i);
     static_for<0, WD>([&](auto ic) { read_w(ic, H2_WIMM(0), decltype(ic)::value); });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -422,8 +437,10 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
             const int st = g0 * 9 + k;
             if (st >= nst) return;                          // workgroup-uniform
             __builtin_amdgcn_sched_barrier(0);
-            const bool w_iss = st + 3 < nst, h_iss = tap < 7 && g + 1 < ngroups;
-            constexpr int hfirst = tap < 5 ? 2 * tap : tap + 5, hcnt = tap < 5 ? 2 : (tap < 7 ? 1 : 0);     // 12 halo pieces over taps 0..6: 2,2,2,2,2,1,1
+            // the wave's halo pieces of the next group go out over the first taps: 12 pieces (4 waves) as 2,2,2,2,2,1,1; 6 pieces (8 waves) as 1,1,1,1,1,1
+            constexpr int hfirst = NW == 4 ? (tap < 5 ? 2 * tap : tap + 5) : tap;
+            constexpr int hcnt = NW == 4 ? (tap < 5 ? 2 : (tap < 7 ? 1 : 0)) : (tap < 6 ? 1 : 0);
+            const bool w_iss = st + 3 < nst, h_iss = hcnt > 0 && g + 1 < ngroups;
             // The stage's DMA pieces (2 weight pieces of stage s+3, up to 2 halo pieces of the next group) go out together at the top of the stage.
             // In-kernel timers (instrumented lab builds): a pure MFMA stage is 1021 cycles (= 64 x 16); the fragment reads add ~250; each LDS-DMA
             // piece blocks its wave's issue for ~128 cycles when all four waves issue together — and ~300 when a wave issues alone between its
@@ -431,16 +448,20 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
             // wave's MFMAs, and with one wave per SIMD nobody else fills the gap: stage time = MFMA + fill / (~32 B/clk/CU) + LDS.  That one
             // relation reproduces every kernel here: this one, the GEMM-shaped 512 x 128 convolution (80 KB per 2048 MFMA cycles: 0.83 PFLOP/s)
             // and the DiT's 256 x 256 GEMM (64 KB per 2048: 1.4 PFLOP/s).  Hence: as few fill bytes per MFMA as the tile allows.
-            if (w_iss) { dma_w((k + 3) % H2_RING, st + 3, 0); dma_w((k + 3) % H2_RING, st + 3, 1); }
+            if (w_iss) {
+#pragma unroll
+                for (int i = 0; i < WP; ++i) dma_w((k + 3) % H2_RING, st + 3, i);
+            }
             if (h_iss) {
 #pragma unroll
-                for (int i = 0; i < 12; ++i)
+                for (int i = 0; i < HP; ++i)
                     if (i >= hfirst && i < hfirst + hcnt) dma_halo((g + 1) & 1, g + 1, i);
             }
             const bool more = st + 1 < nst;
-            // 8 blocks of 8 MFMAs (one W fragment x the 8 voxel fragments).  After the first half of block ni: W fragment ni + 2 (of this stage,
-            // or 0 / 1 of the next one); after the second half: voxel fragment ni of the NEXT stage.  Reads return in order, so before block ni
-            // the W fragment it needs (issued two blocks earlier) is complete once at most 3 younger reads are outstanding.
+            // 8 blocks of MI MFMAs (one W fragment x the wave's MI voxel fragments).  After the first half of block ni: W fragment ni + WD (of this
+            // stage, or of the next one); after the second half of every ASTEP-th block: a voxel fragment of the NEXT stage.  Reads return in order, so
+            // before block ni the W fragment it needs (issued WD blocks earlier) is complete once at most `younger` reads are outstanding:
+            // the WD - 1 W reads behind it + the A reads of blocks ni - WD .. ni - 1.
             static_for<0, 8>([&](auto nc) {
                 constexpr int ni = decltype(nc)::value;
                 constexpr int q = k * 8 + ni;               // W fragment sequence number within the 36-stage iteration (288 % (WD + 1) == 0)
@@ -450,32 +471,40 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
                     // fragment ni was issued WD blocks ago; since then 2 WD - 1 younger reads went out (LDS returns in order).  With WD = 2 the
                     // fragment was 256 cycles old — less than the LDS latency under this kernel's own 60 % LDS load — and every block stalled
                     bf16x8& need = fwr[q % (WD + 1)];
-                    if constexpr (ni >= WD) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(need) : "n"(2 * WD - 1));
+                    constexpr int a_reads = (ni - 1) / ASTEP - (ni - WD + ASTEP - 1) / ASTEP + 1;     // multiples of ASTEP in [ni - WD, ni - 1] (ni >= WD)
+                    constexpr int younger = WD - 1 + a_reads;
+                    static_assert(younger <= 15, "lgkmcnt is a 4-bit counter");
+                    if constexpr (ni >= WD) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(need) : "n"(younger));
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < MI / 2; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwr[q % (WD + 1)], fa[cur][mi], acc[ni][mi], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ni + WD < 8) read_w(std::integral_constant<int, (q + WD) % (WD + 1)>{}, H2_WIMM(k), ni + WD);
                 else if (more) read_w(std::integral_constant<int, (q + WD) % (WD + 1)>{}, H2_WIMM(k + 1), ni + WD - 8);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mi = 4; mi < 8; ++mi)
+                for (int mi = MI / 2; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwr[q % (WD + 1)], fa[cur][mi], acc[ni][mi], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) read_a(std::integral_constant<int, nxt>{}, H2_AIMM(k + 1), ni);
+                if constexpr (ni % ASTEP == 0) {
+                    if (more) read_a(std::integral_constant<int, nxt>{}, H2_AIMM(k + 1), ni / ASTEP);
+                }
             });
             __builtin_amdgcn_sched_barrier(0);
             {
-                bf16x8 &a0 = fa[nxt][0], &a1 = fa[nxt][1], &a2 = fa[nxt][2], &a3 = fa[nxt][3], &a4 = fa[nxt][4], &a5 = fa[nxt][5], &a6 = fa[nxt][6],
-                       &a7 = fa[nxt][7], &w0 = fwr[0], &w1 = fwr[1], &w2 = fwr[2], &w3 = fwr[3], &w4 = fwr[4], &w5 = fwr[5];
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(w0), "+v"(w1), "+v"(w2),
-                             "+v"(w3), "+v"(w4), "+v"(w5));
+                bf16x8 &a0 = fa[nxt][0], &a1 = fa[nxt][1], &a2 = fa[nxt][2], &a3 = fa[nxt][3], &a4 = fa[nxt][MI - 4], &a5 = fa[nxt][MI - 3], &a6 = fa[nxt][MI - 2],
+                       &a7 = fa[nxt][MI - 1], &w0 = fwr[0], &w1 = fwr[1], &w2 = fwr[2], &w3 = fwr[3], &w4 = fwr[4], &w5 = fwr[5];
+                if constexpr (MI == 8)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(w0), "+v"(w1), "+v"(w2),
+                                 "+v"(w3), "+v"(w4), "+v"(w5));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5));
             }
-            // allowed in flight: this stage's own pieces (2 weight pieces, hcnt halo pieces) — all wave-uniform, compile-time counts
-            if (w_iss && h_iss) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + hcnt) : "memory");
-            else if (w_iss) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            // allowed in flight: this stage's own pieces (WP weight pieces, hcnt halo pieces) — all wave-uniform, compile-time counts
+            if (w_iss && h_iss) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP + hcnt) : "memory");
+            else if (w_iss) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP) : "memory");
             else if (h_iss) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(hcnt) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -483,21 +512,21 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
         });
     }
 
-    // ---- epilogue: bias, bf16 rounding before the residual add, bf16 store, GroupNorm sums (Cout = 128: a lane's channel quad is one group) ----
+    // ---- epilogue: bias, bf16 rounding before the residual add, bf16 store, GroupNorm sums per channel quad (a group is cout / 128 quads) ----
     float gs[8], gq[8];
 #pragma unroll
     for (int ni = 0; ni < 8; ++ni) gs[ni] = gq[ni] = 0.f;
     uint2 bq[8];
 #pragma unroll
-    for (int ni = 0; ni < 8; ++ni) bq[ni] = p.bias ? *(const uint2*)(p.bias + ni * 16 + (lane >> 4) * 4) : uint2{0u, 0u};
+    for (int ni = 0; ni < 8; ++ni) bq[ni] = p.bias ? *(const uint2*)(p.bias + slab * 128 + ni * 16 + (lane >> 4) * 4) : uint2{0u, 0u};
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-        const int y = y0 + 4 * wave + (mi >> 1), x = x0 + (mi & 1) * 16 + (lane & 15);
+    for (int mi = 0; mi < MI; ++mi) {
+        const int y = y0 + RW * wave + (mi >> 1), x = x0 + (mi & 1) * 16 + (lane & 15);
         if (y >= p.Ho || x >= p.Wo) continue;
         const long m = ((long)tf * p.Ho + y) * p.Wo + x;
 #pragma unroll
         for (int ni = 0; ni < 8; ++ni) {
-            const int n = ni * 16 + (lane >> 4) * 4;
+            const int n = slab * 128 + ni * 16 + (lane >> 4) * 4;
             float v[4] = {acc[ni][mi][0] + bf16lo_to_f32(bq[ni].x), acc[ni][mi][1] + bf16hi_to_f32(bq[ni].x),
                           acc[ni][mi][2] + bf16lo_to_f32(bq[ni].y), acc[ni][mi][3] + bf16hi_to_f32(bq[ni].y)};
             if (p.residual) {
@@ -532,15 +561,18 @@ __global__ __launch_bounds__(256) void conv3d_halo2_kernel(ConvParams p) {
             }
         }
         __syncthreads();
-        if (tid < 64) {
-            // tile i owns row i of the partial buffer and zeroes rows i + ntiles, i + 2 ntiles, i + 3 ntiles (ntiles <= rows <= 4 ntiles):
-            // tg_groupnorm_finalize sums all ceil(V / 128) rows
-            const int stat = tid >> 5, grp = tid & 31;
+        const int qpg = nslab, gps = 32 / nslab;          // channel quads per GroupNorm(32) group (cout / 128), groups per 128-channel slab
+        if (tid < 64 && (tid & 31) < gps) {
+            // patch i owns row i of the partial buffer and zeroes rows i + ntiles, i + 2 ntiles, i + 3 ntiles (ntiles <= rows <= 4 ntiles), each slab
+            // its own group columns: tg_groupnorm_finalize sums all ceil(V / 128) rows.  Fixed order: waves, then the group's quads.
+            const int stat = tid >> 5, gl = tid & 31;
             float a = 0.f;
-            for (int w_ = 0; w_ < 4; ++w_) a += red[(w_ * 32 + grp) * 2 + stat];
+            for (int w_ = 0; w_ < NW; ++w_)
+                for (int j = 0; j < qpg; ++j) a += red[(w_ * 32 + gl * qpg + j) * 2 + stat];
             const long rows = ((long)p.To * p.Ho * p.Wo + BM - 1) / BM;
-            p.gn_partial[(long)tile * 64 + stat * 32 + grp] = a;
-            for (long r = (long)tile + ntiles; r < rows; r += ntiles) p.gn_partial[r * 64 + stat * 32 + grp] = 0.f;
+            const int col = stat * 32 + slab * gps + gl;
+            p.gn_partial[(long)tile * 64 + col] = a;
+            for (long r = (long)tile + ntiles; r < rows; r += ntiles) p.gn_partial[r * 64 + col] = 0.f;
         }
     }
 }
@@ -979,6 +1011,66 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
 }
 
+// GroupNorm statistics WITHOUT a finalise launch of their own: the norm pass that consumes a convolution's output turns the per-tile sums the convolution's
+// epilogue left (rows of [2][32]: sum, sum of squares per group) into (mean, rstd) in its own prologue — every workgroup does the same few KB of work in
+// the same fixed order (thread (part, column) adds rows part, part + 4, ... in fp64; the four parts meet in LDS), so the result does not depend on which
+// workgroup computes it.  Up to GN_FOLD_ROWS rows are read as they are; longer lists are first cut to <= GN_FOLD_ROWS fp64 rows by gn_reduce_kernel (one
+// coalesced pass, a few microseconds — the launch it replaces walked the rows column-wise from 32 workgroups and averaged 26 us).
+constexpr int GN_FOLD_ROWS = 64;
+
+struct GnSums {
+    const void* rows;     // [n][2][32] float (is_f64 == 0: a convolution's gn_partial) or double (is_f64 == 1: gn_reduce_kernel's output); nullptr: use `stats`
+    int n, is_f64;
+    long V;               // voxels behind the sums (the tensor the norm reads)
+    float eps;
+};
+
+__device__ __forceinline__ void gn_stats_to_lds(const GnSums g, const float* __restrict__ stats, int C, float (*sst)[2]) {
+    __shared__ double sred[4][64];
+    const int t = threadIdx.x;
+    if (!g.rows) {                                        // statistics were computed by a launch of their own (tg_groupnorm_stats / _finalize)
+        if (t < 64) sst[t >> 1][t & 1] = stats[t];
+        __syncthreads();
+        return;
+    }
+    const int col = t & 63, part = t >> 6;
+    double a = 0.0;
+    if (g.is_f64) {
+        const double* r = (const double*)g.rows;
+        for (int b = part; b < g.n; b += 4) a += r[(long)b * 64 + col];
+    } else {
+        const float* r = (const float*)g.rows;
+        for (int b = part; b < g.n; b += 4) a += (double)r[(long)b * 64 + col];
+    }
+    sred[part][col] = a;
+    __syncthreads();
+    if (t < GN_GROUPS) {
+        const double s = (sred[0][t] + sred[1][t]) + (sred[2][t] + sred[3][t]);
+        const double q = (sred[0][GN_GROUPS + t] + sred[1][GN_GROUPS + t]) + (sred[2][GN_GROUPS + t] + sred[3][GN_GROUPS + t]);
+        const double n = (double)g.V * (C / GN_GROUPS);
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0) var = 0;
+        sst[t][0] = (float)mean;
+        sst[t][1] = (float)(1.0 / sqrt(var + (double)g.eps));
+    }
+    __syncthreads();
+}
+
+// rows [n][64] float -> out [gridDim.x][64] double: workgroup r adds the rows of its contiguous range (thread (part, column): rows part, part + 4, ... of
+// the range; parts joined in a fixed order).  Whole 256-byte rows per wave load.
+__global__ __launch_bounds__(256) void gn_reduce_kernel(const float* __restrict__ rows, long n, double* __restrict__ out) {
+    __shared__ double sred[4][64];
+    const int t = threadIdx.x, col = t & 63, part = t >> 6;
+    const long per = (n + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * per, r1 = min(n, r0 + per);
+    double a = 0.0;
+    for (long b = r0 + part; b < r1; b += 4) a += (double)rows[b * 64 + col];
+    sred[part][col] = a;
+    __syncthreads();
+    if (t < 64) out[(long)blockIdx.x * 64 + t] = (sred[0][t] + sred[1][t]) + (sred[2][t] + sred[3][t]);
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 // the streaming norm passes are VALU-bound before they are HBM-bound (~30 VALU per element with a true division and per-value bf16 round
 // trips): pairwise rounding through one v_cvt_pk_bf16_f32, exp2 + v_rcp_f32 instead of expf + division (the result is rounded to bf16 next)
@@ -989,9 +1081,12 @@ __device__ __forceinline__ void round_bf16_pair(float& a, float& b) {
     b = bf16hi_to_f32(p);
 }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, long V, int C, const float* __restrict__ stats,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, long V, int C, const float* __restrict__ stats_g, GnSums sums,
                                                        const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
                                                        bf16_t* __restrict__ y, int apply_silu) {
+    __shared__ float sst[GN_GROUPS][2];
+    gn_stats_to_lds(sums, stats_g, C, sst);
+    const float* const stats = &sst[0][0];
     const int vec_per_row = C >> 3, cg = C / GN_GROUPS;
     const long total = V * vec_per_row;
     if (256 % vec_per_row == 0) {
@@ -1053,10 +1148,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
 // with nearest-neighbour resizing, so they are evaluated once per LATENT voxel (yz, bz: [Tz*Hz*Wz][C] bf16, a tiny GEMM) and
 // this kernel is a pure streaming pass: y = silu( GN(f) * yz[map(voxel)] + bz[map(voxel)] ).
 __global__ __launch_bounds__(256) void spatialnorm_kernel(const bf16_t* __restrict__ f, int T, int H, int W, int C,
-                                                          const float* __restrict__ stats, const bf16_t* __restrict__ gamma,
+                                                          const float* __restrict__ stats_g, GnSums sums, const bf16_t* __restrict__ gamma,
                                                           const bf16_t* __restrict__ beta, const bf16_t* __restrict__ yz,
                                                           const bf16_t* __restrict__ bz, long ldz, int Tz, int Hz, int Wz,
                                                           bf16_t* __restrict__ y, int apply_silu) {
+    __shared__ float sst[GN_GROUPS][2];
+    gn_stats_to_lds(sums, stats_g, C, sst);
+    const float* const stats = &sst[0][0];
     const int vec_per_row = C >> 3, cg = C / GN_GROUPS;
     const long V = (long)T * H * W, total = V * vec_per_row;
     const bool split_first = (T > 1) && (T & 1);
@@ -1098,11 +1196,14 @@ __global__ __launch_bounds__(256) void spatialnorm_kernel(const bf16_t* __restri
 // table filled once per workgroup, and a thread keeps ONE channel vector (256 % (C/8) == 0), so gamma / beta / mean / rstd of its 8
 // channels are loaded once.
 __global__ __launch_bounds__(256) void spatialnorm_row_kernel(const bf16_t* __restrict__ f, int T, int H, int W, int C,
-                                                              const float* __restrict__ stats, const bf16_t* __restrict__ gamma,
+                                                              const float* __restrict__ stats_g, GnSums sums, const bf16_t* __restrict__ gamma,
                                                               const bf16_t* __restrict__ beta, const bf16_t* __restrict__ yz,
                                                               const bf16_t* __restrict__ bz, long ldz, int Tz, int Hz, int Wz,
                                                               bf16_t* __restrict__ y, int apply_silu) {
     __shared__ int wzs[2048];
+    __shared__ float sst[GN_GROUPS][2];
+    gn_stats_to_lds(sums, stats_g, C, sst);
+    const float* const stats = &sst[0][0];
     const int tid = threadIdx.x;
     const int h_ = blockIdx.x % H, t_ = blockIdx.x / H;
     const bool split_first = (T > 1) && (T & 1);
@@ -1292,15 +1393,6 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
     }
-    if (w4 && (w4 == 2 || ((M + 255) / 256) * (cout / 256) >= 2L * n_cu) && cout == cout_pad && cout % 256 == 0 && !t_map && M >= 1024 && (long)kt * kh * kw * (Cin / 64) >= 4 && H * up < 2048 && W * up < 2048 &&
-        To < 512 && Ho < 2048 && Wo < 2048 && (long)kt * kh * kw * Cin < (1L << 21) && (long)(T + 2) * H * W * Cin < (1L << 31)) {
-        static bool attr4 = false;
-        if (!attr4) { (void)hipFuncSetAttribute((const void*)conv3d_w4_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS); attr4 = true; }
-        const long tiles4 = ((M + 255) / 256) * (cout / 256);
-        hipLaunchKernelGGL(conv3d_w4_kernel<256>, dim3((unsigned)tiles4), dim3(256), CW_LDS, stream, p);
-        TG_LAUNCH_CHECK("tg_conv3d_cl(w4)");
-        return TG_OK;
-    }
     // Cout = 128, 3x3 spatial taps, stride 1, no upsampling: the halo-tiled kernel.  Against the GEMM-shaped kernels on the 8 x 240 x 360 layers:
     // 128 -> 128: 0.70 vs 0.74 ms per launch; per clip 64 -> 128 (encoder conv_in) 13.3 vs 17.5 ms, 256 -> 128 45.6 vs 51.2 ms.  Why not more:
     // see the stage loop's comment (the fill does not overlap with the issuing wave's MFMAs).
@@ -1309,15 +1401,28 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
     {
         const long h2tiles = (long)To * ((Ho + H2_PH - 1) / H2_PH) * ((Wo + H2_PW - 1) / H2_PW);
         const long rows128 = (M + BM - 1) / BM;
-        if (halo_on && cout == 128 && cout_pad == 128 && kh == 3 && kw == 3 && pad == 1 && stride == 1 && up == 1 && !t_map && (kt == 1 || kt == 3) &&
+        // Cout = 256 (two 128-channel slabs per patch) is legal but measured SLOWER than the 256 x 256 GEMM-shaped kernel (0.66 vs 0.55 ms on 256 -> 256 at
+        // 8 x 120 x 180: each slab re-stages the halo and the weights dominate the fill either way): taken only when forced (TG_CONV_HALO=2, tests)
+        if (halo_on && (cout == 128 || (cout == 256 && halo_on == 2)) && cout_pad == cout && kh == 3 && kw == 3 && pad == 1 && stride == 1 && up == 1 && !t_map && (kt == 1 || kt == 3) &&
             To == T && Ho == H && Wo == W && (halo_on == 2 || h2tiles >= n_cu) && h2tiles <= rows128 &&
             rows128 <= 4 * h2tiles && (long)(T + 2) * H * W * Cin < (1L << 31) && h2tiles < (1L << 31)) {
             static bool attrh = false;
-            if (!attrh) { (void)hipFuncSetAttribute((const void*)conv3d_halo2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS); attrh = true; }
-            hipLaunchKernelGGL(conv3d_halo2_kernel, dim3((unsigned)h2tiles), dim3(256), H2_LDS, stream, p);
+            if (!attrh) { (void)hipFuncSetAttribute((const void*)conv3d_halo2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS); attrh = true; }
+            // 8 waves (two per SIMD): 0.716 vs 0.730 ms (128 -> 128 at 8 x 240 x 360), 1.19 vs 1.26 ms (256 -> 128) against the one-wave-per-SIMD form of
+            // the same kernel, same box (profiles/NOTES.md, round 4)
+            hipLaunchKernelGGL(conv3d_halo2_kernel<8>, dim3((unsigned)(h2tiles * (cout / 128))), dim3(512), H2_LDS, stream, p);
             TG_LAUNCH_CHECK("tg_conv3d_cl(halo)");
             return TG_OK;
         }
+    }
+    if (w4 && (w4 == 2 || ((M + 255) / 256) * (cout / 256) >= 2L * n_cu) && cout == cout_pad && cout % 256 == 0 && !t_map && M >= 1024 && (long)kt * kh * kw * (Cin / 64) >= 4 && H * up < 2048 && W * up < 2048 &&
+        To < 512 && Ho < 2048 && Wo < 2048 && (long)kt * kh * kw * Cin < (1L << 21) && (long)(T + 2) * H * W * Cin < (1L << 31)) {
+        static bool attr4 = false;
+        if (!attr4) { (void)hipFuncSetAttribute((const void*)conv3d_w4_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS); attr4 = true; }
+        const long tiles4 = ((M + 255) / 256) * (cout / 256);
+        hipLaunchKernelGGL(conv3d_w4_kernel<256>, dim3((unsigned)tiles4), dim3(256), CW_LDS, stream, p);
+        TG_LAUNCH_CHECK("tg_conv3d_cl(w4)");
+        return TG_OK;
     }
     // Cout = 128: the 512x128 variant (plain 3x3x3 / 1x3x3 convolutions only: 16 A pieces per wave are too many for the general address path)
     // (TG_CONV_W4 governs this variant too; measured: 128->128 layers 203 -> 187 ms per decode, 181 -> 162 ms per encode)
@@ -1397,33 +1502,67 @@ extern "C" int tg_groupnorm_finalize(const float* partial, long V, int C, float 
     return TG_OK;
 }
 
-extern "C" int tg_groupnorm_silu(const void* x, long V, int C, const float* stats, const void* gamma, const void* beta, void* y,
-                                 int apply_silu, hipStream_t stream) {
-    TG_REQUIRE(x && stats && gamma && beta && y, TG_ERR_ARG, "tg_groupnorm_silu: null pointer");
+// the statistics source of a norm pass: ready-made (mean, rstd) pairs, or the sums a convolution's epilogue (or tg_groupnorm_reduce) left
+static int gn_sums_arg(const char* who, const float* stats, const void* sums, long nsum, int sums_f64, long V, float eps, GnSums& g) {
+    TG_REQUIRE((stats != nullptr) != (sums != nullptr), TG_ERR_ARG, "%s: exactly one of stats / sums", who);
+    TG_REQUIRE(!sums || (nsum > 0 && nsum <= GN_FOLD_ROWS && tg_aligned16(sums)), TG_ERR_SHAPE, "%s: 1..%d rows of sums (got %ld)", who, GN_FOLD_ROWS, nsum);
+    g = GnSums{sums, (int)nsum, sums_f64, V, eps};
+    return TG_OK;
+}
+
+extern "C" long tg_groupnorm_reduce_rows(long nrows) { return nrows <= GN_FOLD_ROWS ? 0 : (nrows < 32L * GN_FOLD_ROWS ? (nrows + GN_FOLD_ROWS - 1) / GN_FOLD_ROWS : 32); }
+
+extern "C" int tg_groupnorm_reduce(const float* partial, long nrows, double* out, hipStream_t stream) {
+    TG_REQUIRE(partial && out, TG_ERR_ARG, "tg_groupnorm_reduce: null pointer");
+    const long r = tg_groupnorm_reduce_rows(nrows);
+    TG_REQUIRE(r > 0, TG_ERR_SHAPE, "tg_groupnorm_reduce: %ld rows need no reduction (<= %d are read by the norm pass itself)", nrows, GN_FOLD_ROWS);
+    hipLaunchKernelGGL(gn_reduce_kernel, dim3((unsigned)r), dim3(256), 0, stream, partial, nrows, out);
+    TG_LAUNCH_CHECK("tg_groupnorm_reduce");
+    return TG_OK;
+}
+
+extern "C" int tg_groupnorm_silu_ex(const void* x, long V, int C, const float* stats, const void* sums, long nsum, int sums_f64, float eps,
+                                    const void* gamma, const void* beta, void* y, int apply_silu, hipStream_t stream) {
+    TG_REQUIRE(x && gamma && beta && y, TG_ERR_ARG, "tg_groupnorm_silu: null pointer");
     TG_REQUIRE(V > 0 && C % 64 == 0, TG_ERR_SHAPE, "tg_groupnorm_silu: bad shape");
     TG_REQUIRE(tg_aligned16(x) && tg_aligned16(y) && tg_aligned16(gamma) && tg_aligned16(beta), TG_ERR_ALIGN, "tg_groupnorm_silu: alignment");
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(V * (C / 8))), dim3(256), 0, stream, (const bf16_t*)x, V, C, stats, (const bf16_t*)gamma,
+    GnSums g;
+    if (const int rc = gn_sums_arg("tg_groupnorm_silu", stats, sums, nsum, sums_f64, V, eps, g)) return rc;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(V * (C / 8))), dim3(256), 0, stream, (const bf16_t*)x, V, C, stats, g, (const bf16_t*)gamma,
                        (const bf16_t*)beta, (bf16_t*)y, apply_silu);
     TG_LAUNCH_CHECK("tg_groupnorm_silu");
+    return TG_OK;
+}
+
+extern "C" int tg_groupnorm_silu(const void* x, long V, int C, const float* stats, const void* gamma, const void* beta, void* y,
+                                 int apply_silu, hipStream_t stream) {
+    return tg_groupnorm_silu_ex(x, V, C, stats, nullptr, 0, 0, 0.f, gamma, beta, y, apply_silu, stream);
+}
+
+extern "C" int tg_spatialnorm_silu_ex(const void* f, int T, int H, int W, int C, const float* stats, const void* sums, long nsum, int sums_f64, float eps,
+                                      const void* gamma, const void* beta, const void* yz, const void* bz, long ldz, int Tz, int Hz, int Wz, void* y,
+                                      int apply_silu, hipStream_t stream) {
+    TG_REQUIRE(f && gamma && beta && yz && bz && y, TG_ERR_ARG, "tg_spatialnorm_silu: null pointer");
+    TG_REQUIRE(T > 0 && H > 0 && W > 0 && C % 64 == 0 && Tz > 0 && Hz > 0 && Wz > 0 && ldz >= C && ldz % 8 == 0, TG_ERR_SHAPE,
+               "tg_spatialnorm_silu: bad shape");
+    TG_REQUIRE(tg_aligned16(f) && tg_aligned16(y) && tg_aligned16(yz) && tg_aligned16(bz), TG_ERR_ALIGN, "tg_spatialnorm_silu: alignment");
+    GnSums g;
+    if (const int rc = gn_sums_arg("tg_spatialnorm_silu", stats, sums, nsum, sums_f64, (long)T * H * W, eps, g)) return rc;
+    const long total = (long)T * H * W * (C / 8);
+    if (256 % (C / 8) == 0 && W <= 2048 && (long)T * H < (1L << 30) && T * H >= 512)   // one workgroup per row: needs >= 2 rows per CU
+        hipLaunchKernelGGL(spatialnorm_row_kernel, dim3((unsigned)(T * H)), dim3(256), 0, stream, (const bf16_t*)f, T, H, W, C, stats, g,
+                           (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)yz, (const bf16_t*)bz, ldz, Tz, Hz, Wz, (bf16_t*)y, apply_silu);
+    else
+        hipLaunchKernelGGL(spatialnorm_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16_t*)f, T, H, W, C, stats, g,
+                           (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)yz, (const bf16_t*)bz, ldz, Tz, Hz, Wz, (bf16_t*)y, apply_silu);
+    TG_LAUNCH_CHECK("tg_spatialnorm_silu");
     return TG_OK;
 }
 
 extern "C" int tg_spatialnorm_silu(const void* f, int T, int H, int W, int C, const float* stats, const void* gamma, const void* beta,
                                    const void* yz, const void* bz, long ldz, int Tz, int Hz, int Wz, void* y, int apply_silu,
                                    hipStream_t stream) {
-    TG_REQUIRE(f && stats && gamma && beta && yz && bz && y, TG_ERR_ARG, "tg_spatialnorm_silu: null pointer");
-    TG_REQUIRE(T > 0 && H > 0 && W > 0 && C % 64 == 0 && Tz > 0 && Hz > 0 && Wz > 0 && ldz >= C && ldz % 8 == 0, TG_ERR_SHAPE,
-               "tg_spatialnorm_silu: bad shape");
-    TG_REQUIRE(tg_aligned16(f) && tg_aligned16(y) && tg_aligned16(yz) && tg_aligned16(bz), TG_ERR_ALIGN, "tg_spatialnorm_silu: alignment");
-    const long total = (long)T * H * W * (C / 8);
-    if (256 % (C / 8) == 0 && W <= 2048 && (long)T * H < (1L << 30) && T * H >= 512)   // one workgroup per row: needs >= 2 rows per CU
-        hipLaunchKernelGGL(spatialnorm_row_kernel, dim3((unsigned)(T * H)), dim3(256), 0, stream, (const bf16_t*)f, T, H, W, C, stats,
-                           (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)yz, (const bf16_t*)bz, ldz, Tz, Hz, Wz, (bf16_t*)y, apply_silu);
-    else
-        hipLaunchKernelGGL(spatialnorm_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16_t*)f, T, H, W, C, stats,
-                           (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)yz, (const bf16_t*)bz, ldz, Tz, Hz, Wz, (bf16_t*)y, apply_silu);
-    TG_LAUNCH_CHECK("tg_spatialnorm_silu");
-    return TG_OK;
+    return tg_spatialnorm_silu_ex(f, T, H, W, C, stats, nullptr, 0, 0, 0.f, gamma, beta, yz, bz, ldz, Tz, Hz, Wz, y, apply_silu, stream);
 }
 
 extern "C" int tg_avgpool_time(const void* x, int T, long HW, int C, void* y, hipStream_t stream) {

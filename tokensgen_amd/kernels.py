@@ -291,12 +291,15 @@ class BwdDeviceState:
         lib = L.load()
         self.status = torch.zeros(4, dtype=torch.int32, device=device)
         self.one_kernel = False
+        self.probe = None
         if os.environ.get("TG_ATTN_BWD_FUSED", "1") != "0":
             nb = lib.tg_attention_bwd_probe_bytes()
             buf = torch.empty(nb, dtype=torch.uint8, device=device)
             L.check(lib.tg_attention_bwd_probe(_p(buf), nb, _stream()), "tg_attention_bwd_probe")
             host = buf.cpu()                                   # (synchronises this stream, once per device and process)
             self.one_kernel = bool(lib.tg_attention_bwd_probe_verdict(host.data_ptr(), nb))
+            # what the probe saw, for the record (bench.py's train sub-record): workgroups off their XCD / polls that gave up, and the chain's sums
+            self.probe = {"flagged": int(host[:4].view(torch.int32)[0]), "sums_exact": bool((host[4 * 2052:].view(torch.float32) == 528.0).all())}
 
     @classmethod
     def get(cls, device):
@@ -569,8 +572,8 @@ def _splitk_floats(*key):
 def conv3d_cl(x, w_packed, bias, cout, kt, kh, kw, cache=None, stride=1, pad=1, up=1, t_map=None, residual=None, out_dims=None,
               gn_stats_eps=None):
     """x [T,H,W,Cin] channels-last; w_packed [Cout_pad, kt*kh*kw, Cin]; returns y [To,Ho,Wo,cout].
-    gn_stats_eps: also produce the GroupNorm(32) statistics of y from the epilogue's partial sums (cout % 128 == 0): they are
-    attached as y.gn_stats ([32,2] fp32: mean, rstd) for the norm that consumes y."""
+    gn_stats_eps: also produce the GroupNorm(32) sums of y in the epilogue (cout % 128 == 0): attached as y.gn_sums (GnSums) for the norm that
+    consumes y, which finalises them itself — no statistics launch; y.gn_sums.stats() gives the [32, 2] (mean, rstd) tensor on request."""
     _chk(x, "x"); _chk(w_packed, "w")
     assert x.is_contiguous() and w_packed.is_contiguous()
     T, H, W, Cin = x.shape
@@ -590,11 +593,38 @@ def conv3d_cl(x, w_packed, bias, cout, kt, kh, kw, cache=None, stride=1, pad=1, 
                     _p(w_packed), _p(bias), cout, w_packed.shape[0], kt, kh, kw, stride, pad, up, _p(t_map), _p(residual), _p(y), cout, To, Ho,
                     Wo, _p(zero_page(x.device)), _p(partial), _p(ws), _stream()), "tg_conv3d_cl")
     if fuse:
-        stats = torch.empty(32, 2, dtype=torch.float32, device=x.device)
-        L.check(_launch("groupnorm_finalize", L.load().tg_groupnorm_finalize, _p(partial), To * Ho * Wo, cout, float(gn_stats_eps), _p(stats),
-                        _stream()), "tg_groupnorm_finalize")
-        y.gn_stats = stats
+        y.gn_sums = GnSums(partial, To * Ho * Wo, cout, float(gn_stats_eps))
     return y
+
+
+class GnSums:
+    """The GroupNorm(32) sums a convolution's epilogue left for the norm that reads its output: rows of [2][32] (sum, sum of squares per group), one per
+    128 voxels.  The norm pass turns <= 64 rows into (mean, rstd) in its own prologue (tg_groupnorm_silu_ex / tg_spatialnorm_silu_ex); longer lists are
+    cut to <= 64 fp64 rows by one tg_groupnorm_reduce launch first.  `.stats()` gives the classic [32, 2] (mean, rstd) tensor through
+    tg_groupnorm_finalize (tests / callers that want the numbers)."""
+
+    def __init__(self, partial, V, C, eps):
+        self.partial, self.V, self.C, self.eps = partial, V, C, eps
+        self._rows = None
+
+    def rows(self):
+        """(tensor, row count, is_f64) as the *_ex norm entry points take them."""
+        if self._rows is None:
+            n = self.partial.numel() // 64
+            r = L.load().tg_groupnorm_reduce_rows(n)
+            if r == 0:
+                self._rows = (self.partial, n, 0)
+            else:
+                out = torch.empty(r, 64, dtype=torch.float64, device=self.partial.device)
+                L.check(_launch("groupnorm_reduce", L.load().tg_groupnorm_reduce, _p(self.partial), n, _p(out), _stream()), "tg_groupnorm_reduce")
+                self._rows = (out, r, 1)
+        return self._rows
+
+    def stats(self):
+        stats = torch.empty(32, 2, dtype=torch.float32, device=self.partial.device)
+        L.check(_launch("groupnorm_finalize", L.load().tg_groupnorm_finalize, _p(self.partial), self.V, self.C, self.eps, _p(stats), _stream()),
+                "tg_groupnorm_finalize")
+        return stats
 
 
 def groupnorm_stats(x2d, eps=1e-6):
@@ -608,12 +638,21 @@ def groupnorm_stats(x2d, eps=1e-6):
     return stats
 
 
+def _stats_args(stats):
+    """stats: a [32, 2] (mean, rstd) tensor, or a GnSums -> (stats ptr, sums ptr, rows, is_f64, eps) of the *_ex norm entry points."""
+    if isinstance(stats, GnSums):
+        t, n, f64 = stats.rows()
+        return None, _p(t), n, f64, stats.eps
+    return _p(stats), None, 0, 0, 0.0
+
+
 def groupnorm_silu(x, stats, gamma, beta, silu=True):
+    """stats: [32, 2] (mean, rstd) from groupnorm_stats, or the GnSums a convolution attached to x (no statistics launch)."""
     _chk(x, "x"); assert x.is_contiguous()
     C = x.shape[-1]
     y = torch.empty_like(x)
-    L.check(_launch("groupnorm_silu", L.load().tg_groupnorm_silu, _p(x), x.numel() // C, C, _p(stats), _p(gamma), _p(beta), _p(y), 1 if silu else 0,
-                    _stream()), "tg_groupnorm_silu")
+    L.check(_launch("groupnorm_silu", L.load().tg_groupnorm_silu_ex, _p(x), x.numel() // C, C, *_stats_args(stats), _p(gamma), _p(beta), _p(y),
+                    1 if silu else 0, _stream()), "tg_groupnorm_silu")
     return y
 
 
@@ -624,7 +663,7 @@ def spatialnorm_silu(f, stats, gamma, beta, yz, bz, zdims, silu=True):
     Tz, Hz, Wz = zdims
     assert yz.shape[0] == Tz * Hz * Wz and yz.stride(0) == bz.stride(0)
     y = torch.empty_like(f)
-    L.check(_launch("spatialnorm_silu", L.load().tg_spatialnorm_silu, _p(f), T, H, W, C, _p(stats), _p(gamma), _p(beta), _p(yz), _p(bz),
+    L.check(_launch("spatialnorm_silu", L.load().tg_spatialnorm_silu_ex, _p(f), T, H, W, C, *_stats_args(stats), _p(gamma), _p(beta), _p(yz), _p(bz),
                     yz.stride(0), Tz, Hz, Wz, _p(y), 1 if silu else 0, _stream()), "tg_spatialnorm_silu")
     return y
 

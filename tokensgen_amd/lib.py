@@ -64,6 +64,9 @@ PROTOTYPES = {
     "tg_groupnorm_stats": [_vp, _l, _i, _f, _vp, _vp, _vp],
     "tg_groupnorm_silu": [_vp, _l, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "tg_spatialnorm_silu": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _i, _vp],
+    "tg_groupnorm_reduce": [_vp, _l, _vp, _vp],
+    "tg_groupnorm_silu_ex": [_vp, _l, _i, _vp, _vp, _l, _i, _f, _vp, _vp, _vp, _i, _vp],
+    "tg_spatialnorm_silu_ex": [_vp, _i, _i, _i, _i, _vp, _vp, _l, _i, _f, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _i, _vp],
     "tg_avgpool_time": [_vp, _i, _l, _i, _vp, _vp],
     "tg_ncdhw_to_cl": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
     "tg_cl_to_ncdhw": [_vp, _l, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -74,6 +77,7 @@ PROTOTYPES = {
 QUERIES = {
     "tg_groupnorm_partial_floats": [C.c_long, C.c_int],
     "tg_conv3d_gn_partial_floats": [C.c_int, C.c_int, C.c_int],
+    "tg_groupnorm_reduce_rows": [C.c_long],
     "tg_conv3d_splitk_floats": [C.c_int] * 9,
     "tg_attention_bwd_ws_floats": [C.c_int, C.c_int, C.c_int, C.c_int],
     "tg_attention_bwd_probe_bytes": [],

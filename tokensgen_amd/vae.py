@@ -284,7 +284,7 @@ class AutoencoderKLCogVideoX:
         return y
 
     def _norm_act(self, name, x, zq, silu=True):
-        stats = getattr(x, "gn_stats", None)                 # left by the convolution that produced x (its epilogue's partial sums)
+        stats = getattr(x, "gn_sums", None)                  # left by the convolution that produced x (its epilogue's per-tile sums; the norm pass finalises them)
         if stats is None:
             stats = K.groupnorm_stats(x.view(-1, x.shape[-1]), self.config.norm_eps)
         if zq is None:

@@ -31,36 +31,38 @@ def pack(w):
 
 rel = lambda a, b: ((a.float().cpu() - b.float().cpu()).norm() / (b.float().cpu().norm() + 1e-12)).item()
 res = {}
-# (Cin, T, H, W, kt): ragged patches in both directions (H % 16, W % 32 != 0), one and several channel chunks, 1x3x3 and 3x3x3, T = 1
-for ci, T, H, W, kt in [(128, 3, 19, 45, 3), (64, 2, 16, 32, 3), (256, 2, 17, 70, 3), (128, 1, 9, 33, 3), (128, 2, 10, 40, 1), (192, 2, 33, 20, 3)]:
-    w = r(128, ci, kt, 3, 3, seed=1, scale=0.04)
-    b = r(128, seed=2)
+# (Cin, T, H, W, kt, Cout): ragged patches in both directions (H % 16, W % 32 != 0), one and several channel chunks, 1x3x3 and 3x3x3, T = 1;
+# Cout = 256: two 128-channel slabs per patch (GroupNorm groups of 8 channels: two channel quads per group)
+for ci, T, H, W, kt, co in [(128, 3, 19, 45, 3, 128), (64, 2, 16, 32, 3, 128), (256, 2, 17, 70, 3, 128), (128, 1, 9, 33, 3, 128), (128, 2, 10, 40, 1, 128),
+                            (192, 2, 33, 20, 3, 128), (256, 2, 17, 70, 3, 256), (128, 2, 20, 33, 1, 256), (512, 1, 16, 32, 3, 256)]:
+    w = r(co, ci, kt, 3, 3, seed=1, scale=0.04)
+    b = r(co, seed=2)
     x = r(1, ci, T + 2, H, W, seed=3)
     sd = {"c.conv.weight": w.float(), "c.conv.bias": b.float()}
     cl = lambda t: t[0].permute(1, 2, 3, 0).contiguous().to(DEV)
-    wp = pack(w.reshape(128, ci, kt, 3, 3) if kt == 3 else w.reshape(128, ci, 1, 3, 3)).to(DEV)
+    wp = pack(w.reshape(co, ci, kt, 3, 3)).to(DEV)
     x1, x2 = x[:, :, :2], x[:, :, 2:]
     if kt == 3:
         cache = V.ConvCache()
         ref1 = V.causal_conv3d(sd, "c", x1.float(), cache)                      # first call: frame 0 replicated
         ref2 = V.causal_conv3d(sd, "c", x2.float(), cache)                      # second call: the carried cache
-        y1 = K.conv3d_cl(cl(x1), wp, b.to(DEV), 128, 3, 3, 3, gn_stats_eps=1e-6)
-        y2 = K.conv3d_cl(cl(x2), wp, b.to(DEV), 128, 3, 3, 3, cache=cl(x1)[-2:].contiguous(), gn_stats_eps=1e-6)
+        y1 = K.conv3d_cl(cl(x1), wp, b.to(DEV), co, 3, 3, 3, gn_stats_eps=1e-6)
+        y2 = K.conv3d_cl(cl(x2), wp, b.to(DEV), co, 3, 3, 3, cache=cl(x1)[-2:].contiguous(), gn_stats_eps=1e-6)
     else:
         f2 = lambda t: torch.nn.functional.conv2d(t[0].permute(1, 0, 2, 3).float(), w[:, :, 0].float(), b.float(), padding=1).permute(1, 0, 2, 3)[None]
         ref1, ref2 = f2(x1), f2(x2)
-        y1 = K.conv3d_cl(cl(x1), wp, b.to(DEV), 128, 1, 3, 3, gn_stats_eps=1e-6)
-        y2 = K.conv3d_cl(cl(x2), wp, b.to(DEV), 128, 1, 3, 3, gn_stats_eps=1e-6)
+        y1 = K.conv3d_cl(cl(x1), wp, b.to(DEV), co, 1, 3, 3, gn_stats_eps=1e-6)
+        y2 = K.conv3d_cl(cl(x2), wp, b.to(DEV), co, 1, 3, 3, gn_stats_eps=1e-6)
     nc = lambda y: y.permute(3, 0, 1, 2)[None]
     e1, e2 = rel(nc(y1), ref1), rel(nc(y2), ref2)
     resid = r(*y2.shape, seed=9).to(DEV)
-    y3 = K.conv3d_cl(cl(x2), wp, b.to(DEV), 128, kt, 3, 3, cache=(cl(x1)[-2:].contiguous() if kt == 3 else None), residual=resid, gn_stats_eps=1e-6)
+    y3 = K.conv3d_cl(cl(x2), wp, b.to(DEV), co, kt, 3, 3, cache=(cl(x1)[-2:].contiguous() if kt == 3 else None), residual=resid, gn_stats_eps=1e-6)
     e3 = rel(y3, y2.float() + resid.float())
-    st = K.groupnorm_stats(y2.view(-1, 128), 1e-6)
-    es = (y2.gn_stats - st).abs().max().item()
-    y2b = K.conv3d_cl(cl(x2), wp, b.to(DEV), 128, kt, 3, 3, cache=(cl(x1)[-2:].contiguous() if kt == 3 else None), gn_stats_eps=1e-6)
-    same = torch.equal(y2, y2b) and torch.equal(y2.gn_stats, y2b.gn_stats)
-    key = f"ci{ci}_T{T}_H{H}_W{W}_kt{kt}"
+    st = K.groupnorm_stats(y2.view(-1, co), 1e-6)
+    es = (y2.gn_sums.stats() - st).abs().max().item()
+    y2b = K.conv3d_cl(cl(x2), wp, b.to(DEV), co, kt, 3, 3, cache=(cl(x1)[-2:].contiguous() if kt == 3 else None), gn_stats_eps=1e-6)
+    same = torch.equal(y2, y2b) and torch.equal(y2.gn_sums.stats(), y2b.gn_sums.stats())
+    key = f"ci{ci}_T{T}_H{H}_W{W}_kt{kt}_co{co}"
     print(key, f"rel {e1:.2e} {e2:.2e} residual {e3:.2e} stats {es:.2e} repeatable {same}")
     assert max(e1, e2, e3) < 5e-3 and es < 2e-4 and same, key
     res[key] = (y1.cpu(), y2.cpu())

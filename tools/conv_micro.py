@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""One full-resolution 128 -> 128 3x3x3 convolution (the VAE's largest Cout = 128 shape) in a loop: timing / PMC target for the conv kernels.
-TG_CONV_HALO selects the kernel (0: 4-wave 512 x 128 GEMM-shaped kernel, 3: halo-tiled)."""
+"""The VAE decoder's large 3x3x3 convolution shapes, each in a loop: timing / PMC target for the conv kernels.  The dispatch switches of
+tg_conv3d_cl (TG_CONV_HALO, TG_CONV_W4, ...) select the kernel; same-box A/B = one process per setting.
+usage: conv_micro.py [repeats] [case ...]      cases: c128 (128->128 @ 8x240x360), c256 (256->256 @ 8x120x180), c256_128 (256->128 @ 8x240x360),
+                                                c512_256 (512->256 @ 4x60x90), c256s (256->256 @ 4x60x90)"""
+import json
 import os
 import sys
 import time
@@ -12,20 +15,26 @@ sys.path.insert(0, ROOT)
 from tokensgen_amd import kernels as K  # noqa: E402
 
 DEV, BF = "cuda", torch.bfloat16
-T, H, W, C = 8, 240, 360, 128
-g = torch.Generator(device=DEV).manual_seed(0)
-x = torch.randn(T, H, W, C, generator=g, device=DEV).to(BF)
-cache = torch.randn(2, H, W, C, generator=g, device=DEV).to(BF)
-w = (torch.randn(128, 27, C, generator=g, device=DEV) * 0.02).to(BF)
-b = torch.zeros(128, dtype=BF, device=DEV)
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-for _ in range(3):
-    y = K.conv3d_cl(x, w, b, 128, 3, 3, 3, cache=cache, gn_stats_eps=1e-6)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(n):
-    y = K.conv3d_cl(x, w, b, 128, 3, 3, 3, cache=cache, gn_stats_eps=1e-6)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / n
-fl = 2.0 * T * H * W * 27 * C * 128
-print(f"TG_CONV_HALO={os.environ.get('TG_CONV_HALO', '1')}: {dt * 1e3:.3f} ms, {fl / dt / 1e12:.1f} TFLOP/s")
+CASES = {"c128": (128, 128, 8, 240, 360), "c256": (256, 256, 8, 120, 180), "c256_128": (256, 128, 8, 240, 360), "c512_256": (512, 256, 4, 60, 90),
+         "c256s": (256, 256, 4, 60, 90)}
+args = sys.argv[1:]
+n = int(args[0]) if args and args[0].isdigit() else 20
+names = [a for a in args if a in CASES] or list(CASES)
+env = {k: v for k, v in os.environ.items() if k.startswith("TG_CONV")}
+for name in names:
+    Ci, Co, T, H, W = CASES[name]
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(T, H, W, Ci, generator=g, device=DEV).to(BF)
+    cache = torch.randn(2, H, W, Ci, generator=g, device=DEV).to(BF)
+    w = (torch.randn(Co, 27, Ci, generator=g, device=DEV) * 0.02).to(BF)
+    b = torch.zeros(Co, dtype=BF, device=DEV)
+    for _ in range(3):
+        y = K.conv3d_cl(x, w, b, Co, 3, 3, 3, cache=cache, gn_stats_eps=1e-6)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        y = K.conv3d_cl(x, w, b, Co, 3, 3, 3, cache=cache, gn_stats_eps=1e-6)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    fl = 2.0 * T * H * W * 27 * Ci * Co
+    print(json.dumps({"case": name, "env": env, "ms": round(dt * 1e3, 4), "TFLOPs": round(fl / dt / 1e12, 1), "checksum": float(y.float().abs().mean())}))
