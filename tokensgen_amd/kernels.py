@@ -292,6 +292,11 @@ class BwdDeviceState:
         self.status = torch.zeros(4, dtype=torch.int32, device=device)
         self.one_kernel = False
         self.probe = None
+        # how the one-kernel form adds the key blocks' dQ contributions: "atomic" (default: fp32 L2 atomics, dq reproducible to summation order — what the
+        # reference's own flash backward does) or "ordered" (key-block order through L2 counters: bitwise reproducible, ~20 % slower)
+        self.dq_mode = os.environ.get("TG_ATTN_BWD_DQ", "atomic")
+        if self.dq_mode not in ("atomic", "ordered"):
+            raise ValueError(f"TG_ATTN_BWD_DQ={self.dq_mode!r}: atomic | ordered")
         if os.environ.get("TG_ATTN_BWD_FUSED", "1") != "0":
             nb = lib.tg_attention_bwd_probe_bytes()
             buf = torch.empty(nb, dtype=torch.uint8, device=device)
@@ -299,7 +304,14 @@ class BwdDeviceState:
             host = buf.cpu()                                   # (synchronises this stream, once per device and process)
             self.one_kernel = bool(lib.tg_attention_bwd_probe_verdict(host.data_ptr(), nb))
             # what the probe saw, for the record (bench.py's train sub-record): workgroups off their XCD / polls that gave up, and the chain's sums
-            self.probe = {"flagged": int(host[:4].view(torch.int32)[0]), "sums_exact": bool((host[4 * 2052:].view(torch.float32) == 528.0).all())}
+            hi = host[:16].view(torch.int32)
+            self.probe = {"flagged": int(hi[0]), "workgroups_not_on_xcd_b_mod_8": int(hi[2]),
+                          "sums_exact": bool((host[4 * 2052:].view(torch.float32) == 528.0).all())}
+
+    def flags(self):
+        if not self.one_kernel:
+            return 0
+        return L.TG_BWD_ATOMIC_DQ if self.dq_mode == "atomic" else L.TG_BWD_ONE_KERNEL
 
     @classmethod
     def get(cls, device):
@@ -320,11 +332,11 @@ def attention_bwd_check(device=None):
         st = BwdDeviceState._by_device.get(idx if idx is not None else torch.cuda.current_device())
         if st is None:
             continue
-        n = int(st.status[0].item())
-        if n:
-            st.status[0].zero_()
-            raise RuntimeError(f"tg_attention_bwd_ex: {n} ordered dQ exchange poll(s) timed out on cuda:{idx} — the gradients of this step are "
-                               "invalid (a key block never saw its predecessor's signal); discard the step. TG_ATTN_BWD_FUSED=0 selects the two-launch form.")
+        n, _, x, _ = st.status.tolist()
+        if n or x:
+            st.status[0].zero_(); st.status[2].zero_()
+            raise RuntimeError(f"tg_attention_bwd_ex on cuda:{idx}: {n} ordered dQ exchange poll(s) timed out, {x} workgroup(s) found their head's key blocks on "
+                               "more than one XCD — the gradients of this step are invalid; discard the step. TG_ATTN_BWD_FUSED=0 selects the two-launch form.")
 
 
 def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, accumulate=False, lse=None):
@@ -353,7 +365,7 @@ def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, acc
     st = BwdDeviceState.get(q.device)
     L.check(_launch("attention_bwd", L.load().tg_attention_bwd_ex, _p(q), qld, qsb, _p(k), kld, ksb, _p(v), vld, vsb, _p(o), old, osb, _p(dout), gld, gsb,
                     _p(dq), dq.stride(1), dq.stride(0), _p(dk), dk.stride(1), dk.stride(0), _p(dv), dv.stride(1), dv.stride(0), nq, nk, heads, B,
-                    float(scale), acc, _p(lse), _p(ws), L.TG_BWD_ONE_KERNEL if st.one_kernel else 0, _p(st.status), _stream()), "tg_attention_bwd_ex")
+                    float(scale), acc, _p(lse), _p(ws), st.flags(), _p(st.status), _stream()), "tg_attention_bwd_ex")
     return dq, dk, dv
 
 
