@@ -306,21 +306,17 @@ int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void* k, long k_
  *         synchronises (e.g. once per optimizer micro-step) and must discard the step when it is non-zero.  The launch itself returns 0: the
  *         condition only exists on the device, and the ABI never synchronises.
  *     [1] poll limit override (0: 2^20 polls of ~100 cycles); tests set 1 to force the path.
- *     [2] sticky count of workgroups that found key blocks of their (batch, head) on MORE than one XCD — the placement both one-kernel forms rest on
+ *     [2] sticky count of workgroups that found key blocks of their (batch, head) on MORE than one XCD — the placement the ordered exchange rests on
  *         (a head's dQ traffic meets in ONE XCD's L2) did not hold for that launch: dq INVALID, same handling as [0].   [3] reserved (keep zero).
- *   flags & TG_BWD_ATOMIC_DQ: the one-kernel form with the key blocks' dQ contributions added by fire-and-forget fp32 L2 atomics instead of the ordered
- *     chain (no counters, no polling: nothing can time out).  dk / dv stay bitwise reproducible; dq is reproducible to fp32 summation order only —
- *     the contract of the flash-attention backward the reference itself trains with (F.scaled_dot_product_attention's backward accumulates dq
- *     atomically).  Same shape conditions, same probe, same status words ([2] applies).  accumulate bit 0 clear: the call zeroes dq itself first.
  * Nothing is allocated, freed or synchronised inside; safe under stream capture; no process-wide state. */
-enum { TG_BWD_ONE_KERNEL = 1, TG_BWD_ATOMIC_DQ = 2 };
+enum { TG_BWD_ONE_KERNEL = 1 };
 int tg_attention_bwd_ex(const void* q, long q_ld, long q_sb, const void* k, long k_ld, long k_sb, const void* v, long v_ld, long v_sb,
                         const void* o, long o_ld, long o_sb, const void* dout, long do_ld, long do_sb,
                         float* dq, long dq_ld, long dq_sb, float* dk, long dk_ld, long dk_sb, float* dv, long dv_ld, long dv_sb,
                         int nq, int nk, int heads, int batch, float scale, int accumulate, const float* lse, float* ws, int flags, int* status,
                         hipStream_t stream);
 
-/* Device probe of what the one-kernel forms rely on: (1) the workgroups of one residue class mod 8 of a 1-D launch share an XCD; (2) the exchange protocol itself — a chain
+/* Device probe of what the one-kernel form relies on: (1) the workgroups of one residue class mod 8 of a 1-D launch share an XCD; (2) the exchange protocol itself — a chain
  * of 32 workgroups on one XCD adds to 64 tiles in chain order with exactly the kernel's primitives.  buf: caller-owned device memory of
  * tg_attention_bwd_probe_bytes() bytes (16-byte aligned); the call clears it and launches the probe, asynchronously.  The caller copies buf to the
  * host once the stream has passed it; tg_attention_bwd_probe_verdict(host copy) = 1 when every sum is exact and no poll timed out, else 0. */

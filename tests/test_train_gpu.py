@@ -53,15 +53,9 @@ def test_attention_bwd_vs_autograd(B, H, nq, nk):
     assert _rel(dv, vf.grad) < 4.5e-3          # tolerances = 2x the values measured on MI355X (profiles/r2_parity_report.json: 2.3e-3 / 2.7e-3)
     assert _rel(dq, qf.grad) < 5.5e-3
     assert _rel(dk, kf.grad) < 5.5e-3
-    # deterministic: dk / dv always (no atomics on them); dq bitwise too except in the one-kernel form's default "atomic" dQ mode, whose contract is
-    # reproducibility to fp32 summation order (TG_ATTN_BWD_DQ=ordered in a child run below holds the same shapes to bitwise)
+    # deterministic (no atomics on the data) and accumulate adds
     dq2, dk2, dv2 = K.attention_bwd(qd, kd, vd, o.detach().to(BF).to(DEV), g.to(DEV), H, scale)
-    st = K.BwdDeviceState.get(DEV)
-    assert torch.equal(dk, dk2) and torch.equal(dv, dv2)
-    if st.one_kernel and st.dq_mode == "atomic":
-        assert torch.allclose(dq, dq2, rtol=1e-4, atol=1e-5 * dq.abs().max().item())
-    else:
-        assert torch.equal(dq, dq2)
+    assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
     K.attention_bwd_check(DEV)                                   # no poll timed out, every head's key blocks sat on one XCD
     K.attention_bwd(qd, kd, vd, o.detach().to(BF).to(DEV), g.to(DEV), H, scale, dq=dq2, dk=dk2, dv=dv2, accumulate=True)
     # (the one-kernel form adds its key blocks' dQ contributions to what is there one after the other: equal up to fp32 summation order)
@@ -148,14 +142,6 @@ def test_attention_bwd_poll_timeout_is_reported_not_silent():
         pytest.skip("the one-kernel form is switched off in this run")
     st = K.BwdDeviceState.get(DEV)
     assert st.one_kernel, "tg_attention_bwd_probe failed on this device: the one-kernel backward would never be selected"
-    mode, st.dq_mode = st.dq_mode, "ordered"                         # (the atomic dQ form has nothing that can time out)
-    try:
-        _poll_timeout_body(K, st)
-    finally:
-        st.dq_mode = mode
-
-
-def _poll_timeout_body(K, st):
     B, H, nq, nk = 1, 8, 1100, 700
     scale = 0.125
     fused = _rand(B, nq, 3 * H * 64, seed=11, scale=1.5).to(DEV)
@@ -210,53 +196,6 @@ def test_attention_bwd_without_the_probe_flag_takes_two_launches():
                                    dk.data_ptr(), dk.stride(1), dk.stride(0), dv.data_ptr(), dv.stride(1), dv.stride(0), nq, nk, H, B, scale, 0, None,
                                    ws.data_ptr(), L.TG_BWD_ONE_KERNEL, None, K._stream())
     assert code == -1 and b"status" in lib.tg_last_error_string()
-
-
-def test_attention_bwd_ordered_dq_mode_in_a_child_process():
-    """TG_ATTN_BWD_DQ=ordered: the one-kernel form with the key blocks' dQ contributions added in key-block order through L2 counters — bitwise
-    reproducible dq (the assertion test_attention_bwd_vs_autograd makes in that mode), same autograd comparison."""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get("TG_ATTN_BWD_DQ") == "ordered" or os.environ.get("TG_ATTN_BWD_FUSED") == "0" or os.environ.get("TG_ATTN_BWD_V1") == "1":
-        pytest.skip("already inside a cross-check run")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k",
-                        "test_attention_bwd_vs_autograd or test_attention_bwd_poll_timeout", "-x"],
-                       env=dict(os.environ, TG_ATTN_BWD_DQ="ordered"), capture_output=True, text=True, timeout=600,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
-
-
-def test_attention_bwd_atomic_and_ordered_dq_agree():
-    """The two dQ forms of the one-kernel backward on the same inputs in one process: dk / dv bitwise equal (the same code), dq equal to fp32 summation
-    order; the placement self-check (status[2]) stays clean for both."""
-    import os
-    from tokensgen_amd import kernels as K
-    if os.environ.get("TG_ATTN_BWD_FUSED") == "0" or os.environ.get("TG_ATTN_BWD_V1") == "1":
-        pytest.skip("the one-kernel form is switched off in this run")
-    st = K.BwdDeviceState.get(DEV)
-    assert st.one_kernel
-    B, H, nq, nk = 2, 4, 2500, 300
-    scale = 0.125
-    fused = _rand(B, nq, 3 * H * 64, seed=31, scale=1.5).to(DEV)
-    q, k, v = fused[:, :, :H * 64], fused[:, :nk, H * 64:2 * H * 64], fused[:, :nk, 2 * H * 64:]
-    g = _rand(B, nq, H * 64, seed=32).to(DEV)
-    o = _sdpa(q.float(), k.float(), v.float(), H, scale).to(BF)
-    mode = st.dq_mode
-    try:
-        res = {}
-        for m in ("ordered", "atomic"):
-            st.dq_mode = m
-            res[m] = K.attention_bwd(q, k, v, o, g, H, scale)
-            acc = tuple(t.clone() for t in res[m])
-            K.attention_bwd(q, k, v, o, g, H, scale, dq=acc[0], dk=acc[1], dv=acc[2], accumulate=True)      # adds onto what is there, both forms
-            assert torch.allclose(acc[0], 2 * res[m][0], rtol=1e-4, atol=1e-5) and torch.allclose(acc[1], 2 * res[m][1]) and torch.allclose(acc[2], 2 * res[m][2])
-            K.attention_bwd_check(DEV)
-    finally:
-        st.dq_mode = mode
-    assert torch.equal(res["ordered"][1], res["atomic"][1]) and torch.equal(res["ordered"][2], res["atomic"][2])
-    assert torch.allclose(res["ordered"][0], res["atomic"][0], rtol=1e-4, atol=1e-5 * res["ordered"][0].abs().max().item())
 
 
 def test_attention_bwd_two_kernel_form_in_a_child_process():

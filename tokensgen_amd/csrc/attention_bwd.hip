@@ -654,12 +654,6 @@ __device__ __forceinline__ int cnt_read(int* c) {
 }
 __device__ __forceinline__ void cnt_write(int* c, int v) { asm volatile("global_store_dword %0, %1, off" :: "v"(c), "v"(v) : "memory"); }
 
-// ATOMIC: the key blocks' dQ contributions are added with fire-and-forget fp32 L2 atomics instead of the ordered read-add-write chain: no counters, no
-// polling, no L1 invalidate, nothing to wait for — and the sum's ORDER is whatever the hardware makes it, so dq is reproducible to fp32 rounding only
-// (exactly the contract of the flash-attention backward the reference trains with, which accumulates dq with atomics too).  The atomics carry no sc1 bit:
-// they are performed AT the XCD's L2, which is coherent for the workgroups that use it — all key blocks of a head run on one XCD (xcd_block), the same
-// placement property the ordered form needs and tg_attention_bwd_probe checks; nothing reads dq before the kernel boundary.
-template <bool ATOMIC>
 __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
     const BwdParams& p = fp.p;
     extern __shared__ __attribute__((aligned(16))) char fsm[];
@@ -679,7 +673,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
     const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
     const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
     const long stat0 = ((long)b * p.heads + h) * p.nq;
-    // Self-check of the ONE placement property both dQ forms rest on — every key block of a head on the same XCD (its L2 is where their dQ traffic
+    // Self-check of the ONE placement property the ordered exchange rests on — every key block of a head on the same XCD (its L2 is where their dQ traffic
     // meets): each workgroup ORs its XCC id into the head's mask word and looks at what was there.  Device-scope atomic (the blocks it must catch
     // are exactly those on another XCD); one per workgroup, its latency hidden behind the K / V fragment loads below.  A violation is counted in
     // status[2] and reported by the host like a poll time-out — never a silently wrong dq.
@@ -773,8 +767,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
     const bool first = blk == 0 && !(p.accumulate & 1);      // nothing to read: this workgroup's block starts the sum
     f32x4 ldv = f32x4{0.f, 0.f, 0.f, 0.f};
     int cval = 0;                                           // wave 0: counter of the next tile to check, sampled one iteration ahead
-    if constexpr (!ATOMIC)
-        asm volatile("buffer_inv sc1" ::: "memory");        // ONCE per workgroup: whatever earlier workgroups on this CU left in its L1 is gone; from here on
+    asm volatile("buffer_inv sc1" ::: "memory");            // ONCE per workgroup: whatever earlier workgroups on this CU left in its L1 is gone; from here on
                                                             // every dQ line is loaded once, and only after the key block before has completed the whole tile
     auto e_signal = [&](int T) {                             // (wave 0, behind a barrier behind every wave's vmcnt(0)): the stores of tile T are in L2
         if (tid == 0) cnt_write(cntw + (long)T * CNT_PAD, blk + 1);
@@ -817,23 +810,17 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
         }
         pWr += stepDQ;
     };
-    // ATOMIC: this lane's 4 consecutive floats of dQ row (16 qh + t16) of a tile, head dims 16 dblk + 4 g4 ..: its block goes out as 4 atomic adds
-    float* pAt = p.dq + (long)b * p.dq_sb + h * HD + (long)(16 * qh + t16) * p.dq_ld + 16 * dblk + 4 * g4;
-    if constexpr (!ATOMIC) e_sample(0);
+    e_sample(0);
     for (int it = 0; it < ntile; ++it) {
         const int buf = it % 3, sbuf = (it + 2) % 3;
         // the dQ pipeline, all at the top of the iteration where a whole iteration has passed since the loads / stores it waits for were issued:
         // tile it - 3 signalled (its store went out one iteration ago), tile it - 2 written (its old values were requested one iteration ago), tile it - 1 requested
         // the dQ pipeline: tile T is checked (wave 0) during iteration T, requested at the top of T + 1, written at the top of T + 2, signalled behind the
         // barrier of T + 2 (every wave waits for its store in front of that barrier)
-        if constexpr (!ATOMIC) {
-            e_landed();
-            if (it >= 2) e_write(it - 2);
-        }
+        e_landed();
+        if (it >= 2) e_write(it - 2);
         fetch(min(it + 2, ntile - 1) * BT);
-        if constexpr (!ATOMIC) {
-            if (it >= 1) e_request(it - 1);                  // (tile it - 1 was checked before the previous barrier)
-        }
+        if (it >= 1) e_request(it - 1);                      // (tile it - 1 was checked before the previous barrier)
         // ---- S, dP of this tile (statistics seeded through the matrix pipe) ----
         bf16x8 aQ[4], aO[4];
 #pragma unroll
@@ -890,15 +877,11 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
             }
         TG_SB();
         stash(sbuf);
-        if constexpr (!ATOMIC) {
-            e_check(it);                                    // wave 0: key block blk - 1 has completed tile it (needed from the top of the next iteration on)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ldv)); // the store of tile it - 2 (issued at the top of this iteration) is in L2, the request is in
-        }
+        e_check(it);                                        // wave 0: key block blk - 1 has completed tile it (needed from the top of the next iteration on)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ldv));     // the store of tile it - 2 (issued at the top of this iteration) is in L2, the request is in
         __syncthreads();
-        if constexpr (!ATOMIC) {
-            if (it >= 2) e_signal(it - 2);
-            e_sample(it + 1);
-        }
+        if (it >= 2) e_signal(it - 2);
+        e_sample(it + 1);
         // ---- this tile's dQ block: dS [16 q][256 keys] x K [256 keys][16 d] ----
         {
             const bf16_t* dsr = sDS + (it & 1) * 256 * DSLD + (8 * g4 + (t16 >> 2)) * DSLD + 16 * qh + (t16 & 3) * 4;
@@ -912,36 +895,22 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s2 = 0; s2 < 8; ++s2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb8[s2].v, a8[s2].v, acc, 0, 0, 0);     // rows = head dims, column = query
-            if constexpr (ATOMIC) {
-                // fire and forget: issued here, behind the tile's barrier, the adds have a whole iteration before this wave next waits on vmcnt
-                if (it * BT + 16 * qh + t16 < p.nq) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = acc[e] * p.scale;
-                        asm volatile("global_atomic_add_f32 %0, %1, off" :: "v"(pAt + e), "v"(v) : "memory");
-                    }
-                }
-                pAt += (long)BT * p.dq_ld;
-            } else {
-                *(f32x4*)(sDQ + ((it & 1) * BT + 16 * qh + t16) * DQLD + 16 * dblk + 4 * g4) = acc;
-            }
+            *(f32x4*)(sDQ + ((it & 1) * BT + 16 * qh + t16) * DQLD + 16 * dblk + 4 * g4) = acc;
         }
     }
-    if constexpr (!ATOMIC) {
-        // drain the dQ pipeline (tiles ntile - 2 and ntile - 1 are still to be written, ntile - 3 .. ntile - 1 to be signalled)
-        __syncthreads();                                    // the last tile's blocks are in the LDS tile
-        e_landed();
-        if (ntile >= 2) e_write(ntile - 2);
-        e_request(ntile - 1);                               // (checked before the last barrier)
-        e_landed();
-        e_write(ntile - 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            for (int T = max(ntile - 2, 0); T < ntile; ++T) cnt_write(cntw + (long)T * CNT_PAD, blk + 1);
-        }
-        asm volatile("s_nop 15" ::: "memory");
+    // drain the dQ pipeline (tiles ntile - 2 and ntile - 1 are still to be written, ntile - 3 .. ntile - 1 to be signalled)
+    __syncthreads();                                        // the last tile's blocks are in the LDS tile
+    e_landed();
+    if (ntile >= 2) e_write(ntile - 2);
+    e_request(ntile - 1);                                   // (checked before the last barrier)
+    e_landed();
+    e_write(ntile - 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        for (int T = max(ntile - 2, 0); T < ntile; ++T) cnt_write(cntw + (long)T * CNT_PAD, blk + 1);
     }
+    asm volatile("s_nop 15" ::: "memory");
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
         float* DK = p.dk + (long)b * p.dk_sb + h * HD + db * 32 + j;
@@ -998,7 +967,7 @@ __global__ __launch_bounds__(64) void fused_probe_kernel(int* bad, int* cnt, flo
 // statistics: 2 floats per query row (log-sum-exp unless the forward kept it, and D) + the 16-byte seed row of the dK/dV kernel
 extern "C" long tg_attention_bwd_ws_floats(int nq, int nk, int heads, int batch) {
     (void)nk;
-    return 6L * batch * heads * nq + 8 + (long)batch * heads * ((nq + BT - 1) / BT) * 32 + 8 + (long)batch * heads;   // + the one-kernel forms' dQ counters and per-head XCD masks
+    return 6L * batch * heads * nq + 8 + (long)batch * heads * ((nq + BT - 1) / BT) * 32 + 8 + (long)batch * heads;   // + the one-kernel form's dQ counters and per-head XCD masks
 }
 
 // The device probe of the one-kernel form (fused_probe_kernel) as explicit entry points on CALLER-owned memory: nothing is allocated, freed or
@@ -1064,26 +1033,18 @@ extern "C" int tg_attention_bwd_ex(const void* q, long q_ld, long q_sb, const vo
     if (lse) pp.p.lse = const_cast<float*>(lse);
     const dim3 gq((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), gk((unsigned)((nk + 255) / 256), (unsigned)(batch * heads));
     hipLaunchKernelGGL(attn_bwd_stats2_kernel, gq, dim3(256), 0, stream, pp.p);
-    TG_REQUIRE(!(flags & (TG_BWD_ONE_KERNEL | TG_BWD_ATOMIC_DQ)) || status, TG_ERR_ARG, "tg_attention_bwd_ex: TG_BWD_ONE_KERNEL / TG_BWD_ATOMIC_DQ need the status words");
+    TG_REQUIRE(!(flags & TG_BWD_ONE_KERNEL) || status, TG_ERR_ARG, "tg_attention_bwd_ex: TG_BWD_ONE_KERNEL needs the status words");
     // the ordered dQ accumulation runs the key blocks of a head as a chain a few tiles apart: worth it only when there are many more query tiles than
     // key blocks (the 17776^2 call: 556 tiles, 70 blocks; the vip queries' call with 15 tiles and 72 blocks would serialise)
     const bool chain_ok = (long)((nq + BT - 1) / BT) >= 4L * gk.x && dq_ld % 4 == 0 && dq_sb % 4 == 0 && tg_aligned16(dq);
-    if ((flags & (TG_BWD_ONE_KERNEL | TG_BWD_ATOMIC_DQ)) && chain_ok && ((heads * batch) & 7) == 0) {
-        const bool atomic = (flags & TG_BWD_ATOMIC_DQ) != 0;
+    if ((flags & TG_BWD_ONE_KERNEL) && chain_ok && ((heads * batch) & 7) == 0) {
         int* const base = (int*)(ws + ((6 * nrow + 8 + 3) & ~3L));
-        const long ncnt = (long)batch * heads * ((nq + BT - 1) / BT) * 32;       // the ordered form's counters; the per-head XCD masks sit behind them
+        const long ncnt = (long)batch * heads * ((nq + BT - 1) / BT) * 32;       // the exchange counters; the per-head XCD masks sit behind them
         FusedParams fp{pp.p, base, status, base + ncnt};
-        hipError_t e = atomic ? hipMemsetAsync(fp.xmask, 0, (size_t)batch * heads * sizeof(int), stream)
-                              : hipMemsetAsync(fp.cnt, 0, (size_t)(ncnt + (long)batch * heads) * sizeof(int), stream);
-        if (e == hipSuccess && atomic && !(accumulate & 1))                        // the adds need a zero to start from: one strided clear of the dq rows
-            for (int b_ = 0; b_ < batch && e == hipSuccess; ++b_)
-                e = hipMemset2DAsync(dq + (long)b_ * dq_sb, (size_t)dq_ld * sizeof(float), 0, (size_t)heads * HD * sizeof(float), (size_t)nq, stream);
-        if (e == hipSuccess)                                                       // (per device: cheap, no state kept here)
-            e = atomic ? hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS)
-                       : hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
+        hipError_t e = hipMemsetAsync(fp.cnt, 0, (size_t)(ncnt + (long)batch * heads) * sizeof(int), stream);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);   // (per device: cheap, no state kept here)
         if (e != hipSuccess) return tg_set_error(TG_ERR_HIP - (int)e, "tg_attention_bwd_ex: %s", hipGetErrorString(e));
-        if (atomic) hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, dim3(gk.x * gk.y), dim3(512), FUSED_LDS, stream, fp);
-        else hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, dim3(gk.x * gk.y), dim3(512), FUSED_LDS, stream, fp);
+        hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(gk.x * gk.y), dim3(512), FUSED_LDS, stream, fp);
         TG_LAUNCH_CHECK("tg_attention_bwd(one kernel)");
         return TG_OK;
     }

@@ -292,11 +292,6 @@ class BwdDeviceState:
         self.status = torch.zeros(4, dtype=torch.int32, device=device)
         self.one_kernel = False
         self.probe = None
-        # how the one-kernel form adds the key blocks' dQ contributions: "atomic" (default: fp32 L2 atomics, dq reproducible to summation order — what the
-        # reference's own flash backward does) or "ordered" (key-block order through L2 counters: bitwise reproducible, ~20 % slower)
-        self.dq_mode = os.environ.get("TG_ATTN_BWD_DQ", "atomic")
-        if self.dq_mode not in ("atomic", "ordered"):
-            raise ValueError(f"TG_ATTN_BWD_DQ={self.dq_mode!r}: atomic | ordered")
         if os.environ.get("TG_ATTN_BWD_FUSED", "1") != "0":
             nb = lib.tg_attention_bwd_probe_bytes()
             buf = torch.empty(nb, dtype=torch.uint8, device=device)
@@ -309,9 +304,7 @@ class BwdDeviceState:
                           "sums_exact": bool((host[4 * 2052:].view(torch.float32) == 528.0).all())}
 
     def flags(self):
-        if not self.one_kernel:
-            return 0
-        return L.TG_BWD_ATOMIC_DQ if self.dq_mode == "atomic" else L.TG_BWD_ONE_KERNEL
+        return L.TG_BWD_ONE_KERNEL if self.one_kernel else 0
 
     @classmethod
     def get(cls, device):

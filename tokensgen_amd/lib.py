@@ -91,7 +91,6 @@ QUERIES = {
 }
 
 TG_BWD_ONE_KERNEL = 1
-TG_BWD_ATOMIC_DQ = 2
 
 _lib = None
 
