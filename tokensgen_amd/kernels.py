@@ -400,6 +400,9 @@ class AttnRetry:
         self.buf = torch.zeros(self.ints, dtype=torch.int32, device=device)
         self._host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self._event = None
+        # the fast-path launches issued against THIS buffer and (launches, retries) at the last landed poll: the counter lives in this buffer, so
+        # the bookkeeping that interprets it does too (a model owns one AttnRetry per workspace shape; mixing their deltas would be meaningless)
+        self.launches, self.mark = 0, (0, 0)
         # the key-split scratch of the same launch shape (tg_attn_workspace.split; 0 floats when the shape leaves no half-round tail)
         nsf = int(L.load().tg_attention_split_floats(nq0, nq1, heads, batch))
         self.split = torch.empty(nsf, dtype=torch.float32, device=device) if nsf else None

@@ -169,7 +169,6 @@ class CogVideoXTransformer3DModel(nn.Module):
         self._ws = {}
         # "constant_shift" (default) | "running_max": see _attn_fast; TG_ATTN_FIXEDM=0 in the environment forces the latter inside the library
         self.attn_path = "constant_shift"
-        self._attn_launches, self._attn_mark = 0, (0, 0)        # fast launches issued; (launches, retries) at the last landed poll
         D = num_attention_heads * attention_head_dim
         self.inner_dim = D
         self.patch_embed = _PatchEmbed()
@@ -391,15 +390,16 @@ class CogVideoXTransformer3DModel(nn.Module):
         maximum, and the model then stays on it until the weights change (`attn_path`)."""
         if self.attn_path == "running_max" or ws.retry is None:
             return False
-        got = ws.retry.poll(self._attn_launches)
+        r = ws.retry                                       # launch count and poll mark live with the counter they describe (one per workspace shape)
+        got = r.poll(r.launches)
         if got is not None:
             n, mark = got
-            launches, retries = mark - self._attn_mark[0], n - self._attn_mark[1]
-            self._attn_mark = (mark, n)
-            if launches > 0 and retries > 0.02 * launches * (ws.retry.ints - 1):
+            launches, retries = mark - r.mark[0], n - r.mark[1]
+            r.mark = (mark, n)
+            if launches > 0 and retries > 0.02 * launches * (r.ints - 1):
                 self.attn_path = "running_max"
                 return False
-        self._attn_launches += 1
+        r.launches += 1
         return True
 
     def load_state_dict(self, state_dict, strict=True, **kw):
