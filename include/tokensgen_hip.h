@@ -236,6 +236,7 @@ int tg_cfg_dpm_step_f32(const void* model_out, const void* x, const float* old_x
                         int frames, long frame_elems, hipStream_t stream);
 
 /* The general form behind the two above — every guidance / prediction branch of the reference's two sampling loops in the same single launch:
+ *   branches = 1: model_out [1][frames][E], no classifier-free guidance:           v = model_out                 (cogvideo_sampling_mp_fifo.py:497-498: guidance_scale <= 1)
  *   branches = 2: model_out [2][frames][E] = (uncond, cond):                       v = u + g (c - u)            (cogvideo_sampling_mp_fifo.py:531-533)
  *   branches = 3: model_out [3][frames][E] = (uncond_txt, uncond_img, txt_img):    v = c + (g - 1)(c - ut) + (gi - 1)(c - ui)
  *                 (`use_separate_guidance`, :528-530 / pipeline_cogvideox_mp_fifo.py:1261-1263; gi = guidance_img)

@@ -66,14 +66,16 @@ def find_embed_index(cond_t, pos, start_frame_idx):
 
 
 def window_step(denoise, ac, guidance_scale, latents, old_x0, t, prev_t, next_t, draw, out_dtype, use_separate_guidance=False,
-                guidance_scale_img=None, use_dynamic_cfg=False, num_inference_steps=None, prediction_type="v_prediction"):
-    """Worker body :491-550: CFG-batched denoiser call, CFG combine, 13 per-frame DPM steps.
+                guidance_scale_img=None, use_dynamic_cfg=False, num_inference_steps=None, prediction_type="v_prediction",
+                do_classifier_free_guidance=True):
+    """Worker body :491-550: CFG-batched denoiser call, CFG combine, 13 per-frame DPM steps.  do_classifier_free_guidance=False (:497-498, 528: the
+    batch is the latents alone, the model output is the prediction; a dynamic-cfg schedule is still evaluated by the reference and never used).
 
     denoise(latent_in [nb,nf,C,H,W], timesteps [nb,nf]) -> [nb,nf,C,H,W] with nb = 3 for `use_separate_guidance` (uncond_txt, uncond_img,
     txt_img; :493-497, 528-530) else 2; `use_dynamic_cfg`: per-frame cosine guidance as an fp32 tensor (:519-527), which promotes the guided
     prediction to fp32;  draw() -> next gaussian [1,1,C,H,W] (see scheduler_ref.dpm_step).  Returns (latents_out, x0 list)."""
     nf = latents.shape[1]
-    nb = 3 if use_separate_guidance else 2
+    nb = (3 if use_separate_guidance else 2) if do_classifier_free_guidance else 1
     inp = torch.cat([latents] * nb)
     tv = torch.as_tensor(t)
     tt = tv[None].expand(nb, -1)
@@ -81,7 +83,8 @@ def window_step(denoise, ac, guidance_scale, latents, old_x0, t, prev_t, next_t,
     if use_dynamic_cfg:
         g, gi = S.dynamic_guidance(g, tv, num_inference_steps), S.dynamic_guidance(gi, tv, num_inference_steps)
     pred = denoise(inp, tt)
-    pred = S.cfg_combine_separate(pred, g, gi) if use_separate_guidance else S.cfg_combine(pred, g)
+    if do_classifier_free_guidance:
+        pred = S.cfg_combine_separate(pred, g, gi) if use_separate_guidance else S.cfg_combine(pred, g)
     out = latents.clone()
     x0s = []
     for j in range(nf):
@@ -187,7 +190,7 @@ def run_fifo_prenoise(denoise_window, betas, ac, fifo_latents, fifo_old_x0, time
 
 
 def base_stage(denoise, ac, latents, timesteps, guidance_scale, noise_fn, nf=13, use_separate_guidance=False, guidance_scale_img=None,
-               use_dynamic_cfg=False, export=None):
+               use_dynamic_cfg=False, export=None, do_classifier_free_guidance=True):
     """Base stage of the pipeline, pipeline_cogvideox_mp_fifo.py:1186-1307 (chunk 0, scalar timestep, CFG in fp32,
     whole-chunk scheduler step, latents cast back to the model dtype).  denoise(x[nb,nf,...], t[nb]) -> [nb,nf,...] (nb = 3 with
     use_separate_guidance, :1197-1200); noise_fn(i) -> [nf,2,C,H,W] (draw 1 of every frame is the one the 2M branch keeps).  Returns
@@ -198,7 +201,7 @@ def base_stage(denoise, ac, latents, timesteps, guidance_scale, noise_fn, nf=13,
     optional) receives what the stage hands to the FIFO driver: guidance_scale (the argument, :1335) and guidance_scale_img (the compounded
     local, :1336)."""
     import math
-    nb = 3 if use_separate_guidance else 2
+    nb = (3 if use_separate_guidance else 2) if do_classifier_free_guidance else 1        # :1012 (guidance_scale > 1), :1196-1200
     gi = guidance_scale if guidance_scale_img is None else guidance_scale_img      # :1026-1029
     T = len(timesteps)
     dt = latents.dtype
@@ -213,7 +216,9 @@ def base_stage(denoise, ac, latents, timesteps, guidance_scale, noise_fn, nf=13,
         if use_dynamic_cfg:                                                     # :1252-1259
             g = 1 + guidance_scale * ((1 - math.cos(math.pi * ((T - t) / T) ** 5.0)) / 2)
             gi = 1 + gi * ((1 - math.cos(math.pi * ((T - t) / T) ** 5.0)) / 2)      # (the local is overwritten: compounds)
-        if use_separate_guidance:                                               # :1261-1263
+        if not do_classifier_free_guidance:                                     # :1260: the model output is the prediction
+            pass
+        elif use_separate_guidance:                                             # :1261-1263
             ut, ui, c = pred.chunk(3)
             pred = c + (g - 1) * (c - ut) + (gi - 1) * (c - ui)
         else:

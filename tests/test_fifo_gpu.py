@@ -190,9 +190,53 @@ def test_base_stage_dynamic_separate_guidance_vs_reference_pipeline_golden(golde
     parity(rel(out.orig_latents, c["orig_latents"]), 2e-2, "dynamic + 3-way base stage final latents vs reference pipeline run")
 
 
+@pytest.mark.timeout(900)
+def test_flow_without_classifier_free_guidance_vs_oracle(golden_dir, parity):
+    """guidance_scale <= 1 switches classifier-free guidance off in the reference (pipeline_cogvideox_mp_fifo.py:1012, 1196-1200, 1260; worker
+    cogvideo_sampling_mp_fifo.py:497-498, 528): batch of ONE through the DiT, the model output is the prediction.  Base stage on the HIP path (B = 1
+    forwards, tg_cfg_dpm_step_ex branches = 1) against the oracle's base stage with the same keyed noise; its output then drives the FIFO stage in the
+    same mode (the worker's no-guidance arithmetic itself is pinned to runs of the reference worker: fifo_worker_variants.pt "no_cfg")."""
+    from tokensgen_amd import fifo
+    from tokensgen_amd.pipeline import MPFIFOVideoIPAdapterCogVideoXPipeline
+    from tokensgen_amd.scheduler import CogVideoXDPMScheduler
+    from tokensgen_amd.transformer import CogVideoXTransformer3DModel
+    gt = torch.load(os.path.join(golden_dir, "dit_tiny.pt"), weights_only=False)
+    g = torch.load(os.path.join(golden_dir, "fifo_tiny.pt"), weights_only=False)
+    cfg, vipcfg = gt["cfg"], gt["vip"]
+    sd = {k: v.to(BF) for k, v in O.make_state_dict(cfg, 128, seed=g["weight_seed"]).items()}
+    H, W, nf, T = g["H"], g["W"], 13, 52
+    gen = torch.Generator().manual_seed(79)
+    lat0 = torch.randn(1, nf, 16, H, W, generator=gen).to(BF)
+    prompt = g["prompt"].to(BF)[1:]
+    emb1 = g["image_embeddings"].to(BF)[:1, :8]
+    rope = O.rope_3d_crop(64, (0, 0, 0), (nf, H // 2, W // 2), (nf, H // 2, W // 2))
+    _, ac = S.alphas_cumprod()
+    ts = S.trailing_timesteps(T)
+    vr = O.rope_3d(64, g["grid_t"][:13], g["grid_h"], g["grid_w"])
+    cr = O.rope_3d(64, g["cond_t"][:5], g["cond_h"], g["cond_w"])
+    den = lambda x, t: O.dit_forward(sd, cfg, x, prompt, t, emb1[:, :5], rope, vr, cr, vip_scale=[0.6])
+    ref_lat, ref_old, ref_final = Fq.base_stage(den, ac, lat0, ts, 1.0, lambda i: _noise(i, 5, (nf, 2, 16, H, W)), do_classifier_free_guidance=False)
+    m = CogVideoXTransformer3DModel(num_attention_heads=2, attention_head_dim=64, num_layers=2, time_embed_dim=cfg["time_embed_dim"],
+                                    text_embed_dim=cfg["text_embed_dim"], use_rotary_positional_embeddings=True, device=DEV)
+    m.set_vip_layers(None, **vipcfg)
+    m.load_state_dict(sd, strict=True)
+    sched = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
+    pipe = MPFIFOVideoIPAdapterCogVideoXPipeline(m, sched, resampler_config=dict(num_temporal_queries=4, num_height_queries=2, num_width_queries=3))
+    out = pipe(prompt_embeds=prompt, negative_prompt_embeds=None, image_embeddings=emb1, height=H * 8, width=W * 8, latents=lat0, guidance_scale=1.0,
+               step_noise=lambda i: _noise(i, 5, (nf, 2, 16, H, W)))
+    assert not out.do_classifier_free_guidance and out.prompt_embeds.shape[0] == 1 and out.image_embeddings.shape[0] == 1
+    rel = lambda a, b: ((a.float().cpu() - b.float()).norm() / b.float().norm()).item()
+    parity(rel(out.fifo_latents, ref_lat), 2e-2, "no-guidance base stage, FIFO seed latents vs oracle")
+    parity(rel(out.orig_latents, ref_final), 2e-2, "no-guidance base stage, final latents vs oracle")
+    out.num_frames = 1
+    lat = fifo.cogvideo_fifo_mp_v2([pipe], out, noise_seed=3)[1]
+    assert lat.shape[1] == 1 and bool(torch.isfinite(lat).all())
+
+
 def test_fifo_worker_guidance_variants_vs_reference_runs(golden_dir, parity):
     """FifoWorker.window_step on the HIP path against RUNS OF THE REFERENCE WORKER BODY (`fifo_onestep_per_gpu`,
     cogvideo_sampling_mp_fifo.py:408-579; tests/golden/fifo_worker_variants.pt, bf16 cases) for the branches the shipped configs leave off:
+    no classifier-free guidance at all (B = 1 forward, branches = 1: the model output is the prediction, :497-498),
     3-way `use_separate_guidance` with guidance_scale_img (B = 3 forward, tg_cfg_dpm_step_ex branches = 3), `use_dynamic_cfg` (per-frame fp32
     guidance -> fp32 solver arithmetic), both together, and an epsilon-prediction scheduler — head window (prev_t = -1) and tail window
     (t = 999 / no back step), with the reference's gaussian draws replayed in order."""
@@ -216,7 +260,7 @@ def test_fifo_worker_guidance_variants_vs_reference_runs(golden_dir, parity):
         sched.set_timesteps(52)
         w = FifoWorker(m, sched, c["prompt"], rope, c["guidance_scale"], c["grid_h"], c["grid_w"], c["cond_h"], c["cond_w"],
                        use_separate_guidance=c["separate"], guidance_scale_img=c["guidance_scale_img"], use_dynamic_cfg=c["dynamic"],
-                       num_inference_steps=52)
+                       num_inference_steps=52, do_classifier_free_guidance=c.get("cfg", True))
         t, prev_t, next_t = c["t"].tolist(), c["prev_t"].tolist(), c["next_t"].tolist()
         has_old = [o is not None for o in c["old"]]
         old = torch.stack([(o if o is not None else torch.zeros(1, 1, 16, H, W, dtype=BF))[0, 0] for o in c["old"]]).to(DEV)
@@ -239,7 +283,8 @@ def test_fifo_worker_guidance_variants_vs_reference_runs(golden_dir, parity):
         o32, x032 = Fq.window_step(den, ac, c["guidance_scale"], c["latents"].float(), [None if o is None else o.float() for o in c["old"]], c["t"].numpy(),
                                    c["prev_t"].numpy(), c["next_t"].numpy(), lambda: torch.randn(1, 1, 16, H, W, generator=gen2, dtype=BF).float(),
                                    torch.float32, use_separate_guidance=c["separate"], guidance_scale_img=c["guidance_scale_img"],
-                                   use_dynamic_cfg=c["dynamic"], num_inference_steps=52, prediction_type=c["prediction_type"])
+                                   use_dynamic_cfg=c["dynamic"], num_inference_steps=52, prediction_type=c["prediction_type"],
+                                   do_classifier_free_guidance=c.get("cfg", True))
         want_x0 = torch.cat(c["out_x0"], dim=1)[0]
         floor = max(rel(c["out_latents"], o32), rel(want_x0, torch.cat(x032, dim=1)[0]))
         parity(floor, 1.0, f"noise floor, {tag}: the reference's bf16 worker run vs the fp32 oracle (informative)")
@@ -247,7 +292,7 @@ def test_fifo_worker_guidance_variants_vs_reference_runs(golden_dir, parity):
         parity(rel(x, c["out_latents"]), tol, f"worker latents, {tag}, HIP vs reference worker run (bf16)")
         parity(rel(x0, want_x0), tol, f"worker x0, {tag}")
         seen.add(c["name"])
-    assert seen == {"separate", "dynamic", "separate_dynamic", "epsilon_static"}
+    assert seen == {"separate", "dynamic", "separate_dynamic", "epsilon_static", "no_cfg", "no_cfg_dynamic"}
 
 
 @pytest.mark.timeout(900)

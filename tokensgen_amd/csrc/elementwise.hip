@@ -100,7 +100,9 @@ __global__ void cfg_dpm_step_kernel(const bf16_t* __restrict__ mo, const bf16_t*
     const float* c = coef + f * 8;
     const float g = gpf ? gpf[2 * f] : g_s, gi = gpf ? gpf[2 * f + 1] : gi_s;
     float v;
-    if (BR == 2) {
+    if (BR == 1) {                                        // no classifier-free guidance (cogvideo_sampling_mp_fifo.py:497-498, 528: the model output is the prediction)
+        v = bf16_to_f32(mo[idx]);
+    } else if (BR == 2) {
         const float u = bf16_to_f32(mo[idx]), cd = bf16_to_f32(mo[total + idx]);
         if (F32MATH) v = gpf ? u + g * round_bf16(cd - u) : u + g * (cd - u);      // fp32 guidance tensor x the bf16 difference | all fp32 after .float()
         else v = round_bf16(u + round_bf16(g * round_bf16(cd - u)));
@@ -251,7 +253,7 @@ static int cfg_dpm_launch(const char* who, const void* model_out, int branches, 
                           void* x_out, void* x0_out, int frames, long frame_elems, hipStream_t stream) {
     TG_REQUIRE(model_out && x && old_x0 && noise && coef && x_out && x0_out, TG_ERR_ARG, "%s: null pointer", who);
     TG_REQUIRE(frames > 0 && frame_elems > 0, TG_ERR_SHAPE, "%s: bad shape", who);
-    TG_REQUIRE(branches == 2 || branches == 3, TG_ERR_ARG, "%s: branches must be 2 (uncond, cond) or 3 (uncond_txt, uncond_img, txt_img)", who);
+    TG_REQUIRE(branches >= 1 && branches <= 3, TG_ERR_ARG, "%s: branches must be 1 (no guidance), 2 (uncond, cond) or 3 (uncond_txt, uncond_img, txt_img)", who);
     TG_REQUIRE(prediction_type >= 0 && prediction_type <= 2, TG_ERR_ARG, "%s: prediction_type %d", who, prediction_type);
     TG_REQUIRE(f32_math || !f32_state, TG_ERR_ARG, "%s: an fp32 solver state implies fp32 model-output arithmetic", who);
     const long total = (long)frames * frame_elems;
@@ -260,7 +262,9 @@ static int cfg_dpm_launch(const char* who, const void* model_out, int branches, 
     hipLaunchKernelGGL((cfg_dpm_step_kernel<BR_, FM_, FS_>), grid, block, 0, stream, (const bf16_t*)model_out, (const bf16_t*)x, old_x0,        \
                        (const bf16_t*)noise, coef, guidance, guidance_img, guidance_per_frame, prediction_type, (bf16_t*)x_out, x0_out, frames, \
                        frame_elems)
-    if (branches == 2) {
+    if (branches == 1) {
+        if (f32_state) TG_DPM(1, true, true); else if (f32_math) TG_DPM(1, true, false); else TG_DPM(1, false, false);
+    } else if (branches == 2) {
         if (f32_state) TG_DPM(2, true, true); else if (f32_math) TG_DPM(2, true, false); else TG_DPM(2, false, false);
     } else {
         if (f32_state) TG_DPM(3, true, true); else if (f32_math) TG_DPM(3, true, false); else TG_DPM(3, false, false);

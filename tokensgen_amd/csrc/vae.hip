@@ -1065,7 +1065,15 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const float* __restrict_
     const long per = (n + gridDim.x - 1) / gridDim.x;
     const long r0 = (long)blockIdx.x * per, r1 = min(n, r0 + per);
     double a = 0.0;
-    for (long b = r0 + part; b < r1; b += 4) a += (double)rows[b * 64 + col];
+    long b = r0 + part;
+    for (; b + 28 < r1; b += 32) {                        // eight independent loads in flight, added in row order (the first version waited for every row:
+        float v[8];                                       // 39 us for a 5 400-row list, all of it load latency)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = rows[(b + 4 * u) * 64 + col];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += (double)v[u];
+    }
+    for (; b < r1; b += 4) a += (double)rows[b * 64 + col];
     sred[part][col] = a;
     __syncthreads();
     if (t < 64) out[(long)blockIdx.x * 64 + t] = (sred[0][t] + sred[1][t]) + (sred[2][t] + sred[3][t]);
@@ -1510,7 +1518,7 @@ static int gn_sums_arg(const char* who, const float* stats, const void* sums, lo
     return TG_OK;
 }
 
-extern "C" long tg_groupnorm_reduce_rows(long nrows) { return nrows <= GN_FOLD_ROWS ? 0 : (nrows < 32L * GN_FOLD_ROWS ? (nrows + GN_FOLD_ROWS - 1) / GN_FOLD_ROWS : 32); }
+extern "C" long tg_groupnorm_reduce_rows(long nrows) { return nrows <= GN_FOLD_ROWS ? 0 : (nrows < 64L * GN_FOLD_ROWS ? (nrows + GN_FOLD_ROWS - 1) / GN_FOLD_ROWS : 64); }
 
 extern "C" int tg_groupnorm_reduce(const float* partial, long nrows, double* out, hipStream_t stream) {
     TG_REQUIRE(partial && out, TG_ERR_ARG, "tg_groupnorm_reduce: null pointer");

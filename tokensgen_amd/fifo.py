@@ -24,7 +24,7 @@ class FifoWorker:
 
     def __init__(self, transformer, scheduler, prompt_embeds, image_rotary_emb, guidance_scale,
                  vip_grid_h=None, vip_grid_w=None, cond_grid_h=None, cond_grid_w=None, use_separate_guidance=False, guidance_scale_img=None,
-                 use_dynamic_cfg=False, num_inference_steps=None):
+                 use_dynamic_cfg=False, num_inference_steps=None, do_classifier_free_guidance=True):
         self.transformer = transformer
         self.scheduler = scheduler
         self.device = transformer.device
@@ -37,9 +37,11 @@ class FifoWorker:
         self.guidance_scale_img = float(guidance_scale if guidance_scale_img is None else guidance_scale_img)
         self.use_dynamic_cfg = bool(use_dynamic_cfg)
         self.num_inference_steps = num_inference_steps
-        nb = 3 if self.use_separate_guidance else 2
+        # :491-498, 528: without classifier-free guidance (guidance_scale <= 1) the batch is the latents alone and the model output IS the prediction
+        self.do_cfg = bool(do_classifier_free_guidance)
+        nb = self.branches = (3 if self.use_separate_guidance else 2) if self.do_cfg else 1
         if self.prompt_embeds.shape[0] != nb:
-            raise ValueError(f"prompt_embeds must hold {nb} rows ({'uncond, cond, cond' if nb == 3 else 'uncond, cond'}); got {self.prompt_embeds.shape[0]}")
+            raise ValueError(f"prompt_embeds must hold {nb} rows ({('cond', 'uncond, cond', 'uncond, cond, cond')[nb - 1]}); got {self.prompt_embeds.shape[0]}")
         if self.use_dynamic_cfg and not num_inference_steps:
             raise ValueError("use_dynamic_cfg needs num_inference_steps")
         self.vip_grid_h, self.vip_grid_w = vip_grid_h, vip_grid_w
@@ -64,7 +66,7 @@ class FifoWorker:
         if use_vip:
             vr, cr = self.ropes_for(grid_t, cond_grid_t)
         x = latents.to(self.device, BF16)
-        nb = 3 if self.use_separate_guidance else 2
+        nb = self.branches
         if use_vip and image_embeddings.shape[0] != nb:
             raise ValueError(f"image_embeddings must hold {nb} batch rows for this guidance mode; got {image_embeddings.shape[0]}")
         inp = torch.cat([x] * nb, dim=0)                                      # :492-497 (CFG batch: uncond, cond | uncond_txt, uncond_img, txt_img)
@@ -79,7 +81,7 @@ class FifoWorker:
             if t_back[j] is None and has_old[j] and int(prev_t[j]) >= 0:
                 raise IndexError("frame without timestep_back must not carry an old x0 (scheduling_dpm_cogvideox.py:459)")
         gpf = None
-        if self.use_dynamic_cfg:
+        if self.use_dynamic_cfg and self.do_cfg:            # (without CFG the reference still evaluates the schedule, :519-527, and never uses it)
             # :519-527, evaluated like the reference: fp32 tensor arithmetic on the window's integer timesteps (the expression uses the timestep
             # VALUE against num_inference_steps, as the reference does); one small H2D copy per window
             tv = torch.as_tensor(np.asarray(t, dtype=np.int64))
@@ -185,8 +187,6 @@ def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None
     sp = bo.sampling_params
     if sp.get("use_sliding_window_embedding"):
         raise NotImplementedError("use_sliding_window_embedding is not used by the shipped configs")
-    if not bo.do_classifier_free_guidance:
-        raise NotImplementedError("the FIFO stage runs with classifier-free guidance (every shipped config; infer_cogvideo_mp_fifo.py:300-340)")
     if len(getattr(bo, "cache_idx", []) or []):
         raise NotImplementedError("cache_idx capture is a debugging feature of the reference and is not mirrored")
     num_partitions = sp.get("num_partitions", 4)
@@ -233,7 +233,7 @@ def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None
         worker = FifoWorker(pipe.transformer, pipe.scheduler, bo.prompt_embeds, bo.image_rotary_emb, bo.guidance_scale,
                             *((g_h, g_w, c_h, c_w) if use_vip else (None,) * 4), use_separate_guidance=getattr(bo, "use_separate_guidance", False),
                             guidance_scale_img=getattr(bo, "guidance_scale_img", None), use_dynamic_cfg=getattr(bo, "use_dynamic_cfg", False),
-                            num_inference_steps=T)
+                            num_inference_steps=T, do_classifier_free_guidance=bool(bo.do_classifier_free_guidance))
         window_fn = lambda **kw: worker.window_step(**kw)
     noise = _SeededNoise(noise_seed, dev)
     step_noise_fn = step_noise_fn or noise.step

@@ -508,7 +508,7 @@ PRED_TYPES = {"v_prediction": 0, "epsilon": 1, "sample": 2}
 
 def cfg_dpm_step_ex(model_out, x, old_x0, noise, coef, guidance, x_out, x0_out, guidance_img=0.0, guidance_per_frame=None, f32_math=False,
                     prediction_type="v_prediction"):
-    """tg_cfg_dpm_step_ex: model_out [2 or 3, F, E] bf16; x / x_out / noise [F,2,E] bf16; old_x0 / x0_out [F,E] bf16 or fp32 (fp32: the pipelines'
+    """tg_cfg_dpm_step_ex: model_out [1 (no guidance), 2 or 3, F, E] bf16; x / x_out / noise [F,2,E] bf16; old_x0 / x0_out [F,E] bf16 or fp32 (fp32: the pipelines'
     solver state, implies f32_math); guidance_per_frame: fp32 [F, 2] device tensor {g, g_img} (the worker's dynamic cfg) or None."""
     for n, t in (("model_out", model_out), ("x", x), ("x_out", x_out), ("noise", noise)):
         _chk(t, n)
@@ -520,7 +520,7 @@ def cfg_dpm_step_ex(model_out, x, old_x0, noise, coef, guidance, x_out, x0_out, 
     _chk(coef, "coef", torch.float32)
     F_, E = x.shape[0], x[0].numel()
     br = model_out.shape[0]
-    assert br in (2, 3) and model_out.numel() == br * F_ * E and coef.shape == (F_, 8) and coef.is_contiguous()
+    assert br in (1, 2, 3) and model_out.numel() == br * F_ * E and coef.shape == (F_, 8) and coef.is_contiguous()
     if guidance_per_frame is not None:
         _chk(guidance_per_frame, "guidance_per_frame", torch.float32)
         assert guidance_per_frame.is_contiguous() and guidance_per_frame.shape == (F_, 2)

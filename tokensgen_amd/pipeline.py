@@ -171,15 +171,16 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
         Python float per step."""
         if prompt is not None or frames is not None:
             raise NotImplementedError("T5 prompt encoding and the Resampler are upstream of the hot path: pass prompt_embeds / image_embeddings")
-        if prompt_embeds is None or negative_prompt_embeds is None:
-            raise ValueError("prompt_embeds and negative_prompt_embeds are required")
+        do_cfg = guidance_scale > 1.0                                                               # :1012
+        if prompt_embeds is None or (do_cfg and negative_prompt_embeds is None):
+            raise ValueError("prompt_embeds (and, with guidance_scale > 1, negative_prompt_embeds) are required")
         dev = self.device
         self._guidance_scale = guidance_scale
         self._set_vip_scale(video_ipadapter_scale)
         use_vip = image_embeddings is not None
-        nb = 3 if use_separate_guidance else 2
+        nb = (3 if use_separate_guidance else 2) if do_cfg else 1       # without guidance: the prompt alone, the model output is the prediction (:1196-1200, 1260)
         g_img = guidance_scale if guidance_scale_img is None else guidance_scale_img                 # infer_cogvideo_mp_fifo.py:313
-        embeds = torch.cat([negative_prompt_embeds] + [prompt_embeds] * (nb - 1), dim=0).to(dev, BF16)   # :1026-1029 (uncond, cond[, cond])
+        embeds = (torch.cat([negative_prompt_embeds] + [prompt_embeds] * (nb - 1), dim=0) if do_cfg else prompt_embeds).to(dev, BF16)   # :1026-1029
         self.scheduler.set_timesteps(num_inference_steps, device=None)
         ts = self.scheduler.timesteps.tolist()
         nf = (num_frames_per_chunk - 1) // self.vae_scale_factor_temporal + 1
@@ -211,7 +212,9 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
                 # (pipeline_cogvideox_mp_fifo.py:611-646; the zero-video "uncond" tokens are computed there but not used)
                 per_chunk = image_embeddings.shape[1] // num_chunks
                 image_embeddings = torch.cat([image_embeddings] + [image_embeddings[:, [-1]]] * per_chunk, dim=1)
-                if use_separate_guidance:
+                if not do_cfg:
+                    pass                                                                             # :618: no CFG rows are added
+                elif use_separate_guidance:
                     if uncond_image_embeddings is None:
                         raise ValueError("use_separate_guidance with single-row image_embeddings needs uncond_image_embeddings (the tokens of an "
                                          "all-zero video: vae_encode_image(zeros, do_classifier_free_guidance=False))")
@@ -265,7 +268,7 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
             fifo_latents=torch.cat(fifo_latents, dim=1), fifo_old_pred_original_sample=fifo_old, orig_latents=latents.clone(),
             nf_per_chunk=nf, vip_nf_per_chunk=self.resampler.config.num_temporal_queries if use_vip else None,
             num_frames=num_chunks * nf, image_embeddings=image_embeddings, timesteps=self.scheduler.timesteps,
-            num_inference_steps=num_inference_steps, do_classifier_free_guidance=True, use_separate_guidance=bool(use_separate_guidance),
+            num_inference_steps=num_inference_steps, do_classifier_free_guidance=bool(do_cfg), use_separate_guidance=bool(use_separate_guidance),
             use_dynamic_cfg=bool(use_dynamic_cfg),
             prompt_embeds=embeds, image_rotary_emb=rope, vip_image_rotary_grid=grids[0] if use_vip else None,
             vip_condition_rotary_grid=grids[1] if use_vip else None, attention_kwargs=None, guidance_scale=guidance_scale,

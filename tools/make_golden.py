@@ -666,8 +666,9 @@ def gen_fifo_worker():
             return get_3d_rotary_pos_embed_v2(64, grid_t, grid_h, grid_w)
 
     variants = [("separate", True, False, "v_prediction"), ("dynamic", False, True, "v_prediction"), ("separate_dynamic", True, True, "v_prediction"),
-                ("epsilon_static", False, False, "epsilon")]
+                ("epsilon_static", False, False, "epsilon"), ("no_cfg", False, False, "v_prediction"), ("no_cfg_dynamic", False, True, "v_prediction")]
     for name, sep, dyn, ptype in variants:
+        cfg_on = not name.startswith("no_cfg")            # do_classifier_free_guidance=False (:497-498): batch of one, model output = prediction
         for dt in (torch.float32, torch.bfloat16):
             # alphas_cumprod[999] = 0 under zero terminal SNR and epsilon prediction divides by sqrt(alpha) (inf in the reference too): the epsilon
             # tail window stops one position short of t = 999 (its last frame then has t_back = 999: r = inf, d = x0)
@@ -676,7 +677,7 @@ def gen_fifo_worker():
                 m = m.to(dt)
                 sched = CogVideoXDPMScheduler(prediction_type=ptype, rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
                 sched.set_timesteps(T)
-                nb = 3 if sep else 2
+                nb = (3 if sep else 2) if cfg_on else 1
                 pipe = Pipe(m, sched, 6.0)
                 t = torch.tensor(lvl[start:start + nf])
                 prev_t = torch.tensor([(-1 if q <= 6 else lvl[q - 1]) for q in range(start, start + nf)])
@@ -696,9 +697,9 @@ def gen_fifo_worker():
                 qin.put(None)
                 seed = 9000 + len(cases)
                 torch.manual_seed(seed)
-                fifo.fifo_onestep_per_gpu(0, qin, qout, pipe, prompt, rope, T, True, sep, 6.0, 4.0, dyn, None)
+                fifo.fifo_onestep_per_gpu(0, qin, qout, pipe, prompt, rope, T, cfg_on, sep, 6.0, 4.0, dyn, None)
                 (_, _, _, _, _, out_lat, out_x0, _) = qout.get()
-                cases.append(dict(name=name, separate=sep, dynamic=dyn, prediction_type=ptype, dtype=str(dt), start=start, t=t, prev_t=prev_t, next_t=next_t,
+                cases.append(dict(name=name, separate=sep, dynamic=dyn, cfg=cfg_on, prediction_type=ptype, dtype=str(dt), start=start, t=t, prev_t=prev_t, next_t=next_t,
                                   latents=lat, old=old, prompt=prompt, image_embeddings=emb, grid_t=grid_t, grid_h=grid_h, grid_w=grid_w, cond_t=cond_t,
                                   cond_h=cond_h, cond_w=cond_w, rng_seed=seed, guidance_scale=6.0, guidance_scale_img=4.0, out_latents=out_lat.clone(),
                                   out_x0=[x.clone() for x in out_x0]))
