@@ -198,6 +198,56 @@ def test_attention_bwd_without_the_probe_flag_takes_two_launches():
     assert code == -1 and b"status" in lib.tg_last_error_string()
 
 
+def test_attention_bwd_one_kernel_form_after_multi_stream_graph_work_in_a_child_process(golden_dir):
+    """bench.py's default run is window -> VAE (three tile streams + captured HIP graphs) -> training in ONE process, and after that VAE phase the
+    dispatcher no longer puts workgroup b on XCD b % 8 (all 4096 probe workgroups were off it; residue classes still share an XCD).  The probe used to
+    demand the identity and silently sent the training record to the two-launch form.  Child process: tiny tiled VAE decode / encode three times (eager,
+    capture, replay), THEN the first backward call of the process — the device probe must pass, the one-kernel form must run, the gradients must match
+    autograd, and the placement / poll status words must be clean."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("TG_ATTN_BWD_FUSED") == "0" or os.environ.get("TG_ATTN_BWD_V1") == "1":
+        pytest.skip("the one-kernel form is switched off in this run")
+    if os.environ.get("TG_TEST_AFTER_VAE") != "1":
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "after_multi_stream_graph_work", "-x"],
+                           env=dict(os.environ, TG_TEST_AFTER_VAE="1"), capture_output=True, text=True, timeout=600,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+        return
+    from oracle import vae_ref as V
+    from tokensgen_amd import kernels as K
+    from tokensgen_amd.vae import AutoencoderKLCogVideoX
+    assert not K.BwdDeviceState._by_device, "the probe must not have run yet in this process"
+    g = torch.load(os.path.join(golden_dir, "vae_tiny.pt"), weights_only=False)
+    cfg = g["cfg"]
+    vae = AutoencoderKLCogVideoX(block_out_channels=cfg["block_out_channels"], layers_per_block=cfg["layers_per_block"], sample_height=64, sample_width=96,
+                                 device=DEV)
+    vae.load_state_dict(V.make_state_dict(cfg, seed=g["weight_seed"]))
+    vae.enable_tiling(); vae.enable_slicing()
+    gen = torch.Generator().manual_seed(5)
+    z = torch.randn(1, 16, 13, 8, 12, generator=gen).to(DEV, BF)
+    x = (torch.rand(1, 3, 17, 64, 96, generator=gen) * 2 - 1).to(DEV, BF)
+    for _ in range(3):
+        vae.decode(z).sample
+        vae.encode(x).latent_dist.parameters
+    torch.cuda.synchronize()
+    B, H, nq, nk = 1, 8, 1100, 700
+    scale = 0.125
+    fused = _rand(B, nq, 3 * H * 64, seed=41, scale=1.5)
+    q, k, v = fused[:, :, :H * 64], fused[:, :nk, H * 64:2 * H * 64], fused[:, :nk, 2 * H * 64:]
+    gq = _rand(B, nq, H * 64, seed=42)
+    qf, kf, vf = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    o = _sdpa(qf, kf, vf, H, scale)
+    (o * gq.float()).sum().backward()
+    fd = fused.to(DEV)
+    dq, dk, dv = K.attention_bwd(fd[:, :, :H * 64], fd[:, :nk, H * 64:2 * H * 64], fd[:, :nk, 2 * H * 64:], o.detach().to(BF).to(DEV), gq.to(DEV), H, scale)
+    st = K.BwdDeviceState.get(DEV)
+    assert st.one_kernel and st.probe["flagged"] == 0 and st.probe["sums_exact"], st.probe
+    K.attention_bwd_check(DEV)
+    assert _rel(dq, qf.grad) < 5.5e-3 and _rel(dk, kf.grad) < 5.5e-3 and _rel(dv, vf.grad) < 4.5e-3
+
+
 def test_attention_bwd_two_kernel_form_in_a_child_process():
     """TG_ATTN_BWD_FUSED=0: the dK/dV + dQ launches for the shapes the one-kernel form would take (same autograd comparison, same determinism check)."""
     import os

@@ -34,7 +34,7 @@ for name in what:
     K.PROFILE_ON[0] = False
     prof = K.profile_summary()
     flop = {"decode": 3.1e14, "encode": 1.5e14}[name]      # untiled algorithmic count; executed = x1.40
-    top = sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:8]
+    top = sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:int(os.environ.get("TG_BENCH_VAE_TOP", "8"))]
     print(json.dumps({"op": f"vae_{name}", "out_shape": list(out.shape), "seconds": dt, "seconds_with_profiling_events": dt_prof, "clips_per_s": 1 / dt,
                       "algorithmic_TFLOPs": flop / dt / 1e12, "executed_TFLOPs": 1.4 * flop / dt / 1e12, "finite": bool(torch.isfinite(out).all()),
                       "kernel_total_ms": {k: round(v["total_ms"], 1) for k, v in top}, "launches": sum(v["n"] for v in prof.values())}))
