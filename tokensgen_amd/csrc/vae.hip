@@ -1356,8 +1356,8 @@ static int conv_ksplit(long M, int cout, int cout_pad, long nk, int n_cu) {
     if (!on || cout != cout_pad || cout_pad % BN != 0 || cout > 512 || nk < 32) return 1;
     const long tiles = ((M + BM - 1) / BM) * (cout_pad / BN);
     if (tiles >= n_cu) return 1;
-    long ks = (2L * n_cu + tiles - 1) / tiles;
-    if (ks > 8) ks = 8;
+    long ks = (2L * n_cu) / tiles;            // FLOOR: tiles * ks must not exceed the 2 n_cu resident slots — the first version rounded up, and the most common
+    if (ks > 8) ks = 8;                       // shape (88 tiles: 2 x 30 x 45 latent voxels x 512 channels) ran 528 workgroups = one full round + 16 stragglers
     if (ks > nk / 8) ks = nk / 8;
     return ks < 2 ? 1 : (int)ks;
 }

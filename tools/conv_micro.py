@@ -2,7 +2,7 @@
 """The VAE decoder's large 3x3x3 convolution shapes, each in a loop: timing / PMC target for the conv kernels.  The dispatch switches of
 tg_conv3d_cl (TG_CONV_HALO, TG_CONV_W4, ...) select the kernel; same-box A/B = one process per setting.
 usage: conv_micro.py [repeats] [case ...]      cases: c128 (128->128 @ 8x240x360), c256 (256->256 @ 8x120x180), c256_128 (256->128 @ 8x240x360),
-                                                c512_256 (512->256 @ 4x60x90), c256s (256->256 @ 4x60x90)"""
+                                                c512_256 (512->256 @ 4x60x90), c256s (256->256 @ 4x60x90), c512 / c512t3 (512->512 @ 2 / 3 x 30x45)"""
 import json
 import os
 import sys
@@ -16,7 +16,7 @@ from tokensgen_amd import kernels as K  # noqa: E402
 
 DEV, BF = "cuda", torch.bfloat16
 CASES = {"c128": (128, 128, 8, 240, 360), "c256": (256, 256, 8, 120, 180), "c256_128": (256, 128, 8, 240, 360), "c512_256": (512, 256, 4, 60, 90),
-         "c256s": (256, 256, 4, 60, 90)}
+         "c256s": (256, 256, 4, 60, 90), "c512": (512, 512, 2, 30, 45), "c512t3": (512, 512, 3, 30, 45)}
 args = sys.argv[1:]
 n = int(args[0]) if args and args[0].isdigit() else 20
 names = [a for a in args if a in CASES] or list(CASES)

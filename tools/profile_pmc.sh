@@ -8,7 +8,7 @@ out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-vae > $out/bench_under_rocprof.json 2> $out/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-vae --no-train > $out/bench_under_rocprof.json 2> $out/stats.err
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/pmc1 -o pmc -- python $R/bench.py --steps 1 --warmup 0 --layers 4 --no-cpu-baseline --no-vae > /dev/null 2> $out/pmc1.err
 rocprofv3 --pmc WRITE_SIZE SQ_BUSY_CYCLES --output-format csv -d $out/pmc2 -o pmc -- python $R/bench.py --steps 1 --warmup 0 --layers 4 --no-cpu-baseline --no-vae > /dev/null 2> $out/pmc2.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $out/pmc3 -o pmc -- python $R/bench.py --steps 1 --warmup 0 --layers 4 --no-cpu-baseline --no-vae > /dev/null 2> $out/pmc3.err
