@@ -140,6 +140,33 @@ def test_c_abi_exports_every_declared_symbol():
     assert b"N%128" in lib.tg_last_error_string()
 
 
+def test_c_abi_rejects_null_arguments_everywhere():
+    """Error convention of the boundary: EVERY export, called with null pointers and zero sizes, returns a negative code and leaves a
+    message in tg_last_error_string() — it validates before it touches HIP, so this holds on a box without a GPU, and nothing crosses the ABI as a
+    crash.  Run in a child process so that a missing check would show up as a failed test, not as a dead test session."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from tokensgen_amd import lib as L
+lib = L.load()
+bad = []
+for name, argtypes in L.PROTOTYPES.items():
+    if name == "tg_attention_bwd_probe_verdict":      # a predicate (0 / 1), not a launch
+        assert lib.tg_attention_bwd_probe_verdict(None, 0) == 0
+        continue
+    args = [None if (t is C.c_void_p or (isinstance(t, type) and issubclass(t, C._Pointer))) else (0.0 if t is C.c_float else 0) for t in argtypes]
+    rc = getattr(lib, name)(*args)
+    if not (rc < 0 and lib.tg_last_error_string()):
+        bad.append((name, rc))
+print("checked", len(L.PROTOTYPES), "bad", bad)
+assert not bad
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "bad []" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_longvgen_alias_and_vae_host_contract():
     import sys
     from tokensgen_amd import compat
