@@ -188,7 +188,10 @@ def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None
     if sp.get("use_sliding_window_embedding"):
         raise NotImplementedError("use_sliding_window_embedding is not used by the shipped configs")
     if len(getattr(bo, "cache_idx", []) or []):
-        raise NotImplementedError("cache_idx capture is a debugging feature of the reference and is not mirrored")
+        # (the reference itself cannot run this branch: its merge loop indexes a list with a list — `for cid in cache_latents: cache_latents[cid] = ...`,
+        #  cogvideo_sampling_mp_fifo.py:330-331 — and raises TypeError as soon as cache_idx is non-empty)
+        raise NotImplementedError("cache_idx capture is a debugging feature the reference itself cannot complete (TypeError at "
+                                  "cogvideo_sampling_mp_fifo.py:330-331 for any non-empty cache_idx); it is not mirrored")
     num_partitions = sp.get("num_partitions", 4)
     adaptive = sp.get("use_adaptive_padding", True)
     pipe = pipe_list[0]
