@@ -353,16 +353,18 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo2_kernel(ConvParams p) {
         if (tv >= 0) return p.x + (long)tv * frame;
         return p.cache ? p.cache + (long)(tv + p.kt - 1) * frame : p.x;
     };
-    auto dma_halo = [&](int buf, int g, int i) {          // piece i (0..HP-1) of this wave for group g = dt * nc32 + c32
-        const int dt = g / nc32, c32 = g - dt * nc32;
-        const bf16_t* src = hoff[i] >= 0 ? frame_base(dt) + hoff[i] + c32 * 32 : p.zeros + (lane & 7) * 8;
+    // The DMA sources are RUNNING values, advanced by wave-uniform adds: in-kernel stamps (profiles/NOTES.md, round 4) showed the two DMA instructions of
+    // a stage taking 460-830 cycles per wave — not the DMA, but its address arithmetic: stage -> (group, tap) -> (dt, c32) through two integer divisions by a
+    // runtime value, a 64-bit multiply and the frame_base() branches, all on the scalar unit beside the partner wave's MFMA stream.
+    //   hsrc: source of the halo of the group being staged = frame_base(dt) + 32 c32 (one pointer per group, set when the group before it starts)
+    //   wk:   element offset (dt * 9 + tap) * Cin + 32 c32 of the next weight stage to issue; stages follow each other as tap 0..8 within a group, groups as
+    //         c32 = 0..nc32-1 within a temporal tap: +Cin per tap; at a group change +32 - 8 Cin, which is +32 when c32 wraps as well (32 nc32 = Cin)
+    auto dma_halo = [&](int buf, const bf16_t* hsrc, int i) {      // piece i (0..HP-1) of this wave
+        const bf16_t* src = hoff[i] >= 0 ? hsrc + hoff[i] : p.zeros + (lane & 7) * 8;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(sH + buf * H2_HALO_BYTES + (wave * HP + i) * 1024), 16, 0, 0);
     };
-    auto dma_w = [&](int slot3, int st_, int i) {         // weight piece i (< WP) of this wave for stage st_ = g * 9 + tap into ring slot slot3
-        const int g = st_ / 9, tap = st_ - g * 9;
-        const int dt = g / nc32, c32 = g - dt * nc32;
-        const long koff = (long)(dt * 9 + tap) * p.Cin + c32 * 32;
+    auto dma_w = [&](int slot3, long koff, int i) {       // weight piece i (< WP) of this wave for the stage at element offset koff into ring slot slot3
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.w + woffs[i] + koff),
                                          (__attribute__((address_space(3))) void*)(sW + slot3 * H2_W_BYTES + (WP * wave + i) * 1024), 16, 0, 0);
     };
@@ -412,10 +414,17 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo2_kernel(ConvParams p) {
 #define H2_WIMM(kk) std::integral_constant<int, ((kk) % H2_RING) * H2_W_BYTES>{}
 
     // ---- prologue: halo of group 0, weights of stages 0 and 1; A fragments of stage 0, W fragments 0 and 1 ----
+    {
+        const bf16_t* const h0 = frame_base(0);
 #pragma unroll
-    for (int i = 0; i < HP; ++i) dma_halo(0, 0, i);
+        for (int i = 0; i < HP; ++i) dma_halo(0, h0, i);
+    }
 #pragma unroll
-    for (int i = 0; i < WP; ++i) { dma_w(0, 0, i); dma_w(1, 1, i); dma_w(2, 2, i); }
+    for (int i = 0; i < WP; ++i) { dma_w(0, 0, i); dma_w(1, p.Cin, i); dma_w(2, 2L * p.Cin, i); }       // stages 0..2 = taps 0..2 of group 0
+    long wk = 3L * p.Cin;                                   // stage 3: tap 3 of group 0
+    int wc32 = 0;                                           // c32 of the group the next weight stage belongs to
+    int hdt = nc32 > 1 ? 0 : 1, hc32 = nc32 > 1 ? 1 : 0;    // (dt, c32) of group 1: the first group whose halo the stage loop stages
+    const bf16_t* hsrc = p.x;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
@@ -450,12 +459,22 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo2_kernel(ConvParams p) {
             // and the DiT's 256 x 256 GEMM (64 KB per 2048: 1.4 PFLOP/s).  Hence: as few fill bytes per MFMA as the tile allows.
             if (w_iss) {
 #pragma unroll
-                for (int i = 0; i < WP; ++i) dma_w((k + 3) % H2_RING, st + 3, i);
+                for (int i = 0; i < WP; ++i) dma_w((k + 3) % H2_RING, wk, i);
+                constexpr int wtap = (k + 3) % 9;           // tap of the stage just issued (the 36-stage body starts at a group boundary)
+                if constexpr (wtap < 8) wk += p.Cin;
+                else {                                      // next stage: tap 0 of the following group
+                    wk += 32 - (wc32 + 1 == nc32 ? 0 : 8 * p.Cin);
+                    wc32 = wc32 + 1 == nc32 ? 0 : wc32 + 1;
+                }
+            }
+            if constexpr (tap == 0) {                       // this group's stages stage the NEXT group's halo: its source, once
+                if (g + 1 < ngroups) hsrc = frame_base(hdt) + hc32 * 32;
+                if (hc32 + 1 == nc32) { hc32 = 0; ++hdt; } else ++hc32;
             }
             if (h_iss) {
 #pragma unroll
                 for (int i = 0; i < HP; ++i)
-                    if (i >= hfirst && i < hfirst + hcnt) dma_halo((g + 1) & 1, g + 1, i);
+                    if (i >= hfirst && i < hfirst + hcnt) dma_halo((g + 1) & 1, hsrc, i);
             }
             const bool more = st + 1 < nst;
             // 8 blocks of MI MFMAs (one W fragment x the wave's MI voxel fragments).  After the first half of block ni: W fragment ni + WD (of this
