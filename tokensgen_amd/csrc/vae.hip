@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
         const int wo = (int)(m % p.Wo);
         const long q = m / p.Wo;
         vw[i] = wo; vh[i] = (int)(q % p.Ho); vt[i] = (int)(q / p.Ho);
-        srcW[i] = (const char*)(p.w + (long)(n0 + (r < BN ? r : 0)) * Kw + slot * 8);
+        srcW[i] = (const char*)(p.w + (long)(n0 + (r < BN ? r : 0)) * Kw + slot * 8);      // (advanced to the first k-tile of this workgroup's range below)
     }
     const int Hv = p.H * p.up, Wv = p.W * p.up;
     const long frame = (long)p.H * p.W * p.Cin;
@@ -102,24 +102,39 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
     const int ntaps = p.kt * p.kh * p.kw;
     const int nk = ntaps * cpt;
     const char* srcA[4];
-    auto set_tap = [&](int tap) {
-        const int dw = tap % p.kw, q = tap / p.kw;
-        const int dh = q % p.kh, dt = q / p.kh;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) srcA[i] = tap_src(i, dt, dh, dw);
-    };
     const int kt_begin = (int)((long)nk * split / p.ksplit), kt_end = (int)((long)nk * (split + 1) / p.ksplit);
-    auto stage = [&](int buf, int kt_) {
-        const int tap = kt_ / cpt, cc = kt_ - tap * cpt;
-        if (cc == 0 || kt_ == kt_begin) set_tap(tap);
+    // Staging cursor: stages are issued in order kt_begin, kt_begin + 1, ..., so (tap -> dt, dh, dw; channel block cc) advance by increments.  The
+    // first version divided per stage (kt / cpt, and tap % kw, / kw, % kh, / kh at every tap change): runtime integer divisions on the scalar unit,
+    // which the halo kernel's stamps priced at hundreds of cycles per stage — against 512 cycles of MFMA per stage and wave here.
+    int s_cc, s_dw, s_dh, s_dt;
+    {
+        const int tap0 = kt_begin / cpt;
+        s_cc = kt_begin - tap0 * cpt;
+        s_dw = tap0 % p.kw;
+        const int q = tap0 / p.kw;
+        s_dh = q % p.kh; s_dt = q / p.kh;
+    }
+    bool s_first = true;
+    auto stage = [&](int buf) {                      // stages the cursor's k-tile into buffer buf and advances the cursor
+        if (s_cc == 0 || s_first) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) srcA[i] = tap_src(i, s_dt, s_dh, s_dw);
+            s_first = false;
+        }
         char* base = smem + buf * STAGE_BYTES + wave * (32 * 128);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + (long)cc * (BK * 2)),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + s_cc * (BK * 2)),
                                              (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
-            if (wave * 32 + i * 8 < BN)       // wave-uniform: the W tile has BN rows
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + (long)kt_ * (BK * 2)),
+            if (wave * 32 + i * 8 < BN) {     // wave-uniform: the W tile has BN rows
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcW[i],
                                                  (__attribute__((address_space(3))) void*)(base + TILE_BYTES + i * 1024), 16, 0, 0);
+                srcW[i] += BK * 2;
+            }
+        }
+        if (++s_cc == cpt) {
+            s_cc = 0;
+            if (++s_dw == p.kw) { s_dw = 0; if (++s_dh == p.kh) { s_dh = 0; ++s_dt; } }
         }
     };
 
@@ -145,12 +160,14 @@ __global__ __launch_bounds__(256) void conv3d_cl_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    stage(0, kt_begin);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) srcW[i] += (long)kt_begin * (BK * 2);
+    stage(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt_ = kt_begin; kt_ < kt_end; ++kt_) {
         const int cur = (kt_ - kt_begin) & 1;
-        if (kt_ + 1 < kt_end) stage(cur ^ 1, kt_ + 1);
+        if (kt_ + 1 < kt_end) stage(cur ^ 1);
         const char* tA = smem + cur * STAGE_BYTES;
         const char* tW = tA + TILE_BYTES;
 #pragma unroll
@@ -738,9 +755,10 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
     const int cpt = p.Cin / 64;                      // stages per tap
     const int nk = p.kt * p.kh * p.kw * cpt;
     const char* srcA[NA];
-    auto set_tap = [&](int tap) {
-        const int dw = tap % p.kw, q = tap / p.kw;
-        const int dh = q % p.kh, dt = q / p.kh;
+    int t_dw = 0, t_dh = 0, t_dt = 0;                // (dt, dh, dw) of the tap set_tap is called for next: taps are visited in order 0, 1, 2, ...
+    auto set_tap = [&](int) {
+        const int dw = t_dw, dh = t_dh, dt = t_dt;     // (no tap % kw, / kw, % kh, / kh: runtime divisions on the scalar unit at every tap change)
+        if (++t_dw == p.kw) { t_dw = 0; if (++t_dh == p.kh) { t_dh = 0; ++t_dt; } }
         if (plain) {
             // in-window frames: x + cen + doff.  Frames before the window (to + dt < kt-1): the cache tensor holds frames -(kt-1)..-1 at
             // indices 0.., i.e. cache + cen + doff + (kt-1)*frame; without a cache frame 0 is replicated: x + cen + doff - tv*frame
