@@ -392,9 +392,14 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             const int na = max(1, min(ntiles - 1, (ntiles + nt2 + 1) >> 1));
             if (half == 0) te = na; else tb = na;
         }
+        // running source pointer (tiles are issued in order tb, tb + 1, ...): only the last tile of the segment can hold rows beyond nk and takes the clamped form
+        const bf16_t* kcur = kbase + (long)min(tb * KVBLK + drow, S.nk - 1) * S.k_ld;
+        const bf16_t* const klast = kbase + (long)min((ntiles - 1) * KVBLK + drow, S.nk - 1) * S.k_ld;
+        const long kstep = (long)KVBLK * S.k_ld;
         auto dmaK = [&](int t) {      // K(t) -> K buffer t&1
-            const int key = min(t * KVBLK + drow, S.nk - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (long)key * S.k_ld),
+            const bf16_t* const ksrc = t == ntiles - 1 ? klast : kcur;
+            kcur += kstep;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ksrc,
                                              (__attribute__((address_space(3))) void*)(smem + (t & 1) * TILE_B + wave * 1024), 16, 0, 0);
         };
         auto dmaV = [&](int t) {      // V^T(t) -> V buffer t&1
