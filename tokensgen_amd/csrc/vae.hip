@@ -613,6 +613,140 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo2_kernel(ConvParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_out of the decoder (Cin = 128 -> Cout = 3, 3x3x3, full resolution).  On the 128 x 16 GEMM-shaped tile every (tap, 64-channel chunk) fetched a fresh
+// A tile through the L2 -> LDS fill path: 6.9 KB per output voxel for 10 KFLOP of useful work — the launch was fill-bound (17.7 ms per decode, and under the
+// three tile streams it took the fill path from the other tiles' convolutions: skipping it moved the decode's wall time by 17 ms).  Here the halo staging of
+// conv3d_halo2_kernel (a 16 x 32 patch per workgroup, the 18 x 34 halo once per (temporal tap, 32-channel chunk), all nine taps read it shifted) feeds ONE
+// 16-wide MFMA column: the few real weight rows (Cout <= 4: 27 KB) stay resident in LDS for the whole workgroup, one more all-zero row serves the lanes of
+// the unused output channels, and no weight DMA is left in the loop.  Per (group, tap) a wave reads 4 voxel fragments + 1 weight fragment and issues 4 MFMAs,
+// the reads of tap + 1 in flight behind the MFMAs of tap; one barrier per GROUP.  LDS-read-bound (6.9 KB per voxel from LDS instead of from L2).
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int KT>
+__global__ __launch_bounds__(512) void conv3d_halo_narrow_kernel(ConvParams p) {
+    constexpr int NW = 8, HP = 48 / NW, RW = H2_PH / NW, MI = 2 * RW;
+    constexpr int NC32 = CIN / 32, NG = KT * NC32;
+    constexpr int WROW = KT * 9 * CIN * 2 + 64;           // LDS stride of a weight row: rows 0, 1, 2, (zero row) start 64 B apart mod 256 -> 16 lanes x 16 B = all banks once
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sH = smem;
+    char* const sW = smem + 2 * H2_HALO_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (p.Wo + H2_PW - 1) / H2_PW, tiles_y = (p.Ho + H2_PH - 1) / H2_PH;
+    const int tile = xcd_remap(blockIdx.x, p.To * tiles_y * tiles_x);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tf = tile / (tiles_x * tiles_y);
+    const int x0 = tx * H2_PW, y0 = ty * H2_PH;
+    const long frame = (long)p.H * p.W * CIN;
+
+    // ---- weights: rows [0, cout) of the packed [cout_pad][KT * 9][CIN] tensor as they are, row `cout` = zeros ----
+    {
+        constexpr int CH = KT * 9 * CIN * 2 / 16;         // 16-byte chunks per row
+        for (int i = tid; i < (p.cout + 1) * CH; i += 64 * NW) {
+            const int r = i / CH, c = i - r * CH;
+            const uint4 v = r < p.cout ? *(const uint4*)(p.w + (long)r * (KT * 9 * CIN) + c * 8) : uint4{0u, 0u, 0u, 0u};
+            *(uint4*)(sW + r * WROW + c * 16) = v;
+        }
+    }
+    int hoff[HP];
+#pragma unroll
+    for (int i = 0; i < HP; ++i) {
+        const int o = (wave * HP + i) * 1024 + lane * 16;
+        const int hr = o / H2_STRIDE, slot = (o - hr * H2_STRIDE) >> 4;
+        const int hy = hr / H2_LW, hx = hr - hy * H2_LW;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        hoff[i] = (slot < 4 && hr < H2_ROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? (y * p.W + x) * CIN + slot * 8 : -1;
+    }
+    auto frame_base = [&](int dt) -> const bf16_t* {
+        const int tv = tf + dt - (KT - 1);
+        if (tv >= 0) return p.x + (long)tv * frame;
+        return p.cache ? p.cache + (long)(tv + KT - 1) * frame : p.x;
+    };
+    auto dma_halo = [&](int buf, const bf16_t* hsrc, int i) {
+        const bf16_t* src = hoff[i] >= 0 ? hsrc + hoff[i] : p.zeros + (lane & 7) * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sH + buf * H2_HALO_BYTES + (wave * HP + i) * 1024), 16, 0, 0);
+    };
+    uint32_t abase[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+        abase[mi] = (uint32_t)(uintptr_t)sH + (uint32_t)(((RW * wave + (mi >> 1)) * H2_LW + (mi & 1) * 16 + (lane & 15)) * H2_STRIDE + (lane >> 4) * 16);
+    const uint32_t wbase = (uint32_t)(uintptr_t)sW + (uint32_t)(min(lane & 15, p.cout) * WROW + (lane >> 4) * 16);
+
+    f32x4 acc[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[2][MI], fw[2];
+    auto reads = [&](auto setc, auto gc, auto tapc) {
+        constexpr int set = decltype(setc)::value, g = decltype(gc)::value, tap = decltype(tapc)::value;
+        constexpr int aimm = (g & 1) * H2_HALO_BYTES + ((tap / 3) * H2_LW + tap % 3) * H2_STRIDE;
+        constexpr int wimm = (((g / NC32) * 9 + tap) * CIN + (g % NC32) * 32) * 2;
+        static_assert(aimm < 65536 && wimm < 65536, "ds_read offset field");
+        {
+            bf16x8& d = fw[set];
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(wbase), "n"(wimm));
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            bf16x8& d = fa[set][mi];
+            const uint32_t a = abase[mi];
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(aimm));
+        }
+    };
+
+    {
+        const bf16_t* const h0 = frame_base(0);
+#pragma unroll
+        for (int i = 0; i < HP; ++i) dma_halo(0, h0, i);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    static_for<0, NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g + 1 < NG) {                      // the next group's halo goes out now and has the whole group to land
+            const bf16_t* const hsrc = frame_base((g + 1) / NC32) + ((g + 1) % NC32) * 32;
+#pragma unroll
+            for (int i = 0; i < HP; ++i) dma_halo((g + 1) & 1, hsrc, i);
+        }
+        reads(std::integral_constant<int, 0>{}, gc, std::integral_constant<int, 0>{});
+        static_for<0, 9>([&](auto tc) {
+            constexpr int tap = decltype(tc)::value, cur = tap & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (tap < 8) reads(std::integral_constant<int, cur ^ 1>{}, gc, std::integral_constant<int, (tap < 8 ? tap + 1 : 8)>{});
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                bf16x8 &w0 = fw[cur], &a0 = fa[cur][0], &a1 = fa[cur][1], &a2 = fa[cur][2], &a3 = fa[cur][3];
+                static_assert(MI == 4, "the wait below names four voxel fragments");
+                if constexpr (tap < 8) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(w0), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));   // LDS returns in order: this tap's five
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[cur], fa[cur][mi], acc[mi], 0, 0, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g + 1 < NG) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+
+    // ---- epilogue: lanes 0..15 hold output channels 0..3 (acc element r) of voxel (lane & 15) of each fragment ----
+    if (lane < 16) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int y = y0 + RW * wave + (mi >> 1), x = x0 + (mi & 1) * 16 + lane;
+            if (y >= p.Ho || x >= p.Wo) continue;
+            bf16_t* dst = p.y + (((long)tf * p.Ho + y) * p.Wo + x) * p.ldy;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < p.cout) dst[e] = f32_to_bf16(acc[mi][e] + (p.bias ? bf16_to_f32(p.bias[e]) : 0.f));
+        }
+    }
+}
+
 // Split-K epilogue: sum the ksplit fp32 partial tensors in a fixed order, then exactly what conv3d_cl_kernel's own epilogue does (bias, the
 // reference's bf16 rounding before the residual add, bf16 store, per-128-voxel-tile GroupNorm sums of the stored values).  One workgroup per
 // (128-voxel tile, 128-channel slab) — a slab holds whole GroupNorm groups (cout / 32 <= 16 channels each) — so a 30 x 45 latent tile's 512-channel
@@ -1418,6 +1552,26 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
     TG_REQUIRE(!gn_partial || (cout == cout_pad && cout % BN == 0 && (cout / GN_GROUPS) % 4 == 0), TG_ERR_SHAPE,
                "tg_conv3d_cl: fused GroupNorm sums need cout in {128, 256, 512, ...} (cout=%d)", cout);
     const long M = (long)To * Ho * Wo;
+    static const int halo_on = [] { const char* e = getenv("TG_CONV_HALO"); return e ? atoi(e) : 1; }();   // 0 never, 1 (default) at launch scale, 2 whenever legal (tests)
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    if (cout_pad % BN != 0 && halo_on && cout <= 4 && Cin == 128 && kt == 3 && kh == 3 && kw == 3 && pad == 1 && stride == 1 && up == 1 && !t_map && !residual &&
+        To == T && Ho == H && Wo == W && (long)(T + 2) * H * W * Cin < (1L << 31)) {
+        // the decoder's conv_out: halo-tiled, weights resident in LDS (17.7 -> 3 ms per decode against the 128 x 16 GEMM-shaped tile below)
+        const long h2tiles = (long)To * ((Ho + H2_PH - 1) / H2_PH) * ((Wo + H2_PW - 1) / H2_PW);
+        if ((halo_on == 2 || h2tiles >= n_cu) && h2tiles < (1L << 31)) {
+            const int lds = 2 * H2_HALO_BYTES + (cout + 1) * (27 * 128 * 2 + 64);
+            static bool attrn = false;
+            if (!attrn) { (void)hipFuncSetAttribute((const void*)conv3d_halo_narrow_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * H2_HALO_BYTES + 5 * (27 * 128 * 2 + 64)); attrn = true; }
+            hipLaunchKernelGGL((conv3d_halo_narrow_kernel<128, 3>), dim3((unsigned)h2tiles), dim3(512), lds, stream, p);
+            TG_LAUNCH_CHECK("tg_conv3d_cl(halo narrow)");
+            return TG_OK;
+        }
+    }
     if (cout_pad % BN != 0) {          // narrow output (conv_out): 128 voxels x 16 channels per workgroup
         const long tiles16 = ((M + BM - 1) / BM) * (cout_pad / 16);
         TG_REQUIRE(tiles16 < (1L << 31), TG_ERR_SHAPE, "tg_conv3d_cl: too many tiles");
@@ -1432,17 +1586,10 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
     // 4-wave kernel: 256x256 tiles need enough of them to fill the chip (>= 2 per CU; the 512-channel layers of the VAE have 128 and stay on
     // the 128x128 kernel: measured 161 vs 142 ms there, 226 vs 248 ms on the 256-channel layers).  TG_CONV_W4=0: never, 2: whenever legal
     static const int w4 = [] { const char* e = getenv("TG_CONV_W4"); return e ? atoi(e) : 1; }();
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    }
     // Cout = 128, 3x3 spatial taps, stride 1, no upsampling: the halo-tiled kernel.  Against the GEMM-shaped kernels on the 8 x 240 x 360 layers:
     // 128 -> 128: 0.70 vs 0.74 ms per launch; per clip 64 -> 128 (encoder conv_in) 13.3 vs 17.5 ms, 256 -> 128 45.6 vs 51.2 ms.  Why not more:
     // see the stage loop's comment (the fill does not overlap with the issuing wave's MFMAs).
     // TG_CONV_HALO: 0 never, 1 (default) at launch scale, 2 whenever legal (tests).
-    static const int halo_on = [] { const char* e = getenv("TG_CONV_HALO"); return e ? atoi(e) : 1; }();
     {
         const long h2tiles = (long)To * ((Ho + H2_PH - 1) / H2_PH) * ((Wo + H2_PW - 1) / H2_PW);
         const long rows128 = (M + BM - 1) / BM;
