@@ -415,7 +415,10 @@ int tg_pca_lowrank_filter(const void* x, long ldx, const float* comp, const floa
  * (0,1,0,1) zero pad implied).  w is repacked [Cout_pad][kt*kh*kw][Cin] (Cout_pad % 128 == 0, or Cout_pad in {16, 32, ..., 112} for the
  * narrow output layers — conv_out: 3 / 32 channels — which run 128 x 16 tiles); only columns < cout
  * are stored (row stride ldy).  residual (optional, same layout as y) is added in the epilogue (ResnetBlock3D :309).
- * zeros: >= 2*Cin + 128 bytes of device zeros (source of out-of-range taps).  Cin % 64 == 0.
+ * zeros: >= 2*Cin + 128 bytes of device zeros (source of out-of-range taps).  Cin % 64 == 0, with one exception:
+ * Cin == 8 is the encoder's input convolution (CogVideoXEncoder3D.conv_in, :708-712: 3 -> 128 channels, 3x3x3, stride 1): x and cache carry 8 channels per
+ * voxel (3 used, the rest zero), w is packed [128][96] with reduction index k = tap * 3 + channel (81 real entries, the rest zero), cout = cout_pad = 128.
+ * The decoder's conv_out (Cin = 128 -> cout <= 4, 3x3x3) takes a halo-tiled kernel with LDS-resident weights at launch scale; same arguments as any narrow layer.
  * gn_partial (optional, tg_conv3d_gn_partial_floats(To,Ho,Wo) floats; needs cout % 128 == 0): per 128-voxel tile row the sums and
  * sums of squares, per GroupNorm(32) group, of the bf16 values this launch stores — summed in a fixed order — so that the
  * GroupNorm / SpatialNorm that reads y next needs no statistics pass of its own: tg_groupnorm_finalize turns them into

@@ -747,6 +747,142 @@ __global__ __launch_bounds__(512) void conv3d_halo_narrow_kernel(ConvParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_in of the encoder (3 -> 128 channels, 3x3x3, full resolution).  With the input padded to the 64-channel granule of the LDS-DMA loaders the layer ran
+// 54 stages of K = 32 for 81 real products per output channel (21x the MACs, 16x the input bytes).  Here the input is channels-last with EIGHT channels
+// (16 B per voxel, 3 used), the reduction index is k = tap * 3 + channel (81 -> 96 = three MFMA k-steps, weights packed [128][96] by the host), and a
+// workgroup's 16 x 32 patch needs its three 18 x 34 input halos (29 KB) exactly once: the A fragments are gathered from them with 2-byte LDS reads through
+// a per-lane table of 24 offsets, the 24 KB of weights sit in LDS, 96 MFMAs per wave.  The kernel is bound by its 256 B per voxel of output.
+// Epilogue (bias, bf16 store, GroupNorm sums per patch) as in conv3d_halo2_kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int CI_WROW = 208;                                   // LDS stride of a weight row: 96 k x 2 B + 16
+constexpr int CI_HALO = 3 * H2_ROWS * 16;                      // three frames x 612 voxels x 8 channels
+constexpr int CI_LDS = CI_HALO + 128 * CI_WROW;
+
+__global__ __launch_bounds__(512) void conv3d_in_kernel(ConvParams p) {
+    constexpr int NW = 8, RW = H2_PH / NW, MI = 2 * RW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sH = smem;
+    char* const sW = smem + CI_HALO;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (p.Wo + H2_PW - 1) / H2_PW, tiles_y = (p.Ho + H2_PH - 1) / H2_PH;
+    const int ntiles = p.To * tiles_y * tiles_x;
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tf = tile / (tiles_x * tiles_y);
+    const int x0 = tx * H2_PW, y0 = ty * H2_PH;
+    const long frame = (long)p.H * p.W * 8;
+
+    for (int i = tid; i < 128 * 12; i += 64 * NW) {            // weights [128][96]: 12 chunks of 16 B per row
+        const int r = i / 12, c = i - r * 12;
+        *(uint4*)(sW + r * CI_WROW + c * 16) = *(const uint4*)(p.w + r * 96 + c * 8);
+    }
+    for (int i = tid; i < 3 * H2_ROWS; i += 64 * NW) {         // halos of frames tf - 2, tf - 1, tf (cache / frame 0 replicated before the window)
+        const int dt = i / H2_ROWS, hr = i - dt * H2_ROWS;
+        const int hy = hr / H2_LW, hx = hr - hy * H2_LW;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        uint4 v{0u, 0u, 0u, 0u};
+        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+            const int tv = tf + dt - 2;
+            const bf16_t* base = tv >= 0 ? p.x + (long)tv * frame : (p.cache ? p.cache + (long)(tv + 2) * frame : p.x);
+            v = *(const uint4*)(base + ((long)y * p.W + x) * 8);
+        }
+        *(uint4*)(sH + i * 16) = v;
+    }
+    // per-lane gather table: element j of k-step ks is k = 32 ks + 8 (lane >> 4) + j = tap * 3 + channel; k >= 81 reads a zero (channel 3 of the lane's own voxel)
+    int off[3][8];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ks * 32 + (lane >> 4) * 8 + j;
+            const int tap = k / 3, ci = k - tap * 3;
+            const int dt = tap / 9, dh = (tap - dt * 9) / 3, dw = tap % 3;
+            off[ks][j] = k < 81 ? ((dt * (H2_PH + 2) + dh) * H2_LW + dw) * 16 + ci * 2 : 6;
+        }
+    __syncthreads();
+
+    f32x4 acc[8][MI];
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        bf16x8 fa[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const char* vb = sH + ((RW * wave + (mi >> 1)) * H2_LW + (mi & 1) * 16 + (lane & 15)) * 16;
+            uint32_t u[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                u[j] = (uint32_t)*(const uint16_t*)(vb + off[ks][2 * j]) | ((uint32_t)*(const uint16_t*)(vb + off[ks][2 * j + 1]) << 16);
+            const uint4 q{u[0], u[1], u[2], u[3]};
+            fa[mi] = __builtin_bit_cast(bf16x8, q);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+            const bf16x8 fw = *(const bf16x8*)(sW + (ni * 16 + (lane & 15)) * CI_WROW + ks * 64 + (lane >> 4) * 16);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fa[mi], acc[ni][mi], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue (conv3d_halo2_kernel's, one 128-channel slab): bias, bf16 store, GroupNorm sums per channel quad ----
+    float gs[8], gq[8];
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) gs[ni] = gq[ni] = 0.f;
+    uint2 bq[8];
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) bq[ni] = p.bias ? *(const uint2*)(p.bias + ni * 16 + (lane >> 4) * 4) : uint2{0u, 0u};
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int y = y0 + RW * wave + (mi >> 1), x = x0 + (mi & 1) * 16 + (lane & 15);
+        if (y >= p.Ho || x >= p.Wo) continue;
+        const long m = ((long)tf * p.Ho + y) * p.Wo + x;
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+            const int n = ni * 16 + (lane >> 4) * 4;
+            uint2 o;
+            o.x = pack_bf16x2(acc[ni][mi][0] + bf16lo_to_f32(bq[ni].x), acc[ni][mi][1] + bf16hi_to_f32(bq[ni].x));
+            o.y = pack_bf16x2(acc[ni][mi][2] + bf16lo_to_f32(bq[ni].y), acc[ni][mi][3] + bf16hi_to_f32(bq[ni].y));
+            *(uint2*)(p.y + m * p.ldy + n) = o;
+            const float r0 = bf16lo_to_f32(o.x), r1 = bf16hi_to_f32(o.x), r2 = bf16lo_to_f32(o.y), r3 = bf16hi_to_f32(o.y);
+            gs[ni] += (r0 + r1) + (r2 + r3);
+            gq[ni] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+        }
+    }
+    if (p.gn_partial) {
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+#pragma unroll
+            for (int o_ = 1; o_ < 16; o_ <<= 1) {
+                gs[ni] += __shfl_xor(gs[ni], o_, 64);
+                gq[ni] += __shfl_xor(gq[ni], o_, 64);
+            }
+        }
+        __syncthreads();                                   // every wave is past its LDS reads
+        float* red = (float*)smem;
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) {
+                red[(wave * 32 + ni * 4 + (lane >> 4)) * 2 + 0] = gs[ni];
+                red[(wave * 32 + ni * 4 + (lane >> 4)) * 2 + 1] = gq[ni];
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {                                    // one channel quad per GroupNorm(32) group at 128 channels; fixed order over the waves
+            const int stat = tid >> 5, gl = tid & 31;
+            float a = 0.f;
+            for (int w_ = 0; w_ < NW; ++w_) a += red[(w_ * 32 + gl) * 2 + stat];
+            const long rows = ((long)p.To * p.Ho * p.Wo + BM - 1) / BM;
+            const int col = stat * 32 + gl;
+            p.gn_partial[(long)tile * 64 + col] = a;
+            for (long r = (long)tile + ntiles; r < rows; r += ntiles) p.gn_partial[r * 64 + col] = 0.f;
+        }
+    }
+}
+
 // Split-K epilogue: sum the ksplit fp32 partial tensors in a fixed order, then exactly what conv3d_cl_kernel's own epilogue does (bias, the
 // reference's bf16 rounding before the residual add, bf16 store, per-128-voxel-tile GroupNorm sums of the stored values).  One workgroup per
 // (128-voxel tile, 128-channel slab) — a slab holds whole GroupNorm groups (cout / 32 <= 16 channels each) — so a 30 x 45 latent tile's 512-channel
@@ -1541,6 +1677,20 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
                             float* splitk_ws, hipStream_t stream) {
     TG_REQUIRE(x && w && y && zeros, TG_ERR_ARG, "tg_conv3d_cl: null pointer");
     TG_REQUIRE(T > 0 && H > 0 && W > 0 && To > 0 && Ho > 0 && Wo > 0, TG_ERR_SHAPE, "tg_conv3d_cl: bad spatial shape");
+    if (Cin == 8) {                    // the encoder's conv_in: 8-channel input (3 used), weights packed [128][96] with k = tap * 3 + channel
+        TG_REQUIRE(cout == 128 && cout_pad == 128 && kt == 3 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && up == 1 && !t_map && !residual && To == T &&
+                   Ho == H && Wo == W, TG_ERR_SHAPE, "tg_conv3d_cl: Cin = 8 is the 3x3x3, stride-1, 128-output-channel input convolution only");
+        TG_REQUIRE(tg_aligned16(x) && tg_aligned16(w) && (!cache || tg_aligned16(cache)) && (((uintptr_t)y) & 7) == 0 && ldy % 4 == 0, TG_ERR_ALIGN,
+                   "tg_conv3d_cl: alignment");
+        const long tiles_in = (long)To * ((Ho + H2_PH - 1) / H2_PH) * ((Wo + H2_PW - 1) / H2_PW), rows_in = ((long)To * Ho * Wo + BM - 1) / BM;
+        TG_REQUIRE(tiles_in < (1L << 31) && (long)(T + 2) * H * W * 8 < (1L << 31), TG_ERR_SHAPE, "tg_conv3d_cl: too many tiles");
+        TG_REQUIRE(!gn_partial || rows_in <= 4 * tiles_in, TG_ERR_SHAPE, "tg_conv3d_cl: GroupNorm sums need <= 4 rows of 128 voxels per 16 x 32 patch");
+        ConvParams pi{(const bf16_t*)x, T, H, W, Cin, (const bf16_t*)cache, (const bf16_t*)w, (const bf16_t*)bias, cout, cout_pad, kt, kh, kw,
+                      stride, pad, up, nullptr, nullptr, (bf16_t*)y, ldy, To, Ho, Wo, (const bf16_t*)zeros, gn_partial, 1, nullptr};
+        hipLaunchKernelGGL(conv3d_in_kernel, dim3((unsigned)tiles_in), dim3(512), CI_LDS, stream, pi);
+        TG_LAUNCH_CHECK("tg_conv3d_cl(in)");
+        return TG_OK;
+    }
     TG_REQUIRE(Cin % BK == 0 && (cout_pad % BN == 0 || (cout_pad < BN && cout_pad % 16 == 0)) && cout > 0 && cout <= cout_pad, TG_ERR_SHAPE,
                "tg_conv3d_cl: need Cin%%64==0 and cout_pad%%128==0 (or cout_pad in {16, 32, ..., 112}) (Cin=%d cout=%d cout_pad=%d)", Cin, cout, cout_pad);
     TG_REQUIRE(kt >= 1 && kt <= 3 && kh >= 1 && kh <= 3 && kw >= 1 && kw <= 3 && (stride == 1 || stride == 2) && (up == 1 || up == 2) &&

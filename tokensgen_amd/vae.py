@@ -118,6 +118,11 @@ class AutoencoderKLCogVideoX:
                 taps = v.shape[2:]
                 if all(t == 1 for t in taps) and ci == 16 and (k.endswith("conv_y.conv.weight") or k.endswith("conv_b.conv.weight")):
                     continue                                                               # SpatialNorm convs: fused below
+                if k == "encoder.conv_in.conv.weight" and ci == 3 and co == 128 and tuple(taps) == (3, 3, 3):
+                    # the encoder's input convolution: reduction index k = tap * 3 + channel (81 -> 96), input tiles carry 8 channels (csrc/vae.hip conv3d_in_kernel)
+                    w = torch.zeros(co, 96, dtype=BF16, device=self.device)
+                    w[:, :81] = v.reshape(co, ci, 27).permute(0, 2, 1).reshape(co, 81)
+                    self._packed[k + ".k96"] = w.contiguous()          # beside the general packing: tiles too small for the patch kernel take that
                 cin_p = _pad_to(ci, 64)
                 cout_p = _pad_to(co, 16) if co <= 32 else _pad_to(co, 128)     # conv_out (3 / 32 channels): the narrow 128 x 16 tile
                 w = torch.zeros(cout_p, int(np.prod(taps)), cin_p, dtype=BF16, device=self.device)
@@ -267,12 +272,12 @@ class AutoencoderKLCogVideoX:
         return self
 
     # ---- building blocks -----------------------------------------------------------------------------------
-    def _conv(self, name, x, cache, residual=None):
+    def _conv(self, name, x, cache, residual=None, packed=None):
         """CogVideoXCausalConv3d (autoencoder_kl_cogvideox.py:120-145): the carried cache is read in place by the kernel."""
         w = self._sd[name + ".conv.weight"]
         co, kt = w.shape[0], w.shape[2]
         prev = cache.get(name) if kt > 1 else None
-        y = K.conv3d_cl(x, self._packed[name + ".conv.weight"], self._sd[name + ".conv.bias"], co, kt, w.shape[3], w.shape[4], cache=prev,
+        y = K.conv3d_cl(x, self._packed[packed or name + ".conv.weight"], self._sd[name + ".conv.bias"], co, kt, w.shape[3], w.shape[4], cache=prev,
                         residual=residual, gn_stats_eps=self.config.norm_eps)    # the next norm's statistics come with y
         if kt > 1:
             need = kt - 1
@@ -341,10 +346,10 @@ class AutoencoderKLCogVideoX:
                            out_dims=(T, (H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1), gn_stats_eps=self.config.norm_eps)
 
     def _encoder(self, x_cl, cache):
-        """CogVideoXEncoder3D.forward (:708-742) on a channels-last tile [T,H,W,64(3 used)] -> [T',H/8,W/8,32]."""
+        """CogVideoXEncoder3D.forward (:708-742) on a channels-last tile [T,H,W,8 or 64 (3 used)] -> [T',H/8,W/8,32]."""
         c = self.config
         nb = len(c.block_out_channels)
-        h = self._conv("encoder.conv_in", x_cl, cache)
+        h = self._conv("encoder.conv_in", x_cl, cache, packed="encoder.conv_in.conv.weight.k96" if x_cl.shape[-1] == 8 else None)
         for i in range(nb):
             for j in range(c.layers_per_block):
                 h = self._resnet(f"encoder.down_blocks.{i}.resnets.{j}", h, None, cache)
@@ -396,7 +401,9 @@ class AutoencoderKLCogVideoX:
                 z2 = z64.view(-1, 64)
                 y = self._decoder(z64, (z2, (b - a, Hc, Wc), self._spatialnorm_tables(z2)), cache)
             else:
-                y = self._encoder(K.ncdhw_to_cl(src, a, b - a, i, Hc, j, Wc, 64), cache)
+                # 8-channel input + the k = tap * 3 + channel kernel when every 16 x 32 patch owns a row (128 voxels) of the GroupNorm partial buffer
+                in8 = os.environ.get("TG_VAE_IN8", "1") != "0" and "encoder.conv_in.conv.weight.k96" in self._packed and -(-Hc // 16) * -(-Wc // 32) * 128 <= Hc * Wc     # (per frame: the same for every batch of the tile)
+                y = self._encoder(K.ncdhw_to_cl(src, a, b - a, i, Hc, j, Wc, 8 if in8 else 64), cache)
             outs.append(y)
         To = sum(o.shape[0] for o in outs)
         Ho, Wo, Co = outs[0].shape[1:]

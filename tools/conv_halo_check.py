@@ -96,6 +96,38 @@ for T, H, W, co in [(3, 19, 45, 3), (2, 16, 32, 3), (1, 33, 70, 4), (2, 9, 33, 1
     print(key, f"rel {e1:.2e} {e2:.2e} repeatable {torch.equal(y2, y2b)}")
     assert max(e1, e2) < 5e-3 and torch.equal(y2, y2b), key
     res[key] = (y1.cpu(), y2.cpu())
+# the encoder's conv_in (3 -> 128) on the 8-channel-input kernel (k = tap * 3 + channel, weights [128][96]): against the fp32 oracle, its GroupNorm sums against a
+# statistics launch, run-to-run bitwise
+for T, H, W in [(3, 19, 45), (2, 16, 32), (1, 33, 70), (4, 48, 40)]:
+    co, ci = 128, 3
+    w = r(co, ci, 3, 3, 3, seed=21, scale=0.2)
+    b = r(co, seed=22)
+    x = r(1, ci, T + 2, H, W, seed=23)
+    sd = {"c.conv.weight": w.float(), "c.conv.bias": b.float()}
+
+    def cl8(t):
+        o = torch.zeros(t.shape[2], H, W, 8, dtype=BF)
+        o[..., :3] = t[0].permute(1, 2, 3, 0)
+        return o.to(DEV)
+    w96 = torch.zeros(co, 96, dtype=BF)
+    w96[:, :81] = w.reshape(co, ci, 27).permute(0, 2, 1).reshape(co, 81)
+    w96 = w96.to(DEV)
+    x1, x2 = x[:, :, :2], x[:, :, 2:]
+    cache = V.ConvCache()
+    ref1 = V.causal_conv3d(sd, "c", x1.float(), cache)
+    ref2 = V.causal_conv3d(sd, "c", x2.float(), cache)
+    y1 = K.conv3d_cl(cl8(x1), w96, b.to(DEV), co, 3, 3, 3, gn_stats_eps=1e-6)
+    y2 = K.conv3d_cl(cl8(x2), w96, b.to(DEV), co, 3, 3, 3, cache=cl8(x1)[-2:].contiguous(), gn_stats_eps=1e-6)
+    y2b = K.conv3d_cl(cl8(x2), w96, b.to(DEV), co, 3, 3, 3, cache=cl8(x1)[-2:].contiguous(), gn_stats_eps=1e-6)
+    nc = lambda y: y.permute(3, 0, 1, 2)[None]
+    e1, e2 = rel(nc(y1), ref1), rel(nc(y2), ref2)
+    st = K.groupnorm_stats(y2.view(-1, co), 1e-6)
+    es = (y2.gn_sums.stats() - st).abs().max().item()
+    same = torch.equal(y2, y2b) and torch.equal(y2.gn_sums.stats(), y2b.gn_sums.stats())
+    key = f"in8_T{T}_H{H}_W{W}"
+    print(key, f"rel {e1:.2e} {e2:.2e} stats {es:.2e} repeatable {same}")
+    assert max(e1, e2) < 5e-3 and es < 2e-4 and same, key
+    res[key] = (y1.cpu(), y2.cpu())
 path = os.path.join(out_dir, "halo_mode_default.pt")
 if mode == "2":
     base = torch.load(path)
