@@ -1733,8 +1733,11 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
     }
     const long tiles = ((M + BM - 1) / BM) * (cout_pad / BN);
     TG_REQUIRE(tiles < (1L << 31), TG_ERR_SHAPE, "tg_conv3d_cl: too many tiles");
-    // 4-wave kernel: 256x256 tiles need enough of them to fill the chip (>= 2 per CU; the 512-channel layers of the VAE have 128 and stay on
-    // the 128x128 kernel: measured 161 vs 142 ms there, 226 vs 248 ms on the 256-channel layers).  TG_CONV_W4=0: never, 2: whenever legal
+    // 4-wave kernel: 256x256 tiles.  Its launch threshold was "at least 2 tiles per CU" (set from single-stream timings in round 2: a launch of 270 tiles pays
+    // two rounds for 1.05); under the three tile streams a partial round is filled by the other tiles' launches, and what counts is the fill-path bytes per
+    // flop — half of the 128 x 128 kernel's.  Swept in round 4 (decode / encode wall, same box): 2 n_cu 0.469 / 0.246 s, n_cu 0.461 / 0.233, n_cu/2 0.446 / 0.228,
+    // n_cu/5 0.441 / 0.226, n_cu/8 0.436 / 0.220, n_cu/12 0.451 / 0.224 (there the 512-channel layers at 30 x 45 — 22 tiles — leave split-K).
+    // TG_CONV_W4=0: never, 2: whenever legal
     static const int w4 = [] { const char* e = getenv("TG_CONV_W4"); return e ? atoi(e) : 1; }();
     // Cout = 128, 3x3 spatial taps, stride 1, no upsampling: the halo-tiled kernel.  Against the GEMM-shaped kernels on the 8 x 240 x 360 layers:
     // 128 -> 128: 0.70 vs 0.74 ms per launch; per clip 64 -> 128 (encoder conv_in) 13.3 vs 17.5 ms, 256 -> 128 45.6 vs 51.2 ms.  Why not more:
@@ -1757,7 +1760,7 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
             return TG_OK;
         }
     }
-    if (w4 && (w4 == 2 || ((M + 255) / 256) * (cout / 256) >= 2L * n_cu) && cout == cout_pad && cout % 256 == 0 && !t_map && M >= 1024 && (long)kt * kh * kw * (Cin / 64) >= 4 && H * up < 2048 && W * up < 2048 &&
+    if (w4 && (w4 == 2 || ((M + 255) / 256) * (cout / 256) >= n_cu / 8) && cout == cout_pad && cout % 256 == 0 && !t_map && M >= 1024 && (long)kt * kh * kw * (Cin / 64) >= 4 && H * up < 2048 && W * up < 2048 &&
         To < 512 && Ho < 2048 && Wo < 2048 && (long)kt * kh * kw * Cin < (1L << 21) && (long)(T + 2) * H * W * Cin < (1L << 31)) {
         static bool attr4 = false;
         if (!attr4) { (void)hipFuncSetAttribute((const void*)conv3d_w4_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS); attr4 = true; }
