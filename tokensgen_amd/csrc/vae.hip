@@ -381,7 +381,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo2_kernel(ConvParams p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(sH + buf * H2_HALO_BYTES + (wave * HP + i) * 1024), 16, 0, 0);
     };
-    auto dma_w = [&](int slot3, long koff, int i) {       // weight piece i (< WP) of this wave for the stage at element offset koff into ring slot slot3
+    auto dma_w = [&](int slot3, int koff, int i) {       // weight piece i (< WP) of this wave for the stage at element offset koff into ring slot slot3
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.w + woffs[i] + koff),
                                          (__attribute__((address_space(3))) void*)(sW + slot3 * H2_W_BYTES + (WP * wave + i) * 1024), 16, 0, 0);
     };
@@ -438,7 +438,8 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo2_kernel(ConvParams p) {
     }
 #pragma unroll
     for (int i = 0; i < WP; ++i) { dma_w(0, 0, i); dma_w(1, p.Cin, i); dma_w(2, 2L * p.Cin, i); }       // stages 0..2 = taps 0..2 of group 0
-    long wk = 3L * p.Cin;                                   // stage 3: tap 3 of group 0
+    int wk = 3 * p.Cin;                                     // stage 3: tap 3 of group 0
+    const int wk_last = ((p.kt - 1) * 9 + 8) * p.Cin + (nc32 - 1) * 32;   // the last stage's offset: issues past the end re-fetch it (see the stage loop)
     int wc32 = 0;                                           // c32 of the group the next weight stage belongs to
     int hdt = nc32 > 1 ? 0 : 1, hc32 = nc32 > 1 ? 1 : 0;    // (dt, c32) of group 1: the first group whose halo the stage loop stages
     const bf16_t* hsrc = p.x;
@@ -466,7 +467,12 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo2_kernel(ConvParams p) {
             // the wave's halo pieces of the next group go out over the first taps: 12 pieces (4 waves) as 2,2,2,2,2,1,1; 6 pieces (8 waves) as 1,1,1,1,1,1
             constexpr int hfirst = NW == 4 ? (tap < 5 ? 2 * tap : tap + 5) : tap;
             constexpr int hcnt = NW == 4 ? (tap < 5 ? 2 : (tap < 7 ? 1 : 0)) : (tap < 6 ? 1 : 0);
-            const bool w_iss = st + 3 < nst, h_iss = hcnt > 0 && g + 1 < ngroups;
+            // NO wave-uniform guards inside the stage: the first version skipped the DMA of stages past the end (w_iss, h_iss), the next-stage fragment reads of the
+            // last stage (`more`) and picked one of four vmcnt waits — ~29 s_cbranch per stage and wave between the MFMAs, and a stage took ~1 750 cycles for 1 024 of
+            // MFMA with the DMA, the fragment reads or the barrier removed one at a time changing almost nothing (round 4 ablations; tools/ubench/dma_mfma.hip runs
+            // the same MFMA / DMA / read mix at 1 100).  Everything past the end is now simply done and harmless: the weight issue re-fetches the last stage into a
+            // ring slot nobody reads again, the halo issue re-reads the last group's source into the idle buffer, the fragment reads fetch stale LDS into
+            // registers nobody uses; the vmcnt count is then a compile-time constant of the stage.
             // The stage's DMA pieces (2 weight pieces of stage s+3, up to 2 halo pieces of the next group) go out together at the top of the stage.
             // In-kernel timers (instrumented lab builds): a pure MFMA stage is 1021 cycles (= 64 x 16); the fragment reads add ~250; each LDS-DMA
             // piece blocks its wave's issue for ~128 cycles when all four waves issue together — and ~300 when a wave issues alone between its
@@ -474,26 +480,27 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo2_kernel(ConvParams p) {
             // wave's MFMAs, and with one wave per SIMD nobody else fills the gap: stage time = MFMA + fill / (~32 B/clk/CU) + LDS.  That one
             // relation reproduces every kernel here: this one, the GEMM-shaped 512 x 128 convolution (80 KB per 2048 MFMA cycles: 0.83 PFLOP/s)
             // and the DiT's 256 x 256 GEMM (64 KB per 2048: 1.4 PFLOP/s).  Hence: as few fill bytes per MFMA as the tile allows.
-            if (w_iss) {
+            {
+                const int wk_use = min(wk, wk_last);
 #pragma unroll
-                for (int i = 0; i < WP; ++i) dma_w((k + 3) % H2_RING, wk, i);
+                for (int i = 0; i < WP; ++i) dma_w((k + 3) % H2_RING, wk_use, i);
                 constexpr int wtap = (k + 3) % 9;           // tap of the stage just issued (the 36-stage body starts at a group boundary)
                 if constexpr (wtap < 8) wk += p.Cin;
                 else {                                      // next stage: tap 0 of the following group
-                    wk += 32 - (wc32 + 1 == nc32 ? 0 : 8 * p.Cin);
-                    wc32 = wc32 + 1 == nc32 ? 0 : wc32 + 1;
+                    const bool wrap = wc32 + 1 == nc32;
+                    wk += wrap ? 32 : 32 - 8 * p.Cin;
+                    wc32 = wrap ? 0 : wc32 + 1;
                 }
             }
             if constexpr (tap == 0) {                       // this group's stages stage the NEXT group's halo: its source, once
                 if (g + 1 < ngroups) hsrc = frame_base(hdt) + hc32 * 32;
                 if (hc32 + 1 == nc32) { hc32 = 0; ++hdt; } else ++hc32;
             }
-            if (h_iss) {
+            if constexpr (hcnt > 0) {
 #pragma unroll
                 for (int i = 0; i < HP; ++i)
                     if (i >= hfirst && i < hfirst + hcnt) dma_halo((g + 1) & 1, hsrc, i);
             }
-            const bool more = st + 1 < nst;
             // 8 blocks of MI MFMAs (one W fragment x the wave's MI voxel fragments).  After the first half of block ni: W fragment ni + WD (of this
             // stage, or of the next one); after the second half of every ASTEP-th block: a voxel fragment of the NEXT stage.  Reads return in order, so
             // before block ni the W fragment it needs (issued WD blocks earlier) is complete once at most `younger` reads are outstanding:
@@ -518,15 +525,13 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo2_kernel(ConvParams p) {
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwr[q % (WD + 1)], fa[cur][mi], acc[ni][mi], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ni + WD < 8) read_w(std::integral_constant<int, (q + WD) % (WD + 1)>{}, H2_WIMM(k), ni + WD);
-                else if (more) read_w(std::integral_constant<int, (q + WD) % (WD + 1)>{}, H2_WIMM(k + 1), ni + WD - 8);
+                else read_w(std::integral_constant<int, (q + WD) % (WD + 1)>{}, H2_WIMM(k + 1), ni + WD - 8);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mi = MI / 2; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwr[q % (WD + 1)], fa[cur][mi], acc[ni][mi], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (ni % ASTEP == 0) {
-                    if (more) read_a(std::integral_constant<int, nxt>{}, H2_AIMM(k + 1), ni / ASTEP);
-                }
+                if constexpr (ni % ASTEP == 0) read_a(std::integral_constant<int, nxt>{}, H2_AIMM(k + 1), ni / ASTEP);
             });
             __builtin_amdgcn_sched_barrier(0);
             {
@@ -539,10 +544,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo2_kernel(ConvParams p) {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5));
             }
             // allowed in flight: this stage's own pieces (WP weight pieces, hcnt halo pieces) — all wave-uniform, compile-time counts
-            if (w_iss && h_iss) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP + hcnt) : "memory");
-            else if (w_iss) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP) : "memory");
-            else if (h_iss) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(hcnt) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP + hcnt) : "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         });
