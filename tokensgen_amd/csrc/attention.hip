@@ -410,6 +410,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             if (u + 1 < te) dmaK(u + 1);
             if (u < te) dmaV(u);
         };
+        auto dma_pair_all = [&](int u) { dmaK(u + 1); dmaV(u); };      // steady tiles: both exist
 
         f32x16 acc_o[2][2], sc[2][2];
         bf16x8 pf[2][4];
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         };
         // X(t): the 8 fragment groups {V^T(t-1) ks=0..3, K(t) kd=0..3} software-pipelined one group ahead, so the
         // ds_read_b128 latency of group g+1 runs under the 4 MFMAs (128 cycles) of group g instead of after them
-        auto xseg = [&](int t) {
+        auto xseg = [&](int t, auto guardc) {
             const char* tV = smem + (2 + ((t - 1) & 1)) * TILE_B;
             const char* tK = smem + (t & 1) * TILE_B;
             // fragment i = 2g + xb (g: k-step group, xb: 32-row block of V^T / K); NFR 4-register buffers, fragment i+NFR is
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
                 if (i + NFR < 16) ld(i + NFR);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if ((t + 1) * KVBLK > S.nk) {
+            if constexpr (decltype(guardc)::value) if ((t + 1) * KVBLK > S.nk) {
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -636,22 +637,32 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             dma_pair(tb);
             PP_BAR();
         }
-        for (int t = tb; t < te; ++t) {
+        // The tile body exists twice: "guarded" (the last two tiles of a range: DMA issue past the end, key mask) and "steady" (everything unconditional) — the end-of-range
+        // tests (te twice per DMA issue, nk once per tile) were five of the eleven s_cbranch per tile and wave; without them the launch is 1.0-1.6 % faster (same box,
+        // three interleaved rounds).  Specialising the body on the wave group as well (no grp tests left, one back-branch per tile) measured 4-5 % SLOWER: the two
+        // groups then run different copies of the loop.
+        auto tile = [&](auto guardc, int t) {
+            constexpr bool GUARD = decltype(guardc)::value;
             // X(t): matrix segment
-            if (grp == 0) dma_pair(t);
+            if (grp == 0) { if constexpr (GUARD) dma_pair(t); else dma_pair_all(t); }
             // the matrix segment runs at raised priority: its MFMA / ds_read issue slots are few (one per ~32 cycles) but each one the
             // partner's VALU stream delays idles the matrix pipe; measured -4..6 % (7.52 vs 7.94 ms same box); prio 1: -2 %, prio 3 = 2
             __builtin_amdgcn_s_setprio(2);
-            xseg(t);
+            xseg(t, guardc);
             __builtin_amdgcn_s_setprio(0);                         // (fencing this with sched_barrier(0) measured 2.5 % slower)
             if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t (issued one segment ago) has landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PP_BAR();
             // Y(t): vector segment
-            if (grp == 1) dma_pair(t + 1);
+            if (grp == 1) { if constexpr (GUARD) dma_pair(t + 1); else dma_pair_all(t + 1); }
             softmax();
             if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t has landed
             PP_BAR();
+        };
+        {
+            int t = tb;
+            for (; t < te - 2; ++t) tile(std::false_type{}, t);
+            for (; t < te; ++t) tile(std::true_type{}, t);
         }
         pv(te - 1);                                                                // X(nt): last P.V
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
