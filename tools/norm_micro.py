@@ -23,7 +23,8 @@ for name, (T, H, W, C, Tz, Hz, Wz) in {"sn128": (8, 240, 360, 128, 2, 30, 45), "
     if Tz:
         yz = torch.randn(Tz * Hz * Wz, C, generator=g, device=DEV).to(BF)
         bz = torch.randn(Tz * Hz * Wz, C, generator=g, device=DEV).to(BF)
-        run = lambda: K.spatialnorm_silu(f, st, gamma, beta, yz, bz, (Tz, Hz, Wz))
+        nosilu = os.environ.get("TG_NORM_MICRO_NOSILU") == "1"          # timing probe: how much of the pass is the SiLU's exp / rcp
+        run = lambda: K.spatialnorm_silu(f, st, gamma, beta, yz, bz, (Tz, Hz, Wz), silu=not nosilu)
     else:
         run = lambda: K.groupnorm_silu(f, st, gamma, beta)
     for _ in range(3):
