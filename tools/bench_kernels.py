@@ -33,6 +33,8 @@ def timeit(fn, iters=5, warm=2):
 
 
 def rnd(*shape, scale=1.0):
+    if os.environ.get("TG_BENCH_ZERO") == "1":       # power probe: the same launches on all-zero operands (timing only)
+        return torch.zeros(*shape, device=DEV, dtype=BF)
     return (torch.randn(*shape, device=DEV, dtype=torch.float32) * scale).to(BF)
 
 

@@ -30,6 +30,8 @@ for name in names:
     w = torch.zeros(Cp, 27, Ci, dtype=BF, device=DEV)
     w[:Co] = (torch.randn(Co, 27, Ci, generator=g, device=DEV) * 0.02).to(BF)
     b = torch.zeros(Co, dtype=BF, device=DEV)
+    if os.environ.get("TG_CONV_MICRO_ZERO") == "1":          # power probe: the same launch on all-zero operands (no toggling in the matrix pipe)
+        x.zero_(); cache.zero_(); w.zero_()
     gn = 1e-6 if Co % 128 == 0 else None
     for _ in range(3):
         y = K.conv3d_cl(x, w, b, Co, 3, 3, 3, cache=cache, gn_stats_eps=gn)
