@@ -18,6 +18,7 @@ Prints ONE JSON line (rank 0).
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -86,6 +87,139 @@ def _physical_cores():
     except (OSError, ValueError, AttributeError):
         pass
     return os.cpu_count() or 1
+
+
+class PowerSampler:
+    """Socket power and shader clock of ONE GPU sampled by a host thread while a timed region runs (the power-cap reading of the
+    roofline fractions belongs on the driver's record).  No GPU work: sysfs hwmon files of the device (power1_average / power1_input in microwatts,
+    power1_cap, freq1_input in Hz; the starred line of pp_dpm_sclk as a second clock source), else the amdsmi python binding that ships with ROCm, else one
+    rocm-smi subprocess per sample.  `summary()` says which source answered; every figure is None when none did — never a guess."""
+
+    def __init__(self, device_index=0, period_s=0.05):
+        self.period, self.samples, self._stop, self._thread = period_s, [], False, None
+        self.source, self.cap_W = None, None
+        self._read = self._pick(device_index)
+
+    # -- sources --------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _num(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip().split()[0])
+        except (OSError, ValueError, IndexError):
+            return None
+
+    def _pick(self, idx):
+        import glob
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(idx)
+            want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception:  # noqa: BLE001
+            pass
+        cands = []
+        for c in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            hw = sorted(glob.glob(os.path.join(c, "hwmon", "hwmon*")))
+            if hw:
+                cands.append((c, hw[0], os.path.basename(os.path.realpath(c)).lower()))
+        pick = next(((c, hw) for c, hw, addr in cands if want and addr.startswith(want)), None)
+        if pick is None and len(cands) == 1:
+            pick = cands[0][:2]
+        self.pci = want
+        if pick is not None:
+            c, hw = pick
+            pfile = next((p for p in (os.path.join(hw, "power1_average"), os.path.join(hw, "power1_input")) if self._num(p) is not None), None)
+            ffile = os.path.join(hw, "freq1_input") if self._num(os.path.join(hw, "freq1_input")) is not None else None
+            dpm = os.path.join(c, "pp_dpm_sclk") if os.path.exists(os.path.join(c, "pp_dpm_sclk")) else None
+            if pfile or ffile or dpm:
+                cap = self._num(os.path.join(hw, "power1_cap"))
+                self.cap_W = cap / 1e6 if cap else None
+                self.source = "sysfs:" + hw
+
+                def read():
+                    p = self._num(pfile) if pfile else None
+                    f = self._num(ffile) if ffile else None
+                    mhz = f / 1e6 if f else None
+                    if mhz is None and dpm:
+                        try:
+                            with open(dpm) as fh:
+                                for line in fh:
+                                    if "*" in line:
+                                        mhz = float(re.search(r"(\d+)\s*mhz", line.lower()).group(1))
+                        except (OSError, AttributeError, ValueError):
+                            pass
+                    return (p / 1e6 if p else None, mhz)
+                if any(v is not None for v in read()):
+                    return read
+        try:
+            sys.path.append("/opt/rocm/share/amd_smi")
+            import amdsmi
+            amdsmi.amdsmi_init()
+            h = amdsmi.amdsmi_get_processor_handles()[idx]
+            try:
+                self.cap_W = float(amdsmi.amdsmi_get_power_cap_info(h)["power_cap"]) / 1e6
+            except Exception:  # noqa: BLE001
+                pass
+            self.source = "amdsmi"
+
+            def read():
+                p = mhz = None
+                try:
+                    pi = amdsmi.amdsmi_get_power_info(h)
+                    p = float(pi.get("current_socket_power") or pi.get("average_socket_power") or 0) or None
+                except Exception:  # noqa: BLE001
+                    pass
+                try:
+                    mhz = float(amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)["clk"]) or None
+                except Exception:  # noqa: BLE001
+                    pass
+                return (p, mhz)
+            if any(v is not None for v in read()):
+                return read
+        except Exception:  # noqa: BLE001
+            pass
+        import shutil
+        import subprocess
+        if shutil.which("rocm-smi"):
+            self.source, self.period = "rocm-smi", max(self.period, 0.25)
+
+            def read():
+                try:
+                    out = subprocess.run(["rocm-smi", "-d", str(idx), "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+                    d = next(iter(json.loads(out).values()))
+                    p = next((float(v) for k, v in d.items() if "power" in k.lower() and "(w)" in k.lower()), None)
+                    m = next((re.search(r"(\d+)", v) for k, v in d.items() if k.lower().startswith("sclk")), None)
+                    return (p, float(m.group(1)) if m else None)
+                except Exception:  # noqa: BLE001
+                    return (None, None)
+            return read
+        self.source = None
+        return lambda: (None, None)
+
+    # -- sampling -------------------------------------------------------------------------------------------------------------
+    def __enter__(self):
+        import threading
+        self.samples, self._stop = [], False
+
+        def loop():
+            while not self._stop:
+                self.samples.append(self._read())
+                time.sleep(self.period)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        self._thread.join(timeout=10)
+        return False
+
+    def summary(self):
+        pw = [p for p, _ in self.samples if p is not None]
+        ck = [c for _, c in self.samples if c is not None]
+        mean = lambda v: (sum(v) / len(v)) if v else None
+        return {"power_W_mean": mean(pw), "power_W_max": max(pw) if pw else None, "power_cap_W": self.cap_W, "sclk_MHz_mean": mean(ck),
+                "sclk_MHz_min": min(ck) if ck else None, "sclk_MHz_max": max(ck) if ck else None, "samples": len(self.samples), "source": self.source, "pci": getattr(self, "pci", None)}
 
 
 def cpu_baseline(seconds_budget=150.0):
@@ -232,13 +366,35 @@ def run_e2e(a, rank, world, device, dist):
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier(); torch.cuda.synchronize()
+    # checkpoints inside the FIFO loop (nothing may grow or drift over the 351 iterations of gen.yaml): device memory, a checksum of the
+    # queue, wall time and window count at iterations 0, 100, 200, ..., last.  One host sync per checkpoint (a handful per run), nothing on the other iterations
+    ckpt = []
+
+    def hook(i, n_iter, lat, x0q):
+        if i % 100 == 0 or i == n_iter - 1:
+            lf = lat.float()
+            ckpt.append({"iteration": i, "of": n_iter, "seconds_since_start": None, "window_forwards_so_far": counts["fifo"],
+                         "queue_sum": float(lf.sum()), "queue_abs_mean": float(lf.abs().mean()), "queue_finite": bool(torch.isfinite(lf).all()),
+                         "x0_abs_mean": float(x0q.float().abs().mean()),
+                         "mem_allocated_GB": torch.cuda.memory_allocated() / 2 ** 30, "mem_max_allocated_GB": torch.cuda.max_memory_allocated() / 2 ** 30,
+                         "mem_reserved_GB": torch.cuda.memory_reserved() / 2 ** 30})
+            torch.cuda.synchronize()
+            ckpt[-1]["seconds_since_start"] = time.perf_counter() - t0
     fence()
+    power = PowerSampler(device.index or 0, period_s=0.5)
+    power.__enter__()
     t0 = time.perf_counter()
     base = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image_embeddings=emb, num_chunks=a.chunks, num_inference_steps=52,
                 guidance_scale=6.0, video_ipadapter_scale=[0.6], output_type="pt")
     fence(); t_base = time.perf_counter() - t0
-    orig, video, _ = F.cogvideo_fifo_mp_v2([pipe], base, noise_seed=7)
+    orig, video, _ = F.cogvideo_fifo_mp_v2([pipe], base, noise_seed=7, iteration_hook=hook)
     fence(); dt = time.perf_counter() - t0
+    power.__exit__()
+    power = power.summary()
+    # steady-state rate between the first and the last checkpoint (ramp and decode excluded), for comparison with the window benchmark
+    steady = None
+    if len(ckpt) >= 2 and ckpt[-1]["seconds_since_start"] > ckpt[0]["seconds_since_start"]:
+        steady = (ckpt[-1]["window_forwards_so_far"] - ckpt[0]["window_forwards_so_far"]) / (ckpt[-1]["seconds_since_start"] - ckpt[0]["seconds_since_start"]) / world
     if t_t2to is not None:
         dt += t_t2to                                              # the whole generation: T2To stage + To2V
     F.window_plan = orig_plan
@@ -258,6 +414,9 @@ def run_e2e(a, rank, world, device, dist):
                                    f"+ VAE decode of {a.chunks + 1} clips", "layers": a.layers, "chunks": a.chunks},
             "seconds": {"total": dt, "base_stage": t_base, "fifo_and_decode": dt - t_base - (t_t2to or 0.0), "t2to_stage": t_t2to},
             "t2to": None if t_t2to is None else {"tokens": t2to_tokens, "steps": 52, "ms_per_cfg_step": 1e3 * t_t2to / 52},
+            "fifo_steps_per_s_per_gpu_between_checkpoints": steady, "checkpoints": ckpt,
+            "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30, "power_W_mean": power["power_W_mean"], "power_cap_W": power["power_cap_W"],
+            "sclk_MHz_mean": power["sclk_MHz_mean"],
             "frames_out": list(video.shape), "finite": bool(torch.isfinite(video).all())}))
 
 
@@ -341,14 +500,17 @@ def train_measure(a, rank, world, device, dist):
     K.PROFILE_ON[0] = True
     K.PROFILE_FILTER[0] = None if os.environ.get("TG_BENCH_PROFILE_ALL") == "1" else {"attention_bwd"}     # 1: every launch timed (per-shape table, slower step)
     fence()
-    t0 = time.perf_counter()
-    n_opt = 0
-    for _ in range(a.steps):
-        loss, did = micro()
-        n_opt += int(did)
-    fence()
-    dt = time.perf_counter() - t0
+    power = PowerSampler(device.index or 0)
+    with power:
+        t0 = time.perf_counter()
+        n_opt = 0
+        for _ in range(a.steps):
+            loss, did = micro()
+            n_opt += int(did)
+        fence()
+        dt = time.perf_counter() - t0
     K.PROFILE_ON[0] = False
+    power = power.summary()
     rank_ms = 1e3 * dt / a.steps
     if dist is not None:
         tm = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -381,13 +543,15 @@ def train_measure(a, rank, world, device, dist):
                          "achieved": alg / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else None, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": (alg / (tot_ms * 1e-3) / 1e12 / 2500.0) if tot_ms > 0 else None, "traffic": traffic,
                          "traffic_note": "bytes past L2 of ONE main (17776 x 17776, 96 heads) call's backward launch(es) behind the statistics; algorithmic 3.06e9; the one-kernel form's ordered dQ accumulation is 60 GB of L2 read-modify-write, part of which reaches memory",
-                         "ms_per_micro_step_in_this_kernel": tot_ms, "launches_per_micro_step": prof["n"] / max(1, a.steps)},
+                         "ms_per_micro_step_in_this_kernel": tot_ms, "launches_per_micro_step": prof["n"] / max(1, a.steps),
+                         "frac_at_measured_clock": (alg / (tot_ms * 1e-3) / 1e12 / (2500.0 * power["sclk_MHz_mean"] / 2400.0)) if tot_ms > 0 and power["sclk_MHz_mean"] else None},
             **({"kernel_ms_per_micro_step": {k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(K.profile_summary().items(), key=lambda kv: -kv[1]["total_ms"])},
                 "launches_per_micro_step": {k: v["n"] / a.steps for k, v in K.profile_summary().items()}} if K.PROFILE_FILTER[0] is None else {}),
             "loss": float(loss), "grad_norm_last_step": float(opt.coef[0]) if n_opt else None,
             "attention_bwd_form": "one kernel (dK, dV, dQ; ordered dQ exchange, status word checked every micro-step)" if K.BwdDeviceState.get(device).one_kernel
                                   else "two launches (dK/dV + dQ)",
             "attention_bwd_probe": K.BwdDeviceState.get(device).probe,
+            "power_W_mean": power["power_W_mean"], "power_cap_W": power["power_cap_W"], "sclk_MHz_mean": power["sclk_MHz_mean"],
             "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30})
     return None
 
@@ -406,6 +570,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE (BASELINE config 4) sub-record")
     ap.add_argument("--no-train", action="store_true", help="skip the training (BASELINE config 5) sub-record")
+    ap.add_argument("--no-zero-control", action="store_true", help="skip the zero-operand control (3 untimed steps on zeroed weights and inputs)")
     a = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -495,12 +660,15 @@ def main():
     # kernels' durations come from one extra, untimed step afterwards, so their ~1800 event markers do not sit in the measurement
     ATTN = "attention_2seg+rider"
     K.PROFILE.clear(); K.PROFILE_FILTER[0] = {ATTN}; K.PROFILE_ON[0] = True
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        x_last = step()
-    fence()
-    dt = time.perf_counter() - t0
+    power = PowerSampler(local_rank)                 # a host thread reading sysfs / amdsmi: no GPU work, nothing on the launch stream
+    with power:
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            x_last = step()
+        fence()
+        dt = time.perf_counter() - t0
     K.PROFILE_ON[0] = False
+    power = power.summary()
     attn_prof = K.profile_summary().get(ATTN, {"ms": float("nan"), "n": 0})
     attn_path = model.attn_path                      # what the timed region ran on ("constant_shift" unless the retry counter said otherwise)
     retry_ws = next(iter(model._ws.values())).retry
@@ -522,6 +690,36 @@ def main():
     K.PROFILE_ON[0] = False
     other_prof = K.profile_summary().get(ATTN, {"ms": float("nan"), "n": 0})
     model.attn_path = attn_path
+    # zero-operand control (untimed, rank-local, AFTER everything that needs the weights): the same launches on all-zero weights and inputs.  With nothing
+    # toggling in the matrix pipe the chip is no longer on its socket power cap; the ratio to `ms_per_step` is how much of the headline is clock, not schedule
+    zero_ctl = None
+    if world == 1 and not a.no_zero_control:
+        keep = {k: t.clone() for k, t in model._fused.items()}
+        for t_ in model._fused.values():
+            t_.zero_()
+        zl, zx0, zp, ze = latents.clone(), old_x0.clone(), prompt.clone(), emb.clone()
+        latents.zero_(); old_x0.zero_(); prompt.zero_(); emb.zero_()
+        znoise = torch.zeros(nf, 2, C, H, W, device=device, dtype=bf)
+
+        def zstep():
+            return worker.window_step(latents, old_x0, has_old, t, prev_t, next_t, znoise, grid_t, cond_t, emb)
+        zstep(); fence()
+        K.PROFILE.clear(); K.PROFILE_FILTER[0] = {ATTN}; K.PROFILE_ON[0] = True
+        zpow = PowerSampler(local_rank)
+        with zpow:
+            t1 = time.perf_counter()
+            for _ in range(3):
+                zx = zstep()
+            fence()
+            zdt = time.perf_counter() - t1
+        K.PROFILE_ON[0] = False
+        zattn = K.profile_summary().get(ATTN, {"ms": float("nan"), "n": 0})
+        zero_ctl = {"what": "the same 3 window steps with every weight and every input zeroed (same launches, same schedules; timing only)", "steps": 3,
+                    "ms_per_step": 1e3 * zdt / 3, "attention_launch_ms": zattn["ms"], "finite": bool(torch.isfinite(zx[0]).all()), **zpow.summary()}
+        for k, t_ in model._fused.items():
+            t_.copy_(keep[k])
+        latents.copy_(zl); old_x0.copy_(zx0); prompt.copy_(zp); emb.copy_(ze)
+        del keep, zl, zx0, zp, ze
     rank_ms = [1e3 * dt / a.steps]
     if use_dist:
         mine = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -562,7 +760,14 @@ def main():
                                          "frac": ATTN_FLOP_PER_LAUNCH / (other_prof["ms"] * 1e-3) / PEAK_BF16, "step_ms_one_untimed_step": other_step_ms},
             "kernel_ms": {k: round(v["ms"], 4) for k, v in prof.items()},
             "rank_ms_per_step": [round(v, 3) for v in rank_ms],
+            # socket power and shader clock over the timed region (PowerSampler), top level so that the driver's record carries them
+            "power_W_mean": power["power_W_mean"], "power_cap_W": power["power_cap_W"], "sclk_MHz_mean": power["sclk_MHz_mean"], "power": power,
+            "zero_operand_control": zero_ctl,
         }
+        sclk = power["sclk_MHz_mean"]
+        # the same achieved rates against the peak AT THE CLOCK THE CHIP ACTUALLY RAN (2.5 PF is quoted at 2400 MHz)
+        out["roofline"]["frac_at_measured_clock"] = achieved / (PEAK_BF16 / 1e12 * sclk / 2400.0) if sclk else None
+        out["step_mfma_frac_at_measured_clock"] = out["step_mfma_frac"] / (sclk / 2400.0) if sclk else None
         if not a.no_vae and world == 1:
             out["vae"] = vae_record(device)
         if not a.no_train and world == 1 and a.layers == 42:
@@ -570,7 +775,7 @@ def main():
             worker = model = retry_ws = None          # (the step closure sees the same cells: nothing keeps the 14 GB of weights + workspaces)
             import gc
             gc.collect(); torch.cuda.empty_cache()
-            ta = argparse.Namespace(layers=a.layers, steps=3, warmup=1, accum=9)
+            ta = argparse.Namespace(layers=a.layers, steps=9, warmup=1, accum=9)      # one whole accumulation window: the optimizer step is inside
             out["train"] = train_measure(ta, 0, 1, device, None)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

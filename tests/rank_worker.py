@@ -51,6 +51,49 @@ if mode == "gradsync":                  # DDP gradient exchange of the training 
     dist.destroy_process_group()
     sys.exit(0)
 
+if mode == "verdict":                   # an invalid attention backward on ONE rank must discard the accumulation window and raise on EVERY rank
+    init_distributed("gloo", timeout_s=120)
+    from types import SimpleNamespace
+    from tokensgen_amd.optim import GradSync
+    from tokensgen_amd.train import To2VTrainStep
+    flat = torch.full((1000,), float(rank + 1))
+    steps = [0]
+    opt = SimpleNamespace(step=lambda: steps.__setitem__(0, steps[0] + 1))
+    sync = GradSync(flat, bucket_elems=300)
+    ts = To2VTrainStep(None, SimpleNamespace(grad=flat), opt, None, accumulation_steps=3, sync=sync)
+    log = []
+    # window 1: micro-steps 1, 2 fine; on the LAST one rank 1's status word is set while both ranks already handed buckets to the exchange
+    for m in range(3):
+        ts.micro += 1
+        last = ts.micro % 3 == 0
+        if last:
+            sync.ready(650)
+        try:
+            ts._apply_or_discard(2 if (rank == 1 and last) else 0, 0, last, "cpu")
+            log.append("ok")
+        except RuntimeError as e:
+            log.append("raised:" + ("rank(s) [1] of 2" in str(e) and "discarded" in str(e) and "yes" or "no"))
+    ok = log == ["ok", "ok", "raised:yes"] and ts.micro == 0 and steps[0] == 0 and float(flat.abs().max()) == 0.0 and sync._next == 0 and not sync._work
+    # window 2: the same window fed again goes through, the optimizer steps once on both ranks, the exchange sums the ranks' gradients
+    flat.fill_(float(rank + 1))
+    for m in range(3):
+        ts.micro += 1
+        last = ts.micro % 3 == 0
+        ts._apply_or_discard(0, 0, last, "cpu")
+    ok = ok and steps[0] == 1 and ts.micro == 3 and torch.equal(flat, torch.full((1000,), 3.0))
+    # a failure in the MIDDLE of a window (no exchange in flight) also raises everywhere and rolls the counter back to the window's start
+    ts.micro += 1
+    ts._apply_or_discard(0, 0, False, "cpu")
+    ts.micro += 1
+    try:
+        ts._apply_or_discard(0, 1 if rank == 0 else 0, False, "cpu")
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "rank(s) [0] of 2" in str(e) and ts.micro == 3 and float(flat.abs().max()) == 0.0
+    done("ok" if ok else "mismatch " + repr(log) + f" micro={ts.micro} steps={steps[0]}")
+    dist.destroy_process_group()
+    sys.exit(0)
+
 if mode == "broadcast":                 # runtime.broadcast_weights: rank 0 owns the weights, rank 1 must end up with them bit for bit
     init_distributed("gloo", timeout_s=120)
     from oracle import dit_ref as O

@@ -55,6 +55,17 @@ def test_gradient_all_reduce_buckets_two_ranks(tmp_path):
     assert _read(tmp_path, 0) == "ok" and _read(tmp_path, 1) == "ok"
 
 
+@pytest.mark.timeout(120)
+def test_invalid_attention_backward_on_one_rank_discards_the_window_on_every_rank(tmp_path):
+    """Training step, failure leg (train_cogvideo_to2v.py:1995-2021 has no counterpart: autograd cannot fail this way): the one-kernel attention backward's
+    sticky status word set on ONE rank — on the window's last micro-step, with gradient buckets already handed to the exchange, and in the middle of a
+    window — makes EVERY rank drain the exchange, zero the gradient arena, roll the micro counter back to the window's start and raise; feeding the window
+    again then steps the optimizer once with the rank sum (To2VTrainStep._apply_or_discard; gloo, 2 ranks)."""
+    from tokensgen_amd.runtime import launch
+    launch(2, [sys.executable, WORKER, "verdict", str(tmp_path)])
+    assert _read(tmp_path, 0) == "ok" and _read(tmp_path, 1) == "ok", (_read(tmp_path, 0), _read(tmp_path, 1))
+
+
 @pytest.mark.timeout(180)
 def test_weight_broadcast_two_ranks(tmp_path):
     """runtime.broadcast_weights (north_star: "RCCL broadcast of weights"; replaces the reference's whole-pipeline CUDA-IPC pickling,

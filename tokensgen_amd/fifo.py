@@ -173,7 +173,7 @@ def decode_chunks_sharded(pipe, latents, nf, decode_chunk_fn=None):
 
 
 def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None, tail_noise_fn=None, trace=None,
-                        window_fn=None, decode_chunk_fn=None, **kwargs):
+                        window_fn=None, decode_chunk_fn=None, iteration_hook=None, **kwargs):
     """Mirror of cogvideo_sampling_mp_fifo.py:27-395.
 
     `pipe_list` holds this process's pipeline(s); with torch.distributed initialised (one process per GPU) the
@@ -181,7 +181,8 @@ def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None
     bookkeeping and the tail noise are replicated.  Returns (orig_video, video, cache_video) like the reference
     (latents when output_type == "latent").  `window_fn(worker, **window_inputs)` lets tests substitute the
     denoiser (CPU/gloo tests of the exchange logic); the default is FifoWorker.window_step (HIP).  With an output_type other
-    than "latent" the final VAE decode is sharded by chunk over the ranks (decode_chunks_sharded)."""
+    than "latent" the final VAE decode is sharded by chunk over the ranks (decode_chunks_sharded).  `iteration_hook(i, n_iter, latents, x0q)` is called
+    on every rank after iteration i's queue shift (measurement only: bench.py records memory and queue checksums there; it must not modify the queue)."""
     import torch.distributed as dist
     bo = base_output
     sp = bo.sampling_params
@@ -294,6 +295,8 @@ def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None
             q_grid_t[-1] = feed[0]
             feed = feed[1:]
         queue_start = max(0, queue_start - 1)
+        if iteration_hook is not None:
+            iteration_hook(i, n_iter, latents, x0q)
 
     video_latents = torch.cat(outs[T - nf:], dim=1)                                              # :367
     if getattr(bo, "output_type", "latent") == "latent":

@@ -317,19 +317,34 @@ class BwdDeviceState:
         return st
 
 
-def attention_bwd_check(device=None):
-    """Read the sticky status word of the one-kernel backward on `device` (synchronises) and raise if any ordered-exchange poll timed out since the
-    last check: the dq of that launch is invalid, the step must not be applied.  Called by the training step once per micro-step."""
+def attention_bwd_status(device=None, clear=True):
+    """(timed-out exchange polls, workgroups off their head's XCD) summed over the devices this process has used since the last call — the sticky status
+    words of the one-kernel backward (one synchronisation).  `clear` resets them, so that a discarded step can be attempted again."""
     devs = [torch.device(device).index] if device is not None else list(BwdDeviceState._by_device)
+    polls = xcd = 0
     for idx in devs:
         st = BwdDeviceState._by_device.get(idx if idx is not None else torch.cuda.current_device())
         if st is None:
             continue
         n, _, x, _ = st.status.tolist()
-        if n or x:
+        polls, xcd = polls + n, xcd + x
+        if clear and (n or x):
             st.status[0].zero_(); st.status[2].zero_()
-            raise RuntimeError(f"tg_attention_bwd_ex on cuda:{idx}: {n} ordered dQ exchange poll(s) timed out, {x} workgroup(s) found their head's key blocks on "
-                               "more than one XCD — the gradients of this step are invalid; discard the step. TG_ATTN_BWD_FUSED=0 selects the two-launch form.")
+    return polls, xcd
+
+
+def attention_bwd_error(polls, xcd, where="this process"):
+    return RuntimeError(f"tg_attention_bwd_ex ({where}): {polls} ordered dQ exchange poll(s) timed out, {xcd} workgroup(s) found their head's key blocks on "
+                        "more than one XCD — the gradients of this step are invalid; discard the step. TG_ATTN_BWD_FUSED=0 selects the two-launch form.")
+
+
+def attention_bwd_check(device=None):
+    """Read the sticky status word of the one-kernel backward on `device` (synchronises) and raise if any ordered-exchange poll timed out since the
+    last check: the dq of that launch is invalid, the step must not be applied.  Single-process callers; the training step uses attention_bwd_status
+    and makes the verdict collective before anything is applied (train.To2VTrainStep.micro_step)."""
+    polls, xcd = attention_bwd_status(device)
+    if polls or xcd:
+        raise attention_bwd_error(polls, xcd, f"cuda:{torch.device(device).index}" if device is not None else "this process")
 
 
 def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, accumulate=False, lse=None):

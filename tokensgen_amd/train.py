@@ -669,6 +669,34 @@ class To2VTrainStep:
         self.opt.load_state_dict(sd["optimizer"])
         self.micro = int(sd["micro"])
 
+    def _failed_ranks(self, failed, device):
+        """Ranks whose micro-step is invalid, known to EVERY rank (one tiny all_gather per micro-step when a process group carries the step)."""
+        if self.sync is None or not self.sync.dist.is_initialized():
+            return [0] if failed else []
+        dist = self.sync.dist
+        flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=device if dist.get_backend(self.sync.group) == "nccl" else "cpu")
+        every = [torch.zeros_like(flag) for _ in range(self.world)]
+        dist.all_gather(every, flag, group=self.sync.group)
+        return [r for r, f in enumerate(every) if int(f.item())]
+
+    def _apply_or_discard(self, polls, xcd, last, device):
+        """Tail of a micro-step: collective verdict, then either the optimizer step (last micro-step of the window) or the discard + RuntimeError on EVERY rank."""
+        bad_ranks = self._failed_ranks(bool(polls or xcd), device)
+        if bad_ranks:
+            if last and self.sync is not None:
+                self.sync.finish()                            # the buckets handed over during the backward complete on every rank, then are thrown away
+            self.discard_window()
+            raise K.attention_bwd_error(polls, xcd, f"rank(s) {bad_ranks} of {self.world}; this rank: {polls} / {xcd}; the accumulation window was discarded on every rank")
+        if last:
+            if self.sync is not None:
+                self.sync.finish()
+            self.opt.step()
+
+    def discard_window(self):
+        """Throw the current accumulation window away: accumulated gradients zeroed, the micro counter back at the window's first micro-step."""
+        self.arena.grad.zero_()
+        self.micro = (max(self.micro, 1) - 1) // self.accum * self.accum
+
     def _frames_per_chunk(self, image_embeddings):
         return min(self.latent_frames_per_chunk, image_embeddings.shape[1])
 
@@ -735,13 +763,12 @@ class To2VTrainStep:
                 d_all[b, int(emb_start_idx[b]) * slot:(int(emb_start_idx[b]) + vip_frames) * slot] = d_vip[b]
             for c, ctx in enumerate(ctxs):
                 self.arena.accumulate(self.rs.backward(ctx, d_all[:, c * Nq:(c + 1) * Nq].contiguous()), scale)
-        # the one-kernel attention backward reports an ordered-exchange poll that gave up through a sticky device word: read it (one
-        # synchronisation per micro-step) BEFORE the optimizer may apply anything — RuntimeError, never silently wrong gradients
-        K.attention_bwd_check(out.device)
-        if last:
-            if self.sync is not None:
-                self.sync.finish()
-            self.opt.step()
+        # The one-kernel attention backward reports an ordered-exchange poll that gave up through a sticky device word: read it (one synchronisation per
+        # micro-step) BEFORE the optimizer may apply anything.  The verdict is COLLECTIVE (as fifo.py's RankGuard flag is): a rank that raised alone would
+        # leave the others in sync.finish() / opt.step() — a hang or diverged weights — so every rank learns whether ANY rank failed, and on failure every
+        # rank drains the exchange it has already started, DISCARDS the accumulation window (gradient arena zeroed, micro counter back at the window's
+        # start: the caller may simply feed the window again) and raises.  Never silently wrong gradients, never a half-applied step.
+        self._apply_or_discard(*K.attention_bwd_status(out.device), last, out.device)
         return loss, last
 
 
