@@ -8,7 +8,8 @@
  * Conventions:
  *   - plain pointers + sizes only; all tensors are bf16 (raw uint16 bits) unless stated, fp32 accumulate;
  *   - the caller owns every buffer (outputs and workspace are caller-allocated); nothing is retained;
- *   - every call is asynchronous on the given hipStream_t, never synchronises, never selects a device;
+ *   - every call is asynchronous on the given hipStream_t, never synchronises, never selects a device, reads no environment variable;
+ *   - nothing process-wide is kept except what is keyed by the CURRENT device id (CU count, per-kernel launch attributes) and the tg_debug_set knobs;
  *   - returns 0 on success; <0 on error (-1 argument, -2 shape, -3 alignment, <=-100 HIP error);
  *     tg_last_error_string() gives the message for the calling thread.  No exceptions cross the ABI.
  */
@@ -19,6 +20,10 @@
 
 #ifdef __cplusplus
 extern "C" {
+#endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared in this header are exported (tests/test_abi_cpu.py holds `nm -D` to it). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
 #endif
 
 typedef struct ihipStream_t* hipStream_t;   /* same declaration as <hip/hip_runtime_api.h>; opaque to C callers */
@@ -291,7 +296,7 @@ int tg_attention_fwd_lse_ex(const void* q, long q_ld, long q_strideB, const void
  * P is recomputed from the log-sum-exp tile by tile.  Launches: statistics, then dK/dV per 256-key workgroup + dQ per 256-query workgroup (7 executed
  * GEMMs).  No atomics on the data: run-to-run deterministic.  lse: optional [batch][heads][nq] fp32 row log-sum-exp (log2 domain) written by
  * tg_attention_fwd_lse for the same q / k / scale — the statistics launch then only forms rowsum(dO o O); NULL: recomputed here.
- * TG_ATTN_BWD_V1=1 selects the earlier correct-first kernels (cross-check). */
+ * (An independent correct-first implementation of the same mathematics lives in the TEST-ONLY library tests/libtg_crosscheck.so.) */
 int tg_attention_bwd(const void* q, long q_ld, long q_sb, const void* k, long k_ld, long k_sb, const void* v, long v_ld, long v_sb,
                      const void* o, long o_ld, long o_sb, const void* dout, long do_ld, long do_sb,
                      float* dq, long dq_ld, long dq_sb, float* dk, long dk_ld, long dk_sb, float* dv, long dv_ld, long dv_sb,
@@ -417,7 +422,8 @@ int tg_pca_lowrank_filter(const void* x, long ldx, const float* comp, const floa
  * are stored (row stride ldy).  residual (optional, same layout as y) is added in the epilogue (ResnetBlock3D :309).
  * zeros: >= 2*Cin + 128 bytes of device zeros (source of out-of-range taps).  Cin % 64 == 0, with one exception:
  * Cin == 8 is the encoder's input convolution (CogVideoXEncoder3D.conv_in, :708-712: 3 -> 128 channels, 3x3x3, stride 1): x and cache carry 8 channels per
- * voxel (3 used, the rest zero), w is packed [128][96] with reduction index k = tap * 3 + channel (81 real entries, the rest zero), cout = cout_pad = 128.
+ * voxel (3 used; HARD PRECONDITION: channels 3..7 of x and cache are finite — the kernel's padded reduction entries multiply them by zero weights, so a NaN / Inf
+ * there would reach all 128 outputs; tokensgen_amd.vae zero-fills them), w is packed [128][96] with reduction index k = tap * 3 + channel (81 real entries, the rest zero), cout = cout_pad = 128.
  * The decoder's conv_out (Cin = 128 -> cout <= 4, 3x3x3) takes a halo-tiled kernel with LDS-resident weights at launch scale; same arguments as any narrow layer.
  * gn_partial (optional, tg_conv3d_gn_partial_floats(To,Ho,Wo) floats; needs cout % 128 == 0): per 128-voxel tile row the sums and
  * sums of squares, per GroupNorm(32) group, of the bf16 values this launch stores — summed in a fixed order — so that the
@@ -482,6 +488,19 @@ int tg_cl_to_ncdhw(const void* src, long ld, int C, int T, int H, int W, void* d
 int tg_tile_blend(const void* a, void* b, int is_fp32, int C, int T, int Ha, int Wa, int Hb, int Wb, int axis, int extent,
                   hipStream_t stream);
 
+/* Dispatch overrides for the cross-check tests — NOT part of the operator surface.  The library reads no environment variable and keeps no other
+ * process-wide state: the defaults are the shipped path, and these knobs only choose between two PRODUCT kernels of the same operator (each pair is held
+ * bitwise or to rounding against each other by tests/).  Knobs: TG_ATTN_PP_MIN_WG (1024: workgroups from which the 8-wave attention kernel is used),
+ * TG_ATTN_FIXEDM (1; 0: always the running row maximum), TG_ATTN_SPLIT (1; 0: no key-axis split of the last half round), TG_GEMM_W4 (1; 0: 8-wave GEMM),
+ * TG_CONV_SPLITK (1; 0: never), TG_CONV_HALO / TG_CONV_W4 (1; 0: never, 2: whenever legal).  tokensgen_amd.lib forwards same-named environment
+ * variables here at load time.  Unknown knob: TG_ERR_ARG.  tg_debug_knob_name(i) enumerates the names (NULL past the end). */
+int tg_debug_set(const char* knob, long value);
+int tg_debug_get(const char* knob, long* value);
+const char* tg_debug_knob_name(int index);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -1,11 +1,53 @@
-// Correct-first attention backward kernels (head_dim 64): LDS-staged 64 x 64 tiles, 4 waves, one 32 x 32 block per wave, explicit transposes
-// while staging.  Not on the product path: TG_ATTN_BWD_V1=1 makes tg_attention_bwd launch them instead of the register-resident kernels of
-// attention_bwd.hip, as an independent cross-check of the same mathematics (tests/test_train_gpu.py runs the autograd comparison on both).
+// TEST SCAFFOLDING (tests/libtg_crosscheck.so, built by tests/csrc/Makefile; never linked into libtokensgen_hip.so): the correct-first attention
+// backward kernels (head_dim 64) — LDS-staged 64 x 64 tiles, 4 waves, one 32 x 32 block per wave, explicit transposes while staging, and a
+// one-thread-per-query statistics kernel — kept as an INDEPENDENT implementation of the same mathematics.  tests/test_train_gpu.py runs the autograd
+// comparison on them through `tgx_attention_bwd` (same arguments as tg_attention_bwd) and holds the product kernels against them.
 //   dV = P^T dO        dP = dO V^T        dS = P o (dP - D)        dQ = scale dS K       dK = scale dS^T Q
+#include <stdarg.h>
+#include <stdio.h>
+
 #include "attention_bwd.h"
-#include "tokensgen_hip.h"
+
+// the product library's error plumbing is not exported: a local one for the TG_REQUIRE / TG_LAUNCH_CHECK macros of common.h
+static thread_local char g_xerr[512] = "";
+extern "C" __attribute__((visibility("hidden"))) int tg_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_xerr, sizeof(g_xerr), fmt, ap);
+    va_end(ap);
+    return code;
+}
+extern "C" const char* tgx_last_error_string(void) { return g_xerr; }
 
 namespace {
+
+// statistics, the slow obvious way: one thread per (batch, head, query) walks all keys twice (row maximum, then the sum) and forms D_i = sum_d dO_id O_id
+__global__ void xcheck_stats_kernel(BwdParams p) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)p.batch * p.heads * p.nq) return;
+    const int q = (int)(i % p.nq), h = (int)((i / p.nq) % p.heads), b = (int)(i / ((long)p.nq * p.heads));
+    const bf16_t* Q = p.q + (long)b * p.q_sb + (long)q * p.q_ld + h * HD;
+    const bf16_t* O = p.o + (long)b * p.o_sb + (long)q * p.o_ld + h * HD;
+    const bf16_t* G = p.dout + (long)b * p.do_sb + (long)q * p.do_ld + h * HD;
+    float qv[HD], d = 0.f;
+    for (int c = 0; c < HD; ++c) {
+        qv[c] = bf16_to_f32(Q[c]);
+        d += bf16_to_f32(O[c]) * bf16_to_f32(G[c]);
+    }
+    float m = -1e30f;
+    for (int pass = 0; pass < 2; ++pass) {
+        float l = 0.f;
+        for (int k = 0; k < p.nk; ++k) {
+            const bf16_t* Kr = p.k + (long)b * p.k_sb + (long)k * p.k_ld + h * HD;
+            float s = 0.f;
+            for (int c = 0; c < HD; ++c) s += qv[c] * bf16_to_f32(Kr[c]);
+            s *= p.scale_log2;
+            if (pass == 0) m = fmaxf(m, s); else l += exp2f(s - m);
+        }
+        if (pass == 1) p.lse[i] = m + log2f(l);
+    }
+    p.dsum[i] = d;
+}
 
 // rows [r0, r0 + 64) x 64 head columns of a [n][ld] bf16 matrix -> dst[row][LDT]; rows >= n are zero
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, long ld, int r0, int n, bf16_t* __restrict__ dst) {
@@ -185,17 +227,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdParams p) {
 
 }  // namespace
 
-int tg_attention_bwd_ref_launch(const BwdParams& p, hipStream_t stream) {
+// same arguments as tg_attention_bwd (include/tokensgen_hip.h) except the workspace: `ws` = 2 * batch * heads * nq floats (log-sum-exp | D); `lse` is ignored
+extern "C" int tgx_attention_bwd(const void* q, long q_ld, long q_sb, const void* k, long k_ld, long k_sb, const void* v, long v_ld, long v_sb,
+                                  const void* o, long o_ld, long o_sb, const void* dout, long do_ld, long do_sb,
+                                  float* dq, long dq_ld, long dq_sb, float* dk, long dk_ld, long dk_sb, float* dv, long dv_ld, long dv_sb,
+                                  int nq, int nk, int heads, int batch, float scale, int accumulate, const float* lse, float* ws, hipStream_t stream) {
+    (void)lse;
+    TG_REQUIRE(q && k && v && o && dout && dq && dk && dv && ws, TG_ERR_ARG, "tgx_attention_bwd: null pointer");
+    TG_REQUIRE(nq > 0 && nk > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tgx_attention_bwd: bad shape");
+    accumulate = accumulate == 1 ? 3 : (accumulate & 3);
+    const long nrow = (long)batch * heads * nq;
+    const BwdParams p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, q_ld, q_sb, k_ld, k_sb, v_ld, v_sb,
+                      o_ld, o_sb, do_ld, do_sb, dq, dk, dv, dq_ld, dq_sb, dk_ld, dk_sb, dv_ld, dv_sb, ws, ws + nrow, nullptr, nq, nk, heads,
+                      batch, scale * 1.4426950408889634f, scale, accumulate, 0};
+    hipLaunchKernelGGL(xcheck_stats_kernel, dim3((unsigned)((nrow + 127) / 128)), dim3(128), 0, stream, p);
     constexpr int LDS_KV = 8 * TILE_EL * 2 + 128 * 4, LDS_Q = 6 * TILE_EL * 2;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_Q);
-        attr = true;
-    }
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_Q);
     const dim3 gq((unsigned)((p.nq + TQ - 1) / TQ), (unsigned)(p.batch * p.heads)), gk((unsigned)((p.nk + TK - 1) / TK), (unsigned)(p.batch * p.heads));
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, gk, dim3(256), LDS_KV, stream, p);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(256), LDS_Q, stream, p);
-    TG_LAUNCH_CHECK("tg_attention_bwd (cross-check kernels)");
+    TG_LAUNCH_CHECK("tgx_attention_bwd (cross-check kernels)");
     return TG_OK;
 }

@@ -129,8 +129,30 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(so, name), f"{name} declared in include/tokensgen_hip.h but not exported"
     lib = L.load()
-    assert set(L.PROTOTYPES) | set(L.QUERIES) | {"tg_version", "tg_last_error_string"} == declared
+    assert set(L.PROTOTYPES) | set(L.QUERIES) | set(L.OTHER_EXPORTS) == declared
     assert b"gfx950" in lib.tg_version()
+    # ... and NOTHING ELSE: the library is built with -fvisibility=hidden, `nm -D` of its defined symbols == the header's declarations
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in "TWBDRV"}
+    exported -= {"_init", "_fini", "__bss_start", "_edata", "_end"}
+    exported = {n for n in exported if not n.startswith("__hip_")}          # the HIP fat-binary registration objects of every hipcc-built library
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+    # the product sources read no environment variable, and the test-only cross-check kernels are not in the product library
+    csrc = os.path.join(ROOT, "tokensgen_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".cpp", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+    assert not os.path.exists(os.path.join(csrc, "attention_bwd_ref.hip"))
+    # the debug knobs: defaults, set / get round trip, unknown names refused
+    val = ctypes.c_long(-1)
+    assert lib.tg_debug_get(b"TG_ATTN_PP_MIN_WG", ctypes.byref(val)) == 0 and val.value == 1024
+    assert L.debug_set("TG_GEMM_W4", 0) == 1 and L.debug_set("TG_GEMM_W4", 1) == 0
+    assert lib.tg_debug_set(b"TG_NO_SUCH_KNOB", 1) == -1 and b"unknown knob" in lib.tg_last_error_string()
+    names = []
+    while lib.tg_debug_knob_name(len(names)) is not None:
+        names.append(lib.tg_debug_knob_name(len(names)).decode())
+    assert names == ["TG_ATTN_PP_MIN_WG", "TG_ATTN_FIXEDM", "TG_ATTN_SPLIT", "TG_GEMM_W4", "TG_CONV_SPLITK", "TG_CONV_HALO", "TG_CONV_W4"]
     # argument validation happens before any launch, so it is testable without a GPU
     assert lib.tg_gemm_bf16(None, 0, 0, None, 0, None, None, 0, 0, 1, 128, 64, 1, 0, None, 0, 0, None, None) == -1
     assert b"null pointer" in lib.tg_last_error_string()

@@ -114,20 +114,42 @@ def test_attention_lse_on_the_constant_shift_kernel_and_its_backward():
 
 
 
-def test_attention_bwd_cross_check_kernels_in_a_child_process():
-    """TG_ATTN_BWD_V1=1 selects the correct-first backward kernels (LDS-staged 64 x 64 tiles, explicit transposes) kept as the cross-check of the
-    register-resident ones: the same autograd comparison must hold for them (the switch is read once per process, hence the child)."""
+@pytest.mark.parametrize("B,H,nq,nk", [(1, 2, 200, 333), (2, 4, 1100, 260)])
+def test_attention_bwd_product_kernels_vs_the_independent_cross_check_library(B, H, nq, nk):
+    """tests/libtg_crosscheck.so (tests/csrc/attention_bwd_crosscheck.hip: correct-first kernels — LDS-staged 64 x 64 tiles, explicit transposes, a
+    one-thread-per-query statistics pass; TEST-ONLY, never in the product library) is an independent implementation of the same mathematics: it must pass
+    the same autograd comparison, and the product kernels must agree with it to bf16-operand rounding.  Both are called through their C ABIs."""
+    import ctypes as C
     import os
-    import subprocess
-    import sys
-    name, val = "TG_ATTN_BWD_V1", "1"
-    if os.environ.get("TG_ATTN_BWD_V1") == "1":
-        pytest.skip("already inside the cross-check run")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "test_attention_bwd_vs_autograd", "-x"],
-                       env=dict(os.environ, **{name: val}), capture_output=True, text=True, timeout=600,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
+    from tokensgen_amd import kernels as K
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtg_crosscheck.so")
+    assert os.path.exists(so), "build it: python -c 'import __graft_entry__ as g; g.build()' (make -C tests/csrc)"
+    x = C.CDLL(so)
+    vp, l, i, f = C.c_void_p, C.c_long, C.c_int, C.c_float
+    x.tgx_attention_bwd.argtypes = [vp, l, l] * 5 + [vp, l, l] * 3 + [i, i, i, i, f, i, vp, vp, vp]
+    x.tgx_attention_bwd.restype = C.c_int
+    x.tgx_last_error_string.restype = C.c_char_p
+    scale = 1.0 / math.sqrt(64)
+    D = H * 64
+    fused = _rand(B, max(nq, nk), 3 * D, seed=11, scale=1.5)
+    q, k, v = fused[:, :nq, :D], fused[:, :nk, D:2 * D], fused[:, :nk, 2 * D:]
+    g = _rand(B, nq, D, seed=12)
+    qf, kf, vf = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    o = _sdpa(qf, kf, vf, H, scale)
+    (o * g.float()).sum().backward()
+    fd, od, gd = fused.to(DEV), o.detach().to(BF).to(DEV), g.to(DEV)
+    qd, kd, vd = fd[:, :nq, :D], fd[:, :nk, D:2 * D], fd[:, :nk, 2 * D:]
+    dq, dk, dv = (torch.full((B, n, D), float("nan"), dtype=torch.float32, device=DEV) for n in (nq, nk, nk))
+    ws = torch.empty(2 * B * H * nq, dtype=torch.float32, device=DEV)
+    st = lambda t: (t.data_ptr(), t.stride(1), t.stride(0))
+    rc = x.tgx_attention_bwd(*st(qd), *st(kd), *st(vd), *st(od), *st(gd), *st(dq), *st(dk), *st(dv), nq, nk, H, B, scale, 0, None, ws.data_ptr(),
+                             torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, x.tgx_last_error_string()
+    torch.cuda.synchronize()
+    assert _rel(dv, vf.grad) < 4.5e-3 and _rel(dq, qf.grad) < 5.5e-3 and _rel(dk, kf.grad) < 5.5e-3
+    pq, pk, pv = K.attention_bwd(qd, kd, vd, od, gd, H, scale)
+    K.attention_bwd_check(DEV)
+    assert _rel(pq, dq) < 5e-3 and _rel(pk, dk) < 5e-3 and _rel(pv, dv) < 4e-3
 
 
 def test_attention_bwd_poll_timeout_is_reported_not_silent():
@@ -138,7 +160,7 @@ def test_attention_bwd_poll_timeout_is_reported_not_silent():
     word is clear and an ordinary call is exact again."""
     import os
     from tokensgen_amd import kernels as K
-    if os.environ.get("TG_ATTN_BWD_FUSED") == "0" or os.environ.get("TG_ATTN_BWD_V1") == "1":
+    if os.environ.get("TG_ATTN_BWD_FUSED") == "0":
         pytest.skip("the one-kernel form is switched off in this run")
     st = K.BwdDeviceState.get(DEV)
     assert st.one_kernel, "tg_attention_bwd_probe failed on this device: the one-kernel backward would never be selected"
@@ -207,7 +229,7 @@ def test_attention_bwd_one_kernel_form_after_multi_stream_graph_work_in_a_child_
     import os
     import subprocess
     import sys
-    if os.environ.get("TG_ATTN_BWD_FUSED") == "0" or os.environ.get("TG_ATTN_BWD_V1") == "1":
+    if os.environ.get("TG_ATTN_BWD_FUSED") == "0":
         pytest.skip("the one-kernel form is switched off in this run")
     if os.environ.get("TG_TEST_AFTER_VAE") != "1":
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "after_multi_stream_graph_work", "-x"],
@@ -253,7 +275,7 @@ def test_attention_bwd_two_kernel_form_in_a_child_process():
     import os
     import subprocess
     import sys
-    if os.environ.get("TG_ATTN_BWD_FUSED") == "0" or os.environ.get("TG_ATTN_BWD_V1") == "1":
+    if os.environ.get("TG_ATTN_BWD_FUSED") == "0":
         pytest.skip("already inside a cross-check run")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "test_attention_bwd_vs_autograd", "-x"],
                        env=dict(os.environ, TG_ATTN_BWD_FUSED="0"), capture_output=True, text=True, timeout=600,

@@ -1,7 +1,11 @@
-// Error plumbing and version string of libtokensgen_hip.so (host only).
+// Error plumbing, version string, per-device launch prerequisites and the debug knobs of libtokensgen_hip.so (host only).
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
+#include <atomic>
+
+#include "common.h"
 #include "tokensgen_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -16,3 +20,60 @@ extern "C" int tg_set_error(int code, const char* fmt, ...) {
 
 extern "C" const char* tg_last_error_string(void) { return g_err; }
 extern "C" const char* tg_version(void) { return "tokensgen_hip 0.1 (gfx950)"; }
+
+// ---- per-device prerequisites (common.h) ----
+int tg_device_cus(void) {
+    static std::atomic<int> cus[256];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<int>& slot = cus[dev & 255];
+    int v = slot.load(std::memory_order_relaxed);
+    if (v <= 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        slot.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+bool tg_first_on_device(TgOnce& once) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    unsigned long long* w = &once.mask[(dev >> 6) & 3];
+    if (__atomic_load_n(w, __ATOMIC_ACQUIRE) & bit) return false;
+    // (two threads racing here both set the attribute: harmless, it is idempotent)
+    __atomic_fetch_or(w, bit, __ATOMIC_RELEASE);
+    return true;
+}
+
+// ---- debug knobs: dispatch overrides of the cross-check tests; see tg_debug_set in the header ----
+namespace {
+struct KnobDef { const char* name; long def; };
+const KnobDef kKnobs[TG_KNOB_COUNT] = {{"TG_ATTN_PP_MIN_WG", 1024}, {"TG_ATTN_FIXEDM", 1}, {"TG_ATTN_SPLIT", 1}, {"TG_GEMM_W4", 1},
+                                        {"TG_CONV_SPLITK", 1},       {"TG_CONV_HALO", 1},  {"TG_CONV_W4", 1}};
+std::atomic<long> g_knob[TG_KNOB_COUNT];
+std::atomic<unsigned> g_knob_set{0};
+}  // namespace
+
+long tg_knob(TgKnob k) { return (g_knob_set.load(std::memory_order_relaxed) >> k) & 1u ? g_knob[k].load(std::memory_order_relaxed) : kKnobs[k].def; }
+
+extern "C" int tg_debug_set(const char* knob, long value) {
+    for (int i = 0; knob && i < TG_KNOB_COUNT; ++i)
+        if (!strcmp(knob, kKnobs[i].name)) {
+            g_knob[i].store(value, std::memory_order_relaxed);
+            g_knob_set.fetch_or(1u << i, std::memory_order_relaxed);
+            return TG_OK;
+        }
+    return tg_set_error(TG_ERR_ARG, "tg_debug_set: unknown knob '%s'", knob ? knob : "(null)");
+}
+
+extern "C" int tg_debug_get(const char* knob, long* value) {
+    for (int i = 0; knob && value && i < TG_KNOB_COUNT; ++i)
+        if (!strcmp(knob, kKnobs[i].name)) {
+            *value = tg_knob((TgKnob)i);
+            return TG_OK;
+        }
+    return tg_set_error(TG_ERR_ARG, "tg_debug_get: unknown knob '%s'", knob ? knob : "(null)");
+}
+
+extern "C" const char* tg_debug_knob_name(int index) { return index >= 0 && index < TG_KNOB_COUNT ? kKnobs[index].name : nullptr; }

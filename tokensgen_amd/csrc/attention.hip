@@ -839,7 +839,7 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
     // 4-wave kernel with 256-row tiles (2 query blocks per wave) while those still give >= 4 workgroups per CU, else 128-row tiles.
     // Measured on MI355X at N = 17776: ping-pong 1.12-1.18 PFLOP/s, 256-row tiles 0.90, 128-row tiles 0.85.
     const long wg256 = (long)((nq + 255) / 256) * heads * batch;
-    static const long pp_min = [] { const char* e = getenv("TG_ATTN_PP_MIN_WG"); return e ? atol(e) : 1024L; }();   // the tests lower it
+    const long pp_min = tg_knob(TG_KNOB_ATTN_PP_MIN_WG);    // 1024; the cross-check tests lower it (tg_debug_set)
     const long wg512 = (long)((nq + 511) / 512) * heads * batch;
     const bool pp = wg512 >= pp_min;
     if (p.r_nq > 0 && !pp) {
@@ -852,12 +852,7 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
         const int rc = attention_launch(p, scale, k_prescaled, who, stream);
         return rc ? rc : attention_launch(r, scale, k_prescaled, who, stream);
     }
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = tg_device_cus();
     // ---- ragged last query tile: every ping-pong workgroup takes the same time, so a launch of G workgroups costs ceil(G / CUs) rounds.
     // When dropping the ragged last tile of every (head, batch) saves a round, those rows go to the 4-wave kernel in 128-row workgroups
     // right behind the ping-pong launch (same stream): N = 17776 without a rider 7.69 -> 7.53 ms, the T2To stage's N = 9442 (19 -> 18
@@ -880,8 +875,8 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
         return TG_OK;
     }
     // constant-shift softmax (attn_fwd_pp_kernel<.., FIXEDM = 1>): every segment of a k_prescaled launch carries the key-norm bound and the
-    // caller gave a retry workspace.  TG_ATTN_FIXEDM=0 forces the running-max kernel.
-    static const int fixedm_on = [] { const char* e = getenv("TG_ATTN_FIXEDM"); return e ? atoi(e) : 1; }();
+    // caller gave a retry workspace.  The TG_ATTN_FIXEDM knob = 0 (tg_debug_set) forces the running-max kernel.
+    const bool fixedm_on = tg_knob(TG_KNOB_ATTN_FIXEDM) != 0;
     bool fixedm = fixedm_on && p.prescaled && pp && p.retry;
     for (int sg = 0; sg < p.nseg && fixedm; ++sg) fixedm = p.s[sg].kn2 != nullptr;
     if (fixedm && p.r_nq > 0) fixedm = p.r_s.kn2 != nullptr;
@@ -895,8 +890,8 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
     // attn_split_combine_kernel): the tail then costs half a round, 13.5 instead of 14.  Splitting over the queries cannot do that (DESIGN §8:
     // 128-row workgroups are themselves badly quantised).  The split parents are the last R workgroups of the MAIN problem, not the riders:
     // the halves of one head's query tiles share that head's K / V in their XCD's L2, whereas every rider has a (batch, head) of its own and
-    // 256 of those streaming at once are HBM-bound.  TG_ATTN_SPLIT=0 disables; needs the caller's split workspace.
-    static const int split_on = [] { const char* e = getenv("TG_ATTN_SPLIT"); return e ? atoi(e) : 1; }();
+    // 256 of those streaming at once are HBM-bound.  The TG_ATTN_SPLIT knob = 0 disables; needs the caller's split workspace.
+    const bool split_on = tg_knob(TG_KNOB_ATTN_SPLIT) != 0;
     p.nsplit = 0;
     p.split_first = (int)grid512;
     if (pp && split_on && p.split_ws && !p.lse && grid512 > n_cu) {
@@ -910,15 +905,10 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
     // whole workgroups | halves of the split parents (rounded up to whole groups of 16 = 8 XCDs x 2 halves)
     const unsigned main_grid = (unsigned)(grid512 - p.nsplit), split_grid = (unsigned)(16 * ((p.nsplit + 7) / 8));
     constexpr size_t PP_LDS = 4 * TILE_B + 8 * 8192;
-    // launch one instantiation of the ping-pong kernel (96 KiB of dynamic LDS: the attribute is set once per instantiation)
+    // launch one instantiation of the ping-pong kernel (96 KiB of dynamic LDS: the attribute is set once per instantiation AND device)
 #define TG_PP(GRID, ...)                                                                                                            \
     do {                                                                                                                            \
-        static const bool attr_ = [] {                                                                                              \
-            (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                      4 * TILE_B + 8 * 8192);                                                                       \
-            return true;                                                                                                            \
-        }();                                                                                                                        \
-        (void)attr_;                                                                                                                \
+        TG_DYN_LDS((attn_fwd_pp_kernel<__VA_ARGS__>), 4 * TILE_B + 8 * 8192);                                                       \
         hipLaunchKernelGGL((attn_fwd_pp_kernel<__VA_ARGS__>), dim3(GRID), dim3(512), PP_LDS, stream, p);                            \
     } while (0)
     if (pp && fixedm) {

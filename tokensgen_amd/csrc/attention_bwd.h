@@ -1,5 +1,5 @@
 // Shared declarations of the attention-backward translation units (attention_bwd.hip: the kernels the entry point launches;
-// attention_bwd_ref.hip: the correct-first cross-check kernels).
+// tests/csrc/attention_bwd_crosscheck.hip: the correct-first cross-check kernels of the test-only library).
 #pragma once
 #include "common.h"
 
@@ -31,6 +31,3 @@ __device__ __forceinline__ f32x16 zero16() {
     return z;
 }
 
-
-// attention_bwd_ref.hip: dK/dV and dQ launches of the correct-first kernels (statistics in p.lse / p.dsum must be filled already)
-int tg_attention_bwd_ref_launch(const BwdParams& p, hipStream_t stream);

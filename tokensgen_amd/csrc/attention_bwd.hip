@@ -9,15 +9,12 @@
 // (tg_attention_fwd_lse); (2) dK, dV: one workgroup per 256 keys walks the query tiles; (3) dQ: one workgroup per 256 queries walks the key
 // tiles.  All products run on v_mfma_f32_32x32x16_bf16; gradients are fp32 (accumulate flag: the To2V processor's three attention calls share
 // K / V tensors, so their gradients add up).
-#include <cstdlib>
-#include <vector>
-
 #include "attention_bwd.h"
 #include "tokensgen_hip.h"
 
 namespace {
 // =================================================================================================================================
-// The kernels the entry point launches (the correct-first ones live in attention_bwd_ref.hip as the TG_ATTN_BWD_V1=1 cross-check).
+// The kernels the entry point launches (the correct-first ones live in the TEST-ONLY library, tests/csrc/attention_bwd_crosscheck.hip).
 //
 // What changed against the correct-first version, and why:
 //  * no LDS round trip for P / dS and no in-kernel transposes.  The 32x32x16 MFMA sums over 16 k values, 8 per lane half; WHICH 16 values a
@@ -1012,20 +1009,12 @@ extern "C" int tg_attention_bwd_ex(const void* q, long q_ld, long q_sb, const vo
                                     int nq, int nk, int heads, int batch, float scale, int accumulate, const float* lse, float* ws, int flags, int* status,
                                     hipStream_t stream) {
     accumulate = accumulate == 1 ? 3 : (accumulate & 3);      // bit 0: dq, bit 1: dk and dv; 1 = all three (the original meaning of the flag)
-    static const bool v1 = [] { const char* e = getenv("TG_ATTN_BWD_V1"); return e && e[0] == '1'; }();   // the cross-check kernels (attention_bwd_ref.hip)
     TG_REQUIRE(q && k && v && o && dout && dq && dk && dv && ws, TG_ERR_ARG, "tg_attention_bwd: null pointer");
     TG_REQUIRE(nq > 0 && nk > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_attention_bwd: bad shape nq=%d nk=%d heads=%d batch=%d", nq, nk, heads, batch);
     TG_REQUIRE(tg_aligned16(q) && tg_aligned16(k) && tg_aligned16(v) && tg_aligned16(o) && tg_aligned16(dout) && tg_aligned16(ws) && q_ld % 8 == 0 &&
                k_ld % 8 == 0 && v_ld % 8 == 0 && o_ld % 8 == 0 && do_ld % 8 == 0 && q_sb % 8 == 0 && k_sb % 8 == 0 && v_sb % 8 == 0 && o_sb % 8 == 0 &&
                do_sb % 8 == 0, TG_ERR_ALIGN, "tg_attention_bwd: q/k/v/o/dO need 16-byte aligned rows");
     const long nrow = (long)batch * heads * nq;               // workspace: seed rows (16 B each, first: alignment) | log-sum-exp | D
-    if (v1) {
-        const BwdParams p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, q_ld, q_sb, k_ld, k_sb, v_ld, v_sb,
-                          o_ld, o_sb, do_ld, do_sb, dq, dk, dv, dq_ld, dq_sb, dk_ld, dk_sb, dv_ld, dv_sb, ws + 4 * nrow, ws + 5 * nrow, (uint4*)ws, nq, nk, heads,
-                          batch, scale * 1.4426950408889634f, scale, accumulate, 0};
-        hipLaunchKernelGGL(attn_bwd_stats2_kernel, dim3((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), dim3(256), 0, stream, p);
-        return tg_attention_bwd_ref_launch(p, stream);
-    }
     Bwd2Params pp{};
     pp.p = BwdParams{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, q_ld, q_sb, k_ld, k_sb, v_ld, v_sb,
                      o_ld, o_sb, do_ld, do_sb, dq, dk, dv, dq_ld, dq_sb, dk_ld, dk_sb, dv_ld, dv_sb, ws + 4 * nrow, ws + 5 * nrow, (uint4*)ws, nq, nk, heads, batch,

@@ -33,6 +33,26 @@ extern "C" int tg_set_error(int code, const char* fmt, ...);
 
 static inline bool tg_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// ---- per-DEVICE launch prerequisites (api.cpp).  hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count belong to a device, not to the
+// process: a host that drives several GPUs from one process (the reference's own topology, infer_cogvideo_mp_fifo.py:191,211-213) must get them on
+// every device it launches on.  Nothing here is keyed by anything but the CURRENT device id, and nothing changes a result.
+int tg_device_cus(void);                                    // multiprocessor count of the current device (cached per device id)
+// true once per (device, slot): the caller then sets its kernel's attribute.  `slot` = a TgOnce the launcher owns (one per kernel instantiation).
+struct TgOnce { unsigned long long mask[4]; };              // one bit per device id (< 256); zero-initialised static
+bool tg_first_on_device(TgOnce& once);
+#define TG_DYN_LDS(kernel, bytes)                                                                                      \
+    do {                                                                                                               \
+        static TgOnce once__;                                                                                          \
+        if (tg_first_on_device(once__))                                                                                \
+            (void)hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes));     \
+    } while (0)
+
+// ---- dispatch overrides for the cross-check tests (tg_debug_set in the header): which of two product kernels of the same op a launcher picks.
+// The library reads no environment variable; the defaults are the shipped path.
+enum TgKnob { TG_KNOB_ATTN_PP_MIN_WG, TG_KNOB_ATTN_FIXEDM, TG_KNOB_ATTN_SPLIT, TG_KNOB_GEMM_W4, TG_KNOB_CONV_SPLITK, TG_KNOB_CONV_HALO, TG_KNOB_CONV_W4,
+              TG_KNOB_COUNT };
+long tg_knob(TgKnob k);
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ float bf16lo_to_f32(uint32_t packed) { return __uint_as_float(packed << 16); }
 __device__ __forceinline__ float bf16hi_to_f32(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }

@@ -892,39 +892,22 @@ int launch(GemmParams p, hipStream_t stream) {
         // Infinity Cache, so small groups win: measured sum over the four block GEMMs 7.61 (8) / 7.48 (4) / 7.53 (6) / 7.62 (2) ms,
         // and for K = 12288 (6.3 MB per A panel) a single m-tile per group is another 3 % faster (2.31 vs 2.34 vs 2.40 ms)
         p.group_m = p.K >= 8192 ? 1 : 4;
-        static bool attr2 = false;
-        if (!attr2) {
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, RING2_BYTES);
-            attr2 = true;
-        }
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-        }
+        const int n_cu = tg_device_cus();
         const dim3 grid2(tiles2 < n_cu ? tiles2 : n_cu);
-        static const int w4 = [] { const char* e = getenv("TG_GEMM_W4"); return e ? atoi(e) : 1; }();   // 0: the 8-wave kernel for every shape
+        const bool w4 = tg_knob(TG_KNOB_GEMM_W4) != 0;     // 0 (cross-check tests): the 8-wave kernel for every shape
         if (w4 && p.K >= 4 * BK3 && p.lda < (1L << 21) && p.ldw < (1L << 21)) {   // 32-bit buffer offsets: 256 rows * ld * 2 B < 2^31
-            static bool attr4 = false;
-            if (!attr4) {
-                (void)hipFuncSetAttribute((const void*)gemm256w4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES);
-                attr4 = true;
-            }
+            TG_DYN_LDS(gemm256w4_kernel<EPI>, W4_LDS_BYTES);
             hipLaunchKernelGGL(gemm256w4_kernel<EPI>, grid2, dim3(256), W4_LDS_BYTES, stream, p);
             TG_LAUNCH_CHECK("tg_gemm_bf16(256w4)");
             return TG_OK;
         }
+        TG_DYN_LDS(gemm256_kernel<EPI>, RING2_BYTES);
         hipLaunchKernelGGL(gemm256_kernel<EPI>, grid2, dim3(512), RING2_BYTES, stream, p);
         TG_LAUNCH_CHECK("tg_gemm_bf16(256)");
         return TG_OK;
     }
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN) * p.batch;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-        attr_set = true;
-    }
+    TG_DYN_LDS(gemm_bf16_kernel<EPI>, 2 * STAGE_BYTES);
     hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(tiles), dim3(256), 2 * STAGE_BYTES, stream, p);
     TG_LAUNCH_CHECK("tg_gemm_bf16");
     return TG_OK;
@@ -1001,7 +984,7 @@ extern "C" int tg_gemm_bf16_qkv(const void* A1, long strideA1, const void* W1, c
     TG_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && strideA1 % 8 == 0 && strideC1 % 8 == 0 && strideA2 % 8 == 0 && strideC2 % 8 == 0 &&
                tg_aligned16(A1) && tg_aligned16(W1) && tg_aligned16(C1) && tg_aligned16(Vt1) && tg_aligned16(A2) && tg_aligned16(W2) &&
                tg_aligned16(C2) && tg_aligned16(Vt2), TG_ERR_ALIGN, "tg_gemm_bf16_qkv: alignment");
-    static const bool w4_off = [] { const char* e = getenv("TG_GEMM_W4"); return e && atoi(e) == 0; }();
+    const bool w4_off = tg_knob(TG_KNOB_GEMM_W4) == 0;
     TG_REQUIRE(lda < (1L << 21) && ldw < (1L << 21), TG_ERR_SHAPE, "tg_gemm_bf16_qkv: leading dimensions must be < 2^21 elements");
     TG_REQUIRE(!w4_off, TG_ERR_ARG, "tg_gemm_bf16_qkv: only the 4-wave GEMM kernel has the V^T epilogue (TG_GEMM_W4=0 is set)");
     GemmParams p{};

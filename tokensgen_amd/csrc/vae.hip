@@ -590,7 +590,10 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo2_kernel(ConvParams p) {
                 gq[ni] += __shfl_xor(gq[ni], off, 64);
             }
         }
-        float* red = (float*)smem;                        // LDS is idle: the stage loop ended with a barrier
+        // The stage loop leaves the weight pieces of its last (past-the-end, never read) stages in flight — its final wait is vmcnt(WP) — and they land in the
+        // weight ring; `red` reuses the head of the halo area.  Drain them before LDS is reused at all, so that no ring / `red` placement can ever race.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float* red = (float*)smem;
         if ((lane & 15) == 0) {
 #pragma unroll
             for (int ni = 0; ni < 8; ++ni) {
@@ -1661,8 +1664,7 @@ inline unsigned grid_for(long total, int block = 256) { return (unsigned)min((to
 // is long; aims at ~2 workgroups per CU (the kernel waits on every stage: a second resident workgroup hides that), >= 8 K steps per range.
 // TG_CONV_SPLITK=0 disables it (A/B runs, and the bitwise 4-wave-vs-128 test).  The w4 kernels are chosen first where they apply.
 static int conv_ksplit(long M, int cout, int cout_pad, long nk, int n_cu) {
-    static const int on = [] { const char* e = getenv("TG_CONV_SPLITK"); return e ? atoi(e) : 1; }();
-    if (!on || cout != cout_pad || cout_pad % BN != 0 || cout > 512 || nk < 32) return 1;
+    if (!tg_knob(TG_KNOB_CONV_SPLITK) || cout != cout_pad || cout_pad % BN != 0 || cout > 512 || nk < 32) return 1;
     const long tiles = ((M + BM - 1) / BM) * (cout_pad / BN);
     if (tiles >= n_cu) return 1;
     long ks = (2L * n_cu) / tiles;            // FLOOR: tiles * ks must not exceed the 2 n_cu resident slots — the first version rounded up, and the most common
@@ -1687,6 +1689,9 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
         const long tiles_in = (long)To * ((Ho + H2_PH - 1) / H2_PH) * ((Wo + H2_PW - 1) / H2_PW), rows_in = ((long)To * Ho * Wo + BM - 1) / BM;
         TG_REQUIRE(tiles_in < (1L << 31) && (long)(T + 2) * H * W * 8 < (1L << 31), TG_ERR_SHAPE, "tg_conv3d_cl: too many tiles");
         TG_REQUIRE(!gn_partial || rows_in <= 4 * tiles_in, TG_ERR_SHAPE, "tg_conv3d_cl: GroupNorm sums need <= 4 rows of 128 voxels per 16 x 32 patch");
+        // every patch writes gn_partial[patch * 64 ..]: the buffer (tg_conv3d_gn_partial_floats) has one row per 128 voxels, so there may not be more patches than rows
+        TG_REQUIRE(!gn_partial || tiles_in <= rows_in, TG_ERR_SHAPE, "tg_conv3d_cl: GroupNorm sums need at least as many 128-voxel rows (%ld) as 16 x 32 patches (%ld)",
+                   rows_in, tiles_in);
         ConvParams pi{(const bf16_t*)x, T, H, W, Cin, (const bf16_t*)cache, (const bf16_t*)w, (const bf16_t*)bias, cout, cout_pad, kt, kh, kw,
                       stride, pad, up, nullptr, nullptr, (bf16_t*)y, ldy, To, Ho, Wo, (const bf16_t*)zeros, gn_partial, 1, nullptr};
         hipLaunchKernelGGL(conv3d_in_kernel, dim3((unsigned)tiles_in), dim3(512), CI_LDS, stream, pi);
@@ -1704,21 +1709,15 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
     TG_REQUIRE(!gn_partial || (cout == cout_pad && cout % BN == 0 && (cout / GN_GROUPS) % 4 == 0), TG_ERR_SHAPE,
                "tg_conv3d_cl: fused GroupNorm sums need cout in {128, 256, 512, ...} (cout=%d)", cout);
     const long M = (long)To * Ho * Wo;
-    static const int halo_on = [] { const char* e = getenv("TG_CONV_HALO"); return e ? atoi(e) : 1; }();   // 0 never, 1 (default) at launch scale, 2 whenever legal (tests)
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    }
+    const int halo_on = (int)tg_knob(TG_KNOB_CONV_HALO);    // 0 never, 1 (default) at launch scale, 2 whenever legal (cross-check tests, tg_debug_set)
+    const int n_cu = tg_device_cus();
     if (cout_pad % BN != 0 && halo_on && cout <= 4 && Cin == 128 && kt == 3 && kh == 3 && kw == 3 && pad == 1 && stride == 1 && up == 1 && !t_map && !residual &&
         To == T && Ho == H && Wo == W && (long)(T + 2) * H * W * Cin < (1L << 31)) {
         // the decoder's conv_out: halo-tiled, weights resident in LDS (17.7 -> 3 ms per decode against the 128 x 16 GEMM-shaped tile below)
         const long h2tiles = (long)To * ((Ho + H2_PH - 1) / H2_PH) * ((Wo + H2_PW - 1) / H2_PW);
         if ((halo_on == 2 || h2tiles >= n_cu) && h2tiles < (1L << 31)) {
             const int lds = 2 * H2_HALO_BYTES + (cout + 1) * (27 * 128 * 2 + 64);
-            static bool attrn = false;
-            if (!attrn) { (void)hipFuncSetAttribute((const void*)conv3d_halo_narrow_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * H2_HALO_BYTES + 5 * (27 * 128 * 2 + 64)); attrn = true; }
+            TG_DYN_LDS((conv3d_halo_narrow_kernel<128, 3>), 2 * H2_HALO_BYTES + 5 * (27 * 128 * 2 + 64));
             hipLaunchKernelGGL((conv3d_halo_narrow_kernel<128, 3>), dim3((unsigned)h2tiles), dim3(512), lds, stream, p);
             TG_LAUNCH_CHECK("tg_conv3d_cl(halo narrow)");
             return TG_OK;
@@ -1727,8 +1726,7 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
     if (cout_pad % BN != 0) {          // narrow output (conv_out): 128 voxels x 16 channels per workgroup
         const long tiles16 = ((M + BM - 1) / BM) * (cout_pad / 16);
         TG_REQUIRE(tiles16 < (1L << 31), TG_ERR_SHAPE, "tg_conv3d_cl: too many tiles");
-        static bool attr16 = false;
-        if (!attr16) { (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel<1, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES); attr16 = true; }
+        TG_DYN_LDS((conv3d_cl_kernel<1, 2, 1>), 2 * STAGE_BYTES);
         hipLaunchKernelGGL((conv3d_cl_kernel<1, 2, 1>), dim3((unsigned)tiles16), dim3(256), 2 * STAGE_BYTES, stream, p);
         TG_LAUNCH_CHECK("tg_conv3d_cl(n16)");
         return TG_OK;
@@ -1740,7 +1738,7 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
     // flop — half of the 128 x 128 kernel's.  Swept in round 4 (decode / encode wall, same box): 2 n_cu 0.469 / 0.246 s, n_cu 0.461 / 0.233, n_cu/2 0.446 / 0.228,
     // n_cu/5 0.441 / 0.226, n_cu/8 0.436 / 0.220, n_cu/12 0.451 / 0.224 (there the 512-channel layers at 30 x 45 — 22 tiles — leave split-K).
     // TG_CONV_W4=0: never, 2: whenever legal
-    static const int w4 = [] { const char* e = getenv("TG_CONV_W4"); return e ? atoi(e) : 1; }();
+    const int w4 = (int)tg_knob(TG_KNOB_CONV_W4);
     // Cout = 128, 3x3 spatial taps, stride 1, no upsampling: the halo-tiled kernel.  Against the GEMM-shaped kernels on the 8 x 240 x 360 layers:
     // 128 -> 128: 0.70 vs 0.74 ms per launch; per clip 64 -> 128 (encoder conv_in) 13.3 vs 17.5 ms, 256 -> 128 45.6 vs 51.2 ms.  Why not more:
     // see the stage loop's comment (the fill does not overlap with the issuing wave's MFMAs).
@@ -1753,8 +1751,7 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
         if (halo_on && (cout == 128 || (cout == 256 && halo_on == 2)) && cout_pad == cout && kh == 3 && kw == 3 && pad == 1 && stride == 1 && up == 1 && !t_map && (kt == 1 || kt == 3) &&
             To == T && Ho == H && Wo == W && (halo_on == 2 || h2tiles >= n_cu) && h2tiles <= rows128 &&
             rows128 <= 4 * h2tiles && (long)(T + 2) * H * W * Cin < (1L << 31) && h2tiles < (1L << 31)) {
-            static bool attrh = false;
-            if (!attrh) { (void)hipFuncSetAttribute((const void*)conv3d_halo2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS); attrh = true; }
+            TG_DYN_LDS((conv3d_halo2_kernel<8>), H2_LDS);
             // 8 waves (two per SIMD): 0.716 vs 0.730 ms (128 -> 128 at 8 x 240 x 360), 1.19 vs 1.26 ms (256 -> 128) against the one-wave-per-SIMD form of
             // the same kernel, same box (profiles/NOTES.md, round 4)
             hipLaunchKernelGGL(conv3d_halo2_kernel<8>, dim3((unsigned)(h2tiles * (cout / 128))), dim3(512), H2_LDS, stream, p);
@@ -1764,8 +1761,7 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
     }
     if (w4 && (w4 == 2 || ((M + 255) / 256) * (cout / 256) >= n_cu / 8) && cout == cout_pad && cout % 256 == 0 && !t_map && M >= 1024 && (long)kt * kh * kw * (Cin / 64) >= 4 && H * up < 2048 && W * up < 2048 &&
         To < 512 && Ho < 2048 && Wo < 2048 && (long)kt * kh * kw * Cin < (1L << 21) && (long)(T + 2) * H * W * Cin < (1L << 31)) {
-        static bool attr4 = false;
-        if (!attr4) { (void)hipFuncSetAttribute((const void*)conv3d_w4_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS); attr4 = true; }
+        TG_DYN_LDS((conv3d_w4_kernel<256>), CW_LDS);
         const long tiles4 = ((M + 255) / 256) * (cout / 256);
         hipLaunchKernelGGL(conv3d_w4_kernel<256>, dim3((unsigned)tiles4), dim3(256), CW_LDS, stream, p);
         TG_LAUNCH_CHECK("tg_conv3d_cl(w4)");
@@ -1777,15 +1773,13 @@ extern "C" int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const v
         (long)kt * kh * kw * (Cin / 64) >= 4 && H < 2048 && W < 2048 && To < 512 && Ho < 2048 && Wo < 2048 && (long)kt * kh * kw * Cin < (1L << 21) &&
         (long)(T + 2) * H * W * Cin < (1L << 31)) {
         constexpr int LDS_N = 2 * (512 * 128 + 128 * 128);
-        static bool attrn = false;
-        if (!attrn) { (void)hipFuncSetAttribute((const void*)conv3d_w4_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_N); attrn = true; }
+        TG_DYN_LDS((conv3d_w4_kernel<128>), LDS_N);
         const long tiles5 = (M + 511) / 512;
         hipLaunchKernelGGL(conv3d_w4_kernel<128>, dim3((unsigned)tiles5), dim3(256), LDS_N, stream, p);
         TG_LAUNCH_CHECK("tg_conv3d_cl(w4n)");
         return TG_OK;
     }
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)conv3d_cl_kernel<2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES); attr = true; }
+    TG_DYN_LDS((conv3d_cl_kernel<2, 4, 4>), 2 * STAGE_BYTES);
     // split-K: the small-M layers (the 512-channel layers at 30 x 45 latent: 88 tiles for 256 CUs, each walking 216 K steps alone on its CU)
     p.ksplit = conv_ksplit(M, cout, cout_pad, (long)kt * kh * kw * (Cin / BK), n_cu);
     if (p.ksplit > 1) {

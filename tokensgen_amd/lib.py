@@ -91,6 +91,8 @@ QUERIES = {
 }
 
 TG_BWD_ONE_KERNEL = 1
+# declared in the header besides PROTOTYPES and QUERIES (bound by hand in load())
+OTHER_EXPORTS = ("tg_version", "tg_last_error_string", "tg_debug_set", "tg_debug_get", "tg_debug_knob_name")
 
 _lib = None
 
@@ -114,8 +116,30 @@ def load():
         fn.restype = C.c_long
     lib.tg_version.restype = C.c_char_p
     lib.tg_last_error_string.restype = C.c_char_p
+    lib.tg_debug_set.argtypes, lib.tg_debug_set.restype = [C.c_char_p, C.c_long], C.c_int
+    lib.tg_debug_get.argtypes, lib.tg_debug_get.restype = [C.c_char_p, C.POINTER(C.c_long)], C.c_int
+    lib.tg_debug_knob_name.argtypes, lib.tg_debug_knob_name.restype = [C.c_int], C.c_char_p
     _lib = lib
+    # The library itself reads no environment variable.  The cross-check tests select between two product kernels of one operator per child process:
+    # same-named environment variables are forwarded to tg_debug_set here, once, at load time (header: "Dispatch overrides for the cross-check tests").
+    i = 0
+    while True:
+        name = lib.tg_debug_knob_name(i)
+        if name is None:
+            break
+        if os.environ.get(name.decode()) not in (None, ""):
+            check(lib.tg_debug_set(name, int(os.environ[name.decode()])), f"tg_debug_set({name.decode()})")
+        i += 1
     return lib
+
+
+def debug_set(knob, value):
+    """tg_debug_set: dispatch override for a cross-check test (see the header); returns the previous value."""
+    lib = load()
+    old = C.c_long(0)
+    check(lib.tg_debug_get(knob.encode(), C.byref(old)), f"tg_debug_get({knob})")
+    check(lib.tg_debug_set(knob.encode(), int(value)), f"tg_debug_set({knob})")
+    return old.value
 
 
 def check(code, what):
