@@ -32,10 +32,12 @@ def _rand(*shape, seed, scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).to(BF)
 
 
-@pytest.mark.parametrize("B,H,nq,nk", [(1, 2, 50, 70), (2, 3, 513, 1500), (1, 1, 64, 64), (1, 4, 200, 33), (1, 8, 1100, 700), (2, 4, 2500, 300)])
+@pytest.mark.parametrize("B,H,nq,nk", [(1, 2, 50, 70), (2, 3, 513, 1500), (1, 1, 64, 64), (1, 4, 200, 33), (1, 8, 1100, 700), (2, 4, 2500, 300),
+                                       (2, 4, 1030, 257), (1, 8, 4100, 1000), (1, 8, 129, 5)])
 def test_attention_bwd_vs_autograd(B, H, nq, nk):
-    """(the last two shapes — 8 (batch, head) pairs, >= 4 query tiles per key block — take the one-kernel form; TG_ATTN_BWD_FUSED=0 in the child run
-    below sends them through the two-kernel form as well)"""
+    """(the shapes from the fifth on — 8 (batch, head) pairs, >= 4 query tiles per key block — take the one-kernel form: ragged last query tile, a key
+    block with a single key, 4 key blocks chained, the smallest legal call; TG_ATTN_BWD_FUSED=0 in the child run below sends them through the two-kernel
+    form as well)"""
     from tokensgen_amd import kernels as K
     scale = 1.0 / math.sqrt(64)
     # q|k|v as column slices of one fused buffer (what the QKV GEMM writes): exercises the row / batch strides

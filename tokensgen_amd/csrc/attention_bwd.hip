@@ -925,6 +925,383 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
     }
 }
 
+// =================================================================================================================================
+// The one-kernel backward as a TWO-GROUP PING-PONG (round 5): attn_bwd_dkdv7_kernel's structure — every wave alternates a matrix segment X (all MFMAs, all
+// LDS reads, every read issued three fragment groups ahead of its use) and a vector segment Y (VALU, LDS writes, global traffic), one s_barrier after
+// each, waves 4-7 one segment behind waves 0-3 — with the dQ product and the ordered dQ exchange of attn_bwd_fused_kernel laid INTO those segments.
+// The in-phase one-kernel form ran at 0.78 PFLOP/s on the 17776^2 call (every wave of a SIMD in the same phase: their MFMA blocks collide, their softmax
+// blocks collide, the matrix pipe idles through both softmaxes), and on all-zero operands it gained only 5.6 % where the forward gained 27 %: schedule-bound.
+//   X(t) = { dQ^T partial of tile t-2 ; dV += P(t-1)^T dO(t-1), dK += dS(t-1)^T Q(t-1) ; S(t) = Q(t) K^T, dP(t) = dO(t) V^T }
+//          8 MFMAs 16x16x32 + 18 MFMAs 32x32x16, 32 transposed b64 + 9 b128 LDS reads, 2 b128 LDS writes (the dQ partial)
+//   Y(t) = { exchange of tile t - lag (read-add-write of 16 bytes per thread) ; stage write + fetch of a later tile ; P = exp2(S), dS = P o dP -> bf16 A operands,
+//            dS^T -> LDS }                                                                                                VALU + memory only
+// dQ: a GROUP (4 waves, 128 keys) forms its own partial of the tile's dQ^T [64 d][32 q] — wave w the two 16 x 16 blocks of head dims 16 w .. over both query
+// halves, A = its K rows (resident, 16 AGPRs), B = the group's dS^T blocks through transposed reads — TWO tiles behind the softmax that wrote them: a
+// dS^T block written in Y(t) is complete when its writer's X(t+1) has drained its LDS queue, so X(t+2) reads it with no wait anywhere (two slots).  The two
+// groups' partials meet in LDS ([group][slot][32 q][64 d] fp32) and are added by the exchange: group g owns rows 16 g .. 16 g + 15 of every tile and is its own
+// chain (counter word g of the tile's line): key block kb's group g adds to what key block kb - 1's group g left — in key-block order, bitwise reproducible,
+// no atomics on the data; coherence through the XCD's L2 exactly as in the in-phase form (plain stores, one buffer_inv sc1 per workgroup, sc1 polls).
+//   tile T: dS^T in Y(T) -> partial in X(T+2) -> [group 1: exchanged in Y(T+2); group 0: in Y(T+3)] -> acknowledged at the top of the next Y -> signalled
+//   at the head of the X after that.  The loop runs PP_EXTRA masked tiles past the last one (P = dS = 0 exactly: they add nothing to dK / dV) instead of a drain.
+// UNIT: scale * log2(e) == 1 (the training step hands over K prescaled by scale * log2 e and scale = ln 2): exp2 of the accumulator, no multiply.
+// =================================================================================================================================
+constexpr int PP_EXTRA = 3;
+constexpr int PP_RING = 4;
+constexpr int PP_ST_BYTES = 2 * PP_RING * ROWT_EL * 2;          // Q | dO tiles
+constexpr int PP_SEED_BYTES = PP_RING * 64 * 16;
+constexpr int PP_DS_SLOT = 256 * DSLD * 2;                      // one dS^T tile [256 keys][DSLD] bf16
+constexpr int PP_DQ_SLOT = BT * DQLD * 4;                       // one dQ partial [32 q][DQLD] fp32
+constexpr int PP_LDS = PP_ST_BYTES + PP_SEED_BYTES + 2 * PP_DS_SLOT + 4 * PP_DQ_SLOT;
+
+// global accesses of the vector segment: wave-uniform 64-bit base in SGPRs + a 32-bit lane offset.  A tile step is then ONE scalar add — VALU instructions
+// are the currency of Y (the partner wave's MFMA stream owns the issue port: ~13 cycles per VALU instruction there)
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;      // (a native vector: HIP's uint4 struct cannot be a tied "+v" asm operand)
+__device__ __forceinline__ u32x4 mask16v(u32x4 v, bool ok) { return u32x4{ok ? v[0] : 0u, ok ? v[1] : 0u, ok ? v[2] : 0u, ok ? v[3] : 0u}; }
+__device__ __forceinline__ u32x4 sel16v(bool c, u32x4 a, u32x4 b) { return u32x4{c ? a[0] : b[0], c ? a[1] : b[1], c ? a[2] : b[2], c ? a[3] : b[3]}; }
+__device__ __forceinline__ void gld16(u32x4& dst, const void* sbase, uint32_t voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void gld16f(f32x4& dst, const void* sbase, uint32_t voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void gst16f(const f32x4& v, void* sbase, uint32_t voff) {
+    asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+
+template <bool UNIT>
+__global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) {
+    const BwdParams& p = fp.p;
+    constexpr int RING = PP_RING;
+    constexpr int DO_OFF = RING * ROWT_EL * 2;              // byte distance Q tile b -> dO tile b
+    extern __shared__ __attribute__((aligned(16))) char psm[];
+    bf16_t* const sT = (bf16_t*)psm;                                                   // [2][RING][ROWT_EL]: [0] Q tiles, [1] dO tiles
+    uint4* const sSt = (uint4*)(psm + PP_ST_BYTES);                                    // [RING][64] seed rows (entries 32..63 stay zero)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wg = wave & 3;
+    const int j = lane & 31, hi = lane >> 5, t16 = lane & 15, g4 = lane >> 4;
+    int blk, hb;
+    xcd_block((p.nk + 255) / 256, p.heads * p.batch, blk, hb);
+    const int h = hb % p.heads, b = hb / p.heads;
+    const int kw0 = blk * 256 + wave * 32;
+    const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
+    const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
+    const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
+    const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
+    const long stat0 = ((long)b * p.heads + h) * p.nq;
+    // placement self-check (see attn_bwd_fused_kernel): every key block of a head on ONE XCD
+    int xold = 0, xbit = 0;
+    if (tid == 0) {
+        xbit = 1 << (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u);           // HW_REG_XCC_ID, bits 3:0
+        xold = __hip_atomic_fetch_or(fp.xmask + hb, xbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const long r = min(kw0 + j, p.nk - 1);
+        load_frag_agpr(kf[ks], Kp + r * p.k_ld + ks * 16 + hi * 8);
+        load_frag_agpr(vf[ks], Vp + r * p.v_ld + ks * 16 + hi * 8);
+    }
+    TG_WAIT_FRAGS1(kf);
+    TG_WAIT_FRAGS1(vf);
+    if (tid == 0 && (xold & ~xbit)) atomicAdd(fp.status + 2, 1);
+    Frag oS, oD;                                            // B operands of the seed k-step (k-slots 0..2 -> S, 3..5 -> dP; lanes hi = 0 only)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { oS.w[w] = 0; oD.w[w] = 0; }
+    if (hi == 0) { oS.w[0] = 0x3F803F80u; oS.w[1] = 0x00003F80u; oD.w[1] = 0x3F800000u; oD.w[2] = 0x3F803F80u; }
+    f32x16 dk[2], dv[2];                                   // [d block]: rows = keys, column = head dim j
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { dk[c] = zero16(); dv[c] = zero16(); }
+    // dQ^T blocks of this wave: head dims 16 wg .. 16 wg + 15 x queries (16 qh .. ), qh = 0, 1, over the GROUP's 128 keys = 4 k-steps of 32.
+    // A operand (rows = head dims, k = keys): lane (t16, g4) holds K[key 8 g4 + e][16 wg + t16], e = 0..7, of the k-step's 32 keys (zero beyond nk); resident
+    Frag kq[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const int k0 = blk * 256 + 128 * grp + 32 * ks + 8 * g4 + e;
+            const uint32_t lo = k0 < p.nk ? Kp[(long)k0 * p.k_ld + 16 * wg + t16] : 0u;
+            const uint32_t hi16 = k0 + 1 < p.nk ? Kp[(long)(k0 + 1) * p.k_ld + 16 * wg + t16] : 0u;
+            kq[ks].w[e >> 1] = lo | (hi16 << 16);
+        }
+    // ---- staging: group 0's threads own Q (+ wave 0, lanes 0..31: the seed rows), group 1's dO; one 16-byte chunk per thread and tile ----
+    const int t8 = tid & 255, row = t8 >> 3, chunk = (t8 & 7) * 8;
+    const long ldR = grp ? p.do_ld : p.q_ld;
+    const int ntile = (p.nq + BT - 1) / BT;
+    const int qlast = (ntile - 1) * BT;
+    const char* sbR = (const char*)(grp ? dO : Q);          // scalar: base of the tile the next fetch() loads
+    const long stepRb = (long)BT * ldR * 2;
+    const uint32_t voR = (uint32_t)(((long)row * ldR + chunk) * 2);
+    const uint32_t voRLast = (uint32_t)(((long)(min(qlast + row, p.nq - 1) - qlast) * ldR + chunk) * 2);
+    const char* sbS = (const char*)(p.seed + stat0);
+    const uint32_t voS = (uint32_t)j * 16u, voSLast = (uint32_t)(min(qlast + j, p.nq - 1) - qlast) * 16u;
+    const bool okLast = qlast + row < p.nq, okSLast = qlast + j < p.nq;
+    bf16_t* const dstR = sT + (grp * RING) * ROWT_EL + row * LQ2 + chunk;
+    u32x4 maskrow;                                          // seed row of a masked query: l = -1e30 (P = exp2(s - 1e30) = 0), d = 0
+    {
+        uint32_t l1, l2, l3;
+        split_bf16x3(-1e30f, l1, l2, l3);
+        maskrow = u32x4{(l1 >> 16) | l2, l3 >> 16, 0u, 0u};
+    }
+    u32x4 g0 = u32x4{0, 0, 0, 0}, gseed = maskrow;
+    int tf = 0;                                             // tile the next fetch() loads
+    int kindF = 0;                                          // of the tile held in g0: 0 wholly inside the query range, 1 the (ragged) last tile, 2 past the end (all masked)
+    auto fetch = [&]() {
+        kindF = tf < ntile - 1 ? 0 : (tf == ntile - 1 ? 1 : 2);
+        gld16(g0, sbR, kindF == 0 ? voR : voRLast);
+        if (wave == 0) gld16(gseed, sbS, kindF == 0 ? voS : voSLast);
+        if (tf < ntile - 1) { sbR += stepRb; sbS += BT * 16; }       // (tiles past the end re-read the last tile's rows: in bounds, masked below)
+        ++tf;
+    };
+    auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0), "+v"(gseed)); };
+    auto stash = [&](int buf) {
+        if (kindF == 0) {
+            *(u32x4*)(dstR + buf * ROWT_EL) = g0;
+            if (wave == 0 && hi == 0) *(u32x4*)(sSt + buf * 64 + j) = gseed;
+        } else {
+            *(u32x4*)(dstR + buf * ROWT_EL) = mask16v(g0, kindF == 1 && okLast);
+            if (wave == 0 && hi == 0) *(u32x4*)(sSt + buf * 64 + j) = sel16v(kindF == 1 && okSLast, gseed, maskrow);
+        }
+    };
+    // prologue: Q(0), Q(1) + their seed rows, dO(0..2); the buffers of "tile -1" (index RING - 1) zeroed — X(0) multiplies them by P = dS = 0
+    *(uint4*)(dstR + (RING - 1) * ROWT_EL) = uint4{0, 0, 0, 0};
+    if (wave == 0 && hi == 1) {
+#pragma unroll
+        for (int bb = 0; bb < RING; ++bb) sSt[bb * 64 + lane] = uint4{0, 0, 0, 0};
+    }
+    fetch(); landed(); stash(0);
+    fetch(); landed(); stash(1);
+    fetch();
+    if (grp == 1) {
+        landed(); stash(2);
+        fetch();
+    }
+    Frag pA[2], dA[2];                                      // P^T / dS^T A operands, carried from Y(t) to X(t+1)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { pA[t].w[w] = 0; dA[t].w[w] = 0; }
+    f32x16 s, dp;                                           // rows = queries, column = key j
+    // ---- LDS lane bases ----
+    const uint32_t lds0 = lds_addr(psm);
+    const uint32_t offA = (uint32_t)((j * LQ2 + hi * 8) * 2);
+    const uint32_t offB = (uint32_t)(((4 * hi + ((lane & 15) >> 2)) * LQ2 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2);
+    const uint32_t ldsT = lds0, ldsS = lds0 + PP_ST_BYTES + (uint32_t)lane * 16;
+    const uint32_t ldsDS = lds0 + PP_ST_BYTES + PP_SEED_BYTES, ldsDQ = ldsDS + 2 * PP_DS_SLOT;
+    // dS^T [256 keys][DSLD]: this lane writes keys row (wave * 32 + j), queries 8 g + 4 hi .. (Y); reads the group's rows through transposed 4 x 16 blocks (X)
+    const uint32_t dsW = ldsDS + (uint32_t)(((wave * 32 + j) * DSLD + 4 * hi) * 2);
+    const uint32_t dsR = ldsDS + (uint32_t)(((128 * grp + 8 * g4 + (t16 >> 2)) * DSLD + (t16 & 3) * 4) * 2);
+    // dQ partial [group][slot][32 q][DQLD]: this wave's two blocks land at rows (16 qh + t16), columns 16 wg + 4 g4 ..
+    const uint32_t dqW = ldsDQ + (uint32_t)(grp * 2 * PP_DQ_SLOT) + (uint32_t)((t16 * DQLD + 16 * wg + 4 * g4) * 4);
+    // exchange: group g owns rows 16 g + (t8 >> 4) of every tile, 16 lanes cover one whole 256-byte dQ row (full lines, as in the in-phase form)
+    const int er = 16 * grp + (t8 >> 4), ec = (t8 & 15) * 4;
+    const uint32_t dqR = ldsDQ + (uint32_t)((er * DQLD + ec) * 4);
+    char* sbDQr = (char*)(p.dq + (long)b * p.dq_sb + h * HD);                    // scalar: dQ rows of the tile the next request loads
+    char* sbDQw = sbDQr;                                                         //         ... the next write stores
+    const long stepDQb = (long)BT * p.dq_ld * 4;
+    const uint32_t voDQ = (uint32_t)(((long)er * p.dq_ld + ec) * 4);
+    const uint32_t voDQLast = (uint32_t)(((long)(min(qlast + er, p.nq - 1) - qlast) * p.dq_ld + ec) * 4);
+    const bool okDQLast = qlast + er < p.nq;
+    const bool first = blk == 0 && !(p.accumulate & 1);      // nothing to read: this workgroup's block starts the sum
+    constexpr int CNT_PAD = 32;                               // one 128-byte line per (head, tile); word g = group g's chain
+    int* const cntw = fp.cnt + (long)hb * ntile * CNT_PAD + grp;
+    const int lag = 3 - grp;                                 // Y(u) exchanges tile u - lag (both groups' partials of it are complete and behind a barrier)
+    f32x4 ldv = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cval = 0;                                           // (wave 4 g) counter of the next tile to check, sampled one Y ahead
+    asm volatile("buffer_inv sc1" ::: "memory");            // ONCE per workgroup (see attn_bwd_fused_kernel)
+    Frag fr[4][2];
+    f32x4 qa0, qa1;                                         // this wave's dQ^T blocks (query halves 0, 1)
+#define PP_RD_T(dst, base, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "i"(off))
+#define PP_RD_A(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "i"(off))
+#define PP_WAIT(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0].v), "+v"(f[1].v))
+    // fragment group i of X: 0..3 = dS^T blocks of k-step i (query halves 0 | 1) of tile t - 2; 4..7 = transposed dO | Q blocks (t2 = (i - 4) >> 1, db = (i - 4) & 1) of
+    // tile t - 1; 8 = seed row of tile t; 9..12 = Q | dO rows of k-step i - 9 of tile t
+#define PP_ISSUE(i)                                                                                                               \
+        do {                                                                                                                      \
+            Frag(&f)[2] = fr[(i) & 3];                                                                                            \
+            if ((i) < 4) {                                                                                                        \
+                constexpr int o = ((i) & 3) * (32 * DSLD * 2);                                                                    \
+                PP_RD_T(f[0].u[0], vD, o);      PP_RD_T(f[0].u[1], vD, o + 4 * DSLD * 2);                                         \
+                PP_RD_T(f[1].u[0], vD, o + 32); PP_RD_T(f[1].u[1], vD, o + 4 * DSLD * 2 + 32);                                    \
+            } else if ((i) < 8) {                                                                                                 \
+                constexpr int o = ((((i) - 4) >> 1) & 1) * (16 * LQ2 * 2) + (((i) - 4) & 1) * 64;                                 \
+                PP_RD_T(f[0].u[0], vB, DO_OFF + o); PP_RD_T(f[0].u[1], vB, DO_OFF + o + 8 * LQ2 * 2);                             \
+                PP_RD_T(f[1].u[0], vB, o);          PP_RD_T(f[1].u[1], vB, o + 8 * LQ2 * 2);                                      \
+            } else if ((i) == 8) {                                                                                                \
+                PP_RD_A(f[0].v, vS, 0);                                                                                           \
+            } else {                                                                                                              \
+                constexpr int ks = (i) >= 9 ? ((i) - 9) & 3 : 0;                                                                  \
+                PP_RD_A(f[0].v, vA, ks * 32); PP_RD_A(f[1].v, vA, DO_OFF + ks * 32);                                              \
+            }                                                                                                                     \
+        } while (0)
+#define PP_CONSUME(i)                                                                                                             \
+        do {                                                                                                                      \
+            Frag(&f)[2] = fr[(i) & 3];                                                                                            \
+            if ((i) == 0) {                                                                                                       \
+                asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %2, %3, 0\n\tv_mfma_f32_16x16x32_bf16 %1, %2, %4, 0"                   \
+                    : "=&v"(qa0), "=&v"(qa1) : "a"(kq[0].v), "v"(f[0].v), "v"(f[1].v));                                           \
+            } else if ((i) < 4) {                                                                                                 \
+                asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %2, %4, %1"                 \
+                    : "+v"(qa0), "+v"(qa1) : "a"(kq[(i) & 3].v), "v"(f[0].v), "v"(f[1].v));                                       \
+            } else if ((i) < 8) {                                                                                                 \
+                constexpr int t2 = (((i) - 4) >> 1) & 1, db = ((i) - 4) & 1;                                                      \
+                asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dv[db]) : "v"(pA[t2].v), "v"(f[0].v));              \
+                asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dk[db]) : "v"(dA[t2].v), "v"(f[1].v));              \
+            } else if ((i) == 8) {                                                                                                \
+                asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %3, 0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, 0"                   \
+                    : "=&v"(s), "=&v"(dp) : "v"(f[0].v), "a"(oS.v), "a"(oD.v));                                                   \
+            } else {                                                                                                              \
+                constexpr int ks = (i) >= 9 ? ((i) - 9) & 3 : 0;                                                                  \
+                asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %5, %1"                 \
+                    : "+v"(s), "+v"(dp) : "v"(f[0].v), "v"(f[1].v), "a"(kf[ks]), "a"(vf[ks]));                                    \
+            }                                                                                                                     \
+        } while (0)
+    // X(t): cb = buffer of tile t, pb = of tile t - 1, slot = (t & 1) = dS^T / dQ-partial slot of tile t - 2.
+    // LDS operations in flight (lgkmcnt, 4 bits: <= 15): groups 0..2 were issued by xprefetch() before the barrier that opens the segment.  The two b128
+    // writes of the dQ partial go out behind group 4's MFMAs (the blocks' last MFMA is three issue groups old by then) and are complete — LDS returns in
+    // order — when group 8 is waited for: the partial is in LDS long before the segment's closing barrier.
+    auto xseg = [&](const int cb, const int pb, const int slot) {
+        const uint32_t vB = ldsT + (uint32_t)(pb * ROWT_EL * 2) + offB;
+        const uint32_t vA = ldsT + (uint32_t)(cb * ROWT_EL * 2) + offA;
+        const uint32_t vS = ldsS + (uint32_t)(cb * 1024);
+        const uint32_t vD = dsR + (uint32_t)(slot * PP_DS_SLOT);
+        const uint32_t vW = dqW + (uint32_t)(slot * PP_DQ_SLOT);
+        TG_SB(); PP_WAIT(8, fr[0]); PP_ISSUE(3); TG_SB(); PP_CONSUME(0);                       // in flight behind the wait: 1 2 | after the issue: 1 2 3 (12)
+        TG_SB(); PP_WAIT(8, fr[1]); PP_ISSUE(4); TG_SB(); PP_CONSUME(1);                       // 2 3 4 (12)
+        TG_SB(); PP_WAIT(8, fr[2]); PP_ISSUE(5); TG_SB(); PP_CONSUME(2);                       // 3 4 5 (12)
+        TG_SB(); PP_WAIT(8, fr[3]); PP_ISSUE(6); TG_SB(); PP_CONSUME(3);                       // 4 5 6 (12)
+        TG_SB(); PP_WAIT(8, fr[0]); PP_ISSUE(7); TG_SB(); PP_CONSUME(4);                       // 5 6 7 (12)
+        TG_SB();
+        asm volatile("s_nop 7\n\tds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:%3" :: "v"(vW), "v"(qa0), "v"(qa1), "i"(16 * DQLD * 4) : "memory");   // 5 6 7 W (14)
+        TG_SB(); PP_WAIT(10, fr[1]); PP_ISSUE(8); TG_SB(); PP_CONSUME(5);                      // 6 7 W 8 (11)
+        TG_SB(); PP_WAIT(7, fr[2]); PP_ISSUE(9); TG_SB(); PP_CONSUME(6);                       // 7 W 8 9 (9)
+        TG_SB(); PP_WAIT(5, fr[3]); PP_ISSUE(10); TG_SB(); PP_CONSUME(7);                      // W 8 9 10 (7)
+        TG_SB(); PP_WAIT(4, fr[0]); PP_ISSUE(11); TG_SB(); PP_CONSUME(8);                      // 9 10 11 (6)
+        TG_SB(); PP_WAIT(4, fr[1]); PP_ISSUE(12); TG_SB(); PP_CONSUME(9);                      // 10 11 12 (6)
+        TG_SB(); PP_WAIT(4, fr[2]); PP_CONSUME(10);
+        TG_SB(); PP_WAIT(2, fr[3]); PP_CONSUME(11);
+        TG_SB(); PP_WAIT(0, fr[0]); PP_CONSUME(12);
+        TG_SB();
+        asm volatile("s_nop 11" : "+v"(s), "+v"(dp));      // an 8-pass MFMA result needs 12 wait states before VALU reads it (the barrier may be short)
+    };
+    auto xprefetch = [&](const int slot) {                  // fragment groups 0..2 of the next X: dS^T blocks of a tile whose writes completed an X ago
+        const uint32_t vD = dsR + (uint32_t)(slot * PP_DS_SLOT), vB = 0, vA = 0, vS = 0;     // (vB, vA, vS: dead branches of the macro)
+        PP_ISSUE(0); PP_ISSUE(1); PP_ISSUE(2);
+    };
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    xprefetch(0);
+    if (grp == 1) BWD_BAR();                                // group 1 falls one segment behind group 0
+    int cb = 0, pb = RING - 1, wb = 2 + grp;                // current / previous tile buffer; buffer this thread stages next
+    const int nit = ntile + PP_EXTRA;
+    for (int it = 0; it < nit; ++it) {
+        // ---------------- X(it): matrix segment ----------------
+        {   // signal: the stores of tile it - 2 - lag went out in Y(it - 2), every wave of the group has seen them acknowledged at the top of its Y(it - 1), and
+            // the barrier that closed Y(it - 1) lies behind us
+            const int ts = it - 2 - lag;
+            if ((tid & 255) == 0 && ts >= 0 && ts < ntile) cnt_write(cntw + (long)ts * CNT_PAD, blk + 1);
+        }
+        __builtin_amdgcn_s_setprio(2);
+        xseg(cb, pb, it & 1);
+        __builtin_amdgcn_s_setprio(0);
+        BWD_BAR();
+        // ---------------- Y(it): vector segment ----------------
+        const int tw = it - lag;                            // tile this group exchanges now; tw + 1 is requested, tw + 2 checked, tw + 3 sampled
+        const bool doW = tw >= 0 && tw < ntile;
+        f32x4 e0 = f32x4{0.f, 0.f, 0.f, 0.f}, e1 = e0;
+        if (doW) {
+            const uint32_t a = dqR + (uint32_t)((tw & 1) * PP_DQ_SLOT);
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3" : "=&v"(e0), "=&v"(e1) : "v"(a), "i"(2 * PP_DQ_SLOT) : "memory");
+        }
+        // everything this wave left in flight in Y(it - 1) — the fetched tile, the requested dQ rows, the dQ store, the counter sample — has had a whole X to land
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0), "+v"(gseed), "+v"(ldv), "+v"(cval));
+        stash(wb);                                          // tile it + 2 + grp; not waited for: first read two barriers from now, behind this wave's own X(it + 1)
+        fetch();
+        wb = (wb + 1) & (RING - 1);
+        if (doW) {
+            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(e0), "+v"(e1));       // (younger: the stage write; wave 0 also waits for its first of two)
+            // (ldv stays zero in the workgroup that starts the sum: it never requests)
+            const f32x4 v = f32x4{(e0[0] + e1[0]) * p.scale + ldv[0], (e0[1] + e1[1]) * p.scale + ldv[1], (e0[2] + e1[2]) * p.scale + ldv[2],
+                                  (e0[3] + e1[3]) * p.scale + ldv[3]};
+            if (tw < ntile - 1) gst16f(v, sbDQw, voDQ);
+            else if (okDQLast) gst16f(v, sbDQw, voDQLast);
+            if (tw < ntile - 1) sbDQw += stepDQb;
+        }
+        if (!first && tw + 1 >= 0 && tw + 1 < ntile) {      // (tile tw + 1 was checked before the barrier that closed Y(it - 1))
+            gld16f(ldv, sbDQr, tw + 1 < ntile - 1 ? voDQ : voDQLast);
+            if (tw + 1 < ntile - 1) sbDQr += stepDQb;
+        }
+        // P = exp2(S), dS = P o dP -> the A operands of X(it + 1); dS^T -> LDS for X(it + 2)
+        {
+            const uint32_t dsw = dsW + (uint32_t)((it & 1) * PP_DS_SLOT);
+#define PP_SOFTMAX(g)                                                                                                             \
+            do {                                                                                                                  \
+                uint2 w01;                                                                                                        \
+                {                                                                                                                 \
+                    const float p0 = fast_exp2(UNIT ? s[4 * (g)] : s[4 * (g)] * p.scale_log2);                                    \
+                    const float p1 = fast_exp2(UNIT ? s[4 * (g) + 1] : s[4 * (g) + 1] * p.scale_log2);                            \
+                    pA[(g) >> 1].w[((g) & 1) * 2] = pack_bf16x2_trans(p0, p1);                                                    \
+                    w01.x = pack_bf16x2(p0 * dp[4 * (g)], p1 * dp[4 * (g) + 1]);                                                  \
+                    dA[(g) >> 1].w[((g) & 1) * 2] = w01.x;                                                                        \
+                }                                                                                                                 \
+                {                                                                                                                 \
+                    const float p0 = fast_exp2(UNIT ? s[4 * (g) + 2] : s[4 * (g) + 2] * p.scale_log2);                            \
+                    const float p1 = fast_exp2(UNIT ? s[4 * (g) + 3] : s[4 * (g) + 3] * p.scale_log2);                            \
+                    pA[(g) >> 1].w[((g) & 1) * 2 + 1] = pack_bf16x2_trans(p0, p1);                                                \
+                    w01.y = pack_bf16x2(p0 * dp[4 * (g) + 2], p1 * dp[4 * (g) + 3]);                                              \
+                    dA[(g) >> 1].w[((g) & 1) * 2 + 1] = w01.y;                                                                    \
+                }                                                                                                                 \
+                asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(dsw), "v"(w01), "i"(16 * (g)) : "memory");                    \
+            } while (0)
+            PP_SOFTMAX(0); PP_SOFTMAX(1); PP_SOFTMAX(2); PP_SOFTMAX(3);
+#undef PP_SOFTMAX
+        }
+        if (wg == 0) {                                      // the group's first wave keeps its chain: tile tw + 2 must be complete before anybody requests it in Y(it + 1)
+            const int tc = tw + 2;
+            if (blk > 0 && tc >= 0 && tc < ntile && lane == 0 && cval != blk) {
+                // bounded: a workgroup that never sees its turn goes on instead of hanging the GPU — and SAYS so in the sticky status word (see attn_bwd_fused_kernel)
+                const int lim = fp.status[1] > 0 ? fp.status[1] : (1 << 20);
+                int spin = 0;
+                while (cnt_read(cntw + (long)tc * CNT_PAD) != blk && ++spin < lim) __builtin_amdgcn_s_sleep(2);
+                if (spin >= lim) atomicAdd(fp.status, 1);
+            }
+            const int tn = min(max(tc + 1, 0), ntile - 1);
+            asm volatile("global_load_dword %0, %1, off sc1" : "=v"(cval) : "v"(cntw + (long)tn * CNT_PAD) : "memory");
+        }
+        pb = cb;
+        cb = (cb + 1) & (RING - 1);
+        TG_SB();
+        xprefetch((it + 1) & 1);
+        BWD_BAR();
+    }
+    if (grp == 0) BWD_BAR();                                // pairs with group 1's extra barrier
+    // the last tiles' stores: acknowledged (vmcnt), seen by the whole group (barrier), then signalled; the prefetched fragments of an X that never runs are drained
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if ((tid & 255) == 0)
+        for (int ts = max(nit - 2 - lag, 0); ts < ntile; ++ts) cnt_write(cntw + (long)ts * CNT_PAD, blk + 1);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        float* DK = p.dk + (long)b * p.dk_sb + h * HD + db * 32 + j;
+        float* DV = p.dv + (long)b * p.dv_sb + h * HD + db * 32 + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kw0 + acc_row(r, hi);
+            if (key >= p.nk) continue;
+            float* a = DK + (long)key * p.dk_ld;
+            float* c = DV + (long)key * p.dv_ld;
+            const float vk = dk[db][r] * p.scale, vv = dv[db][r];
+            *a = (p.accumulate & 2) ? *a + vk : vk;
+            *c = (p.accumulate & 2) ? *c + vv : vv;
+        }
+    }
+#undef PP_RD_T
+#undef PP_RD_A
+#undef PP_WAIT
+#undef PP_ISSUE
+#undef PP_CONSUME
+}
+
 // One-time probe of what the one-kernel backward relies on, on THIS device: (1) workgroup w of a 1-D launch runs on XCD w % 8; (2) the exchange protocol
 // itself — a chain of 32 workgroups of XCD 0, each adding its number to 64 tiles of a buffer in chain order with exactly the kernel's primitives (L1
 // invalidated once per workgroup; sc1 poll of a counter; plain 16-byte load; plain store; vmcnt(0); plain-store signal).  Any stale read, lost update or
@@ -1020,6 +1397,7 @@ extern "C" int tg_attention_bwd_ex(const void* q, long q_ld, long q_sb, const vo
                      o_ld, o_sb, do_ld, do_sb, dq, dk, dv, dq_ld, dq_sb, dk_ld, dk_sb, dv_ld, dv_sb, ws + 4 * nrow, ws + 5 * nrow, (uint4*)ws, nq, nk, heads, batch,
                      scale * 1.4426950408889634f, scale, accumulate, lse ? 1 : 0};
     if (lse) pp.p.lse = const_cast<float*>(lse);
+    if (fabsf(pp.p.scale_log2 - 1.0f) < 4e-7f) pp.p.scale_log2 = 1.0f;      // ln 2 * log2 e: exactly one for the seed rows and the kernels alike
     const dim3 gq((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), gk((unsigned)((nk + 255) / 256), (unsigned)(batch * heads));
     hipLaunchKernelGGL(attn_bwd_stats2_kernel, gq, dim3(256), 0, stream, pp.p);
     TG_REQUIRE(!(flags & TG_BWD_ONE_KERNEL) || status, TG_ERR_ARG, "tg_attention_bwd_ex: TG_BWD_ONE_KERNEL needs the status words");
@@ -1031,9 +1409,21 @@ extern "C" int tg_attention_bwd_ex(const void* q, long q_ld, long q_sb, const vo
         const long ncnt = (long)batch * heads * ((nq + BT - 1) / BT) * 32;       // the exchange counters; the per-head XCD masks sit behind them
         FusedParams fp{pp.p, base, status, base + ncnt};
         hipError_t e = hipMemsetAsync(fp.cnt, 0, (size_t)(ncnt + (long)batch * heads) * sizeof(int), stream);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);   // (per device: cheap, no state kept here)
         if (e != hipSuccess) return tg_set_error(TG_ERR_HIP - (int)e, "tg_attention_bwd_ex: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(gk.x * gk.y), dim3(512), FUSED_LDS, stream, fp);
+        if (tg_knob(TG_KNOB_ATTN_BWD_PP)) {
+            // the two-group ping-pong form; UNIT: scale * log2(e) = 1 (K handed over prescaled, scale = ln 2: the training step) -> no multiply in front of exp2
+            const bool unit = fabsf(pp.p.scale_log2 - 1.0f) < 4e-7f;
+            if (unit) {
+                TG_DYN_LDS(attn_bwd_fused_pp_kernel<true>, PP_LDS);
+                hipLaunchKernelGGL(attn_bwd_fused_pp_kernel<true>, dim3(gk.x * gk.y), dim3(512), PP_LDS, stream, fp);
+            } else {
+                TG_DYN_LDS(attn_bwd_fused_pp_kernel<false>, PP_LDS);
+                hipLaunchKernelGGL(attn_bwd_fused_pp_kernel<false>, dim3(gk.x * gk.y), dim3(512), PP_LDS, stream, fp);
+            }
+        } else {
+            TG_DYN_LDS(attn_bwd_fused_kernel, FUSED_LDS);
+            hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(gk.x * gk.y), dim3(512), FUSED_LDS, stream, fp);
+        }
         TG_LAUNCH_CHECK("tg_attention_bwd(one kernel)");
         return TG_OK;
     }

@@ -102,10 +102,15 @@ def bench_attn_bwd():
     o, do = rnd(B, N1, D, scale=0.3), rnd(B, N1, D, scale=0.3)
     f32 = torch.float32
     dq, dk, dv = (torch.empty(B, N1, D, dtype=f32, device=DEV) for _ in range(3))
-    fn = lambda: K.attention_bwd(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], o, do, H, 0.125, dq=dq, dk=dk, dv=dv)
+    # TG_BENCH_BWD_UNIT=1: the training step's form — K prescaled by scale * log2 e, scale = ln 2 (the kernel's exp2 needs no multiply)
+    unit = os.environ.get("TG_BENCH_BWD_UNIT") == "1"
+    import math
+    kk = (qkv[:, :, D:2 * D].float() * (0.125 * 1.4426950408889634)).to(BF) if unit else qkv[:, :, D:2 * D]
+    fn = lambda: K.attention_bwd(qkv[:, :, :D], kk, qkv[:, :, 2 * D:], o, do, H, math.log(2.0) if unit else 0.125, dq=dq, dk=dk, dv=dv)
     ms = timeit(fn, iters=3, warm=1)
+    K.attention_bwd_check()
     fl = 5 * 2.0 * B * N1 * N1 * D
-    print(json.dumps({"kernel": "attention_bwd_main", "ms": ms, "tflops_algorithmic(5 GEMMs)": fl / ms / 1e9, "tflops_executed(7 GEMMs)": fl * 1.4 / ms / 1e9}))
+    print(json.dumps({"kernel": "attention_bwd_main", "unit_scale": unit, "pp": os.environ.get("TG_ATTN_BWD_PP", "1"), "ms": ms, "tflops_algorithmic(5 GEMMs)": fl / ms / 1e9, "tflops_executed(7 GEMMs)": fl * 1.4 / ms / 1e9}))
 
 
 def bench_gemm():
