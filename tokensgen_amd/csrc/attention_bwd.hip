@@ -9,6 +9,8 @@
 // (tg_attention_fwd_lse); (2) dK, dV: one workgroup per 256 keys walks the query tiles; (3) dQ: one workgroup per 256 queries walks the key
 // tiles.  All products run on v_mfma_f32_32x32x16_bf16; gradients are fp32 (accumulate flag: the To2V processor's three attention calls share
 // K / V tensors, so their gradients add up).
+#include <type_traits>
+
 #include "attention_bwd.h"
 #include "tokensgen_hip.h"
 
@@ -975,7 +977,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) 
     constexpr int DO_OFF = RING * ROWT_EL * 2;              // byte distance Q tile b -> dO tile b
     extern __shared__ __attribute__((aligned(16))) char psm[];
     bf16_t* const sT = (bf16_t*)psm;                                                   // [2][RING][ROWT_EL]: [0] Q tiles, [1] dO tiles
-    uint4* const sSt = (uint4*)(psm + PP_ST_BYTES);                                    // [RING][64] seed rows (entries 32..63 stay zero)
+    uint4* const sSt = (uint4*)(psm + PP_ST_BYTES);                                    // [RING][64] seed rows (entries 0..31 used: the seed k-step's A operand row j for
+                                                                                       // BOTH lane halves — the hi = 1 half's k-slots 8..15 meet zero B operands, any finite value will do)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wg = wave & 3;
     const int j = lane & 31, hi = lane >> 5, t16 = lane & 15, g4 = lane >> 4;
@@ -1056,18 +1059,14 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) 
     auto stash = [&](int buf) {
         if (kindF == 0) {
             *(u32x4*)(dstR + buf * ROWT_EL) = g0;
-            if (wave == 0 && hi == 0) *(u32x4*)(sSt + buf * 64 + j) = gseed;
+            if (wave == 0) *(u32x4*)(sSt + buf * 64 + j) = gseed;             // (both lane halves write row j: same address, same data — no exec masking in Y)
         } else {
             *(u32x4*)(dstR + buf * ROWT_EL) = mask16v(g0, kindF == 1 && okLast);
-            if (wave == 0 && hi == 0) *(u32x4*)(sSt + buf * 64 + j) = sel16v(kindF == 1 && okSLast, gseed, maskrow);
+            if (wave == 0) *(u32x4*)(sSt + buf * 64 + j) = sel16v(kindF == 1 && okSLast, gseed, maskrow);
         }
     };
     // prologue: Q(0), Q(1) + their seed rows, dO(0..2); the buffers of "tile -1" (index RING - 1) zeroed — X(0) multiplies them by P = dS = 0
     *(uint4*)(dstR + (RING - 1) * ROWT_EL) = uint4{0, 0, 0, 0};
-    if (wave == 0 && hi == 1) {
-#pragma unroll
-        for (int bb = 0; bb < RING; ++bb) sSt[bb * 64 + lane] = uint4{0, 0, 0, 0};
-    }
     fetch(); landed(); stash(0);
     fetch(); landed(); stash(1);
     fetch();
@@ -1085,7 +1084,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) 
     const uint32_t lds0 = lds_addr(psm);
     const uint32_t offA = (uint32_t)((j * LQ2 + hi * 8) * 2);
     const uint32_t offB = (uint32_t)(((4 * hi + ((lane & 15) >> 2)) * LQ2 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2);
-    const uint32_t ldsT = lds0, ldsS = lds0 + PP_ST_BYTES + (uint32_t)lane * 16;
+    const uint32_t ldsT = lds0, ldsS = lds0 + PP_ST_BYTES + (uint32_t)j * 16;
     const uint32_t ldsDS = lds0 + PP_ST_BYTES + PP_SEED_BYTES, ldsDQ = ldsDS + 2 * PP_DS_SLOT;
     // dS^T [256 keys][DSLD]: this lane writes keys row (wave * 32 + j), queries 8 g + 4 hi .. (Y); reads the group's rows through transposed 4 x 16 blocks (X)
     const uint32_t dsW = ldsDS + (uint32_t)(((wave * 32 + j) * DSLD + 4 * hi) * 2);
@@ -1193,12 +1192,19 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) 
     if (grp == 1) BWD_BAR();                                // group 1 falls one segment behind group 0
     int cb = 0, pb = RING - 1, wb = 2 + grp;                // current / previous tile buffer; buffer this thread stages next
     const int nit = ntile + PP_EXTRA;
-    for (int it = 0; it < nit; ++it) {
+    // One iteration = X(it) | barrier | Y(it) | barrier.  Every instruction of Y costs ~13 cycles of issue (the partner wave's MFMA stream has the priority), scalar ones
+    // included: the first version's Y carried ~70 scalar instructions and 27 branches of range tests per tile (is the tile to exchange / request / check / signal / fetch
+    // inside the range? is it the ragged last one?) and took ~1900 cycles beside an X of 1300.  FAST = the iterations in which every such test is known to be true and every
+    // tile involved lies wholly inside the query range: no tests, unconditional cursor steps.  The head and tail iterations run the general body (same state, same order).
+    const char* pcnt = (const char*)cntw - (long)lag * (CNT_PAD * 4);      // scalar cursor: counter line of tile (it - lag); +-k lines through the instruction offset
+    auto body = [&](auto fast_c, const int it) {
+        constexpr bool FAST = decltype(fast_c)::value;
         // ---------------- X(it): matrix segment ----------------
         {   // signal: the stores of tile it - 2 - lag went out in Y(it - 2), every wave of the group has seen them acknowledged at the top of its Y(it - 1), and
             // the barrier that closed Y(it - 1) lies behind us
             const int ts = it - 2 - lag;
-            if ((tid & 255) == 0 && ts >= 0 && ts < ntile) cnt_write(cntw + (long)ts * CNT_PAD, blk + 1);
+            if ((tid & 255) == 0 && (FAST || (ts >= 0 && ts < ntile)))
+                asm volatile("global_store_dword %0, %1, %2 offset:%3" :: "v"(0u), "v"(blk + 1), "s"(pcnt), "i"(-2 * CNT_PAD * 4) : "memory");
         }
         __builtin_amdgcn_s_setprio(2);
         xseg(cb, pb, it & 1);
@@ -1206,29 +1212,39 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) 
         BWD_BAR();
         // ---------------- Y(it): vector segment ----------------
         const int tw = it - lag;                            // tile this group exchanges now; tw + 1 is requested, tw + 2 checked, tw + 3 sampled
-        const bool doW = tw >= 0 && tw < ntile;
-        f32x4 e0 = f32x4{0.f, 0.f, 0.f, 0.f}, e1 = e0;
+        const bool doW = FAST || (tw >= 0 && tw < ntile);
+        f32x4 e0, e1;                                       // (written and read under doW only)
         if (doW) {
             const uint32_t a = dqR + (uint32_t)((tw & 1) * PP_DQ_SLOT);
             asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3" : "=&v"(e0), "=&v"(e1) : "v"(a), "i"(2 * PP_DQ_SLOT) : "memory");
         }
         // everything this wave left in flight in Y(it - 1) — the fetched tile, the requested dQ rows, the dQ store, the counter sample — has had a whole X to land
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0), "+v"(gseed), "+v"(ldv), "+v"(cval));
-        stash(wb);                                          // tile it + 2 + grp; not waited for: first read two barriers from now, behind this wave's own X(it + 1)
-        fetch();
+        // stage write of tile it + 2 + grp (not waited for: first read two barriers from now, behind this wave's own X(it + 1)), fetch of tile it + 3 + grp
+        if (FAST) {
+            *(u32x4*)(dstR + wb * ROWT_EL) = g0;
+            if (wave == 0) *(u32x4*)(sSt + wb * 64 + j) = gseed;
+            gld16(g0, sbR, voR);
+            if (wave == 0) gld16(gseed, sbS, voS);
+            sbR += stepRb; sbS += BT * 16;
+            ++tf;
+        } else {
+            stash(wb);
+            fetch();
+        }
         wb = (wb + 1) & (RING - 1);
         if (doW) {
             asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(e0), "+v"(e1));       // (younger: the stage write; wave 0 also waits for its first of two)
             // (ldv stays zero in the workgroup that starts the sum: it never requests)
             const f32x4 v = f32x4{(e0[0] + e1[0]) * p.scale + ldv[0], (e0[1] + e1[1]) * p.scale + ldv[1], (e0[2] + e1[2]) * p.scale + ldv[2],
                                   (e0[3] + e1[3]) * p.scale + ldv[3]};
-            if (tw < ntile - 1) gst16f(v, sbDQw, voDQ);
+            if (FAST || tw < ntile - 1) gst16f(v, sbDQw, voDQ);
             else if (okDQLast) gst16f(v, sbDQw, voDQLast);
-            if (tw < ntile - 1) sbDQw += stepDQb;
+            if (FAST || tw < ntile - 1) sbDQw += stepDQb;
         }
-        if (!first && tw + 1 >= 0 && tw + 1 < ntile) {      // (tile tw + 1 was checked before the barrier that closed Y(it - 1))
-            gld16f(ldv, sbDQr, tw + 1 < ntile - 1 ? voDQ : voDQLast);
-            if (tw + 1 < ntile - 1) sbDQr += stepDQb;
+        if (!first && (FAST || (tw + 1 >= 0 && tw + 1 < ntile))) {      // (tile tw + 1 was checked before the barrier that closed Y(it - 1))
+            gld16f(ldv, sbDQr, (FAST || tw + 1 < ntile - 1) ? voDQ : voDQLast);
+            if (FAST || tw + 1 < ntile - 1) sbDQr += stepDQb;
         }
         // P = exp2(S), dS = P o dP -> the A operands of X(it + 1); dS^T -> LDS for X(it + 2)
         {
@@ -1257,25 +1273,41 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) 
         }
         if (wg == 0) {                                      // the group's first wave keeps its chain: tile tw + 2 must be complete before anybody requests it in Y(it + 1)
             const int tc = tw + 2;
-            if (blk > 0 && tc >= 0 && tc < ntile && lane == 0 && cval != blk) {
+            if (blk > 0 && (FAST || (tc >= 0 && tc < ntile)) && lane == 0 && cval != blk) {
                 // bounded: a workgroup that never sees its turn goes on instead of hanging the GPU — and SAYS so in the sticky status word (see attn_bwd_fused_kernel)
                 const int lim = fp.status[1] > 0 ? fp.status[1] : (1 << 20);
                 int spin = 0;
                 while (cnt_read(cntw + (long)tc * CNT_PAD) != blk && ++spin < lim) __builtin_amdgcn_s_sleep(2);
                 if (spin >= lim) atomicAdd(fp.status, 1);
             }
-            const int tn = min(max(tc + 1, 0), ntile - 1);
-            asm volatile("global_load_dword %0, %1, off sc1" : "=v"(cval) : "v"(cntw + (long)tn * CNT_PAD) : "memory");
+            if (FAST) {
+                asm volatile("global_load_dword %0, %1, %2 offset:%3 sc1" : "=v"(cval) : "v"(0u), "s"(pcnt), "i"(3 * CNT_PAD * 4) : "memory");
+            } else {
+                const int tn = min(max(tc + 1, 0), ntile - 1);
+                asm volatile("global_load_dword %0, %1, off sc1" : "=v"(cval) : "v"(cntw + (long)tn * CNT_PAD) : "memory");
+            }
         }
+        pcnt += CNT_PAD * 4;
         pb = cb;
         cb = (cb + 1) & (RING - 1);
         TG_SB();
         xprefetch((it + 1) & 1);
         BWD_BAR();
-    }
+    };
+    // FAST iterations: the signalled tile it - 5 (group 0) exists, and the fetched tile it + 4 (group 1) still lies wholly inside the query range
+    const int itLo = min(5, nit), itHi = max(itLo, ntile - 5);
+    int it = 0;
+    for (; it < itLo; ++it) body(std::false_type{}, it);
+    for (; it < itHi; ++it) body(std::true_type{}, it);
+    for (; it < nit; ++it) body(std::false_type{}, it);
+    // The last Y prefetched the fragments of an X that never runs: their LDS reads are still IN FLIGHT towards fr[0..2].  The wait must name those registers —
+    // to the compiler the asm outputs were written when the reads were issued and are dead here, so it would hand the same VGPRs to the epilogue's
+    // v_accvgpr_read of dK / dV at once, and the late returns would overwrite them (found on hardware: run-to-run differences in accumulator rows 0..2 of one wave).
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(fr[0][0].v), "+v"(fr[0][1].v), "+v"(fr[1][0].v), "+v"(fr[1][1].v), "+v"(fr[2][0].v), "+v"(fr[2][1].v), "+v"(g0), "+v"(gseed), "+v"(ldv), "+v"(cval)
+                 :: "memory");
     if (grp == 0) BWD_BAR();                                // pairs with group 1's extra barrier
-    // the last tiles' stores: acknowledged (vmcnt), seen by the whole group (barrier), then signalled; the prefetched fragments of an X that never runs are drained
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // the last tiles' stores: acknowledged (vmcnt, above), seen by the whole group (barrier), then signalled
     __syncthreads();
     if ((tid & 255) == 0)
         for (int ts = max(nit - 2 - lag, 0); ts < ntile; ++ts) cnt_write(cntw + (long)ts * CNT_PAD, blk + 1);
