@@ -610,22 +610,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
 }
 
 // =================================================================================================================================
-// ONE kernel for dK, dV AND dQ (5 executed GEMMs instead of 7: S and dP are formed once).  DESIGN §10 "one-kernel backward".
-// A workgroup owns 256 keys (8 waves x 32) like the dK/dV kernel and walks the query tiles; per tile it also forms its 256 keys' contribution to the
-// tile's dQ [32 q][64 d]: every wave leaves its dS^T block [32 keys][32 queries] (bf16) in LDS, and behind the tile's barrier wave w computes ONE 16 x 16
-// block of dQ^T (head dims 16 (w >> 1) .., queries 16 (w & 1) ..) over all 256 keys on v_mfma_f32_16x16x32_bf16 — A = the workgroup's K rows of its 16
-// head dims, resident; B = dS through transposed reads of the [key][query] tiles; a lane ends up with 4 consecutive floats of one dQ row.
+// ONE kernel for dK, dV AND dQ (5 executed GEMMs instead of 7: S and dP are formed once) — attn_bwd_fused_pp_kernel below.  What it shares with the
+// two-launch form: a workgroup owns 256 keys (8 waves x 32) and walks the query tiles.  Per tile it also forms its 256 keys' contribution to the tile's
+// dQ [32 q][64 d]: every wave leaves its dS^T block [32 keys][32 queries] (bf16) in LDS, 16 x 16 blocks of dQ^T are formed on v_mfma_f32_16x16x32_bf16
+// (A = the workgroup's K rows, resident; B = dS through transposed reads of the [key][query] tiles; a lane ends up with 4 consecutive floats of one dQ row).
 // The key blocks of a head add their blocks to the fp32 dQ tile in global memory IN KEY-BLOCK ORDER (bitwise reproducible, no atomics on the data): per
-// (head, tile) a counter says how many key blocks have added; key block kb waits for the counter to reach kb (wave 0, before the tile's barrier), every
-// thread reads 16 bytes of the tile (the eight blocks meet in an LDS tile so that 16 lanes cover a whole 256-byte dQ row: full lines), adds, writes,
-// and when every wave's write has been acknowledged by L2 (vmcnt(0) + the next barrier) the counter is set to kb + 1.  All workgroups of a head run on ONE XCD (xcd_block), whose L2 is the coherence point: stores are written through the CU's L1; the CU's
-// L1 is invalidated once per workgroup, after which every dQ line is loaded once and only when complete; the counter is polled with sc1 loads (past the
-// L1).  fused_probe_kernel checks exactly these primitives and the workgroup -> XCD mapping on the device before the launcher uses this kernel.
-// The wait never points at a workgroup that has not started (kb - 1 has the lower index).  The read-add-write of a tile is spread over the next
-// iterations (checked during iteration T, requested at the top of T + 1, written at the top of T + 2, signalled behind the barrier of T + 2), so
-// consecutive key blocks run a few tiles apart — which is why the launcher uses this kernel only for calls with many more query tiles than key blocks.
-// In-phase structure (one barrier per tile), statistics seeded through the matrix pipe as in the ping-pong kernel.  Measured at the training shape: ~23.8 ms
-// against 15.9 + 11.4 for the two launches it replaces; without the dQ exchange the same kernel takes 19.1.
+// (head, tile, row half) a counter says how many key blocks have added; key block kb waits for the counter to reach kb, every thread reads 16 bytes of the
+// tile (the blocks meet in an LDS tile so that 16 lanes cover a whole 256-byte dQ row: full lines — half-line stores were not kept in this L2), adds, writes,
+// and when every wave's write has been acknowledged by L2 (vmcnt(0) + a barrier) the counter is set to kb + 1.  All workgroups of a head run on ONE XCD
+// (xcd_block), whose L2 is the coherence point.  fused_probe_kernel checks exactly these primitives and the workgroup -> XCD mapping on the device before a
+// caller may select this form.  The wait never points at a workgroup that has not started (kb - 1 has the lower index).  The read-add-write of a tile is
+// spread over several iterations, so consecutive key blocks run a few tiles apart — which is why the launcher uses the form only for calls with many more
+// query tiles than key blocks.  History (profiles/NOTES.md §D, §F): the first, in-phase version of this kernel (round 3: one barrier per tile, every wave in
+// the same phase) ran the 17776^2 call in 26.4 ms; the ping-pong version below in 23.7 ms on the same box.
 // =================================================================================================================================
 struct FusedParams {
     BwdParams p;
@@ -636,7 +633,6 @@ struct FusedParams {
 };
 constexpr int DSLD = 40;                 // dS^T tile row stride in elements (80 B: 8-byte aligned 4-query runs)
 constexpr int DQLD = 68;                 // dQ tile row stride in floats (272 B: the 16 lanes of a block column land on different banks)
-constexpr int FUSED_LDS = 2 * 3 * ROWT_EL * 2 + 3 * 64 * 16 + 2 * 256 * DSLD * 2 + 2 * BT * DQLD * 4;
 
 // The counters and the dQ blocks are exchanged between workgroups of ONE XCD, whose L2 is the coherence point.  What the kernel uses, and what
 // tg_attention_bwd_probe checks on the device before a caller may select this form: dQ lines are read with PLAIN 16-byte loads behind one
@@ -653,284 +649,10 @@ __device__ __forceinline__ int cnt_read(int* c) {
 }
 __device__ __forceinline__ void cnt_write(int* c, int v) { asm volatile("global_store_dword %0, %1, off" :: "v"(c), "v"(v) : "memory"); }
 
-__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedParams fp) {
-    const BwdParams& p = fp.p;
-    extern __shared__ __attribute__((aligned(16))) char fsm[];
-    bf16_t (*sQ)[ROWT_EL] = (bf16_t (*)[ROWT_EL])fsm;                                   // [3]
-    bf16_t (*sdO)[ROWT_EL] = (bf16_t (*)[ROWT_EL])(fsm + 3 * ROWT_EL * 2);              // [3]
-    uint4 (*sSt)[64] = (uint4 (*)[64])(fsm + 6 * ROWT_EL * 2);                            // [3] seed rows (entries 32..63 zero)
-    bf16_t* sDS = (bf16_t*)(fsm + 6 * ROWT_EL * 2 + 3 * 64 * 16);                         // [2][256][DSLD]
-    float* sDQ = (float*)(fsm + 6 * ROWT_EL * 2 + 3 * 64 * 16 + 2 * 256 * DSLD * 2);     // [2][32][DQLD]: the tile's dQ contribution, all eight blocks
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, hi = lane >> 5, t16 = lane & 15, g4 = lane >> 4;
-    int blk, hb;
-    xcd_block((p.nk + 255) / 256, p.heads * p.batch, blk, hb);
-    const int h = hb % p.heads, b = hb / p.heads;
-    const int kw0 = blk * 256 + wave * 32;
-    const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
-    const bf16_t* dO = p.dout + (long)b * p.do_sb + h * HD;
-    const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
-    const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
-    const long stat0 = ((long)b * p.heads + h) * p.nq;
-    // Self-check of the ONE placement property the ordered exchange rests on — every key block of a head on the same XCD (its L2 is where their dQ traffic
-    // meets): each workgroup ORs its XCC id into the head's mask word and looks at what was there.  Device-scope atomic (the blocks it must catch
-    // are exactly those on another XCD); one per workgroup, its latency hidden behind the K / V fragment loads below.  A violation is counted in
-    // status[2] and reported by the host like a poll time-out — never a silently wrong dq.
-    int xold = 0, xbit = 0;
-    if (tid == 0) {
-        xbit = 1 << (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u);           // HW_REG_XCC_ID, bits 3:0
-        xold = __hip_atomic_fetch_or(fp.xmask + hb, xbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const long r = min(kw0 + j, p.nk - 1);
-        load_frag_agpr(kf[ks], Kp + r * p.k_ld + ks * 16 + hi * 8);
-        load_frag_agpr(vf[ks], Vp + r * p.v_ld + ks * 16 + hi * 8);
-    }
-    TG_WAIT_FRAGS1(kf);
-    TG_WAIT_FRAGS1(vf);
-    if (tid == 0 && (xold & ~xbit)) atomicAdd(fp.status + 2, 1);
-    Frag oS, oD;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { oS.w[w] = 0; oD.w[w] = 0; }
-    if (hi == 0) { oS.w[0] = 0x3F803F80u; oS.w[1] = 0x00003F80u; oD.w[1] = 0x3F800000u; oD.w[2] = 0x3F803F80u; }
-    f32x16 dk[2], dv[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) { dk[c] = zero16(); dv[c] = zero16(); }
-    // this wave's dQ block and its resident B operand: K rows of the workgroup's 256 keys (zero beyond nk), head dims 16 dblk ..
-    const int qh = wave & 1, dblk = wave >> 1;
-    Frag kb8[8];
-#pragma unroll
-    for (int s2 = 0; s2 < 8; ++s2)
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-            const int k0 = blk * 256 + 32 * s2 + 8 * g4 + e;
-            const uint32_t lo = k0 < p.nk ? Kp[(long)k0 * p.k_ld + 16 * dblk + t16] : 0u;
-            const uint32_t hi16 = k0 + 1 < p.nk ? Kp[(long)(k0 + 1) * p.k_ld + 16 * dblk + t16] : 0u;
-            kb8[s2].w[e >> 1] = lo | (hi16 << 16);
-        }
-    const int half = tid >> 8, t8 = tid & 255, row = t8 >> 3, chunk = (t8 & 7) * 8;
-    const bf16_t* const srcR = half ? dO : Q;
-    const long ldR = half ? p.do_ld : p.q_ld;
-    const int trb = (4 * hi + ((lane & 15) >> 2)) * LQ2 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
-    const int ntile = (p.nq + BT - 1) / BT;
-    uint4 maskrow;
-    {
-        uint32_t l1, l2, l3;
-        split_bf16x3(-1e30f, l1, l2, l3);
-        maskrow = uint4{(l1 >> 16) | l2, l3 >> 16, 0u, 0u};
-    }
-    uint4 g0 = uint4{0, 0, 0, 0}, gseed = maskrow;
-    bool okr = false, oks = false;
-    // running pointers: a tile that lies wholly inside the query range costs one load and one pointer add; clamped rows + masking for the last tile and the
-    // (never consumed) ones behind it.  The address arithmetic of an iteration's top (fetch, request, write: five 64-bit multiplies per lane) was a
-    // measurable part of the tile: ~500 of ~4000 cycles per tile went into that section
-    const bf16_t* pR = srcR + (long)row * ldR + chunk;
-    const long stepR = (long)BT * ldR;
-    const uint4* pS = p.seed + stat0 + j;
-    const int qlast = (ntile - 1) * BT;
-    const bf16_t* const pRLast = srcR + (long)min(qlast + row, p.nq - 1) * ldR + chunk;
-    const uint4* const pSLast = p.seed + stat0 + min(qlast + j, p.nq - 1);
-    const bool okrLast = qlast + row < p.nq, oksLast = qlast + j < p.nq;
-    int tfetch = 0;                                         // tile the next fetch() loads
-    auto fetch = [&](int) {
-        const bool inner = tfetch < ntile - 1;
-        okr = inner || okrLast; oks = inner || oksLast;
-        g0 = *(const uint4*)(inner ? pR : pRLast);
-        if (wave == 0) gseed = *(inner ? pS : pSLast);
-        pR += stepR; pS += BT;
-        ++tfetch;
-    };
-    auto stash = [&](int buf) {
-        *(uint4*)((half ? sdO[buf] : sQ[buf]) + row * LQ2 + chunk) = mask16(g0, okr);
-        if (wave == 0 && hi == 0) sSt[buf][j] = sel16(oks, gseed, maskrow);
-    };
-    if (wave == 0 && hi == 1) {
-#pragma unroll
-        for (int bb = 0; bb < 3; ++bb) sSt[bb][lane] = uint4{0, 0, 0, 0};
-    }
-    fetch(0);
-    stash(0);
-    fetch(min(1, ntile - 1) * BT);
-    stash(1);
-    __syncthreads();
-    constexpr int CNT_PAD = 32;                               // one counter per 128-byte line
-    int* const cntw = fp.cnt + (long)hb * ntile * CNT_PAD;   // one counter per (head, tile): key blocks that have added
-    // the blocks are formed TRANSPOSED (rows = head dims 4 g4 + r, column = query t16: a lane owns 4 consecutive floats of one dQ row) and meet in an LDS tile
-    // [32 q][64 d]; the exchange with global memory is done by thread (er = tid >> 4, ec = 4 (tid & 15)): 16 lanes cover one whole 256-byte dQ row — FULL
-    // 128-byte lines.  (With every wave exchanging its own 16 x 16 block, two waves shared a line: half-line stores, 13.9 GB of the 30 GB stored went out past
-    // the L2 and the reads behind them came back late.)
-    const int er = tid >> 4, ec = (tid & 15) * 4;
-    float* const DQb = p.dq + (long)b * p.dq_sb + h * HD + ec;
-    const bool first = blk == 0 && !(p.accumulate & 1);      // nothing to read: this workgroup's block starts the sum
-    f32x4 ldv = f32x4{0.f, 0.f, 0.f, 0.f};
-    int cval = 0;                                           // wave 0: counter of the next tile to check, sampled one iteration ahead
-    asm volatile("buffer_inv sc1" ::: "memory");            // ONCE per workgroup: whatever earlier workgroups on this CU left in its L1 is gone; from here on
-                                                            // every dQ line is loaded once, and only after the key block before has completed the whole tile
-    auto e_signal = [&](int T) {                             // (wave 0, behind a barrier behind every wave's vmcnt(0)): the stores of tile T are in L2
-        if (tid == 0) cnt_write(cntw + (long)T * CNT_PAD, blk + 1);
-    };
-    auto e_sample = [&](int T) {                             // (wave 0) sc1 load: served by the L2, not by this CU's L1
-        if (wave == 0) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(cval) : "v"(cntw + (long)min(T, ntile - 1) * CNT_PAD) : "memory");
-    };
-    auto e_check = [&](int T) {                              // (wave 0, before the barrier that lets the others request tile T)
-        if (wave == 0 && blk > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cval));
-            if (lane == 0 && cval != blk) {
-                // bounded: a workgroup that never sees its turn (its predecessor descheduled for seconds) goes on instead of hanging the GPU — and SAYS so:
-                // the sticky word status[0] counts the polls that gave up; the dq this launch leaves is then invalid and the host must not use it
-                // (kernels.attention_bwd_check raises).  status[1] != 0 overrides the limit (tests force the path with 1).
-                const int lim = fp.status[1] > 0 ? fp.status[1] : (1 << 20);
-                int spin = 0;
-                while (cnt_read(cntw + (long)T * CNT_PAD) != blk && ++spin < lim) __builtin_amdgcn_s_sleep(2);
-                if (spin >= lim) atomicAdd(fp.status, 1);
-            }
-        }
-    };
-    // this lane's dQ row of tile 0 and the tile-to-tile step; the last tile's rows may lie beyond nq: its request reads a clamped row, its write is skipped
-    float* pRq = DQb + (long)min(er, p.nq - 1) * p.dq_ld;                    // next request
-    float* pWr = pRq;                                                        // next write
-    const long stepDQ = (long)BT * p.dq_ld;
-    float* const pDQLast = DQb + (long)min(qlast + er, p.nq - 1) * p.dq_ld;
-    const bool okDQLast = qlast + er < p.nq;
-    auto e_request = [&](int T) {
-        const float* src = T < ntile - 1 ? pRq : pDQLast;
-        if (!first) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ldv) : "v"(src) : "memory");
-        pRq += stepDQ;
-    };
-    auto e_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(ldv)); };      // last iteration's request is in, its store has been acknowledged by L2
-    auto e_write = [&](int T) {
-        if (T < ntile - 1 || okDQLast) {
-            const f32x4 acc = *(const f32x4*)(sDQ + ((T & 1) * BT + er) * DQLD + ec);        // (written behind the barrier of iteration T, one barrier ago at least)
-            f32x4 v = f32x4{acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale};
-            if (!first) v = f32x4{v[0] + ldv[0], v[1] + ldv[1], v[2] + ldv[2], v[3] + ldv[3]};
-            *(f32x4*)(T < ntile - 1 ? pWr : pDQLast) = v;
-        }
-        pWr += stepDQ;
-    };
-    e_sample(0);
-    for (int it = 0; it < ntile; ++it) {
-        const int buf = it % 3, sbuf = (it + 2) % 3;
-        // the dQ pipeline, all at the top of the iteration where a whole iteration has passed since the loads / stores it waits for were issued:
-        // tile it - 3 signalled (its store went out one iteration ago), tile it - 2 written (its old values were requested one iteration ago), tile it - 1 requested
-        // the dQ pipeline: tile T is checked (wave 0) during iteration T, requested at the top of T + 1, written at the top of T + 2, signalled behind the
-        // barrier of T + 2 (every wave waits for its store in front of that barrier)
-        e_landed();
-        if (it >= 2) e_write(it - 2);
-        fetch(min(it + 2, ntile - 1) * BT);
-        if (it >= 1) e_request(it - 1);                      // (tile it - 1 was checked before the previous barrier)
-        // ---- S, dP of this tile (statistics seeded through the matrix pipe) ----
-        bf16x8 aQ[4], aO[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            aQ[ks] = *(const bf16x8*)(sQ[buf] + j * LQ2 + ks * 16 + hi * 8);
-            aO[ks] = *(const bf16x8*)(sdO[buf] + j * LQ2 + ks * 16 + hi * 8);
-        }
-        Frag sd;
-        {
-            const uint4 t_ = sSt[buf][lane];
-            sd.w[0] = t_.x; sd.w[1] = t_.y; sd.w[2] = t_.z; sd.w[3] = t_.w;
-        }
-        f32x16 s, dp;
-        asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %3, 0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, 0" : "=&v"(s), "=&v"(dp) : "v"(sd.v), "v"(oS.v), "v"(oD.v));
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks < 3) mfma_pair_step<false, false>(s, dp, aQ[ks], aO[ks], kf[ks], vf[ks]);
-            else mfma_pair_step<false, true>(s, dp, aQ[ks], aO[ks], kf[ks], vf[ks]);
-        }
-        // ---- P, dS -> A operands; dS^T block -> LDS ----
-        Frag pA[2], dA[2];
-        bf16_t* const dsw = sDS + (it & 1) * 256 * DSLD + (wave * 32 + j) * DSLD + 4 * hi;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint32_t w01[2];
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-                const float p0 = fast_exp2(s[4 * g + e] * p.scale_log2), p1 = fast_exp2(s[4 * g + e + 1] * p.scale_log2);
-                pA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = pack_bf16x2_trans(p0, p1);
-                w01[e >> 1] = pack_bf16x2(p0 * dp[4 * g + e], p1 * dp[4 * g + e + 1]);
-                dA[g >> 1].w[(g & 1) * 2 + (e >> 1)] = w01[e >> 1];
-            }
-            *(uint2*)(dsw + 8 * g) = uint2{w01[0], w01[1]};
-        }
-        // ---- dV += P^T dO, dK += dS^T Q ----
-        Frag bO[2][2], bQ[2][2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const int o = trb + 16 * t * LQ2 + db * 32;
-                bO[t][db].u[0] = lds_tr_b64(sdO[buf] + o); bO[t][db].u[1] = lds_tr_b64(sdO[buf] + o + 8 * LQ2);
-                bQ[t][db].u[0] = lds_tr_b64(sQ[buf] + o);  bQ[t][db].u[1] = lds_tr_b64(sQ[buf] + o + 8 * LQ2);
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bO[0][0].v), "+v"(bO[0][1].v), "+v"(bO[1][0].v), "+v"(bO[1][1].v), "+v"(bQ[0][0].v), "+v"(bQ[0][1].v),
-                     "+v"(bQ[1][0].v), "+v"(bQ[1][1].v));
-        TG_SB();
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                mfma_acc(dv[db], pA[t].v, bO[t][db].v);
-                mfma_acc(dk[db], dA[t].v, bQ[t][db].v);
-            }
-        TG_SB();
-        stash(sbuf);
-        e_check(it);                                        // wave 0: key block blk - 1 has completed tile it (needed from the top of the next iteration on)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ldv));     // the store of tile it - 2 (issued at the top of this iteration) is in L2, the request is in
-        __syncthreads();
-        if (it >= 2) e_signal(it - 2);
-        e_sample(it + 1);
-        // ---- this tile's dQ block: dS [16 q][256 keys] x K [256 keys][16 d] ----
-        {
-            const bf16_t* dsr = sDS + (it & 1) * 256 * DSLD + (8 * g4 + (t16 >> 2)) * DSLD + 16 * qh + (t16 & 3) * 4;
-            Frag a8[8];
-#pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2) {
-                a8[s2].u[0] = lds_tr_b64(dsr + 32 * s2 * DSLD);
-                a8[s2].u[1] = lds_tr_b64(dsr + (32 * s2 + 4) * DSLD);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a8[0].v), "+v"(a8[1].v), "+v"(a8[2].v), "+v"(a8[3].v), "+v"(a8[4].v), "+v"(a8[5].v), "+v"(a8[6].v), "+v"(a8[7].v));
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb8[s2].v, a8[s2].v, acc, 0, 0, 0);     // rows = head dims, column = query
-            *(f32x4*)(sDQ + ((it & 1) * BT + 16 * qh + t16) * DQLD + 16 * dblk + 4 * g4) = acc;
-        }
-    }
-    // drain the dQ pipeline (tiles ntile - 2 and ntile - 1 are still to be written, ntile - 3 .. ntile - 1 to be signalled)
-    __syncthreads();                                        // the last tile's blocks are in the LDS tile
-    e_landed();
-    if (ntile >= 2) e_write(ntile - 2);
-    e_request(ntile - 1);                                   // (checked before the last barrier)
-    e_landed();
-    e_write(ntile - 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        for (int T = max(ntile - 2, 0); T < ntile; ++T) cnt_write(cntw + (long)T * CNT_PAD, blk + 1);
-    }
-    asm volatile("s_nop 15" ::: "memory");
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-        float* DK = p.dk + (long)b * p.dk_sb + h * HD + db * 32 + j;
-        float* DV = p.dv + (long)b * p.dv_sb + h * HD + db * 32 + j;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kw0 + acc_row(r, hi);
-            if (key >= p.nk) continue;
-            float* a = DK + (long)key * p.dk_ld;
-            float* c = DV + (long)key * p.dv_ld;
-            const float vk = dk[db][r] * p.scale, vv = dv[db][r];
-            *a = (p.accumulate & 2) ? *a + vk : vk;
-            *c = (p.accumulate & 2) ? *c + vv : vv;
-        }
-    }
-}
-
 // =================================================================================================================================
 // The one-kernel backward as a TWO-GROUP PING-PONG (round 5): attn_bwd_dkdv7_kernel's structure — every wave alternates a matrix segment X (all MFMAs, all
 // LDS reads, every read issued three fragment groups ahead of its use) and a vector segment Y (VALU, LDS writes, global traffic), one s_barrier after
-// each, waves 4-7 one segment behind waves 0-3 — with the dQ product and the ordered dQ exchange of attn_bwd_fused_kernel laid INTO those segments.
+// each, waves 4-7 one segment behind waves 0-3 — with the dQ product and the ordered dQ exchange (banner above FusedParams) laid INTO those segments.
 // The in-phase one-kernel form ran at 0.78 PFLOP/s on the 17776^2 call (every wave of a SIMD in the same phase: their MFMA blocks collide, their softmax
 // blocks collide, the matrix pipe idles through both softmaxes), and on all-zero operands it gained only 5.6 % where the forward gained 27 %: schedule-bound.
 //   X(t) = { dQ^T partial of tile t-2 ; dV += P(t-1)^T dO(t-1), dK += dS(t-1)^T Q(t-1) ; S(t) = Q(t) K^T, dP(t) = dO(t) V^T }
@@ -991,7 +713,9 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) 
     const bf16_t* Kp = p.k + (long)b * p.k_sb + h * HD;
     const bf16_t* Vp = p.v + (long)b * p.v_sb + h * HD;
     const long stat0 = ((long)b * p.heads + h) * p.nq;
-    // placement self-check (see attn_bwd_fused_kernel): every key block of a head on ONE XCD
+    // Self-check of the ONE placement property the ordered exchange rests on — every key block of a head on the same XCD (its L2 is where their dQ traffic
+    // meets): each workgroup ORs its XCC id into the head's mask word and looks at what was there (device-scope atomic; one per workgroup, its latency hidden
+    // behind the K / V fragment loads).  A violation is counted in status[2] and reported by the host like a poll time-out — never a silently wrong dq.
     int xold = 0, xbit = 0;
     if (tid == 0) {
         xbit = 1 << (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u);           // HW_REG_XCC_ID, bits 3:0
@@ -1106,7 +830,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) 
     const int lag = 3 - grp;                                 // Y(u) exchanges tile u - lag (both groups' partials of it are complete and behind a barrier)
     f32x4 ldv = f32x4{0.f, 0.f, 0.f, 0.f};
     int cval = 0;                                           // (wave 4 g) counter of the next tile to check, sampled one Y ahead
-    asm volatile("buffer_inv sc1" ::: "memory");            // ONCE per workgroup (see attn_bwd_fused_kernel)
+    asm volatile("buffer_inv sc1" ::: "memory");            // ONCE per workgroup: whatever earlier workgroups on this CU left in its L1 is gone; from here on
+                                                            // every dQ line is loaded once, and only after the key block before has completed the whole tile
     Frag fr[4][2];
     f32x4 qa0, qa1;                                         // this wave's dQ^T blocks (query halves 0, 1)
 #define PP_RD_T(dst, base, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "i"(off))
@@ -1274,7 +999,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) 
         if (wg == 0) {                                      // the group's first wave keeps its chain: tile tw + 2 must be complete before anybody requests it in Y(it + 1)
             const int tc = tw + 2;
             if (blk > 0 && (FAST || (tc >= 0 && tc < ntile)) && lane == 0 && cval != blk) {
-                // bounded: a workgroup that never sees its turn goes on instead of hanging the GPU — and SAYS so in the sticky status word (see attn_bwd_fused_kernel)
+                // bounded: a workgroup that never sees its turn goes on instead of hanging the GPU — and SAYS so: status[0] counts the polls that gave up, the dq of this launch
+                // is then invalid and the host must not use it (kernels.attention_bwd_status); status[1] != 0 overrides the limit (tests force the path with 1)
                 const int lim = fp.status[1] > 0 ? fp.status[1] : (1 << 20);
                 int spin = 0;
                 while (cnt_read(cntw + (long)tc * CNT_PAD) != blk && ++spin < lim) __builtin_amdgcn_s_sleep(2);
@@ -1442,19 +1168,13 @@ extern "C" int tg_attention_bwd_ex(const void* q, long q_ld, long q_sb, const vo
         FusedParams fp{pp.p, base, status, base + ncnt};
         hipError_t e = hipMemsetAsync(fp.cnt, 0, (size_t)(ncnt + (long)batch * heads) * sizeof(int), stream);
         if (e != hipSuccess) return tg_set_error(TG_ERR_HIP - (int)e, "tg_attention_bwd_ex: %s", hipGetErrorString(e));
-        if (tg_knob(TG_KNOB_ATTN_BWD_PP)) {
-            // the two-group ping-pong form; UNIT: scale * log2(e) = 1 (K handed over prescaled, scale = ln 2: the training step) -> no multiply in front of exp2
-            const bool unit = fabsf(pp.p.scale_log2 - 1.0f) < 4e-7f;
-            if (unit) {
-                TG_DYN_LDS(attn_bwd_fused_pp_kernel<true>, PP_LDS);
-                hipLaunchKernelGGL(attn_bwd_fused_pp_kernel<true>, dim3(gk.x * gk.y), dim3(512), PP_LDS, stream, fp);
-            } else {
-                TG_DYN_LDS(attn_bwd_fused_pp_kernel<false>, PP_LDS);
-                hipLaunchKernelGGL(attn_bwd_fused_pp_kernel<false>, dim3(gk.x * gk.y), dim3(512), PP_LDS, stream, fp);
-            }
+        // UNIT: scale * log2(e) = 1 (K handed over prescaled, scale = ln 2: the training step) -> no multiply in front of exp2
+        if (fabsf(pp.p.scale_log2 - 1.0f) < 4e-7f) {
+            TG_DYN_LDS(attn_bwd_fused_pp_kernel<true>, PP_LDS);
+            hipLaunchKernelGGL(attn_bwd_fused_pp_kernel<true>, dim3(gk.x * gk.y), dim3(512), PP_LDS, stream, fp);
         } else {
-            TG_DYN_LDS(attn_bwd_fused_kernel, FUSED_LDS);
-            hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(gk.x * gk.y), dim3(512), FUSED_LDS, stream, fp);
+            TG_DYN_LDS(attn_bwd_fused_pp_kernel<false>, PP_LDS);
+            hipLaunchKernelGGL(attn_bwd_fused_pp_kernel<false>, dim3(gk.x * gk.y), dim3(512), PP_LDS, stream, fp);
         }
         TG_LAUNCH_CHECK("tg_attention_bwd(one kernel)");
         return TG_OK;
