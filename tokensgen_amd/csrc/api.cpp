@@ -50,7 +50,7 @@ bool tg_first_on_device(TgOnce& once) {
 namespace {
 struct KnobDef { const char* name; long def; };
 const KnobDef kKnobs[TG_KNOB_COUNT] = {{"TG_ATTN_PP_MIN_WG", 1024}, {"TG_ATTN_FIXEDM", 1}, {"TG_ATTN_SPLIT", 1}, {"TG_GEMM_W4", 1},
-                                        {"TG_CONV_SPLITK", 1},       {"TG_CONV_HALO", 1},  {"TG_CONV_W4", 1},     {"TG_ATTN_M16", 1}};
+                                        {"TG_CONV_SPLITK", 1},       {"TG_CONV_HALO", 1},  {"TG_CONV_W4", 1}};
 std::atomic<long> g_knob[TG_KNOB_COUNT];
 std::atomic<unsigned> g_knob_set{0};
 }  // namespace

@@ -773,303 +773,6 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
     }
 }
 
-// =================================================================================================================================
-// The constant-shift ping-pong kernel on v_mfma_f32_16x16x32_bf16 (round 5; VERDICT r4 item 4: the energy-per-flop restructuring).  Same choreography as
-// attn_fwd_pp_kernel<true, 1> — 8 waves x 64 query rows, K / V^T tiles by LDS-DMA, the two waves of a SIMD in anti-phase, X(t) = {O^T += V^T(t-1) P(t-1),
-// S^T(t) = K(t) Q^T}, Y(t) = softmax — with the products cut into 16 x 16 blocks:
-//   * half the accumulator-file traffic per flop (a 16x16x32 MFMA reads / writes 4 accumulator registers for 16 K flop, a 32x32x16 one 16 for 32 K): under the
-//     socket power cap a pure 16x16x32 loop sustains 2.05 PFLOP/s against 1.79 (profiles/NOTES.md §B);
-//   * NO seed MFMAs: a lane of a 16 x 16 S^T block owns ONE query column, so the constant shift -c[query] is the same number in all four accumulator registers
-//     and enters as the C operand of the block's first MFMA (ONE register quad: a lane uses the largest bound of its four queries) — the 32 x 32 form needed 4 extra MFMAs per tile
-//     (of 36) to seed 64 registers;
-//   * lane (q = lane & 15, g = lane >> 4) of S^T block kb holds keys kappa(kb, 4 g + r), r = 0..3, with kappa(kb, m) = 32 (kb >> 1) + 8 (m >> 2) + 4 (kb & 1) + (m & 3):
-//     the two blocks of a 32-key step leave lane (q, g) exactly the 8 CONSECUTIVE keys 32 kp + 8 g .. + 7 — P feeds O^T += V^T P from the accumulator registers,
-//     and the V^T operand stays one ds_read_b128.  The K tile's LDS slot swizzle is chosen for this row order (conflict-free 16-lane read groups).
-// Row sums are lane-partial (a lane sees a quarter of a row's keys) and meet in the epilogue (two xor shuffles).  Constant shift only: rows the verification
-// flags go to the RETRY instantiation of the 32 x 32 kernel like before; the split tail and the running-max paths stay on it as well.
-// =================================================================================================================================
-template <bool LSE>
-__global__ __launch_bounds__(512) void attn_fwd_pp16_kernel(AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;
-    const int n16 = lane & 15, kg = lane >> 4;
-    const int w_ = (int)blockIdx.x;
-    const int wgid = w_ < p.split_first ? w_ : w_ + p.nsplit;          // whole workgroups: the launch skips the split parents
-
-    const bool rider = p.r_nq > 0 && wgid >= p.main_wgs;      // workgroup-uniform
-    const int bid = rider ? wgid - p.main_wgs : wgid;
-    const int nq_ = rider ? p.r_nq : p.nq;
-    const int nseg_ = rider ? 1 : p.nseg;
-    bf16_t* const out_ = rider ? p.r_out : p.out;
-    const long o_ld_ = rider ? p.r_o_ld : p.o_ld, o_sb_ = rider ? p.r_o_sb : p.o_sb;
-    const int nqt = (nq_ + 511) / 512;
-    const int nhb = p.heads * p.batch;
-    int hb, qt;
-    if ((nhb & 7) == 0) {
-        const int xcd = bid & 7, slot = bid >> 3;
-        hb = xcd + 8 * (slot / nqt);
-        qt = slot % nqt;
-    } else {
-        hb = bid / nqt;
-        qt = bid % nqt;
-    }
-    const int h = hb % p.heads, b = hb / p.heads;
-    const int q0 = qt * 512 + wave * 64;
-
-    // fragment offsets inside a [64 rows][128 B] tile.  K: row kappa(kb, n16), 16-B slot (4 ks + kg) ^ fK(row), fK(row) = 2 perm[(row >> 3) & 3] + ((row >> 1) & 1),
-    // perm = (0, 2, 3, 1): with this row order every 16-lane ds_read_b128 group ({0-3, 12-15, 20-27}, ...) touches 16 distinct bank quads.  fK depends on the lane only
-    // (kb moves the row by multiples of 4 inside its 8-row group and by 32).  V^T: row 16 db + n16, slot (4 kp + kg) ^ ((row >> 1) & 7) — the 32 x 32 kernel's swizzle.
-    const int fKl = 2 * ((0x1320 >> (4 * (n16 >> 2))) & 3) + ((n16 >> 1) & 1);
-    const int offK0 = (8 * (n16 >> 2) + (n16 & 3)) * 128 + ((kg ^ fKl) << 4);
-    const int offV0 = n16 * 128 + ((kg ^ ((n16 >> 1) & 7)) << 4);
-    // LDS-DMA piece of this wave: tile rows [wave*8, +8), lane -> row wave*8 + (lane>>3), physical slot lane&7; the source column is the LOGICAL slot stored there
-    const int drow = wave * 8 + (lane >> 3);
-    const int dslotV = ((lane & 7) ^ ((drow >> 1) & 7)) * 8;
-    const int dslotK = ((lane & 7) ^ (2 * ((0x1320 >> (4 * (wave & 3))) & 3) + ((lane >> 4) & 1))) * 8;
-
-#define PP_BAR()                                         \
-    do {                                                 \
-        __builtin_amdgcn_sched_barrier(0);               \
-        __builtin_amdgcn_s_barrier();                    \
-        __builtin_amdgcn_sched_barrier(0);               \
-    } while (0)
-
-    for (int sg = 0; sg < nseg_; ++sg) {
-        const Seg& S = rider ? p.r_s : p.s[sg];
-        bf16x8 qf[4][2];                                     // B operands of S^T: query 16 qb + n16, head dims 32 ks + 8 kg ..
-#pragma unroll
-        for (int qb = 0; qb < 4; ++qb) {
-            const int qrow = min(q0 + qb * 16 + n16, nq_ - 1);
-            const bf16_t* qp = S.q + (long)b * S.q_sb + (long)qrow * S.q_ld + h * 64 + kg * 8;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) qf[qb][ks] = *(const bf16x8*)(qp + ks * 32);
-        }
-        const bf16_t* kbase = S.k + (long)b * S.k_sb + h * 64 + dslotK;
-        const bf16_t* vsrc = S.vt + ((long)(b * p.heads + h) * 64 + drow) * S.vt_ld + dslotV;
-        const int ntiles = (S.nk + KVBLK - 1) / KVBLK;
-        const int tb = 0, te = ntiles;
-        const bf16_t* kcur = kbase + (long)min(tb * KVBLK + drow, S.nk - 1) * S.k_ld;
-        const bf16_t* const klast = kbase + (long)min((ntiles - 1) * KVBLK + drow, S.nk - 1) * S.k_ld;
-        const long kstep = (long)KVBLK * S.k_ld;
-        auto dmaK = [&](int t) {      // K(t) -> K buffer t&1
-            const bf16_t* const ksrc = t == ntiles - 1 ? klast : kcur;
-            kcur += kstep;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ksrc,
-                                             (__attribute__((address_space(3))) void*)(smem + (t & 1) * TILE_B + wave * 1024), 16, 0, 0);
-        };
-        auto dmaV = [&](int t) {      // V^T(t) -> V buffer t&1
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + (long)t * KVBLK),
-                                             (__attribute__((address_space(3))) void*)(smem + (2 + (t & 1)) * TILE_B + wave * 1024), 16, 0, 0);
-        };
-        auto dma_pair = [&](int u) {  // (K(u+1), V(u))
-            if (u + 1 < te) dmaK(u + 1);
-            if (u < te) dmaV(u);
-        };
-        auto dma_pair_all = [&](int u) { dmaK(u + 1); dmaV(u); };      // steady tiles: both exist
-
-        f32x4 acc_o[4][4], sc[4][4];                         // [query block][d block] rows = head dims 16 db + 4 kg + r; [query block][key block] rows = keys kappa(kb, 4 kg + r)
-        bf16x8 pf[4][2];                                     // B operands of O^T += V^T P: keys 32 kp + 8 kg .. + 7 of query 16 qb + n16
-        f32x4 cneg;                                          // -c, four times: the C operand that opens every S^T block.  ONE shift per lane for its four
-                                                             // queries (16 qb + n16) — the largest of their bounds; the four lanes of a query row (same n16) agree on it
-        // lane-partial row sums in element 0 (a lane sees a quarter of a row's keys; they meet in the epilogue).  Measured and not kept: the sums on the matrix
-        // pipe (all-ones A operand against P, 8 more MFMAs per tile for ~36 fewer VALU instructions): 7.02 vs 6.93 ms on the launch, same box
-        f32x4 lsum[4];
-        float cshift = 0.f;
-        {
-            const float kn2 = S.kn2[b * p.heads + h];
-#pragma unroll
-            for (int qb = 0; qb < 4; ++qb) {
-                float qn2 = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float v = bf16_to_f32((bf16_t)qf[qb][ks][i]);
-                        qn2 += v * v;
-                    }
-                qn2 += __shfl_xor(qn2, 16, 64);                        // the other three lanes of the query hold the other 48 head channels of the row
-                qn2 += __shfl_xor(qn2, 32, 64);
-                const float B = sqrtf(qn2 * kn2) * 1.01f;              // 1 %: fp32 accumulation order of the dot products and of the norms
-                uint32_t u = __float_as_uint(fmaxf(B - 64.f, 0.f));
-                if (u & 0xffffu) u = (u + 0x10000u) & 0xffff0000u;     // a bf16-representable value, rounded UP (the 32 x 32 kernel's seed had to be one; kept identical)
-                cshift = fmaxf(cshift, __uint_as_float(u));
-                lsum[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int db = 0; db < 4; ++db) acc_o[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            cneg = f32x4{-cshift, -cshift, -cshift, -cshift};
-        }
-        // P(t-1).V(t-1) alone (the last tile's)
-        auto pv = [&](int tprev) {
-            const char* tV = smem + (2 + (tprev & 1)) * TILE_B;
-#pragma unroll
-            for (int db = 0; db < 4; ++db)
-#pragma unroll
-                for (int kp = 0; kp < 2; ++kp) {
-                    const bf16x8 vf = *(const bf16x8*)(tV + ((offV0 ^ (kp << 6)) + db * 2048));
-#pragma unroll
-                    for (int qb = 0; qb < 4; ++qb) acc_o[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][kp], acc_o[qb][db], 0, 0, 0);
-                }
-        };
-        // X(t): 16 fragments — V^T(t-1) (db, kp) then K(t) (kb, ks) — software-pipelined NFR - 1 ahead; every fragment feeds 4 MFMAs (the four query blocks: 64 cycles)
-        auto xseg = [&](int t, auto guardc) {
-            const char* tV = smem + (2 + ((t - 1) & 1)) * TILE_B;
-            const char* tK = smem + (t & 1) * TILE_B;
-            constexpr int NFR = 3;
-            bf16x8 fr[NFR];
-            const uint32_t ldsV = (uint32_t)(uintptr_t)tV, ldsK = (uint32_t)(uintptr_t)tK;
-            auto ld = [&](int i) {
-                const int blk = (i & 7) >> 1, st = i & 1;
-                const uint32_t a = (i < 8) ? ldsV + (uint32_t)((offV0 ^ (st << 6)) + blk * 2048)
-                                           : ldsK + (uint32_t)((offK0 ^ (st << 6)) + (blk >> 1) * 4096 + (blk & 1) * 512);
-                asm volatile("ds_read_b128 %0, %1" : "=v"(fr[i % NFR]) : "v"(a));
-            };
-            auto wait_frag = [&](int i) {
-                const int younger = (15 - i) < (NFR - 1) ? (15 - i) : (NFR - 1);
-                if (younger == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fr[i % NFR]));
-                else if (younger == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fr[i % NFR]));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[i % NFR]));
-            };
-#pragma unroll
-            for (int i = 0; i < NFR; ++i) ld(i);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int blk = (i & 7) >> 1, st = i & 1;
-                __builtin_amdgcn_sched_barrier(0);
-                wait_frag(i);
-#pragma unroll
-                for (int qb = 0; qb < 4; ++qb) {
-                    if (i < 8) acc_o[qb][blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[i % NFR], pf[qb][st], acc_o[qb][blk], 0, 0, 0);
-                    else if (st == 0) sc[qb][blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[i % NFR], qf[qb][0], cneg, 0, 0, 0);
-                    else sc[qb][blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[i % NFR], qf[qb][1], sc[qb][blk], 0, 0, 0);
-                }
-
-                __builtin_amdgcn_sched_barrier(0);
-                if (i + NFR < 16) ld(i + NFR);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (decltype(guardc)::value) if ((t + 1) * KVBLK > S.nk) {
-#pragma unroll
-                for (int qb = 0; qb < 4; ++qb)
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int key = t * KVBLK + 32 * (kb >> 1) + 8 * kg + 4 * (kb & 1) + r;
-                            if (key >= S.nk) sc[qb][kb][r] = -1e30f;
-                        }
-            }
-        };
-        // softmax with the constant shift: P = exp2(s - c) straight from the accumulators, packed to the B operands of the next X; lane-partial row sums
-        auto softmax = [&]() {
-#pragma unroll
-            for (int qb = 0; qb < 4; ++qb) {
-                float e[4][4];
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) e[kb][r] = __builtin_amdgcn_exp2f(sc[qb][kb][r]);
-#pragma unroll
-                for (int kp = 0; kp < 2; ++kp) {
-                    union { bf16x8 v; uint32_t u[4]; } pk;
-                    pk.u[0] = pack_bf16x2(e[2 * kp][0], e[2 * kp][1]);
-                    pk.u[1] = pack_bf16x2(e[2 * kp][2], e[2 * kp][3]);
-                    pk.u[2] = pack_bf16x2(e[2 * kp + 1][0], e[2 * kp + 1][1]);
-                    pk.u[3] = pack_bf16x2(e[2 * kp + 1][2], e[2 * kp + 1][3]);
-                    pf[qb][kp] = pk.v;
-                }
-                f32x2 ls2[4];
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) ls2[kb] = f32x2{e[kb][0], e[kb][1]} + f32x2{e[kb][2], e[kb][3]};
-                const f32x2 lsm = (ls2[0] + ls2[1]) + (ls2[2] + ls2[3]);
-                lsum[qb][0] += lsm[0] + lsm[1];
-            }
-        };
-
-        // ---- prologue: K(0) resident for everybody; group 1 issues pair 0 and falls one barrier behind ----
-        // X(0) runs the P.V half too, on P = 0 against V buffer 1: zero both so that 0 x stale-LDS cannot make a NaN
-#pragma unroll
-        for (int qb = 0; qb < 4; ++qb)
-#pragma unroll
-            for (int kp = 0; kp < 2; ++kp) pf[qb][kp] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        *(uint4*)(smem + (2 + ((tb & 1) ^ 1)) * TILE_B + tid * 16) = uint4{0, 0, 0, 0};
-        dmaK(tb);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        PP_BAR();
-        if (grp == 1) {
-            dma_pair(tb);
-            PP_BAR();
-        }
-        auto tile = [&](auto guardc, int t) {
-            constexpr bool GUARD = decltype(guardc)::value;
-            if (grp == 0) { if constexpr (GUARD) dma_pair(t); else dma_pair_all(t); }
-            __builtin_amdgcn_s_setprio(2);
-            xseg(t, guardc);
-            __builtin_amdgcn_s_setprio(0);
-            if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t (issued one segment ago) has landed
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            PP_BAR();
-            if (grp == 1) { if constexpr (GUARD) dma_pair(t + 1); else dma_pair_all(t + 1); }
-            softmax();
-            if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t has landed
-            PP_BAR();
-        };
-        {
-            int t = tb;
-            for (; t < te - 2; ++t) tile(std::false_type{}, t);
-            for (; t < te; ++t) tile(std::true_type{}, t);
-        }
-        pv(te - 1);                                                                // X(nt): last P.V
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (grp == 0) PP_BAR();                                                    // barrier counts of the two groups meet again
-        PP_BAR();                                                                  // all LDS reads of this segment done
-
-        // ---- segment epilogue (as in the 32 x 32 kernel: O through the wave's LDS staging area [64 rows][128 B], 16-B slots XOR-swizzled by row & 7, so that every
-        // global access is a whole 128-byte row of this head; with two key segments the normalised result of segment 1 waits there and segment 2 adds on top).
-        // A lane holds 4 consecutive head dims (16 db + 4 kg ..) of ONE query per d block: 8-byte pieces.
-        char* stg = smem + 4 * TILE_B + wave * 8192;
-#pragma unroll
-        for (int qb = 0; qb < 4; ++qb) {
-            float lt = lsum[qb][0] + __shfl_xor(lsum[qb][0], 16, 64);
-            lt += __shfl_xor(lt, 32, 64);
-            const float w = (sg == 0 ? 1.f : p.seg2_scale_b[b & 15]) / lt;
-            const int row = qb * 16 + n16;
-            if (LSE && kg == 0 && q0 + row < nq_) p.lse[((long)b * p.heads + h) * p.lse_rows + q0 + row] = cshift + log2f(lt);
-            // verification of the constant shift (kernel header of attn_fwd_pp_kernel); also catches a NaN / inf row sum
-            if (__any(!(lt >= 5.421011e-20f && lt < 3.0e38f)) && lane == 0) p.retry[1 + wgid] = 1;
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                uint2* dst = (uint2*)(stg + row * 128 + (((2 * db + (kg >> 1)) ^ (row & 7)) << 4) + (kg & 1) * 8);
-                float v0 = acc_o[qb][db][0] * w, v1 = acc_o[qb][db][1] * w, v2 = acc_o[qb][db][2] * w, v3 = acc_o[qb][db][3] * w;
-                if (sg > 0) {     // `scale * O2` is a bf16 tensor before it is added to O1 (attention_processor.py:2117-2134)
-                    const uint2 prev = *dst;
-                    v0 = bf16lo_to_f32(prev.x) + round_bf16(v0); v1 = bf16hi_to_f32(prev.x) + round_bf16(v1);
-                    v2 = bf16lo_to_f32(prev.y) + round_bf16(v2); v3 = bf16hi_to_f32(prev.y) + round_bf16(v3);
-                }
-                uint2 o;
-                o.x = pack_bf16x2(v0, v1);
-                o.y = pack_bf16x2(v2, v3);
-                *dst = o;
-            }
-        }
-        if (sg + 1 == nseg_) {       // last segment: the staged rows go out, 8 rows (8 lanes x 16 B each) per instruction
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's own LDS writes (no other wave touches its area)
-            const int rl = lane >> 3, sl = lane & 7;
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = it * 8 + rl;
-                const int q = q0 + row;
-                const uint4 val = *(const uint4*)(stg + row * 128 + ((sl ^ (row & 7)) << 4));
-                if (q < nq_) *(uint4*)(out_ + (long)b * o_sb_ + (long)q * o_ld_ + h * 64 + sl * 8) = val;
-            }
-        }
-    }
-#undef PP_BAR
-}
-
 // Joins the two halves of every split parent: O = (Oa 2^(ma-M) + Ob 2^(mb-M)) / (la 2^(ma-M) + lb 2^(mb-M)), M = max(ma, mb) — with the
 // constant shift ma == mb and this is a plain sum — rounds to bf16, adds the second segment's bf16(seg2_scale * O2) like the unsplit epilogue,
 // and writes the parent's output rows.  The constant-shift verification of a split parent's segment 1 happens here, on the JOINED row sum.
@@ -1208,20 +911,14 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
         TG_DYN_LDS((attn_fwd_pp_kernel<__VA_ARGS__>), 4 * TILE_B + 8 * 8192);                                                       \
         hipLaunchKernelGGL((attn_fwd_pp_kernel<__VA_ARGS__>), dim3(GRID), dim3(512), PP_LDS, stream, p);                            \
     } while (0)
-#define TG_PP16(GRID, LSE_)                                                                                                          \
-    do {                                                                                                                            \
-        TG_DYN_LDS((attn_fwd_pp16_kernel<LSE_>), 4 * TILE_B + 8 * 8192);                                                           \
-        hipLaunchKernelGGL((attn_fwd_pp16_kernel<LSE_>), dim3(GRID), dim3(512), PP_LDS, stream, p);                                 \
-    } while (0)
-    const bool m16 = tg_knob(TG_KNOB_ATTN_M16) != 0;        // the whole constant-shift workgroups on the 16x16x32 kernel (0, cross-check tests: on the 32x32x16 one)
     if (pp && fixedm) {
         // the verified constant-shift pass, [the split tail and its join,] then the retry launch: a persistent grid that re-runs the flagged
         // workgroups (normally none)
         if (p.lse) {
-            if (m16) TG_PP16(main_grid, true); else TG_PP(main_grid, true, 1, true);
+            TG_PP(main_grid, true, 1, true);
             TG_PP(retry_grid, true, 0, true, true);
         } else {
-            if (m16) TG_PP16(main_grid, false); else TG_PP(main_grid, true, 1);
+            TG_PP(main_grid, true, 1);
             if (p.nsplit) {
                 TG_PP(split_grid, true, 1, false, false, true);
                 hipLaunchKernelGGL(attn_split_combine_kernel, dim3((unsigned)(4 * p.nsplit)), dim3(256), 0, stream, p, 1);
@@ -1246,7 +943,6 @@ static int attention_launch(AttnParams& p, float scale, int k_prescaled, const c
         hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3((unsigned)(nqt * heads * batch)), dim3(256), 0, stream, p);
     }
 #undef TG_PP
-#undef TG_PP16
     TG_LAUNCH_CHECK(who);
     return TG_OK;
 }

@@ -50,7 +50,7 @@ bool tg_first_on_device(TgOnce& once);
 // ---- dispatch overrides for the cross-check tests (tg_debug_set in the header): which of two product kernels of the same op a launcher picks.
 // The library reads no environment variable; the defaults are the shipped path.
 enum TgKnob { TG_KNOB_ATTN_PP_MIN_WG, TG_KNOB_ATTN_FIXEDM, TG_KNOB_ATTN_SPLIT, TG_KNOB_GEMM_W4, TG_KNOB_CONV_SPLITK, TG_KNOB_CONV_HALO, TG_KNOB_CONV_W4,
-              TG_KNOB_ATTN_M16, TG_KNOB_COUNT };
+              TG_KNOB_COUNT };
 long tg_knob(TgKnob k);
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
