@@ -374,6 +374,16 @@ int tg_act(const void* x, const void* dy, void* out, long n, int mode, hipStream
 
 /* tg_colsum for an fp32 matrix (same partial layout). */
 int tg_colsum_f32(const float* src, long ld, int rows, int cols, float* partial, hipStream_t stream);
+/* Column sums of up to TG_COLSUM_MAX matrices (bf16 or fp32, any row counts) in ONE launch: every item is cut into `row_blocks` row blocks, the partial sums form one
+ * fp32 matrix partial[row_blocks][sum of cols] (item i's columns start at the sum of the earlier items' cols); the caller adds the rows in order.  `items`: HOST memory. */
+#define TG_COLSUM_MAX 16
+typedef struct tg_colsum_item {
+    const void* src;
+    long        ld;
+    int         rows, cols;
+    int         src_is_f32;
+} tg_colsum_item;
+int tg_colsum_multi(const tg_colsum_item* items, int count, int row_blocks, float* partial, hipStream_t stream);
 
 /* Optimizer step on flat arenas (train_cogvideo_to2v.py:2012-2021: accelerator.clip_grad_norm_(transformer.parameters(), max_grad_norm), AdamW
  * (:1091-1098; betas / eps / weight decay of the yaml), zero_grad).  The reference's use_8bit_adam (bitsandbytes block-wise 8-bit moments, not under
@@ -383,6 +393,16 @@ int tg_colsum_f32(const float* src, long ld, int rows, int cols, float* partial,
  *   tg_adamw_step:      torch.optim.AdamW update of bf16 parameters with fp32 moments, gradient scaled by *clip_coef when given (device pointer,
  *                       no host synchronisation); zero_grad != 0 clears grad in the same pass. */
 int tg_grad_accumulate(const void* grad, int grad_is_bf16, float* acc, long n, float scale, int overwrite, hipStream_t stream);
+/* acc_i += scale * grad_i for a whole list of (gradient, accumulator) pairs in ONE launch per TG_ACCUM_MAX items (a transformer block hands over ~20
+ * gradients at once).  `items` is HOST memory: the table travels in the kernel arguments, nothing is copied to or kept on the device. */
+#define TG_ACCUM_MAX 48
+typedef struct tg_accum_item {
+    const void* grad;            /* bf16 or fp32 device tensor, n elements */
+    float*      acc;             /* fp32 device accumulator, n elements */
+    long        n;
+    int         grad_is_bf16;
+} tg_accum_item;
+int tg_grad_accumulate_multi(const tg_accum_item* items, int count, float scale, hipStream_t stream);
 long tg_grad_norm_ws_floats(void);
 int tg_grad_clip_coef(const float* grad, long n, float max_norm, float* ws, float* coef, hipStream_t stream);
 int tg_adamw_step(void* param, float* grad, float* exp_avg, float* exp_avg_sq, long n, int step, float lr, float beta1, float beta2, float eps,

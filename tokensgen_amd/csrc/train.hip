@@ -393,6 +393,30 @@ __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, 
     *(uint4*)(out + i * 8) = uint4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
 }
 
+// Column sums of SEVERAL matrices in one launch (a vip_norm's gradients need eight: 16 launches with their `partial.sum(0)`s, now 2).  Every item is cut into the
+// same number of row blocks NB, so the partials form ONE [NB][total columns] matrix that a single fixed-order sum finishes; the table travels by value.
+struct ColsumTable {
+    const void* src[TG_COLSUM_MAX];
+    long ld[TG_COLSUM_MAX];
+    int rows[TG_COLSUM_MAX], cols[TG_COLSUM_MAX], col0[TG_COLSUM_MAX];      // col0: first column of the item in the joint partial matrix
+    unsigned first_block[TG_COLSUM_MAX + 1];                                  // blockIdx.y ranges (256 columns per block)
+    unsigned f32_mask;
+    int count, total_cols;
+};
+__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumTable t, float* __restrict__ partial) {
+    int it = 0;
+    while (it + 1 < t.count && blockIdx.y >= t.first_block[it + 1]) ++it;
+    const int c = (blockIdx.y - t.first_block[it]) * 256 + threadIdx.x;
+    if (c >= t.cols[it]) return;
+    const int rows = t.rows[it], per = (rows + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
+    const long ld = t.ld[it];
+    float a = 0.f;
+    if ((t.f32_mask >> it) & 1u) for (int r = r0; r < r1; ++r) a += ((const float*)t.src[it])[(long)r * ld + c];
+    else for (int r = r0; r < r1; ++r) a += bf16_to_f32(((const bf16_t*)t.src[it])[(long)r * ld + c]);
+    partial[(long)blockIdx.x * t.total_cols + t.col0[it] + c] = a;
+}
+
 __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ src, long ld, int rows, int cols, float* __restrict__ partial, int CS_ROWS) {
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c >= cols) return;
@@ -444,6 +468,28 @@ extern "C" int tg_transpose_2d(const void* src, long ld, int rows, int cols, voi
 extern "C" long tg_colsum_partial_floats(int rows, int cols) {
     const int CS_ROWS = cs_rows(rows, cols);
     return (long)((rows + CS_ROWS - 1) / CS_ROWS) * cols;
+}
+
+extern "C" int tg_colsum_multi(const tg_colsum_item* items, int count, int row_blocks, float* partial, hipStream_t stream) {
+    TG_REQUIRE(items && partial && count > 0 && count <= TG_COLSUM_MAX && row_blocks > 0 && row_blocks <= 1024, TG_ERR_ARG, "tg_colsum_multi: 1..%d items, 1..1024 row blocks", TG_COLSUM_MAX);
+    ColsumTable t{};
+    t.count = count;
+    unsigned nb = 0;
+    int col0 = 0;
+    for (int i = 0; i < count; ++i) {
+        const tg_colsum_item& it = items[i];
+        TG_REQUIRE(it.src && it.rows > 0 && it.cols > 0 && it.ld >= it.cols, TG_ERR_SHAPE, "tg_colsum_multi: item %d: bad shape", i);
+        t.src[i] = it.src; t.ld[i] = it.ld; t.rows[i] = it.rows; t.cols[i] = it.cols; t.col0[i] = col0;
+        if (it.src_is_f32) t.f32_mask |= 1u << i;
+        t.first_block[i] = nb;
+        nb += (unsigned)((it.cols + 255) / 256);
+        col0 += it.cols;
+    }
+    t.first_block[count] = nb;
+    t.total_cols = col0;
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3((unsigned)row_blocks, nb), dim3(256), 0, stream, t, partial);
+    TG_LAUNCH_CHECK("tg_colsum_multi");
+    return TG_OK;
 }
 
 extern "C" int tg_colsum(const void* src, long ld, int rows, int cols, float* partial, hipStream_t stream) {
@@ -546,6 +592,33 @@ __global__ __launch_bounds__(OPT_BLOCK) void grad_accum_kernel(const void* __res
     }
 }
 
+// One launch for a whole dictionary of gradients (a block's ~20 parameters were 20 launches of 5 us): the table travels BY VALUE in the kernel arguments (no device
+// copy); workgroup w finds its item by a search over the cumulative block counts and covers OPT_BLOCK * 8 elements of it.
+struct AccumTable {
+    const void* src[TG_ACCUM_MAX];
+    float* dst[TG_ACCUM_MAX];
+    long n[TG_ACCUM_MAX];
+    unsigned first_block[TG_ACCUM_MAX + 1];
+    unsigned bf16_mask[(TG_ACCUM_MAX + 31) / 32];
+    int count;
+};
+__global__ __launch_bounds__(OPT_BLOCK) void grad_accum_multi_kernel(AccumTable t, float scale) {
+    int lo = 0, hi = t.count;                                  // first_block[lo] <= blockIdx.x < first_block[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (blockIdx.x >= t.first_block[mid]) lo = mid; else hi = mid;
+    }
+    const long base = (long)(blockIdx.x - t.first_block[lo]) * (OPT_BLOCK * 8);
+    const bool bf = (t.bf16_mask[lo >> 5] >> (lo & 31)) & 1u;
+    float* acc = t.dst[lo];
+    const long n = t.n[lo];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long i = base + (long)k * OPT_BLOCK + threadIdx.x;
+        if (i < n) acc[i] += scale * (bf ? bf16_to_f32(((const bf16_t*)t.src[lo])[i]) : ((const float*)t.src[lo])[i]);
+    }
+}
+
 __global__ __launch_bounds__(OPT_BLOCK) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
     float a = 0.f;
     for (long i = (long)blockIdx.x * OPT_BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * OPT_BLOCK) { const float v = g[i]; a += v * v; }
@@ -596,6 +669,29 @@ extern "C" int tg_grad_accumulate(const void* grad, int grad_is_bf16, float* acc
     if (grad_is_bf16) hipLaunchKernelGGL(grad_accum_kernel<true>, dim3(opt_blocks(n)), dim3(OPT_BLOCK), 0, stream, grad, acc, n, scale, overwrite);
     else hipLaunchKernelGGL(grad_accum_kernel<false>, dim3(opt_blocks(n)), dim3(OPT_BLOCK), 0, stream, grad, acc, n, scale, overwrite);
     TG_LAUNCH_CHECK("tg_grad_accumulate");
+    return TG_OK;
+}
+
+extern "C" int tg_grad_accumulate_multi(const tg_accum_item* items, int count, float scale, hipStream_t stream) {
+    TG_REQUIRE(items && count > 0, TG_ERR_ARG, "tg_grad_accumulate_multi: no items");
+    for (int i0 = 0; i0 < count; i0 += TG_ACCUM_MAX) {
+        AccumTable t{};
+        t.count = count - i0 < TG_ACCUM_MAX ? count - i0 : TG_ACCUM_MAX;
+        unsigned nb = 0;
+        for (int i = 0; i < t.count; ++i) {
+            const tg_accum_item& it = items[i0 + i];
+            TG_REQUIRE(it.grad && it.acc && it.n > 0, TG_ERR_ARG, "tg_grad_accumulate_multi: item %d: null pointer or empty", i0 + i);
+            t.src[i] = it.grad; t.dst[i] = it.acc; t.n[i] = it.n;
+            if (it.grad_is_bf16) t.bf16_mask[i >> 5] |= 1u << (i & 31);
+            t.first_block[i] = nb;
+            const long blocks = (it.n + OPT_BLOCK * 8 - 1) / (OPT_BLOCK * 8);
+            TG_REQUIRE(blocks < (1L << 30) && nb + blocks < (1L << 31), TG_ERR_SHAPE, "tg_grad_accumulate_multi: too many elements");
+            nb += (unsigned)blocks;
+        }
+        t.first_block[t.count] = nb;
+        hipLaunchKernelGGL(grad_accum_multi_kernel, dim3(nb), dim3(OPT_BLOCK), 0, stream, t, scale);
+    }
+    TG_LAUNCH_CHECK("tg_grad_accumulate_multi");
     return TG_OK;
 }
 

@@ -46,6 +46,8 @@ PROTOTYPES = {
     "tg_gate_residual_bwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, C.POINTER(GroupTable), _vp, _i, _vp],
     "tg_act": [_vp, _vp, _vp, _l, _i, _vp],
     "tg_colsum_f32": [_vp, _l, _i, _i, _vp, _vp],
+    "tg_colsum_multi": [_vp, _i, _i, _vp, _vp],
+    "tg_grad_accumulate_multi": [_vp, _i, _f, _vp],
     "tg_grad_accumulate": [_vp, _i, _vp, _l, _f, _i, _vp],
     "tg_grad_clip_coef": [_vp, _l, _f, _vp, _vp, _vp],
     "tg_adamw_step": [_vp, _vp, _vp, _vp, _l, _i, _f, _f, _f, _f, _f, _vp, _i, _vp],
@@ -145,6 +147,19 @@ def debug_set(knob, value):
 def check(code, what):
     if code != 0:
         raise RuntimeError(f"{what} failed ({code}): {load().tg_last_error_string().decode()}")
+
+
+class AccumItem(C.Structure):
+    """tg_accum_item (include/tokensgen_hip.h)"""
+    _fields_ = [("grad", C.c_void_p), ("acc", C.c_void_p), ("n", C.c_long), ("grad_is_bf16", C.c_int)]
+
+
+class ColsumItem(C.Structure):
+    """tg_colsum_item (include/tokensgen_hip.h)"""
+    _fields_ = [("src", C.c_void_p), ("ld", C.c_long), ("rows", C.c_int), ("cols", C.c_int), ("src_is_f32", C.c_int)]
+
+
+TG_ACCUM_MAX, TG_COLSUM_MAX = 48, 16
 
 
 class AttnSegment(C.Structure):

@@ -82,16 +82,21 @@ class ParamArena:
 
     @torch.no_grad()
     def accumulate(self, grads, scale=1.0):
-        """grad arena += scale * grads[name] for every entry (bf16 or fp32 tensors shaped like the parameter)."""
+        """grad arena += scale * grads[name] for every entry (bf16 or fp32 tensors shaped like the parameter) — one launch per L.TG_ACCUM_MAX entries."""
+        if not grads:
+            return
         lib = L.load()
-        for n, g in grads.items():
+        items = (L.AccumItem * len(grads))()
+        keep = []                                          # the contiguous copies must outlive the launch call
+        for i, (n, g) in enumerate(grads.items()):
             if tuple(g.shape) != self.shapes[n]:
                 raise ValueError(f"gradient of {n}: shape {tuple(g.shape)} != parameter shape {self.shapes[n]}")
             g = g.contiguous()
             if g.dtype not in (BF16, torch.float32):
                 raise TypeError(f"gradient of {n}: dtype {g.dtype}")
-            dst = self.grad.data_ptr() + 4 * self.offsets[n]
-            L.check(lib.tg_grad_accumulate(g.data_ptr(), 1 if g.dtype == BF16 else 0, dst, g.numel(), float(scale), 0, K._stream()), "tg_grad_accumulate")
+            keep.append(g)
+            items[i].grad, items[i].acc, items[i].n, items[i].grad_is_bf16 = g.data_ptr(), self.grad.data_ptr() + 4 * self.offsets[n], g.numel(), 1 if g.dtype == BF16 else 0
+        L.check(lib.tg_grad_accumulate_multi(items, len(grads), float(scale), K._stream()), "tg_grad_accumulate_multi")
 
     def state_dict(self):
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}

@@ -86,6 +86,29 @@ def transpose_2d(src, rows_pad=None):
     return dst
 
 
+def colsum_multi(mats):
+    """Column sums of several [R_i, C_i] matrices (bf16 or fp32) with two launches in all: tg_colsum_multi (every matrix cut into the same number of row blocks)
+    + one fixed-order sum of the joint partial matrix.  Returns the list of fp32 [C_i] sums."""
+    lib = L.load()
+    assert 0 < len(mats) <= L.TG_COLSUM_MAX
+    items = (L.ColsumItem * len(mats))()
+    rmax = 0
+    for i, m in enumerate(mats):
+        assert m.dim() == 2 and m.stride(1) == 1 and m.dtype in (BF16, torch.float32)
+        items[i].src, items[i].ld, items[i].rows, items[i].cols, items[i].src_is_f32 = m.data_ptr(), m.stride(0), m.shape[0], m.shape[1], 1 if m.dtype == torch.float32 else 0
+        rmax = max(rmax, m.shape[0])
+    total = sum(m.shape[1] for m in mats)
+    nb = max(1, min(256, rmax // 8))                     # >= 8 rows per block of the tallest item; a function of the shapes only (fixed summation order)
+    part = torch.empty(nb, total, dtype=torch.float32, device=mats[0].device)
+    L.check(lib.tg_colsum_multi(items, len(mats), nb, part.data_ptr(), K._stream()), "tg_colsum_multi")
+    sums = part.sum(dim=0)
+    out, c0 = [], 0
+    for m in mats:
+        out.append(sums[c0:c0 + m.shape[1]])
+        c0 += m.shape[1]
+    return out
+
+
 def colsum(src):
     """fp32 [C] column sums of a bf16 [R, C] matrix (tg_colsum + a fixed-order sum of the per-block partials)."""
     K._chk(src, "src")
@@ -123,21 +146,33 @@ def linear_backward(x2d, dy2d, weight=None, need_dx=False):
     return dW, db, dx
 
 
-def linear_backward_dx(dy2d, weight, accumulate_into=None, ones=None):
-    """dx = dy W only (frozen layers): [M, out] x [out, in] -> [M, in] bf16.  accumulate_into ([B, T, in] bf16 view) + ones (a unit-gate GroupTable):
-    dy is [B, T, out] and dx is ADDED to the view through the GEMM's gated-residual epilogue (in place, no separate pass)."""
+def _weight_t(weight, frozen):
+    """W^T [in_p, out_p] (zero padded to the GEMM's granules) of an nn.Linear weight [out, in].  frozen: None, or (cache dict owned by the caller, key) for a
+    weight that never changes during training — its transpose is made once and kept there (the dgrad GEMMs of the frozen layers transposed ~190 MB per block
+    and micro-step again and again; 8.6 GB kept for the 42 blocks at the 5B shapes)."""
+    cout, cin = weight.shape
+    cin_p, cout_p = _pad_to(cin, 128), _pad_to(cout, 64)
+    if frozen is not None and frozen[1] in frozen[0]:
+        return frozen[0][frozen[1]]
+    wT = (torch.zeros if (cin_p != cin or cout_p != cout) else torch.empty)(cin_p, cout_p, dtype=BF16, device=weight.device)
+    L.check(L.load().tg_transpose_2d(weight.data_ptr(), weight.stride(0), cout, cin, wT.data_ptr(), cout_p, cout_p, K._stream()), "tg_transpose_2d")
+    if frozen is not None:
+        frozen[0][frozen[1]] = wT
+    return wT
+
+
+def linear_backward_dx(dy2d, weight, accumulate_into=None, ones=None, frozen=None):
+    """dx = dy W only: [M, out] x [out, in] -> [M, in] bf16.  accumulate_into ([B, T, in] bf16 view) + ones (a unit-gate GroupTable):
+    dy is [B, T, out] and dx is ADDED to the view through the GEMM's gated-residual epilogue (in place, no separate pass).  frozen: see _weight_t."""
     if accumulate_into is not None:
         cout, cin = weight.shape
         assert cin % 128 == 0 and cout % 64 == 0 and dy2d.dim() == 3
-        wT = torch.empty(cin, cout, dtype=BF16, device=dy2d.device)
-        L.check(L.load().tg_transpose_2d(weight.data_ptr(), weight.stride(0), cout, cin, wT.data_ptr(), cout, cout, K._stream()), "tg_transpose_2d")
-        K.gemm(dy2d, wT, None, accumulate_into, L.EPI_BIAS_GATE_RES, residual=accumulate_into, gate=ones)
+        K.gemm(dy2d, _weight_t(weight, frozen), None, accumulate_into, L.EPI_BIAS_GATE_RES, residual=accumulate_into, gate=ones)
         return accumulate_into
     M, cout = dy2d.shape
     cin = weight.shape[1]
     cin_p, cout_p = _pad_to(cin, 128), _pad_to(cout, 64)
-    wT = torch.zeros(cin_p, cout_p, dtype=BF16, device=dy2d.device)
-    L.check(L.load().tg_transpose_2d(weight.data_ptr(), weight.stride(0), cout, cin, wT.data_ptr(), cout_p, cout_p, K._stream()), "tg_transpose_2d")
+    wT = _weight_t(weight, frozen)
     dyp = dy2d if cout_p == cout else torch.nn.functional.pad(dy2d, (0, cout_p - cout))
     dxp = torch.empty(M, cin_p, dtype=BF16, device=dy2d.device)
     K.gemm(dyp, wT, None, dxp, L.EPI_BIAS)
@@ -208,6 +243,26 @@ def _colsum_f32(src2d):
 
 LOG2E = 1.4426950408889634
 _FAST_WS = {}
+_TOK_GROUP, _VT_SCRATCH = {}, {}
+
+
+def _tok_group(Nt, Nv, Np, frames, dev):
+    """token -> modulation group of the joint stream text | video | vip (one device tensor per geometry, shared by every block)."""
+    key = (Nt, Nv, Np, frames, str(dev))
+    if key not in _TOK_GROUP:
+        tg = torch.empty(Nt + Nv + Np, dtype=torch.uint8)
+        tg[:Nt], tg[Nt:Nt + Nv], tg[Nt + Nv:] = frames, (torch.arange(Nv) // (Nv // frames)).to(torch.uint8), frames + 1
+        _TOK_GROUP[key] = tg.to(dev)
+    return _TOK_GROUP[key]
+
+
+def _vt_scratch(B, H, padded, tag, dev):
+    """V^T scratch of one attention call [B, H, 64, padded keys]: read by that call's forward only (nothing of it is kept for the backward), so every block reuses
+    the same buffer per (shape, call); zero once — the transposition rewrites every real key column, the pad columns stay zero."""
+    key = (B, H, padded, tag, str(dev))
+    if key not in _VT_SCRATCH:
+        _VT_SCRATCH[key] = torch.zeros(B, H, 64, padded, dtype=BF16, device=dev)
+    return _VT_SCRATCH[key]
 
 
 def _fast_attention_ws(nq, heads, batch, device):
@@ -284,6 +339,7 @@ class To2VBlockTrainer:
         vip_scale = float(torch.tensor(float(vip_scale), dtype=BF16))
         self.sd, self.pre, self.H, self.Nt, self.Np, self.F, self.s, self.eps = sd, pre, heads, n_text, n_vip, frames, vip_scale, eps
         self.keep = True          # False: forward only (the checkpointed pass of To2VTrainer keeps nothing but the block inputs)
+        self._wt = {}             # transposes of this block's FROZEN weights, made on first use (_weight_t); a trainer built on other weights starts empty
         g = lambda n: sd[f"{pre}.{n}"]
         P = "attn1.processor."
         self.Wqkv = _cat_or_view([g(f"attn1.to_{n}.weight") for n in "qkv"])
@@ -296,7 +352,7 @@ class To2VBlockTrainer:
         sd, pre = self.sd, self.pre
         B, F_, _ = emb.shape
         D = self.D
-        mod = torch.zeros(B, F_, 9 * D, dtype=BF16, device=emb.device)
+        mod = torch.empty(B, F_, 9 * D, dtype=BF16, device=emb.device)            # (columns 6D.. of frames > 0 are never read: the vip groups use row 0)
         K.gemm(emb, sd[f"{pre}.norm{which}.linear.weight"], sd[f"{pre}.norm{which}.linear.bias"], mod[:, :, :6 * D], L.EPI_BIAS)
         K.gemm(emb[:, :1], sd[f"{pre}.vip_norm{which}.linear.weight"], sd[f"{pre}.vip_norm{which}.linear.bias"], mod[:, :1, 6 * D:], L.EPI_BIAS)
         D_, Fr = D, self.F
@@ -322,9 +378,7 @@ class To2VBlockTrainer:
         dev = X0.device
         e = lambda *s: torch.empty(*s, dtype=BF16, device=dev)
         hw = Nv // self.F
-        tg = torch.empty(N, dtype=torch.uint8)
-        tg[:Nt], tg[Nt:N1], tg[N1:] = self.F, (torch.arange(Nv) // hw).to(torch.uint8), self.F + 1
-        self.tok_group = tg.to(dev)
+        self.tok_group = _tok_group(Nt, Nv, Np, self.F, dev)
         S = self.saved = {}
         emb = _act(temb.contiguous())
         mod1, t1 = self._mod(emb, 1)
@@ -353,7 +407,7 @@ class To2VBlockTrainer:
         K.qk_layernorm_rope_pair(qkvv[:, :, :D], qkvv[:, :, D:2 * D], H, sd[A + "processor.vip_norm_q.weight"], sd[A + "processor.vip_norm_q.bias"],
                                  sd[A + "processor.vip_norm_k.weight"], sd[A + "processor.vip_norm_k.bias"], 1e-6, (Nt, vrope), (N1, crope))
         pad = lambda n: (n + 63) // 64 * 64
-        vt = lambda v, n0, n: K.transpose_v(v, H, n0, n, torch.zeros(B, H, 64, pad(n), dtype=BF16, device=dev))
+        vt = lambda v, n0, n: K.transpose_v(v, H, n0, n, _vt_scratch(B, H, pad(n), (n0, n), dev))      # (tag = the call's key range: three distinct buffers)
         q, k, v = qkv[:, :, :D], qkv[:, :, D:2 * D], qkv_pre[:, :, 2 * D:]
         qx, kx, vx = qkvv[:, :N1, :D], qkvv[:, :N1, D:2 * D], qkvv_pre[:, :N1, 2 * D:]
         qv, kv, vv = qkvv[:, N1:, :D], qkvv[:, N1:, D:2 * D], qkvv_pre[:, N1:, 2 * D:]
@@ -399,9 +453,13 @@ class To2VBlockTrainer:
         Np = N - N1
         rows = lambda t, b: t.view(B, Np, D)[b]
         name = f"vip_norm{which}"
-        grads[f"{name}.norm.weight"] = sum(_colsum_f32(rows(t_dlnx, b)) for b in range(B))
-        grads[f"{name}.norm.bias"] = sum(_colsum_f32(rows(t_dln, b)) for b in range(B))
-        dmod = torch.stack([torch.cat([colsum(dxn[b, N1:]), _colsum_f32(rows(t_dyln, b)), _colsum_f32(rows(t_dgate, b))]) for b in range(B)])   # [B, 3D]: shift | scale | gate
+        # eight column sums, one launch + one fixed-order sum: the affine's over both batch items' rows at once, the modulation's (shift | scale | gate) per item
+        mats = [t_dlnx.view(B * Np, D), t_dln.view(B * Np, D)]
+        for b in range(B):
+            mats += [dxn[b, N1:], rows(t_dyln, b), rows(t_dgate, b)]
+        sums = colsum_multi(mats)
+        grads[f"{name}.norm.weight"], grads[f"{name}.norm.bias"] = sums[0], sums[1]
+        dmod = torch.stack([torch.cat(sums[2 + 3 * b:5 + 3 * b]) for b in range(B)])      # [B, 3D]: shift | scale | gate
         dW, db, _ = linear_backward(S["emb"][:, 0].contiguous(), dmod.to(BF16).contiguous())
         grads[f"{name}.linear.weight"], grads[f"{name}.linear.bias"] = dW, db
 
@@ -431,9 +489,9 @@ class To2VBlockTrainer:
         # ---- feed-forward residual (step 7), FeedForward, norm2 ----
         dy_ff, tg2 = _gate_res_bwd(dX2, S["y_ff"], S["t2"], row0=N1)          # gate products only for the vip rows (the group whose gate trains)
         Fw1, Fw2 = sd[f"{pre}.ff.net.0.proj.weight"], sd[f"{pre}.ff.net.2.weight"]
-        dhid = _dgrad(dy_ff.view(B * N, D), Fw2)
+        dhid = _dgrad(dy_ff.view(B * N, D), Fw2, frozen=(self._wt, "ff2"))
         dpre = _act(S["ffpre"].view(B * N, -1), dhid)
-        dXn2 = _dgrad(dpre, Fw1).view(B, N, D)
+        dXn2 = _dgrad(dpre, Fw1, frozen=(self._wt, "ff1")).view(B, N, D)
         dX1 = torch.empty(B, N, D, dtype=BF16, device=dX2.device)
         # norm2 is frozen on the text / video rows (no parameter products); `add`: X2 = X1 + gate * FF(norm2(X1)) also hands dX2 straight to X1
         _adaln_bwd(S["X1"][:, :N1], dXn2[:, :N1], dX1[:, :N1], sd[f"{pre}.norm2.norm.weight"], sd[f"{pre}.norm2.norm.bias"], self.eps, S["t2"], products=False,
@@ -443,7 +501,7 @@ class To2VBlockTrainer:
         self._vip_norm_grads(2, tb[0], tb[1], tb[2], dXn2, tg2, grads)
         # ---- attention residual (step 5), to_out ----
         dy_attn, tg1 = _gate_res_bwd(dX1, S["y_attn"], S["t1"], row0=N1)
-        dAO = _dgrad(dy_attn.view(B * N, D), sd[A + "to_out.0.weight"]).view(B, N, D)
+        dAO = _dgrad(dy_attn.view(B * N, D), sd[A + "to_out.0.weight"], frozen=(self._wt, "out")).view(B, N, D)
         # ---- the three attention calls, QK-norm + RoPE, projections ----
         ga = to2v_attention_backward(S["q"], S["k"], S["v"], S["qx"], S["kx"], S["vx"], S["qv"], S["kv"], S["vv"], S["o1"], S["o2"], S["o3"], dAO, H, 1.0 / 8.0, self.s, lse=S["lse"],
                                      kcat=S["kcat"], vcat=S["vcat"], k1_prescaled=True)
@@ -458,10 +516,10 @@ class To2VBlockTrainer:
         d_pre_b[:, :, 2 * D:] = ga["v"]
         dXn = _dgrad(d_pre_v.view(B * N, 3 * D), self.Wv).view(B, N, D)
         if dXn.is_contiguous() and D % 128 == 0:     # the base projection's share lands on the text + video rows through the GEMM's residual epilogue
-            linear_backward_dx(d_pre_b, self.Wqkv, accumulate_into=dXn[:, :N1], ones=self._ones(N1, D, B, dX2.device))
+            linear_backward_dx(d_pre_b, self.Wqkv, accumulate_into=dXn[:, :N1], ones=self._ones(N1, D, B, dX2.device), frozen=(self._wt, "qkv"))
         else:
             dXn = dXn.float()
-            dXn[:, :N1] += _dgrad(d_pre_b.reshape(B * N1, 3 * D), self.Wqkv).view(B, N1, D).float()
+            dXn[:, :N1] += _dgrad(d_pre_b.reshape(B * N1, 3 * D), self.Wqkv, frozen=(self._wt, "qkv")).view(B, N1, D).float()
             dXn = dXn.to(BF16)
         # ---- norm1 ----
         dX0 = torch.empty(B, N, D, dtype=BF16, device=dX2.device)
@@ -473,9 +531,9 @@ class To2VBlockTrainer:
         return grads, dX0
 
 
-def _dgrad(dy2d, weight):
+def _dgrad(dy2d, weight, frozen=None):
     """dx = dy W for y = x W^T (bf16 [M, out] x [out, in] -> [M, in]) through the MFMA GEMM."""
-    return linear_backward_dx(dy2d.contiguous(), weight)
+    return linear_backward_dx(dy2d.contiguous(), weight, frozen=frozen)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -564,6 +622,8 @@ class To2VTrainer:
         N1 = Nt + Nv
         if self._blocks is None or self._blocks[0].Nt != Nt or self._blocks[0].Np != Np or self._blocks[0].F != Fm:
             self._blocks = [To2VBlockTrainer(sd, f"transformer_blocks.{i}", self.H, Nt, Np, Fm, self.s, self.eps) for i in range(self.L)]
+        # the RoPE tables go to the device ONCE per forward (fp32, contiguous): every block's `.to(dev)` is then a no-op (six host-to-device copies per block before)
+        rope, vrope, crope = (tuple(t_.to(X.device, torch.float32).contiguous() for t_ in r) for r in (rope, vrope, crope))
         self._ropes = (rope, vrope, crope)
         # Per-block checkpointing as in the reference (cogvideox_transformer_3d.py:700-719) — except where memory allows otherwise: 80 GB parts
         # must recompute every block; with 288 GB most blocks can simply KEEP their activations (5 GB per block at batch 2), and only the rest

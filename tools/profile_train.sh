@@ -2,7 +2,7 @@
 # rocprofv3 kernel trace of the training bench, summed per (kernel, grid size) so that GEMM shapes show up separately.
 #   tools/profile_train.sh TAG [steps]  -> gpurun_out/TAG_train_kernel_stats.csv, gpurun_out/TAG_train_by_grid.json (ms per micro-step)
 tag=${1:-r3}
-steps=${2:-2}
+steps=${2:-5}
 R=$PWD
 out=$R/gpurun_out/prof_${tag}_train
 mkdir -p $out
