@@ -678,6 +678,36 @@ def test_optimizer_step_vs_torch_adamw_with_clipping():
             ref[k].data.copy_(got)                                           # the reference continues from the bf16 parameters, moments carry over
 
 
+def test_multi_item_launches_of_the_training_step_are_exact():
+    """Round-5 launch diet (train_cogvideo_to2v.py:1995-2021 has one autograd graph instead): tg_grad_accumulate_multi over MORE items than one kernel
+    argument table holds (chunks of TG_ACCUM_MAX, bf16 and fp32 sources of very different sizes) equals the per-item tg_grad_accumulate bit for bit, and
+    tg_colsum_multi (several matrices of different heights and dtypes, one launch + one fixed-order sum) matches fp64 column sums and is run-to-run bitwise."""
+    from tokensgen_amd import lib as L, optim, train
+    g = torch.Generator().manual_seed(21)
+    n_items = L.TG_ACCUM_MAX + 7
+    shapes = {f"transformer_blocks.0.p{i:02d}": ((3 + 5 * i, 17) if i % 3 else (4099 * (1 + i % 2),)) for i in range(n_items)}
+    params = {k: torch.zeros(*s).to(BF) for k, s in shapes.items()}
+    arena = optim.ParamArena({k: v.to(DEV) for k, v in params.items()}, optim.arena_order(list(params), 1), DEV)
+    grads = {k: (torch.randn(*s, generator=g).to(BF) if i % 2 else torch.randn(*s, generator=g)).to(DEV) for i, (k, s) in enumerate(shapes.items())}
+    arena.accumulate(grads, 0.25)
+    arena.accumulate(grads, 0.5)
+    lib = L.load()
+    want = torch.zeros_like(arena.grad)
+    for sc in (0.25, 0.5):
+        for k, gk in grads.items():
+            L.check(lib.tg_grad_accumulate(gk.data_ptr(), 1 if gk.dtype == BF else 0, want.data_ptr() + 4 * arena.offsets[k], gk.numel(), sc, 0,
+                                           torch.cuda.current_stream().cuda_stream), "tg_grad_accumulate")
+    assert torch.equal(arena.grad, want)
+    for k, gk in grads.items():
+        assert _rel(arena.grad_view(k), 0.75 * gk.float()) < 1e-6, k
+    mats = [torch.randn(960, 384, generator=g).to(DEV), torch.randn(960, 384, generator=g).to(BF).to(DEV), torch.randn(2, 480, 512, generator=g).to(BF).to(DEV)[1],
+            torch.randn(480, 384, generator=g).to(DEV)[:, :130], torch.randn(7, 33, generator=g).to(DEV)]
+    s1, s2 = train.colsum_multi(mats), train.colsum_multi(mats)
+    for a, b, m in zip(s1, s2, mats):
+        assert torch.equal(a, b) and a.shape == (m.shape[1],) and a.dtype == torch.float32
+        assert _rel(a, m.double().sum(dim=0)) < 2e-6
+
+
 def test_training_steps_reduce_the_loss_and_update_only_trainable_parameters(tmp_path):
     """train.To2VTrainStep end to end on a 2-layer model: three optimizer steps of two micro-steps each on one fixed batch — the loss falls, the
     arena-backed views are what the next forward reads (the fused vip_to_qkv weight is a view, not a stale copy), frozen tensors are untouched."""
