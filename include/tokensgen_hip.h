@@ -322,6 +322,18 @@ int tg_attention_bwd_ex(const void* q, long q_ld, long q_sb, const void* k, long
                         int nq, int nk, int heads, int batch, float scale, int accumulate, const float* lse, float* ws, int flags, int* status,
                         hipStream_t stream);
 
+/* One or two backward problems of the same heads / batch in one call — identical in effect to calling tg_attention_bwd_ex on each in order (problem 1's accumulate
+ * flags see problem 0's results only through tensors the CALLER orders: the two may not write the same dq / dk / dv rows).  When both take the one-kernel form they share ONE launch:
+ * the second problem's workgroups are appended behind the first's and fill its last, partial round of CUs (the To2V processor's main call, attention_processor.py:2066-2069, leaves a
+ * quarter round; its vip-key call, :2117-2125, has the same number of query tiles and rides there).  Fields as the arguments of tg_attention_bwd_ex. */
+typedef struct tg_attn_bwd_problem {
+    const void* q; long q_ld, q_sb;  const void* k; long k_ld, k_sb;  const void* v; long v_ld, v_sb;
+    const void* o; long o_ld, o_sb;  const void* dout; long do_ld, do_sb;
+    float* dq; long dq_ld, dq_sb;  float* dk; long dk_ld, dk_sb;  float* dv; long dv_ld, dv_sb;
+    int nq, nk;  float scale;  int accumulate;  const float* lse;  float* ws;
+} tg_attn_bwd_problem;
+int tg_attention_bwd_multi(const tg_attn_bwd_problem* problems, int count, int heads, int batch, int flags, int* status, hipStream_t stream);
+
 /* Device probe of what the one-kernel form relies on: (1) the workgroups of one residue class mod 8 of a 1-D launch share an XCD; (2) the exchange protocol itself — a chain
  * of 32 workgroups on one XCD adds to 64 tiles in chain order with exactly the kernel's primitives.  buf: caller-owned device memory of
  * tg_attention_bwd_probe_bytes() bytes (16-byte aligned); the call clears it and launches the probe, asynchronously.  The caller copies buf to the

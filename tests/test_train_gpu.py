@@ -154,6 +154,38 @@ def test_attention_bwd_product_kernels_vs_the_independent_cross_check_library(B,
     assert _rel(pq, dq) < 5e-3 and _rel(pk, dk) < 5e-3 and _rel(pv, dv) < 4e-3
 
 
+def test_attention_bwd_two_problems_in_one_launch_equal_two_calls():
+    """tg_attention_bwd_multi: the To2V processor's main call and its vip-key call (attention_processor.py:2066-2069, 2117-2125; same queries' length) handed over
+    together — when both take the one-kernel form the second rides in the first's launch.  Bitwise equal to the two separate calls (each head's key blocks still add
+    their dQ shares in key-block order), accumulate flags per problem honoured, status words clean; a pair whose second problem takes the two-launch form works too."""
+    from tokensgen_amd import kernels as K
+    B, H, nq, nk1, nk2 = 1, 8, 4100, 1000, 300
+    D = H * 64
+    mk = lambda n, seed, sc=1.2: _rand(B, n, D, seed=seed, scale=sc).to(DEV)
+    q1, k1, v1, o1, g1 = mk(nq, 31), mk(nk1, 32), mk(nk1, 33), mk(nq, 34, 0.3), mk(nq, 35, 0.3)
+    q2, k2, v2, o2, g2 = mk(nq, 36), mk(nk2, 37), mk(nk2, 38), mk(nq, 39, 0.3), mk(nq, 40, 0.3)
+    base = torch.randn(B, nk2, D, generator=torch.Generator().manual_seed(41)).to(DEV)
+    for kk2, nkk2 in ((k2, nk2), (mk(1500, 42), 1500)):            # second case: 6 key blocks for 129 query tiles -> still one kernel; then a two-launch second problem below
+        vv2 = v2 if nkk2 == nk2 else mk(nkk2, 43)
+        b0 = base if nkk2 == nk2 else torch.randn(B, nkk2, D, generator=torch.Generator().manual_seed(44)).to(DEV)
+        a1 = K.attention_bwd(q1, k1, v1, o1, g1, H, math.log(2.0))
+        dk_s, dv_s = b0.clone(), b0.clone() * 2
+        a2 = K.attention_bwd(q2, kk2, vv2, o2, g2, H, 0.125, dk=dk_s, dv=dv_s, accumulate=2)
+        dk_m, dv_m = b0.clone(), b0.clone() * 2
+        m1, m2 = K.attention_bwd_multi([dict(q=q1, k=k1, v=v1, o=o1, dout=g1, scale=math.log(2.0)),
+                                        dict(q=q2, k=kk2, v=vv2, o=o2, dout=g2, scale=0.125, dk=dk_m, dv=dv_m, accumulate=2)], H)
+        K.attention_bwd_check(DEV)
+        for x, y in zip(a1 + a2, m1 + m2):
+            assert torch.equal(x, y)
+    # a second problem with few query tiles per key block (two-launch form) beside a one-kernel first problem
+    q3, o3, g3 = mk(200, 45), mk(200, 46, 0.3), mk(200, 47, 0.3)
+    s3 = K.attention_bwd(q3, k1, v1, o3, g3, H, 0.125)
+    m1, m3 = K.attention_bwd_multi([dict(q=q1, k=k1, v=v1, o=o1, dout=g1, scale=math.log(2.0)), dict(q=q3, k=k1, v=v1, o=o3, dout=g3, scale=0.125)], H)
+    K.attention_bwd_check(DEV)
+    for x, y in zip(a1 + s3, m1 + m3):
+        assert torch.equal(x, y)
+
+
 def test_attention_bwd_poll_timeout_is_reported_not_silent():
     """The one-kernel backward's ordered dQ exchange is bounded (a key block that never sees its predecessor's signal goes on instead of hanging the
     GPU) — and that MUST be visible: the poll limit is forced to 1 through the caller-owned status words (include/tokensgen_hip.h, tg_attention_bwd_ex

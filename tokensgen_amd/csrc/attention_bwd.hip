@@ -87,8 +87,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2_trans(float lo, float hi) {
 // (Q | dO for dK/dV, K | V for dQ) nearly in step and share it in that XCD's L2.  With the plain (block, head-batch) grid the 70 key blocks of a
 // head were dealt round-robin to all 8 XCDs and each XCD streamed the head's Q / dO on its own: 14.7 GB of L2 misses per dK/dV launch against
 // ~1.5 GB algorithmic (profiles/r2_attention_bwd_pmc.json).
-__device__ __forceinline__ void xcd_block(int nx, int nhb, int& blk, int& hb) {
-    const int w = blockIdx.x;
+__device__ __forceinline__ void xcd_block(int w, int nx, int nhb, int& blk, int& hb) {
     if ((nhb & 7) == 0) {
         const int xcd = w & 7, slot = w >> 3;
         hb = xcd + 8 * (slot / nx);
@@ -175,7 +174,7 @@ __global__ __launch_bounds__(256) void attn_bwd_stats2_kernel(BwdParams p) {
             }
             p.dsum[stat0 + r] = d;
             sDs[tid] = d;
-            if (p.have_lse) p.seed[stat0 + r] = seed_row(p.lse[stat0 + r], d, p.scale_log2);
+            if (p.have_lse) p.seed[stat0 + r] = seed_row(p.lse[stat0 + r], d, p.unit_seed ? 1.0f : p.scale_log2);
         }
     }
     if (p.have_lse) return;
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(256) void attn_bwd_stats2_kernel(BwdParams p) {
         if (hi == 0 && q < p.nq) {
             const float lse = M + log2f(Lsum);
             p.lse[stat0 + q] = lse;
-            p.seed[stat0 + q] = seed_row(lse, sDs[wave * 64 + qb * 32 + j], p.scale_log2);      // sDs: written before the tile loop's barriers
+            p.seed[stat0 + q] = seed_row(lse, sDs[wave * 64 + qb * 32 + j], p.unit_seed ? 1.0f : p.scale_log2);      // sDs: written before the tile loop's barriers
         }
     }
 }
@@ -267,7 +266,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv7_kernel(Bwd2Params pp) {
     const int grp = wave >> 2;
     const int j = lane & 31, hi = lane >> 5;
     int blk, hb;
-    xcd_block((p.nk + 255) / 256, p.heads * p.batch, blk, hb);
+    xcd_block((int)blockIdx.x, (p.nk + 255) / 256, p.heads * p.batch, blk, hb);
     const int h = hb % p.heads, b = hb / p.heads;
     const int kw0 = blk * 256 + wave * 32;
     const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
@@ -490,7 +489,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hi = lane >> 5;
     int blk, hb;
-    xcd_block((p.nq + 255) / 256, p.heads * p.batch, blk, hb);
+    xcd_block((int)blockIdx.x, (p.nq + 255) / 256, p.heads * p.batch, blk, hb);
     const int h = hb % p.heads, b = hb / p.heads;
     const int qw0 = blk * 256 + wave * 64;
     const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
@@ -630,6 +629,13 @@ struct FusedParams {
     int* status;         // caller-owned int32[4]: [0] sticky count of exchange polls that timed out (dq of such a launch is INVALID), [1] poll limit (0: 2^20),
                          // [2] sticky count of workgroups that found their head's key blocks on MORE than one XCD (the exchange then is not coherent: dq INVALID)
     int* xmask;          // [heads * batch]: bit x set = a key block of this (batch, head) ran on XCD x (zeroed by the launcher)
+    // "rider": a second call of the same heads / batch whose workgroups are appended to the launch (workgroup index >= main_wgs; main_wgs is a multiple of 8, so a
+    // rider workgroup keeps its XCD residue).  The training step's main call leaves 6720 - 26 * 256 = 64 workgroups for its last round of 256 CUs; the vip-key call of the
+    // same processor (192 workgroups of the same length: 17776 queries) rides in that round instead of costing a launch of its own.
+    BwdParams r;
+    int* r_cnt;
+    int* r_xmask;
+    int main_wgs;        // workgroups of the main call; the grid is main_wgs + (r.nq > 0 ? rider workgroups : 0)
 };
 constexpr int DSLD = 40;                 // dS^T tile row stride in elements (80 B: 8-byte aligned 4-query runs)
 constexpr int DQLD = 68;                 // dQ tile row stride in floats (272 B: the 16 lanes of a block column land on different banks)
@@ -667,7 +673,9 @@ __device__ __forceinline__ void cnt_write(int* c, int v) { asm volatile("global_
 // no atomics on the data; coherence through the XCD's L2 exactly as in the in-phase form (plain stores, one buffer_inv sc1 per workgroup, sc1 polls).
 //   tile T: dS^T in Y(T) -> partial in X(T+2) -> [group 1: exchanged in Y(T+2); group 0: in Y(T+3)] -> acknowledged at the top of the next Y -> signalled
 //   at the head of the X after that.  The loop runs PP_EXTRA masked tiles past the last one (P = dS = 0 exactly: they add nothing to dK / dV) instead of a drain.
-// UNIT: scale * log2(e) == 1 (the training step hands over K prescaled by scale * log2 e and scale = ln 2): exp2 of the accumulator, no multiply.
+// scale * log2(e) == 1 (the training step hands over its main call's K prescaled by scale * log2 e, and scale = ln 2): P = exp2 of the accumulator, no multiply — a
+// workgroup-uniform choice between two copies of the softmax (the main call and a rider may differ).  Measured and dropped: folding the factor into the resident K
+// fragments for every caller (bf16(k * scale_log2): no multiply anywhere) — the forward had used the unrounded K, and the gradient error of such calls doubled (dV 2.3e-3 -> 4.9e-3).
 // =================================================================================================================================
 constexpr int PP_EXTRA = 3;
 constexpr int PP_RING = 4;
@@ -692,9 +700,11 @@ __device__ __forceinline__ void gst16f(const f32x4& v, void* sbase, uint32_t vof
     asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 
-template <bool UNIT>
 __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) {
-    const BwdParams& p = fp.p;
+    const bool rider = (int)blockIdx.x >= fp.main_wgs;       // workgroup-uniform
+    const BwdParams& p = rider ? fp.r : fp.p;
+    int* const cnt_base = rider ? fp.r_cnt : fp.cnt;
+    int* const xmask_base = rider ? fp.r_xmask : fp.xmask;
     constexpr int RING = PP_RING;
     constexpr int DO_OFF = RING * ROWT_EL * 2;              // byte distance Q tile b -> dO tile b
     extern __shared__ __attribute__((aligned(16))) char psm[];
@@ -705,7 +715,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) 
     const int grp = wave >> 2, wg = wave & 3;
     const int j = lane & 31, hi = lane >> 5, t16 = lane & 15, g4 = lane >> 4;
     int blk, hb;
-    xcd_block((p.nk + 255) / 256, p.heads * p.batch, blk, hb);
+    xcd_block((int)blockIdx.x - (rider ? fp.main_wgs : 0), (p.nk + 255) / 256, p.heads * p.batch, blk, hb);
     const int h = hb % p.heads, b = hb / p.heads;
     const int kw0 = blk * 256 + wave * 32;
     const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
@@ -719,8 +729,9 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) 
     int xold = 0, xbit = 0;
     if (tid == 0) {
         xbit = 1 << (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u);           // HW_REG_XCC_ID, bits 3:0
-        xold = __hip_atomic_fetch_or(fp.xmask + hb, xbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        xold = __hip_atomic_fetch_or(xmask_base + hb, xbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    const bool unit = p.scale_log2 == 1.0f;                  // workgroup-uniform
     bf16x8 kf[4], vf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -826,7 +837,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) 
     const bool okDQLast = qlast + er < p.nq;
     const bool first = blk == 0 && !(p.accumulate & 1);      // nothing to read: this workgroup's block starts the sum
     constexpr int CNT_PAD = 32;                               // one 128-byte line per (head, tile); word g = group g's chain
-    int* const cntw = fp.cnt + (long)hb * ntile * CNT_PAD + grp;
+    int* const cntw = cnt_base + (long)hb * ntile * CNT_PAD + grp;
     const int lag = 3 - grp;                                 // Y(u) exchanges tile u - lag (both groups' partials of it are complete and behind a barrier)
     f32x4 ldv = f32x4{0.f, 0.f, 0.f, 0.f};
     int cval = 0;                                           // (wave 4 g) counter of the next tile to check, sampled one Y ahead
@@ -974,26 +985,29 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) 
         // P = exp2(S), dS = P o dP -> the A operands of X(it + 1); dS^T -> LDS for X(it + 2)
         {
             const uint32_t dsw = dsW + (uint32_t)((it & 1) * PP_DS_SLOT);
-#define PP_SOFTMAX(g)                                                                                                             \
+#define PP_SOFTMAX(g, SC)                                                                                                         \
             do {                                                                                                                  \
                 uint2 w01;                                                                                                        \
                 {                                                                                                                 \
-                    const float p0 = fast_exp2(UNIT ? s[4 * (g)] : s[4 * (g)] * p.scale_log2);                                    \
-                    const float p1 = fast_exp2(UNIT ? s[4 * (g) + 1] : s[4 * (g) + 1] * p.scale_log2);                            \
+                    const float p0 = fast_exp2(SC(s[4 * (g)])), p1 = fast_exp2(SC(s[4 * (g) + 1]));                               \
                     pA[(g) >> 1].w[((g) & 1) * 2] = pack_bf16x2_trans(p0, p1);                                                    \
                     w01.x = pack_bf16x2(p0 * dp[4 * (g)], p1 * dp[4 * (g) + 1]);                                                  \
                     dA[(g) >> 1].w[((g) & 1) * 2] = w01.x;                                                                        \
                 }                                                                                                                 \
                 {                                                                                                                 \
-                    const float p0 = fast_exp2(UNIT ? s[4 * (g) + 2] : s[4 * (g) + 2] * p.scale_log2);                            \
-                    const float p1 = fast_exp2(UNIT ? s[4 * (g) + 3] : s[4 * (g) + 3] * p.scale_log2);                            \
+                    const float p0 = fast_exp2(SC(s[4 * (g) + 2])), p1 = fast_exp2(SC(s[4 * (g) + 3]));                           \
                     pA[(g) >> 1].w[((g) & 1) * 2 + 1] = pack_bf16x2_trans(p0, p1);                                                \
                     w01.y = pack_bf16x2(p0 * dp[4 * (g) + 2], p1 * dp[4 * (g) + 3]);                                              \
                     dA[(g) >> 1].w[((g) & 1) * 2 + 1] = w01.y;                                                                    \
                 }                                                                                                                 \
                 asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(dsw), "v"(w01), "i"(16 * (g)) : "memory");                    \
             } while (0)
-            PP_SOFTMAX(0); PP_SOFTMAX(1); PP_SOFTMAX(2); PP_SOFTMAX(3);
+#define PP_SC_UNIT(x) (x)
+#define PP_SC_MUL(x) ((x) * p.scale_log2)
+            if (unit) { PP_SOFTMAX(0, PP_SC_UNIT); PP_SOFTMAX(1, PP_SC_UNIT); PP_SOFTMAX(2, PP_SC_UNIT); PP_SOFTMAX(3, PP_SC_UNIT); }
+            else { PP_SOFTMAX(0, PP_SC_MUL); PP_SOFTMAX(1, PP_SC_MUL); PP_SOFTMAX(2, PP_SC_MUL); PP_SOFTMAX(3, PP_SC_MUL); }
+#undef PP_SC_UNIT
+#undef PP_SC_MUL
 #undef PP_SOFTMAX
         }
         if (wg == 0) {                                      // the group's first wave keeps its chain: tile tw + 2 must be complete before anybody requests it in Y(it + 1)
@@ -1143,44 +1157,81 @@ extern "C" int tg_attention_bwd_ex(const void* q, long q_ld, long q_sb, const vo
                                     float* dq, long dq_ld, long dq_sb, float* dk, long dk_ld, long dk_sb, float* dv, long dv_ld, long dv_sb,
                                     int nq, int nk, int heads, int batch, float scale, int accumulate, const float* lse, float* ws, int flags, int* status,
                                     hipStream_t stream) {
-    accumulate = accumulate == 1 ? 3 : (accumulate & 3);      // bit 0: dq, bit 1: dk and dv; 1 = all three (the original meaning of the flag)
-    TG_REQUIRE(q && k && v && o && dout && dq && dk && dv && ws, TG_ERR_ARG, "tg_attention_bwd: null pointer");
-    TG_REQUIRE(nq > 0 && nk > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_attention_bwd: bad shape nq=%d nk=%d heads=%d batch=%d", nq, nk, heads, batch);
-    TG_REQUIRE(tg_aligned16(q) && tg_aligned16(k) && tg_aligned16(v) && tg_aligned16(o) && tg_aligned16(dout) && tg_aligned16(ws) && q_ld % 8 == 0 &&
-               k_ld % 8 == 0 && v_ld % 8 == 0 && o_ld % 8 == 0 && do_ld % 8 == 0 && q_sb % 8 == 0 && k_sb % 8 == 0 && v_sb % 8 == 0 && o_sb % 8 == 0 &&
-               do_sb % 8 == 0, TG_ERR_ALIGN, "tg_attention_bwd: q/k/v/o/dO need 16-byte aligned rows");
+    const tg_attn_bwd_problem pr{q, q_ld, q_sb, k, k_ld, k_sb, v, v_ld, v_sb, o, o_ld, o_sb, dout, do_ld, do_sb, dq, dq_ld, dq_sb, dk, dk_ld, dk_sb, dv, dv_ld, dv_sb,
+                                 nq, nk, scale, accumulate, lse, ws};
+    return tg_attention_bwd_multi(&pr, 1, heads, batch, flags, status, stream);
+}
+
+namespace {
+struct Prepared {
+    Bwd2Params pp;
+    dim3 gq, gk;
+    bool one_kernel;
+    int* cnt;
+    long ncnt;
+};
+// validation + parameter block of one problem; decides the form (one kernel / two launches) exactly as documented for tg_attention_bwd_ex
+int bwd_prepare(const tg_attn_bwd_problem& a, int heads, int batch, int flags, Prepared& out) {
+    const int accumulate = a.accumulate == 1 ? 3 : (a.accumulate & 3);      // bit 0: dq, bit 1: dk and dv; 1 = all three (the original meaning of the flag)
+    TG_REQUIRE(a.q && a.k && a.v && a.o && a.dout && a.dq && a.dk && a.dv && a.ws, TG_ERR_ARG, "tg_attention_bwd: null pointer");
+    TG_REQUIRE(a.nq > 0 && a.nk > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_attention_bwd: bad shape nq=%d nk=%d heads=%d batch=%d", a.nq, a.nk, heads, batch);
+    TG_REQUIRE(tg_aligned16(a.q) && tg_aligned16(a.k) && tg_aligned16(a.v) && tg_aligned16(a.o) && tg_aligned16(a.dout) && tg_aligned16(a.ws) && a.q_ld % 8 == 0 &&
+               a.k_ld % 8 == 0 && a.v_ld % 8 == 0 && a.o_ld % 8 == 0 && a.do_ld % 8 == 0 && a.q_sb % 8 == 0 && a.k_sb % 8 == 0 && a.v_sb % 8 == 0 && a.o_sb % 8 == 0 &&
+               a.do_sb % 8 == 0, TG_ERR_ALIGN, "tg_attention_bwd: q/k/v/o/dO need 16-byte aligned rows");
+    const int nq = a.nq, nk = a.nk;
     const long nrow = (long)batch * heads * nq;               // workspace: seed rows (16 B each, first: alignment) | log-sum-exp | D
-    Bwd2Params pp{};
-    pp.p = BwdParams{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)dout, q_ld, q_sb, k_ld, k_sb, v_ld, v_sb,
-                     o_ld, o_sb, do_ld, do_sb, dq, dk, dv, dq_ld, dq_sb, dk_ld, dk_sb, dv_ld, dv_sb, ws + 4 * nrow, ws + 5 * nrow, (uint4*)ws, nq, nk, heads, batch,
-                     scale * 1.4426950408889634f, scale, accumulate, lse ? 1 : 0};
-    if (lse) pp.p.lse = const_cast<float*>(lse);
-    if (fabsf(pp.p.scale_log2 - 1.0f) < 4e-7f) pp.p.scale_log2 = 1.0f;      // ln 2 * log2 e: exactly one for the seed rows and the kernels alike
-    const dim3 gq((unsigned)((nq + 255) / 256), (unsigned)(batch * heads)), gk((unsigned)((nk + 255) / 256), (unsigned)(batch * heads));
-    hipLaunchKernelGGL(attn_bwd_stats2_kernel, gq, dim3(256), 0, stream, pp.p);
-    TG_REQUIRE(!(flags & TG_BWD_ONE_KERNEL) || status, TG_ERR_ARG, "tg_attention_bwd_ex: TG_BWD_ONE_KERNEL needs the status words");
+    out.pp.p = BwdParams{(const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (const bf16_t*)a.o, (const bf16_t*)a.dout, a.q_ld, a.q_sb, a.k_ld, a.k_sb, a.v_ld,
+                         a.v_sb, a.o_ld, a.o_sb, a.do_ld, a.do_sb, a.dq, a.dk, a.dv, a.dq_ld, a.dq_sb, a.dk_ld, a.dk_sb, a.dv_ld, a.dv_sb, a.ws + 4 * nrow, a.ws + 5 * nrow,
+                         (uint4*)a.ws, nq, nk, heads, batch, a.scale * 1.4426950408889634f, a.scale, accumulate, a.lse ? 1 : 0, 0};
+    if (a.lse) out.pp.p.lse = const_cast<float*>(a.lse);
+    if (fabsf(out.pp.p.scale_log2 - 1.0f) < 4e-7f) out.pp.p.scale_log2 = 1.0f;      // ln 2 * log2 e: exactly one
+    out.gq = dim3((unsigned)((nq + 255) / 256), (unsigned)(batch * heads));
+    out.gk = dim3((unsigned)((nk + 255) / 256), (unsigned)(batch * heads));
     // the ordered dQ accumulation runs the key blocks of a head as a chain a few tiles apart: worth it only when there are many more query tiles than
     // key blocks (the 17776^2 call: 556 tiles, 70 blocks; the vip queries' call with 15 tiles and 72 blocks would serialise)
-    const bool chain_ok = (long)((nq + BT - 1) / BT) >= 4L * gk.x && dq_ld % 4 == 0 && dq_sb % 4 == 0 && tg_aligned16(dq);
-    if ((flags & TG_BWD_ONE_KERNEL) && chain_ok && ((heads * batch) & 7) == 0) {
-        int* const base = (int*)(ws + ((6 * nrow + 8 + 3) & ~3L));
-        const long ncnt = (long)batch * heads * ((nq + BT - 1) / BT) * 32;       // the exchange counters; the per-head XCD masks sit behind them
-        FusedParams fp{pp.p, base, status, base + ncnt};
-        hipError_t e = hipMemsetAsync(fp.cnt, 0, (size_t)(ncnt + (long)batch * heads) * sizeof(int), stream);
-        if (e != hipSuccess) return tg_set_error(TG_ERR_HIP - (int)e, "tg_attention_bwd_ex: %s", hipGetErrorString(e));
-        // UNIT: scale * log2(e) = 1 (K handed over prescaled, scale = ln 2: the training step) -> no multiply in front of exp2
-        if (fabsf(pp.p.scale_log2 - 1.0f) < 4e-7f) {
-            TG_DYN_LDS(attn_bwd_fused_pp_kernel<true>, PP_LDS);
-            hipLaunchKernelGGL(attn_bwd_fused_pp_kernel<true>, dim3(gk.x * gk.y), dim3(512), PP_LDS, stream, fp);
-        } else {
-            TG_DYN_LDS(attn_bwd_fused_pp_kernel<false>, PP_LDS);
-            hipLaunchKernelGGL(attn_bwd_fused_pp_kernel<false>, dim3(gk.x * gk.y), dim3(512), PP_LDS, stream, fp);
-        }
-        TG_LAUNCH_CHECK("tg_attention_bwd(one kernel)");
-        return TG_OK;
+    const bool chain_ok = (long)((nq + BT - 1) / BT) >= 4L * out.gk.x && a.dq_ld % 4 == 0 && a.dq_sb % 4 == 0 && tg_aligned16(a.dq);
+    out.one_kernel = (flags & TG_BWD_ONE_KERNEL) && chain_ok && ((heads * batch) & 7) == 0;
+    out.pp.p.unit_seed = 0;                                  // (seed = -lse / scale_log2; with scale_log2 == 1 that is -lse itself)
+    out.cnt = (int*)(a.ws + ((6 * nrow + 8 + 3) & ~3L));
+    out.ncnt = (long)batch * heads * ((nq + BT - 1) / BT) * 32;       // the exchange counters; the per-head XCD masks sit behind them
+    return TG_OK;
+}
+}  // namespace
+
+extern "C" int tg_attention_bwd_multi(const tg_attn_bwd_problem* problems, int count, int heads, int batch, int flags, int* status, hipStream_t stream) {
+    TG_REQUIRE(problems && count >= 1 && count <= 2, TG_ERR_ARG, "tg_attention_bwd_multi: one or two problems");
+    TG_REQUIRE(!(flags & TG_BWD_ONE_KERNEL) || status, TG_ERR_ARG, "tg_attention_bwd_ex: TG_BWD_ONE_KERNEL needs the status words");
+    Prepared P[2];
+    for (int i = 0; i < count; ++i) {
+        const int rc = bwd_prepare(problems[i], heads, batch, flags, P[i]);
+        if (rc) return rc;
     }
-    hipLaunchKernelGGL(attn_bwd_dkdv7_kernel, dim3(gk.x * gk.y), dim3(512), 0, stream, pp);
-    hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(gq.x * gq.y), dim3(256), 0, stream, pp);
-    TG_LAUNCH_CHECK("tg_attention_bwd");
+    for (int i = 0; i < count; ++i) hipLaunchKernelGGL(attn_bwd_stats2_kernel, P[i].gq, dim3(256), 0, stream, P[i].pp.p);
+    // one-kernel problems: the first is the main call, a second one rides in the same launch (its workgroups behind the main call's: they fill the last round)
+    int main_i = -1, rider_i = -1;
+    for (int i = 0; i < count; ++i)
+        if (P[i].one_kernel) { if (main_i < 0) main_i = i; else rider_i = i; }
+    if (main_i >= 0) {
+        FusedParams fp{};
+        fp.p = P[main_i].pp.p; fp.cnt = P[main_i].cnt; fp.status = status; fp.xmask = P[main_i].cnt + P[main_i].ncnt;
+        fp.main_wgs = (int)(P[main_i].gk.x * P[main_i].gk.y);
+        unsigned grid = (unsigned)fp.main_wgs;
+        hipError_t e = hipMemsetAsync(fp.cnt, 0, (size_t)(P[main_i].ncnt + (long)batch * heads) * sizeof(int), stream);
+        if (e == hipSuccess && rider_i >= 0) {
+            fp.r = P[rider_i].pp.p; fp.r_cnt = P[rider_i].cnt; fp.r_xmask = P[rider_i].cnt + P[rider_i].ncnt;
+            grid += P[rider_i].gk.x * P[rider_i].gk.y;
+            e = hipMemsetAsync(fp.r_cnt, 0, (size_t)(P[rider_i].ncnt + (long)batch * heads) * sizeof(int), stream);
+        }
+        if (e != hipSuccess) return tg_set_error(TG_ERR_HIP - (int)e, "tg_attention_bwd_ex: %s", hipGetErrorString(e));
+        TG_DYN_LDS(attn_bwd_fused_pp_kernel, PP_LDS);
+        hipLaunchKernelGGL(attn_bwd_fused_pp_kernel, dim3(grid), dim3(512), PP_LDS, stream, fp);
+        TG_LAUNCH_CHECK("tg_attention_bwd(one kernel)");
+    }
+    for (int i = 0; i < count; ++i) {
+        if (P[i].one_kernel) continue;
+        hipLaunchKernelGGL(attn_bwd_dkdv7_kernel, dim3(P[i].gk.x * P[i].gk.y), dim3(512), 0, stream, P[i].pp);
+        hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(P[i].gq.x * P[i].gq.y), dim3(256), 0, stream, P[i].pp);
+        TG_LAUNCH_CHECK("tg_attention_bwd");
+    }
     return TG_OK;
 }

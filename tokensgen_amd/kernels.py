@@ -347,11 +347,8 @@ def attention_bwd_check(device=None):
         raise attention_bwd_error(polls, xcd, f"cuda:{torch.device(device).index}" if device is not None else "this process")
 
 
-def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, accumulate=False, lse=None):
-    """Gradients of o = softmax(scale q k^T) v per head (tg_attention_bwd_ex).  q/o/dout [B,nq,heads*64], k/v [B,nk,heads*64] bf16 views;
-    returns fp32 (dq, dk, dv) shaped like q, k, v (given tensors are written, or added to with accumulate=True).  lse: the forward's
-    log-sum-exp from attention_lse (optional; recomputed when None).  The one-kernel form is offered to the library when the device probe
-    passed (BwdDeviceState); a poll time-out inside it is reported by attention_bwd_check(), never silently."""
+def _bwd_problem(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, accumulate=False, lse=None):
+    """One tg_attn_bwd_problem + the tensors that must outlive the launch call: (struct, (dq, dk, dv), keep)."""
     for n, t in (("q", q), ("k", k), ("v", v), ("o", o), ("dout", dout)):
         _chk(t, n)
     if lse is not None:
@@ -370,11 +367,35 @@ def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, acc
     dk = new(B, nk, HD, dtype=f32, device=q.device) if dk is None else _chk(dk, "dk", f32)
     dv = new(B, nk, HD, dtype=f32, device=q.device) if dv is None else _chk(dv, "dv", f32)
     ws = torch.empty(L.load().tg_attention_bwd_ws_floats(nq, nk, heads, B), dtype=f32, device=q.device)
-    st = BwdDeviceState.get(q.device)
-    L.check(_launch("attention_bwd", L.load().tg_attention_bwd_ex, _p(q), qld, qsb, _p(k), kld, ksb, _p(v), vld, vsb, _p(o), old, osb, _p(dout), gld, gsb,
-                    _p(dq), dq.stride(1), dq.stride(0), _p(dk), dk.stride(1), dk.stride(0), _p(dv), dv.stride(1), dv.stride(0), nq, nk, heads, B,
-                    float(scale), acc, _p(lse), _p(ws), st.flags(), _p(st.status), _stream()), "tg_attention_bwd_ex")
-    return dq, dk, dv
+    pr = L.AttnBwdProblem()
+    (pr.q, pr.q_ld, pr.q_sb, pr.k, pr.k_ld, pr.k_sb, pr.v, pr.v_ld, pr.v_sb, pr.o, pr.o_ld, pr.o_sb, pr.dout, pr.do_ld, pr.do_sb) = (
+        _p(q), qld, qsb, _p(k), kld, ksb, _p(v), vld, vsb, _p(o), old, osb, _p(dout), gld, gsb)
+    (pr.dq, pr.dq_ld, pr.dq_sb, pr.dk, pr.dk_ld, pr.dk_sb, pr.dv, pr.dv_ld, pr.dv_sb) = (
+        _p(dq), dq.stride(1), dq.stride(0), _p(dk), dk.stride(1), dk.stride(0), _p(dv), dv.stride(1), dv.stride(0))
+    pr.nq, pr.nk, pr.scale, pr.accumulate, pr.lse, pr.ws = nq, nk, float(scale), acc, _p(lse), _p(ws)
+    return pr, (dq, dk, dv), (ws, B)
+
+
+def attention_bwd_multi(problems, heads):
+    """One or two attention backward problems in ONE call (tg_attention_bwd_multi): the same as attention_bwd on each in order, except that two problems that both
+    take the one-kernel form share a launch (the second rides in the first's last round of CUs).  problems: dicts of attention_bwd's arguments (without `heads`).
+    Returns the list of (dq, dk, dv)."""
+    assert 1 <= len(problems) <= 2
+    built = [_bwd_problem(heads=heads, **pr) for pr in problems]
+    arr = (L.AttnBwdProblem * len(built))(*[b[0] for b in built])
+    B = built[0][2][1]
+    dev = problems[0]["q"].device
+    st = BwdDeviceState.get(dev)
+    L.check(_launch("attention_bwd", L.load().tg_attention_bwd_multi, arr, len(built), heads, B, st.flags(), _p(st.status), _stream()), "tg_attention_bwd_multi")
+    return [b[1] for b in built]
+
+
+def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, accumulate=False, lse=None):
+    """Gradients of o = softmax(scale q k^T) v per head (tg_attention_bwd_multi with one problem).  q/o/dout [B,nq,heads*64], k/v [B,nk,heads*64] bf16 views;
+    returns fp32 (dq, dk, dv) shaped like q, k, v (given tensors are written, or added to with accumulate=True).  lse: the forward's
+    log-sum-exp from attention_lse (optional; recomputed when None).  The one-kernel form is offered to the library when the device probe
+    passed (BwdDeviceState); a poll time-out inside it is reported by attention_bwd_status() / attention_bwd_check(), never silently."""
+    return attention_bwd_multi([dict(q=q, k=k, v=v, o=o, dout=dout, scale=scale, dq=dq, dk=dk, dv=dv, accumulate=accumulate, lse=lse)], heads)[0]
 
 
 def _attn_problem(q1, k1, vt1, nk1, out, q2=None, k2=None, vt2=None, nk2=0, seg2_scale=0.0, kmax1=None, kmax2=None, seg2_scale_batch=None):

@@ -35,6 +35,7 @@ PROTOTYPES = {
                          _i, _i, _i, _i, _f, _i, _vp, _vp, _vp],
     "tg_attention_bwd_ex": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l,
                             _i, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp],
+    "tg_attention_bwd_multi": [_vp, _i, _i, _i, _i, _vp, _vp],
     "tg_attention_bwd_probe": [_vp, _l, _vp],
     "tg_attention_bwd_probe_verdict": [_vp, _l],
     "tg_attention_fwd_lse": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp, _l, _l, _i, _i, _i, _f, _vp, _vp],
@@ -147,6 +148,14 @@ def debug_set(knob, value):
 def check(code, what):
     if code != 0:
         raise RuntimeError(f"{what} failed ({code}): {load().tg_last_error_string().decode()}")
+
+
+class AttnBwdProblem(C.Structure):
+    """tg_attn_bwd_problem (include/tokensgen_hip.h)"""
+    _fields_ = ([(n, t) for base in ("q", "k", "v", "o") for n, t in ((base, C.c_void_p), (base + "_ld", C.c_long), (base + "_sb", C.c_long))] +
+                [("dout", C.c_void_p), ("do_ld", C.c_long), ("do_sb", C.c_long)] +
+                [(n, t) for base in ("dq", "dk", "dv") for n, t in ((base, C.c_void_p), (base + "_ld", C.c_long), (base + "_sb", C.c_long))] +
+                [("nq", C.c_int), ("nk", C.c_int), ("scale", C.c_float), ("accumulate", C.c_int), ("lse", C.c_void_p), ("ws", C.c_void_p)])
 
 
 class AccumItem(C.Structure):

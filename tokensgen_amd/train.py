@@ -56,7 +56,6 @@ def to2v_attention_backward(q, k, v, qx, kx, vx, qv, kv, vv, o1, o2, o3, d_out, 
     f32 = torch.float32
     B, HD = q.shape[0], q.shape[2]
     g1 = d_out[:, :N1]
-    dq, dk, dv = K.attention_bwd(q, k, v, o1, g1, heads, math.log(2.0) if k1_prescaled else sm_scale, lse=lse[0])
     dq_all = torch.empty(B, N1 + Np, HD, dtype=f32, device=q.device)
     dk_all, dv_all = torch.empty_like(dq_all), torch.empty_like(dq_all)
     kcat = torch.cat([kx, kv], 1) if kcat is None else kcat
@@ -64,7 +63,11 @@ def to2v_attention_backward(q, k, v, qx, kx, vx, qv, kv, vv, o1, o2, o3, d_out, 
     # call 3 first: it writes EVERY row of dk_all / dv_all; call 2 then adds its share into the vip rows (accumulate = 2: dk / dv only)
     K.attention_bwd(qv, kcat, vcat, o3, d_out[:, N1:], heads, sm_scale, dq=dq_all[:, N1:], dk=dk_all, dv=dv_all, lse=lse[2])
     g2 = g1 if float(vip_scale) == 1.0 else g1 * float(vip_scale)      # `scale * O2` is a bf16 tensor in the forward (bf16 x scalar: fp32 product, one rounding)
-    K.attention_bwd(qx, kv, vv, o2, g2, heads, sm_scale, dq=dq_all[:, :N1], dk=dk_all[:, N1:], dv=dv_all[:, N1:], accumulate=2, lse=lse[1])
+    # calls 1 and 2 in ONE call: both walk the N1 queries, so when both take the one-kernel form the vip-key call's 2 key blocks per head ride in the last,
+    # partial round of the main call's launch (tg_attention_bwd_multi) instead of costing a launch of their own
+    (dq, dk, dv), _ = K.attention_bwd_multi([
+        dict(q=q, k=k, v=v, o=o1, dout=g1, scale=math.log(2.0) if k1_prescaled else sm_scale, lse=lse[0]),
+        dict(q=qx, k=kv, v=vv, o=o2, dout=g2, scale=sm_scale, dq=dq_all[:, :N1], dk=dk_all[:, N1:], dv=dv_all[:, N1:], accumulate=2, lse=lse[1])], heads)
     return dict(q=dq, k=dk, v=dv, qx=dq_all[:, :N1], kx=dk_all[:, :N1], vx=dv_all[:, :N1], qv=dq_all[:, N1:], kv=dk_all[:, N1:], vv=dv_all[:, N1:],
                 q_all=dq_all, k_all=dk_all, v_all=dv_all)
 
