@@ -288,11 +288,15 @@ def vae_record(device, reps=3):
     for name, fn in (("decode", lambda: vae.decode(z).sample), ("encode", lambda: vae.encode(x).latent_dist.parameters)):
         y = fn(); torch.cuda.synchronize()
         best = float("inf")
-        for _ in range(reps):
-            t0 = time.perf_counter(); y = fn(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        ps = PowerSampler(device.index or 0, period_s=0.02)        # the convolutions are MFMA kernels under the same socket power cap as the DiT: on the record
+        with ps:
+            for _ in range(reps):
+                t0 = time.perf_counter(); y = fn(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        pw = ps.summary()
         out[name] = {"seconds": best, "algorithmic_TFLOPs": VAE_FLOP[name] / best / 1e12, "executed_TFLOPs": 1.4 * VAE_FLOP[name] / best / 1e12,
                      "frac_of_peak_algorithmic": VAE_FLOP[name] / best / PEAK_BF16, "frac_of_peak_executed": 1.4 * VAE_FLOP[name] / best / PEAK_BF16,
-                     "out_shape": list(y.shape), "finite": bool(torch.isfinite(y).all())}
+                     "out_shape": list(y.shape), "finite": bool(torch.isfinite(y).all()), "power_W_mean": pw["power_W_mean"], "sclk_MHz_mean": pw["sclk_MHz_mean"],
+                     "frac_of_peak_executed_at_measured_clock": (1.4 * VAE_FLOP[name] / best / (PEAK_BF16 * pw["sclk_MHz_mean"] / 2400.0)) if pw["sclk_MHz_mean"] else None}
     del vae
     torch.cuda.empty_cache()
     return out
