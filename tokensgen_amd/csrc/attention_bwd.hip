@@ -115,6 +115,11 @@ constexpr int ROWT_EL = BT * LQ2;
 
 struct Bwd2Params {
     BwdParams p;
+    // dQ launch only: key-axis split.  With few queries (the vip-query call: 480 rows = 2 query blocks per head, 192 workgroups for 512 resident slots, each walking 571 key
+    // tiles alone) the key tiles are cut into kparts ranges, one workgroup each; the partial dQ blocks go to dq_part [kparts][batch][nq][heads * 64] (scaled, fp32) and
+    // attn_bwd_dq_join_kernel adds them in range order — deterministic like everything else here.
+    int kparts;
+    float* dq_part;
 };
 
 union Frag { bf16x8 v; uint2 u[2]; uint32_t w[4]; };
@@ -489,7 +494,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hi = lane >> 5;
     int blk, hb;
-    xcd_block((int)blockIdx.x, (p.nq + 255) / 256, p.heads * p.batch, blk, hb);
+    const int nqb = (p.nq + 255) / 256, per_part = nqb * p.heads * p.batch;
+    const int part = pp.kparts > 1 ? (int)blockIdx.x / per_part : 0;
+    xcd_block((int)blockIdx.x - part * per_part, nqb, p.heads * p.batch, blk, hb);
     const int h = hb % p.heads, b = hb / p.heads;
     const int qw0 = blk * 256 + wave * 64;
     const bf16_t* Q = p.q + (long)b * p.q_sb + h * HD;
@@ -520,13 +527,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
         for (int c = 0; c < 2; ++c) dq[a][c] = zero16();
     const int row = tid >> 3, chunk = (tid & 7) * 8;
     const int trb = (4 * hi + ((lane & 15) >> 2)) * LQ2 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;     // transpose-read base of this lane inside a [32][LQ2] tile: row 4 hi + (a >> 2), 4-element chunk (a & 3) of its 16-lane group's columns (lds_tr_b64)
-    const int ntile = (p.nk + BT - 1) / BT;
+    const int ntile_all = (p.nk + BT - 1) / BT;
+    const int tile0 = pp.kparts > 1 ? (int)((long)part * ntile_all / pp.kparts) : 0;                  // this workgroup's key tiles [tile0, tile0 + ntile)
+    const int ntile = (pp.kparts > 1 ? (int)((long)(part + 1) * ntile_all / pp.kparts) : ntile_all) - tile0;
     uint4 g0, g1;
     bool okr = false;
     // running pointers: tiles are fetched in order, so a tile that lies wholly inside the key range costs three loads and three pointer adds — the
     // clamped 64-bit index arithmetic is kept for the ragged last tile only (this kernel is VALU-bound: 61 % VALU busy against 51 % MFMA busy)
-    const bf16_t* pK = Kp + (long)row * p.k_ld + chunk;
-    const bf16_t* pV = Vp + (long)row * p.v_ld + chunk;
+    const bf16_t* pK = Kp + ((long)tile0 * BT + row) * p.k_ld + chunk;
+    const bf16_t* pV = Vp + ((long)tile0 * BT + row) * p.v_ld + chunk;
     const long stepK = (long)BT * p.k_ld, stepV = (long)BT * p.v_ld;
     auto fetch = [&](int k0) {
         if (k0 + BT <= p.nk) {
@@ -544,12 +553,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
         *(uint4*)(sK[buf] + row * LQ2 + chunk) = mask16(g0, okr);
         *(uint4*)(sV[buf] + row * LQ2 + chunk) = mask16(g1, okr);
     };
-    fetch(0);
+    fetch(tile0 * BT);
     stash(0);
     __syncthreads();
     for (int it = 0; it < ntile; ++it) {
         const int buf = it & 1;
-        if (it + 1 < ntile) fetch((it + 1) * BT);
+        if (it + 1 < ntile) fetch((tile0 + it + 1) * BT);
         bf16x8 aK[4], aV[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -596,16 +605,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(Bwd2Params pp) {
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-            float* DQ = p.dq + (long)b * p.dq_sb + h * HD + db * 32 + j;
+            const long pld = (long)p.heads * HD;                                  // partial tensors: [part][batch][nq][heads * 64]
+            float* DQ = pp.kparts > 1 ? pp.dq_part + ((long)part * p.batch + b) * p.nq * pld + h * HD + db * 32 + j : p.dq + (long)b * p.dq_sb + h * HD + db * 32 + j;
+            const long qld = pp.kparts > 1 ? pld : p.dq_ld;
+            const bool add = pp.kparts > 1 ? false : (p.accumulate & 1) != 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int q = qw0 + qb * 32 + acc_row(r, hi);
                 if (q >= p.nq) continue;
-                float* a = DQ + (long)q * p.dq_ld;
+                float* a = DQ + (long)q * qld;
                 const float vq = dq[qb][db][r] * p.scale;
-                *a = (p.accumulate & 1) ? *a + vq : vq;
+                *a = add ? *a + vq : vq;
             }
         }
+}
+
+// dq[b][q][:] = (accumulate ? dq : 0) + sum over the key ranges, in range order, of the dQ launch's partial tensors (4 floats per thread)
+__global__ __launch_bounds__(256) void attn_bwd_dq_join_kernel(Bwd2Params pp) {
+    const BwdParams& p = pp.p;
+    const long pld = (long)p.heads * HD, per_b = (long)p.nq * pld, i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= (long)p.batch * per_b) return;
+    const int b = (int)(i / per_b);
+    const long rem = i - (long)b * per_b;
+    const int q = (int)(rem / pld), c = (int)(rem - (long)q * pld);
+    float* dst = p.dq + (long)b * p.dq_sb + (long)q * p.dq_ld + c;
+    f32x4 a = (p.accumulate & 1) ? *(const f32x4*)dst : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < pp.kparts; ++k) {
+        const f32x4 v = *(const f32x4*)(pp.dq_part + (long)k * p.batch * per_b + i);
+        a = f32x4{a[0] + v[0], a[1] + v[1], a[2] + v[2], a[3] + v[3]};
+    }
+    *(f32x4*)dst = a;
 }
 
 // =================================================================================================================================
@@ -1111,9 +1140,15 @@ __global__ __launch_bounds__(64) void fused_probe_kernel(int* bad, int* cnt, flo
 }  // namespace
 
 // statistics: 2 floats per query row (log-sum-exp unless the forward kept it, and D) + the 16-byte seed row of the dK/dV kernel
+// key-axis split of the dQ launch: only for calls with so few query blocks that one workgroup per block leaves most of the chip idle
+constexpr int DQ_SPLIT_MAX = 8;
+static inline bool dq_split_shape(int nq, int heads, int batch) { return (long)((nq + 255) / 256) * heads * batch <= 256; }
+static inline long dq_split_floats(int nq, int heads, int batch) { return dq_split_shape(nq, heads, batch) ? (long)DQ_SPLIT_MAX * batch * nq * heads * HD + 4 : 0; }
+
 extern "C" long tg_attention_bwd_ws_floats(int nq, int nk, int heads, int batch) {
     (void)nk;
-    return 6L * batch * heads * nq + 8 + (long)batch * heads * ((nq + BT - 1) / BT) * 32 + 8 + (long)batch * heads;   // + the one-kernel form's dQ counters and per-head XCD masks
+    return 6L * batch * heads * nq + 8 + (long)batch * heads * ((nq + BT - 1) / BT) * 32 + 8 + (long)batch * heads     // + the one-kernel form's dQ counters and per-head XCD masks
+           + dq_split_floats(nq, heads, batch);                                                                           // + the dQ launch's key-range partials (few queries only)
 }
 
 // The device probe of the one-kernel form (fused_probe_kernel) as explicit entry points on CALLER-owned memory: nothing is allocated, freed or
@@ -1184,6 +1219,8 @@ int bwd_prepare(const tg_attn_bwd_problem& a, int heads, int batch, int flags, P
                          a.v_sb, a.o_ld, a.o_sb, a.do_ld, a.do_sb, a.dq, a.dk, a.dv, a.dq_ld, a.dq_sb, a.dk_ld, a.dk_sb, a.dv_ld, a.dv_sb, a.ws + 4 * nrow, a.ws + 5 * nrow,
                          (uint4*)a.ws, nq, nk, heads, batch, a.scale * 1.4426950408889634f, a.scale, accumulate, a.lse ? 1 : 0, 0};
     if (a.lse) out.pp.p.lse = const_cast<float*>(a.lse);
+    out.pp.kparts = 1;
+    out.pp.dq_part = nullptr;
     if (fabsf(out.pp.p.scale_log2 - 1.0f) < 4e-7f) out.pp.p.scale_log2 = 1.0f;      // ln 2 * log2 e: exactly one
     out.gq = dim3((unsigned)((nq + 255) / 256), (unsigned)(batch * heads));
     out.gk = dim3((unsigned)((nk + 255) / 256), (unsigned)(batch * heads));
@@ -1230,7 +1267,23 @@ extern "C" int tg_attention_bwd_multi(const tg_attn_bwd_problem* problems, int c
     for (int i = 0; i < count; ++i) {
         if (P[i].one_kernel) continue;
         hipLaunchKernelGGL(attn_bwd_dkdv7_kernel, dim3(P[i].gk.x * P[i].gk.y), dim3(512), 0, stream, P[i].pp);
-        hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(P[i].gq.x * P[i].gq.y), dim3(256), 0, stream, P[i].pp);
+        // dQ: one workgroup per 256 queries and head — or, with few queries, per (256 queries, head, key range): ~3 rounds of the chip's resident slots (2 per CU)
+        const BwdParams& bp = P[i].pp.p;
+        const long wgs = (long)P[i].gq.x * P[i].gq.y, ntile = (bp.nk + BT - 1) / BT;
+        int kparts = 1;
+        if (dq_split_shape(bp.nq, heads, batch) && bp.dq_ld % 4 == 0 && bp.dq_sb % 4 == 0 && tg_aligned16(bp.dq)) {
+            kparts = (int)((6L * tg_device_cus()) / wgs);
+            if (kparts > DQ_SPLIT_MAX) kparts = DQ_SPLIT_MAX;
+            if (kparts > ntile / 16) kparts = (int)(ntile / 16);               // at least 16 key tiles per range
+            if (kparts < 2) kparts = 1;
+        }
+        P[i].pp.kparts = kparts;
+        P[i].pp.dq_part = (float*)(((uintptr_t)(P[i].cnt + P[i].ncnt + (long)batch * heads) + 15) & ~(uintptr_t)15);
+        hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3((unsigned)(wgs * kparts)), dim3(256), 0, stream, P[i].pp);
+        if (kparts > 1) {
+            const long n4 = (long)batch * bp.nq * heads * HD / 4;
+            hipLaunchKernelGGL(attn_bwd_dq_join_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, P[i].pp);
+        }
         TG_LAUNCH_CHECK("tg_attention_bwd");
     }
     return TG_OK;
