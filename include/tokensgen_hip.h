@@ -21,7 +21,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* The library is built with -fvisibility=hidden: exactly the functions declared in this header are exported (tests/test_abi_cpu.py holds `nm -D` to it). */
+/* The library is built with -fvisibility=hidden: exactly the functions declared in this header are exported (tests/test_host_cpu.py holds `nm -D` to it). */
 #if defined(__GNUC__)
 #pragma GCC visibility push(default)
 #endif
@@ -125,6 +125,14 @@ int tg_qk_layernorm_rope_pair_kmax(void* xq, void* xk, long ld, long strideB, in
                                    int start0, int len0, const float* cos0, const float* sin0,
                                    int start1, int len1, const float* cos1, const float* sin1, float q_scale, float k_scale,
                                    float* k_norm2_max, float* ws, hipStream_t stream);
+
+/* tg_qk_layernorm_rope_pair[_kmax] OUT OF PLACE: reads the q | k slices (xq, xk; rows ld, batch stride strideB) and writes the normalised, rotated, scaled rows to
+ * yq, yk (rows y_ld, batch stride y_strideB) — the source stays as the projection left it.  The training forward keeps the pre-norm projection for the backward and the
+ * post-norm rows for the attention calls: in place that was a copy pass + the norm pass.  k_norm2_max / ws: both NULL, or as for tg_qk_layernorm_rope_pair_kmax. */
+int tg_qk_layernorm_rope_pair_out(const void* xq, const void* xk, long ld, long strideB, void* yq, void* yk, long y_ld, long y_strideB, int tokens, int heads,
+                                  int batch, const void* q_weight, const void* q_bias, const void* k_weight, const void* k_bias, float eps,
+                                  int start0, int len0, const float* cos0, const float* sin0, int start1, int len1, const float* cos1, const float* sin1,
+                                  float q_scale, float k_scale, float* k_norm2_max, float* ws, hipStream_t stream);
 
 /* vt[b][h][d][j] = v[b*strideB + (key_start + j)*ld + h*64 + d] for j < n_keys, zero for n_keys <= j < ldvt.
  * Lays V out key-contiguous so the PV MFMA operands are plain 16-byte LDS reads (the "transpose" that

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void adaln_kernel(const bf16_t* __restrict__ x
 // ------------------------------------------------------------------------------------------------
 // one (token, head) slice of 8 elements per lane: LayerNorm over the 8-lane group, affine, bf16 rounding, RoPE, scale, store
 // returns the sum of squares of the 8 values as STORED (bf16-rounded, scaled): an 8-lane partial of the row's squared norm
-__device__ __forceinline__ float qk_norm_rope_slice(bf16_t* p, const bf16_t* __restrict__ w, const bf16_t* __restrict__ bvec, int part,
+__device__ __forceinline__ float qk_norm_rope_slice(const bf16_t* p, bf16_t* dstp, const bf16_t* __restrict__ w, const bf16_t* __restrict__ bvec, int part,
                                                     float eps, bool rope, const float (&c)[8], const float (&sv)[8], float out_scale, bool live) {
     const uint4 raw = *(const uint4*)p;
     const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -132,7 +132,7 @@ __device__ __forceinline__ float qk_norm_rope_slice(bf16_t* p, const bf16_t* __r
     uint4 o;
     o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
     o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-    if (live) *(uint4*)p = o;
+    if (live) *(uint4*)dstp = o;
     const uint32_t ou[4] = {o.x, o.y, o.z, o.w};
     float ss = 0.f;
 #pragma unroll
@@ -151,7 +151,7 @@ __device__ __forceinline__ float qk_norm_rope_slice(bf16_t* p, const bf16_t* __r
 // float bits — non-negative floats order like unsigned integers) and writes one row of `partial[batch][row block][heads]`;
 // qk_kmax_finalize_kernel takes the column maxima.
 template <int HPG, bool STATS = false>   // heads per 8-lane group: the token's table slice stays in registers while the group walks HPG heads
-__global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ x, bf16_t* __restrict__ x2, long ld, long sb, int tokens,
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* x, bf16_t* x2, bf16_t* y, bf16_t* y2, long yld, long ysb, long ld, long sb, int tokens,
                                                            int heads, int batch, const bf16_t* __restrict__ w,
                                                            const bf16_t* __restrict__ bvec, const bf16_t* __restrict__ w2,
                                                            const bf16_t* __restrict__ bvec2, float eps,
@@ -195,9 +195,10 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
 #pragma unroll
     for (int hh = 0; hh < HPG; ++hh) {
         const long off = (long)b * sb + (long)t * ld + (h0 + hh) * 64 + part * 8;
-        qk_norm_rope_slice(x + off, w, bvec, part, eps, cs != nullptr, c, sv, out_scale, live);
+        const long offy = (long)b * ysb + (long)t * yld + (h0 + hh) * 64 + part * 8;       // (y == x, yld == ld, ysb == sb: in place)
+        qk_norm_rope_slice(x + off, y + offy, w, bvec, part, eps, cs != nullptr, c, sv, out_scale, live);
         if (x2) {
-            float ss = qk_norm_rope_slice(x2 + off, w2, bvec2, part, eps, cs != nullptr, c, sv, out_scale2, live);
+            float ss = qk_norm_rope_slice(x2 + off, y2 + offy, w2, bvec2, part, eps, cs != nullptr, c, sv, out_scale2, live);
             if (STATS) {
                 ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
                 if (part == 0 && live) atomicMax(&smax[h0 + hh], __float_as_uint(ss));
@@ -292,7 +293,9 @@ extern "C" int tg_adaln_modulate(const void* x, long ldx, long strideX, void* y,
 static int qk_norm_rope_launch(void* xq, void* xk, long ld, long strideB, int tokens, int heads, int batch, const void* wq, const void* bq,
                                const void* wk, const void* bk, float eps, int start0, int len0, const float* cos0, const float* sin0,
                                int start1, int len1, const float* cos1, const float* sin1, float q_scale, float k_scale, hipStream_t stream,
-                               float* k_norm2_max = nullptr, float* ws = nullptr) {
+                               float* k_norm2_max = nullptr, float* ws = nullptr, void* yq = nullptr, void* yk = nullptr, long yld = 0, long ysb = 0) {
+    if (!yq) { yq = xq; yk = xk; yld = ld; ysb = strideB; }             // in place unless a destination is given
+    TG_REQUIRE(yld % 8 == 0 && ysb % 8 == 0 && tg_aligned16(yq) && (!xk || (yk && tg_aligned16(yk))), TG_ERR_ALIGN, "tg_qk_layernorm_rope: destination rows must be 16-byte aligned");
     TG_REQUIRE(xq && wq && bq && (!xk || (wk && bk)), TG_ERR_ARG, "tg_qk_layernorm_rope: null pointer");
     TG_REQUIRE(tokens > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_qk_layernorm_rope: bad shape");
     TG_REQUIRE(ld % 8 == 0 && strideB % 8 == 0 && tg_aligned16(xq) && (!xk || tg_aligned16(xk)), TG_ERR_ALIGN,
@@ -309,7 +312,7 @@ static int qk_norm_rope_launch(void* xq, void* xk, long ld, long strideB, int to
         const long rows = (long)tokens * (heads / hpg);            // per batch item
         const unsigned nblk = (unsigned)((rows * 8 + 255) / 256);
 #define TG_QK_LAUNCH_S(H_)                                                                                                                \
-    hipLaunchKernelGGL((qk_norm_rope_kernel<H_, true>), dim3(nblk, (unsigned)batch), dim3(256), 0, stream, (bf16_t*)xq, (bf16_t*)xk, ld,    \
+    hipLaunchKernelGGL((qk_norm_rope_kernel<H_, true>), dim3(nblk, (unsigned)batch), dim3(256), 0, stream, (bf16_t*)xq, (bf16_t*)xk, (bf16_t*)yq, (bf16_t*)yk, yld, ysb, ld,    \
                        strideB, tokens, heads, batch, (const bf16_t*)wq, (const bf16_t*)bq, (const bf16_t*)wk, (const bf16_t*)bk, eps,     \
                        start0, len0, cos0, sin0, start1, len1, cos1, sin1, q_scale, k_scale, ws)
         if (hpg == 4) TG_QK_LAUNCH_S(4); else if (hpg == 2) TG_QK_LAUNCH_S(2); else TG_QK_LAUNCH_S(1);
@@ -322,7 +325,7 @@ static int qk_norm_rope_launch(void* xq, void* xk, long ld, long strideB, int to
     }
     const long threads = (long)batch * tokens * (heads / hpg) * 8;
 #define TG_QK_LAUNCH(H_)                                                                                                                 \
-    hipLaunchKernelGGL(qk_norm_rope_kernel<H_>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (bf16_t*)xq, (bf16_t*)xk, ld, \
+    hipLaunchKernelGGL(qk_norm_rope_kernel<H_>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (bf16_t*)xq, (bf16_t*)xk, (bf16_t*)yq, (bf16_t*)yk, yld, ysb, ld, \
                        strideB, tokens, heads, batch, (const bf16_t*)wq, (const bf16_t*)bq, (const bf16_t*)wk, (const bf16_t*)bk, eps,     \
                        start0, len0, cos0, sin0, start1, len1, cos1, sin1, q_scale, k_scale, (float*)nullptr)
     if (hpg == 4) TG_QK_LAUNCH(4); else if (hpg == 2) TG_QK_LAUNCH(2); else TG_QK_LAUNCH(1);
@@ -364,6 +367,16 @@ extern "C" int tg_qk_layernorm_rope_pair_kmax(void* xq, void* xk, long ld, long 
     TG_REQUIRE(xk && k_norm2_max && ws, TG_ERR_ARG, "tg_qk_layernorm_rope_pair_kmax: null pointer");
     return qk_norm_rope_launch(xq, xk, ld, strideB, tokens, heads, batch, q_weight, q_bias, k_weight, k_bias, eps, start0, len0, cos0, sin0,
                                start1, len1, cos1, sin1, q_scale, k_scale, stream, k_norm2_max, ws);
+}
+
+extern "C" int tg_qk_layernorm_rope_pair_out(const void* xq, const void* xk, long ld, long strideB, void* yq, void* yk, long y_ld, long y_strideB, int tokens, int heads,
+                                             int batch, const void* q_weight, const void* q_bias, const void* k_weight, const void* k_bias, float eps,
+                                             int start0, int len0, const float* cos0, const float* sin0, int start1, int len1, const float* cos1, const float* sin1,
+                                             float q_scale, float k_scale, float* k_norm2_max, float* ws, hipStream_t stream) {
+    TG_REQUIRE(xq && xk && yq && yk, TG_ERR_ARG, "tg_qk_layernorm_rope_pair_out: null pointer");
+    TG_REQUIRE(!k_norm2_max == !ws, TG_ERR_ARG, "tg_qk_layernorm_rope_pair_out: k_norm2_max and ws go together");
+    return qk_norm_rope_launch(const_cast<void*>(xq), const_cast<void*>(xk), ld, strideB, tokens, heads, batch, q_weight, q_bias, k_weight, k_bias, eps, start0, len0, cos0,
+                               sin0, start1, len1, cos1, sin1, q_scale, k_scale, stream, k_norm2_max, ws, yq, yk, y_ld, y_strideB);
 }
 
 extern "C" int tg_transpose_v(const void* v, long ld, long strideB, int key_start, int n_keys, int heads, int batch,

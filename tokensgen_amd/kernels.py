@@ -200,13 +200,18 @@ def kmax_workspace(tokens, heads, batch, device):
 
 
 def qk_layernorm_rope_pair(xq, xk, heads, q_weight, q_bias, k_weight, k_bias, eps, seg0=None, seg1=None, q_scale=1.0, k_scale=1.0,
-                           kmax=None, kmax_ws=None):
+                           kmax=None, kmax_ws=None, out=None):
     """qk_layernorm_rope on the q and the k column slices of the same fused buffer in one launch (rotary tables read once).
     kmax (fp32 [B, heads], with kmax_ws from kmax_workspace): also receives max_t ||k_t||^2 of the stored K rows — the key-side range
-    bound of the constant-shift attention (tg_qk_layernorm_rope_pair_kmax)."""
+    bound of the constant-shift attention (tg_qk_layernorm_rope_pair_kmax).  out = (yq, yk): OUT OF PLACE (tg_qk_layernorm_rope_pair_out) — xq / xk stay as they are."""
     _chk(xq, "xq"); _chk(xk, "xk")
     B, T, HD, ld, sb = _bmk(xq)
     assert HD == heads * 64 and _bmk(xk) == (B, T, HD, ld, sb)
+    if out is not None:
+        yq, yk = out
+        _chk(yq, "yq"); _chk(yk, "yk")
+        _, _, _, yld, ysb = _bmk(yq)
+        assert _bmk(yk) == (B, T, HD, yld, ysb)
 
     def unpack(seg):
         if seg is None:
@@ -220,6 +225,12 @@ def qk_layernorm_rope_pair(xq, xk, heads, q_weight, q_bias, k_weight, k_bias, ep
     if kmax is not None:
         _chk(kmax, "kmax", torch.float32); _chk(kmax_ws, "kmax_ws", torch.float32)
         assert kmax.is_contiguous() and kmax.shape == (B, heads) and kmax_ws.numel() >= L.load().tg_qk_kmax_ws_floats(T, heads, B)
+    if out is not None:
+        L.check(_launch("qk_layernorm_rope_pair", L.load().tg_qk_layernorm_rope_pair_out, _p(xq), _p(xk), ld, sb, _p(yq), _p(yk), yld, ysb, T, heads, B, _p(q_weight),
+                        _p(q_bias), _p(k_weight), _p(k_bias), float(eps), s0, l0, _p(c0), _p(n0), s1, l1, _p(c1), _p(n1), float(q_scale), float(k_scale),
+                        _p(kmax), _p(kmax_ws) if kmax is not None else None, _stream()), "tg_qk_layernorm_rope_pair_out")
+        return yq, yk
+    if kmax is not None:
         L.check(_launch("qk_layernorm_rope_pair", L.load().tg_qk_layernorm_rope_pair_kmax, _p(xq), _p(xk), ld, sb, T, heads, B, _p(q_weight), _p(q_bias),
                         _p(k_weight), _p(k_bias), float(eps), s0, l0, _p(c0), _p(n0), s1, l1, _p(c1), _p(n1), float(q_scale), float(k_scale),
                         _p(kmax), _p(kmax_ws), _stream()), "tg_qk_layernorm_rope_pair_kmax")

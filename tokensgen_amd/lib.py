@@ -27,6 +27,7 @@ PROTOTYPES = {
     "tg_qk_layernorm_rope": [_vp, _l, _l, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _vp],
     "tg_qk_layernorm_rope_pair": [_vp, _vp, _l, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _f, _vp],
     "tg_qk_layernorm_rope_pair_kmax": [_vp, _vp, _l, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp],
+    "tg_qk_layernorm_rope_pair_out": [_vp, _vp, _l, _l, _vp, _vp, _l, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp],
     "tg_transpose_v": [_vp, _l, _l, _i, _i, _i, _i, _vp, _l, _vp],
     "tg_attention_fwd": [_vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _f, _vp, _l, _l,
                          _i, _i, _i, _f, _i, _vp],

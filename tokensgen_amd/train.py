@@ -394,10 +394,9 @@ class To2VBlockTrainer:
         else:
             K.gemm(Xn[:, :N1], self.Wqkv, self.bqkv, qkv_pre, L.EPI_BIAS)
             K.gemm(Xn, self.Wv, self.bv, qkvv_pre, L.EPI_BIAS)
-        # the norm + RoPE kernel works in place and the backward needs the pre-norm Q / K: copy those two thirds; V is read where the projection left it
+        # the backward needs the pre-norm Q / K (left in qkv_pre / qkvv_pre) AND the attention calls the post-norm rows: the norm + RoPE kernel writes the latter out of
+        # place (a copy pass + the in-place pass before: two tensor passes less per projection); V is read where the projection left it
         qkv, qkvv = e(B, N1, 2 * D), e(B, N, 2 * D)
-        qkv.copy_(qkv_pre[:, :, :2 * D])
-        qkvv.copy_(qkvv_pre[:, :, :2 * D])
         A = f"{pre}.attn1."
         tab = lambda r: tuple(t.to(dev, torch.float32).contiguous() for t in r)
         rope, vrope, crope = tab(rope), tab(vrope), tab(crope)
@@ -405,10 +404,11 @@ class To2VBlockTrainer:
         # key-norm bound comes out of the same launch, and the backward sees the scaled rows (to2v_attention_backward k1_prescaled)
         sm = 1.0 / 8.0
         retry, km1, kws = _fast_attention_ws(N1, H, B, dev)
-        K.qk_layernorm_rope_pair(qkv[:, :, :D], qkv[:, :, D:2 * D], H, sd[A + "norm_q.weight"], sd[A + "norm_q.bias"], sd[A + "norm_k.weight"],
-                                 sd[A + "norm_k.bias"], 1e-6, (Nt, rope), k_scale=sm * LOG2E, kmax=km1, kmax_ws=kws)
-        K.qk_layernorm_rope_pair(qkvv[:, :, :D], qkvv[:, :, D:2 * D], H, sd[A + "processor.vip_norm_q.weight"], sd[A + "processor.vip_norm_q.bias"],
-                                 sd[A + "processor.vip_norm_k.weight"], sd[A + "processor.vip_norm_k.bias"], 1e-6, (Nt, vrope), (N1, crope))
+        K.qk_layernorm_rope_pair(qkv_pre[:, :, :D], qkv_pre[:, :, D:2 * D], H, sd[A + "norm_q.weight"], sd[A + "norm_q.bias"], sd[A + "norm_k.weight"],
+                                 sd[A + "norm_k.bias"], 1e-6, (Nt, rope), k_scale=sm * LOG2E, kmax=km1, kmax_ws=kws, out=(qkv[:, :, :D], qkv[:, :, D:2 * D]))
+        K.qk_layernorm_rope_pair(qkvv_pre[:, :, :D], qkvv_pre[:, :, D:2 * D], H, sd[A + "processor.vip_norm_q.weight"], sd[A + "processor.vip_norm_q.bias"],
+                                 sd[A + "processor.vip_norm_k.weight"], sd[A + "processor.vip_norm_k.bias"], 1e-6, (Nt, vrope), (N1, crope),
+                                 out=(qkvv[:, :, :D], qkvv[:, :, D:2 * D]))
         pad = lambda n: (n + 63) // 64 * 64
         vt = lambda v, n0, n: K.transpose_v(v, H, n0, n, _vt_scratch(B, H, pad(n), (n0, n), dev))      # (tag = the call's key range: three distinct buffers)
         q, k, v = qkv[:, :, :D], qkv[:, :, D:2 * D], qkv_pre[:, :, 2 * D:]
