@@ -531,7 +531,7 @@ def train_measure(a, rank, world, device, dist):
         try:
             with open(os.path.join(ROOT, "profiles", BWD_PMC_SUMMARY)) as f:
                 pm = json.load(f)
-            traffic = sum(v["l2_miss_traffic_bytes_per_launch"] for k, v in pm.items() if k.startswith(("attn_bwd_dkdv", "attn_bwd_dq", "attn_bwd_fused")))
+            traffic = sum(v["l2_miss_traffic_bytes_per_launch"] for k, v in pm.items() if any(t in k for t in ("attn_bwd_dkdv", "attn_bwd_dq", "attn_bwd_fused"))) or None
         except (OSError, KeyError, ValueError):
             pass
         return ({
