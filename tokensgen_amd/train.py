@@ -571,6 +571,12 @@ class To2VTrainer:
         os.makedirs(vip_ckpt_dir, exist_ok=True)
         torch.save({n: self.sd[n].detach().to("cpu").to(torch.float32) for n in self.trainable}, os.path.join(vip_ckpt_dir, "vip.pt"))
 
+    def reset_frozen_cache(self):
+        """Forget the kept transposes of the FROZEN weights (To2VBlockTrainer._wt): call after frozen tensors of the state dict were overwritten IN PLACE (a trainer built
+        on other tensors, or `use_arena`, starts empty anyway)."""
+        for blk in self._blocks or []:
+            blk._wt.clear()
+
     def use_arena(self, arena):
         """Move the trainable parameters into a ParamArena (optim.py): the state-dict entries become views of its flat bf16 buffer, so an
         optimizer step on the arena is what the next forward reads."""
