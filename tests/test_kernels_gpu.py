@@ -415,6 +415,21 @@ def test_qk_layernorm_rope_pair_equals_two_single_launches(K):
     K.qk_layernorm_rope(a[:, :, H * 64:2 * H * 64], H, wk, bk, 1e-6, (8, c0), (34, c1), out_scale=0.18033688)
     K.qk_layernorm_rope_pair(b[:, :, :H * 64], b[:, :, H * 64:2 * H * 64], H, wq, bq, wk, bk, 1e-6, (8, c0), (34, c1), k_scale=0.18033688)
     assert torch.equal(a, b) and not torch.equal(a[:, :, :2 * H * 64], buf[:, :, :2 * H * 64])
+    # OUT OF PLACE (tg_qk_layernorm_rope_pair_out, the training forward: the pre-norm projection stays for the backward): the same rows into a buffer of another row stride,
+    # the source untouched — without and with the key-norm bound of the constant-shift attention (same numbers as the in-place launch's)
+    src = buf.clone()
+    dst = torch.full((B, T, 2 * H * 64 + 64), 7.0, dtype=torch.bfloat16, device=DEV)
+    K.qk_layernorm_rope_pair(src[:, :, :H * 64], src[:, :, H * 64:2 * H * 64], H, wq, bq, wk, bk, 1e-6, (8, c0), (34, c1), k_scale=0.18033688,
+                             out=(dst[:, :, :H * 64], dst[:, :, H * 64:2 * H * 64]))
+    assert torch.equal(src, buf) and torch.equal(dst[:, :, :2 * H * 64], a[:, :, :2 * H * 64]) and (dst[:, :, 2 * H * 64:] == 7.0).all()
+    km_in, km_out = (torch.zeros(B, H, dtype=torch.float32, device=DEV) for _ in range(2))
+    kws = K.kmax_workspace(T, H, B, DEV)
+    c = buf.clone()
+    K.qk_layernorm_rope_pair(c[:, :, :H * 64], c[:, :, H * 64:2 * H * 64], H, wq, bq, wk, bk, 1e-6, (8, c0), (34, c1), k_scale=0.18033688, kmax=km_in, kmax_ws=kws)
+    dst.fill_(7.0)
+    K.qk_layernorm_rope_pair(src[:, :, :H * 64], src[:, :, H * 64:2 * H * 64], H, wq, bq, wk, bk, 1e-6, (8, c0), (34, c1), k_scale=0.18033688, kmax=km_out, kmax_ws=kws,
+                             out=(dst[:, :, :H * 64], dst[:, :, H * 64:2 * H * 64]))
+    assert torch.equal(src, buf) and torch.equal(dst[:, :, :2 * H * 64], c[:, :, :2 * H * 64]) and torch.equal(km_in, km_out) and float(km_out.min()) > 0
 
 
 def test_rope_tables_on_device_match_host():
