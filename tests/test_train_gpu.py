@@ -497,6 +497,26 @@ def test_vip_processor_trainable_parameter_gradients_vs_autograd_of_the_oracle(p
            "worst trainable processor tensor, HIP vs fp32 autograd (r2 measured 2.3e-2; compare the floor above)")
 
 
+@pytest.mark.parametrize("D", [3072, 4096, 4608])
+def test_adaln_backward_row_forms_vs_autograd(D):
+    """tg_adaln_modulate_bwd at the widths that pick its three forms (row kept in registers as 6 or 8 chunks per lane; rows re-read beyond 4096): plain affine LayerNorm
+    backward against autograd of the fp32 formula, with and without the product tensors / the residual add."""
+    import torch.nn.functional as F
+    from tokensgen_amd import train
+    B, T = 2, 37
+    x, dy, res = _rand(B, T, D, seed=171), _rand(B, T, D, seed=172), _rand(B, T, D, seed=173)
+    w, bvec = (1 + 0.2 * _rand(D, seed=174).float()).to(BF), _rand(D, seed=175, scale=0.2)
+    xf, wf, bf_ = x.float().requires_grad_(True), w.float().requires_grad_(True), bvec.float().requires_grad_(True)
+    (F.layer_norm(xf, (D,), wf, bf_, 1e-5) * dy.float()).sum().backward()
+    dx = torch.empty(B, T, D, dtype=BF, device=DEV)
+    t_dln, t_dlnx, _ = train._adaln_bwd(x.to(DEV), dy.to(DEV), dx, w.to(DEV), bvec.to(DEV), 1e-5, None)
+    assert _rel(dx, xf.grad) < 4e-3
+    assert _rel(train._colsum_f32(t_dln), bf_.grad) < 1e-5 and _rel(train._colsum_f32(t_dlnx), wf.grad) < 1e-5
+    dx2 = torch.empty(B, T, D, dtype=BF, device=DEV)
+    train._adaln_bwd(x.to(DEV), dy.to(DEV), dx2, w.to(DEV), bvec.to(DEV), 1e-5, None, products=False, add=res.to(DEV))
+    assert torch.equal(dx2, (dx.float() + res.to(DEV).float()).to(BF))
+
+
 def test_adaln_gate_and_activation_backward_kernels_vs_autograd():
     """tg_adaln_modulate_bwd / tg_gate_residual_bwd / tg_act / tg_colsum_f32 one by one against autograd of the fp32 formulas
     (normalization.py:441-488, cogvideox_transformer_3d.py:290-324, FeedForward gelu-approximate)."""

@@ -19,8 +19,6 @@ struct BwdParams {
     float scale_log2, scale;
     int accumulate;
     int have_lse;                          // lse was written by the forward (tg_attention_fwd_lse): the statistics launch only computes D
-    int unit_seed;                         // the seed rows carry -lse itself (not -lse / scale_log2): the one-kernel form scales its resident K fragments by
-                                           // scale_log2 instead of multiplying every score
 };
 
 // accumulator element r of lane (j, hi) sits at row 8*(r/4) + 4*hi + (r%4), column j of the 32 x 32 block

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void attn_bwd_stats2_kernel(BwdParams p) {
             }
             p.dsum[stat0 + r] = d;
             sDs[tid] = d;
-            if (p.have_lse) p.seed[stat0 + r] = seed_row(p.lse[stat0 + r], d, p.unit_seed ? 1.0f : p.scale_log2);
+            if (p.have_lse) p.seed[stat0 + r] = seed_row(p.lse[stat0 + r], d, p.scale_log2);
         }
     }
     if (p.have_lse) return;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void attn_bwd_stats2_kernel(BwdParams p) {
         if (hi == 0 && q < p.nq) {
             const float lse = M + log2f(Lsum);
             p.lse[stat0 + q] = lse;
-            p.seed[stat0 + q] = seed_row(lse, sDs[wave * 64 + qb * 32 + j], p.unit_seed ? 1.0f : p.scale_log2);      // sDs: written before the tile loop's barriers
+            p.seed[stat0 + q] = seed_row(lse, sDs[wave * 64 + qb * 32 + j], p.scale_log2);      // sDs: written before the tile loop's barriers
         }
     }
 }
@@ -1217,7 +1217,7 @@ int bwd_prepare(const tg_attn_bwd_problem& a, int heads, int batch, int flags, P
     const long nrow = (long)batch * heads * nq;               // workspace: seed rows (16 B each, first: alignment) | log-sum-exp | D
     out.pp.p = BwdParams{(const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (const bf16_t*)a.o, (const bf16_t*)a.dout, a.q_ld, a.q_sb, a.k_ld, a.k_sb, a.v_ld,
                          a.v_sb, a.o_ld, a.o_sb, a.do_ld, a.do_sb, a.dq, a.dk, a.dv, a.dq_ld, a.dq_sb, a.dk_ld, a.dk_sb, a.dv_ld, a.dv_sb, a.ws + 4 * nrow, a.ws + 5 * nrow,
-                         (uint4*)a.ws, nq, nk, heads, batch, a.scale * 1.4426950408889634f, a.scale, accumulate, a.lse ? 1 : 0, 0};
+                         (uint4*)a.ws, nq, nk, heads, batch, a.scale * 1.4426950408889634f, a.scale, accumulate, a.lse ? 1 : 0};
     if (a.lse) out.pp.p.lse = const_cast<float*>(a.lse);
     out.pp.kparts = 1;
     out.pp.dq_part = nullptr;
@@ -1228,7 +1228,6 @@ int bwd_prepare(const tg_attn_bwd_problem& a, int heads, int batch, int flags, P
     // key blocks (the 17776^2 call: 556 tiles, 70 blocks; the vip queries' call with 15 tiles and 72 blocks would serialise)
     const bool chain_ok = (long)((nq + BT - 1) / BT) >= 4L * out.gk.x && a.dq_ld % 4 == 0 && a.dq_sb % 4 == 0 && tg_aligned16(a.dq);
     out.one_kernel = (flags & TG_BWD_ONE_KERNEL) && chain_ok && ((heads * batch) & 7) == 0;
-    out.pp.p.unit_seed = 0;                                  // (seed = -lse / scale_log2; with scale_log2 == 1 that is -lse itself)
     out.cnt = (int*)(a.ws + ((6 * nrow + 8 + 3) & ~3L));
     out.ncnt = (long)batch * heads * ((nq + BT - 1) / BT) * 32;       // the exchange counters; the per-head XCD masks sit behind them
     return TG_OK;

@@ -245,6 +245,10 @@ __device__ __forceinline__ void unpack8(uint4 v, float (&f)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { f[2 * i] = bf16lo_to_f32(u[i]); f[2 * i + 1] = bf16hi_to_f32(u[i]); }
 }
+// NC > 0: the row's chunks (dim <= 512 NC) stay in registers as packed bf16 — x, dy and the modulation scale are read from memory ONCE (the NC = 0 form re-reads the row
+// for each of its four passes: L1 / L2 hits, but four dependent load -> reduce chains per row; 3.2 TB/s of compulsory traffic at dim 3072).  Same arithmetic in the
+// same order: bitwise the same result.
+template <int NC>
 __global__ __launch_bounds__(256) void adaln_bwd_kernel(const bf16_t* __restrict__ x, long ldx, long sxb, const bf16_t* __restrict__ dy, long ldd, long sdb,
                                                         bf16_t* __restrict__ dx, long ldo, long sob, const bf16_t* __restrict__ w,
                                                         const bf16_t* __restrict__ bvec, float eps, int tokens, int dim, int batch, int modulate,
@@ -258,33 +262,58 @@ __global__ __launch_bounds__(256) void adaln_bwd_kernel(const bf16_t* __restrict
     const bf16_t* dr = dy + (long)b * sdb + (long)t * ldd;
     bf16_t* outr = dx + (long)b * sob + (long)t * ldo;
     const int nch = dim >> 3;
-    float s = 0.f, f[8], e[8];
-    for (int c = lane; c < nch; c += 64) {
-        unpack8(*(const uint4*)(xr + c * 8), f);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s += f[i];
-    }
-    const float mean = wave_sum(s) / dim;
-    float q = 0.f;
-    for (int c = lane; c < nch; c += 64) {
-        unpack8(*(const uint4*)(xr + c * 8), f);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { const float d = f[i] - mean; q += d * d; }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / dim + eps);
+    constexpr int NR = NC > 0 ? NC : 1;
+    uint4 xq[NR], dq[NR], sq[NR];                      // (the residual rows are read in the last pass: holding them too costs a wave of occupancy and measured slower)
     const bf16_t* scale = nullptr;
     if (modulate) {
         const int gi = g.tok_group[t];
         scale = (const bf16_t*)g.mod + (long)b * g.mod_batch_stride + (long)g.row[gi] * g.mod_ld + g.scale_col[gi];
     }
+    const bf16_t* ar = add ? add + (long)b * sab + (long)t * lda : nullptr;
+    if (NC > 0) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int c = lane + 64 * k;
+            const bool in = c < nch;
+            xq[k] = in ? *(const uint4*)(xr + c * 8) : uint4{0, 0, 0, 0};
+            dq[k] = in ? *(const uint4*)(dr + c * 8) : uint4{0, 0, 0, 0};
+            sq[k] = in && scale ? *(const uint4*)(scale + c * 8) : uint4{0, 0, 0, 0};
+        }
+    }
+    auto ld_x = [&](int k, int c, float (&f)[8]) { unpack8(NC > 0 ? xq[k] : *(const uint4*)(xr + c * 8), f); };
+    auto ld_d = [&](int k, int c, float (&f)[8]) { unpack8(NC > 0 ? dq[k] : *(const uint4*)(dr + c * 8), f); };
+    auto ld_s = [&](int k, int c, float (&f)[8]) { unpack8(NC > 0 ? sq[k] : *(const uint4*)(scale + c * 8), f); };
+    float s = 0.f, f[8], e[8];
+#pragma unroll NR
+    for (int k = 0; k < (NC > 0 ? NC : 1 << 20); ++k) {
+        const int c = lane + 64 * k;
+        if (c >= nch) break;
+        ld_x(k, c, f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += f[i];
+    }
+    const float mean = wave_sum(s) / dim;
+    float q = 0.f;
+#pragma unroll NR
+    for (int k = 0; k < (NC > 0 ? NC : 1 << 20); ++k) {
+        const int c = lane + 64 * k;
+        if (c >= nch) break;
+        ld_x(k, c, f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = f[i] - mean; q += d * d; }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / dim + eps);
     float m1 = 0.f, m2 = 0.f;
-    for (int c = lane; c < nch; c += 64) {
+#pragma unroll NR
+    for (int k = 0; k < (NC > 0 ? NC : 1 << 20); ++k) {
+        const int c = lane + 64 * k;
+        if (c >= nch) break;
         float gam[8], bet[8], sc[8];
-        unpack8(*(const uint4*)(xr + c * 8), f);
-        unpack8(*(const uint4*)(dr + c * 8), e);
+        ld_x(k, c, f);
+        ld_d(k, c, e);
         if (w) unpack8(*(const uint4*)(w + c * 8), gam);
         if (bvec) unpack8(*(const uint4*)(bvec + c * 8), bet);
-        if (scale) unpack8(*(const uint4*)(scale + c * 8), sc);
+        if (scale) ld_s(k, c, sc);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float xh = (f[i] - mean) * rstd;
@@ -299,13 +328,15 @@ __global__ __launch_bounds__(256) void adaln_bwd_kernel(const bf16_t* __restrict
         }
     }
     m1 = wave_sum(m1) / dim; m2 = wave_sum(m2) / dim;
-    const bf16_t* ar = add ? add + (long)b * sab + (long)t * lda : nullptr;
-    for (int c = lane; c < nch; c += 64) {
+#pragma unroll NR
+    for (int k = 0; k < (NC > 0 ? NC : 1 << 20); ++k) {
+        const int c = lane + 64 * k;
+        if (c >= nch) break;
         float gam[8], sc[8], a8[8], v[8];
-        unpack8(*(const uint4*)(xr + c * 8), f);
-        unpack8(*(const uint4*)(dr + c * 8), e);
+        ld_x(k, c, f);
+        ld_d(k, c, e);
         if (w) unpack8(*(const uint4*)(w + c * 8), gam);
-        if (scale) unpack8(*(const uint4*)(scale + c * 8), sc);
+        if (scale) ld_s(k, c, sc);
         if (ar) unpack8(*(const uint4*)(ar + c * 8), a8);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -363,25 +394,20 @@ __global__ __launch_bounds__(256) void gate_res_bwd_kernel(const bf16_t* __restr
 // mode 0: y = silu(x);  mode 1: dx = dy * gelu_tanh'(x)  (F.gelu(approximate="tanh"), diffusers FeedForward);  mode 2: y = gelu_tanh(x), the
 // same function as the GEMM's GELU epilogue (the training forward keeps the pre-activation for mode 1 and applies the activation in this pass
 // instead of running the FF1 GEMM a second time)
-__global__ __launch_bounds__(256) void act_scalar_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ out, long n, int mode) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float v = bf16_to_f32(x[i]);
-    if (mode == 0) { out[i] = f32_to_bf16(v / (1.f + __expf(-v))); return; }
-    if (mode == 2) { out[i] = f32_to_bf16(gelu_tanh(v)); return; }
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    const float u = k0 * (v + k1 * v * v * v), th = tanhf(u);
-    const float dg = 0.5f * (1.f + th) + 0.5f * v * (1.f - th * th) * k0 * (1.f + 3.f * k1 * v * v);
-    out[i] = f32_to_bf16(bf16_to_f32(dy[i]) * dg);
-}
-
 __device__ __forceinline__ float act_one(float v, float dyv, int mode) {
     if (mode == 0) return v / (1.f + __expf(-v));
     if (mode == 2) return gelu_tanh(v);
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    const float u = k0 * (v + k1 * v * v * v), th = tanhf(u);
+    // tanh(u) = 1 - 2 / (1 + exp(2u)): one v_exp + one v_rcp (exp -> inf gives 1, -> 0 gives -1) instead of tanhf's ~40 instructions — the pass went from VALU- to HBM-bound
+    const float u = k0 * (v + k1 * v * v * v), th = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.f * 1.4426950408889634f * u));
     return dyv * (0.5f * (1.f + th) + 0.5f * v * (1.f - th * th) * k0 * (1.f + 3.f * k1 * v * v));
 }
+__global__ __launch_bounds__(256) void act_scalar_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ out, long n, int mode) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = f32_to_bf16(act_one(bf16_to_f32(x[i]), mode == 1 ? bf16_to_f32(dy[i]) : 0.f, mode));      // (the same function as the 16-byte form: same values)
+}
+
 __global__ __launch_bounds__(256) void act_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ out, long n8, int mode) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;                  // 8 elements per thread
     if (i >= n8) return;
@@ -525,9 +551,16 @@ extern "C" int tg_adaln_modulate_bwd(const void* x, long ldx, long strideX, cons
         for (int i = 0; i < TG_MAX_GROUPS; ++i) vec = vec && gt.scale_col[i] % 8 == 0;
     }
     if (vec)
-        hipLaunchKernelGGL(adaln_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, strideX, (const bf16_t*)dy, ld_dy, stride_dy,
-                           (bf16_t*)dx, ld_dx, stride_dx, (const bf16_t*)ln_weight, (const bf16_t*)ln_bias, eps, tokens, dim, batch, modulate, gt, t_dln, t_dlnx,
-                           t_dyln, (const bf16_t*)add, ld_add, stride_add);
+    {
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, strideX, (const bf16_t*)dy, ld_dy, stride_dy,
+                               (bf16_t*)dx, ld_dx, stride_dx, (const bf16_t*)ln_weight, (const bf16_t*)ln_bias, eps, tokens, dim, batch, modulate, gt, t_dln, t_dlnx,
+                               t_dyln, (const bf16_t*)add, ld_add, stride_add);
+        };
+        if (dim <= 512 * 6) go(adaln_bwd_kernel<6>);          // (the 5B model: 3072)
+        else if (dim <= 512 * 8) go(adaln_bwd_kernel<8>);
+        else go(adaln_bwd_kernel<0>);
+    }
     else
         hipLaunchKernelGGL(adaln_bwd_scalar_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, strideX, (const bf16_t*)dy, ld_dy,
                            stride_dy, (bf16_t*)dx, ld_dx, stride_dx, (const bf16_t*)ln_weight, (const bf16_t*)ln_bias, eps, tokens, dim, batch, modulate, gt, t_dln,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmarks at the CogVideoX-5B To2V shapes (GPU box only): TFLOP/s per hot kernel.
-Usage: python tools/bench_kernels.py [attn] [attn_bwd] [gemm] [norm]"""
+Usage: python tools/bench_kernels.py [attn] [attn_bwd] [gemm] [norm] [train_elem]"""
 import json
 import os
 import sys
@@ -144,6 +144,22 @@ def bench_norm():
     print(json.dumps({"kernel": "transpose_v", "ms": ms, "GBps": 2 * B * N * D * 2 / ms / 1e6}))
 
 
+def bench_train_elem():
+    """The HBM-bound passes of the training backward at the block's shapes (frozen-norm AdaLN backward with the residual add; GELU forward / backward)."""
+    from tokensgen_amd import train
+    x, dy, add, dx = rnd(B, N1, D), rnd(B, N1, D), rnd(B, N1, D), torch.empty(B, N1, D, dtype=BF, device=DEV)
+    w, b = rnd(D), rnd(D)
+    tok = torch.zeros(N1, dtype=torch.uint8, device=DEV)
+    table = K.GroupTable(rnd(B, 1, 6 * D, scale=0.3), tok, [0], [0], [D], [2 * D])
+    ms = timeit(lambda: train._adaln_bwd(x, dy, dx, w, b, 1e-5, table, products=False, add=add))
+    print(json.dumps({"kernel": "adaln_bwd(frozen norm, modulated, + residual)", "ms": ms, "GBps": 4 * x.numel() * 2 / ms / 1e6}))
+    pre, dh = rnd(B * N, 4 * D), rnd(B * N, 4 * D)
+    ms = timeit(lambda: train._act(pre, gelu=True))
+    print(json.dumps({"kernel": "gelu forward pass", "ms": ms, "GBps": 2 * pre.numel() * 2 / ms / 1e6}))
+    ms = timeit(lambda: train._act(pre, dh))
+    print(json.dumps({"kernel": "gelu backward pass", "ms": ms, "GBps": 3 * pre.numel() * 2 / ms / 1e6}))
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["attn", "gemm", "norm"]
     if "attn" in what:
@@ -156,3 +172,5 @@ if __name__ == "__main__":
         bench_gemm()
     if "norm" in what:
         bench_norm()
+    if "train_elem" in what:
+        bench_train_elem()
