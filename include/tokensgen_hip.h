@@ -51,7 +51,10 @@ enum {
     TG_EPI_BIAS = 0,          /* C = A W^T + bias                                   (nn.Linear)            */
     TG_EPI_BIAS_GELU = 1,     /* C = gelu_tanh(bf16(A W^T + bias))                  (FeedForward net.0)    */
     TG_EPI_BIAS_SILU = 2,     /* C = silu(bf16(A W^T + bias))                       (TimestepEmbedding act)*/
-    TG_EPI_BIAS_GATE_RES = 3  /* C = R + gate[group(m)] * (A W^T + bias)            (gated residual)       */
+    TG_EPI_BIAS_GATE_RES = 3, /* C = R + gate[group(m)] * (A W^T + bias)            (gated residual)       */
+    /* training step, 4-wave kernel shapes only (M >= 1024, N % 256 == 0, K >= 256; TG_ERR_SHAPE otherwise — the caller then runs tg_gemm_bf16 + tg_act): */
+    TG_EPI_BIAS_KEEP_GELU = 4,     /* C = bf16(A W^T + bias) AND R (an OUTPUT here, ldr / strideR) = gelu_tanh(C): FF1 keeping its pre-activation, == TG_EPI_BIAS + tg_act mode 2 */
+    TG_EPI_BIAS_MUL_GELU_GRAD = 5  /* C = bf16(A W^T + bias) * gelu_tanh'(R), R = the kept pre-activation: FF2's dgrad, == TG_EPI_BIAS + tg_act mode 1 */
 };
 
 const char* tg_version(void);

@@ -588,6 +588,35 @@ def test_adaln_gate_and_activation_backward_kernels_vs_autograd():
     assert torch.equal(train._act(v[:2995].contiguous().to(DEV), g_[:2995].contiguous().to(DEV)), train._act(v.to(DEV), g_.to(DEV))[:2995])
 
 
+def test_gemm_activation_epilogues_equal_gemm_plus_act_pass():
+    """The training step's two GEMM epilogues (4-wave kernel): TG_EPI_BIAS_KEEP_GELU writes the pre-activation and its GELU in one launch, TG_EPI_BIAS_MUL_GELU_GRAD
+    multiplies the dgrad by gelu'(kept pre-activation) — bitwise tg_gemm_bf16(TG_EPI_BIAS) followed by tg_act (modes 2 / 1), ragged last m-tile, two batch items,
+    strided outputs; shapes without the 4-wave kernel are refused (the caller keeps the two-step form)."""
+    from tokensgen_amd import kernels as K
+    from tokensgen_amd import lib as L
+    from tokensgen_amd import train
+    B, M, Kd, N = 2, 1100, 256, 512
+    a_, w_, b_ = _rand(B, M, Kd, seed=181), _rand(N, Kd, seed=182, scale=0.1), _rand(N, seed=183)
+    a_, w_, b_ = a_.to(DEV), w_.to(DEV), b_.to(DEV)
+    assert K.gemm_act_supported(M, N, Kd) and not K.gemm_act_supported(300, N, Kd)
+    pre_ref = torch.empty(B, M, N, dtype=BF, device=DEV)
+    K.gemm(a_, w_, b_, pre_ref, L.EPI_BIAS)
+    act_ref = train._act(pre_ref, gelu=True)
+    big = torch.full((B, M, 2 * N), 9.0, dtype=BF, device=DEV)                   # both outputs as column halves of one buffer (strided rows)
+    K.gemm(a_, w_, b_, big[:, :, :N], L.EPI_BIAS_KEEP_GELU, residual=big[:, :, N:])
+    assert torch.equal(big[:, :, :N], pre_ref) and torch.equal(big[:, :, N:], act_ref) and float(act_ref.float().abs().sum()) > 0
+    # dgrad: dy [M2, N] x W [N, Kin] with the kept pre-activation [M2, Kin]
+    M2, Kin = B * M, 768
+    dy, w2, pre = _rand(M2, N, seed=184).to(DEV), _rand(N, Kin, seed=185, scale=0.1).to(DEV), _rand(M2, Kin, seed=186, scale=2.0).to(DEV)
+    ref = train._act(pre, train.linear_backward_dx(dy, w2).contiguous())
+    got = train.linear_backward_dx(dy, w2, gelu_pre=pre)
+    assert got.shape == ref.shape and torch.equal(got, ref) and float(ref.float().abs().sum()) > 0
+    small = train.linear_backward_dx(dy[:300].contiguous(), w2, gelu_pre=pre[:300].contiguous())        # no 4-wave kernel at M = 300: the two-step form, same values
+    assert torch.equal(small, ref[:300])
+    with pytest.raises(RuntimeError):
+        K.gemm(a_[:, :300], w_, b_, pre_ref[:, :300], L.EPI_BIAS_KEEP_GELU, residual=act_ref[:, :300])
+
+
 def test_to2v_block_backward_vs_autograd_of_the_oracle_block():
     """one whole CogVideoXBlock with the vip branch.  HIP forward (the product kernels, intermediates kept) + HIP backward
     (train.To2VBlockTrainer) against torch.autograd through oracle.dit_ref.block_forward in fp32 on the same bf16-rounded weights and inputs:

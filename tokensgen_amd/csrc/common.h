@@ -83,6 +83,16 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(t));   // t -> +inf: x * 0; t -> -inf: x
 }
 
+// dy * d/dx gelu_tanh(x).  tanh(u) = 1 - 2 / (1 + exp(2u)): one v_exp + one v_rcp (exp -> inf gives 1, -> 0 gives -1) instead of tanhf's ~40 instructions.  Shared by the
+// stand-alone pass (train.hip: tg_act mode 1) and the dgrad GEMM's epilogue (gemm.hip: TG_EPI_MUL_GELU_GRAD).
+// contract(off): the function is inlined into two very different kernels and must give the same bits in both (fused multiply-adds are formed per context otherwise)
+__device__ __forceinline__ float gelu_tanh_bwd(float v, float dyv) {
+#pragma clang fp contract(off)
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float u = k0 * (v + k1 * v * v * v), th = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.f * 1.4426950408889634f * u));
+    return dyv * (0.5f * (1.f + th) + 0.5f * v * (1.f - th * th) * k0 * (1.f + 3.f * k1 * v * v));
+}
+
 // XCD-aware block remap (8 XCDs, block b lands on XCD b%8): give each XCD a contiguous chunk.
 // Bijective for any nwg (cdna guide T1).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

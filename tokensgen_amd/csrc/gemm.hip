@@ -800,7 +800,7 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
             constexpr int BLK = decltype(blkc)::value, MT = BLK >> 1, NH = BLK & 1;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                gq[BLK & 1][it] = *(const uint4*)(gbase + goff[MT][it] + NH * 64);
+                if (EPI == TG_EPI_BIAS_GATE_RES) gq[BLK & 1][it] = *(const uint4*)(gbase + goff[MT][it] + NH * 64);
                 rq[BLK & 1][it] = *(const uint4*)(rbase_g + (long)min(MT * 32 + it * 8, rowclamp) * p.ldr + NH * 64);
             }
         };
@@ -825,10 +825,12 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
             W4_SB();
             gate_issue(std::integral_constant<int, 0>{});
         }
+        if (EPI == TG_EPI_BIAS_MUL_GELU_GRAD) gate_issue(std::integral_constant<int, 0>{});      // (the R rows only: the pre-activation tile)
+        bf16_t* const aux = EPI == TG_EPI_BIAS_KEEP_GELU ? const_cast<bf16_t*>(p.R) + (long)ec.b * p.sRb : nullptr;
         static_for<0, 8>([&](auto blkc) {
             constexpr int BLK = decltype(blkc)::value, mt = BLK >> 1, nh = BLK & 1;
             {
-                if constexpr (EPI == TG_EPI_BIAS_GATE_RES && BLK < 7) gate_issue(std::integral_constant<int, (BLK < 7 ? BLK + 1 : 7)>{});
+                if constexpr ((EPI == TG_EPI_BIAS_GATE_RES || EPI == TG_EPI_BIAS_MUL_GELU_GRAD) && BLK < 7) gate_issue(std::integral_constant<int, (BLK < 7 ? BLK + 1 : 7)>{});
                 static_for<0, 8>([&](auto wc) {
                     constexpr int MB2 = decltype(wc)::value >> 2, NB4 = decltype(wc)::value & 3;
                     const f32x4 a = acc[mt * 2 + MB2][nh * 4 + NB4];
@@ -872,6 +874,25 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmParams p) {
                                 ou[i] = pack_bf16x2(bf16lo_to_f32(ru[i]) + bf16lo_to_f32(gu[i]) * bf16lo_to_f32(vu[i]),
                                                     bf16hi_to_f32(ru[i]) + bf16hi_to_f32(gu[i]) * bf16hi_to_f32(vu[i]));
                             o = uint4{ou[0], ou[1], ou[2], ou[3]};
+                        }
+                        if (EPI == TG_EPI_BIAS_MUL_GELU_GRAD) {      // dx = bf16(dy W) * gelu'(pre-activation): tg_act mode 1 on the tile, no dhid round trip
+                            const uint4 rr = rq[BLK & 1][it];
+                            const uint32_t vu[4] = {o.x, o.y, o.z, o.w}, ru[4] = {rr.x, rr.y, rr.z, rr.w};
+                            uint32_t ou[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                ou[i] = pack_bf16x2(gelu_tanh_bwd(bf16lo_to_f32(ru[i]), bf16lo_to_f32(vu[i])), gelu_tanh_bwd(bf16hi_to_f32(ru[i]), bf16hi_to_f32(vu[i])));
+                            o = uint4{ou[0], ou[1], ou[2], ou[3]};
+                        }
+                        if (EPI == TG_EPI_BIAS_KEEP_GELU) {          // second output: gelu_tanh of the stored pre-activation (== TG_EPI_BIAS_GELU's values)
+                            const uint32_t vu[4] = {o.x, o.y, o.z, o.w};
+                            uint32_t gu[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const f32x2v g = gelu_tanh2(f32x2v{bf16lo_to_f32(vu[i]), bf16hi_to_f32(vu[i])});
+                                gu[i] = pack_bf16x2(g.x, g.y);
+                            }
+                            *(uint4*)(aux + (long)m * p.ldr + n) = uint4{gu[0], gu[1], gu[2], gu[3]};
                         }
                         *(uint4*)(obase + (long)m * ostride + n) = o;
                     }
@@ -941,6 +962,24 @@ extern "C" int tg_gemm_bf16(const void* A, long lda, long strideA, const void* W
                        tg_aligned16(gate->mod), TG_ERR_ALIGN, "tg_gemm_bf16: residual / gate table must be 16-byte aligned");
             p.g = *gate;
             return launch<TG_EPI_BIAS_GATE_RES>(p, stream);
+        case TG_EPI_BIAS_KEEP_GELU:
+        case TG_EPI_BIAS_MUL_GELU_GRAD: {
+            TG_REQUIRE(R && ldr % 8 == 0 && strideR % 8 == 0 && tg_aligned16(R), TG_ERR_ARG, "tg_gemm_bf16: this epilogue needs R (16-byte aligned rows)");
+            TG_REQUIRE(M >= 1024 && N % BN2 == 0 && K >= 4 * BK3 && lda < (1L << 21) && ldw < (1L << 21) && tg_knob(TG_KNOB_GEMM_W4) != 0, TG_ERR_SHAPE,
+                       "tg_gemm_bf16: the keep-GELU / GELU-grad epilogues exist in the 4-wave kernel only (M >= 1024, N%%256 == 0, K >= 256)");
+            p.group_m = p.K >= 8192 ? 1 : 4;
+            const int tiles2 = ((p.M + BM2 - 1) / BM2) * (p.N / BN2) * p.batch;
+            const int n_cu = tg_device_cus();
+            if (epilogue == TG_EPI_BIAS_KEEP_GELU) {
+                TG_DYN_LDS(gemm256w4_kernel<TG_EPI_BIAS_KEEP_GELU>, W4_LDS_BYTES);
+                hipLaunchKernelGGL(gemm256w4_kernel<TG_EPI_BIAS_KEEP_GELU>, dim3(tiles2 < n_cu ? tiles2 : n_cu), dim3(256), W4_LDS_BYTES, stream, p);
+            } else {
+                TG_DYN_LDS(gemm256w4_kernel<TG_EPI_BIAS_MUL_GELU_GRAD>, W4_LDS_BYTES);
+                hipLaunchKernelGGL(gemm256w4_kernel<TG_EPI_BIAS_MUL_GELU_GRAD>, dim3(tiles2 < n_cu ? tiles2 : n_cu), dim3(256), W4_LDS_BYTES, stream, p);
+            }
+            TG_LAUNCH_CHECK("tg_gemm_bf16(256w4, activation epilogue)");
+            return TG_OK;
+        }
         default: return tg_set_error(TG_ERR_ARG, "tg_gemm_bf16: unknown epilogue %d", epilogue);
     }
 }

@@ -397,10 +397,7 @@ __global__ __launch_bounds__(256) void gate_res_bwd_kernel(const bf16_t* __restr
 __device__ __forceinline__ float act_one(float v, float dyv, int mode) {
     if (mode == 0) return v / (1.f + __expf(-v));
     if (mode == 2) return gelu_tanh(v);
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    // tanh(u) = 1 - 2 / (1 + exp(2u)): one v_exp + one v_rcp (exp -> inf gives 1, -> 0 gives -1) instead of tanhf's ~40 instructions — the pass went from VALU- to HBM-bound
-    const float u = k0 * (v + k1 * v * v * v), th = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.f * 1.4426950408889634f * u));
-    return dyv * (0.5f * (1.f + th) + 0.5f * v * (1.f - th * th) * k0 * (1.f + 3.f * k1 * v * v));
+    return gelu_tanh_bwd(v, dyv);               // (common.h)
 }
 __global__ __launch_bounds__(256) void act_scalar_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ out, long n, int mode) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;

@@ -113,6 +113,12 @@ def gemm(a, w, bias, out, epilogue=L.EPI_BIAS, residual=None, gate=None):
     return out
 
 
+def gemm_act_supported(M, N, K):
+    """Shapes that have the training step's activation epilogues (EPI_BIAS_KEEP_GELU: `residual` is the second OUTPUT, gelu of the kept pre-activation;
+    EPI_BIAS_MUL_GELU_GRAD: `residual` is the kept pre-activation): the 4-wave GEMM kernel's.  Elsewhere: gemm(EPI_BIAS) + tg_act."""
+    return M >= 1024 and N % 256 == 0 and K % 64 == 0 and K >= 256 and os.environ.get("TG_GEMM_W4", "1") != "0"
+
+
 def gemm_pair(a1, w1, bias1, out1, a2, w2, bias2, out2, epilogue=L.EPI_BIAS):
     """out1 = epi(a1 @ w1^T + bias1) and out2 = epi(a2 @ w2^T + bias2) in one launch (tg_gemm_bf16_pair): same N, K, batch, leading
     dimensions; [B, M, K] activations with M >= 1024."""

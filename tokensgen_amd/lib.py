@@ -7,6 +7,7 @@ LIB_PATH = os.environ.get("TG_LIB_PATH") or os.path.join(_HERE, "libtokensgen_hi
 TG_MAX_GROUPS = 16
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SILU, EPI_BIAS_GATE_RES = 0, 1, 2, 3
+EPI_BIAS_KEEP_GELU, EPI_BIAS_MUL_GELU_GRAD = 4, 5      # training step; 4-wave GEMM shapes only (kernels.gemm_act_supported)
 
 
 class GroupTable(C.Structure):

@@ -164,7 +164,7 @@ def _weight_t(weight, frozen):
     return wT
 
 
-def linear_backward_dx(dy2d, weight, accumulate_into=None, ones=None, frozen=None):
+def linear_backward_dx(dy2d, weight, accumulate_into=None, ones=None, frozen=None, gelu_pre=None):
     """dx = dy W only: [M, out] x [out, in] -> [M, in] bf16.  accumulate_into ([B, T, in] bf16 view) + ones (a unit-gate GroupTable):
     dy is [B, T, out] and dx is ADDED to the view through the GEMM's gated-residual epilogue (in place, no separate pass).  frozen: see _weight_t."""
     if accumulate_into is not None:
@@ -178,8 +178,11 @@ def linear_backward_dx(dy2d, weight, accumulate_into=None, ones=None, frozen=Non
     wT = _weight_t(weight, frozen)
     dyp = dy2d if cout_p == cout else torch.nn.functional.pad(dy2d, (0, cout_p - cout))
     dxp = torch.empty(M, cin_p, dtype=BF16, device=dy2d.device)
+    if gelu_pre is not None and cin_p == cin and K.gemm_act_supported(M, cin_p, cout_p):
+        K.gemm(dyp, wT, None, dxp, L.EPI_BIAS_MUL_GELU_GRAD, residual=gelu_pre)
+        return dxp
     K.gemm(dyp, wT, None, dxp, L.EPI_BIAS)
-    return dxp[:, :cin]
+    return dxp[:, :cin] if gelu_pre is None else _act(gelu_pre, dxp[:, :cin].contiguous())
 
 
 def qk_layernorm_rope_backward(x_pre, dy, heads, ln_weight, eps, seg0=None, seg1=None, out_scale=1.0, out=None):
@@ -434,8 +437,12 @@ class To2VBlockTrainer:
         K.adaln_modulate(X1[:, N1:], Xn2[:, N1:], sd[f"{pre}.vip_norm2.norm.weight"], sd[f"{pre}.vip_norm2.norm.bias"], self.eps, t2.offset(N1))
         Fw1, Fb1, Fw2, Fb2 = (sd[f"{pre}.ff.net.{n}"] for n in ("0.proj.weight", "0.proj.bias", "2.weight", "2.bias"))
         ffpre = e(B, N, Fw1.shape[0])
-        K.gemm(Xn2, Fw1, Fb1, ffpre, L.EPI_BIAS)
-        ffh = _act(ffpre, gelu=True)                          # == the GELU epilogue on the same pre-activation, as one streaming pass (not a second GEMM)
+        if K.gemm_act_supported(N, Fw1.shape[0], D):          # pre-activation kept AND its GELU written by the same epilogue (bitwise the two-step form below)
+            ffh = e(B, N, Fw1.shape[0])
+            K.gemm(Xn2, Fw1, Fb1, ffpre, L.EPI_BIAS_KEEP_GELU, residual=ffh)
+        else:
+            K.gemm(Xn2, Fw1, Fb1, ffpre, L.EPI_BIAS)
+            ffh = _act(ffpre, gelu=True)                      # == the GELU epilogue on the same pre-activation, as one streaming pass (not a second GEMM)
         y_ff = e(B, Np, D)
         K.gemm(ffh[:, N1:], Fw2, Fb2, y_ff, L.EPI_BIAS)
         X2 = e(B, N, D)
@@ -492,8 +499,7 @@ class To2VBlockTrainer:
         # ---- feed-forward residual (step 7), FeedForward, norm2 ----
         dy_ff, tg2 = _gate_res_bwd(dX2, S["y_ff"], S["t2"], row0=N1)          # gate products only for the vip rows (the group whose gate trains)
         Fw1, Fw2 = sd[f"{pre}.ff.net.0.proj.weight"], sd[f"{pre}.ff.net.2.weight"]
-        dhid = _dgrad(dy_ff.view(B * N, D), Fw2, frozen=(self._wt, "ff2"))
-        dpre = _act(S["ffpre"].view(B * N, -1), dhid)
+        dpre = _dgrad(dy_ff.view(B * N, D), Fw2, frozen=(self._wt, "ff2"), gelu_pre=S["ffpre"].view(B * N, -1))     # (dy W2) * gelu'(pre-activation)
         dXn2 = _dgrad(dpre, Fw1, frozen=(self._wt, "ff1")).view(B, N, D)
         dX1 = torch.empty(B, N, D, dtype=BF16, device=dX2.device)
         # norm2 is frozen on the text / video rows (no parameter products); `add`: X2 = X1 + gate * FF(norm2(X1)) also hands dX2 straight to X1
@@ -534,9 +540,10 @@ class To2VBlockTrainer:
         return grads, dX0
 
 
-def _dgrad(dy2d, weight, frozen=None):
-    """dx = dy W for y = x W^T (bf16 [M, out] x [out, in] -> [M, in]) through the MFMA GEMM."""
-    return linear_backward_dx(dy2d.contiguous(), weight, frozen=frozen)
+def _dgrad(dy2d, weight, frozen=None, gelu_pre=None):
+    """dx = dy W for y = x W^T (bf16 [M, out] x [out, in] -> [M, in]) through the MFMA GEMM.  gelu_pre ([M, in] bf16, the kept pre-activation of a GELU whose
+    output was x): returns dx * gelu'(gelu_pre) — in the GEMM's epilogue where the shape has it, else as tg_act's pass over dx (same values)."""
+    return linear_backward_dx(dy2d.contiguous(), weight, frozen=frozen, gelu_pre=gelu_pre)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
