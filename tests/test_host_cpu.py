@@ -160,6 +160,15 @@ def test_c_abi_exports_every_declared_symbol():
     p = ctypes.addressof(buf) + (16 - ctypes.addressof(buf) % 16)
     assert lib.tg_gemm_bf16(p, 64, 0, p, 64, None, p, 100, 0, 4, 100, 64, 1, 0, None, 0, 0, None, None) == -2
     assert b"N%128" in lib.tg_last_error_string()
+    # the epilogue enum of the header == the constants of the binding; the two training-step epilogues refuse shapes without the 4-wave kernel (no launch: testable here)
+    raw = open(os.path.join(ROOT, "include", "tokensgen_hip.h")).read()
+    enum = dict(re.findall(r"\b(TG_EPI_[A-Z_]+)\s*=\s*(\d+)", raw))
+    assert {k: int(v) for k, v in enum.items()} == {"TG_EPI_BIAS": L.EPI_BIAS, "TG_EPI_BIAS_GELU": L.EPI_BIAS_GELU, "TG_EPI_BIAS_SILU": L.EPI_BIAS_SILU,
+                                                    "TG_EPI_BIAS_GATE_RES": L.EPI_BIAS_GATE_RES, "TG_EPI_BIAS_KEEP_GELU": L.EPI_BIAS_KEEP_GELU,
+                                                    "TG_EPI_BIAS_MUL_GELU_GRAD": L.EPI_BIAS_MUL_GELU_GRAD}
+    for epi in (L.EPI_BIAS_KEEP_GELU, L.EPI_BIAS_MUL_GELU_GRAD):
+        assert lib.tg_gemm_bf16(p, 64, 0, p, 64, None, p, 128, 0, 512, 128, 64, 1, epi, p, 128, 0, None, None) == -2 and b"4-wave kernel only" in lib.tg_last_error_string()
+        assert lib.tg_gemm_bf16(p, 64, 0, p, 64, None, p, 128, 0, 512, 128, 64, 1, epi, None, 128, 0, None, None) == -1
 
 
 def test_c_abi_rejects_null_arguments_everywhere():
