@@ -98,6 +98,7 @@ class PowerSampler:
     def __init__(self, device_index=0, period_s=0.05):
         self.period, self.samples, self._stop, self._thread = period_s, [], False, None
         self.source, self.cap_W = None, None
+        self._smi, self._idx, self._viol0, self._viol1, self.pci = None, device_index, None, None, None
         self._read = self._pick(device_index)
 
     # -- sources --------------------------------------------------------------------------------------------------------------
@@ -196,10 +197,93 @@ class PowerSampler:
         self.source = None
         return lambda: (None, None)
 
+    # -- which limiter held the clock down (VERDICT r5 weak #4a: read, not asserted) ------------------------------------------------
+    def _violations(self):
+        """Accumulated throttler residencies of the device (amdsmi violation status: counts of firmware intervals spent on each limiter — package power PPT,
+        socket / VR / HBM thermal, PROCHOT — beside the count of all intervals), or the gpu_metrics residency accumulators, or None.  Two snapshots around a
+        timed region give the fraction of the region each limiter was active; nothing is derived from power or clock."""
+        try:
+            if self._smi is None:
+                sys.path.append("/opt/rocm/share/amd_smi")
+                import amdsmi
+                try:
+                    amdsmi.amdsmi_init()
+                except Exception:  # noqa: BLE001  (already initialised by _pick)
+                    pass
+                hs = amdsmi.amdsmi_get_processor_handles()
+                h = None
+                for cand in hs:
+                    try:
+                        bdf = amdsmi.amdsmi_get_gpu_device_bdf(cand).lower()
+                        if self.pci and bdf.startswith(self.pci):
+                            h = cand
+                    except Exception:  # noqa: BLE001
+                        pass
+                if h is None:
+                    h = hs[self._idx] if len(hs) > self._idx else hs[0]
+                self._smi = (amdsmi, h)
+            amdsmi, h = self._smi
+        except Exception:  # noqa: BLE001
+            self._smi = False
+            return None
+        if not self._smi:
+            return None
+        num = lambda v: float(v) if isinstance(v, (int, float)) else None
+
+        def leaves(v):
+            if isinstance(v, (list, tuple)):
+                vals = [x for x in (leaves(u) for u in v) if x is not None]
+                return sum(vals) if vals else None
+            return num(v)
+        try:
+            v = amdsmi.amdsmi_get_violation_status(h)
+            snap = {"source": "amdsmi_get_violation_status", "intervals": num(v.get("acc_counter")), "ppt": num(v.get("acc_ppt_pwr")),
+                    "socket_thermal": num(v.get("acc_socket_thrm")), "vr_thermal": num(v.get("acc_vr_thrm")), "hbm_thermal": num(v.get("acc_hbm_thrm")),
+                    "prochot": num(v.get("acc_prochot_thrm")),
+                    # per-XCD "shader clock below the host limit because of power / of temperature" accumulators (gpu_metrics 1.8 xcp_stats), summed over the XCDs
+                    "gfx_clk_below_host_limit_pwr": leaves(v.get("acc_gfx_clk_below_host_limit_pwr")),
+                    "gfx_clk_below_host_limit_thm": leaves(v.get("acc_gfx_clk_below_host_limit_thm"))}
+            if snap["intervals"] is not None:
+                return snap
+        except Exception:  # noqa: BLE001
+            pass
+        try:
+            m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+            snap = {"source": "amdsmi_get_gpu_metrics_info", "intervals": num(m.get("accumulation_counter")), "ppt": num(m.get("ppt_residency_acc")),
+                    "socket_thermal": num(m.get("socket_thm_residency_acc")), "vr_thermal": num(m.get("vr_thm_residency_acc")),
+                    "hbm_thermal": num(m.get("hbm_thm_residency_acc")), "prochot": num(m.get("prochot_residency_acc")),
+                    "throttle_status": m.get("throttle_status") if isinstance(m.get("throttle_status"), int) else None}
+            if snap["intervals"] is not None or snap["ppt"] is not None:
+                return snap
+        except Exception:  # noqa: BLE001
+            pass
+        return None
+
+    def limiter(self):
+        """{limiter: fraction of the sampled region it was active} + the name of the largest, from the two snapshots taken by __enter__ / __exit__; None when the box offers no source."""
+        a, b = self._viol0, self._viol1
+        if not a or not b:
+            return None
+        names = ("ppt", "socket_thermal", "vr_thermal", "hbm_thermal", "prochot", "gfx_clk_below_host_limit_pwr", "gfx_clk_below_host_limit_thm")
+        dn = (b["intervals"] - a["intervals"]) if a.get("intervals") is not None and b.get("intervals") is not None else None
+        out = {"source": b["source"], "intervals": dn}
+        frac = {}
+        for n in names:
+            if a.get(n) is not None and b.get(n) is not None:
+                d = b[n] - a[n]
+                frac[n] = (d / dn) if dn else d
+        out["active_frac" if dn else "active_counts"] = {k: round(v, 4) for k, v in frac.items()}
+        main = {k: v for k, v in frac.items() if not k.startswith("gfx_clk")}      # the per-XCD sums are reported, not ranked
+        top = max(main, key=main.get) if main else None
+        # named only when it was active for at least 5 % of the region (a handful of intervals at the start of a burst is not "the limiter")
+        out["limiter"] = (top if (frac.get(top, 0) >= 0.05 if dn else frac.get(top, 0) > 0) else "none") if top else None
+        return out
+
     # -- sampling -------------------------------------------------------------------------------------------------------------
     def __enter__(self):
         import threading
         self.samples, self._stop = [], False
+        self._viol0, self._viol1 = self._violations(), None
 
         def loop():
             while not self._stop:
@@ -210,6 +294,7 @@ class PowerSampler:
         return self
 
     def __exit__(self, *exc):
+        self._viol1 = self._violations()
         self._stop = True
         self._thread.join(timeout=10)
         return False
@@ -219,7 +304,7 @@ class PowerSampler:
         ck = [c for _, c in self.samples if c is not None]
         mean = lambda v: (sum(v) / len(v)) if v else None
         return {"power_W_mean": mean(pw), "power_W_max": max(pw) if pw else None, "power_cap_W": self.cap_W, "sclk_MHz_mean": mean(ck),
-                "sclk_MHz_min": min(ck) if ck else None, "sclk_MHz_max": max(ck) if ck else None, "samples": len(self.samples), "source": self.source, "pci": getattr(self, "pci", None)}
+                "sclk_MHz_min": min(ck) if ck else None, "sclk_MHz_max": max(ck) if ck else None, "samples": len(self.samples), "source": self.source, "pci": getattr(self, "pci", None), "limiter": self.limiter()}
 
 
 def cpu_baseline(seconds_budget=150.0):
@@ -272,6 +357,9 @@ def cpu_baseline(seconds_budget=150.0):
             "threads_probe_s": {str(k): round(v, 4) for k, v in probe.items()}}
 
 
+# To2V training micro-step (B = 2), algorithmic transformer flops per layer: forward 18.47 T (QKV 2.013 + vip QKV over all rows 2.067 + attention 8.19 + out 0.689 + FF 5.513)
+# + attention backward 2.5 x 8.19 = 20.48 T + dgrad of the same five linears 10.28 T + wgrad of vip_to_{q,k,v} 2.067 T; x 42 layers
+TRAIN_FLOP_PER_MICRO_STEP = 776.0e12 + 860.0e12 + 431.8e12 + 86.8e12
 VAE_FLOP = {"decode": 3.1e14, "encode": 1.5e14}     # untiled algorithmic count per 49-frame clip; executed = x1.40 (9-tile overlap)
 
 
@@ -451,7 +539,7 @@ def run_train(a, rank, world, device, dist):
         print(json.dumps(rec))
 
 
-def train_measure(a, rank, world, device, dist):
+def train_measure(a, rank, world, device, dist, ckpt_leg_steps=0):
     """BASELINE config 5 (`--mode train`, and the `train` sub-record of the default run): To2V training micro-steps at the yaml's shapes — per_gpu_batch_size 2, 13 latent frames of 60 x 90, 226 text
     tokens, the Resampler (trainable) over two 13-frame chunks -> 480 vip tokens, transformer forward with per-block checkpointing, v-prediction
     loss, backward with recompute, gradient accumulation over `--accum` micro-steps, then bucketed RCCL all-reduce (N > 1), clip, AdamW.
@@ -520,6 +608,34 @@ def train_measure(a, rank, world, device, dist):
         tm = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dt = float(tm.item())
+    # second leg, the yaml's own schedule (cogvideo_5b_vaevip_4x8x12_to2v.yaml:59 gradient_checkpointing: true -> train_cogvideo_to2v.py:1323-1324): every block keeps only
+    # its input and re-runs its forward inside the backward (activation_budget_bytes = 0).  Same objects, 1 warm-up + `ckpt_leg_steps` micro-steps from the start of a
+    # window (no optimizer step inside unless ckpt_leg_steps >= accum); peak memory counted from a reset
+    ckpt_leg = None
+    peak_kept = torch.cuda.max_memory_allocated() / 2 ** 30
+    kept_blocks = tr.blocks_kept
+    if ckpt_leg_steps > 0:
+        step.discard_window()
+        tr.activation_budget_bytes = 0
+        tr._kept, tr._ckpt = {}, []
+        for blk in tr._blocks or []:
+            blk.saved = None
+        import gc
+        gc.collect(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+        micro(); step.discard_window()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(ckpt_leg_steps):
+            lc, _ = micro()
+        fence()
+        cdt = time.perf_counter() - t0
+        step.discard_window()
+        ckpt_leg = {"schedule": "gradient_checkpointing: true (the yaml's): every block recomputed in the backward", "steps": ckpt_leg_steps, "warmup": 1,
+                    "ms_per_step": 1e3 * cdt / ckpt_leg_steps, "blocks_keeping_activations": tr.blocks_kept, "blocks_recomputed_in_backward": a.layers - tr.blocks_kept,
+                    "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30, "loss": float(lc),
+                    "step_mfma_frac": TRAIN_FLOP_PER_MICRO_STEP * (a.layers / 42.0) / (cdt / ckpt_leg_steps) / PEAK_BF16,
+                    "executed_mfma_frac_incl_recompute": (TRAIN_FLOP_PER_MICRO_STEP + FLOP_PER_STEP) * (a.layers / 42.0) / (cdt / ckpt_leg_steps) / PEAK_BF16}
+        tr.activation_budget_bytes = None
     if rank == 0:
         prof = K.profile_summary().get("attention_bwd", {"ms": float("nan"), "n": 0, "total_ms": 0.0})
         # dominant kernel group: the attention backward launches (statistics + dK/dV + dQ).  Algorithmic flops per transformer layer and micro-step:
@@ -541,8 +657,13 @@ def train_measure(a, rank, world, device, dist):
             "data": "synthetic latents / embeddings, random-init weights at CogVideoX-5B + Resampler(4x8x12) shapes",
             "config": {"workload": "To2V train micro-step (BASELINE config 5): batch 2 x 13 latent frames 60x90, 226 text + 480 vip tokens, Resampler over 2 chunks of 17550 tokens",
                        "layers": a.layers, "accumulation_steps": a.accum, "optimizer_steps_in_timed_region": n_opt,
-                       "blocks_keeping_activations": tr.blocks_kept, "blocks_recomputed_in_backward": a.layers - tr.blocks_kept,
+                       "blocks_keeping_activations": kept_blocks, "blocks_recomputed_in_backward": a.layers - kept_blocks,
                        "trainable_parameters": int(sum(v.numel() for v in arena.views.values()))},
+            # whole micro-step against the MFMA peak: ALGORITHMIC flops of the transformer (forward 776.0 T + attention backward 860.0 T + dgrad through the frozen and vip linears
+            # 431.8 T + wgrad of the trainable vip_to_{q,k,v} 86.8 T = 2154.6 T at B = 2; the Resampler's ~1.5 % and any recomputed forward are NOT counted) / time / 2.5 PF
+            "step_mfma_frac": TRAIN_FLOP_PER_MICRO_STEP * (a.layers / 42.0) / (dt / a.steps) / PEAK_BF16,
+            "flop_per_micro_step": TRAIN_FLOP_PER_MICRO_STEP * (a.layers / 42.0),
+            "checkpointed_leg": ckpt_leg,
             "roofline": {"bound": "mfma", "kernel": "tg_attention_bwd (statistics + the one-kernel dK/dV/dQ launch for the 17776^2 and the vip-key calls, dK/dV + dQ launches for the vip-query call; all transformer layers of one micro-step)",
                          "achieved": alg / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else None, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": (alg / (tot_ms * 1e-3) / 1e12 / 2500.0) if tot_ms > 0 else None, "traffic": traffic,
@@ -556,8 +677,71 @@ def train_measure(a, rank, world, device, dist):
                                   else "two launches (dK/dV + dQ)",
             "attention_bwd_probe": K.BwdDeviceState.get(device).probe,
             "power_W_mean": power["power_W_mean"], "power_cap_W": power["power_cap_W"], "sclk_MHz_mean": power["sclk_MHz_mean"],
-            "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30})
+            "peak_mem_GB": peak_kept})
     return None
+
+
+def _r(v, n=4):
+    return round(v, n) if isinstance(v, float) else v
+
+
+def compact_line(out):
+    """The ONE JSON line of the bench contract, short enough (< 4 KB) that a record which keeps only the head and the tail of stdout still holds every number
+    (the 13 KB line lost `vae` and `train.ms_per_step` in the driver's copy).  `summary` sits right behind `ms_per_step`; no prose.  The full
+    record — every key of earlier rounds — goes to gpurun_out/bench_detail.json (copied to profiles/ by the builder)."""
+    g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+    vae, tr, pw, z = out.get("vae"), out.get("train"), out.get("power") or {}, out.get("zero_operand_control")
+    ck = g(tr, "checkpointed_leg")
+    summary = {"step_mfma_frac": out.get("step_mfma_frac"), "attn_frac": g(out, "roofline", "frac"), "attn_ms": g(out, "roofline", "launch_ms"),
+               "zero_ctl_ms": g(z, "ms_per_step"), "power_W": pw.get("power_W_mean"), "power_cap_W": pw.get("power_cap_W"), "sclk_MHz": pw.get("sclk_MHz_mean"),
+               "limiter": g(pw, "limiter", "limiter"),
+               "vae_decode_s": g(vae, "decode", "seconds"), "vae_encode_s": g(vae, "encode", "seconds"),
+               "vae_decode_frac": g(vae, "decode", "frac_of_peak_algorithmic"), "vae_encode_frac": g(vae, "encode", "frac_of_peak_algorithmic"),
+               "train_ms_per_micro_step": g(tr, "ms_per_step"), "train_step_mfma_frac": g(tr, "step_mfma_frac"), "train_bwd_frac": g(tr, "roofline", "frac"),
+               "train_peak_mem_GB": g(tr, "peak_mem_GB"), "train_ckpt_ms_per_micro_step": g(ck, "ms_per_step"), "train_ckpt_peak_mem_GB": g(ck, "peak_mem_GB"),
+               "train_ckpt_step_mfma_frac": g(ck, "step_mfma_frac")}
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")}
+    line["summary"] = {k: _r(v) for k, v in summary.items()}
+    line.update({k: out[k] for k in ("higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "value_aggregate", "value_per_gpu", "finite", "step_mfma_frac")})
+    rf = out["roofline"]
+    line["roofline"] = {k: _r(rf.get(k), 5) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "launches_timed", "attn_path", "frac_at_measured_clock")}
+    if out.get("cpu_baseline"):
+        cb = out["cpu_baseline"]
+        line["cpu_baseline"] = {k: _r(cb.get(k), 6) for k in ("value", "unit", "cores", "kind", "sample", "fp32_value", "cpu_model", "physical_cores")}
+    line["power"] = {"W_mean": _r(pw.get("power_W_mean"), 1), "cap_W": pw.get("power_cap_W"), "sclk_MHz_mean": _r(pw.get("sclk_MHz_mean"), 1), "limiter": pw.get("limiter")}
+    if z:
+        line["zero_operand_control"] = {"ms_per_step": _r(z["ms_per_step"], 2), "attention_launch_ms": _r(z["attention_launch_ms"], 3), "W_mean": _r(z.get("power_W_mean"), 1),
+                                        "sclk_MHz_mean": _r(z.get("sclk_MHz_mean"), 1), "limiter": g(z, "limiter", "limiter")}
+    km = sorted(out.get("kernel_ms", {}).items(), key=lambda kv: -kv[1])[:6]
+    line["kernel_ms_top"] = {k: _r(v, 3) for k, v in km}
+    line["rank_ms_per_step"] = out.get("rank_ms_per_step")
+    if vae:
+        line["vae"] = {n: {"seconds": _r(vae[n]["seconds"]), "frac_algorithmic": _r(vae[n]["frac_of_peak_algorithmic"]), "frac_executed": _r(vae[n]["frac_of_peak_executed"]),
+                           "W_mean": _r(vae[n]["power_W_mean"], 1), "sclk_MHz_mean": _r(vae[n]["sclk_MHz_mean"], 1)} for n in ("decode", "encode")}
+    if tr:
+        line["train"] = {"value": _r(tr["value"]), "unit": tr["unit"], "steps": tr["steps"], "ms_per_step": _r(tr["ms_per_step"], 2), "step_mfma_frac": _r(tr["step_mfma_frac"]),
+                         "flop_per_micro_step": tr["flop_per_micro_step"], "optimizer_steps_in_timed_region": g(tr, "config", "optimizer_steps_in_timed_region"),
+                         "blocks_recomputed_in_backward": g(tr, "config", "blocks_recomputed_in_backward"), "peak_mem_GB": _r(tr["peak_mem_GB"], 2),
+                         "roofline": {k: _r(g(tr, "roofline", k), 5) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "ms_per_micro_step_in_this_kernel")},
+                         "loss": _r(tr["loss"], 5), "grad_norm_last_step": _r(tr["grad_norm_last_step"], 4), "W_mean": _r(tr["power_W_mean"], 1), "sclk_MHz_mean": _r(tr["sclk_MHz_mean"], 1),
+                         "checkpointed_leg": None if not ck else {k: _r(ck[k]) for k in ("steps", "ms_per_step", "blocks_recomputed_in_backward", "peak_mem_GB", "step_mfma_frac",
+                                                                                         "executed_mfma_frac_incl_recompute")}}
+    line["detail"] = "gpurun_out/bench_detail.json"
+    return line
+
+
+def emit(out):
+    """Full record to the scratch file gpurun_out/bench_detail.json (nothing long on stdout or stderr: a record that keeps head and tail of the streams must keep the
+    contract line whole), then the compact contract line as the only line of stdout."""
+    detail = json.dumps(out)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w") as f:
+            f.write(detail + "\n")
+    except OSError:
+        pass
+    print(json.dumps(compact_line(out)))
+    sys.stdout.flush()
 
 
 def main():
@@ -743,7 +927,7 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         out = {
-            "metric": "DiT denoising steps/sec (CFG-batched 13-frame window: DiT fwd + CFG + 13 DPM updates), CogVideoX-5B To2V 720x480",
+            "metric": "DiT denoising steps/sec, CogVideoX-5B To2V 720x480 (CFG-batched 13-frame FIFO window: DiT fwd + CFG + 13 DPM updates)",
             # `value` is the WHOLE-JOB aggregate over the N ranks (the bench contract); BASELINE's metric is quoted per GPU: that is value_per_gpu.
             # At N = 1 the two coincide.  Each rank runs a steady-state window (weak scaling); the end-to-end rate incl. the ramp is `--mode e2e`.
             "value": world * a.steps / dt, "value_aggregate": world * a.steps / dt, "value_per_gpu": a.steps / dt, "value_is": "aggregate over n_gpus",
@@ -751,11 +935,10 @@ def main():
             "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic latents/embeddings, random-init weights at CogVideoX-5B shapes",
-            "config": {"workload": "To2V FIFO window step, CogVideoX-5B (42 layers, D=3072, 48x64 heads), 13x60x90 latent "
-                                   "window = 226 text + 17550 video + 480 condensed tokens, CFG batch 2, DPM-solver++ (52 trailing steps)",
+            "config": {"workload": "To2V FIFO window step, CogVideoX-5B 42 layers D=3072, 226 text + 17550 video + 480 vip tokens, CFG batch 2, DPM-solver++",
                        "layers": a.layers, "exchange": "RCCL all_gather of kept half-windows per step" if use_dist else "none"},
             "step_mfma_frac": FLOP_PER_STEP * (a.layers / 42.0) * (a.steps / dt) / PEAK_BF16,
-            "roofline": {"bound": "mfma", "kernel": "attn_fwd_pp_kernel (SDPA#1+#2 fused + SDPA#3 riding; whole workgroups, key-split tail + combine, retry grid: one tg_attention_fwd_multi call)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "attn_fwd_pp_kernel (tg_attention_fwd_multi: SDPA#1+#2 fused, SDPA#3 riding, key-split tail + combine)", "achieved": achieved,
                          "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16 / 1e12), "traffic": traffic,
                          "launch_ms": attn["ms"], "launches_timed": attn["n"], "attn_path": attn_path},
             "attn_path": attn_path, "attn_retried_workgroups": retried, "finite": finite,
@@ -780,10 +963,10 @@ def main():
             import gc
             gc.collect(); torch.cuda.empty_cache()
             ta = argparse.Namespace(layers=a.layers, steps=9, warmup=1, accum=9)      # one whole accumulation window: the optimizer step is inside
-            out["train"] = train_measure(ta, 0, 1, device, None)
+            out["train"] = train_measure(ta, 0, 1, device, None, ckpt_leg_steps=3)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        emit(out)
     if use_dist:
         dist.destroy_process_group()
 

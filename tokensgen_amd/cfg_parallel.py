@@ -43,3 +43,29 @@ def predict(mode, forward_half, forward_both, n=2):
     allp = torch.empty((world,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
     dist.all_gather_into_tensor(allp, mine)
     return allp[:n].contiguous()          # rank h < n holds branch h
+
+
+def map_chunks_sharded(n_chunks, fn, device=None):
+    """[fn(0), ..., fn(n_chunks - 1)] on EVERY rank, each rank having run only the chunks c with c % world == rank, brought together by ONE all_gather_into_tensor
+    (rank-major slots, like fifo.decode_chunks_sharded).  fn(c) -> tensor of one fixed shape / dtype on `device` (this rank's; needed by a rank that holds no chunk).
+    For work that is independent per chunk and that the reference runs chunk after chunk on one GPU: the condensed-token encoding of the source clips
+    (pipeline_cogvideox_mp_fifo.py:585-609: vae.encode -> patch_embed.proj -> Resampler per 49-frame chunk).  With no process group: a plain loop; with one — of any
+    size — the collective runs.  fn must not depend on state the other chunks' calls would have changed (the caller draws any random numbers for ALL chunks itself, in
+    chunk order, so every rank's generator stays in step)."""
+    import torch.distributed as dist
+    dist_on = dist.is_available() and dist.is_initialized()
+    world, me = world_and_rank()
+    mine = [fn(c) for c in range(n_chunks) if c % world == me]
+    if not dist_on:
+        return mine
+    meta = [None] * world
+    dist.all_gather_object(meta, (tuple(mine[0].shape), mine[0].dtype) if mine else None)     # a rank may hold no chunk
+    shape, dtype = next(m for m in meta if m is not None)
+    dev = mine[0].device if mine else torch.device(device if device is not None else "cpu")
+    per = (n_chunks + world - 1) // world
+    buf = torch.zeros((per,) + shape, dtype=dtype, device=dev)
+    for slot, t in enumerate(mine):
+        buf[slot] = t
+    allbuf = torch.empty((world * per,) + shape, dtype=dtype, device=dev)
+    dist.all_gather_into_tensor(allbuf, buf)
+    return [allbuf[(c % world) * per + c // world] for c in range(n_chunks)]

@@ -35,15 +35,25 @@ int tg_device_cus(void) {
     return v;
 }
 
-bool tg_first_on_device(TgOnce& once) {
+static unsigned long long* once_word(TgOnce& once, unsigned long long* bit) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const unsigned long long bit = 1ull << (dev & 63);
-    unsigned long long* w = &once.mask[(dev >> 6) & 3];
-    if (__atomic_load_n(w, __ATOMIC_ACQUIRE) & bit) return false;
-    // (two threads racing here both set the attribute: harmless, it is idempotent)
+    *bit = 1ull << (dev & 63);
+    return &once.mask[(dev >> 6) & 3];
+}
+
+bool tg_done_on_device(TgOnce& once) {
+    unsigned long long bit;
+    const unsigned long long* w = once_word(once, &bit);
+    return (__atomic_load_n(w, __ATOMIC_ACQUIRE) & bit) != 0;
+}
+
+// called AFTER the attribute call has returned: a second host thread that sees the bit may launch at once.  Two threads that both find the bit
+// clear both set the attribute (idempotent) and both mark it.
+void tg_mark_on_device(TgOnce& once) {
+    unsigned long long bit;
+    unsigned long long* w = once_word(once, &bit);
     __atomic_fetch_or(w, bit, __ATOMIC_RELEASE);
-    return true;
 }
 
 // ---- debug knobs: dispatch overrides of the cross-check tests; see tg_debug_set in the header ----

@@ -37,14 +37,18 @@ static inline bool tg_aligned16(const void* p) { return (((uintptr_t)p) & 15) ==
 // process: a host that drives several GPUs from one process (the reference's own topology, infer_cogvideo_mp_fifo.py:191,211-213) must get them on
 // every device it launches on.  Nothing here is keyed by anything but the CURRENT device id, and nothing changes a result.
 int tg_device_cus(void);                                    // multiprocessor count of the current device (cached per device id)
-// true once per (device, slot): the caller then sets its kernel's attribute.  `slot` = a TgOnce the launcher owns (one per kernel instantiation).
+// `slot` = a TgOnce the launcher owns (one per kernel instantiation), one bit per device id.  The bit is set only AFTER hipFuncSetAttribute has returned,
+// so a second host thread never skips the attribute while the first is still inside the call (both may set it: idempotent).
 struct TgOnce { unsigned long long mask[4]; };              // one bit per device id (< 256); zero-initialised static
-bool tg_first_on_device(TgOnce& once);
+bool tg_done_on_device(TgOnce& once);
+void tg_mark_on_device(TgOnce& once);
 #define TG_DYN_LDS(kernel, bytes)                                                                                      \
     do {                                                                                                               \
         static TgOnce once__;                                                                                          \
-        if (tg_first_on_device(once__))                                                                                \
+        if (!tg_done_on_device(once__)) {                                                                              \
             (void)hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes));     \
+            tg_mark_on_device(once__);                                                                                 \
+        }                                                                                                              \
     } while (0)
 
 // ---- dispatch overrides for the cross-check tests (tg_debug_set in the header): which of two product kernels of the same op a launcher picks.

@@ -113,10 +113,11 @@ def gemm(a, w, bias, out, epilogue=L.EPI_BIAS, residual=None, gate=None):
     return out
 
 
-def gemm_act_supported(M, N, K):
+def gemm_act_supported(M, N, K, lda=0, ldw=0):
     """Shapes that have the training step's activation epilogues (EPI_BIAS_KEEP_GELU: `residual` is the second OUTPUT, gelu of the kept pre-activation;
     EPI_BIAS_MUL_GELU_GRAD: `residual` is the kept pre-activation): the 4-wave GEMM kernel's.  Elsewhere: gemm(EPI_BIAS) + tg_act."""
-    return M >= 1024 and N % 256 == 0 and K % 64 == 0 and K >= 256 and os.environ.get("TG_GEMM_W4", "1") != "0"
+    return (M >= 1024 and N % 256 == 0 and K % 64 == 0 and K >= 256 and max(lda, ldw, K) < (1 << 21)      # csrc/gemm.hip: 32-bit buffer offsets in the 4-wave kernel
+            and L.debug_get("TG_GEMM_W4") != 0)                                                            # the knob the library dispatches on, not the environment
 
 
 def gemm_pair(a1, w1, bias1, out1, a2, w2, bias2, out2, epilogue=L.EPI_BIAS):
@@ -136,8 +137,7 @@ def gemm_pair(a1, w1, bias1, out1, a2, w2, bias2, out2, epilogue=L.EPI_BIAS):
 
 def gemm_qkv_supported(M, N, K, v_col0):
     """Shapes the fused QKV + V^T launch (tg_gemm_bf16_qkv) takes; TG_GEMM_W4=0 (the cross-check tests' switch to the 8-wave GEMM) disables it too."""
-    import os
-    return M >= 1024 and N % 256 == 0 and K % 64 == 0 and K >= 256 and v_col0 % 256 == 0 and os.environ.get("TG_GEMM_W4", "1") != "0"
+    return M >= 1024 and N % 256 == 0 and K % 64 == 0 and K >= 256 and v_col0 % 256 == 0 and L.debug_get("TG_GEMM_W4") != 0
 
 
 def gemm_qkv(a1, w1, bias1, out1, vt1, a2=None, w2=None, bias2=None, out2=None, vt2=None, v_col0=None):

@@ -147,6 +147,14 @@ def debug_set(knob, value):
     return old.value
 
 
+def debug_get(knob):
+    """tg_debug_get: the value a dispatch knob has NOW (default, environment at load time, or a later debug_set) — what the library itself will dispatch on."""
+    lib = load()
+    v = C.c_long(0)
+    check(lib.tg_debug_get(knob.encode(), C.byref(v)), f"tg_debug_get({knob})")
+    return v.value
+
+
 def check(code, what):
     if code != 0:
         raise RuntimeError(f"{what} failed ({code}): {load().tg_last_error_string().decode()}")

@@ -120,16 +120,22 @@ class MPFIFOVideoIPAdapterCogVideoXPipeline:
         def encode(video_bfchw):
             video = video_bfchw.to(dev, BF16).permute(0, 2, 1, 3, 4)
             video = torch.cat([video] + [video[:, :, [-1]]] * nf_per_chunk, dim=2)                      # :581 pad one chunk
-            lat = []
-            for c in range(video.shape[2] // nf_per_chunk):
+            n_chunks = video.shape[2] // nf_per_chunk
+            b, _, _, Hs, Ws = video.shape
+            sf = self.vae_scale_factor_spatial
+            zshape = (b, self.vae.config.latent_channels, compressed_nf_per_chunk, Hs // sf, Ws // sf)
+            # The chunks are independent (the reference runs them one after the other on GPU 0, :585-609): chunk c goes to rank c % world, ONE all_gather brings
+            # every chunk's tokens to every rank (cfg_parallel.map_chunks_sharded).  The posterior noise of ALL chunks is drawn here, in chunk order, on every rank —
+            # the draw `latent_dist.sample(generator)` would make — so the generator ends in the same state and the tokens are bitwise the one-rank run's.
+            noises = [torch.randn(zshape, generator=generator, device=dev, dtype=torch.float32).to(BF16) if sample_posterior else None for _ in range(n_chunks)]
+
+            def one(c):
                 post = self.vae.encode(video[:, :, c * nf_per_chunk:(c + 1) * nf_per_chunk].contiguous()).latent_dist
-                z = post.sample(generator=generator) if sample_posterior else post.mode()
-                lat.append((z.float() * self.vae.config.scaling_factor).to(BF16))
-            lat = torch.cat(lat, dim=2).permute(0, 2, 1, 3, 4).contiguous()                             # b f c h w
-            tokens = self.transformer.patch_embed_proj(lat)                                              # b f (h w) D
-            out = [self._resampler(tokens[:, c * compressed_nf_per_chunk:(c + 1) * compressed_nf_per_chunk].contiguous(), image_rotary_emb=img,
-                                   sampling_rotary_emb=smp) for c in range(tokens.shape[1] // compressed_nf_per_chunk)]
-            return torch.cat(out, dim=1)
+                z = (post.mean + post.std * noises[c]) if sample_posterior else post.mode()
+                lat = (z.float() * self.vae.config.scaling_factor).to(BF16).permute(0, 2, 1, 3, 4).contiguous()     # b f c h w, one chunk
+                tokens = self.transformer.patch_embed_proj(lat)                                          # b f (h w) D
+                return self._resampler(tokens.contiguous(), image_rotary_emb=img, sampling_rotary_emb=smp).contiguous()
+            return torch.cat(CP.map_chunks_sharded(n_chunks, one, device=dev), dim=1)
         emb = encode(frames)
         if not do_classifier_free_guidance:
             return emb

@@ -90,25 +90,31 @@ def transpose_2d(src, rows_pad=None):
 
 
 def colsum_multi(mats):
-    """Column sums of several [R_i, C_i] matrices (bf16 or fp32) with two launches in all: tg_colsum_multi (every matrix cut into the same number of row blocks)
-    + one fixed-order sum of the joint partial matrix.  Returns the list of fp32 [C_i] sums."""
+    """Column sums of several [R_i, C_i] matrices (bf16 or fp32): per group of at most TG_COLSUM_MAX matrices one tg_colsum_multi launch (every matrix cut into the
+    same number of row blocks) + one fixed-order sum of the joint partial matrix.  Returns the list of fp32 [C_i] sums.  Any count of matrices (a per-rank batch
+    above 4 hands over 2 + 3 B > 16 of them): the groups are cut in order, and a matrix's sum does not depend on which group it fell into (its row blocks depend on
+    the group's tallest matrix only through `nb`, which is computed over ALL matrices)."""
     lib = L.load()
-    assert 0 < len(mats) <= L.TG_COLSUM_MAX
-    items = (L.ColsumItem * len(mats))()
+    assert len(mats) > 0
     rmax = 0
-    for i, m in enumerate(mats):
-        assert m.dim() == 2 and m.stride(1) == 1 and m.dtype in (BF16, torch.float32)
-        items[i].src, items[i].ld, items[i].rows, items[i].cols, items[i].src_is_f32 = m.data_ptr(), m.stride(0), m.shape[0], m.shape[1], 1 if m.dtype == torch.float32 else 0
-        rmax = max(rmax, m.shape[0])
-    total = sum(m.shape[1] for m in mats)
-    nb = max(1, min(256, rmax // 8))                     # >= 8 rows per block of the tallest item; a function of the shapes only (fixed summation order)
-    part = torch.empty(nb, total, dtype=torch.float32, device=mats[0].device)
-    L.check(lib.tg_colsum_multi(items, len(mats), nb, part.data_ptr(), K._stream()), "tg_colsum_multi")
-    sums = part.sum(dim=0)
-    out, c0 = [], 0
     for m in mats:
-        out.append(sums[c0:c0 + m.shape[1]])
-        c0 += m.shape[1]
+        assert m.dim() == 2 and m.stride(1) == 1 and m.dtype in (BF16, torch.float32)
+        rmax = max(rmax, m.shape[0])
+    nb = max(1, min(256, rmax // 8))                     # >= 8 rows per block of the tallest item; a function of the shapes only (fixed summation order)
+    out = []
+    for g0 in range(0, len(mats), L.TG_COLSUM_MAX):
+        grp = mats[g0:g0 + L.TG_COLSUM_MAX]
+        items = (L.ColsumItem * len(grp))()
+        for i, m in enumerate(grp):
+            items[i].src, items[i].ld, items[i].rows, items[i].cols, items[i].src_is_f32 = m.data_ptr(), m.stride(0), m.shape[0], m.shape[1], 1 if m.dtype == torch.float32 else 0
+        total = sum(m.shape[1] for m in grp)
+        part = torch.empty(nb, total, dtype=torch.float32, device=grp[0].device)
+        L.check(lib.tg_colsum_multi(items, len(grp), nb, part.data_ptr(), K._stream()), "tg_colsum_multi")
+        sums = part.sum(dim=0)
+        c0 = 0
+        for m in grp:
+            out.append(sums[c0:c0 + m.shape[1]])
+            c0 += m.shape[1]
     return out
 
 
@@ -155,12 +161,17 @@ def _weight_t(weight, frozen):
     and micro-step again and again; 8.6 GB kept for the 42 blocks at the 5B shapes)."""
     cout, cin = weight.shape
     cin_p, cout_p = _pad_to(cin, 128), _pad_to(cout, 64)
-    if frozen is not None and frozen[1] in frozen[0]:
-        return frozen[0][frozen[1]]
+    # a kept transpose is valid for ONE weight storage at ONE version: a frozen entry that was replaced or written to in place since (a re-loaded
+    # checkpoint) is transposed again instead of silently feeding the dgrad a stale matrix
+    stamp = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.stride(0))
+    if frozen is not None:
+        hit = frozen[0].get(frozen[1])
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
     wT = (torch.zeros if (cin_p != cin or cout_p != cout) else torch.empty)(cin_p, cout_p, dtype=BF16, device=weight.device)
     L.check(L.load().tg_transpose_2d(weight.data_ptr(), weight.stride(0), cout, cin, wT.data_ptr(), cout_p, cout_p, K._stream()), "tg_transpose_2d")
     if frozen is not None:
-        frozen[0][frozen[1]] = wT
+        frozen[0][frozen[1]] = (stamp, wT)
     return wT
 
 
@@ -569,7 +580,10 @@ class To2VTrainer:
             return int(self.activation_budget_bytes)
         free, _ = torch.cuda.mem_get_info()
         free += torch.cuda.memory_reserved() - torch.cuda.memory_allocated()      # cached blocks of the allocator are reusable
-        return max(0, free - self.activation_reserve_bytes)
+        # the kept transposes of the frozen weights (_weight_t: to_out, QKV, FF1, FF2 = 12 D^2 bf16 per block) are allocated in the FIRST backward, after this
+        # budget has been handed to kept activations: what is not there yet comes off the budget now, not out of the reserve
+        pending = sum(24 * self.D * self.D for blk in (self._blocks or []) if len(blk._wt) < 4)
+        return max(0, free - self.activation_reserve_bytes - pending)
 
     def save_vip_layers(self, vip_ckpt_dir):
         """The reference's save hook for the transformer's trained part (cogvideox_transformer_3d.py:624-634 via train_cogvideo_to2v.py:1346-1390):
