@@ -472,7 +472,10 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         };
         // X(t): the 8 fragment groups {V^T(t-1) ks=0..3, K(t) kd=0..3} software-pipelined one group ahead, so the
         // ds_read_b128 latency of group g+1 runs under the 4 MFMAs (128 cycles) of group g instead of after them
-        auto xseg = [&](int t, auto guardc) {
+        auto xseg = [&](int t, auto guardc, auto seedc) {
+            // SEED false (round 6): every row of this WAVE has the constant shift c_row = 0 (B_row <= 64: LayerNorm gains around 1, the shipped weights) — the four seed
+            // MFMAs of a tile would write zeros.  The first K k-step then takes the inline constant 0 as its C operand and the tile runs 32 MFMAs instead of 36.
+            constexpr bool SEED = decltype(seedc)::value;
             const char* tV = smem + (2 + ((t - 1) & 1)) * TILE_B;
             const char* tK = smem + (t & 1) * TILE_B;
             // fragment i = 2g + xb (g: k-step group, xb: 32-row block of V^T / K); NFR 4-register buffers, fragment i+NFR is
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
 #pragma unroll
             for (int i = 0; i < NFR; ++i) ld(i);
             const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (PRESCALED) {
+            if (PRESCALED && SEED) {
                 // seed S with -m through the matrix pipe: ones[key][k=0] x negm[k=0][query] = -m[query] in every register of
                 // the lane's row, 4 MFMAs that run under the first fragments' ds_read latency (no 64 v_mov per tile)
 #pragma unroll
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
                     if (g < 4) acc_o[qb][xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % NFR], pf[qb][g], acc_o[qb][xb], 0, 0, 0);
-                    else sc[qb][xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % NFR], qf[qb][g - 4], sc[qb][xb], 0, 0, 0);
+                    else sc[qb][xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % NFR], qf[qb][g - 4], (PRESCALED && !SEED && g == 4) ? z : sc[qb][xb], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (i + NFR < 16) ld(i + NFR);
@@ -641,14 +644,14 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
         // tests (te twice per DMA issue, nk once per tile) were five of the eleven s_cbranch per tile and wave; without them the launch is 1.0-1.6 % faster (same box,
         // three interleaved rounds).  Specialising the body on the wave group as well (no grp tests left, one back-branch per tile) measured 4-5 % SLOWER: the two
         // groups then run different copies of the loop.
-        auto tile = [&](auto guardc, int t) {
+        auto tile = [&](auto guardc, auto seedc, int t) {
             constexpr bool GUARD = decltype(guardc)::value;
             // X(t): matrix segment
             if (grp == 0) { if constexpr (GUARD) dma_pair(t); else dma_pair_all(t); }
             // the matrix segment runs at raised priority: its MFMA / ds_read issue slots are few (one per ~32 cycles) but each one the
             // partner's VALU stream delays idles the matrix pipe; measured -4..6 % (7.52 vs 7.94 ms same box); prio 1: -2 %, prio 3 = 2
             __builtin_amdgcn_s_setprio(2);
-            xseg(t, guardc);
+            xseg(t, guardc, seedc);
             __builtin_amdgcn_s_setprio(0);                         // (fencing this with sched_barrier(0) measured 2.5 % slower)
             if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t (issued one segment ago) has landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -659,10 +662,20 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnParams p) {
             if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pair t has landed
             PP_BAR();
         };
-        {
+        // Two copies of the tile loop for the constant-shift kernel, chosen per WAVE (wave-uniform; the barrier structure of the copies is identical, so waves of one
+        // workgroup may differ): without the seed MFMAs when every row of the wave has c_row = 0 — with the shipped weights that is every wave of every launch, so
+        // the instruction cache sees one copy — and with them otherwise.  (Two copies run by the two wave groups of a workgroup at the same time measured 4-5 % slower,
+        // see above: that is not this case.)
+        auto run = [&](auto seedc) {
             int t = tb;
-            for (; t < te - 2; ++t) tile(std::false_type{}, t);
-            for (; t < te; ++t) tile(std::true_type{}, t);
+            for (; t < te - 2; ++t) tile(std::false_type{}, seedc, t);
+            for (; t < te; ++t) tile(std::true_type{}, seedc, t);
+        };
+        if constexpr (FIXEDM == 1 && PRESCALED) {
+            if (!__any(cshift[0] != 0.f || cshift[1] != 0.f)) run(std::false_type{});
+            else run(std::true_type{});
+        } else {
+            run(std::true_type{});
         }
         pv(te - 1);                                                                // X(nt): last P.V
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

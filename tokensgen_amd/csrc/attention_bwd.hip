@@ -700,8 +700,8 @@ __device__ __forceinline__ void cnt_write(int* c, int v) { asm volatile("global_
 // groups' partials meet in LDS ([group][slot][32 q][64 d] fp32) and are added by the exchange: group g owns rows 16 g .. 16 g + 15 of every tile and is its own
 // chain (counter word g of the tile's line): key block kb's group g adds to what key block kb - 1's group g left — in key-block order, bitwise reproducible,
 // no atomics on the data; coherence through the XCD's L2 exactly as in the in-phase form (plain stores, one buffer_inv sc1 per workgroup, sc1 polls).
-//   tile T: dS^T in Y(T) -> partial in X(T+2) -> [group 1: exchanged in Y(T+2); group 0: in Y(T+3)] -> acknowledged at the top of the next Y -> signalled
-//   at the head of the X after that.  The loop runs PP_EXTRA masked tiles past the last one (P = dS = 0 exactly: they add nothing to dK / dV) instead of a drain.
+//   tile T: dS^T in Y(T) -> partial in X(T+2) -> [group 1: exchanged in Y(T+2); group 0: in Y(T+3)] -> acknowledged at the END of that same Y (round 6; round 5:
+//   at the top of the next Y) -> signalled at the head of the next X.  The loop runs PP_EXTRA masked tiles past the last one (P = dS = 0 exactly: they add nothing to dK / dV) instead of a drain.
 // scale * log2(e) == 1 (the training step hands over its main call's K prescaled by scale * log2 e, and scale = ln 2): P = exp2 of the accumulator, no multiply — a
 // workgroup-uniform choice between two copies of the softmax (the main call and a rider may differ).  Measured and dropped: folding the factor into the resident K
 // fragments for every caller (bf16(k * scale_log2): no multiply anywhere) — the forward had used the unrounded K, and the gradient error of such calls doubled (dV 2.3e-3 -> 4.9e-3).
@@ -965,11 +965,13 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) 
     auto body = [&](auto fast_c, const int it) {
         constexpr bool FAST = decltype(fast_c)::value;
         // ---------------- X(it): matrix segment ----------------
-        {   // signal: the stores of tile it - 2 - lag went out in Y(it - 2), every wave of the group has seen them acknowledged at the top of its Y(it - 1), and
-            // the barrier that closed Y(it - 1) lies behind us
-            const int ts = it - 2 - lag;
+        {   // signal: the stores of tile it - 1 - lag went out in Y(it - 1), every wave of the group waited for their acknowledgement at the END of that same Y (the
+            // vmcnt wait in front of its closing barrier), and that barrier lies behind us.  Round 5 signalled a tile later (acknowledged at the top of the NEXT Y):
+            // bitwise the same gradients, the same 22.7 ms for the 17776^2 call, but the follower key block then re-read a dQ line one tile time later — and 26.3 GB
+            // instead of 13.8 GB of the launch's 30.6 GB of dQ stores had left the XCD's L2 by then (profiles/NOTES.md F / G; r5 -> r6_attention_bwd_pmc.json)
+            const int ts = it - 1 - lag;
             if ((tid & 255) == 0 && (FAST || (ts >= 0 && ts < ntile)))
-                asm volatile("global_store_dword %0, %1, %2 offset:%3" :: "v"(0u), "v"(blk + 1), "s"(pcnt), "i"(-2 * CNT_PAD * 4) : "memory");
+                asm volatile("global_store_dword %0, %1, %2 offset:%3" :: "v"(0u), "v"(blk + 1), "s"(pcnt), "i"(-1 * CNT_PAD * 4) : "memory");
         }
         __builtin_amdgcn_s_setprio(2);
         xseg(cb, pb, it & 1);
@@ -1061,6 +1063,9 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) 
         cb = (cb + 1) & (RING - 1);
         TG_SB();
         xprefetch((it + 1) & 1);
+        // the dQ stores of this Y acknowledged before the barrier, so that the head of the next X may signal them (the one load still in flight in the steady
+        // state is the counter sample issued after them; loads and stores retire in order)
+        if (FAST && !first) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         BWD_BAR();
     };
     // FAST iterations: the signalled tile it - 5 (group 0) exists, and the fetched tile it + 4 (group 1) still lies wholly inside the query range
@@ -1076,7 +1081,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) 
                  : "+v"(fr[0][0].v), "+v"(fr[0][1].v), "+v"(fr[1][0].v), "+v"(fr[1][1].v), "+v"(fr[2][0].v), "+v"(fr[2][1].v), "+v"(g0), "+v"(gseed), "+v"(ldv), "+v"(cval)
                  :: "memory");
     if (grp == 0) BWD_BAR();                                // pairs with group 1's extra barrier
-    // the last tiles' stores: acknowledged (vmcnt, above), seen by the whole group (barrier), then signalled
+    // the last tiles' stores: acknowledged (vmcnt, above), seen by the whole group (barrier), then signalled (tile nit - 2 - lag was signalled by the last X already:
+    // writing the same value again is harmless)
     __syncthreads();
     if ((tid & 255) == 0)
         for (int ts = max(nit - 2 - lag, 0); ts < ntile; ++ts) cnt_write(cntw + (long)ts * CNT_PAD, blk + 1);
