@@ -384,6 +384,7 @@ def vae_record(device, reps=3):
         out[name] = {"seconds": best, "algorithmic_TFLOPs": VAE_FLOP[name] / best / 1e12, "executed_TFLOPs": 1.4 * VAE_FLOP[name] / best / 1e12,
                      "frac_of_peak_algorithmic": VAE_FLOP[name] / best / PEAK_BF16, "frac_of_peak_executed": 1.4 * VAE_FLOP[name] / best / PEAK_BF16,
                      "out_shape": list(y.shape), "finite": bool(torch.isfinite(y).all()), "power_W_mean": pw["power_W_mean"], "sclk_MHz_mean": pw["sclk_MHz_mean"],
+                     "sclk_MHz_min": pw["sclk_MHz_min"], "sclk_MHz_max": pw["sclk_MHz_max"], "limiter": pw["limiter"],
                      "frac_of_peak_executed_at_measured_clock": (1.4 * VAE_FLOP[name] / best / (PEAK_BF16 * pw["sclk_MHz_mean"] / 2400.0)) if pw["sclk_MHz_mean"] else None}
     del vae
     torch.cuda.empty_cache()
@@ -676,7 +677,7 @@ def train_measure(a, rank, world, device, dist, ckpt_leg_steps=0):
             "attention_bwd_form": "one kernel (dK, dV, dQ; ordered dQ exchange, status word checked every micro-step)" if K.BwdDeviceState.get(device).one_kernel
                                   else "two launches (dK/dV + dQ)",
             "attention_bwd_probe": K.BwdDeviceState.get(device).probe,
-            "power_W_mean": power["power_W_mean"], "power_cap_W": power["power_cap_W"], "sclk_MHz_mean": power["sclk_MHz_mean"],
+            "power_W_mean": power["power_W_mean"], "power_cap_W": power["power_cap_W"], "sclk_MHz_mean": power["sclk_MHz_mean"], "limiter": power["limiter"],
             "peak_mem_GB": peak_kept})
     return None
 
@@ -717,7 +718,8 @@ def compact_line(out):
     line["rank_ms_per_step"] = out.get("rank_ms_per_step")
     if vae:
         line["vae"] = {n: {"seconds": _r(vae[n]["seconds"]), "frac_algorithmic": _r(vae[n]["frac_of_peak_algorithmic"]), "frac_executed": _r(vae[n]["frac_of_peak_executed"]),
-                           "W_mean": _r(vae[n]["power_W_mean"], 1), "sclk_MHz_mean": _r(vae[n]["sclk_MHz_mean"], 1)} for n in ("decode", "encode")}
+                           "W_mean": _r(vae[n]["power_W_mean"], 1), "sclk_MHz_mean": _r(vae[n]["sclk_MHz_mean"], 1),
+                           "ppt_active_frac": g(vae[n], "limiter", "active_frac", "ppt")} for n in ("decode", "encode")}
     if tr:
         line["train"] = {"value": _r(tr["value"]), "unit": tr["unit"], "steps": tr["steps"], "ms_per_step": _r(tr["ms_per_step"], 2), "step_mfma_frac": _r(tr["step_mfma_frac"]),
                          "flop_per_micro_step": tr["flop_per_micro_step"], "optimizer_steps_in_timed_region": g(tr, "config", "optimizer_steps_in_timed_region"),

@@ -35,14 +35,14 @@ def fifo_iterations(chunks, nf=13, T=52, num_partitions=4):
     return out
 
 
-def project(chunks, meas, n, with_t2to, b1_ratio, t_xchg=1.0e-3, t_cfg_xchg=0.5e-3):
+def project(chunks, meas, n, with_t2to, b1_ratio, b1_ratio_t2to=None, t_xchg=1.0e-3, t_cfg_xchg=0.5e-3):
     per_iter = fifo_iterations(chunks)
     fwd1 = sum(per_iter)
     fwdn = sum(math.ceil(w / n) for w in per_iter)
     steps = 52
     cfg_par = n >= 2                                       # cfg_parallel.resolve("auto"): ranks r % 2 take one CFG half each
-    stage = lambda t1: t1 * b1_ratio + steps * t_cfg_xchg if cfg_par else t1
-    t = {"t2to": stage(meas["t2to_s"]) if with_t2to else 0.0, "base": stage(meas["base_s"]),
+    stage = lambda t1, r: t1 * r + steps * t_cfg_xchg if cfg_par else t1
+    t = {"t2to": stage(meas["t2to_s"], b1_ratio_t2to or b1_ratio) if with_t2to else 0.0, "base": stage(meas["base_s"], b1_ratio),
          "fifo": fwdn * meas["window_s"] + (len(per_iter) * t_xchg if n > 1 else 0.0),
          # decode_chunks_sharded twice: the video's `chunks` clips dealt round-robin + the base clip (one rank)
          "decode": (math.ceil(chunks / n) + 1) * meas["decode_clip_s"]}
@@ -61,11 +61,11 @@ def main():
         vae_s = P("r6_bench_detail.json")["vae"]["decode"]["seconds"]; vae_src = "r6_bench_detail.json"
     except (OSError, KeyError, TypeError):
         vae_s = P("r5_bench.json")["vae"]["decode"]["seconds"]; vae_src = "r5_bench.json"
-    b1, b1_src = a.b1_ratio, "--b1-ratio"
+    b1, b1_src, b1t = a.b1_ratio, "--b1-ratio", None
     if b1 is None:
         try:
             r = P("r6_b1_forward.json")
-            b1, b1_src = r["to2v"]["b1_over_b2"], "profiles/r6_b1_forward.json (measured)"
+            b1, b1t, b1_src = r["to2v"]["b1_over_b2"], r["t2to"]["b1_over_b2"], "profiles/r6_b1_forward.json (measured: To2V window shape and T2To shape, tools/bench_b1.py)"
         except (OSError, KeyError):
             b1, b1_src = 0.5, "ASSUMED 0.5 (MFMA-bound forward: half the batch, half the time) — unmeasured"
     runs = {}
@@ -75,7 +75,7 @@ def main():
         meas = {"t2to_s": (rec["seconds"].get("t2to_stage") or 0.0), "base_s": rec["seconds"]["base_stage"], "decode_clip_s": vae_s,
                 "window_s": (rec["seconds"]["fifo_and_decode"] - clips * vae_s) / n_fwd, "fifo_and_decode_s": rec["seconds"]["fifo_and_decode"], "window_forwards": n_fwd}
         assert n_fwd == rec["steps"] - 52, (n_fwd, rec["steps"])        # the walked schedule IS the measured run's
-        rows = [project(chunks, meas, n, with_t2to, b1) for n in (1, 2, 4, 8)]
+        rows = [project(chunks, meas, n, with_t2to, b1, b1t) for n in (1, 2, 4, 8)]
         t1, f1 = rows[0]["seconds"]["total"], rows[0]["seconds"]["fifo"]
         for r in rows:
             n = r["n_gpus"]
@@ -86,7 +86,7 @@ def main():
         runs[name] = {"measured_one_gpu": {k: round(v, 4) for k, v in meas.items()}, "projection": rows}
     out = {"what": "PROJECTION, not a measurement: product window schedule x one-GPU phase seconds; no N > 1 hardware was available to the builder",
            "sources": {"phase_seconds": ["profiles/r5_gen_1gpu_24clips.json", "profiles/r5_e2e_1gpu_12clips.json"], "vae_decode_clip_s": vae_src, "b1_over_b2": b1_src},
-           "b1_over_b2": b1, "placeholders_s": {"fifo_all_gather_per_iteration": 1.0e-3, "cfg_all_gather_per_step": 0.5e-3},
+           "b1_over_b2": b1, "b1_over_b2_t2to": b1t, "placeholders_s": {"fifo_all_gather_per_iteration": 1.0e-3, "cfg_all_gather_per_step": 0.5e-3},
            "not_modelled": "T5 / checkpoint loading (out of scope), the weight broadcast (once per process, ~14 GB over xGMI), the condensed-token encode of edit.yaml "
                            "(chunks + 1 VAE encodes + Resampler calls, sharded round-robin over all ranks since round 6: ceil(13 / N) x ~0.27 s)",
            "runs": runs}
