@@ -481,6 +481,25 @@ int tg_conv3d_cl(const void* x, int T, int H, int W, int Cin, const void* cache,
                  float* splitk_ws, hipStream_t stream);
 long tg_conv3d_splitk_floats(int Cin, int cout, int cout_pad, int kt, int kh, int kw, int To, int Ho, int Wo);
 long tg_conv3d_gn_partial_floats(int To, int Ho, int Wo);
+
+/* CogVideoXUpsample3D's spatial part — F.interpolate(scale 2, nearest) followed by Conv2d 3x3, padding 1 (diffusers CogVideoXUpsample3D; call site
+ * autoencoder_kl_cogvideox.py:849-883, the decoder's up blocks) — as FOUR 2x2 convolutions on the LOW-resolution input, one per output phase (py, px):
+ *   y[t][2 yl + py][2 xl + px][n] = bias[n] + sum_{a,b in {0,1}} sum_c w_phases[py*2+px][n][a*2+b][c] * x[t][yl + a - (1 - py)][xl + b - (1 - px)][c]   (zero outside the image)
+ * Of the three upsampled rows a 3x3 tap row reads, two are the same low-resolution row, so their weights can be added beforehand:
+ *   py = 0: a = 0 <- dy 0, a = 1 <- dy 1 + dy 2;   py = 1: a = 0 <- dy 0 + dy 1, a = 1 <- dy 2        (columns likewise)
+ * 4 taps instead of 9: 44 % of the multiply-adds of tg_conv3d_cl(up = 2) for the same output.  DEVIATION from the reference's arithmetic, stated: the pre-summed weights
+ * are rounded to bf16 once (the caller sums in fp32 and rounds), where the reference adds the two or four bf16 products in fp32 — one more bf16 rounding on three layers of
+ * the decoder, of the size of the activation roundings between its layers (tests hold it against fp32 torch and against tg_conv3d_cl(up = 2)).
+ * time_x2 = 1: the layer also doubles TIME by nearest neighbour (`compress_time`: T frames -> 2T, or 2T - 1 when T is odd > 1 — the first frame is not repeated): the convolution is
+ * 2-D per frame, so duplicate input frames give duplicate output frames — each low-resolution frame is convolved ONCE and stored twice (exact), and counted twice in the sums.
+ * x [T][H][W][Cin] channels-last bf16; w_phases [4][cout][4][Cin] bf16; y [To][2H][2W] voxels with row stride ldy (To = T, or 2T / 2T - 1 with time_x2); gn_partial (optional):
+ * tg_conv3d_up2_subpixel_gn_floats(T, H, W) floats, rows of [2][32] sums as for tg_conv3d_cl (4 x ceil(T H W / 128) rows: each phase owns its rows).
+ * Runs on the 256 x 256 convolution kernel: tg_conv3d_up2_subpixel_ok(...) == 1 says the shape qualifies (cout % 256 == 0, Cin % 64 == 0, enough tiles); else TG_ERR_SHAPE and
+ * the caller keeps tg_conv3d_cl(up = 2).  zeros as for tg_conv3d_cl. */
+long tg_conv3d_up2_subpixel_ok(int T, int H, int W, int Cin, int cout);
+long tg_conv3d_up2_subpixel_gn_floats(int T, int H, int W);
+int tg_conv3d_up2_subpixel(const void* x, int T, int H, int W, int Cin, const void* w_phases, const void* bias, int cout, void* y, long ldy,
+                           int time_x2, const void* zeros, float* gn_partial, hipStream_t stream);
 int tg_groupnorm_finalize(const float* partial, long V, int C, float eps, float* stats, hipStream_t stream);
 
 /* GroupNorm(32 groups, eps) statistics of x[V][C] -> stats[32][2] = {mean, rstd} (fp32).  partial: fp32 workspace of

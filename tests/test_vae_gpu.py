@@ -88,6 +88,55 @@ def test_upsample_and_downsample_convs():
         assert _rel(_ncdhw(y), ref) < 5e-3, (T, compress)
 
 
+@pytest.mark.parametrize("ci,co,T,H,W", [(256, 256, 4, 40, 56), (256, 256, 3, 45, 61), (64, 512, 5, 33, 47)])
+def test_upsample_conv_as_four_phase_convolutions(ci, co, T, H, W, parity):
+    """tg_conv3d_up2_subpixel (nearest x2 + Conv2d 3x3 as four 2x2 convolutions on the low-resolution input, pre-summed weights) against the oracle's
+    upsample3d in fp32 on the same bf16 weights, against the 9-tap kernel on the upsampled grid (tg_conv3d_cl up = 2), and its fused GroupNorm sums against the statistics
+    of what it stored.  Odd sizes: ragged last tiles of every phase, all four image borders."""
+    from tokensgen_amd import kernels as K
+    from tokensgen_amd.vae import pack_up2_phases
+    assert K.conv3d_up2_subpixel_ok(T, H, W, ci, co)
+    w, b = _r(co, ci, 3, 3, seed=31, scale=0.03), _r(co, seed=32)
+    sd = {"u.conv.weight": w.float(), "u.conv.bias": b.float()}
+    x = _r(1, ci, T, H, W, seed=33)
+    ref = V.upsample3d(sd, "u", x.float(), False)                                # [1, co, T, 2H, 2W] fp32
+    xd = _cl(x).to(DEV)
+    y9 = K.conv3d_cl(xd, _pack(w).to(DEV), b.to(DEV), co, 1, 3, 3, up=2, out_dims=(T, 2 * H, 2 * W))
+    y4 = K.conv3d_up2_subpixel(xd, pack_up2_phases(w.to(DEV)), b.to(DEV), co, gn_stats_eps=1e-6)
+    assert y4.shape == y9.shape == (T, 2 * H, 2 * W, co)
+    e9 = parity(_rel(_ncdhw(y9), ref), 5e-3, "9-tap kernel on the upsampled grid vs fp32 oracle (the existing path)")
+    e4 = parity(_rel(_ncdhw(y4), ref), 5e-3, "four 2x2 phase convolutions vs fp32 oracle")
+    assert e4 < 1.5 * e9 + 1e-4                                                   # the pre-summed weights cost no more than the activations' own bf16 rounding
+    parity(_rel(y4, y9), 5e-3, "phase convolutions vs the 9-tap kernel")
+    ref_cl = ref[0].permute(1, 2, 3, 0)                                           # [T, 2H, 2W, co]
+    for sl in ((slice(None), 0), (slice(None), 2 * H - 1), (slice(None), slice(None), 0), (slice(None), slice(None), 2 * W - 1)):      # the zero padding on all four borders
+        assert _rel(y4[sl], ref_cl[sl]) < 8e-3
+    # the fused GroupNorm sums (one row list per phase launch; the norm passes add all rows): against the statistics of the stored values
+    rows = y4.gn_sums.partial.view(-1, 64).double().sum(0).cpu()
+    assert y4.gn_sums.partial.numel() // 64 == 4 * ((T * H * W + 127) // 128)
+    g = y4.double().cpu().reshape(-1, 32, co // 32).permute(1, 0, 2).reshape(32, -1)
+    n = g.shape[1]
+    assert ((rows[:32] / n - g.mean(1)).abs().max().item()) < 1e-5
+    assert ((rows[32:] / n - (g * g).mean(1)).abs() / (g * g).mean(1)).max().item() < 1e-5
+    # ... and through the consumer: the norm pass on these sums == the norm pass on statistics computed from y itself
+    gam, bet = _r(co, seed=34).to(DEV), _r(co, seed=35).to(DEV)
+    n1 = K.groupnorm_silu(y4, y4.gn_sums, gam, bet, True)
+    n2 = K.groupnorm_silu(y4, K.groupnorm_stats(y4.view(-1, co), 1e-6), gam, bet, True)
+    assert _rel(n1, n2) < 2e-3
+    y4b = K.conv3d_up2_subpixel(xd, pack_up2_phases(w.to(DEV)), b.to(DEV), co, gn_stats_eps=1e-6)
+    assert torch.equal(y4, y4b) and torch.equal(y4.gn_sums.partial, y4b.gn_sums.partial)
+    # the time-doubling form (compress_time): every frame convolved once, stored twice (the first of an odd count once); sums count the copies
+    idx = [0] + [t for t in range(1, T) for _ in (0, 1)] if T % 2 else [t for t in range(T) for _ in (0, 1)]
+    yt = K.conv3d_up2_subpixel(xd, pack_up2_phases(w.to(DEV)), b.to(DEV), co, gn_stats_eps=1e-6, time_x2=True)
+    assert yt.shape[0] == len(idx) and torch.equal(yt, y4[torch.tensor(idx, device=DEV)])
+    reft = V.upsample3d(sd, "u", x.float(), True)
+    assert reft.shape[2] == len(idx) and _rel(_ncdhw(yt), reft) < 5e-3
+    rows_t = yt.gn_sums.partial.view(-1, 64).double().sum(0).cpu()
+    gt = yt.double().cpu().reshape(-1, 32, co // 32).permute(1, 0, 2).reshape(32, -1)
+    assert ((rows_t[:32] / gt.shape[1] - gt.mean(1)).abs().max().item()) < 1e-5
+    assert ((rows_t[32:] / gt.shape[1] - (gt * gt).mean(1)).abs() / (gt * gt).mean(1)).max().item() < 1e-5
+
+
 @pytest.mark.parametrize("C", [64, 128, 512])
 def test_groupnorm_and_spatialnorm_silu(C):
     from tokensgen_amd import kernels as K

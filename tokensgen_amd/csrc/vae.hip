@@ -42,6 +42,11 @@ struct ConvParams {
     float* gn_partial;    // optional [tiles_m][2][32]: per-tile GroupNorm(32) sums / sums of squares of the STORED bf16 values
     int ksplit;           // > 1: the (tap, channel) reduction is cut into ksplit ranges, one workgroup each; raw fp32 sums go to kpart
     float* kpart;         // [ksplit][M][cout_pad] fp32 (conv_splitk_reduce_kernel adds them in a fixed order and runs the epilogue)
+    // ---- phase launches of tg_conv3d_up2_subpixel (conv3d_w4_kernel only; all zero = an ordinary convolution) ----
+    int pad_w_off;        // the W axis pads with pad + pad_w_off (the H axis with pad): the 2x2 phase kernels pad on one side only
+    int o_up;             // 2: output voxel (to, ho, wo) of this launch is stored at (to, 2 ho + o_py, 2 wo + o_px) of a [To][2 Ho][2 Wo] tensor
+    int o_py, o_px;
+    int o_tdup;           // with o_up == 2: 0 = frame t -> frame t; 1 = the nearest x2 of an ODD frame count (frame 0 -> 0; t >= 1 -> 2t - 1 and 2t); 2 = of an even one (t -> 2t, 2t + 1)
 };
 
 // WN x (4 / WN) waves; a wave owns FM x FN MFMA 16x16 blocks: <2, 4, 4> = the 128 x 128 tile, <1, 2, 1> = 128 voxels x 16 output channels
@@ -1008,7 +1013,7 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
         int mk = 0;
         for (int dh = 0; dh < p.kh; ++dh)
             for (int dw = 0; dw < p.kw; ++dw)
-                if ((unsigned)(ho + dh - p.pad) < (unsigned)p.H && (unsigned)(wo + dw - p.pad) < (unsigned)p.W) mk |= 1 << (dh * 3 + dw);
+                if ((unsigned)(ho + dh - p.pad) < (unsigned)p.H && (unsigned)(wo + dw - p.pad - p.pad_w_off) < (unsigned)p.W) mk |= 1 << (dh * 3 + dw);
         vmask[i] = mk;
     }
     const int Hv = p.H * p.up, Wv = p.W * p.up;
@@ -1037,7 +1042,7 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
         if (plain) {
             // in-window frames: x + cen + doff.  Frames before the window (to + dt < kt-1): the cache tensor holds frames -(kt-1)..-1 at
             // indices 0.., i.e. cache + cen + doff + (kt-1)*frame; without a cache frame 0 is replicated: x + cen + doff - tv*frame
-            const int doff = ((dt - (p.kt - 1)) * p.H + (dh - p.pad)) * p.W * p.Cin + (dw - p.pad) * p.Cin;
+            const int doff = ((dt - (p.kt - 1)) * p.H + (dh - p.pad)) * p.W * p.Cin + (dw - p.pad - p.pad_w_off) * p.Cin;
             const int bit = 1 << (dh * 3 + dw), tneed = p.kt - 1 - dt;     // the tap reads frame to - tneed
             const bf16_t* early = p.cache ? p.cache + (long)(p.kt - 1) * frame : p.x;
 #pragma unroll
@@ -1194,6 +1199,19 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
         if constexpr (mb < 7) res_load(std::integral_constant<int, (mb < 7 ? mb + 1 : 7)>{});
         const long m = m0 + wm * 128 + mb * 16 + l15;
         if (m < M) {
+            long mo = m, mo2 = -1;                          // where the voxel is stored: itself, or its place(s) in the 2x upsampled tensor (phase launch)
+            float wgt = 1.f;                                // ... and how many output voxels it stands for in the GroupNorm sums
+            if (p.o_up == 2) {
+                const int wo_ = (int)(m % p.Wo);
+                const long q_ = m / p.Wo;
+                const int ho_ = (int)(q_ % p.Ho), to_ = (int)(q_ / p.Ho);
+                int t0 = to_, t1 = -1;                      // time-duplicated frames: a 2-D convolution per frame gives duplicate outputs for duplicate inputs
+                if (p.o_tdup == 1) { t0 = to_ == 0 ? 0 : 2 * to_ - 1; t1 = to_ == 0 ? -1 : 2 * to_; }
+                else if (p.o_tdup == 2) { t0 = 2 * to_; t1 = 2 * to_ + 1; }
+                const long inner = (long)(2 * ho_ + p.o_py) * (2L * p.Wo) + 2 * wo_ + p.o_px, fr = 4L * p.Ho * p.Wo;
+                mo = t0 * fr + inner;
+                if (t1 >= 0) { mo2 = t1 * fr + inner; wgt = 2.f; }
+            }
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb) {
                 const int n = n0 + wn * 128 + nb * 16 + ch * 4;
@@ -1209,11 +1227,12 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
                 uint2 o;
                 o.x = pack_bf16x2(v[0], v[1]);
                 o.y = pack_bf16x2(v[2], v[3]);
-                *(uint2*)(p.y + m * p.ldy + n) = o;
+                *(uint2*)(p.y + mo * p.ldy + n) = o;
+                if (mo2 >= 0) *(uint2*)(p.y + mo2 * p.ldy + n) = o;
                 if (p.gn_partial) {
                     const float r0 = bf16lo_to_f32(o.x), r1 = bf16hi_to_f32(o.x), r2 = bf16lo_to_f32(o.y), r3 = bf16hi_to_f32(o.y);
-                    gs[nb] += (r0 + r1) + (r2 + r3);
-                    gq[nb] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+                    gs[nb] += wgt * ((r0 + r1) + (r2 + r3));
+                    gq[nb] += wgt * ((r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3));
                 }
             }
         }
@@ -1827,6 +1846,43 @@ extern "C" int tg_groupnorm_stats(const void* x, long V, int C, float eps, float
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nblocks), dim3(256), 0, stream, (const bf16_t*)x, V, C, partial);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(GN_GROUPS), dim3(256), 0, stream, (const float*)partial, nblocks, V, C, eps, stats);
     TG_LAUNCH_CHECK("tg_groupnorm_stats");
+    return TG_OK;
+}
+
+// ---- nearest x2 upsampling + 3x3 convolution as four 2x2 phase convolutions on the LOW-resolution input (see the header) ----
+static bool up2_subpixel_shape_ok(int T, int H, int W, int Cin, int cout, int n_cu) {
+    const long M = (long)T * H * W;
+    return Cin % 64 == 0 && cout % 256 == 0 && M >= 1024 && ((M + 255) / 256) * (cout / 256) >= n_cu / 8 && 4L * (Cin / 64) >= 4 && H < 1024 && W < 1024 && T < 512 &&
+           4L * Cin < (1L << 21) && (long)(T + 2) * H * W * Cin < (1L << 31) && 4L * M * cout < (1L << 40);
+}
+
+extern "C" long tg_conv3d_up2_subpixel_ok(int T, int H, int W, int Cin, int cout) {
+    return up2_subpixel_shape_ok(T, H, W, Cin, cout, tg_device_cus()) && tg_knob(TG_KNOB_CONV_W4) != 0 ? 1 : 0;
+}
+
+extern "C" long tg_conv3d_up2_subpixel_gn_floats(int T, int H, int W) { return 4 * ((((long)T * H * W) + BM - 1) / BM) * 2 * GN_GROUPS; }
+
+extern "C" int tg_conv3d_up2_subpixel(const void* x, int T, int H, int W, int Cin, const void* w_phases, const void* bias, int cout, void* y, long ldy,
+                                      int time_x2, const void* zeros, float* gn_partial, hipStream_t stream) {
+    TG_REQUIRE(time_x2 == 0 || time_x2 == 1, TG_ERR_ARG, "tg_conv3d_up2_subpixel: time_x2 is 0 or 1");
+    TG_REQUIRE(x && w_phases && y && zeros, TG_ERR_ARG, "tg_conv3d_up2_subpixel: null pointer");
+    TG_REQUIRE(T > 0 && H > 0 && W > 0, TG_ERR_SHAPE, "tg_conv3d_up2_subpixel: bad spatial shape");
+    TG_REQUIRE(up2_subpixel_shape_ok(T, H, W, Cin, cout, tg_device_cus()) && tg_knob(TG_KNOB_CONV_W4) != 0, TG_ERR_SHAPE,
+               "tg_conv3d_up2_subpixel: shape outside the 256 x 256 kernel's range (T=%d H=%d W=%d Cin=%d cout=%d): ask tg_conv3d_up2_subpixel_ok first", T, H, W, Cin, cout);
+    TG_REQUIRE(tg_aligned16(x) && tg_aligned16(w_phases) && tg_aligned16(zeros) && (((uintptr_t)y) & 7) == 0 && ldy % 4 == 0 && ldy >= cout, TG_ERR_ALIGN,
+               "tg_conv3d_up2_subpixel: alignment");
+    TG_REQUIRE(!gn_partial || (cout / GN_GROUPS) % 4 == 0, TG_ERR_SHAPE, "tg_conv3d_up2_subpixel: fused GroupNorm sums need cout in {256, 512, ...}");
+    const long M = (long)T * H * W, rows = (M + BM - 1) / BM, tiles = ((M + 255) / 256) * (cout / 256);
+    TG_DYN_LDS((conv3d_w4_kernel<256>), CW_LDS);
+    for (int ph = 0; ph < 4; ++ph) {
+        const int py = ph >> 1, px = ph & 1;
+        // rows yl + a - (1 - py), a = 0, 1: phase 0 reads (yl - 1, yl), phase 1 (yl, yl + 1); likewise the columns
+        ConvParams p{(const bf16_t*)x, T, H, W, Cin, nullptr, (const bf16_t*)w_phases + (long)ph * cout * 4 * Cin, (const bf16_t*)bias, cout, cout, 1, 2, 2,
+                     1, 1 - py, 1, nullptr, nullptr, (bf16_t*)y, ldy, T, H, W, (const bf16_t*)zeros, gn_partial ? gn_partial + (long)ph * rows * 2 * GN_GROUPS : nullptr, 1, nullptr,
+                     py - px, 2, py, px, time_x2 && T > 1 ? (T % 2 ? 1 : 2) : 0};
+        hipLaunchKernelGGL(conv3d_w4_kernel<256>, dim3((unsigned)tiles), dim3(256), CW_LDS, stream, p);
+    }
+    TG_LAUNCH_CHECK("tg_conv3d_up2_subpixel");
     return TG_OK;
 }
 

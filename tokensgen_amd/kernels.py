@@ -658,6 +658,30 @@ def conv3d_cl(x, w_packed, bias, cout, kt, kh, kw, cache=None, stride=1, pad=1, 
     return y
 
 
+def conv3d_up2_subpixel_ok(T, H, W, Cin, cout):
+    """Does tg_conv3d_up2_subpixel take this shape (the 256 x 256 convolution kernel's range)?"""
+    return bool(L.load().tg_conv3d_up2_subpixel_ok(T, H, W, Cin, cout))
+
+
+def conv3d_up2_subpixel(x, w_phases, bias, cout, gn_stats_eps=None, time_x2=False):
+    """Nearest x2 spatial upsampling + Conv2d 3x3 (pad 1) as four 2x2 phase convolutions on the low-resolution input (tg_conv3d_up2_subpixel; the deviation — pre-summed
+    bf16 weights — is stated in the header).  x [T, H, W, Cin] channels-last; w_phases [4, cout, 4, Cin] (vae.pack_up2_phases); returns y [To, 2H, 2W, cout], with
+    y.gn_sums as conv3d_cl leaves them.  time_x2: the layer's nearest x2 in TIME as well (each frame convolved once, stored twice; To = 2T, or 2T - 1 for odd T > 1)."""
+    _chk(x, "x"); _chk(w_phases, "w_phases")
+    assert x.is_contiguous() and w_phases.is_contiguous()
+    T, H, W, Cin = x.shape
+    assert tuple(w_phases.shape) == (4, cout, 4, Cin)
+    To = T if not (time_x2 and T > 1) else (2 * T - 1 if T % 2 else 2 * T)        # time_x2: every frame twice, except the first of an odd count (CogVideoXUpsample3D)
+    y = torch.empty(To, 2 * H, 2 * W, cout, dtype=BF16, device=x.device)
+    fuse = gn_stats_eps is not None
+    partial = torch.empty(L.load().tg_conv3d_up2_subpixel_gn_floats(T, H, W), dtype=torch.float32, device=x.device) if fuse else None
+    L.check(_launch(f"conv3d_up2_subpixel_Cin{Cin}_Cout{cout}_t{int(bool(time_x2))}", L.load().tg_conv3d_up2_subpixel, _p(x), T, H, W, Cin, _p(w_phases), _p(bias), cout, _p(y), cout,
+                    1 if time_x2 else 0, _p(zero_page(x.device)), _p(partial), _stream()), "tg_conv3d_up2_subpixel")
+    if fuse:
+        y.gn_sums = GnSums(partial, To * 4 * H * W, cout, float(gn_stats_eps))
+    return y
+
+
 class GnSums:
     """The GroupNorm(32) sums a convolution's epilogue left for the norm that reads its output: rows of [2][32] (sum, sum of squares per group), one per
     128 voxels.  The norm pass turns <= 64 rows into (mean, rstd) in its own prologue (tg_groupnorm_silu_ex / tg_spatialnorm_silu_ex); longer lists are
@@ -682,6 +706,9 @@ class GnSums:
         return self._rows
 
     def stats(self):
+        if self.partial.numel() // 64 != (self.V + 127) // 128:
+            # tg_groupnorm_finalize walks ceil(V / 128) rows: the phase launches of conv3d_up2_subpixel leave 4 x ceil(V / 4 / 128) — the norm passes take any row count (rows())
+            raise ValueError("GnSums.stats(): this buffer has one row list per phase launch; use rows() (what the norm passes read)")
         stats = torch.empty(32, 2, dtype=torch.float32, device=self.partial.device)
         L.check(_launch("groupnorm_finalize", L.load().tg_groupnorm_finalize, _p(self.partial), self.V, self.C, self.eps, _p(stats), _stream()),
                 "tg_groupnorm_finalize")

@@ -65,6 +65,7 @@ PROTOTYPES = {
     "tg_pca_inverse": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "tg_pca_lowrank_filter": [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _vp],
     "tg_conv3d_cl": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "tg_conv3d_up2_subpixel": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _l, _i, _vp, _vp, _vp],
     "tg_groupnorm_finalize": [_vp, _l, _i, _f, _vp, _vp],
     "tg_groupnorm_stats": [_vp, _l, _i, _f, _vp, _vp, _vp],
     "tg_groupnorm_silu": [_vp, _l, _i, _vp, _vp, _vp, _vp, _i, _vp],
@@ -82,6 +83,8 @@ PROTOTYPES = {
 QUERIES = {
     "tg_groupnorm_partial_floats": [C.c_long, C.c_int],
     "tg_conv3d_gn_partial_floats": [C.c_int, C.c_int, C.c_int],
+    "tg_conv3d_up2_subpixel_gn_floats": [C.c_int, C.c_int, C.c_int],
+    "tg_conv3d_up2_subpixel_ok": [C.c_int] * 5,
     "tg_groupnorm_reduce_rows": [C.c_long],
     "tg_conv3d_splitk_floats": [C.c_int] * 9,
     "tg_attention_bwd_ws_floats": [C.c_int, C.c_int, C.c_int, C.c_int],

@@ -42,6 +42,24 @@ class DiagonalGaussianDistribution:
         return self.mean
 
 
+def pack_up2_phases(w):
+    """Conv2d 3x3 weight [co, ci, 3, 3] behind a nearest x2 upsampling -> the four 2x2 phase kernels [4 = py*2+px, co, 4 = a*2+b, ci] (bf16) of tg_conv3d_up2_subpixel:
+    of the three upsampled rows a tap row reads, two are the same low-resolution row — their weights are added (fp32) and rounded to bf16 ONCE.
+    py = 0: a = 0 <- dy 0, a = 1 <- dy 1 + dy 2;  py = 1: a = 0 <- dy 0 + dy 1, a = 1 <- dy 2; columns likewise."""
+    sets = (((0,), (1, 2)), ((0, 1), (2,)))
+    wf = w.float()
+    co, ci = w.shape[:2]
+    out = torch.zeros(4, co, 4, ci, dtype=torch.float32, device=w.device)
+    for py in range(2):
+        for px in range(2):
+            for a in range(2):
+                for b in range(2):
+                    for dy in sets[py][a]:
+                        for dx in sets[px][b]:
+                            out[py * 2 + px, :, a * 2 + b] += wf[:, :, dy, dx]
+    return out.to(BF16).contiguous()
+
+
 class AutoencoderKLCogVideoX:
     def __init__(self, in_channels=3, out_channels=3, block_out_channels=(128, 256, 256, 512), latent_channels=16, layers_per_block=3,
                  act_fn="silu", norm_eps=1e-6, norm_num_groups=32, temporal_compression_ratio=4, sample_height=480, sample_width=720,
@@ -69,6 +87,7 @@ class AutoencoderKLCogVideoX:
         # and replayed afterwards — the host then issues 9 graph launches per clip instead of ~8 500 kernel launches, which is what lets the
         # tile streams actually overlap (the decode was bound by Python's launch rate, not by the GPU, once the tiles ran concurrently)
         self.use_graphs = os.environ.get("TG_VAE_GRAPHS", "1") != "0"
+        self.subpixel_upsample = os.environ.get("TG_VAE_SUBPIXEL", "1") != "0"    # spatial-only upsamplers as four 2x2 phase convolutions (_upsample); flip BEFORE the first decode (graphs)
         self._graphs, self._seen = {}, {}
         self._tl = int(np.log2(temporal_compression_ratio))
 
@@ -123,6 +142,8 @@ class AutoencoderKLCogVideoX:
                     w = torch.zeros(co, 96, dtype=BF16, device=self.device)
                     w[:, :81] = v.reshape(co, ci, 27).permute(0, 2, 1).reshape(co, 81)
                     self._packed[k + ".k96"] = w.contiguous()          # beside the general packing: tiles too small for the patch kernel take that
+                if ".upsamplers." in k and tuple(taps) == (3, 3) and co % 256 == 0 and ci % 64 == 0:
+                    self._packed[k + ".up2"] = pack_up2_phases(v)       # beside the general packing (time-upsampling layers and small tiles keep that)
                 cin_p = _pad_to(ci, 64)
                 cout_p = _pad_to(co, 16) if co <= 32 else _pad_to(co, 128)     # conv_out (3 / 32 channels): the narrow 128 x 16 tile
                 w = torch.zeros(cout_p, int(np.prod(taps)), cin_p, dtype=BF16, device=self.device)
@@ -320,6 +341,12 @@ class AutoencoderKLCogVideoX:
     def _upsample(self, name, x, compress_time):
         """diffusers CogVideoXUpsample3D: nearest x2 (first frame 2-D only when T odd > 1) + Conv2d 3x3 — folded into one conv."""
         T, H, W, C = x.shape
+        w = self._sd[name + ".conv.weight"]
+        ph = self._packed.get(name + ".conv.weight.up2") if self.subpixel_upsample else None
+        if ph is not None and K.conv3d_up2_subpixel_ok(T, H, W, C, w.shape[0]):
+            # four 2x2 phase convolutions on the low-resolution input, 4 taps instead of 9 (pre-summed weights: the deviation stated in include/tokensgen_hip.h); the
+            # time-doubling layers convolve every frame once and store it twice (exact).  The last upsampler (256 -> 256 at 8 x 240 x 360 per tile) was 5 % of the decode's kernel time
+            return K.conv3d_up2_subpixel(x, ph, self._sd[name + ".conv.bias"], w.shape[0], gn_stats_eps=self.config.norm_eps, time_x2=bool(compress_time and T > 1))
         tmap = None
         To = T
         if compress_time and T > 1:
@@ -332,7 +359,6 @@ class AutoencoderKLCogVideoX:
                 # upload must have LANDED before the host enqueues anything else (once per distinct T; never inside a capture: the eager
                 # first pass of a shape has already created it)
                 torch.cuda.current_stream(x.device).synchronize()
-        w = self._sd[name + ".conv.weight"]
         return K.conv3d_cl(x, self._packed[name + ".conv.weight"], self._sd[name + ".conv.bias"], w.shape[0], 1, 3, 3, stride=1, pad=1, up=2,
                            t_map=tmap, out_dims=(To, 2 * H, 2 * W), gn_stats_eps=self.config.norm_eps)
 
@@ -424,7 +450,7 @@ class AutoencoderKLCogVideoX:
         C, Tt, Ht, Wt = src.shape
         Hc, Wc = min(th, Ht - i), min(tw, Wt - j)
         # everything a captured program bakes in besides the weights (load_state_dict drops the cache): shapes, the temporal batching, eps
-        key = (decode, src.dtype, C, Tt, Hc, Wc, slot, bool(getattr(self, "_tiled_pass", False)), self.num_latent_frames_batch_size,
+        key = (decode, src.dtype, C, Tt, Hc, Wc, slot, bool(getattr(self, "_tiled_pass", False)), bool(self.subpixel_upsample), self.num_latent_frames_batch_size,
                self.num_sample_frames_batch_size, float(self.config.norm_eps))
         g = self._graphs.get(key)
         if g is None:
