@@ -75,7 +75,7 @@ def _fake_decode(z):
     return (x * 0.5 + z.float().mean()).to(BF)
 
 
-def _product_run(d, trace=None, output_type="latent"):
+def _product_run(d, trace=None, output_type="latent", split=False, calls=None):
     from tokensgen_amd import fifo
     from tokensgen_amd.scheduler import CogVideoXDPMScheduler
     sched = CogVideoXDPMScheduler(prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=1.0, timestep_spacing="trailing")
@@ -92,12 +92,26 @@ def _product_run(d, trace=None, output_type="latent"):
                          guidance_scale=6.0, cache_idx=[], video_ipadapter_start_frame_idx=1000, output_type=output_type, return_dict=False,
                          orig_latents=d["fifo_latents"][:, :NF])
 
-    def window_fn(latents, old_x0, has_old, t, prev_t, next_t, noise, grid_t, cond_grid_t, image_embeddings):
-        """Same arithmetic as the oracle loop above (this test checks the DRIVER, not the kernels)."""
+    def both_branches(latents, t, grid_t, cond_grid_t, image_embeddings, **unused):
         vs_probe = float(cond_grid_t[0])
         vs = int(round((vs_probe - 1000) / 3.25))
-        pred = S.cfg_combine(_fake_denoise(torch.cat([latents] * 2), torch.as_tensor(np.asarray(t))[None].expand(2, -1), grid_t, cond_grid_t,
-                                           vs, image_embeddings), 6.0)
+        return _fake_denoise(torch.cat([latents] * 2), torch.as_tensor(np.asarray(t))[None].expand(2, -1), grid_t, cond_grid_t, vs, image_embeddings)
+
+    def predict_fn(h, **kw):
+        """One guidance branch of a window (what a rank of a split iteration computes): row h of the stand-in denoiser's batch."""
+        if calls is not None:
+            calls.append(h)
+        return both_branches(**kw)[h]
+
+    def finish_fn(preds, latents, old_x0, has_old, t, prev_t, next_t, noise, **unused):
+        return solve(S.cfg_combine(preds, 6.0), latents, old_x0, has_old, t, prev_t, next_t, noise)
+
+    def window_fn(latents, old_x0, has_old, t, prev_t, next_t, noise, grid_t, cond_grid_t, image_embeddings):
+        """Same arithmetic as the oracle loop above (this test checks the DRIVER, not the kernels)."""
+        pred = S.cfg_combine(both_branches(latents, t, grid_t, cond_grid_t, image_embeddings), 6.0)
+        return solve(pred, latents, old_x0, has_old, t, prev_t, next_t, noise)
+
+    def solve(pred, latents, old_x0, has_old, t, prev_t, next_t, noise):
         o_lat, o_x0 = latents.clone(), torch.zeros_like(old_x0)
         for j in range(NF):
             nxt = int(next_t[j]) if next_t[j] > 0 else None
@@ -109,7 +123,8 @@ def _product_run(d, trace=None, output_type="latent"):
         return o_lat, o_x0
 
     res = fifo.cogvideo_fifo_mp_v2([pipe], bo, step_noise_fn=_noise, tail_noise_fn=lambda i, shape: _noise(i, 97, shape),
-                                   window_fn=window_fn, trace=trace, decode_chunk_fn=_fake_decode)
+                                   window_fn=window_fn, trace=trace, decode_chunk_fn=_fake_decode,
+                                   **(dict(predict_fn=predict_fn, finish_fn=finish_fn) if split else {}))
     return res[1] if output_type == "latent" else torch.cat([res[0], res[1]], dim=2)
 
 
@@ -168,6 +183,50 @@ def test_driver_two_ranks_gloo_matches_single():
         p.join(timeout=60)
     assert torch.equal(got[0][0], ref.float()) and torch.equal(got[1][0], ref.float())
     assert torch.equal(got[0][1], ref_dec.float()) and torch.equal(got[1][1], ref_dec.float())
+
+
+def _split_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+        out = _product_run(_inputs(), split=True, calls=calls)
+        q.put((rank, out.float().numpy(), len(calls), sorted(set(calls))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_small_iterations_split_by_guidance_branch_four_ranks_gloo():
+    """Round 6: the ramp at the head of a run has 1, 2, 2, ... windows per iteration (cogvideo_sampling_mp_fifo.py:235-253 leaves the other workers idle).  With 4 ranks and 2
+    guidance branches, the 7 iterations with <= 2 windows run as batch-1 forwards — rank 2k + h takes branch h of window k — one all_gather of the model outputs, the solver
+    step replicated.  Same latents as the single-process run, bit for bit, on every rank; ranks 0..3 computed branch 0 / 1 / 0 / 1 only, ranks 2, 3 fewer times (the 1-window iteration)."""
+    import torch.multiprocessing as mp
+    from tokensgen_amd.fifo import window_plan
+    ref = _product_run(_inputs())
+    qs, small, one = T - (NF - NF // 2), 0, 0
+    for _ in range(NF + T - NF):
+        n = len(window_plan(qs, NF, 4))
+        small += n <= 2
+        one += n == 1
+        qs = max(0, qs - 1)
+    assert (small, one) == (7, 1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    from conftest import free_port
+    port = free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    got = {r: (torch.from_numpy(o), n, br) for r, o, n, br in (q.get(timeout=280) for _ in range(4))}
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(4):
+        assert torch.equal(got[r][0], ref.float()), r
+        assert got[r][2] == [r % 2] and got[r][1] == (small if r < 2 else small - one), (r, got[r][1:])
 
 
 def test_unsupported_modes_raise():

@@ -271,6 +271,10 @@ def test_fifo_worker_guidance_variants_vs_reference_runs(golden_dir, parity):
             if has_old[j] and prev_t[j] >= 0:
                 noise[j, 1] = torch.randn(1, 1, 16, H, W, generator=gen, dtype=BF)[0, 0]
         x, x0 = w.window_step(c["latents"].to(DEV), old, has_old, t, prev_t, next_t, noise.to(DEV), c["grid_t"], c["cond_t"], c["image_embeddings"].to(DEV))
+        # the guidance branches as separate batch-1 forwards (what the ranks of a split FIFO iteration compute, round 6): per-sample kernels — bitwise the batched step
+        xs, x0s = w.window_step(c["latents"].to(DEV), old, has_old, t, prev_t, next_t, noise.to(DEV), c["grid_t"], c["cond_t"], c["image_embeddings"].to(DEV),
+                                split_branches=True)
+        assert torch.equal(xs, x) and torch.equal(x0s, x0), c["name"]
         rel = lambda a, b: ((a.float().cpu() - b.float()).norm() / b.float().norm()).item()
         tag = f"{c['name']} window@{c['start']}"
         # the reference's own rounding noise on this case: its bf16 run (the fixture) against the oracle in fp32 on the same bf16 weights / inputs /

@@ -55,11 +55,10 @@ class FifoWorker:
         return vr, cr
 
     @torch.no_grad()
-    def window_step(self, latents, old_x0, has_old, t, prev_t, next_t, noise, grid_t=None, cond_grid_t=None,
-                    image_embeddings=None):
-        """latents [1,nf,C,H,W] bf16; old_x0 [nf,C,H,W] (rows without an estimate are ignored via has_old);
-        t/prev_t/next_t: length-nf integer sequences (next_t <= 0 means "no back step", :544);
-        noise [nf,2,C,H,W] bf16.  Returns (latents_out [1,nf,C,H,W], x0 [nf,C,H,W])."""
+    def predict(self, branch, latents, t, grid_t=None, cond_grid_t=None, image_embeddings=None, **unused):
+        """The DiT forward of one window (:491-518): branch None = the whole guidance batch [nb, nf, C, H, W] (uncond, cond | uncond_txt, uncond_img, txt_img);
+        branch h = row h of it alone, as a batch-1 forward [1, nf, C, H, W] — what ONE rank computes when an iteration has so few windows that the ranks split
+        them by guidance branch (cogvideo_fifo_mp_v2, round 6).  The kernels are per-sample: row h of the batched forward is the batch-1 forward of row h."""
         nf = latents.shape[1]
         use_vip = image_embeddings is not None
         vr = cr = None
@@ -69,12 +68,20 @@ class FifoWorker:
         nb = self.branches
         if use_vip and image_embeddings.shape[0] != nb:
             raise ValueError(f"image_embeddings must hold {nb} batch rows for this guidance mode; got {image_embeddings.shape[0]}")
-        inp = torch.cat([x] * nb, dim=0)                                      # :492-497 (CFG batch: uncond, cond | uncond_txt, uncond_img, txt_img)
-        tt = torch.as_tensor(np.asarray(t, dtype=np.int64), device=self.device)[None].expand(nb, -1)
-        pred = self.transformer(hidden_states=inp, encoder_hidden_states=self.prompt_embeds, timestep=tt,
+        rows = slice(0, nb) if branch is None else slice(int(branch), int(branch) + 1)
+        n = rows.stop - rows.start
+        inp = torch.cat([x] * n, dim=0)                                       # :492-497 (CFG batch: uncond, cond | uncond_txt, uncond_img, txt_img)
+        tt = torch.as_tensor(np.asarray(t, dtype=np.int64), device=self.device)[None].expand(n, -1)
+        return self.transformer(hidden_states=inp, encoder_hidden_states=self.prompt_embeds[rows], timestep=tt,
                                 image_rotary_emb=self.image_rotary_emb, vip_image_rotary_emb=vr,
-                                vip_condition_rotary_emb=cr, vip_encoder_hidden_states=image_embeddings,
+                                vip_condition_rotary_emb=cr, vip_encoder_hidden_states=image_embeddings[rows].contiguous() if use_vip else None,
                                 return_dict=False)[0]
+
+    @torch.no_grad()
+    def finish(self, pred, latents, old_x0, has_old, t, prev_t, next_t, noise, **unused):
+        """CFG combine + the window's 13 per-frame DPM updates (:519-550) on the model output `pred` [nb, nf, C, H, W] -> (latents_out [1, nf, C, H, W], x0 [nf, C, H, W])."""
+        nf = latents.shape[1]
+        x = latents.to(self.device, BF16)
         t_back = [int(v) if int(v) > 0 else None for v in next_t]
         # the 2M branch needs a previous x0 AND a back step; the FIFO driver guarantees they coincide (App. C)
         for j in range(nf):
@@ -87,10 +94,21 @@ class FifoWorker:
             tv = torch.as_tensor(np.asarray(t, dtype=np.int64))
             ramp = (1 - torch.cos(math.pi * ((self.num_inference_steps - tv) / self.num_inference_steps) ** 5.0)) / 2
             gpf = torch.stack([1 + self.guidance_scale * ramp, 1 + self.guidance_scale_img * ramp], dim=1).to(torch.float32).contiguous().to(self.device)
-        x_out, x0 = self.scheduler.window_step(pred, x[0].contiguous(), old_x0.contiguous(), noise.contiguous(),
+        x_out, x0 = self.scheduler.window_step(pred.contiguous(), x[0].contiguous(), old_x0.contiguous(), noise.contiguous(),
                                                list(map(int, t)), list(map(int, prev_t)), t_back, list(has_old),
                                                self.guidance_scale, self.guidance_scale_img, gpf)
         return x_out[None], x0
+
+    @torch.no_grad()
+    def window_step(self, latents, old_x0, has_old, t, prev_t, next_t, noise, grid_t=None, cond_grid_t=None,
+                    image_embeddings=None, split_branches=False):
+        """latents [1,nf,C,H,W] bf16; old_x0 [nf,C,H,W] (rows without an estimate are ignored via has_old);
+        t/prev_t/next_t: length-nf integer sequences (next_t <= 0 means "no back step", :544);
+        noise [nf,2,C,H,W] bf16.  Returns (latents_out [1,nf,C,H,W], x0 [nf,C,H,W]).
+        split_branches: run the guidance branches as separate batch-1 forwards, one after the other (what the ranks of a split iteration do, on one GPU)."""
+        kw = dict(latents=latents, t=t, grid_t=grid_t, cond_grid_t=cond_grid_t, image_embeddings=image_embeddings)
+        pred = torch.cat([self.predict(h, **kw) for h in range(self.branches)], dim=0) if split_branches else self.predict(None, **kw)
+        return self.finish(pred, latents, old_x0, has_old, t, prev_t, next_t, noise)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -173,7 +191,7 @@ def decode_chunks_sharded(pipe, latents, nf, decode_chunk_fn=None):
 
 
 def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None, tail_noise_fn=None, trace=None,
-                        window_fn=None, decode_chunk_fn=None, iteration_hook=None, **kwargs):
+                        window_fn=None, decode_chunk_fn=None, iteration_hook=None, predict_fn=None, finish_fn=None, split_small_iterations=True, **kwargs):
     """Mirror of cogvideo_sampling_mp_fifo.py:27-395.
 
     `pipe_list` holds this process's pipeline(s); with torch.distributed initialised (one process per GPU) the
@@ -182,7 +200,13 @@ def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None
     (latents when output_type == "latent").  `window_fn(worker, **window_inputs)` lets tests substitute the
     denoiser (CPU/gloo tests of the exchange logic); the default is FifoWorker.window_step (HIP).  With an output_type other
     than "latent" the final VAE decode is sharded by chunk over the ranks (decode_chunks_sharded).  `iteration_hook(i, n_iter, latents, x0q)` is called
-    on every rank after iteration i's queue shift (measurement only: bench.py records memory and queue checksums there; it must not modify the queue)."""
+    on every rank after iteration i's queue shift (measurement only: bench.py records memory and queue checksums there; it must not modify the queue).
+    Round 6 — iterations with FEW windows (the ramp at the head of every run: 1, 2, 3, ... windows while the queue fills; :235-253 runs them on as many workers and
+    leaves the others idle): when the ranks number at least (guidance branches) x (windows), every window is split by guidance branch — rank nb k + h runs branch h of
+    window k as a batch-1 forward (`predict_fn(h, **window_inputs)`, default FifoWorker.predict), ONE all_gather brings every branch's model output to every rank, and every
+    rank applies the identical CFG + solver step to every window (`finish_fn(preds, **window_inputs)`, default FifoWorker.finish: one small elementwise launch per window).  Such an
+    iteration costs a batch-1 forward (0.51 of a window step) instead of a whole one: on 8 GPUs the 20 iterations with <= 4 windows.  Needs predict_fn AND finish_fn when
+    window_fn is substituted (else such iterations run whole windows as before); split_small_iterations=False turns it off."""
     import torch.distributed as dist
     bo = base_output
     sp = bo.sampling_params
@@ -233,12 +257,19 @@ def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None
         emb = bo.image_embeddings.to(dev, BF16)
         emb = torch.cat([emb] + [emb[:, -vnf:]] * (T // nf + 1), dim=1)                            # :101-108
         n_c = min(vnf + 1, nf)
+    nb_split = 0                                        # guidance branches a window can be split into (0: windows are never split)
+    do_cfg = bool(bo.do_classifier_free_guidance)
+    n_branches = (3 if getattr(bo, "use_separate_guidance", False) else 2) if do_cfg else 1
     if window_fn is None:
         worker = FifoWorker(pipe.transformer, pipe.scheduler, bo.prompt_embeds, bo.image_rotary_emb, bo.guidance_scale,
                             *((g_h, g_w, c_h, c_w) if use_vip else (None,) * 4), use_separate_guidance=getattr(bo, "use_separate_guidance", False),
                             guidance_scale_img=getattr(bo, "guidance_scale_img", None), use_dynamic_cfg=getattr(bo, "use_dynamic_cfg", False),
-                            num_inference_steps=T, do_classifier_free_guidance=bool(bo.do_classifier_free_guidance))
+                            num_inference_steps=T, do_classifier_free_guidance=do_cfg)
         window_fn = lambda **kw: worker.window_step(**kw)
+        predict_fn = predict_fn or (lambda h, **kw: worker.predict(h, **kw)[0])
+        finish_fn = finish_fn or (lambda preds, **kw: worker.finish(preds, **kw))
+    if split_small_iterations and predict_fn is not None and finish_fn is not None and n_branches > 1:
+        nb_split = n_branches
     noise = _SeededNoise(noise_seed, dev)
     step_noise_fn = step_noise_fn or noise.step
     tail_noise_fn = tail_noise_fn or noise.tail
@@ -248,25 +279,50 @@ def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None
     n_iter = bo.num_frames + T - nf
     for i in range(n_iter):
         plan = window_plan(queue_start, nf, num_partitions)
-        mine = [(k, w) for k, w in enumerate(plan) if k % world == me]
-        per_rank = (len(plan) + world - 1) // world
-        n_el = per_rank * 2 * nf * C * H * W
-        xbuf = torch.zeros(n_el + 8, dtype=BF16, device=dev)                   # payload + this rank's failure flag (runtime.RankGuard)
-        buf = xbuf[:n_el].view(per_rank, 2, nf, C, H, W)
+
+        def window_inputs(w, traced):
+            s, e = w["start"], w["end"]
+            kw = dict(latents=latents[:, s:e].clone(), old_x0=x0q[s:e].clone(), has_old=has_old[s:e], t=t_tab[s:e],
+                      prev_t=p_tab[s:e], next_t=n_tab[s:e], noise=step_noise_fn(i, w["rank"], (nf, 2, C, H, W)))
+            if use_vip:
+                vs = int(np.searchsorted(cond_t, q_grid_t[s] + bo.video_ipadapter_start_frame_idx, side="right") - 1)   # :110-115
+                kw.update(grid_t=q_grid_t[s:e].copy(), cond_grid_t=cond_t[vs:vs + n_c].copy(), image_embeddings=emb[:, vs:vs + n_c].contiguous())
+                if traced and trace is not None:
+                    trace.append((i, w["rank"], s, w["mid"], e, w["real_end"], vs))
+            return kw
         guard = RankGuard(f"FIFO iteration {i}")
-        with guard:
-            for slot, (k, w) in enumerate(mine):
-                s, e = w["start"], w["end"]
-                kw = dict(latents=latents[:, s:e].clone(), old_x0=x0q[s:e].clone(), has_old=has_old[s:e], t=t_tab[s:e],
-                          prev_t=p_tab[s:e], next_t=n_tab[s:e], noise=step_noise_fn(i, w["rank"], (nf, 2, C, H, W)))
-                if use_vip:
-                    vs = int(np.searchsorted(cond_t, q_grid_t[s] + bo.video_ipadapter_start_frame_idx, side="right") - 1)   # :110-115
-                    kw.update(grid_t=q_grid_t[s:e].copy(), cond_grid_t=cond_t[vs:vs + n_c].copy(), image_embeddings=emb[:, vs:vs + n_c].contiguous())
-                    if trace is not None:
-                        trace.append((i, w["rank"], s, w["mid"], e, w["real_end"], vs))
-                x_out, x0_out = window_fn(**kw)
-                buf[slot, 0], buf[slot, 1] = x_out[0], x0_out
-        if dist_on:                                     # the path's one exchange: kept windows of every rank (+ the failure flags)
+        if dist_on and nb_split and world >= nb_split * len(plan):
+            # few windows, many ranks: rank nb k + h computes guidance branch h of window k (batch 1); the model outputs are exchanged, the cheap solver step is replicated
+            k_mine, h_mine = divmod(me, nb_split)
+            pel = nf * C * H * W
+            pbuf = torch.zeros(pel + 8, dtype=BF16, device=dev)
+            with guard:
+                if k_mine < len(plan):
+                    pbuf[:pel] = predict_fn(h_mine, **window_inputs(plan[k_mine], h_mine == 0)).reshape(-1)
+            pbuf[pel:pel + 1] = guard.flag(dev)
+            flat = torch.empty(world * (pel + 8), dtype=BF16, device=dev)
+            dist.all_gather_into_tensor(flat, pbuf)
+            allp = flat.view(world, pel + 8)
+            guard.check(allp[:, pel])
+            allbuf = torch.empty(len(plan), 2, nf, C, H, W, dtype=BF16, device=dev)
+            for k, w in enumerate(plan):
+                x_out, x0_out = finish_fn(allp[k * nb_split:(k + 1) * nb_split, :pel].reshape(nb_split, nf, C, H, W), **window_inputs(w, False))
+                allbuf[k, 0], allbuf[k, 1] = x_out[0], x0_out
+            src_of = lambda k: allbuf[k]
+        else:
+            mine = [(k, w) for k, w in enumerate(plan) if k % world == me]
+            per_rank = (len(plan) + world - 1) // world
+            n_el = per_rank * 2 * nf * C * H * W
+            xbuf = torch.zeros(n_el + 8, dtype=BF16, device=dev)                   # payload + this rank's failure flag (runtime.RankGuard)
+            buf = xbuf[:n_el].view(per_rank, 2, nf, C, H, W)
+            with guard:
+                for slot, (k, w) in enumerate(mine):
+                    x_out, x0_out = window_fn(**window_inputs(w, True))
+                    buf[slot, 0], buf[slot, 1] = x_out[0], x0_out
+            src_of = None
+        if src_of is not None:
+            pass
+        elif dist_on:                                   # the path's one exchange: kept windows of every rank (+ the failure flags)
             xbuf[n_el:n_el + 1] = guard.flag(dev)
             flat = torch.empty(world * (n_el + 8), dtype=BF16, device=dev)     # rank-major concat
             dist.all_gather_into_tensor(flat, xbuf)
@@ -278,7 +334,7 @@ def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None
             allbuf = buf
         new_lat, new_x0, new_has = latents.clone(), x0q.clone(), list(has_old)
         for k, w in enumerate(plan):                    # identical write-back on every rank (:308-334)
-            src = allbuf[(k % world) * per_rank + k // world]
+            src = src_of(k) if src_of is not None else allbuf[(k % world) * per_rank + k // world]
             lo, hi, loc = keep_slice(w, queue_start, nf)
             new_lat[0, lo:hi] = src[0, loc:loc + (hi - lo)]
             new_x0[lo:hi] = src[1, loc:loc + (hi - lo)]

@@ -35,10 +35,12 @@ def fifo_iterations(chunks, nf=13, T=52, num_partitions=4):
     return out
 
 
-def project(chunks, meas, n, with_t2to, b1_ratio, b1_ratio_t2to=None, t_xchg=1.0e-3, t_cfg_xchg=0.5e-3):
+def project(chunks, meas, n, with_t2to, b1_ratio, b1_ratio_t2to=None, t_xchg=1.0e-3, t_cfg_xchg=0.5e-3, split=True, nb=2):
     per_iter = fifo_iterations(chunks)
     fwd1 = sum(per_iter)
-    fwdn = sum(math.ceil(w / n) for w in per_iter)
+    # an iteration costs max-over-ranks(windows) window forwards — or, when the ranks number at least nb x windows, ONE batch-1 forward (fifo.py: the windows split by
+    # guidance branch, round 6)
+    fwdn = sum((b1_ratio if (split and n >= nb * w and n > 1) else math.ceil(w / n)) for w in per_iter)
     steps = 52
     cfg_par = n >= 2                                       # cfg_parallel.resolve("auto"): ranks r % 2 take one CFG half each
     stage = lambda t1, r: t1 * r + steps * t_cfg_xchg if cfg_par else t1
@@ -47,7 +49,7 @@ def project(chunks, meas, n, with_t2to, b1_ratio, b1_ratio_t2to=None, t_xchg=1.0
          # decode_chunks_sharded twice: the video's `chunks` clips dealt round-robin + the base clip (one rank)
          "decode": (math.ceil(chunks / n) + 1) * meas["decode_clip_s"]}
     t["total"] = sum(t.values())
-    return {"n_gpus": n, "window_forwards_total": fwd1, "window_forwards_on_the_critical_rank": fwdn, "seconds": {k: round(v, 2) for k, v in t.items()}}
+    return {"n_gpus": n, "window_forwards_total": fwd1, "window_forwards_on_the_critical_rank": round(fwdn, 2), "seconds": {k: round(v, 2) for k, v in t.items()}}
 
 
 def main():
@@ -76,6 +78,7 @@ def main():
                 "window_s": (rec["seconds"]["fifo_and_decode"] - clips * vae_s) / n_fwd, "fifo_and_decode_s": rec["seconds"]["fifo_and_decode"], "window_forwards": n_fwd}
         assert n_fwd == rec["steps"] - 52, (n_fwd, rec["steps"])        # the walked schedule IS the measured run's
         rows = [project(chunks, meas, n, with_t2to, b1, b1t) for n in (1, 2, 4, 8)]
+        whole = [project(chunks, meas, n, with_t2to, b1, b1t, split=False) for n in (1, 2, 4, 8)]       # round 5's driver: small iterations run whole windows
         t1, f1 = rows[0]["seconds"]["total"], rows[0]["seconds"]["fifo"]
         for r in rows:
             n = r["n_gpus"]
@@ -83,6 +86,9 @@ def main():
             r["efficiency_end_to_end"] = round(t1 / r["seconds"]["total"] / n, 4)
             r["efficiency_fifo_phase"] = round(f1 / r["seconds"]["fifo"] / n, 4)
             r["steps_per_s_per_gpu_end_to_end"] = round((52 + n_fwd) / r["seconds"]["total"] / n, 4)
+        for r, w_ in zip(rows, whole):
+            r["without_branch_split"] = {"fifo_s": w_["seconds"]["fifo"], "efficiency_fifo_phase": round(f1 / w_["seconds"]["fifo"] / r["n_gpus"], 4),
+                                         "efficiency_end_to_end": round(t1 / w_["seconds"]["total"] / r["n_gpus"], 4)}
         runs[name] = {"measured_one_gpu": {k: round(v, 4) for k, v in meas.items()}, "projection": rows}
     out = {"what": "PROJECTION, not a measurement: product window schedule x one-GPU phase seconds; no N > 1 hardware was available to the builder",
            "sources": {"phase_seconds": ["profiles/r5_gen_1gpu_24clips.json", "profiles/r5_e2e_1gpu_12clips.json"], "vae_decode_clip_s": vae_src, "b1_over_b2": b1_src},
@@ -95,12 +101,12 @@ def main():
     for name, r in runs.items():
         print(f"\n{name}: window {r['measured_one_gpu']['window_s'] * 1e3:.1f} ms, base {r['measured_one_gpu']['base_s']:.1f} s, t2to {r['measured_one_gpu']['t2to_s']:.1f} s, "
               f"decode {r['measured_one_gpu']['decode_clip_s']:.3f} s/clip, b1/b2 {b1:.3f}")
-        print("| N | T2To s | base s | FIFO s | decode s | total s | speed-up | FIFO-phase eff. | end-to-end eff. | steps/s/GPU e2e |")
-        print("|---|---|---|---|---|---|---|---|---|---|")
+        print("| N | T2To s | base s | FIFO s | decode s | total s | speed-up | FIFO-phase eff. | end-to-end eff. | steps/s/GPU e2e | FIFO / e2e eff. without the branch split |")
+        print("|---|---|---|---|---|---|---|---|---|---|---|")
         for p in r["projection"]:
             s = p["seconds"]
             print(f"| {p['n_gpus']} | {s['t2to']} | {s['base']} | {s['fifo']} | {s['decode']} | {s['total']} | {p['speedup_end_to_end']} | {p['efficiency_fifo_phase']} | "
-                  f"{p['efficiency_end_to_end']} | {p['steps_per_s_per_gpu_end_to_end']} |")
+                  f"{p['efficiency_end_to_end']} | {p['steps_per_s_per_gpu_end_to_end']} | {p['without_branch_split']['efficiency_fifo_phase']} / {p['without_branch_split']['efficiency_end_to_end']} |")
 
 
 if __name__ == "__main__":
