@@ -33,7 +33,7 @@ PEAK_BF16 = 2.5e15                # MI355X dense bf16 MFMA peak (MI355X_MICROARC
 # dominant kernel = fused main attention (SDPA#1 + SDPA#2 of the To2V processor), per launch (B=2):
 N1, NP, D_MODEL = 17776, 480, 3072
 # + the vip-query attention (SDPA#3), whose workgroups ride in the same launch (tg_attention_fwd_multi)
-PMC_SUMMARY = "r5_pmc_summary.json"     # committed rocprofv3 PMC passes the `traffic` figure is read from
+PMC_SUMMARY = "r6_pmc_summary.json"     # committed rocprofv3 PMC passes the `traffic` figure is read from
 BWD_PMC_SUMMARY = "r6_attention_bwd_pmc.json"   # likewise for the training sub-record's dominant kernel (tools/profile_attn_bwd.sh)
 ATTN_FLOP_PER_LAUNCH = 2 * (4.0 * N1 * N1 * D_MODEL + 4.0 * N1 * NP * D_MODEL + 4.0 * NP * (N1 + NP) * D_MODEL)
 

@@ -47,6 +47,8 @@ struct ConvParams {
     int o_up;             // 2: output voxel (to, ho, wo) of this launch is stored at (to, 2 ho + o_py, 2 wo + o_px) of a [To][2 Ho][2 Wo] tensor
     int o_py, o_px;
     int o_tdup;           // with o_up == 2: 0 = frame t -> frame t; 1 = the nearest x2 of an ODD frame count (frame 0 -> 0; t >= 1 -> 2t - 1 and 2t); 2 = of an even one (t -> 2t, 2t + 1)
+    int o_phases;         // 4: ONE launch runs all four phases — virtual tile v = phase * tiles + tile; the phase sets pad / pad_w_off / o_py / o_px, its weights follow
+                          // each other in `w` ([4][cout][4][Cin]) and its GroupNorm rows in gn_partial ([4][ceil(M / 128)][64])
 };
 
 // WN x (4 / WN) waves; a wave owns FM x FN MFMA 16x16 blocks: <2, 4, 4> = the 128 x 128 tile, <1, 2, 1> = 128 voxels x 16 output channels
@@ -989,11 +991,23 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
     // tile order: contiguous chunk of tiles per XCD, n fastest (the tiles_n blocks sharing an A tile run on one XCD).  A temporal-locality order
     // (an XCD walks a spatial stripe through all frames) measured neutral — 200.2 vs 199.9 ms on the 256 -> 256 layers: the 5-6x algorithmic
     // L2-miss bytes PMC shows for these launches are absorbed behind L2 and already hidden.
-    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int Kw = p.kt * p.kh * p.kw * p.Cin;        // row length of the packed weights
+    int t = xcd_remap(blockIdx.x, tiles_m * tiles_n * (p.o_phases == 4 ? 4 : 1));
+    // the phase of a tg_conv3d_up2_subpixel launch: workgroup-uniform padding, output offsets, weight block and GroupNorm rows
+    int pad_h = p.pad, pad_w = p.pad + p.pad_w_off, o_py = p.o_py, o_px = p.o_px;
+    const bf16_t* wbase = p.w;
+    float* gnp = p.gn_partial;
+    if (p.o_phases == 4) {
+        const int per = tiles_m * tiles_n, ph = t / per;
+        t -= ph * per;
+        o_py = ph >> 1; o_px = ph & 1;
+        pad_h = 1 - o_py; pad_w = 1 - o_px;
+        wbase += (long)ph * p.cout * Kw;
+        if (gnp) gnp += (long)ph * ((M + BM - 1) / BM) * 2 * GN_GROUPS;
+    }
     const int tn = t % tiles_n, tm = t / tiles_n;
     const long m0 = (long)tm * TM;
     const int n0 = tn * NT;
-    const int Kw = p.kt * p.kh * p.kw * p.Cin;        // row length of the packed weights
 
     // ---- A side: piece i (0..7) of this wave = tile rows [wave*64 + i*8, +8); lane -> row + (lane>>3), physical slot lane&7 ----
     // Per tile and piece the lane keeps its voxel (t << 22 | h << 11 | w) and, for the plain case (stride 1, no upsampling), the element
@@ -1013,7 +1027,7 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
         int mk = 0;
         for (int dh = 0; dh < p.kh; ++dh)
             for (int dw = 0; dw < p.kw; ++dw)
-                if ((unsigned)(ho + dh - p.pad) < (unsigned)p.H && (unsigned)(wo + dw - p.pad - p.pad_w_off) < (unsigned)p.W) mk |= 1 << (dh * 3 + dw);
+                if ((unsigned)(ho + dh - pad_h) < (unsigned)p.H && (unsigned)(wo + dw - pad_w) < (unsigned)p.W) mk |= 1 << (dh * 3 + dw);
         vmask[i] = mk;
     }
     const int Hv = p.H * p.up, Wv = p.W * p.up;
@@ -1042,7 +1056,7 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
         if (plain) {
             // in-window frames: x + cen + doff.  Frames before the window (to + dt < kt-1): the cache tensor holds frames -(kt-1)..-1 at
             // indices 0.., i.e. cache + cen + doff + (kt-1)*frame; without a cache frame 0 is replicated: x + cen + doff - tv*frame
-            const int doff = ((dt - (p.kt - 1)) * p.H + (dh - p.pad)) * p.W * p.Cin + (dw - p.pad - p.pad_w_off) * p.Cin;
+            const int doff = ((dt - (p.kt - 1)) * p.H + (dh - pad_h)) * p.W * p.Cin + (dw - pad_w) * p.Cin;
             const int bit = 1 << (dh * 3 + dw), tneed = p.kt - 1 - dt;     // the tap reads frame to - tneed
             const bf16_t* early = p.cache ? p.cache + (long)(p.kt - 1) * frame : p.x;
 #pragma unroll
@@ -1067,7 +1081,7 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
         voffW[odd] = (int)(((long)(wave * (NW * 8) + prow) * Kw + dslot * 8) * 2);
     }
     const int pieceW = Kw * 16;
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long)n0 * Kw), 0, (int)((long)NT * Kw * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(wbase + (long)n0 * Kw), 0, (int)((long)NT * Kw * 2), 0x00020000);
     int dk = 0, dcc = 0, dtap = 0, dbuf = 0;          // DMA cursor: stage, channel block inside the tap, tap, LDS buffer
     auto dma_piece = [&](int q) {                    // q = 0..NA-1: A pieces, NA..NA+NW-1: W pieces of the cursor's stage
         if (q < NA) {
@@ -1208,7 +1222,7 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
                 int t0 = to_, t1 = -1;                      // time-duplicated frames: a 2-D convolution per frame gives duplicate outputs for duplicate inputs
                 if (p.o_tdup == 1) { t0 = to_ == 0 ? 0 : 2 * to_ - 1; t1 = to_ == 0 ? -1 : 2 * to_; }
                 else if (p.o_tdup == 2) { t0 = 2 * to_; t1 = 2 * to_ + 1; }
-                const long inner = (long)(2 * ho_ + p.o_py) * (2L * p.Wo) + 2 * wo_ + p.o_px, fr = 4L * p.Ho * p.Wo;
+                const long inner = (long)(2 * ho_ + o_py) * (2L * p.Wo) + 2 * wo_ + o_px, fr = 4L * p.Ho * p.Wo;
                 mo = t0 * fr + inner;
                 if (t1 >= 0) { mo2 = t1 * fr + inner; wgt = 2.f; }
             }
@@ -1229,7 +1243,7 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
                 o.y = pack_bf16x2(v[2], v[3]);
                 *(uint2*)(p.y + mo * p.ldy + n) = o;
                 if (mo2 >= 0) *(uint2*)(p.y + mo2 * p.ldy + n) = o;
-                if (p.gn_partial) {
+                if (gnp) {
                     const float r0 = bf16lo_to_f32(o.x), r1 = bf16hi_to_f32(o.x), r2 = bf16lo_to_f32(o.y), r3 = bf16hi_to_f32(o.y);
                     gs[nb] += wgt * ((r0 + r1) + (r2 + r3));
                     gq[nb] += wgt * ((r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3));
@@ -1238,7 +1252,7 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
         }
     });
     // GroupNorm partial sums in the layout of the 128-row kernel: one row of [2][32] per 128 voxels = per (tile, wm half); fixed order
-    if (p.gn_partial) {
+    if (gnp) {
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) {
 #pragma unroll
@@ -1267,7 +1281,7 @@ __global__ __launch_bounds__(256) void conv3d_w4_kernel(ConvParams p) {
                 a += red[(((wm_ * CW + (cq >> 5)) * 8 + ((cq >> 2) & 7)) * 4 + (cq & 3)) * 2 + stat];
             }
             const long prow_ = (long)tm * RB + wm_;
-            if (prow_ * 128 < M) p.gn_partial[prow_ * 2 * GN_GROUPS + stat * GN_GROUPS + n0 / cg + gl] = a;
+            if (prow_ * 128 < M) gnp[prow_ * 2 * GN_GROUPS + stat * GN_GROUPS + n0 / cg + gl] = a;
         }
     }
 }
@@ -1852,7 +1866,7 @@ extern "C" int tg_groupnorm_stats(const void* x, long V, int C, float eps, float
 // ---- nearest x2 upsampling + 3x3 convolution as four 2x2 phase convolutions on the LOW-resolution input (see the header) ----
 static bool up2_subpixel_shape_ok(int T, int H, int W, int Cin, int cout, int n_cu) {
     const long M = (long)T * H * W;
-    return Cin % 64 == 0 && cout % 256 == 0 && M >= 1024 && ((M + 255) / 256) * (cout / 256) >= n_cu / 8 && 4L * (Cin / 64) >= 4 && H < 1024 && W < 1024 && T < 512 &&
+    return Cin % 64 == 0 && cout % 256 == 0 && M >= 1024 && 4 * ((M + 255) / 256) * (cout / 256) >= n_cu / 8 && 4L * (Cin / 64) >= 4 && H < 1024 && W < 1024 && T < 512 &&
            4L * Cin < (1L << 21) && (long)(T + 2) * H * W * Cin < (1L << 31) && 4L * M * cout < (1L << 40);
 }
 
@@ -1872,16 +1886,15 @@ extern "C" int tg_conv3d_up2_subpixel(const void* x, int T, int H, int W, int Ci
     TG_REQUIRE(tg_aligned16(x) && tg_aligned16(w_phases) && tg_aligned16(zeros) && (((uintptr_t)y) & 7) == 0 && ldy % 4 == 0 && ldy >= cout, TG_ERR_ALIGN,
                "tg_conv3d_up2_subpixel: alignment");
     TG_REQUIRE(!gn_partial || (cout / GN_GROUPS) % 4 == 0, TG_ERR_SHAPE, "tg_conv3d_up2_subpixel: fused GroupNorm sums need cout in {256, 512, ...}");
-    const long M = (long)T * H * W, rows = (M + BM - 1) / BM, tiles = ((M + 255) / 256) * (cout / 256);
+    const long M = (long)T * H * W, tiles = ((M + 255) / 256) * (cout / 256);
     TG_DYN_LDS((conv3d_w4_kernel<256>), CW_LDS);
-    for (int ph = 0; ph < 4; ++ph) {
-        const int py = ph >> 1, px = ph & 1;
-        // rows yl + a - (1 - py), a = 0, 1: phase 0 reads (yl - 1, yl), phase 1 (yl, yl + 1); likewise the columns
-        ConvParams p{(const bf16_t*)x, T, H, W, Cin, nullptr, (const bf16_t*)w_phases + (long)ph * cout * 4 * Cin, (const bf16_t*)bias, cout, cout, 1, 2, 2,
-                     1, 1 - py, 1, nullptr, nullptr, (bf16_t*)y, ldy, T, H, W, (const bf16_t*)zeros, gn_partial ? gn_partial + (long)ph * rows * 2 * GN_GROUPS : nullptr, 1, nullptr,
-                     py - px, 2, py, px, time_x2 && T > 1 ? (T % 2 ? 1 : 2) : 0};
-        hipLaunchKernelGGL(conv3d_w4_kernel<256>, dim3((unsigned)tiles), dim3(256), CW_LDS, stream, p);
-    }
+    // ONE launch for the four phases (virtual tile = phase * tiles + tile; the kernel derives the phase's padding — rows yl + a - (1 - py): phase 0 reads (yl - 1, yl),
+    // phase 1 (yl, yl + 1), columns likewise — its output offsets, weight block and GroupNorm rows): four launches of 675 tiles were four 2.64-round launches with 16-stage
+    // tiles; stand-alone at 8 x 120 x 180 x 256 567 us against 877 for the 9-tap kernel, merged see profiles/NOTES.md G
+    ConvParams p{(const bf16_t*)x, T, H, W, Cin, nullptr, (const bf16_t*)w_phases, (const bf16_t*)bias, cout, cout, 1, 2, 2,
+                 1, 1, 1, nullptr, nullptr, (bf16_t*)y, ldy, T, H, W, (const bf16_t*)zeros, gn_partial, 1, nullptr,
+                 0, 2, 0, 0, time_x2 && T > 1 ? (T % 2 ? 1 : 2) : 0, 4};
+    hipLaunchKernelGGL(conv3d_w4_kernel<256>, dim3((unsigned)(4 * tiles)), dim3(256), CW_LDS, stream, p);
     TG_LAUNCH_CHECK("tg_conv3d_up2_subpixel");
     return TG_OK;
 }
