@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r6_scaling_projection.json"))
     a = ap.parse_args()
     P = lambda f: json.load(open(os.path.join(ROOT, "profiles", f)))
-    gen, edit = P("r5_gen_1gpu_24clips.json"), P("r5_e2e_1gpu_12clips.json")
+    gen, edit = P("r6_gen_1gpu_24clips.json"), P("r6_e2e_1gpu_12clips.json")
     try:
         vae_s = P("r6_bench_detail.json")["vae"]["decode"]["seconds"]; vae_src = "r6_bench_detail.json"
     except (OSError, KeyError, TypeError):
@@ -91,7 +91,7 @@ def main():
                                          "efficiency_end_to_end": round(t1 / w_["seconds"]["total"] / r["n_gpus"], 4)}
         runs[name] = {"measured_one_gpu": {k: round(v, 4) for k, v in meas.items()}, "projection": rows}
     out = {"what": "PROJECTION, not a measurement: product window schedule x one-GPU phase seconds; no N > 1 hardware was available to the builder",
-           "sources": {"phase_seconds": ["profiles/r5_gen_1gpu_24clips.json", "profiles/r5_e2e_1gpu_12clips.json"], "vae_decode_clip_s": vae_src, "b1_over_b2": b1_src},
+           "sources": {"phase_seconds": ["profiles/r6_gen_1gpu_24clips.json", "profiles/r6_e2e_1gpu_12clips.json"], "vae_decode_clip_s": vae_src, "b1_over_b2": b1_src},
            "b1_over_b2": b1, "b1_over_b2_t2to": b1t, "placeholders_s": {"fifo_all_gather_per_iteration": 1.0e-3, "cfg_all_gather_per_step": 0.5e-3},
            "not_modelled": "T5 / checkpoint loading (out of scope), the weight broadcast (once per process, ~14 GB over xGMI), the condensed-token encode of edit.yaml "
                            "(chunks + 1 VAE encodes + Resampler calls, sharded round-robin over all ranks since round 6: ceil(13 / N) x ~0.27 s)",
