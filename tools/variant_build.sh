@@ -17,7 +17,7 @@ open("variants/%s_%s.hip" % (name, f), "w").write(s2)
 PY
 extra=""
 [ "$file" = attention ] && extra="-mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I../../include -I. -Wno-unused-result $extra -c variants/${name}_$file.hip -o variants/$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fno-slp-vectorize -I../../include -I. -Wno-unused-result $extra -c variants/${name}_$file.hip -o variants/$name.o
 objs=""
 for f in gemm attention attention_bwd train norm elementwise vae; do
   if [ "$f" = "$file" ]; then objs="$objs variants/$name.o"; else objs="$objs $f.o"; fi
