@@ -22,3 +22,18 @@ def test_four_ranks_on_one_gpu_over_gloo(tmp_path):
         assert msg.startswith("ok "), f"rank {r}: {msg}\n(all ranks: {msgs})"
         for part in ("fifo_latents", "fifo_decode", "split_counts", "whole_windows"):
             assert part in msg
+
+
+@pytest.mark.timeout(900)
+def test_ddp_two_ranks_on_one_gpu_over_gloo(tmp_path):
+    """BASELINE config 5's data-parallel leg with the real kernels (tests/rank_worker_gpu_ddp.py): two ranks, one micro-batch each, bucketed gradient all-reduce overlapping the
+    backward, collective verdict, clip + AdamW — parameters after the step bitwise equal to one process accumulating the two micro-batches."""
+    sys.path.insert(0, ROOT)
+    from tokensgen_amd.runtime import launch
+    launch(2, [sys.executable, os.path.join(ROOT, "tests", "rank_worker_gpu_ddp.py"), str(tmp_path)], env=dict(os.environ, TG_DIST_TIMEOUT_S="300"))
+    msgs = [(tmp_path / f"rank{r}.txt").read_text() if (tmp_path / f"rank{r}.txt").exists() else "(no result file)" for r in range(2)]
+    print("\n".join(msgs))
+    for r, msg in enumerate(msgs):
+        assert msg.startswith("ok "), f"rank {r}: {msg}\n(all ranks: {msgs})"
+        for part in ("stepped", "loss", "params", "buckets_during_backward"):
+            assert part in msg
