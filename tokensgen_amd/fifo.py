@@ -211,7 +211,10 @@ def cogvideo_fifo_mp_v2(pipe_list, base_output, noise_seed=0, step_noise_fn=None
     bo = base_output
     sp = bo.sampling_params
     if sp.get("use_sliding_window_embedding"):
-        raise NotImplementedError("use_sliding_window_embedding is not used by the shipped configs")
+        # (the reference's multi-process driver cannot run this branch either: it calls prepare_fifo_cond_frames() / shift_cond_frames(), which exist only in the
+        #  single-process fifo_sampling/sampling.py:76,109 — cogvideo_sampling_mp_fifo.py:150,347 raise NameError as soon as the flag is set)
+        raise NotImplementedError("use_sliding_window_embedding: no shipped config sets it, and the reference's cogvideo_fifo_mp_v2 itself raises NameError on it "
+                                  "(cogvideo_sampling_mp_fifo.py:150: prepare_fifo_cond_frames is not defined in that module)")
     if len(getattr(bo, "cache_idx", []) or []):
         # (the reference itself cannot run this branch: its merge loop indexes a list with a list — `for cid in cache_latents: cache_latents[cid] = ...`,
         #  cogvideo_sampling_mp_fifo.py:330-331 — and raises TypeError as soon as cache_idx is non-empty)
