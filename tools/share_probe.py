@@ -3,6 +3,7 @@
 always in a few elements of the Q / K rows the QK-LayerNorm + RoPE kernel had just written.)   python tools/share_probe.py MODE N TAG
    qk       tg_qk_layernorm_rope_pair in place on a [2, 86, 384] fused buffer (the tiny model's shape), copy-in before every launch
    qkmax    the same through tg_qk_layernorm_rope_pair_kmax
+   gemmgelu / gemmkeep   the 4-wave GEMM with its GELU epilogue (TG_EPI_BIAS_GELU / TG_EPI_BIAS_KEEP_GELU)
    torch    a chain of PyTorch's own kernels on the same buffer (layer_norm, mul, add, sin): the control — no code of this repository runs
    copy     only the copy-in (torch copy_) + comparison: the control of the control"""
 import os, sys
@@ -54,6 +55,24 @@ elif mode in ("gemm", "gemmqk", "gemm_gap_qk", "gemmqk_out"):
             return out2
         K.qk_layernorm_rope_pair(buf[:, :, :D], buf[:, :, D:2 * D], H, w[0], b_[0], w[1], b_[1], 1e-6, (8, rope), k_scale=0.18)
         return buf
+elif mode in ("gemmgelu", "gemmkeep"):
+    # the 4-wave GEMM's GELU epilogues (the library's remaining packed-fp32 instructions with an op_sel modifier: v_pk_mul_f32 / v_pk_fma_f32 by a broadcast constant) on a
+    # shape where the epilogue is most of the kernel: [1024 x 256] x [512 x 256]^T
+    from tokensgen_amd import kernels as K
+    from tokensgen_amd import lib as L
+    Mg, Ng, Kg = 1024, 512, 256
+    assert K.gemm_act_supported(Mg, Ng, Kg)
+    xg = torch.randn(Mg, Kg, generator=g).to(BF).to(DEV)
+    wg = (torch.randn(Ng, Kg, generator=g) * 0.1).to(BF).to(DEV)
+    bg = torch.randn(Ng, generator=g).to(BF).to(DEV)
+    og, og2 = torch.empty(Mg, Ng, dtype=BF, device=DEV), torch.empty(Mg, Ng, dtype=BF, device=DEV)
+
+    def op():
+        if mode == "gemmgelu":
+            K.gemm(xg, wg, bg, og, L.EPI_BIAS_GELU)
+            return og
+        K.gemm(xg, wg, bg, og, L.EPI_BIAS_KEEP_GELU, residual=og2)
+        return og2
 elif mode == "torch":
     wt = torch.randn(3 * D, generator=g).to(BF).to(DEV)
 
