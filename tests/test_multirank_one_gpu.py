@@ -37,3 +37,18 @@ def test_ddp_two_ranks_on_one_gpu_over_gloo(tmp_path):
         assert msg.startswith("ok "), f"rank {r}: {msg}\n(all ranks: {msgs})"
         for part in ("stepped", "loss", "params", "buckets_during_backward"):
             assert part in msg
+
+
+@pytest.mark.timeout(900)
+def test_t2to_stage_and_token_encode_three_ranks_on_one_gpu_over_gloo(tmp_path):
+    """The two multi-rank branches the four-rank test does not reach, with the real kernels (tests/rank_worker_gpu_stages.py): the T2To stage CFG-parallel and the condensed-token
+    encode sharded by chunk over three ranks (2 / 1 / 1 chunks, separate guidance) — frames, tokens and generator states bitwise equal to the no-process-group run on every rank."""
+    sys.path.insert(0, ROOT)
+    from tokensgen_amd.runtime import launch
+    launch(3, [sys.executable, os.path.join(ROOT, "tests", "rank_worker_gpu_stages.py"), str(tmp_path)], env=dict(os.environ, TG_DIST_TIMEOUT_S="300"))
+    msgs = [(tmp_path / f"rank{r}.txt").read_text() if (tmp_path / f"rank{r}.txt").exists() else "(no result file)" for r in range(3)]
+    print("\n".join(msgs))
+    for r, msg in enumerate(msgs):
+        assert msg.startswith("ok "), f"rank {r}: {msg}\n(all ranks: {msgs})"
+        for part in ("t2to_frames", "t2to_generator", "tokens", "token_generator", "halves", "chunks"):
+            assert part in msg
