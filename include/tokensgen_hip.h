@@ -342,6 +342,9 @@ typedef struct tg_attn_bwd_problem {
     const void* o; long o_ld, o_sb;  const void* dout; long do_ld, do_sb;
     float* dq; long dq_ld, dq_sb;  float* dk; long dk_ld, dk_sb;  float* dv; long dv_ld, dv_sb;
     int nq, nk;  float scale;  int accumulate;  const float* lse;  float* ws;
+    /* optional (round 6): bf16 of the value dv receives, element (b, key, h, d) at dv_bf16[b*dv_bf16_sb + key*dv_bf16_ld + h*64 + d] — e.g. the V third of the fused
+     * projection gradient, so that no conversion pass follows the backward.  With dv_bf16 given, dv may be null (then accumulate bit 1 must be clear). */
+    void* dv_bf16; long dv_bf16_ld, dv_bf16_sb;
 } tg_attn_bwd_problem;
 int tg_attention_bwd_multi(const tg_attn_bwd_problem* problems, int count, int heads, int batch, int flags, int* status, hipStream_t stream);
 

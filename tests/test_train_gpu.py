@@ -59,9 +59,25 @@ def test_attention_bwd_vs_autograd(B, H, nq, nk):
     dq2, dk2, dv2 = K.attention_bwd(qd, kd, vd, o.detach().to(BF).to(DEV), g.to(DEV), H, scale)
     assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
     K.attention_bwd_check(DEV)                                   # no poll timed out, every head's key blocks sat on one XCD
+    # bf16 dV straight from the epilogue (tg_attn_bwd_problem.dv_bf16) into the V third of a fused projection-gradient buffer: bitwise the conversion pass's values,
+    # alone (no fp32 dv is produced) and beside the fp32 tensor; nothing outside the third is touched
+    dfused = torch.full((B, nk + 3, 3 * H * 64), 7.0, dtype=BF, device=DEV)
+    dq4, dk4, dv4 = K.attention_bwd(qd, kd, vd, o.detach().to(BF).to(DEV), g.to(DEV), H, scale, dv_bf16=dfused[:, :nk, 2 * H * 64:])
+    assert dv4 is None and torch.equal(dq4, dq) and torch.equal(dk4, dk) and torch.equal(dfused[:, :nk, 2 * H * 64:], dv.to(BF))
+    assert bool((dfused[:, nk:] == 7.0).all()) and bool((dfused[:, :, :2 * H * 64] == 7.0).all())
+    dfused2 = torch.zeros_like(dfused)
+    dv5 = torch.empty_like(dv)
+    K.attention_bwd(qd, kd, vd, o.detach().to(BF).to(DEV), g.to(DEV), H, scale, dv=dv5, dv_bf16=dfused2[:, :nk, 2 * H * 64:])
+    assert torch.equal(dv5, dv) and torch.equal(dfused2[:, :nk, 2 * H * 64:], dv.to(BF))
     K.attention_bwd(qd, kd, vd, o.detach().to(BF).to(DEV), g.to(DEV), H, scale, dq=dq2, dk=dk2, dv=dv2, accumulate=True)
     # (the one-kernel form adds its key blocks' dQ contributions to what is there one after the other: equal up to fp32 summation order)
     assert torch.allclose(dq2, 2 * dq, rtol=1e-4, atol=1e-5) and torch.allclose(dk2, 2 * dk) and torch.allclose(dv2, 2 * dv)
+    # accumulate into dk / dv with the bf16 copy: bf16 of the SUM the fp32 tensor now holds; without the fp32 tensor the call is refused
+    dv6 = dv.clone()
+    K.attention_bwd(qd, kd, vd, o.detach().to(BF).to(DEV), g.to(DEV), H, scale, dk=dk.clone(), dv=dv6, accumulate=2, dv_bf16=dfused2[:, :nk, 2 * H * 64:])
+    assert torch.equal(dv6, dv2) and torch.equal(dfused2[:, :nk, 2 * H * 64:], dv2.to(BF))
+    with pytest.raises(AssertionError, match="accumulate into dv"):
+        K.attention_bwd(qd, kd, vd, o.detach().to(BF).to(DEV), g.to(DEV), H, scale, accumulate=2, dv_bf16=dfused2[:, :nk, 2 * H * 64:])
     # the forward's own log-sum-exp (tg_attention_fwd_lse) instead of the statistics pass: same row statistics up to fp32 rounding
     pad = (nk + 63) // 64 * 64
     vt = K.transpose_v(vd, H, 0, nk, torch.zeros(B, H, 64, pad, dtype=BF, device=DEV))

@@ -19,6 +19,8 @@ struct BwdParams {
     float scale_log2, scale;
     int accumulate;
     int have_lse;                          // lse was written by the forward (tg_attention_fwd_lse): the statistics launch only computes D
+    bf16_t* dvb;                           // optional: bf16 of the value dv receives, element (b, key, h, d) at dvb[b*dvb_sb + key*dvb_ld + h*64 + d]; dv itself may then be null
+    long dvb_ld, dvb_sb;
 };
 
 // accumulator element r of lane (j, hi) sits at row 8*(r/4) + 4*hi + (r%4), column j of the 32 x 32 block

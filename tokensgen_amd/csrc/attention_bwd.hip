@@ -479,10 +479,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv7_kernel(Bwd2Params pp) {
             const int key = kw0 + acc_row(r, hi);
             if (key >= p.nk) continue;
             float* a = DK + (long)key * p.dk_ld;
-            float* c = DV + (long)key * p.dv_ld;
-            const float vk = dk[db][r] * p.scale, vv = dv[db][r];
+            const float vk = dk[db][r] * p.scale;
+            float vv = dv[db][r];
             *a = (p.accumulate & 2) ? *a + vk : vk;
-            *c = (p.accumulate & 2) ? *c + vv : vv;
+            if (p.dv) {
+                float* c = DV + (long)key * p.dv_ld;
+                if (p.accumulate & 2) vv += *c;
+                *c = vv;
+            }
+            if (p.dvb) p.dvb[(long)b * p.dvb_sb + (long)key * p.dvb_ld + h * HD + db * 32 + j] = f32_to_bf16(vv);
         }
     }
 }
@@ -1096,10 +1101,15 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_pp_kernel(FusedParams fp) 
             const int key = kw0 + acc_row(r, hi);
             if (key >= p.nk) continue;
             float* a = DK + (long)key * p.dk_ld;
-            float* c = DV + (long)key * p.dv_ld;
-            const float vk = dk[db][r] * p.scale, vv = dv[db][r];
+            const float vk = dk[db][r] * p.scale;
+            float vv = dv[db][r];
             *a = (p.accumulate & 2) ? *a + vk : vk;
-            *c = (p.accumulate & 2) ? *c + vv : vv;
+            if (p.dv) {
+                float* c = DV + (long)key * p.dv_ld;
+                if (p.accumulate & 2) vv += *c;
+                *c = vv;
+            }
+            if (p.dvb) p.dvb[(long)b * p.dvb_sb + (long)key * p.dvb_ld + h * HD + db * 32 + j] = f32_to_bf16(vv);
         }
     }
 #undef PP_RD_T
@@ -1214,7 +1224,9 @@ struct Prepared {
 // validation + parameter block of one problem; decides the form (one kernel / two launches) exactly as documented for tg_attention_bwd_ex
 int bwd_prepare(const tg_attn_bwd_problem& a, int heads, int batch, int flags, Prepared& out) {
     const int accumulate = a.accumulate == 1 ? 3 : (a.accumulate & 3);      // bit 0: dq, bit 1: dk and dv; 1 = all three (the original meaning of the flag)
-    TG_REQUIRE(a.q && a.k && a.v && a.o && a.dout && a.dq && a.dk && a.dv && a.ws, TG_ERR_ARG, "tg_attention_bwd: null pointer");
+    TG_REQUIRE(a.q && a.k && a.v && a.o && a.dout && a.dq && a.dk && (a.dv || a.dv_bf16) && a.ws, TG_ERR_ARG, "tg_attention_bwd: null pointer");
+    TG_REQUIRE(a.dv || !(accumulate & 2), TG_ERR_ARG, "tg_attention_bwd: accumulate into dv needs the fp32 dv");
+    TG_REQUIRE(!a.dv_bf16 || (a.dv_bf16_ld >= (long)heads * HD && a.dv_bf16_sb >= 0), TG_ERR_SHAPE, "tg_attention_bwd: dv_bf16 row stride %ld below heads * 64", a.dv_bf16_ld);
     TG_REQUIRE(a.nq > 0 && a.nk > 0 && heads > 0 && batch > 0, TG_ERR_SHAPE, "tg_attention_bwd: bad shape nq=%d nk=%d heads=%d batch=%d", a.nq, a.nk, heads, batch);
     TG_REQUIRE(tg_aligned16(a.q) && tg_aligned16(a.k) && tg_aligned16(a.v) && tg_aligned16(a.o) && tg_aligned16(a.dout) && tg_aligned16(a.ws) && a.q_ld % 8 == 0 &&
                a.k_ld % 8 == 0 && a.v_ld % 8 == 0 && a.o_ld % 8 == 0 && a.do_ld % 8 == 0 && a.q_sb % 8 == 0 && a.k_sb % 8 == 0 && a.v_sb % 8 == 0 && a.o_sb % 8 == 0 &&
@@ -1223,7 +1235,7 @@ int bwd_prepare(const tg_attn_bwd_problem& a, int heads, int batch, int flags, P
     const long nrow = (long)batch * heads * nq;               // workspace: seed rows (16 B each, first: alignment) | log-sum-exp | D
     out.pp.p = BwdParams{(const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (const bf16_t*)a.o, (const bf16_t*)a.dout, a.q_ld, a.q_sb, a.k_ld, a.k_sb, a.v_ld,
                          a.v_sb, a.o_ld, a.o_sb, a.do_ld, a.do_sb, a.dq, a.dk, a.dv, a.dq_ld, a.dq_sb, a.dk_ld, a.dk_sb, a.dv_ld, a.dv_sb, a.ws + 4 * nrow, a.ws + 5 * nrow,
-                         (uint4*)a.ws, nq, nk, heads, batch, a.scale * 1.4426950408889634f, a.scale, accumulate, a.lse ? 1 : 0};
+                         (uint4*)a.ws, nq, nk, heads, batch, a.scale * 1.4426950408889634f, a.scale, accumulate, a.lse ? 1 : 0, (bf16_t*)a.dv_bf16, a.dv_bf16_ld, a.dv_bf16_sb};
     if (a.lse) out.pp.p.lse = const_cast<float*>(a.lse);
     out.pp.kparts = 1;
     out.pp.dq_part = nullptr;

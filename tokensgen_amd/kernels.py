@@ -364,8 +364,9 @@ def attention_bwd_check(device=None):
         raise attention_bwd_error(polls, xcd, f"cuda:{torch.device(device).index}" if device is not None else "this process")
 
 
-def _bwd_problem(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, accumulate=False, lse=None):
-    """One tg_attn_bwd_problem + the tensors that must outlive the launch call: (struct, (dq, dk, dv), keep)."""
+def _bwd_problem(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, accumulate=False, lse=None, dv_bf16=None):
+    """One tg_attn_bwd_problem + the tensors that must outlive the launch call: (struct, (dq, dk, dv), keep).  dv_bf16 (bf16 [B, nk, heads*64] view, e.g. the V third of a fused
+    projection gradient): receives bf16(dv) from the kernel's epilogue; the fp32 dv is then written only when `dv` is given too (else the tuple's dv is None)."""
     for n, t in (("q", q), ("k", k), ("v", v), ("o", o), ("dout", dout)):
         _chk(t, n)
     if lse is not None:
@@ -382,13 +383,20 @@ def _bwd_problem(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, accu
     new = torch.zeros if acc else torch.empty              # accumulate adds to the buffer: a fresh one must start at zero
     dq = new(B, nq, HD, dtype=f32, device=q.device) if dq is None else _chk(dq, "dq", f32)
     dk = new(B, nk, HD, dtype=f32, device=q.device) if dk is None else _chk(dk, "dk", f32)
-    dv = new(B, nk, HD, dtype=f32, device=q.device) if dv is None else _chk(dv, "dv", f32)
+    if dv_bf16 is not None:
+        _chk(dv_bf16, "dv_bf16")
+        assert dv_bf16.shape == (B, nk, HD) and dv_bf16.stride(2) == 1 and (dv is not None or not (acc & 2)), "accumulate into dv needs the fp32 dv"
+    if dv is not None or dv_bf16 is None:
+        dv = new(B, nk, HD, dtype=f32, device=q.device) if dv is None else _chk(dv, "dv", f32)
     ws = torch.empty(L.load().tg_attention_bwd_ws_floats(nq, nk, heads, B), dtype=f32, device=q.device)
     pr = L.AttnBwdProblem()
     (pr.q, pr.q_ld, pr.q_sb, pr.k, pr.k_ld, pr.k_sb, pr.v, pr.v_ld, pr.v_sb, pr.o, pr.o_ld, pr.o_sb, pr.dout, pr.do_ld, pr.do_sb) = (
         _p(q), qld, qsb, _p(k), kld, ksb, _p(v), vld, vsb, _p(o), old, osb, _p(dout), gld, gsb)
     (pr.dq, pr.dq_ld, pr.dq_sb, pr.dk, pr.dk_ld, pr.dk_sb, pr.dv, pr.dv_ld, pr.dv_sb) = (
-        _p(dq), dq.stride(1), dq.stride(0), _p(dk), dk.stride(1), dk.stride(0), _p(dv), dv.stride(1), dv.stride(0))
+        _p(dq), dq.stride(1), dq.stride(0), _p(dk), dk.stride(1), dk.stride(0), _p(dv) if dv is not None else None, dv.stride(1) if dv is not None else 0,
+        dv.stride(0) if dv is not None else 0)
+    if dv_bf16 is not None:
+        pr.dv_bf16, pr.dv_bf16_ld, pr.dv_bf16_sb = _p(dv_bf16), dv_bf16.stride(1), dv_bf16.stride(0)
     pr.nq, pr.nk, pr.scale, pr.accumulate, pr.lse, pr.ws = nq, nk, float(scale), acc, _p(lse), _p(ws)
     return pr, (dq, dk, dv), (ws, B)
 
@@ -407,12 +415,12 @@ def attention_bwd_multi(problems, heads):
     return [b[1] for b in built]
 
 
-def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, accumulate=False, lse=None):
+def attention_bwd(q, k, v, o, dout, heads, scale, dq=None, dk=None, dv=None, accumulate=False, lse=None, dv_bf16=None):
     """Gradients of o = softmax(scale q k^T) v per head (tg_attention_bwd_multi with one problem).  q/o/dout [B,nq,heads*64], k/v [B,nk,heads*64] bf16 views;
     returns fp32 (dq, dk, dv) shaped like q, k, v (given tensors are written, or added to with accumulate=True).  lse: the forward's
     log-sum-exp from attention_lse (optional; recomputed when None).  The one-kernel form is offered to the library when the device probe
     passed (BwdDeviceState); a poll time-out inside it is reported by attention_bwd_status() / attention_bwd_check(), never silently."""
-    return attention_bwd_multi([dict(q=q, k=k, v=v, o=o, dout=dout, scale=scale, dq=dq, dk=dk, dv=dv, accumulate=accumulate, lse=lse)], heads)[0]
+    return attention_bwd_multi([dict(q=q, k=k, v=v, o=o, dout=dout, scale=scale, dq=dq, dk=dk, dv=dv, accumulate=accumulate, lse=lse, dv_bf16=dv_bf16)], heads)[0]
 
 
 def _attn_problem(q1, k1, vt1, nk1, out, q2=None, k2=None, vt2=None, nk2=0, seg2_scale=0.0, kmax1=None, kmax2=None, seg2_scale_batch=None):

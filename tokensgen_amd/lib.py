@@ -168,7 +168,8 @@ class AttnBwdProblem(C.Structure):
     _fields_ = ([(n, t) for base in ("q", "k", "v", "o") for n, t in ((base, C.c_void_p), (base + "_ld", C.c_long), (base + "_sb", C.c_long))] +
                 [("dout", C.c_void_p), ("do_ld", C.c_long), ("do_sb", C.c_long)] +
                 [(n, t) for base in ("dq", "dk", "dv") for n, t in ((base, C.c_void_p), (base + "_ld", C.c_long), (base + "_sb", C.c_long))] +
-                [("nq", C.c_int), ("nk", C.c_int), ("scale", C.c_float), ("accumulate", C.c_int), ("lse", C.c_void_p), ("ws", C.c_void_p)])
+                [("nq", C.c_int), ("nk", C.c_int), ("scale", C.c_float), ("accumulate", C.c_int), ("lse", C.c_void_p), ("ws", C.c_void_p),
+                 ("dv_bf16", C.c_void_p), ("dv_bf16_ld", C.c_long), ("dv_bf16_sb", C.c_long)])
 
 
 class AccumItem(C.Structure):

@@ -44,14 +44,16 @@ def vpred_loss_and_grad(model_output, noisy_model_input, model_input, timesteps,
 
 @torch.no_grad()
 def to2v_attention_backward(q, k, v, qx, kx, vx, qv, kv, vv, o1, o2, o3, d_out, heads, sm_scale, vip_scale, lse=(None, None, None), kcat=None, vcat=None,
-                            k1_prescaled=False):
+                            k1_prescaled=False, dv1_bf16=None, dv_all_bf16=None):
     """Backward of `cat(sdpa(q, k, v) + vip_scale * sdpa(qx, kv, vv), sdpa(qv, cat(kx, kv), cat(vx, vv)))` (attention_processor.py:2066-2135):
     q..vv are the post-norm / post-RoPE projections [B, n, heads*64] (bf16), o1/o2/o3 the three attention outputs saved by the forward,
     d_out [B, N1 + Np, heads*64] the gradient of the concatenated result.  Returns fp32 gradients keyed like the inputs (views of three combined
     tensors q_all / k_all / v_all over the rows text+video | vip of the vip-weight projection).  kv / vv receive the sum of two calls' gradients.
     lse: the three calls' log-sum-exps from K.attention_lse (optional); kcat / vcat: cat(kx, kv) / cat(vx, vv) as views when the caller has them
     (the fused projection buffer), else they are concatenated here.  k1_prescaled: `k` of the first call carries sm_scale * log2(e) (the training
-    forward's constant-shift attention): that call's backward runs with scale = ln 2 and its "k" gradient is the gradient of the SCALED rows."""
+    forward's constant-shift attention): that call's backward runs with scale = ln 2 and its "k" gradient is the gradient of the SCALED rows.
+    dv1_bf16 / dv_all_bf16 (bf16 views [B, N1, HD] / [B, N1 + Np, HD], e.g. the V thirds of the two fused projection gradients): the kernels' epilogues write bf16(dv) /
+    bf16(dv_all) there, so no conversion pass follows (the fp32 `v` is then not produced: None)."""
     N1, Np = q.shape[1], qv.shape[1]
     f32 = torch.float32
     B, HD = q.shape[0], q.shape[2]
@@ -61,13 +63,15 @@ def to2v_attention_backward(q, k, v, qx, kx, vx, qv, kv, vv, o1, o2, o3, d_out, 
     kcat = torch.cat([kx, kv], 1) if kcat is None else kcat
     vcat = torch.cat([vx, vv], 1) if vcat is None else vcat
     # call 3 first: it writes EVERY row of dk_all / dv_all; call 2 then adds its share into the vip rows (accumulate = 2: dk / dv only)
-    K.attention_bwd(qv, kcat, vcat, o3, d_out[:, N1:], heads, sm_scale, dq=dq_all[:, N1:], dk=dk_all, dv=dv_all, lse=lse[2])
+    K.attention_bwd(qv, kcat, vcat, o3, d_out[:, N1:], heads, sm_scale, dq=dq_all[:, N1:], dk=dk_all, dv=dv_all, lse=lse[2], dv_bf16=dv_all_bf16)
     g2 = g1 if float(vip_scale) == 1.0 else g1 * float(vip_scale)      # `scale * O2` is a bf16 tensor in the forward (bf16 x scalar: fp32 product, one rounding)
     # calls 1 and 2 in ONE call: both walk the N1 queries, so when both take the one-kernel form the vip-key call's 2 key blocks per head ride in the last,
     # partial round of the main call's launch (tg_attention_bwd_multi) instead of costing a launch of their own
     (dq, dk, dv), _ = K.attention_bwd_multi([
-        dict(q=q, k=k, v=v, o=o1, dout=g1, scale=math.log(2.0) if k1_prescaled else sm_scale, lse=lse[0]),
+        dict(q=q, k=k, v=v, o=o1, dout=g1, scale=math.log(2.0) if k1_prescaled else sm_scale, lse=lse[0], dv_bf16=dv1_bf16),
         dict(q=qx, k=kv, v=vv, o=o2, dout=g2, scale=sm_scale, dq=dq_all[:, :N1], dk=dk_all[:, N1:], dv=dv_all[:, N1:], accumulate=2, lse=lse[1])], heads)
+    if dv_all_bf16 is not None:
+        dv_all_bf16[:, N1:] = dv_all[:, N1:]          # the vip rows received call 2's share after call 3's epilogue had rounded them
     return dict(q=dq, k=dk, v=dv, qx=dq_all[:, :N1], kx=dk_all[:, :N1], vx=dv_all[:, :N1], qv=dq_all[:, N1:], kv=dk_all[:, N1:], vv=dv_all[:, N1:],
                 q_all=dq_all, k_all=dk_all, v_all=dv_all)
 
@@ -223,21 +227,25 @@ def qk_layernorm_rope_backward(x_pre, dy, heads, ln_weight, eps, seg0=None, seg1
 
 
 @torch.no_grad()
-def vip_projection_backward(xn_all, qkvv_pre, grads, heads, Nt, N1, vip_norm_q_w, vip_norm_k_w, vip_rope, cond_rope, return_dpre=False):
+def vip_projection_backward(xn_all, qkvv_pre, grads, heads, Nt, N1, vip_norm_q_w, vip_norm_k_w, vip_rope, cond_rope, return_dpre=False, d_pre3=None):
     """From the attention gradients of the vip-weight branch to the gradients of the TRAINABLE processor parameters.
     xn_all [B, N, D] bf16: the normalised inputs (text | video | vip rows) the projection read; qkvv_pre [B, N, 3D] bf16: its raw output
     (before vip_norm_q / vip_norm_k and RoPE); grads: to2v_attention_backward(...) (fp32, UNSCALED keys: the training forward keeps the softmax
-    scale in the attention call).  Returns dict: vip_to_{q,k,v}.{weight,bias}, vip_norm_{q,k}.{weight,bias}."""
+    scale in the attention call).  d_pre3 ([B, N, 3D] bf16): the projection-gradient buffer whose V third to2v_attention_backward(dv_all_bf16=...) has already
+    filled.  Returns dict: vip_to_{q,k,v}.{weight,bias}, vip_norm_{q,k}.{weight,bias}."""
     B, N, D = xn_all.shape
     cat = lambda a, b_: torch.cat([grads[a], grads[b_]], dim=1).contiguous()
     dq = grads["q_all"] if "q_all" in grads else cat("qx", "qv")             # rows: text+video (x-branch) | vip tokens
     dk = grads["k_all"] if "k_all" in grads else cat("kx", "kv")
-    dv = grads["v_all"] if "v_all" in grads else cat("vx", "vv")
     segs = ((Nt, vip_rope), (N1, cond_rope))
-    d_pre3 = torch.empty(B, N, 3 * D, dtype=BF16, device=xn_all.device)     # d(fused vip projection output): q | k | v column thirds, written in place
+    v_done = d_pre3 is not None
+    if not v_done:
+        dv = grads["v_all"] if "v_all" in grads else cat("vx", "vv")
+        d_pre3 = torch.empty(B, N, 3 * D, dtype=BF16, device=xn_all.device)     # d(fused vip projection output): q | k | v column thirds, written in place
     _, dgq, dbq = qk_layernorm_rope_backward(qkvv_pre[:, :, :D], dq, heads, vip_norm_q_w, 1e-6, *segs, out=d_pre3[:, :, :D])
     _, dgk, dbk = qk_layernorm_rope_backward(qkvv_pre[:, :, D:2 * D], dk, heads, vip_norm_k_w, 1e-6, *segs, out=d_pre3[:, :, D:2 * D])
-    d_pre3[:, :, 2 * D:] = dv
+    if not v_done:
+        d_pre3[:, :, 2 * D:] = dv
     d_pre = d_pre3.view(B * N, 3 * D)
     dW, db, _ = linear_backward(xn_all.reshape(B * N, D), d_pre)
     out = {}
@@ -523,17 +531,19 @@ class To2VBlockTrainer:
         dy_attn, tg1 = _gate_res_bwd(dX1, S["y_attn"], S["t1"], row0=N1)
         dAO = _dgrad(dy_attn.view(B * N, D), sd[A + "to_out.0.weight"], frozen=(self._wt, "out")).view(B, N, D)
         # ---- the three attention calls, QK-norm + RoPE, projections ----
+        # d(fused base / vip projection output), written third by third: the V thirds by the attention backward's own epilogues (bf16 of the fp32 dV: what a
+        # conversion pass over the fp32 tensors wrote before — two passes per block less)
+        d_pre_b = torch.empty(B, N1, 3 * D, dtype=BF16, device=dX2.device)
+        d_pre_v3 = torch.empty(B, N, 3 * D, dtype=BF16, device=dX2.device)
         ga = to2v_attention_backward(S["q"], S["k"], S["v"], S["qx"], S["kx"], S["vx"], S["qv"], S["kv"], S["vv"], S["o1"], S["o2"], S["o3"], dAO, H, 1.0 / 8.0, self.s, lse=S["lse"],
-                                     kcat=S["kcat"], vcat=S["vcat"], k1_prescaled=True)
+                                     kcat=S["kcat"], vcat=S["vcat"], k1_prescaled=True, dv1_bf16=d_pre_b[:, :, 2 * D:], dv_all_bf16=d_pre_v3[:, :, 2 * D:])
         pg, d_pre_v = vip_projection_backward(S["Xn"], S["qkvv_pre"], ga, H, Nt, N1, sd[A + "processor.vip_norm_q.weight"], sd[A + "processor.vip_norm_k.weight"],
-                                              S["vrope"], S["crope"], return_dpre=True)
+                                              S["vrope"], S["crope"], return_dpre=True, d_pre3=d_pre_v3)
         for kname, val in pg.items():
             grads["attn1.processor." + kname] = val
-        d_pre_b = torch.empty(B, N1, 3 * D, dtype=BF16, device=dX2.device)       # d(fused base projection output), written third by third
         qk_layernorm_rope_backward(S["qkv_pre"][:, :, :D], ga["q"], H, sd[A + "norm_q.weight"], 1e-6, (Nt, S["rope"]), out=d_pre_b[:, :, :D])
         qk_layernorm_rope_backward(S["qkv_pre"][:, :, D:2 * D], ga["k"], H, sd[A + "norm_k.weight"], 1e-6, (Nt, S["rope"]), out_scale=LOG2E / 8.0,
                                    out=d_pre_b[:, :, D:2 * D])
-        d_pre_b[:, :, 2 * D:] = ga["v"]
         dXn = _dgrad(d_pre_v.view(B * N, 3 * D), self.Wv).view(B, N, D)
         if dXn.is_contiguous() and D % 128 == 0:     # the base projection's share lands on the text + video rows through the GEMM's residual epilogue
             linear_backward_dx(d_pre_b, self.Wqkv, accumulate_into=dXn[:, :N1], ones=self._ones(N1, D, B, dX2.device), frozen=(self._wt, "qkv"))
